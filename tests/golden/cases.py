@@ -1,0 +1,119 @@
+"""Golden-vector case table shared by ``make_golden.py`` (which runs the imported
+reference) and the tests (which run the oracle / the HIP path on the same inputs).
+
+Inputs are regenerated from seeds (``np.random.default_rng`` = PCG64, stream stable
+across NumPy versions), so the committed fixtures hold only the reference's OUTPUTS.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def make_input(kind: str, seed: int, shape, dtype="complex128", amp=0.03):
+    """Seeded test field.
+
+    ``noise``: white complex Gaussian (fills the whole simulated band -- stresses the
+    band edge of the dispersion operator).  ``qpsk``: 16-samples-per-symbol QPSK-like
+    pulses, Gaussian spectral shaping (band-limited, like the bench workload).
+    """
+    rng = np.random.default_rng(seed)
+    shape = tuple(np.atleast_1d(shape))
+    if kind == "noise":
+        a = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * amp
+    elif kind == "qpsk":
+        n = shape[-1]
+        sps = 16
+        nsym = n // sps
+        b = rng.integers(0, 2, size=shape[:-1] + (nsym, 2))
+        sym = ((2 * b[..., 0] - 1) + 1j * (2 * b[..., 1] - 1)) / np.sqrt(2)
+        x = np.zeros(shape, dtype=np.complex128)
+        x[..., sps // 2::sps] = sym
+        f = np.fft.fftfreq(n) * sps                      # in units of the symbol rate
+        x = np.fft.ifft(np.fft.fft(x, axis=-1) * np.exp(-(f / 0.6) ** 2 * np.log(2)), axis=-1)
+        x *= amp / np.sqrt(np.mean(np.abs(x) ** 2, axis=-1, keepdims=True))
+        a = x
+    else:
+        raise ValueError(kind)
+    if np.dtype(dtype).kind == "f":
+        a = a.real
+    return np.ascontiguousarray(a.astype(dtype))
+
+
+# gv(sps, R) -> dt = 1/(sps*R)
+GV_A = dict(sps=16, R=10e9)       # dt = 6.25 ps
+GV_B = dict(sps=16, R=32e9)       # dt = 1.953125 ps (bench grid)
+
+FIB = dict(alpha=0.2, beta_2=-20.0, beta_3=0.1, gamma=2.0)
+SMF = dict(alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
+
+# name -> dict(func, gv, inp=(kind, seed, shape, dtype, amp), noise=(...)|None, kw)
+CASES = {
+    # KAT-0 of SURVEY.md 8(c)
+    "kat0_fixed_2pol": dict(func="FIBER", gv=GV_A, inp=("noise", 0, (2, 4096), "complex128", 0.03),
+                            kw=dict(length=10, h=1.0, **FIB)),
+    # KAT-1: adaptive, phi_max default 0.01
+    "kat1_adaptive_2pol": dict(func="FIBER", gv=GV_A, inp=("noise", 0, (2, 4096), "complex128", 0.03),
+                               kw=dict(length=10, alpha=0.2, beta_2=-20.0, gamma=2.0), want_z=True),
+    "adaptive_phi05_2pol_8k": dict(func="FIBER", gv=GV_B, inp=("qpsk", 5, (2, 8192), "complex128", 0.1),
+                                   kw=dict(length=40, phi_max=0.05, **SMF), want_z=True),
+    "fixed_short_last_1pol": dict(func="FIBER", gv=GV_A, inp=("noise", 1, (2048,), "complex128", 0.03),
+                                  kw=dict(length=2, h=0.3, **FIB)),
+    "fixed_1001_steps_1pol": dict(func="FIBER", gv=GV_A, inp=("qpsk", 2, (1024,), "complex128", 0.03),
+                                  kw=dict(length=100, h=0.1, alpha=0.2, beta_2=-20.0, gamma=2.0), want_z=True),
+    "fixed_alpha0_2pol": dict(func="FIBER", gv=GV_B, inp=("qpsk", 3, (2, 4096), "complex128", 0.0316),
+                              kw=dict(length=20, h=0.5, alpha=0.0, beta_2=-21.7, beta_3=0.13, gamma=1.3)),
+    "gamma0_single_step": dict(func="FIBER", gv=GV_A, inp=("noise", 4, (2, 4096), "complex128", 0.03),
+                               kw=dict(length=10, alpha=0.2, beta_2=-20.0, beta_3=0.1, gamma=0.0)),
+    "beta0_pure_spm": dict(func="FIBER", gv=GV_A, inp=("noise", 6, (2, 4096), "complex128", 0.03),
+                           kw=dict(length=10, alpha=0.2, gamma=2.0)),
+    "attenuation_only": dict(func="FIBER", gv=GV_A, inp=("noise", 7, (2048,), "complex128", 0.1),
+                             kw=dict(length=10, alpha=0.2)),
+    "dbp_negative_ops": dict(func="DBP", gv=GV_A, inp=("noise", 8, (2, 4096), "complex128", 0.03),
+                             kw=dict(length=10, h=1.0, **FIB)),
+    "with_noise_c64_input": dict(func="FIBER", gv=GV_A, inp=("qpsk", 9, (2, 4096), "complex64", 0.03),
+                                 noise=("noise", 10, (2, 4096), "complex64", 0.003),
+                                 kw=dict(length=5, h=0.5, **FIB)),
+    "real_input_1pol": dict(func="FIBER", gv=GV_A, inp=("qpsk", 11, (4096,), "float64", 0.03),
+                            kw=dict(length=5, h=1.0, **FIB)),
+    "npow2_3000_1pol": dict(func="FIBER", gv=GV_A, inp=("noise", 12, (3000,), "complex128", 0.03),
+                            kw=dict(length=3, h=1.0, **FIB)),
+    "fixed_2pol_16k": dict(func="FIBER", gv=GV_B, inp=("qpsk", 13, (2, 16384), "complex128", 0.0316),
+                           kw=dict(length=5, h=0.5, **SMF)),
+    "fixed_2pol_16k_noiseband": dict(func="FIBER", gv=GV_B, inp=("noise", 14, (2, 16384), "complex128", 0.02),
+                                     kw=dict(length=4, h=0.25, **SMF)),
+    "small_256_1pol": dict(func="FIBER", gv=GV_A, inp=("noise", 15, (256,), "complex128", 0.03),
+                           kw=dict(length=4, h=1.0, **FIB)),
+    "small_512_2pol": dict(func="FIBER", gv=GV_A, inp=("noise", 16, (2, 512), "complex128", 0.03),
+                           kw=dict(length=4, h=1.0, **FIB)),
+    "return_steps_1k": dict(func="FIBER", gv=GV_A, inp=("noise", 17, (2, 1024), "complex128", 0.03),
+                            kw=dict(length=5, h=1.0, return_steps=True, **FIB)),
+    # KAT-3: DBP(FIBER(x)) -- the round trip is NOT the identity (stale N^)
+    "fiber_then_dbp": dict(func="FIBER+DBP", gv=GV_A, inp=("noise", 0, (2, 4096), "complex128", 0.03),
+                           kw=dict(length=10, h=1.0, **FIB)),
+    # DM (complex128, signal and noise kept apart) -- KAT-2
+    "dm_2pol": dict(func="DM", gv=GV_A, inp=("noise", 0, (2, 4096), "complex128", 0.03),
+                    kw=dict(D=-200.0)),
+    "dm_noise_retH": dict(func="DM", gv=GV_A, inp=("qpsk", 20, (2, 2048), "complex128", 0.03),
+                          noise=("noise", 21, (2, 2048), "complex128", 0.003),
+                          kw=dict(D=4000.0, retH=True)),
+    "dm_1pol_8k": dict(func="DM", gv=GV_B, inp=("qpsk", 22, (8192,), "complex128", 0.03),
+                       kw=dict(D=-21.7 * 80)),
+    # float64 twin loop (reference devices.py:2425-2486), 1 polarisation only
+    "twin_f64_1pol": dict(func="TWIN", gv=GV_A, inp=("noise", 30, (4096,), "complex128", 0.03),
+                          kw=dict(length=10, h=1.0, **FIB)),
+    "twin_f64_qpsk_8k": dict(func="TWIN", gv=GV_B, inp=("qpsk", 31, (8192,), "complex128", 0.0316),
+                             kw=dict(length=20, h=0.5, **SMF)),
+}
+
+
+def case_dt(case) -> float:
+    g = case["gv"]
+    return 1.0 / (g["R"] * g["sps"])
+
+
+def case_input(case):
+    sig = make_input(*case["inp"][:4], amp=case["inp"][4])
+    noi = None
+    if case.get("noise"):
+        noi = make_input(*case["noise"][:4], amp=case["noise"][4])
+    return sig, noi
