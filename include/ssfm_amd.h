@@ -1,0 +1,124 @@
+/*
+ * ssfm_amd.h -- C ABI of the MI355X (gfx950) split-step Fourier fibre propagator.
+ *
+ * This is the drop-in boundary for ONE path of armando-palacio/opticomlib: the body of
+ * `opticomlib.devices.FIBER` (reference opticomlib/devices.py:1113-1206), its sign-flipped
+ * twin `DBP` (devices.py:1280-1283) and the single linear step `DM` (devices.py:1019-1035).
+ * The reference has no FFI of its own: the seam is the Python function call, and the only
+ * accelerator hook is the CuPy array-API subset used at devices.py:1128-1134.  What a
+ * binding for this path needs is therefore exactly:
+ *
+ *   reference line(s)                              entry point here
+ *   ---------------------------------------------  -------------------------------------------
+ *   devices.py:1137-1145 (coefficients, D~)        ssfm_set_linear_operator (host computes D~ in
+ *                                                  the reference's float32 expression order; the
+ *                                                  library never re-derives it)
+ *   devices.py:1147 (A = complex64(signal+noise))  ssfm_set_field
+ *   devices.py:1155-1161,1172-1196 fixed h         ssfm_propagate_fixed (host supplies the float32
+ *                                                  step schedule z/h produce, devices.py:1173,1196)
+ *   devices.py:1155-1156,1193-1196 h=None          ssfm_propagate_adaptive (step control on device)
+ *   devices.py:1150-1152,1184-1186 return_steps    `snapshots` argument of both propagate calls
+ *   devices.py:1204 (.get() / wrap)                ssfm_get_field
+ *   devices.py:1027-1029 (DM: ifft(fft(x)*H))      ssfm_apply_transfer
+ *
+ * Conventions: plain C types, caller-owned buffers, every call returns an int status
+ * (0 = SSFM_OK), no exceptions cross the ABI, no global mutable state except the
+ * thread-local text behind ssfm_last_error().  One plan owns one HIP stream on one
+ * device, so N plans drive N GPUs from one process or one plan per rank drives one GPU.
+ *
+ * Field layout: `batch` rows of `n` complex samples, row-major, interleaved (re, im);
+ * float32 pairs for SSFM_C64, float64 pairs for SSFM_C128.  A dual-polarisation
+ * optical_signal is 2 rows; F independent fields are 2F rows (rows never interact
+ * except through the shared adaptive step size).
+ */
+#ifndef SSFM_AMD_H
+#define SSFM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSFM_ABI_VERSION 1
+
+enum ssfm_status {
+    SSFM_OK = 0,
+    SSFM_ERR_INVALID = 1,      /* bad argument (message in ssfm_last_error) */
+    SSFM_ERR_UNSUPPORTED = 2,  /* n not a supported power of two, unknown precision */
+    SSFM_ERR_HIP = 3,          /* a HIP runtime call failed */
+    SSFM_ERR_NO_DEVICE = 4,    /* no usable gfx950 device */
+    SSFM_ERR_STATE = 5         /* call order violated (e.g. propagate before set_linear_operator) */
+};
+
+enum ssfm_precision { SSFM_C64 = 0, SSFM_C128 = 1 };
+
+typedef struct ssfm_plan ssfm_plan;
+
+/* Library / device discovery.  ssfm_device_count never initialises a HIP context beyond
+ * hipGetDeviceCount. */
+int ssfm_abi_version(void);
+int ssfm_device_count(int* count);
+const char* ssfm_last_error(void);
+
+/* Smallest / largest supported log2(n) for a precision (currently 8..20). */
+int ssfm_supported_log2n(int precision, int* lo, int* hi);
+
+/* Allocate every device buffer once: field, stale |A|^2, operator tables, twiddles. */
+int ssfm_plan_create(ssfm_plan** out, int device, int64_t n, int batch, int precision);
+int ssfm_plan_destroy(ssfm_plan* plan);
+
+/* D~(w) [1/km], complex (precision's element type), length n, natural FFT order, HOST memory.
+ * Shared by all rows.  (reference devices.py:1145) */
+int ssfm_set_linear_operator(ssfm_plan* plan, const void* dtilde_host);
+
+/* Copy a (batch, n) complex field in / out of the plan.  `is_device` != 0: the pointer is
+ * device memory on the plan's device. Both calls are ordered on the plan's stream;
+ * ssfm_get_field returns after the copy has completed. */
+int ssfm_set_field(ssfm_plan* plan, const void* src, int is_device);
+int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device);
+/* Device address of the plan's resident field (batch*n complex), natural time order
+ * between propagate calls. */
+void* ssfm_field_device_ptr(ssfm_plan* plan);
+
+/* Fixed-step run (reference devices.py:1172-1196 with h given).
+ *   gamma        nonlinear coefficient [1/(W km)] (rounded to the plan's real type)
+ *   h_schedule   nsteps step sizes [km], HOST, float32 (C64) or float64 (C128)
+ *   snapshots    NULL, or HOST buffer for (nsteps+1, batch, n) complex: the field before the
+ *                first step and after every step (reference return_steps, devices.py:1184-1186)
+ * Asynchronous on the plan's stream unless snapshots != NULL; see ssfm_synchronize. */
+int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps,
+                         void* snapshots);
+
+/* Adaptive run (reference devices.py:1155-1156, 1193-1196): h = phi_max / max(|gamma| |A|^2),
+ * maximum over all rows of the plan, clamped to length - z; z and h live on the device.
+ *   single_step  the caller's evaluation of `(beta_2 == 0 and beta_3 == 0) or gamma == 0`
+ *                (devices.py:1156): the first step is then the whole length
+ *   max_steps    capacity of z_out / snapshots (run stops with SSFM_ERR_INVALID beyond it)
+ *   steps_out    number of steps taken
+ *   z_out        NULL or HOST float64[max_steps+1]: z after every step (z_out[0] = 0)
+ *   snapshots    NULL or HOST (max_steps+1, batch, n) complex
+ * Synchronous (the step count is only known at the end). */
+int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double phi_max,
+                            int single_step, int64_t max_steps, int64_t* steps_out, double* z_out,
+                            void* snapshots);
+
+/* out = ifft(fft(field) * H) on every row; H complex, length n, natural FFT order, HOST.
+ * (reference DM, devices.py:1027-1029) */
+int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host);
+
+/* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
+int ssfm_debug_fft(ssfm_plan* plan, void* dst);
+
+int ssfm_synchronize(ssfm_plan* plan);
+/* The plan's hipStream_t (as void*), so callers can record events around propagate calls. */
+void* ssfm_stream(ssfm_plan* plan);
+
+/* Time of the last propagate call measured with HIP events on the plan's stream [ms], and the
+ * number of kernel launches it made.  Valid after ssfm_synchronize. */
+int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSFM_AMD_H */

@@ -1,0 +1,185 @@
+"""ctypes binding of the C ABI in ``include/ssfm_amd.h`` (built as ``_ssfm_amd.so``).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is
+visible, every entry point raises :class:`SsfmError` -- loudly, by design.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ssfm_amd.so")
+
+C64, C128 = 0, 1
+_CDTYPE = {C64: np.complex64, C128: np.complex128}
+_RDTYPE = {C64: np.float32, C128: np.float64}
+
+# every symbol include/ssfm_amd.h declares: name -> (restype, argtypes)
+_VP, _I, _I64, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
+SYMBOLS = {
+    "ssfm_abi_version": (_I, []),
+    "ssfm_device_count": (_I, [C.POINTER(_I)]),
+    "ssfm_last_error": (C.c_char_p, []),
+    "ssfm_supported_log2n": (_I, [_I, C.POINTER(_I), C.POINTER(_I)]),
+    "ssfm_plan_create": (_I, [C.POINTER(_VP), _I, _I64, _I, _I]),
+    "ssfm_plan_destroy": (_I, [_VP]),
+    "ssfm_set_linear_operator": (_I, [_VP, _VP]),
+    "ssfm_set_field": (_I, [_VP, _VP, _I]),
+    "ssfm_get_field": (_I, [_VP, _VP, _I]),
+    "ssfm_field_device_ptr": (_VP, [_VP]),
+    "ssfm_propagate_fixed": (_I, [_VP, _D, _VP, _I64, _VP]),
+    "ssfm_propagate_adaptive": (_I, [_VP, _D, _D, _D, _I, _I64, C.POINTER(_I64), C.POINTER(_D), _VP]),
+    "ssfm_apply_transfer": (_I, [_VP, _VP]),
+    "ssfm_debug_fft": (_I, [_VP, _VP]),
+    "ssfm_synchronize": (_I, [_VP]),
+    "ssfm_stream": (_VP, [_VP]),
+    "ssfm_last_propagate_ms": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(_I64)]),
+}
+
+
+class SsfmError(RuntimeError):
+    """A call into the HIP library failed (or the library itself is missing)."""
+
+
+_lib = None
+
+
+def load():
+    """Load ``_ssfm_amd.so`` and bind every declared symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SsfmError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C opticomlib_amd/csrc`.  There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ssfm_abi_version() != 1:
+        raise SsfmError(f"ABI version mismatch: library reports {lib.ssfm_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().ssfm_last_error().decode(errors="replace")
+        raise SsfmError(f"{what} failed (status {rc}): {msg}")
+
+
+def device_count() -> int:
+    n = _I(0)
+    rc = load().ssfm_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def supported_log2n(precision=C64):
+    lo, hi = _I(0), _I(0)
+    _check(load().ssfm_supported_log2n(precision, C.byref(lo), C.byref(hi)), "ssfm_supported_log2n")
+    return lo.value, hi.value
+
+
+def _ptr(a: np.ndarray):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Plan:
+    """One propagator instance: device buffers + one HIP stream on one GPU."""
+
+    def __init__(self, n: int, batch: int, precision: int = C64, device: int = 0):
+        self._h = None
+        lib = load()
+        h = _VP()
+        _check(lib.ssfm_plan_create(C.byref(h), int(device), int(n), int(batch), int(precision)), "ssfm_plan_create")
+        self._h = h
+        self.n, self.batch, self.precision, self.device = int(n), int(batch), int(precision), int(device)
+        self.cdtype = _CDTYPE[precision]
+        self.rdtype = _RDTYPE[precision]
+
+    def close(self):
+        if self._h is not None and _lib is not None:
+            _lib.ssfm_plan_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data movement
+    def set_linear_operator(self, dtilde: np.ndarray):
+        d = np.ascontiguousarray(dtilde, dtype=self.cdtype)
+        if d.shape != (self.n,):
+            raise ValueError(f"D~ must have shape ({self.n},), got {d.shape}")
+        _check(load().ssfm_set_linear_operator(self._h, _ptr(d)), "ssfm_set_linear_operator")
+
+    def set_field(self, field: np.ndarray):
+        f = np.ascontiguousarray(field, dtype=self.cdtype).reshape(self.batch, self.n)
+        _check(load().ssfm_set_field(self._h, _ptr(f), 0), "ssfm_set_field")
+
+    def set_field_device(self, dev_ptr: int):
+        _check(load().ssfm_set_field(self._h, C.c_void_p(dev_ptr), 1), "ssfm_set_field")
+
+    def get_field(self) -> np.ndarray:
+        out = np.empty((self.batch, self.n), dtype=self.cdtype)
+        _check(load().ssfm_get_field(self._h, _ptr(out), 0), "ssfm_get_field")
+        return out
+
+    def get_field_device(self, dev_ptr: int):
+        _check(load().ssfm_get_field(self._h, C.c_void_p(dev_ptr), 1), "ssfm_get_field")
+
+    @property
+    def field_device_ptr(self) -> int:
+        return int(load().ssfm_field_device_ptr(self._h) or 0)
+
+    @property
+    def stream(self) -> int:
+        return int(load().ssfm_stream(self._h) or 0)
+
+    # -- compute
+    def propagate_fixed(self, gamma: float, h_schedule, snapshots: bool = False):
+        hs = np.ascontiguousarray(h_schedule, dtype=self.rdtype)
+        snap = None
+        if snapshots:
+            snap = np.empty((hs.size + 1, self.batch, self.n), dtype=self.cdtype)
+        _check(load().ssfm_propagate_fixed(self._h, float(gamma), _ptr(hs), hs.size,
+                                           _ptr(snap) if snap is not None else None), "ssfm_propagate_fixed")
+        return snap
+
+    def propagate_adaptive(self, gamma, length, phi_max, single_step, max_steps=1 << 16, snapshots=False):
+        steps = _I64(0)
+        z = np.zeros(max_steps + 1, dtype=np.float64)
+        snap = None
+        if snapshots:
+            snap = np.empty((max_steps + 1, self.batch, self.n), dtype=self.cdtype)
+        _check(load().ssfm_propagate_adaptive(self._h, float(gamma), float(length), float(phi_max), int(bool(single_step)),
+                                              int(max_steps), C.byref(steps), z.ctypes.data_as(C.POINTER(_D)),
+                                              _ptr(snap) if snap is not None else None), "ssfm_propagate_adaptive")
+        s = steps.value
+        return s, z[: s + 1].copy(), (snap[: s + 1] if snap is not None else None)
+
+    def apply_transfer(self, H: np.ndarray):
+        h = np.ascontiguousarray(H, dtype=self.cdtype)
+        if h.shape != (self.n,):
+            raise ValueError(f"H must have shape ({self.n},), got {h.shape}")
+        _check(load().ssfm_apply_transfer(self._h, _ptr(h)), "ssfm_apply_transfer")
+
+    def debug_fft(self) -> np.ndarray:
+        out = np.empty((self.batch, self.n), dtype=self.cdtype)
+        _check(load().ssfm_debug_fft(self._h, _ptr(out)), "ssfm_debug_fft")
+        return out
+
+    def synchronize(self):
+        _check(load().ssfm_synchronize(self._h), "ssfm_synchronize")
+
+    def last_propagate_ms(self):
+        ms, n = C.c_float(0), _I64(0)
+        _check(load().ssfm_last_propagate_ms(self._h, C.byref(ms), C.byref(n)), "ssfm_last_propagate_ms")
+        return ms.value, n.value

@@ -1,0 +1,544 @@
+// ssfm_host.hip -- host side of the C ABI declared in include/ssfm_amd.h: plan, buffers,
+// operator tables, launch sequences.  Pure HIP runtime; no torch types anywhere.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ssfm_amd.h"
+#include "ssfm_kernels.hpp"
+
+using namespace ssfm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(SSFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+constexpr int kLog2Min = 8, kLog2Max = 20;
+constexpr int kColsPerTile = 16;   // C: 128 B (c64) / 256 B (c128) contiguous per row segment
+constexpr int kMaxTables = 4;
+
+constexpr int freq_rows(int n2) { return n2 <= 64 ? 16 : (n2 == 128 ? 8 : (n2 == 256 ? 4 : (n2 == 512 ? 2 : 1))); }
+
+template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ----------------------------------------------------------------------------- launchers
+template <typename T, int MODE, int N1>
+hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
+    constexpr int C = kColsPerTile;
+    constexpr size_t lds = fft_nstages(N1) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0;
+    static hipError_t attr = allow_lds(k_time<T, N1, C, MODE>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_time<T, N1, C, MODE>), grid, dim3(N1 * C / 16), lds, s, a);
+    return hipGetLastError();
+}
+template <typename T, int MODE>
+hipError_t launch_time(int N1, int batch, hipStream_t s, const TimeArgs<T>& a) {
+    const dim3 grid(a.N2 / kColsPerTile, batch);
+    switch (N1) {
+        case 16:  return launch_time_n1<T, MODE, 16>(grid, s, a);
+        case 32:  return launch_time_n1<T, MODE, 32>(grid, s, a);
+        case 64:  return launch_time_n1<T, MODE, 64>(grid, s, a);
+        case 128: return launch_time_n1<T, MODE, 128>(grid, s, a);
+        case 256: return launch_time_n1<T, MODE, 256>(grid, s, a);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename T, int MODE, int N2>
+hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
+    constexpr int ROWS = freq_rows(N2);
+    constexpr size_t lds = fft_nstages(N2) > 1 ? (size_t)ROWS * row_lds_elems(N2) * sizeof(cx<T>) : 0;
+    static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, MODE>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_freq<T, N2, ROWS, MODE>), dim3(nrows / ROWS), dim3(ROWS * N2 / 16), lds, s, a);
+    return hipGetLastError();
+}
+template <typename T, int MODE>
+hipError_t launch_freq(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a) {
+    switch (N2) {
+        case 16:   return launch_freq_n2<T, MODE, 16>(nrows, s, a);
+        case 32:   return launch_freq_n2<T, MODE, 32>(nrows, s, a);
+        case 64:   return launch_freq_n2<T, MODE, 64>(nrows, s, a);
+        case 128:  return launch_freq_n2<T, MODE, 128>(nrows, s, a);
+        case 256:  return launch_freq_n2<T, MODE, 256>(nrows, s, a);
+        case 512:  return launch_freq_n2<T, MODE, 512>(nrows, s, a);
+        case 1024: return launch_freq_n2<T, MODE, 1024>(nrows, s, a);
+        case 2048: return launch_freq_n2<T, MODE, 2048>(nrows, s, a);
+        case 4096: return launch_freq_n2<T, MODE, 4096>(nrows, s, a);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ----------------------------------------------------------------------------- plan
+struct PlanBase {
+    int precision = 0;
+    virtual ~PlanBase() {}
+};
+
+template <typename T> struct PlanT : PlanBase {
+    int device = 0;
+    int64_t n = 0;
+    int batch = 0;
+    int N1 = 0, N2 = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    cx<T>* F = nullptr;        // batch * n
+    T* P = nullptr;            // batch * n
+    cx<T>* twN = nullptr;      // n
+    cx<T>* tw1 = nullptr;      // N1
+    cx<T>* tw2 = nullptr;      // N2
+    cx<T>* dnat = nullptr;     // n  (D~ or H, natural order, staging)
+    cx<T>* dperm = nullptr;    // n  (D~ transposed order)
+    cx<T>* scratch = nullptr;  // batch * n, lazily
+    struct Tab { T h; cx<T>* ptr; bool valid; };
+    Tab tabs[kMaxTables] = {};
+    int tab_rr = 0;
+    AdaptState<T>* st = nullptr;
+    T* zlog = nullptr;
+    int64_t zlog_cap = 0;
+    bool have_op = false;
+    bool timed = false;
+    int64_t last_launches = 0;
+
+    T inv_n() const { return (T)1 / (T)n; }
+
+    int free_all() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        void* bufs[] = {F, P, twN, tw1, tw2, dnat, dperm, scratch, st, zlog};
+        for (void* b : bufs) (void)hipFree(b);
+        for (auto& t : tabs) (void)hipFree(t.ptr);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+        return SSFM_OK;
+    }
+    ~PlanT() override { free_all(); }
+
+    int init(int dev, int64_t n_, int batch_) {
+        device = dev; n = n_; batch = batch_;
+        int k = 0;
+        while ((1ll << k) < n) ++k;
+        const int k1 = k / 2 < 8 ? k / 2 : 8;
+        N1 = 1 << k1;
+        N2 = 1 << (k - k1);
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        const size_t cb = sizeof(cx<T>);
+        HIP_TRY(hipMalloc(&F, cb * n * batch));
+        HIP_TRY(hipMalloc(&P, sizeof(T) * n * batch));
+        HIP_TRY(hipMalloc(&twN, cb * n));
+        HIP_TRY(hipMalloc(&tw1, cb * N1));
+        HIP_TRY(hipMalloc(&tw2, cb * N2));
+        HIP_TRY(hipMalloc(&dnat, cb * n));
+        HIP_TRY(hipMalloc(&dperm, cb * n));
+        HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
+        HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
+        hipLaunchKernelGGL(k_make_twL<T>, dim3((N1 + 255) / 256), dim3(256), 0, stream, tw1, N1);
+        hipLaunchKernelGGL(k_make_twL<T>, dim3((N2 + 255) / 256), dim3(256), 0, stream, tw2, N2);
+        hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SSFM_OK;
+    }
+
+    int use_device() { HIP_TRY(hipSetDevice(device)); return SSFM_OK; }
+
+    int set_operator(const void* host) {
+        if (int rc = use_device()) return rc;
+        HIP_TRY(hipMemcpyAsync(dnat, host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const cx<T>*)dnat, dperm, N1, N2, (T)0, inv_n());
+        HIP_TRY(hipGetLastError());
+        // host buffer may be reused by the caller right after return
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& t : tabs) t.valid = false;
+        have_op = true;
+        return SSFM_OK;
+    }
+
+    // exp(D~ h)/N in transposed order, cached per distinct h
+    int table_for(T h, const cx<T>** out) {
+        for (auto& t : tabs)
+            if (t.valid && std::memcmp(&t.h, &h, sizeof(T)) == 0) { *out = t.ptr; return SSFM_OK; }
+        Tab& t = tabs[tab_rr];
+        tab_rr = (tab_rr + 1) % kMaxTables;
+        if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
+        hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const cx<T>*)dperm_natural(), t.ptr, N1, N2, h, inv_n());
+        HIP_TRY(hipGetLastError());
+        t.h = h; t.valid = true;
+        *out = t.ptr;
+        return SSFM_OK;
+    }
+    const cx<T>* dperm_natural() const { return dnat; }
+
+    TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s) const {
+        TimeArgs<T> a;
+        a.F = F; a.P = P; a.twN = twN; a.tw1 = tw1; a.st = s; a.gamma = gamma;
+        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2;
+        return a;
+    }
+    FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s) const {
+        FreqArgs<T> a;
+        a.F = F; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1;
+        return a;
+    }
+
+    int copy_field_out(void* dst, bool is_device, bool wait) {
+        HIP_TRY(hipMemcpyAsync(dst, F, sizeof(cx<T>) * n * batch, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        if (wait) HIP_TRY(hipStreamSynchronize(stream));
+        return SSFM_OK;
+    }
+
+    int propagate_fixed(double gamma_d, const T* h, int64_t nsteps, void* snapshots) {
+        if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_fixed: call ssfm_set_linear_operator first");
+        if (int rc = use_device()) return rc;
+        const T gamma = (T)gamma_d;
+        const int nrows = N1 * batch;
+        last_launches = 0;
+        timed = false;
+        if (nsteps <= 0) return SSFM_OK;
+        for (int64_t s = 0; s < nsteps; ++s)
+            if (!(h[s] > (T)0) || !std::isfinite((double)h[s]))
+                return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed: step %lld is %g km (must be finite and > 0)", (long long)s, (double)h[s]);
+        // distinct step sizes -> operator tables (normally 1, +1 for a short last step)
+        std::vector<T> distinct;
+        for (int64_t s = 0; s < nsteps && distinct.size() <= (size_t)kMaxTables; ++s) {
+            bool seen = false;
+            for (T d : distinct) seen = seen || std::memcmp(&d, &h[s], sizeof(T)) == 0;
+            if (!seen) distinct.push_back(h[s]);
+        }
+        const bool use_tables = distinct.size() <= (size_t)kMaxTables;
+        std::vector<const cx<T>*> tabptr(distinct.size(), nullptr);
+        if (use_tables)
+            for (size_t i = 0; i < distinct.size(); ++i)
+                if (int rc = table_for(distinct[i], &tabptr[i])) return rc;
+        auto freq = [&](T hs) -> hipError_t {
+            ++last_launches;
+            if (use_tables) {
+                const cx<T>* tp = nullptr;
+                for (size_t i = 0; i < distinct.size(); ++i)
+                    if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
+                return launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(tp, hs, nullptr));
+            }
+            return launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, hs, nullptr));
+        };
+        const T half = (T)0.5;
+        HIP_TRY(hipEventRecord(ev0, stream));
+        if (snapshots == nullptr) {
+            ++last_launches;
+            HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[0] * half, nullptr))));
+            for (int64_t s = 0; s < nsteps; ++s) {
+                HIP_TRY(freq(h[s]));
+                ++last_launches;
+                if (s + 1 < nsteps)
+                    HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, targs(gamma, h[s] * half, h[s + 1] * half, nullptr))));
+                else
+                    HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr))));
+            }
+        } else {
+            const size_t fb = sizeof(cx<T>) * n * batch;
+            char* snap = static_cast<char*>(snapshots);
+            if (int rc = copy_field_out(snap, false, false)) return rc;
+            for (int64_t s = 0; s < nsteps; ++s) {
+                last_launches += 2;
+                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[s] * half, nullptr))));
+                HIP_TRY(freq(h[s]));
+                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr))));
+                if (int rc = copy_field_out(snap + fb * (s + 1), false, false)) return rc;
+            }
+        }
+        HIP_TRY(hipEventRecord(ev1, stream));
+        timed = true;
+        if (snapshots != nullptr) HIP_TRY(hipStreamSynchronize(stream));
+        return SSFM_OK;
+    }
+
+    int propagate_adaptive(double gamma_d, double length, double phi_max, int single_step, int64_t max_steps,
+                           int64_t* steps_out, double* z_out, void* snapshots) {
+        if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_adaptive: call ssfm_set_linear_operator first");
+        if (max_steps < 1 || max_steps > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_propagate_adaptive: max_steps=%lld", (long long)max_steps);
+        if (int rc = use_device()) return rc;
+        const T gamma = (T)gamma_d;
+        const int nrows = N1 * batch;
+        if (zlog_cap < max_steps + 1) {
+            (void)hipFree(zlog); zlog = nullptr; zlog_cap = 0;
+            HIP_TRY(hipMalloc(&zlog, sizeof(T) * (max_steps + 1)));
+            zlog_cap = max_steps + 1;
+        }
+        AdaptState<T> hs;
+        std::memset(&hs, 0, sizeof(hs));
+        hs.length = (T)length;
+        hs.phi_max = (T)phi_max;
+        hs.abs_gamma = gamma < 0 ? -gamma : gamma;
+        hs.adaptive = 1;
+        hs.max_steps = (int)max_steps;
+        last_launches = 0;
+        HIP_TRY(hipEventRecord(ev0, stream));
+        HIP_TRY(hipMemcpyAsync(st, &hs, sizeof(hs), hipMemcpyHostToDevice, stream));
+        if (!single_step) {
+            hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, (const cx<T>*)F, (long long)n * batch, st);
+            ++last_launches;
+        }
+        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, st, zlog, 0, single_step);
+        ++last_launches;
+        HIP_TRY(hipGetLastError());
+        const size_t fb = sizeof(cx<T>) * n * batch;
+        char* snap = static_cast<char*>(snapshots);
+        if (snap) if (int rc = copy_field_out(snap, false, false)) return rc;
+        const int chunk = snap ? 1 : 16;
+        int prev_steps = 0;
+        for (;;) {
+            for (int i = 0; i < chunk; ++i) {
+                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, 0, st))));
+                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, 0, st))));
+                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, 0, 0, st))));
+                hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, st, zlog, 1, 0);
+                HIP_TRY(hipGetLastError());
+                last_launches += 4;
+            }
+            HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (snap && hs.steps == prev_steps + 1)
+                if (int rc = copy_field_out(snap + fb * hs.steps, false, true)) return rc;
+            prev_steps = hs.steps;
+            if (hs.done) break;
+        }
+        HIP_TRY(hipEventRecord(ev1, stream));
+        timed = true;
+        if (steps_out) *steps_out = hs.steps;
+        if (z_out) {
+            std::vector<T> zl(hs.steps + 1);
+            HIP_TRY(hipMemcpy(zl.data(), zlog, sizeof(T) * (hs.steps + 1), hipMemcpyDeviceToHost));
+            for (int i = 0; i <= hs.steps; ++i) z_out[i] = (double)zl[i];
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (!(hs.z >= hs.length) && hs.steps >= hs.max_steps)
+            return fail(SSFM_ERR_INVALID, "ssfm_propagate_adaptive: max_steps=%lld reached at z=%g of %g km",
+                        (long long)max_steps, (double)hs.z, (double)hs.length);
+        return SSFM_OK;
+    }
+
+    // out = ifft(fft(x) * H): BEGIN/END with gamma = 0 are pure column transforms
+    int apply_transfer(const void* H_host) {
+        if (int rc = use_device()) return rc;
+        const int nrows = N1 * batch;
+        if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
+        cx<T>* hperm = scratch;   // n entries are enough
+        // dnat is a staging buffer: the propagator's own D~ must be re-set after a DM call
+        HIP_TRY(hipMemcpyAsync(dnat, H_host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
+        have_op = false;
+        for (auto& t : tabs) t.valid = false;
+        hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const cx<T>*)dnat, hperm, N1, N2, (T)0, inv_n());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev0, stream));
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr))));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr))));
+        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr))));
+        HIP_TRY(hipEventRecord(ev1, stream));
+        last_launches = 3;
+        timed = true;
+        HIP_TRY(hipStreamSynchronize(stream));   // H_host may be released by the caller
+        return SSFM_OK;
+    }
+
+    int debug_fft(void* dst) {
+        if (int rc = use_device()) return rc;
+        const int nrows = N1 * batch;
+        if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr))));
+        HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, nrows, stream, fargs(dperm, 0, nullptr))));
+        const long long total = (long long)n * batch;
+        hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           (const cx<T>*)F, scratch, N1, N2, batch);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(dst, scratch, sizeof(cx<T>) * total, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SSFM_OK;
+    }
+};
+
+}  // namespace
+
+struct ssfm_plan {
+    PlanBase* impl;
+};
+
+#define WITH_PLAN(p, expr)                                                          \
+    do {                                                                            \
+        if ((p) == nullptr || (p)->impl == nullptr) return fail(SSFM_ERR_INVALID, "null plan"); \
+        if ((p)->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>((p)->impl); return (expr); } \
+        auto* P_ = static_cast<PlanT<double>*>((p)->impl);                          \
+        return (expr);                                                              \
+    } while (0)
+
+namespace {
+template <typename PT> static int set_field_impl(PT* P_, const void* src, int is_device) {
+    if (int rc = P_->use_device()) return rc;
+    HIP_TRY(hipMemcpyAsync(P_->F, src, sizeof(*P_->F) * P_->n * P_->batch, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, P_->stream));
+    if (!is_device) HIP_TRY(hipStreamSynchronize(P_->stream));
+    return SSFM_OK;
+}
+
+template <typename PT> static int sync_impl(PT* P_) {
+    if (int rc = P_->use_device()) return rc;
+    HIP_TRY(hipStreamSynchronize(P_->stream));
+    return SSFM_OK;
+}
+
+template <typename PT> static int last_ms_impl(PT* P_, float* ms, int64_t* launches) {
+    if (launches) *launches = P_->last_launches;
+    if (ms) {
+        *ms = 0.f;
+        if (P_->timed) {
+            HIP_TRY(hipEventSynchronize(P_->ev1));
+            HIP_TRY(hipEventElapsedTime(ms, P_->ev0, P_->ev1));
+        }
+    }
+    return SSFM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ssfm_abi_version(void) { return SSFM_ABI_VERSION; }
+
+const char* ssfm_last_error(void) { return g_err; }
+
+int ssfm_device_count(int* count) {
+    if (!count) return fail(SSFM_ERR_INVALID, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return fail(SSFM_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = c;
+    return SSFM_OK;
+}
+
+int ssfm_supported_log2n(int precision, int* lo, int* hi) {
+    if (precision != SSFM_C64 && precision != SSFM_C128) return fail(SSFM_ERR_UNSUPPORTED, "unknown precision %d", precision);
+    if (lo) *lo = kLog2Min;
+    if (hi) *hi = kLog2Max;
+    return SSFM_OK;
+}
+
+int ssfm_plan_create(ssfm_plan** out, int device, int64_t n, int batch, int precision) {
+    if (!out) return fail(SSFM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (precision != SSFM_C64 && precision != SSFM_C128) return fail(SSFM_ERR_UNSUPPORTED, "unknown precision %d", precision);
+    if (batch < 1 || batch > 65535) return fail(SSFM_ERR_INVALID, "batch=%d out of range [1, 65535]", batch);
+    if (n < (1ll << kLog2Min) || n > (1ll << kLog2Max) || (n & (n - 1)) != 0)
+        return fail(SSFM_ERR_UNSUPPORTED, "n=%lld: the HIP path needs a power of two in [2^%d, 2^%d]", (long long)n, kLog2Min, kLog2Max);
+    int count = 0;
+    if (int rc = ssfm_device_count(&count)) return rc;
+    if (device < 0 || device >= count) return fail(SSFM_ERR_NO_DEVICE, "device %d not available (%d visible)", device, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SSFM_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    ssfm_plan* p = new (std::nothrow) ssfm_plan{nullptr};
+    if (!p) return fail(SSFM_ERR_INVALID, "out of host memory");
+    int rc;
+    if (precision == SSFM_C64) {
+        auto* impl = new (std::nothrow) PlanT<float>();
+        impl->precision = precision;
+        p->impl = impl;
+        rc = impl->init(device, n, batch);
+    } else {
+        auto* impl = new (std::nothrow) PlanT<double>();
+        impl->precision = precision;
+        p->impl = impl;
+        rc = impl->init(device, n, batch);
+    }
+    if (rc != SSFM_OK) { delete p->impl; delete p; return rc; }
+    *out = p;
+    return SSFM_OK;
+}
+
+int ssfm_plan_destroy(ssfm_plan* plan) {
+    if (!plan) return SSFM_OK;
+    delete plan->impl;
+    delete plan;
+    return SSFM_OK;
+}
+
+int ssfm_set_linear_operator(ssfm_plan* plan, const void* dtilde_host) {
+    if (!dtilde_host) return fail(SSFM_ERR_INVALID, "dtilde_host is NULL");
+    WITH_PLAN(plan, P_->set_operator(dtilde_host));
+}
+
+int ssfm_set_field(ssfm_plan* plan, const void* src, int is_device) {
+    if (!src) return fail(SSFM_ERR_INVALID, "src is NULL");
+    WITH_PLAN(plan, set_field_impl(P_, src, is_device));
+}
+int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device) {
+    if (!dst) return fail(SSFM_ERR_INVALID, "dst is NULL");
+    WITH_PLAN(plan, (P_->use_device() ? SSFM_ERR_HIP : P_->copy_field_out(dst, is_device != 0, true)));
+}
+void* ssfm_field_device_ptr(ssfm_plan* plan) {
+    if (!plan || !plan->impl) return nullptr;
+    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->F;
+    return static_cast<PlanT<double>*>(plan->impl)->F;
+}
+
+int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, void* snapshots) {
+    if (nsteps < 0) return fail(SSFM_ERR_INVALID, "nsteps=%lld", (long long)nsteps);
+    if (nsteps > 0 && !h_schedule) return fail(SSFM_ERR_INVALID, "h_schedule is NULL");
+    if (!plan || !plan->impl) return fail(SSFM_ERR_INVALID, "null plan");
+    if (plan->impl->precision == SSFM_C64)
+        return static_cast<PlanT<float>*>(plan->impl)->propagate_fixed(gamma, static_cast<const float*>(h_schedule), nsteps, snapshots);
+    return static_cast<PlanT<double>*>(plan->impl)->propagate_fixed(gamma, static_cast<const double*>(h_schedule), nsteps, snapshots);
+}
+
+int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double phi_max, int single_step,
+                            int64_t max_steps, int64_t* steps_out, double* z_out, void* snapshots) {
+    WITH_PLAN(plan, P_->propagate_adaptive(gamma, length, phi_max, single_step, max_steps, steps_out, z_out, snapshots));
+}
+
+int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host) {
+    if (!H_host) return fail(SSFM_ERR_INVALID, "H_host is NULL");
+    WITH_PLAN(plan, P_->apply_transfer(H_host));
+}
+
+int ssfm_debug_fft(ssfm_plan* plan, void* dst) {
+    if (!dst) return fail(SSFM_ERR_INVALID, "dst is NULL");
+    WITH_PLAN(plan, P_->debug_fft(dst));
+}
+
+int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }
+
+void* ssfm_stream(ssfm_plan* plan) {
+    if (!plan || !plan->impl) return nullptr;
+    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->stream;
+    return static_cast<PlanT<double>*>(plan->impl)->stream;
+}
+
+int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches) { WITH_PLAN(plan, last_ms_impl(P_, ms, launches)); }
+
+}  // extern "C"

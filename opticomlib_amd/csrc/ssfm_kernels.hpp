@@ -1,0 +1,308 @@
+// ssfm_kernels.hpp -- the split-step Fourier kernels for gfx950.
+//
+// N = N1 * N2 samples per row (four-step FFT).  Between kernels the field lives in the
+// "half transformed" layout Y[k1][n2] (k1 < N1 column-frequency, n2 < N2 row-time index):
+//
+//   k_time  works on a tile of C columns x all N1 rows:  twiddle^-1 -> IFFT_N1 -> second
+//           nonlinear half step of step k (stale |A|^2) -> |A|^2 -> first nonlinear half
+//           step of step k+1 -> FFT_N1 -> twiddle.  Time-domain samples exist only in
+//           registers.  (reference devices.py:1175,1177,1181)
+//   k_freq  works on whole rows (fixed k1, all n2): FFT_N2 -> multiply by exp(D~ h)/N (table
+//           stored in the transposed order this pass produces) -> IFFT_N2.
+//           (reference devices.py:1178-1180)
+//
+// so one SSFM step is two launches and each reads and writes the field exactly once.
+#pragma once
+#include "wgfft.hpp"
+
+namespace ssfm {
+
+enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2 };
+
+// Device-resident step control of the adaptive mode (reference devices.py:1155-1161,1193-1196).
+template <typename T> struct AdaptState {
+    T h;            // step about to be / being taken
+    T z;            // position reached
+    T length;
+    T phi_max;
+    T abs_gamma;
+    int adaptive;   // 0: keep h (only clamp), 1: h = phi_max / max(|gamma| |A|^2)
+    int done;
+    int steps;
+    int max_steps;
+    unsigned long long maxbits;   // bit pattern of max |A|^2 (non-negative => monotone as integer)
+};
+
+template <typename T> struct TimeArgs {
+    cx<T>* F;                 // field, batch rows of N
+    T* P;                     // stale |A|^2, same indexing as the time-domain field
+    const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]
+    const cx<T>* tw1;         // W_N1^q
+    AdaptState<T>* st;        // nullptr in fixed-step mode
+    T gamma;
+    T hh_prev;                // h/2 of the step being finished
+    T hh_next;                // h/2 of the step being started
+    int N2;
+};
+
+template <typename T> __device__ __forceinline__ void sincos_acc(T x, T& s, T& c);
+template <> __device__ __forceinline__ void sincos_acc<float>(float x, float& s, float& c) { sincosf(x, &s, &c); }
+template <> __device__ __forceinline__ void sincos_acc<double>(double x, double& s, double& c) { sincos(x, &s, &c); }
+
+template <int C> struct ColIdx {
+    int c;
+    __device__ __forceinline__ int operator()(int e) const { return e * C + c; }
+};
+struct RowIdx {
+    int off;
+    __device__ __forceinline__ int operator()(int e) const { return off + e + (e >> 4); }
+};
+__host__ __device__ constexpr int row_lds_elems(int n2) { return n2 + (n2 >> 4); }
+
+template <typename T> __device__ __forceinline__ unsigned long long float_bits(T v);
+template <> __device__ __forceinline__ unsigned long long float_bits<float>(float v) { return (unsigned long long)__float_as_uint(v); }
+template <> __device__ __forceinline__ unsigned long long float_bits<double>(double v) { return (unsigned long long)__double_as_longlong(v); }
+
+// ------------------------------------------------------------------------------ k_time
+template <typename T, int N1, int C, int MODE>
+__global__ __launch_bounds__(N1 * C / 16) void k_time(const TimeArgs<T> a) {
+    constexpr int Q = N1 / 16;                     // threads per column
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+
+    T hh_prev = a.hh_prev, hh_next = a.hh_next;
+    if (a.st != nullptr) {
+        if (a.st->done) return;
+        hh_prev = hh_next = a.st->h * (T)0.5;
+    }
+    const int tid = threadIdx.x;
+    const int c = tid % C;
+    const int j = tid / C;
+    const long long N = (long long)N1 * a.N2;
+    const long long rowbase = (long long)blockIdx.y * N + (long long)blockIdx.x * C + c;
+    const long long twbase = (long long)blockIdx.x * C + c;
+    const ColIdx<C> idx{c};
+
+    cx<T> v[16];
+    cx<T> w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = a.F[rowbase + (long long)(j + t * Q) * a.N2];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = a.twN[twbase + (long long)(j + t * Q) * a.N2];
+
+    if (MODE != TM_BEGIN) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = cmulc(v[t], w[t]);
+        fft_line<T, N1, +1, ColIdx<C>>(v, lds, j, idx, a.tw1);
+        // second half of the step being finished, with the |A|^2 of its START (devices.py:1181)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const T p = a.P[rowbase + (long long)(j + t * Q) * a.N2];
+            const T phi = hh_prev * (a.gamma * p);
+            T s, co;
+            sincos_acc<T>(phi, s, co);
+            v[t] = cmul(v[t], mk<T>(co, s));
+        }
+    }
+    if (MODE == TM_END) {
+        T pmax = (T)0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a.F[rowbase + (long long)(j + t * Q) * a.N2] = v[t];
+            const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+            pmax = p > pmax ? p : pmax;
+        }
+        if (a.st != nullptr && a.st->adaptive) {
+            // wave-level max, then one atomic per wave
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const T o = __shfl_xor(pmax, off);
+                pmax = o > pmax ? o : pmax;
+            }
+            if ((tid & 63) == 0) atomicMax(&a.st->maxbits, float_bits<T>(pmax));
+        }
+        return;
+    }
+    // first half of the step being started (devices.py:1175,1177)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+        a.P[rowbase + (long long)(j + t * Q) * a.N2] = p;
+        const T phi = hh_next * (a.gamma * p);
+        T s, co;
+        sincos_acc<T>(phi, s, co);
+        v[t] = cmul(v[t], mk<T>(co, s));
+    }
+    if (MODE == TM_MID && fft_nstages(N1) > 1) __syncthreads();   // inverse transform's LDS reads are done
+    fft_line<T, N1, -1, ColIdx<C>>(v, lds, j, idx, a.tw1);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) a.F[rowbase + (long long)(j + t * Q) * a.N2] = cmul(v[t], w[t]);
+}
+
+// ------------------------------------------------------------------------------ k_freq
+enum FreqMode { FM_TABLE = 0, FM_FLY = 1, FM_FWD_ONLY = 2 };
+
+template <typename T> struct FreqArgs {
+    cx<T>* F;
+    const cx<T>* tab;        // FM_TABLE: exp(D~ h)/N (or H/N) at [k1*N2 + k2];  FM_FLY: D~ at the same place
+    const cx<T>* tw2;        // W_N2^q
+    const AdaptState<T>* st; // FM_FLY: step size source when non-null
+    T h;                     // FM_FLY with st == nullptr
+    T inv_n;
+    int N1;
+};
+
+template <typename T> __device__ __forceinline__ T exp_acc(T x);
+template <> __device__ __forceinline__ float exp_acc<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double exp_acc<double>(double x) { return exp(x); }
+
+template <typename T, int N2, int ROWS, int MODE>
+__global__ __launch_bounds__(ROWS * N2 / 16) void k_freq(const FreqArgs<T> a) {
+    constexpr int Q = N2 / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+
+    T h = a.h;
+    if (MODE == FM_FLY && a.st != nullptr) {
+        if (a.st->done) return;
+        h = a.st->h;
+    }
+    const int tid = threadIdx.x;
+    const int j = tid % Q;
+    const int rr = tid / Q;
+    const long long row = (long long)blockIdx.x * ROWS + rr;     // over batch*N1 rows
+    const int k1 = (int)(row % a.N1);
+    cx<T>* Frow = a.F + row * N2;
+    const cx<T>* trow = a.tab + (long long)k1 * N2;
+    const RowIdx idx{rr * row_lds_elems(N2)};
+
+    cx<T> v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = Frow[j + t * Q];
+    fft_line<T, N2, -1, RowIdx>(v, lds, j, idx, a.tw2);
+    if (MODE == FM_FWD_ONLY) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        cx<T> m = trow[j + t * Q];
+        if (MODE == FM_FLY) {
+            // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
+            const T e = exp_acc<T>(m.x * h);
+            T s, co;
+            sincos_acc<T>(m.y * h, s, co);
+            m = mk<T>((e * co) * a.inv_n, (e * s) * a.inv_n);
+        }
+        v[t] = cmul(v[t], m);
+    }
+    if (fft_nstages(N2) > 1) __syncthreads();
+    fft_line<T, N2, +1, RowIdx>(v, lds, j, idx, a.tw2);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
+}
+
+// ------------------------------------------------------------------------------ tables
+// W_L^q = exp(-2 pi i q / L), generated in double, rounded once.
+template <typename T> __global__ void k_make_twL(cx<T>* tab, int L) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= L) return;
+    double s, c;
+    sincospi(-2.0 * (double)q / (double)L, &s, &c);
+    tab[q] = mk<T>((T)c, (T)s);
+}
+// W_N^(k1*n2) at [k1*N2 + n2]
+template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long N = (long long)N1 * N2;
+    if (o >= N) return;
+    const long long k1 = o / N2, n2 = o % N2;
+    const long long m = (k1 * n2) % N;
+    double s, c;
+    sincospi(-2.0 * (double)m / (double)N, &s, &c);
+    tab[o] = mk<T>((T)c, (T)s);
+}
+// out[k1*N2 + k2] = f(src[k1 + N1*k2]); MODE 0: copy, 1: * inv_n, 2: exp(src*h) * inv_n
+template <typename T, int MODE>
+__global__ void k_make_freq_table(const cx<T>* __restrict__ src, cx<T>* __restrict__ out, int N1, int N2, T h, T inv_n) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long N = (long long)N1 * N2;
+    if (o >= N) return;
+    const long long k1 = o / N2, k2 = o % N2;
+    cx<T> d = src[k1 + (long long)N1 * k2];
+    if (MODE == 1) { d.x *= inv_n; d.y *= inv_n; }
+    if (MODE == 2) {
+        // the products are taken in T exactly as the reference does (complex64 * float32), the
+        // transcendental functions in double and rounded once: within 1 ulp of any libm's result
+        const T xr = d.x * h, xi = d.y * h;
+        const T e = (T)exp((double)xr);
+        double s, c;
+        sincos((double)xi, &s, &c);
+        d.x = (e * (T)c) * inv_n;
+        d.y = (e * (T)s) * inv_n;
+    }
+    out[o] = d;
+}
+// natural[k1 + N1*k2] = perm[k1*N2 + k2]   (debug: spectrum back to natural order)
+template <typename T>
+__global__ void k_unpermute(const cx<T>* __restrict__ perm, cx<T>* __restrict__ nat, int N1, int N2, int batch) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long N = (long long)N1 * N2;
+    if (o >= N * batch) return;
+    const long long b = o / N, r = o % N;
+    const long long k1 = r / N2, k2 = r % N2;
+    nat[b * N + k1 + (long long)N1 * k2] = perm[o];
+}
+
+// max |A|^2 over the whole (natural-order) field -> st->maxbits
+template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long long total, AdaptState<T>* st) {
+    T pmax = (T)0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const cx<T> v = F[i];
+        const T p = v.x * v.x + v.y * v.y;
+        pmax = p > pmax ? p : pmax;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(pmax, off);
+        pmax = o > pmax ? o : pmax;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&st->maxbits, float_bits<T>(pmax));
+}
+
+template <typename T> __device__ __forceinline__ T bits_float(unsigned long long b);
+template <> __device__ __forceinline__ float bits_float<float>(unsigned long long b) { return __uint_as_float((unsigned)b); }
+template <> __device__ __forceinline__ double bits_float<double>(unsigned long long b) { return __longlong_as_double((long long)b); }
+
+// Step control, one thread.  phase 0: choose the first step (devices.py:1155-1161);
+// phase 1: account for the step just finished and choose the next (devices.py:1173,1193-1196).
+template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog, int phase, int single_step) {
+    if (phase == 0) {
+        T h;
+        if (single_step) h = st->length;
+        else h = st->phi_max / (st->abs_gamma * bits_float<T>(st->maxbits));
+        h = h < st->length ? h : st->length;
+        st->h = h;
+        st->z = (T)0;
+        st->steps = 0;
+        st->done = !((T)0 < st->length);
+        st->maxbits = 0ull;
+        zlog[0] = (T)0;
+        return;
+    }
+    if (st->done) return;
+    const T z = st->z + st->h;
+    T h = st->h;
+    if (st->adaptive) h = st->phi_max / (st->abs_gamma * bits_float<T>(st->maxbits));
+    const T rem = st->length - z;
+    h = h < rem ? h : rem;
+    st->z = z;
+    st->h = h;
+    st->steps += 1;
+    zlog[st->steps] = z;
+    st->maxbits = 0ull;
+    st->done = !(z < st->length) || st->steps >= st->max_steps;
+}
+
+}  // namespace ssfm

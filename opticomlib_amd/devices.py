@@ -1,0 +1,251 @@
+"""``FIBER`` / ``DBP`` / ``DM`` with the reference's call signatures, running on MI355X.
+
+Host-side mirror of reference ``opticomlib/devices.py:1038-1206`` (FIBER), ``:1209-1283``
+(DBP) and ``:945-1035`` (DM): same argument names, defaults, units, return types and the
+same ``TypeError``.  All field arithmetic happens in the HIP library behind the C ABI
+(``include/ssfm_amd.h``); this module only prepares the O(N) operator coefficients and the
+float32 step schedule exactly the way the reference's prologue does, and wraps the result.
+
+There is deliberately NO CPU fallback: sizes the HIP path does not cover raise
+``ValueError``; a missing library or device raises ``SsfmError``.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .typing import NULL, optical_signal
+
+_F32 = np.float32
+_PLANS: "OrderedDict[tuple, _lib.Plan]" = OrderedDict()
+_MAX_PLANS = 4
+
+
+def default_device() -> int:
+    """Device index of this process: ``LOCAL_RANK`` under torchrun, else 0."""
+    return int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)
+
+
+def get_plan(n: int, batch: int, precision: int, device=None) -> _lib.Plan:
+    """Plans own all device buffers; keep the few most recent ones alive."""
+    device = default_device() if device is None else int(device)
+    key = (device, int(n), int(batch), int(precision))
+    plan = _PLANS.pop(key, None)
+    if plan is None:
+        plan = _lib.Plan(n, batch, precision, device)
+    _PLANS[key] = plan
+    while len(_PLANS) > _MAX_PLANS:
+        _, old = _PLANS.popitem(last=False)
+        old.close()
+    return plan
+
+
+def release_plans():
+    while _PLANS:
+        _, p = _PLANS.popitem()
+        p.close()
+
+
+def _check_size(n: int, precision: int):
+    lo, hi = _lib.supported_log2n(precision)
+    if n < (1 << lo) or n > (1 << hi) or n & (n - 1):
+        raise ValueError(
+            f"the MI355X fibre path needs a power-of-two number of samples in [2^{lo}, 2^{hi}] per polarisation, "
+            f"got {n} (pad or resample the signal; there is no CPU fallback)")
+
+
+def _precision_code(precision) -> int:
+    p = np.dtype(precision)
+    if p == np.complex64:
+        return _lib.C64
+    if p == np.complex128:
+        return _lib.C128
+    raise ValueError("precision must be complex64 or complex128")
+
+
+# ------------------------------------------------------------------ operator coefficients
+def linear_operator(n, dt, alpha, beta_2, beta_3, precision=_lib.C64):
+    """D~(w) = -alpha/2 + j beta_2/2 w^2 + j beta_3/6 w^3 in FFT order.
+
+    complex64: every factor is rounded to float32 in the reference's own order
+    (``devices.py:1137-1145``) so both sides start from identical coefficients.
+    complex128: the float64 form of ``devices.py:2440-2442``.
+    """
+    w = np.fft.fftfreq(n, dt) * 2 * np.pi * 1e-12            # rad/ps
+    if precision == _lib.C64:
+        a = np.array(alpha / 4.343, dtype=_F32)
+        b2 = np.array(beta_2, dtype=_F32)
+        b3 = np.array(beta_3, dtype=_F32)
+        w = np.asarray(w, dtype=_F32)
+        return -a / 2 + 1j / 2 * b2 * w**2 + 1j / 6 * b3 * w**3
+    a = alpha / 4.343
+    return -a / 2 + 1j / 2 * beta_2 * w**2 + 1j / 6 * beta_3 * w**3
+
+
+def step_schedule(length, h, precision=_lib.C64):
+    """Step sizes and positions of a fixed-``h`` run.
+
+    The reference accumulates ``z`` and clamps ``h`` in float32 (``devices.py:1158-1161,
+    1173,1196``), which decides the step COUNT (100 km / 0.1 km is 1001 steps); the same
+    arithmetic is replayed here.  Returns ``(h[S], z[S+1])`` in the plan's real type.
+    """
+    rt = _F32 if precision == _lib.C64 else np.float64
+    L = rt(length)
+    hs = rt(h)
+    if not np.isfinite(hs) or hs <= 0:
+        raise ValueError(f"h must be a positive step size in km, got {h!r} (the reference never terminates for h <= 0)")
+    hcur = min(hs, L)
+    z = rt(0)
+    hlist, zlist = [], [z]
+    while z < L:
+        z = rt(z + hcur)
+        hlist.append(hcur)
+        zlist.append(z)
+        hcur = rt(min(hcur, rt(L - z)))
+    return np.array(hlist, dtype=rt), np.array(zlist, dtype=rt)
+
+
+# ------------------------------------------------------------------ FIBER / DBP
+def FIBER(input: optical_signal,
+          length: float,
+          alpha: float = 0.0,
+          beta_2: float = 0.0,
+          beta_3: float = 0.0,
+          gamma: float = 0.0,
+          phi_max: float = 0.01,
+          h: float = None,
+          show_progress: bool = False,
+          return_steps: bool = False,
+          *,
+          precision="complex64",
+          device=None):
+    """Optical fibre: symmetric split-step Fourier solution of the scalar NLSE per polarisation.
+
+    Parameters as the reference (``devices.py:1038-1083``): ``length`` [km], ``alpha`` [dB/km],
+    ``beta_2`` [ps^2/km], ``beta_3`` [ps^3/km], ``gamma`` [1/(W km)], ``phi_max`` [rad] bound of
+    the nonlinear phase per adaptive step, ``h`` fixed step [km] or ``None`` for adaptive.
+    Returns an :class:`optical_signal` (``noise`` folded into ``signal``, ``noise = NULL``) or,
+    with ``return_steps``, ``(z float64 (S+1,), A_z (S+1, [2,] N))``.
+
+    Extensions (keyword-only, defaults keep the reference's behaviour): ``precision``
+    ``"complex64"`` (the reference's arithmetic) or ``"complex128"``; ``device`` index.
+    """
+    t0 = time.time()
+    if not isinstance(input, optical_signal):
+        raise TypeError("`input` must be of type 'optical_signal'.")
+    prec = _precision_code(precision)
+    plan_dtype = np.complex64 if prec == _lib.C64 else np.complex128
+    rt = _F32 if prec == _lib.C64 else np.float64
+
+    A = np.ascontiguousarray(input.to_numpy(), dtype=plan_dtype)
+    shape = A.shape
+    n = shape[-1]
+    batch = 1 if A.ndim == 1 else shape[0]
+    _check_size(n, prec)
+
+    L = rt(length)
+    plan = get_plan(n, batch, prec, device)
+    plan.set_linear_operator(linear_operator(n, input.dt, alpha, beta_2, beta_3, prec))
+    plan.set_field(A)
+
+    bar = None
+    if show_progress:
+        try:
+            from tqdm.auto import tqdm
+            bar = tqdm(total=100, desc="Propagating", bar_format="{l_bar}{bar}|[{elapsed}{postfix}]", postfix={"FFTs": 0})
+        except ImportError:
+            bar = None
+
+    if h is None:
+        b2, b3, g = rt(beta_2), rt(beta_3), rt(gamma)
+        single = bool((b2 == 0 and b3 == 0) or g == 0)
+        steps, z, snaps = plan.propagate_adaptive(gamma, length, phi_max, single, snapshots=return_steps)
+    else:
+        hs, z = step_schedule(length, h, prec)
+        steps = hs.size
+        snaps = None
+        if return_steps:
+            snaps = plan.propagate_fixed(gamma, hs, snapshots=True) if steps else A.reshape(1, batch, n).copy()
+        elif bar is not None and steps:
+            done = 0
+            for chunk in np.array_split(hs, min(20, steps)):      # progress needs sync points
+                _chain_fixed(plan, gamma, chunk)
+                plan.synchronize()
+                done += chunk.size
+                bar.update(100.0 * float(chunk.sum()) / float(L))
+                bar.set_postfix(FFTs=2 * done)
+        elif steps:
+            plan.propagate_fixed(gamma, hs)
+    if bar is not None:
+        if h is None or return_steps:
+            bar.update(100)
+            bar.set_postfix(FFTs=2 * int(steps))
+        bar.close()
+
+    if return_steps:
+        A_z = snaps.reshape((snaps.shape[0],) + shape)
+        return np.asarray(z, dtype=np.float64), A_z
+    out = plan.get_field().reshape(shape)
+    output = optical_signal(out)
+    output.execution_time = time.time() - t0
+    return output
+
+
+def _chain_fixed(plan, gamma, hs):
+    plan.propagate_fixed(gamma, hs)
+
+
+def DBP(input: optical_signal,
+        length: float,
+        alpha: float = 0.0,
+        beta_2: float = 0.0,
+        beta_3: float = 0.0,
+        gamma: float = 0.0,
+        phi_max: float = 0.01,
+        h: float = None,
+        show_progress: bool = False,
+        return_steps: bool = False,
+        *,
+        precision="complex64",
+        device=None):
+    """Digital back-propagation = ``FIBER`` with every operator negated (``devices.py:1280-1283``)."""
+    return FIBER(input, length=length, alpha=-alpha, beta_2=-beta_2, beta_3=-beta_3, gamma=-gamma,
+                 phi_max=phi_max, h=h, show_progress=show_progress, return_steps=return_steps,
+                 precision=precision, device=device)
+
+
+# ------------------------------------------------------------------ DM
+def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
+    """Dispersive medium: one linear step ``H(w) = exp(+j w^2 D/2)``, ``D = beta_2 z`` [ps^2]
+    (``devices.py:1019-1035``).  complex128; signal and noise are filtered separately and stay
+    separate.  With ``retH`` also returns ``fftshift(H)``."""
+    t0 = time.time()
+    if not isinstance(input, optical_signal):
+        raise TypeError("`input` must be of type 'optical_signal'.")
+    D = D * 1e-12**2
+    H = np.exp(1j * input.w() ** 2 * D / 2)
+
+    sig = np.ascontiguousarray(input.signal, dtype=np.complex128)
+    shape = sig.shape
+    n = shape[-1]
+    rows = 1 if sig.ndim == 1 else shape[0]
+    _check_size(n, _lib.C128)
+    has_noise = input.noise is not NULL
+    stack = sig.reshape(rows, n)
+    if has_noise:
+        stack = np.concatenate([stack, np.ascontiguousarray(input.noise, dtype=np.complex128).reshape(rows, n)])
+    plan = get_plan(n, stack.shape[0], _lib.C128, device)
+    plan.set_field(stack)
+    plan.apply_transfer(H)
+    res = plan.get_field()
+    out_sig = res[:rows].reshape(shape)
+    out_noise = res[rows:].reshape(shape) if has_noise else NULL
+    output = optical_signal(out_sig, out_noise, n_pol=input.n_pol)
+    if retH:
+        return output, np.fft.fftshift(H)
+    output.execution_time = time.time() - t0
+    return output

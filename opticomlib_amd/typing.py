@@ -1,0 +1,182 @@
+"""Boundary types of the fibre path: the slice of ``opticomlib.typing`` that ``FIBER`` /
+``DBP`` / ``DM`` touch, and nothing else.
+
+* :data:`NULL`      -- "no noise" sentinel (reference ``typing.py:56-93``): ``x + NULL == x``.
+* :data:`gv`        -- global sampling parameters; a signal does not carry its sample rate,
+                       ``optical_signal.w()`` reads ``gv.dt`` at call time (``typing.py:1641``).
+* :class:`optical_signal` -- ``.signal``, ``.noise``, ``.n_pol``, ``.size``, ``.execution_time``,
+                       ``.w()``, ``.to_numpy()`` with the reference's shape -> ``n_pol`` rules
+                       (``typing.py:2124-2196``).
+
+Operators, plotting, PSD, eye diagrams etc. are out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class _NullType:
+    """Additive identity that swallows everything else."""
+
+    _inst = None
+
+    def __new__(cls):
+        if cls._inst is None:
+            cls._inst = super().__new__(cls)
+        return cls._inst
+
+    def __repr__(self):
+        return "NULL"
+
+    def __add__(self, other):
+        return other
+
+    __radd__ = __add__
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method == "__call__" and ufunc in (np.add, np.subtract) and inputs[1] is self:
+            return inputs[0]
+        return self
+
+    def __bool__(self):
+        return False
+
+
+NULL = _NullType()
+
+
+class _GlobalVars:
+    """Sampling grid shared by all signals (reference ``typing.py:106-388``, the part the path
+    needs: ``sps``, ``R``, ``fs``, ``dt``)."""
+
+    def __init__(self):
+        self.default()
+
+    def default(self):
+        self.sps = 16
+        self.R = 1e9
+        self.fs = self.R * self.sps
+        self.dt = 1 / self.fs
+        return self
+
+    def __call__(self, sps=None, R=None, fs=None, **extra):
+        # same precedence as the reference (typing.py:306-335)
+        if sps:
+            self.sps = int(np.round(sps))
+            if R:
+                self.R = R
+                self.fs = R * self.sps
+            elif fs:
+                self.fs = fs
+                self.R = fs / self.sps
+            else:
+                self.fs = self.R * self.sps
+        elif R:
+            self.R = R
+            if fs:
+                self.fs = fs
+                self.sps = int(np.round(fs / R))
+            else:
+                self.fs = R * self.sps
+        elif fs:
+            self.fs = fs
+            self.sps = int(np.round(fs / self.R))
+        self.dt = 1 / self.fs
+        for k, v in extra.items():
+            setattr(self, k, v)
+        return self
+
+
+gv = _GlobalVars()
+
+
+class optical_signal:
+    """Optical field container: ``signal`` (and optional ``noise``) of shape ``(N,)`` for one
+    polarisation or ``(2, N)`` for two."""
+
+    def __init__(self, signal, noise=NULL, n_pol=None, dtype=None):
+        if isinstance(signal, optical_signal):
+            if noise is not NULL:
+                noise = np.asarray(noise) + signal.noise
+            else:
+                noise = signal.noise
+            signal = signal.signal
+        sig = np.array(signal)
+        noi = noise
+        if noi is not NULL:
+            noi = np.array(noi)
+            common = np.result_type(sig, noi) if dtype is None else dtype
+            sig, noi = sig.astype(common), noi.astype(common)
+            if sig.shape != noi.shape:
+                raise ValueError(f"`signal` and `noise` must have the same shape, mismatch shapes {sig.shape} and {noi.shape}!")
+        elif dtype is not None:
+            sig = sig.astype(dtype)
+
+        if sig.ndim > 2 or (sig.ndim > 1 and sig.shape[0] > 2) or sig.size < 1:
+            raise ValueError(f"Signal must be a scalar, 1D or 2D array for optical_signal, invalid shape {sig.shape}")
+        if n_pol is not None and n_pol not in (1, 2):
+            raise ValueError("n_pol must be either 1 or 2")
+
+        def both(f):
+            return f(sig), (noi if noi is NULL else f(noi))
+
+        want_two = n_pol == 2
+        if sig.ndim == 0:
+            if want_two:
+                sig, noi = both(lambda a: np.array([[a], [a]]))
+            else:
+                sig, noi = both(lambda a: a[np.newaxis])
+                n_pol = 1
+        elif sig.ndim == 1:
+            if want_two:
+                sig, noi = both(lambda a: np.array([a, a]))
+            else:
+                n_pol = 1
+        elif sig.shape[0] == 1:            # (1, N): becomes dual-pol by tiling unless n_pol=1
+            if n_pol in (None, 2):
+                sig, noi = both(lambda a: np.tile(a, (2, 1)))
+                n_pol = 2
+            else:
+                sig, noi = both(lambda a: a[0])
+        else:                              # (2, N)
+            if n_pol in (None, 2):
+                n_pol = 2
+            else:
+                sig, noi = both(lambda a: a[0])
+
+        self.signal = sig
+        self.noise = noi
+        self.n_pol = n_pol
+        self.execution_time = 0.0
+
+    @property
+    def size(self) -> int:
+        """Samples per polarisation (reference ``typing.py:2313-2320``)."""
+        return self.signal.size if self.n_pol == 1 else self.signal[0].size
+
+    def __len__(self):
+        return self.size
+
+    @property
+    def shape(self):
+        return self.signal.shape
+
+    @property
+    def dt(self):
+        return gv.dt
+
+    def to_numpy(self) -> np.ndarray:
+        """``signal + noise`` (reference ``typing.py:1593-1597``)."""
+        return np.asarray(self.signal + self.noise)
+
+    def w(self, shift: bool = False) -> np.ndarray:
+        """Angular frequency grid [rad/s], FFT order (reference ``typing.py:1628-1644``)."""
+        w = np.fft.fftfreq(self.size, gv.dt) * 2 * np.pi
+        return np.fft.fftshift(w, axes=-1) if shift else w
+
+    def power(self):
+        """Mean power per polarisation [W] of ``signal + noise``."""
+        return np.mean(np.abs(self.to_numpy()) ** 2, axis=-1)
+
+    def __repr__(self):
+        return f"optical_signal(n_pol={self.n_pol}, size={self.size}, dtype={self.signal.dtype}, noise={'NULL' if self.noise is NULL else 'array'})"

@@ -1,0 +1,48 @@
+"""Synthetic link inputs of the benchmark configurations.  Host-side input
+generation only -- not on the hot path."""
+from __future__ import annotations
+
+import numpy as np
+
+# fibre of BASELINE.md section 3
+SMF = dict(alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
+BENCH_GV = dict(sps=16, R=32e9)          # fs = 512 GHz, dt = 1.953125 ps
+
+
+def _shape_pulses(sym: np.ndarray, n: int, sps: int, power_w: float) -> np.ndarray:
+    x = np.zeros(sym.shape[:-1] + (n,), dtype=np.complex128)
+    x[..., sps // 2::sps] = sym
+    f = np.fft.fftfreq(n) * sps                                    # in symbol rates
+    x = np.fft.ifft(np.fft.fft(x, axis=-1) * np.exp(-(f / 0.6) ** 2 * np.log(2)), axis=-1)
+    x *= np.sqrt(power_w / np.mean(np.abs(x) ** 2, axis=-1, keepdims=True))
+    return x
+
+
+def qpsk_field(n: int, seed: int, n_pol: int = 2, sps: int = 16, power_w: float = 1e-3) -> np.ndarray:
+    """QPSK-like dual-polarisation field: ``n/sps`` random symbols per polarisation, Gaussian
+    spectral shaping ``exp(-(f/0.6R)^2 ln2)``, 0 dBm (1 mW) mean power per polarisation."""
+    rng = np.random.default_rng(seed)
+    b = rng.integers(0, 2, size=(n_pol, n // sps, 2))
+    sym = ((2 * b[..., 0] - 1) + 1j * (2 * b[..., 1] - 1)) / np.sqrt(2)
+    return _shape_pulses(sym, n, sps, power_w)
+
+
+def lfsr_bits(order: int, length: int, seed: int) -> np.ndarray:
+    """Fibonacci LFSR bit sequence (PRBS-7/9/11/15/20/23/31 taps), for the Monte-Carlo
+    realisations of configuration C4."""
+    taps = {7: (7, 6), 9: (9, 5), 11: (11, 9), 15: (15, 14), 20: (20, 3), 23: (23, 18), 31: (31, 28)}[order]
+    state = seed & ((1 << order) - 1) or 1
+    out = np.empty(length, dtype=np.uint8)
+    for i in range(length):
+        bit = ((state >> (taps[0] - 1)) ^ (state >> (taps[1] - 1))) & 1
+        state = ((state << 1) | bit) & ((1 << order) - 1)
+        out[i] = bit
+    return out
+
+
+def prbs_field(n: int, seed: int, n_pol: int = 2, sps: int = 16, power_w: float = 1e-3, order: int = 15) -> np.ndarray:
+    """QPSK-like field whose bits come from an LFSR seeded per realisation."""
+    nsym = n // sps
+    bits = lfsr_bits(order, 2 * n_pol * nsym, seed).reshape(n_pol, nsym, 2).astype(np.int64)
+    sym = ((2 * bits[..., 0] - 1) + 1j * (2 * bits[..., 1] - 1)) / np.sqrt(2)
+    return _shape_pulses(sym, n, sps, power_w)
