@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- SSFM sample*steps/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One bench "step" = one complete propagation of the workload: configuration C2 of SURVEY.md 8
+(2^20-sample dual-polarisation complex64 field, FIBER(length=125 km, h=0.125 km) = exactly 1000
+SSFM steps; QPSK-like 32 GBd, 16 samples/symbol, 0 dBm/pol; alpha 0.2 dB/km, beta_2 -21.7 ps^2/km,
+beta_3 0.13 ps^3/km, gamma 1.3 /(W km)).  The field is resident in HBM when the timed region
+starts; each timed step restores the input with a device-to-device copy (16 MiB, ~1e-3 of a
+step) so that every step propagates the same physical signal instead of an ever weaker one.
+
+N > 1: every rank propagates its own independent field (WDM channel / Monte-Carlo realisation;
+configuration C3) -- the path shards with no data-path collective -- and a per-rank power
+checksum is gathered over RCCL after the timed region ("scaling": "weak").
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG2N = 20
+N_POL = 2
+SSFM_STEPS = 1000
+LENGTH_KM, H_KM = 125.0, 0.125          # exactly 1000 float32 steps
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md chip table (spec)
+
+
+def cpu_baseline(a, dt, fibre, sample_steps):
+    """The oracle (NumPy restatement of the reference, single thread like the reference) timed on
+    a bounded sample of the SAME workload: `sample_steps` SSFM steps of the 2^20 x 2 field."""
+    from oracle import ssfm_numpy as orc
+    t = time.perf_counter()
+    orc.fiber_c64(a, dt, length=LENGTH_KM, h=H_KM, max_steps=sample_steps, **fibre)
+    el = time.perf_counter() - t
+    return {
+        "value": a.shape[-1] * sample_steps / el,
+        "unit": "sample*steps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{sample_steps} of {SSFM_STEPS} SSFM steps of the same 2^{LOG2N} x {N_POL} complex64 field, "
+                  f"oracle/ssfm_numpy.fiber_c64 (NumPy {np.__version__}), {el:.1f} s, host has {os.cpu_count()} cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=12, help="SSFM steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-kernel HIP-event pass")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from opticomlib_amd import _lib, devices, workloads
+
+    n = 1 << LOG2N
+    fibre = dict(workloads.SMF)
+    dt = 1.0 / (workloads.BENCH_GV["sps"] * workloads.BENCH_GV["R"])
+    seed = 2024 if world == 1 else 3000 + rank                      # C2 / C3 seeds
+    a = workloads.qpsk_field(n, seed=seed, n_pol=N_POL)
+    hs, _ = devices.step_schedule(LENGTH_KM, H_KM, _lib.C64)
+    assert hs.size == SSFM_STEPS
+
+    plan = _lib.Plan(n, N_POL, _lib.C64, device=local_rank)
+    plan.set_linear_operator(devices.linear_operator(n, dt, fibre["alpha"], fibre["beta_2"], fibre["beta_3"], _lib.C64))
+    x_dev = torch.from_numpy(np.ascontiguousarray(a.astype(np.complex64))).cuda()       # resident input
+    torch.cuda.synchronize()
+
+    def one_step():
+        plan.set_field_device(x_dev.data_ptr())          # D2D restore on the plan's stream
+        plan.propagate_fixed(fibre["gamma"], hs)         # 1 + 2*1000 launches, asynchronous
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_dev, launches = plan.last_propagate_ms()
+    out = plan.get_field()
+    power = float(np.mean(np.abs(out.astype(np.complex128)) ** 2))
+
+    # the only "exchange" of this path: gather one checksum per channel at the end
+    checks = [power]
+    if distributed:
+        g = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(g, torch.tensor([power], dtype=torch.float64, device="cuda"))
+        checks = [float(v.item()) for v in g]
+
+    value = world * n * SSFM_STEPS * args.steps / elapsed
+
+    roofline = None
+    cpu = None
+    if rank == 0:
+        b_alg_launch = 2 * N_POL * 8 * n                     # field read once + written once per launch
+        if not args.no_profile_pass:
+            plan.set_profiling(True)
+            one_step()
+            plan.synchronize()
+            kt = plan.kernel_times()
+            plan.set_profiling(False)
+            dom = max(kt, key=lambda k: kt[k][1])
+            cnt, tot = kt[dom]
+            avg_us = tot / cnt * 1e3
+            achieved = b_alg_launch / (avg_us * 1e-6) / 1e9
+            roofline = {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": avg_us,
+                "launch_us": {k: v[1] / max(v[0], 1) * 1e3 for k, v in kt.items()},
+                "algorithmic_bytes_per_launch": b_alg_launch,
+                "step_frac": 2 * N_POL * 8 * value / world / (HBM_PEAK_GBS * 1e9),
+            }
+        if world == 1 and args.cpu_steps > 0:
+            cpu = cpu_baseline(a, dt, fibre, args.cpu_steps)
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    print(json.dumps({
+        "metric": "SSFM sample*steps/sec, 2^20-sample dual-pol fiber",
+        "value": value,
+        "unit": "sample*steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "c64",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: 2^20-sample dual-pol optical_signal, FIBER(length=125, h=0.125) = 1000 SSFM steps, complex64"
+                        + ("" if world == 1 else f"; C3: {world} independent fields, one per GPU"),
+            "n_samples": n, "n_pol": N_POL, "ssfm_steps_per_bench_step": SSFM_STEPS,
+            "fields_per_gpu": 1, "parallelism": f"independent-fields x{world}",
+        },
+        "device_ms_last_propagate": ms_dev,
+        "launches_per_propagate": launches,
+        "us_per_ssfm_step": elapsed / args.steps / SSFM_STEPS * 1e6,
+        "output_power_W_per_rank": checks,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }))
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,15 @@ void* ssfm_stream(ssfm_plan* plan);
  * number of kernel launches it made.  Valid after ssfm_synchronize. */
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
 
+/* Per-kernel timing of ssfm_propagate_fixed.  When enabled, a HIP event is recorded on the plan's
+ * stream before the first and after every kernel launch (measurement runs only: it costs host time
+ * and a marker packet per launch).  After ssfm_synchronize, ssfm_kernel_times returns per kernel
+ * class (index 0 = k_time begin/mid/end, 1 = k_freq) the number of launches and the summed time
+ * from the previous event to the event after the launch, in ms (so a dependent-launch gap is
+ * counted with the kernel that follows it). */
+int ssfm_set_profiling(ssfm_plan* plan, int enabled);
+int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ SYMBOLS = {
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
     "ssfm_last_propagate_ms": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(_I64)]),
+    "ssfm_set_profiling": (_I, [_VP, _I]),
+    "ssfm_kernel_times": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
 }
 
 
@@ -178,6 +180,16 @@ class Plan:
 
     def synchronize(self):
         _check(load().ssfm_synchronize(self._h), "ssfm_synchronize")
+
+    def set_profiling(self, enabled: bool):
+        _check(load().ssfm_set_profiling(self._h, int(bool(enabled))), "ssfm_set_profiling")
+
+    def kernel_times(self):
+        """{'k_time': (launches, total_ms), 'k_freq': (launches, total_ms)} of the last profiled run."""
+        cnt = (_I64 * 2)()
+        ms = (_D * 2)()
+        _check(load().ssfm_kernel_times(self._h, cnt, ms), "ssfm_kernel_times")
+        return {"k_time": (cnt[0], ms[0]), "k_freq": (cnt[1], ms[1])}
 
     def last_propagate_ms(self):
         ms, n = C.c_float(0), _I64(0)

@@ -123,6 +123,38 @@ template <typename T> struct PlanT : PlanBase {
     bool have_op = false;
     bool timed = false;
     int64_t last_launches = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> pev;       // pool of per-launch events
+    std::vector<unsigned char> pcls;   // class of the launch that precedes event i+1
+    size_t pn = 0;                     // events recorded by the last propagate
+
+    int prof_mark(int cls) {           // cls < 0: opening event
+        if (!profiling) return SSFM_OK;
+        if (pn == pev.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            pev.push_back(e);
+            pcls.push_back(0);
+        }
+        HIP_TRY(hipEventRecord(pev[pn], stream));
+        pcls[pn] = (unsigned char)(cls < 0 ? 255 : cls);
+        ++pn;
+        return SSFM_OK;
+    }
+    int kernel_times(int64_t counts[2], double total_ms[2]) {
+        counts[0] = counts[1] = 0;
+        total_ms[0] = total_ms[1] = 0.0;
+        if (pn < 2) return SSFM_OK;
+        HIP_TRY(hipEventSynchronize(pev[pn - 1]));
+        for (size_t i = 1; i < pn; ++i) {
+            if (pcls[i] > 1) continue;
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, pev[i - 1], pev[i]));
+            counts[pcls[i]] += 1;
+            total_ms[pcls[i]] += ms;
+        }
+        return SSFM_OK;
+    }
 
     T inv_n() const { return (T)1 / (T)n; }
 
@@ -131,6 +163,8 @@ template <typename T> struct PlanT : PlanBase {
         void* bufs[] = {F, P, twN, tw1, tw2, dnat, dperm, scratch, st, zlog};
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
+        for (hipEvent_t e : pev) (void)hipEventDestroy(e);
+        pev.clear();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -250,17 +284,22 @@ template <typename T> struct PlanT : PlanBase {
             return launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, hs, nullptr));
         };
         const T half = (T)0.5;
+        pn = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
         if (snapshots == nullptr) {
+            if (int rc = prof_mark(-1)) return rc;
             ++last_launches;
             HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[0] * half, nullptr))));
+            if (int rc = prof_mark(0)) return rc;
             for (int64_t s = 0; s < nsteps; ++s) {
                 HIP_TRY(freq(h[s]));
+                if (int rc = prof_mark(1)) return rc;
                 ++last_launches;
                 if (s + 1 < nsteps)
                     HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, targs(gamma, h[s] * half, h[s + 1] * half, nullptr))));
                 else
                     HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr))));
+                if (int rc = prof_mark(0)) return rc;
             }
         } else {
             const size_t fb = sizeof(cx<T>) * n * batch;
@@ -540,5 +579,11 @@ void* ssfm_stream(ssfm_plan* plan) {
 }
 
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches) { WITH_PLAN(plan, last_ms_impl(P_, ms, launches)); }
+
+int ssfm_set_profiling(ssfm_plan* plan, int enabled) { WITH_PLAN(plan, (P_->profiling = enabled != 0, (int)SSFM_OK)); }
+int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]) {
+    if (!counts || !total_ms) return fail(SSFM_ERR_INVALID, "NULL output");
+    WITH_PLAN(plan, P_->kernel_times(counts, total_ms));
+}
 
 }  // extern "C"

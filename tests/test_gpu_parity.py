@@ -1,0 +1,311 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the C ABI, against
+(1) outputs captured from the imported reference (tests/golden/*.npz),
+(2) the oracle on the same seeded inputs at sizes it finishes in seconds,
+(3) size-independent properties at the full 2^20 x 2 benchmark size.
+
+Stated tolerances: complex64, fixed h: max|d|/peak <= 2e-5 up to 100 steps,
+<= 3e-4 at 1000 steps (the reference's own complex64 noise floor against float64 is 5e-6 /
+8e-5); adaptive: the same bound at z = L with the step count within +-1; complex128: <= 1e-10.
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import opticomlib_amd as oa
+from opticomlib_amd import _lib, workloads
+from opticomlib_amd.typing import NULL, gv, optical_signal
+from cases import CASES, case_dt, case_input
+from oracle import ssfm_numpy as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_100 = 2e-5
+TOL_1000 = 3e-4
+TOL_C128 = 1e-10
+
+
+def relmax(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+
+
+def _npts(case):
+    return case["inp"][2][-1]
+
+
+def _signal(case):
+    gv(**case["gv"])
+    sig, noi = case_input(case)
+    return optical_signal(sig) if noi is None else optical_signal(sig, noi)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if _lib.device_count() < 1:
+        pytest.fail("no MI355X visible: the gpu-marked tests must run on the GPU box")
+    yield
+    oa.devices.release_plans()
+
+
+# ----------------------------------------------------------------------- FFT building block
+@pytest.mark.parametrize("k", range(8, 21))
+@pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
+def test_fft_against_numpy(k, prec):
+    n = 1 << k
+    cd = np.complex64 if prec == _lib.C64 else np.complex128
+    rng = np.random.default_rng(k)
+    x = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(cd)
+    p = _lib.Plan(n, 2, prec)
+    try:
+        p.set_field(x)
+        X = p.debug_fft()
+        ref = np.fft.fft(x.astype(np.complex128), axis=-1)
+        err = np.linalg.norm(X - ref) / np.linalg.norm(ref)
+        assert err < (3e-7 if prec == _lib.C64 else 2e-15)
+        p.set_field(x)
+        p.apply_transfer(np.ones(n, dtype=cd))          # ifft(fft(x))
+        y = p.get_field()
+        err2 = np.linalg.norm(y - x) / np.linalg.norm(x)
+        assert err2 < (5e-7 if prec == _lib.C64 else 2e-15)
+    finally:
+        p.close()
+
+
+# ----------------------------------------------------------------------- golden vectors
+POW2 = [n for n, c in CASES.items() if _npts(c) & (_npts(c) - 1) == 0]
+
+
+@pytest.mark.parametrize("name", [n for n in POW2 if CASES[n]["func"] in ("FIBER", "DBP")])
+def test_fiber_dbp_golden(golden_dir, name):
+    case = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    x = _signal(case)
+    fn = oa.FIBER if case["func"] == "FIBER" else oa.DBP
+    kw = dict(case["kw"])
+    nsteps_ref = len(g["z"]) - 1 if "z" in g else 100
+    tol = TOL_1000 if nsteps_ref > 100 else TOL_100
+    if kw.get("return_steps"):
+        z, A_z = fn(x, **kw)
+        assert z.dtype == np.float64 and A_z.dtype == np.complex64
+        assert A_z.shape == g["A_z"].shape
+        np.testing.assert_array_equal(z, g["z"])
+        assert relmax(A_z, g["A_z"]) < tol
+        return
+    y = fn(x, **kw)
+    assert isinstance(y, optical_signal) and y.noise is NULL
+    assert y.signal.dtype == np.complex64 and y.signal.shape == g["out"].shape
+    assert y.n_pol == (2 if g["out"].ndim == 2 else 1)
+    assert y.execution_time > 0
+    assert relmax(y.signal, g["out"]) < tol
+    if "z" in g:
+        z, A_z = fn(x, return_steps=True, **kw)
+        if kw.get("h") is not None:
+            np.testing.assert_array_equal(z, g["z"])            # float32 schedule reproduced exactly
+        else:
+            assert abs(len(z) - len(g["z"])) <= 1                 # adaptive: chaotic in the last bit
+            m = min(len(z), len(g["z"])) - 1
+            np.testing.assert_allclose(z[:m], g["z"][:m], rtol=2e-4)
+        assert relmax(A_z[-1], g["out"]) < tol
+
+
+def test_fiber_then_dbp_golden(golden_dir):
+    case = CASES["fiber_then_dbp"]
+    g = np.load(os.path.join(golden_dir, "fiber_then_dbp.npz"))
+    x = _signal(case)
+    mid = oa.FIBER(x, **case["kw"])
+    out = oa.DBP(mid, **case["kw"])
+    assert relmax(mid.signal, g["mid"]) < TOL_100
+    assert relmax(out.signal, g["out"]) < TOL_100
+    # KAT-3: not the identity -- parity is against the reference's DBP output, not the input
+    assert np.max(np.abs(out.signal - x.signal)) > 1e-3
+
+
+@pytest.mark.parametrize("name", [n for n in POW2 if CASES[n]["func"] == "DM"])
+def test_dm_golden(golden_dir, name):
+    case = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    x = _signal(case)
+    r = oa.DM(x, **case["kw"])
+    if case["kw"].get("retH"):
+        y, H = r
+        np.testing.assert_array_equal(H, g["H"])
+    else:
+        y = r
+    assert y.signal.dtype == np.complex128 and y.n_pol == x.n_pol
+    assert relmax(y.signal, g["out"]) < 1e-13
+    if "out_noise" in g:
+        assert relmax(y.noise, g["out_noise"]) < 1e-13
+    else:
+        assert y.noise is NULL
+
+
+@pytest.mark.parametrize("name", [n for n in POW2 if CASES[n]["func"] == "TWIN"])
+def test_c128_against_reference_twin(golden_dir, name):
+    case = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    x = _signal(case)
+    kw = case["kw"]
+    y = oa.FIBER(x, precision="complex128", **kw)
+    assert y.signal.dtype == np.complex128
+    want = g["A_last"] * np.exp(-(kw["alpha"] / 4.343) * g["z"][-1] / 2)
+    assert relmax(y.signal, want) < TOL_C128
+
+
+def test_non_power_of_two_is_rejected():
+    gv(sps=16, R=10e9)
+    with pytest.raises(ValueError, match="power-of-two"):
+        oa.FIBER(optical_signal(np.ones(3000, complex)), length=1, h=1.0)
+
+
+# ----------------------------------------------------------------------- oracle, seeded inputs
+@pytest.mark.parametrize("k,npol,steps", [(12, 1, 40), (15, 2, 25), (16, 2, 20), (17, 1, 12), (18, 2, 8), (19, 2, 5)])
+def test_fixed_step_against_oracle(k, npol, steps):
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << k, seed=100 + k, n_pol=npol)
+    a = a[0] if npol == 1 else a
+    kw = dict(length=steps * 0.5, h=0.5, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    ref = orc.fiber_c64(a, gv.dt, **kw)
+    assert y.shape == ref.shape
+    assert relmax(y, ref) < TOL_100
+
+
+def test_thousand_steps_against_oracle():
+    """C2's step count (length=125, h=0.125 -> exactly 1000 float32 steps) at 2^13 x 2."""
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 13, seed=2024)
+    kw = dict(length=125, h=0.125, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    ref = orc.fiber_c64(a, gv.dt, **kw)
+    assert relmax(y, ref) < TOL_1000
+
+
+@pytest.mark.parametrize("phi_max", [0.01, 0.05])
+def test_adaptive_against_oracle(phi_max):
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 14, seed=7, power_w=10e-3)
+    kw = dict(length=30, phi_max=phi_max, **workloads.SMF)
+    z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+    zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+    assert abs(len(z) - len(zr)) <= 1
+    assert abs(z[-1] - 30.0) < 1e-4 and np.all(np.diff(z) > 0)
+    assert relmax(A_z[-1], Ar[-1]) < TOL_100 * 5        # a +-1 step-count difference changes the splitting error
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    assert relmax(y, Ar[-1]) < TOL_100 * 5
+
+
+def test_adaptive_gamma_zero_and_no_dispersion_single_step():
+    gv(sps=16, R=10e9)
+    a = workloads.qpsk_field(1 << 12, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for kw in (dict(length=10, alpha=0.2, beta_2=-20.0), dict(length=10, alpha=0.2, gamma=2.0)):
+            z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+            zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+            np.testing.assert_array_equal(z, zr)
+            assert len(z) == 2
+            assert relmax(A_z[-1], Ar[-1]) < TOL_100
+
+
+def test_c128_against_oracle_dual_pol():
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 16, seed=11)
+    kw = dict(length=10, h=1.0, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal
+    ref = orc.fiber_c128(a, gv.dt, **kw)
+    assert relmax(y, ref) < TOL_C128
+    # and the complex64 path sits at the reference's float32 noise floor from it
+    y32 = oa.FIBER(optical_signal(a), **kw).signal
+    assert relmax(y32, ref) < TOL_100
+
+
+def test_c128_adaptive_against_oracle():
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 12, seed=12, power_w=10e-3)
+    kw = dict(length=20, phi_max=0.05, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal
+    ref = orc.fiber_c128(a, gv.dt, **kw)
+    assert relmax(y, ref) < 1e-7          # step sizes agree to rounding; splitting error tracks
+
+
+# ----------------------------------------------------------------------- reference's own tests
+def test_reference_test_FIBER_and_DBP():
+    """tests/devices_test.py:257-277 of the reference, on the HIP path."""
+    gv(sps=16, R=1e9)
+    x = optical_signal(np.full(2048, np.sqrt(10e-3)))           # LASER(P0=10 dBm) CW
+    y = oa.FIBER(x, length=10, alpha=0.2)
+    assert isinstance(y, optical_signal)
+    np.testing.assert_allclose(np.mean(np.abs(y.signal) ** 2), 10e-3 * np.exp(-0.2 / 4.343 * 10), rtol=1e-3)
+    w = oa.DBP(oa.FIBER(x, 10), 10)
+    np.testing.assert_allclose(w.signal, x.signal, atol=1e-5)
+    d = oa.DM(x, 1000.0)
+    assert isinstance(d, optical_signal) and d.size == x.size
+
+
+# ----------------------------------------------------------------------- analytic properties
+def test_pure_spm_closed_form():
+    """beta = 0: one step of the whole length, A exp(-alpha L/2) exp(j gamma |A|^2 L) -- L, not L_eff
+    (devices.py:1156,1177-1181)."""
+    gv(sps=16, R=10e9)
+    a = workloads.qpsk_field(1 << 12, seed=5, power_w=5e-3)
+    L, al, g = 12.0, 0.2, 2.0
+    y = oa.FIBER(optical_signal(a), length=L, alpha=al, gamma=g, precision="complex128").signal
+    want = a * np.exp(-(al / 4.343) * L / 2) * np.exp(1j * g * np.abs(a) ** 2 * L)
+    assert relmax(y, want) < 1e-12
+
+
+def test_linear_fiber_equals_DM():
+    """FIBER(gamma=0, alpha=0, beta_2) == DM(D = beta_2 L)."""
+    gv(sps=16, R=10e9)
+    a = workloads.qpsk_field(1 << 13, seed=6)
+    y = oa.FIBER(optical_signal(a), length=40, beta_2=-20.0, precision="complex128").signal
+    d = oa.DM(optical_signal(a), D=-20.0 * 40).signal
+    assert relmax(y, d) < 1e-11
+
+
+# ----------------------------------------------------------------------- full benchmark size
+def _bench_field():
+    gv(**workloads.BENCH_GV)
+    return workloads.qpsk_field(1 << 20, seed=2024)
+
+
+def test_full_size_against_oracle_few_steps():
+    """2^20 x 2 complex64, C2's step size, 6 steps (the oracle needs ~1 s per step)."""
+    a = _bench_field()
+    kw = dict(length=6 * 0.125, h=0.125, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    ref = orc.fiber_c64(a, gv.dt, **kw)
+    assert relmax(y, ref) < TOL_100
+
+
+def test_full_size_properties_1000_steps():
+    """C2 in full (2^20 x 2, 1000 steps): energy follows exp(-alpha L) (the nonlinear and the
+    dispersive operators are unitary), polarisations stay independent, and the result agrees
+    with the complex128 run."""
+    a = _bench_field()
+    kw = dict(length=125, h=0.125, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    e_in = np.sum(np.abs(a) ** 2, axis=-1)
+    e_out = np.sum(np.abs(y.astype(np.complex128)) ** 2, axis=-1)
+    # per step the amplitude is multiplied by the float32 value of exp(-alpha/2 h) (devices.py:1179)
+    att = np.exp(np.complex64(-np.float32(0.2 / 4.343) / 2) * np.float32(0.125)).real
+    np.testing.assert_allclose(e_out / e_in, float(att) ** 2000, rtol=1e-4)
+    y0 = oa.FIBER(optical_signal(a[0]), **kw).signal                     # one polarisation alone
+    np.testing.assert_array_equal(y0, y[0])
+    y128 = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal
+    assert relmax(y, y128) < TOL_1000
+
+
+def test_full_size_c128_100_steps_roundtrip_structure():
+    """C1 (2^20 x 2, complex128, 100 x 1 km): FIBER then DBP returns the input up to the known
+    stale-N^ asymmetry, and linear-only propagation is exactly invertible."""
+    a = _bench_field()
+    lin = dict(length=100, h=1.0, alpha=0.2, beta_2=-21.7, beta_3=0.13)
+    y = oa.FIBER(optical_signal(a), precision="complex128", **lin)
+    back = oa.DBP(y, precision="complex128", **lin).signal
+    assert relmax(back, a) < 1e-10
+    kw = dict(length=100, h=1.0, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), precision="complex128", **kw)
+    back = oa.DBP(y, precision="complex128", **kw).signal
+    assert 1e-7 < relmax(back, a) < 5e-2

@@ -1,0 +1,148 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/ssfm_amd.h declares, the
+host-side mirror (types, coefficients, step schedule, error behaviour) matches the reference /
+the oracle.  No compute call is made here (there is no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import opticomlib_amd as oa
+from opticomlib_amd import _lib, devices
+from opticomlib_amd.typing import NULL, gv, optical_signal
+from oracle import ssfm_numpy as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ssfm_amd.h")).read()
+    declared = set(re.findall(r"\b(ssfm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ssfm_plan"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ssfm_abi_version() == 1
+    assert _lib.supported_log2n(_lib.C64) == (8, 20)
+
+
+def test_no_cpu_fallback_without_device():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(oa.SsfmError):
+        oa.Plan(4096, 2)
+    gv(sps=16, R=10e9)
+    with pytest.raises(oa.SsfmError):
+        oa.FIBER(optical_signal(np.ones(4096, complex)), length=1, h=1.0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "opticomlib_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src or f == "_never_", f"{f} mentions the oracle"
+
+
+def test_type_errors_match_reference():
+    # reference devices.py:1121-1122, 1021-1022: checked before anything touches the GPU
+    for fn, kw in ((oa.FIBER, dict(length=1)), (oa.DBP, dict(length=1)), (oa.DM, dict(D=1.0))):
+        with pytest.raises(TypeError, match="`input` must be of type 'optical_signal'."):
+            fn(np.ones(16), **kw)
+
+
+def test_unsupported_size_raises_value_error():
+    if _lib.device_count() == 0:
+        # size is validated against the library's range before a plan is created
+        x = optical_signal(np.ones(3000, complex))
+        with pytest.raises(ValueError, match="power-of-two"):
+            oa.FIBER(x, length=1, h=1.0)
+        with pytest.raises(ValueError, match="power-of-two"):
+            oa.FIBER(optical_signal(np.ones(128, complex)), length=1, h=1.0)
+
+
+def test_bad_step_rejected():
+    with pytest.raises(ValueError):
+        devices.step_schedule(10, 0.0)
+    with pytest.raises(ValueError):
+        devices.step_schedule(10, -1.0)
+
+
+@pytest.mark.parametrize("length,h", [(100, 0.1), (125, 0.125), (1000, 1.0), (2, 0.3), (10, 1.0), (5, 7.0), (0, 1.0), (-3, 1.0)])
+def test_step_schedule_matches_oracle(length, h):
+    hs, z = devices.step_schedule(length, h)
+    want = orc.step_schedule_c64(length, h)
+    assert hs.dtype == np.float32 and np.array_equal(hs, want)
+    assert len(z) == len(hs) + 1 and z[0] == 0
+    if len(hs):
+        assert z[-1] >= np.float32(length)
+
+
+@pytest.mark.parametrize("n,dt", [(4096, 6.25e-12), (1 << 14, 1.953125e-12), (3000, 6.25e-12)])
+def test_linear_operator_bit_exact_with_oracle(n, dt):
+    kw = dict(alpha=0.2, beta_2=-21.7, beta_3=0.13)
+    d = devices.linear_operator(n, dt, precision=_lib.C64, **kw)
+    assert d.dtype == np.complex64
+    assert np.array_equal(d, orc.linear_operator_c64(n, dt, **kw))
+    d2 = devices.linear_operator(n, dt, precision=_lib.C128, **kw)
+    assert np.array_equal(d2, orc.linear_operator_c128(n, dt, **kw))
+
+
+class TestOpticalSignal:
+    """shape -> n_pol table of reference tests/typing_test.py:766-811 and :1244-1251."""
+
+    def test_errors(self):
+        with pytest.raises(TypeError):
+            optical_signal()
+        with pytest.raises(ValueError):
+            optical_signal([0, 1, 2], [0, 1, 2, 3])
+        with pytest.raises(ValueError):
+            optical_signal([[1, 2, 3], [5, 6, 7], [8, 9, 10]])
+        with pytest.raises(ValueError):
+            optical_signal([[[1, 2, 3]]])
+        with pytest.raises(ValueError):
+            optical_signal([1, 2, 3], n_pol=3)
+
+    @pytest.mark.parametrize("mk", [list, tuple, np.array])
+    def test_one_pol(self, mk):
+        x = optical_signal(mk(range(6)), mk([-i for i in range(6)]), n_pol=1)
+        assert np.array_equal(x.signal, np.arange(6)) and np.array_equal(x.noise, -np.arange(6))
+        assert x.n_pol == 1 and x.size == 6 and x.execution_time == 0
+        y = optical_signal(mk(range(6)))
+        assert y.noise is NULL and y.n_pol == 1 and y.size == 6
+
+    def test_two_pol_forms(self):
+        base = np.arange(6)
+        for sig in (base, base[None, :], np.tile(base, (2, 1))):
+            x = optical_signal(sig, -sig, n_pol=2)
+            assert np.array_equal(x.signal, np.tile(base, (2, 1)))
+            assert np.array_equal(x.noise, -np.tile(base, (2, 1)))
+            assert x.n_pol == 2 and x.size == 6 and len(x) == 6
+        # (1, N) silently becomes dual-pol (typing.py:2176-2181); (2, N) with n_pol=1 keeps row 0
+        assert optical_signal(base[None, :]).n_pol == 2
+        assert optical_signal(np.tile(base, (2, 1)), n_pol=1).signal.shape == (6,)
+        s = optical_signal(3.0, n_pol=2)
+        assert s.signal.shape == (2, 1)
+
+    def test_w_and_to_numpy(self):
+        gv(sps=8, R=2e9)
+        for sig in (np.ones(64), np.ones((2, 64))):
+            x = optical_signal(sig)
+            assert np.array_equal(x.w(), 2 * np.pi * np.fft.fftfreq(64) * gv.fs) or np.allclose(x.w(), 2 * np.pi * np.fft.fftfreq(64) * gv.fs, rtol=1e-15)
+            assert np.allclose(x.w(shift=True), np.fft.fftshift(x.w()))
+            assert np.array_equal(x.w(), orc.angular_frequency(64, gv.dt))
+        x = optical_signal(np.ones(8), 2 * np.ones(8))
+        assert np.array_equal(x.to_numpy(), 3 * np.ones(8))
+        assert np.array_equal(optical_signal(np.ones(8)).to_numpy(), np.ones(8))
+        gv.default()
+        assert gv.dt == 1 / 16e9
+
+    def test_gv_precedence(self):
+        gv(sps=16, R=10e9)
+        assert gv.fs == 16 * 10e9 and gv.dt == 1 / (16 * 10e9)
+        gv(R=1e9, fs=32e9)
+        assert gv.sps == 32
+        gv(fs=8e9)
+        assert gv.R == 1e9 and gv.sps == 8
+        gv.default()
