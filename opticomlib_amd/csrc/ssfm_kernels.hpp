@@ -45,8 +45,83 @@ template <typename T> struct TimeArgs {
     int N2;
 };
 
+// sin/cos of the nonlinear phase.  float: Cody-Waite reduction by pi/2 (three fma terms whose sum
+// is pi/2 to double precision) + the fdlibm float kernels; absolute error < 9e-8 for |x| <= 65000
+// (0.5 ulp for the small phases an SSFM step produces).  Larger arguments are reduced in double
+// (good to |x| ~ 1e14; beyond that one float ulp spans many turns and the phase carries no
+// information, but the result is still a unit rotation).  The callers test once per thread whether
+// any of its 16 phases needs the slow reduction, so the common path has no branches.
+__device__ __forceinline__ void sincos_reduced(float r, int q, float& s, float& c) {
+    const float z = r * r;
+    float ps = fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f);
+    ps = fmaf(z, ps, 8.3333293858894631756e-3f);
+    ps = fmaf(z, ps, -1.66666666416265235595e-1f);
+    const float sr = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f);
+    pc = fmaf(z, pc, 4.16666233237390631894e-2f);
+    pc = fmaf(z, pc, -4.99999997251031003120e-1f);
+    const float cr = fmaf(z, pc, 1.0f);
+    const float a = (q & 1) ? cr : sr;
+    const float b = (q & 1) ? sr : cr;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+constexpr float kSincosSmallMax = 65000.0f;
+template <bool BIG> __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+    float r;
+    int q;
+    if (!BIG) {
+        const float k = rintf(x * 0.6366197723675814f);
+        r = fmaf(k, -1.570770263671875f, x);
+        r = fmaf(k, -2.6063062250614166e-05f, r);
+        r = fmaf(k, -6.077094383272197e-11f, r);
+        q = (int)k;
+    } else {
+        const double xd = (double)x;
+        const double kd = rint(xd * 0.63661977236758134308);
+        double rd = fma(kd, -1.57079632679489655800e+00, xd);
+        rd = fma(kd, -6.12323399573676603587e-17, rd);
+        r = (float)rd;
+        q = (int)((long long)kd & 3);
+    }
+    sincos_reduced(r, q, s, c);
+    if (BIG && !(fabsf(x) < __builtin_inff())) s = c = __builtin_nanf("");
+}
+// rotate 16 values by their phases
+__device__ __forceinline__ void rotate16(float2 (&v)[16], const float (&phi)[16]) {
+    bool big = false;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) big = big || !(fabsf(phi[t]) <= kSincosSmallMax);
+    if (__builtin_expect(big, 0)) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float s, c;
+            sincos_f32<true>(phi[t], s, c);
+            v[t] = cmul(v[t], make_float2(c, s));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float s, c;
+            sincos_f32<false>(phi[t], s, c);
+            v[t] = cmul(v[t], make_float2(c, s));
+        }
+    }
+}
+__device__ __forceinline__ void rotate16(double2 (&v)[16], const double (&phi)[16]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        double s, c;
+        sincos(phi[t], &s, &c);
+        v[t] = cmul(v[t], make_double2(c, s));
+    }
+}
+// scalar form (on-the-fly linear operator of the adaptive mode)
 template <typename T> __device__ __forceinline__ void sincos_acc(T x, T& s, T& c);
-template <> __device__ __forceinline__ void sincos_acc<float>(float x, float& s, float& c) { sincosf(x, &s, &c); }
+template <> __device__ __forceinline__ void sincos_acc<float>(float x, float& s, float& c) {
+    if (__builtin_expect(fabsf(x) <= kSincosSmallMax, 1)) sincos_f32<false>(x, s, c);
+    else sincos_f32<true>(x, s, c);
+}
 template <> __device__ __forceinline__ void sincos_acc<double>(double x, double& s, double& c) { sincos(x, &s, &c); }
 
 template <int C> struct ColIdx {
@@ -65,7 +140,7 @@ template <> __device__ __forceinline__ unsigned long long float_bits<double>(dou
 
 // ------------------------------------------------------------------------------ k_time
 template <typename T, int N1, int C, int MODE>
-__global__ __launch_bounds__(N1 * C / 16) void k_time(const TimeArgs<T> a) {
+__global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 ? 2 : 1)) void k_time(const TimeArgs<T> a) {
     constexpr int Q = N1 / 16;                     // threads per column
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -79,64 +154,71 @@ __global__ __launch_bounds__(N1 * C / 16) void k_time(const TimeArgs<T> a) {
     const int c = tid % C;
     const int j = tid / C;
     const long long N = (long long)N1 * a.N2;
-    const long long rowbase = (long long)blockIdx.y * N + (long long)blockIdx.x * C + c;
-    const long long twbase = (long long)blockIdx.x * C + c;
+    // wave-uniform bases (SGPRs) + one 32-bit lane offset
+    cx<T>* __restrict__ Fb = a.F + (long long)blockIdx.y * N + (long long)blockIdx.x * C;
+    T* __restrict__ Pb = a.P + (long long)blockIdx.y * N + (long long)blockIdx.x * C;
+    const cx<T>* __restrict__ Wb = a.twN + (long long)blockIdx.x * C;
+    const int off = j * a.N2 + c;
+    const int stride = Q * a.N2;
     const ColIdx<C> idx{c};
 
+    // issue every global load of the tile up front
     cx<T> v[16];
     cx<T> w[16];
+    T pold[16];
+    LineTw<T, N1> tw;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = a.F[rowbase + (long long)(j + t * Q) * a.N2];
+    for (int t = 0; t < 16; ++t) v[t] = Fb[off + t * stride];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) w[t] = a.twN[twbase + (long long)(j + t * Q) * a.N2];
+    for (int t = 0; t < 16; ++t) w[t] = Wb[off + t * stride];
+    if (MODE != TM_BEGIN) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pold[t] = Pb[off + t * stride];
+    }
+    load_line_twiddles<T, N1>(tw, j, a.tw1);
 
     if (MODE != TM_BEGIN) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = cmulc(v[t], w[t]);
-        fft_line<T, N1, +1, ColIdx<C>>(v, lds, j, idx, a.tw1);
-        // second half of the step being finished, with the |A|^2 of its START (devices.py:1181)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const T p = a.P[rowbase + (long long)(j + t * Q) * a.N2];
-            const T phi = hh_prev * (a.gamma * p);
-            T s, co;
-            sincos_acc<T>(phi, s, co);
-            v[t] = cmul(v[t], mk<T>(co, s));
-        }
+        fft_line<T, N1, +1, ColIdx<C>>(v, lds, j, idx, tw);
     }
-    if (MODE == TM_END) {
-        T pmax = (T)0;
+    // v = time-domain samples A(n1, n2).  Nonlinear operator (reference devices.py:1175-1181):
+    // the second half step of the step being finished uses the |A|^2 of its START (pold), the
+    // first half step of the next one the |A|^2 of the field after that rotation -- a rotation
+    // does not change |A|, so both phases are known here and are applied as ONE rotation.
+    T pmax = (T)0;
+    T phi[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            a.F[rowbase + (long long)(j + t * Q) * a.N2] = v[t];
-            const T p = v[t].x * v[t].x + v[t].y * v[t].y;
-            pmax = p > pmax ? p : pmax;
+    for (int t = 0; t < 16; ++t) {
+        const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+        T ph = (T)0;
+        if (MODE != TM_BEGIN) ph = hh_prev * (a.gamma * pold[t]);
+        if (MODE != TM_END) {
+            Pb[off + t * stride] = p;
+            ph += hh_next * (a.gamma * p);
         }
+        phi[t] = ph;
+        pmax = p > pmax ? p : pmax;
+    }
+    rotate16(v, phi);
+    if (MODE == TM_END) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Fb[off + t * stride] = v[t];
         if (a.st != nullptr && a.st->adaptive) {
             // wave-level max, then one atomic per wave
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const T o = __shfl_xor(pmax, off);
-                pmax = o > pmax ? o : pmax;
+            for (int o = 32; o > 0; o >>= 1) {
+                const T other = __shfl_xor(pmax, o);
+                pmax = other > pmax ? other : pmax;
             }
             if ((tid & 63) == 0) atomicMax(&a.st->maxbits, float_bits<T>(pmax));
         }
         return;
     }
-    // first half of the step being started (devices.py:1175,1177)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const T p = v[t].x * v[t].x + v[t].y * v[t].y;
-        a.P[rowbase + (long long)(j + t * Q) * a.N2] = p;
-        const T phi = hh_next * (a.gamma * p);
-        T s, co;
-        sincos_acc<T>(phi, s, co);
-        v[t] = cmul(v[t], mk<T>(co, s));
-    }
     if (MODE == TM_MID && fft_nstages(N1) > 1) __syncthreads();   // inverse transform's LDS reads are done
-    fft_line<T, N1, -1, ColIdx<C>>(v, lds, j, idx, a.tw1);
+    fft_line<T, N1, -1, ColIdx<C>>(v, lds, j, idx, tw);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) a.F[rowbase + (long long)(j + t * Q) * a.N2] = cmul(v[t], w[t]);
+    for (int t = 0; t < 16; ++t) Fb[off + t * stride] = cmul(v[t], w[t]);
 }
 
 // ------------------------------------------------------------------------------ k_freq
@@ -157,7 +239,7 @@ template <> __device__ __forceinline__ float exp_acc<float>(float x) { return ex
 template <> __device__ __forceinline__ double exp_acc<double>(double x) { return exp(x); }
 
 template <typename T, int N2, int ROWS, int MODE>
-__global__ __launch_bounds__(ROWS * N2 / 16) void k_freq(const FreqArgs<T> a) {
+__global__ __launch_bounds__(ROWS * N2 / 16, (ROWS * N2 / 16 >= 256 && sizeof(T) == 4 ? 2 : 1)) void k_freq(const FreqArgs<T> a) {
     constexpr int Q = N2 / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -172,14 +254,21 @@ __global__ __launch_bounds__(ROWS * N2 / 16) void k_freq(const FreqArgs<T> a) {
     const int rr = tid / Q;
     const long long row = (long long)blockIdx.x * ROWS + rr;     // over batch*N1 rows
     const int k1 = (int)(row % a.N1);
-    cx<T>* Frow = a.F + row * N2;
-    const cx<T>* trow = a.tab + (long long)k1 * N2;
+    cx<T>* __restrict__ Frow = a.F + row * N2;
+    const cx<T>* __restrict__ trow = a.tab + (long long)k1 * N2;
     const RowIdx idx{rr * row_lds_elems(N2)};
 
     cx<T> v[16];
+    cx<T> m[16];
+    LineTw<T, N2> tw;
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = Frow[j + t * Q];
-    fft_line<T, N2, -1, RowIdx>(v, lds, j, idx, a.tw2);
+    load_line_twiddles<T, N2>(tw, j, a.tw2);
+    if (MODE != FM_FWD_ONLY) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) m[t] = trow[j + t * Q];
+    }
+    fft_line<T, N2, -1, RowIdx>(v, lds, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
@@ -187,18 +276,18 @@ __global__ __launch_bounds__(ROWS * N2 / 16) void k_freq(const FreqArgs<T> a) {
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        cx<T> m = trow[j + t * Q];
+        cx<T> mm = m[t];
         if (MODE == FM_FLY) {
             // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
-            const T e = exp_acc<T>(m.x * h);
+            const T e = exp_acc<T>(mm.x * h);
             T s, co;
-            sincos_acc<T>(m.y * h, s, co);
-            m = mk<T>((e * co) * a.inv_n, (e * s) * a.inv_n);
+            sincos_acc<T>(mm.y * h, s, co);
+            mm = mk<T>((e * co) * a.inv_n, (e * s) * a.inv_n);
         }
-        v[t] = cmul(v[t], m);
+        v[t] = cmul(v[t], mm);
     }
     if (fft_nstages(N2) > 1) __syncthreads();
-    fft_line<T, N2, +1, RowIdx>(v, lds, j, idx, a.tw2);
+    fft_line<T, N2, +1, RowIdx>(v, lds, j, idx, tw);
 #pragma unroll
     for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
 }

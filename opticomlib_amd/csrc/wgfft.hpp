@@ -162,18 +162,44 @@ __host__ __device__ constexpr int fft_ls(int L, int s) {   // product of radices
     return s == 0 ? 1 : fft_ls(L, s - 1) * fft_radix(L, s - 1);
 }
 
+// Stage twiddles of one thread, loaded once per kernel and kept in registers: they depend only on
+// the thread's position in the line, and the forward and the inverse transform share them.
+template <typename T, int L> struct LineTw {
+    static constexpr int M = fft_nstages(L);
+    cx<T> w[M > 1 ? M - 1 : 1][15];
+};
+template <typename T, int L, int S>
+__device__ __forceinline__ void load_stage_twiddles(LineTw<T, L>& tw, const int j, const cx<T>* __restrict__ tab) {
+    constexpr int R  = fft_radix(L, S);
+    constexpr int NB = 16 / R;
+    constexpr int Q  = L / 16;
+    constexpr int LS = fft_ls(L, S);
+    constexpr int STEP = L / (LS * R);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int k = (j + i * Q) & (LS - 1);
+#pragma unroll
+        for (int u = 1; u < R; ++u) tw.w[S - 1][i * (R - 1) + (u - 1)] = tab[k * u * STEP];
+    }
+}
+template <typename T, int L>
+__device__ __forceinline__ void load_line_twiddles(LineTw<T, L>& tw, const int j, const cx<T>* __restrict__ tab) {
+    constexpr int M = fft_nstages(L);
+    if constexpr (M > 1) load_stage_twiddles<T, L, 1>(tw, j, tab);
+    if constexpr (M > 2) load_stage_twiddles<T, L, 2>(tw, j, tab);
+}
+
 // One Stockham stage.  IDX maps a line element index to an LDS element index.
 template <typename T, int L, int DIR, int S, typename IDX>
 __device__ __forceinline__ void fft_stage(cx<T> (&v)[16], cx<T>* lds, const int j, const IDX& idx,
-                                          const cx<T>* __restrict__ tw) {
+                                          const LineTw<T, L>& tw) {
     constexpr int M  = fft_nstages(L);
     constexpr int R  = fft_radix(L, S);
     constexpr int NB = 16 / R;          // butterflies per thread
     constexpr int Q  = L / 16;          // threads per line
     constexpr int LS = fft_ls(L, S);
-    constexpr int STEP = L / (LS * R);  // table stride of this stage's twiddles
 
-    if (S > 0) {
+    if constexpr (S > 0) {
         // all reads of the previous exchange happen here; writers finished before the barrier
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -183,9 +209,9 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[16], cx<T>* lds, const int 
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int k = (j + i * Q) & (LS - 1);
 #pragma unroll
-            for (int u = 1; u < R; ++u) v[i + u * NB] = cmuld<DIR>(v[i + u * NB], tw[k * u * STEP]);
+            for (int u = 1; u < R; ++u)
+                v[i + u * NB] = cmuld<DIR>(v[i + u * NB], tw.w[S - 1][i * (R - 1) + (u - 1)]);
         }
     }
 #pragma unroll
@@ -197,8 +223,8 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[16], cx<T>* lds, const int 
 #pragma unroll
         for (int u = 0; u < R; ++u) v[i + u * NB] = tmp[u];
     }
-    if (S < M - 1) {
-        if (S > 0) __syncthreads();     // every thread has read its inputs of this stage
+    if constexpr (S < M - 1) {
+        if constexpr (S > 0) __syncthreads();     // every thread has read its inputs of this stage
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int jb = j + i * Q;
@@ -215,11 +241,11 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[16], cx<T>* lds, const int 
 // earlier exchange when this is entered (i.e. there was a barrier since).
 template <typename T, int L, int DIR, typename IDX>
 __device__ __forceinline__ void fft_line(cx<T> (&v)[16], cx<T>* lds, const int j, const IDX& idx,
-                                         const cx<T>* __restrict__ tw) {
+                                         const LineTw<T, L>& tw) {
     constexpr int M = fft_nstages(L);
     fft_stage<T, L, DIR, 0, IDX>(v, lds, j, idx, tw);
-    if (M > 1) fft_stage<T, L, DIR, (M > 1 ? 1 : 0), IDX>(v, lds, j, idx, tw);
-    if (M > 2) fft_stage<T, L, DIR, (M > 2 ? 2 : 0), IDX>(v, lds, j, idx, tw);
+    if constexpr (M > 1) fft_stage<T, L, DIR, 1, IDX>(v, lds, j, idx, tw);
+    if constexpr (M > 2) fft_stage<T, L, DIR, 2, IDX>(v, lds, j, idx, tw);
 }
 
 }  // namespace ssfm
