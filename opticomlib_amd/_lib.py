@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_ssfm_amd.so")
+LIB_PATH = os.environ.get("SSFM_LIB") or os.path.join(_HERE, "_ssfm_amd.so")   # SSFM_LIB: dev override
 
 C64, C128 = 0, 1
 _CDTYPE = {C64: np.complex64, C128: np.complex128}

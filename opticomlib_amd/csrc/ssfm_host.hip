@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -124,6 +125,14 @@ template <typename T> struct PlanT : PlanBase {
     bool timed = false;
     int64_t last_launches = 0;
     bool profiling = false;
+    // "lanes": rows are independent (they only share the adaptive step size), so a fixed-step run
+    // drives disjoint row groups on separate streams; kernels of different groups overlap, which
+    // hides launch gaps and lets one group compute while another waits for memory.
+    static constexpr int kMaxLanes = 8;
+    int nlanes = 1;
+    hipStream_t lane_stream[kMaxLanes] = {};
+    hipEvent_t lane_ev[kMaxLanes] = {};
+    hipEvent_t fork_ev = nullptr;
     std::vector<hipEvent_t> pev;       // pool of per-launch events
     std::vector<unsigned char> pcls;   // class of the launch that precedes event i+1
     size_t pn = 0;                     // events recorded by the last propagate
@@ -163,6 +172,11 @@ template <typename T> struct PlanT : PlanBase {
         void* bufs[] = {F, P, twN, tw1, tw2, dnat, dperm, scratch, st, zlog};
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
+        for (int g = 1; g < kMaxLanes; ++g) {
+            if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
+            if (lane_stream[g]) (void)hipStreamDestroy(lane_stream[g]);
+        }
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
         for (hipEvent_t e : pev) (void)hipEventDestroy(e);
         pev.clear();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -183,6 +197,17 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
+        int want = 2;
+        if (const char* e = std::getenv("SSFM_LANES")) want = std::atoi(e);
+        nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
+        if (nlanes > batch) nlanes = batch;
+        while (batch % nlanes) --nlanes;
+        lane_stream[0] = stream;
+        HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        for (int g = 1; g < nlanes; ++g) {
+            HIP_TRY(hipStreamCreateWithFlags(&lane_stream[g], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&lane_ev[g], hipEventDisableTiming));
+        }
         const size_t cb = sizeof(cx<T>);
         HIP_TRY(hipMalloc(&F, cb * n * batch));
         HIP_TRY(hipMalloc(&P, sizeof(T) * n * batch));
@@ -232,15 +257,15 @@ template <typename T> struct PlanT : PlanBase {
     }
     const cx<T>* dperm_natural() const { return dnat; }
 
-    TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s) const {
+    TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s, int row0 = 0) const {
         TimeArgs<T> a;
-        a.F = F; a.P = P; a.twN = twN; a.tw1 = tw1; a.st = s; a.gamma = gamma;
+        a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.tw1 = tw1; a.st = s; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2;
         return a;
     }
-    FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s) const {
+    FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0) const {
         FreqArgs<T> a;
-        a.F = F; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1;
+        a.F = F + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1;
         return a;
     }
 
@@ -273,20 +298,44 @@ template <typename T> struct PlanT : PlanBase {
         if (use_tables)
             for (size_t i = 0; i < distinct.size(); ++i)
                 if (int rc = table_for(distinct[i], &tabptr[i])) return rc;
-        auto freq = [&](T hs) -> hipError_t {
+        auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
             ++last_launches;
             if (use_tables) {
                 const cx<T>* tp = nullptr;
                 for (size_t i = 0; i < distinct.size(); ++i)
                     if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
-                return launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(tp, hs, nullptr));
+                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0));
             }
-            return launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, hs, nullptr));
+            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0));
         };
+        auto freq = [&](T hs) -> hipError_t { return freq_rows(hs, 0, batch, stream); };
+        (void)nrows;
         const T half = (T)0.5;
         pn = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
-        if (snapshots == nullptr) {
+        if (snapshots == nullptr && !profiling && nlanes > 1) {
+            const int rows = batch / nlanes;
+            HIP_TRY(hipEventRecord(fork_ev, stream));
+            for (int g = 1; g < nlanes; ++g) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
+            for (int g = 0; g < nlanes; ++g) {
+                ++last_launches;
+                HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows))));
+            }
+            for (int64_t s = 0; s < nsteps; ++s) {
+                for (int g = 0; g < nlanes; ++g) HIP_TRY(freq_rows(h[s], g * rows, rows, lane_stream[g]));
+                for (int g = 0; g < nlanes; ++g) {
+                    ++last_launches;
+                    if (s + 1 < nsteps)
+                        HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows))));
+                    else
+                        HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows))));
+                }
+            }
+            for (int g = 1; g < nlanes; ++g) {
+                HIP_TRY(hipEventRecord(lane_ev[g], lane_stream[g]));
+                HIP_TRY(hipStreamWaitEvent(stream, lane_ev[g], 0));
+            }
+        } else if (snapshots == nullptr) {
             if (int rc = prof_mark(-1)) return rc;
             ++last_launches;
             HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[0] * half, nullptr))));

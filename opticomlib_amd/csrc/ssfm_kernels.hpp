@@ -15,6 +15,23 @@
 #pragma once
 #include "wgfft.hpp"
 
+// Timing-only ablation knobs for tools/ablate.sh (results are WRONG when any is set).
+#ifndef SSFM_ABL_NO_TWN
+#define SSFM_ABL_NO_TWN 0
+#endif
+#ifndef SSFM_ABL_NO_P
+#define SSFM_ABL_NO_P 0
+#endif
+#ifndef SSFM_ABL_NO_TAB
+#define SSFM_ABL_NO_TAB 0
+#endif
+#ifndef SSFM_ABL_NO_FFT
+#define SSFM_ABL_NO_FFT 0
+#endif
+#ifndef SSFM_ABL_NO_NL
+#define SSFM_ABL_NO_NL 0
+#endif
+
 namespace ssfm {
 
 enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2 };
@@ -88,7 +105,7 @@ template <bool BIG> __device__ __forceinline__ void sincos_f32(float x, float& s
     if (BIG && !(fabsf(x) < __builtin_inff())) s = c = __builtin_nanf("");
 }
 // rotate 16 values by their phases
-__device__ __forceinline__ void rotate16(float2 (&v)[16], const float (&phi)[16]) {
+__device__ __forceinline__ void rotate16(cf32 (&v)[16], const float (&phi)[16]) {
     bool big = false;
 #pragma unroll
     for (int t = 0; t < 16; ++t) big = big || !(fabsf(phi[t]) <= kSincosSmallMax);
@@ -97,23 +114,23 @@ __device__ __forceinline__ void rotate16(float2 (&v)[16], const float (&phi)[16]
         for (int t = 0; t < 16; ++t) {
             float s, c;
             sincos_f32<true>(phi[t], s, c);
-            v[t] = cmul(v[t], make_float2(c, s));
+            v[t] = cmul(v[t], mk<float>(c, s));
         }
     } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             float s, c;
             sincos_f32<false>(phi[t], s, c);
-            v[t] = cmul(v[t], make_float2(c, s));
+            v[t] = cmul(v[t], mk<float>(c, s));
         }
     }
 }
-__device__ __forceinline__ void rotate16(double2 (&v)[16], const double (&phi)[16]) {
+__device__ __forceinline__ void rotate16(cf64 (&v)[16], const double (&phi)[16]) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         double s, c;
         sincos(phi[t], &s, &c);
-        v[t] = cmul(v[t], make_double2(c, s));
+        v[t] = cmul(v[t], mk<double>(c, s));
     }
 }
 // scalar form (on-the-fly linear operator of the adaptive mode)
@@ -170,17 +187,17 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = Fb[off + t * stride];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) w[t] = Wb[off + t * stride];
+    for (int t = 0; t < 16; ++t) w[t] = SSFM_ABL_NO_TWN ? mk<T>((T)1, (T)0) : Wb[off + t * stride];
     if (MODE != TM_BEGIN) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pold[t] = Pb[off + t * stride];
+        for (int t = 0; t < 16; ++t) pold[t] = SSFM_ABL_NO_P ? (T)1e-3 : Pb[off + t * stride];
     }
     load_line_twiddles<T, N1>(tw, j, a.tw1);
 
     if (MODE != TM_BEGIN) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = cmulc(v[t], w[t]);
-        fft_line<T, N1, +1, ColIdx<C>>(v, lds, j, idx, tw);
+        if (!SSFM_ABL_NO_FFT) fft_line<T, N1, +1, ColIdx<C>>(v, lds, j, idx, tw);
     }
     // v = time-domain samples A(n1, n2).  Nonlinear operator (reference devices.py:1175-1181):
     // the second half step of the step being finished uses the |A|^2 of its START (pold), the
@@ -194,13 +211,17 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
         T ph = (T)0;
         if (MODE != TM_BEGIN) ph = hh_prev * (a.gamma * pold[t]);
         if (MODE != TM_END) {
-            Pb[off + t * stride] = p;
+            if (!SSFM_ABL_NO_P) Pb[off + t * stride] = p;
             ph += hh_next * (a.gamma * p);
         }
         phi[t] = ph;
         pmax = p > pmax ? p : pmax;
     }
-    rotate16(v, phi);
+    if (!SSFM_ABL_NO_NL) rotate16(v, phi);
+    else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t].x += phi[t];
+    }
     if (MODE == TM_END) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) Fb[off + t * stride] = v[t];
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
         return;
     }
     if (MODE == TM_MID && fft_nstages(N1) > 1) __syncthreads();   // inverse transform's LDS reads are done
-    fft_line<T, N1, -1, ColIdx<C>>(v, lds, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N1, -1, ColIdx<C>>(v, lds, j, idx, tw);
 #pragma unroll
     for (int t = 0; t < 16; ++t) Fb[off + t * stride] = cmul(v[t], w[t]);
 }
@@ -266,9 +287,9 @@ __global__ __launch_bounds__(ROWS * N2 / 16, (ROWS * N2 / 16 >= 256 && sizeof(T)
     load_line_twiddles<T, N2>(tw, j, a.tw2);
     if (MODE != FM_FWD_ONLY) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) m[t] = trow[j + t * Q];
+        for (int t = 0; t < 16; ++t) m[t] = SSFM_ABL_NO_TAB ? mk<T>(a.inv_n, (T)0) : trow[j + t * Q];
     }
-    fft_line<T, N2, -1, RowIdx>(v, lds, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, -1, RowIdx>(v, lds, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(ROWS * N2 / 16, (ROWS * N2 / 16 >= 256 && sizeof(T)
         v[t] = cmul(v[t], mm);
     }
     if (fft_nstages(N2) > 1) __syncthreads();
-    fft_line<T, N2, +1, RowIdx>(v, lds, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, +1, RowIdx>(v, lds, j, idx, tw);
 #pragma unroll
     for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
 }

@@ -9,47 +9,97 @@
 // The transform is a Stockham autosort: 1..3 radix-{16,8,4} stages.  The first stage works
 // straight out of registers, every later stage after one exchange through LDS, and the
 // last stage leaves its results in registers.  Stage twiddles W_L^q come from one table of
-// L entries per line length (generated in double, rounded once).
+// L entries per line length (generated in double, rounded once) and are kept in registers.
+//
+// complex64 arithmetic is written directly in CDNA packed-FP32 instructions: one complex
+// number is one 64-bit VGPR pair (re, im); v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with
+// op_sel (half swizzle) and neg_lo/neg_hi modifiers give a complex add or a +-i rotation folded
+// into an add in ONE instruction and a complex multiply in TWO, with no register shuffling.
+// (hipcc's own SLP packing of scalar code needs ~25 % extra v_mov and folds no half negation.)
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace ssfm {
 
+typedef float  cf32 __attribute__((ext_vector_type(2)));
+typedef double cf64 __attribute__((ext_vector_type(2)));
 template <typename T> struct cx_of;
-template <> struct cx_of<float>  { using type = float2; };
-template <> struct cx_of<double> { using type = double2; };
+template <> struct cx_of<float>  { using type = cf32; };
+template <> struct cx_of<double> { using type = cf64; };
 template <typename T> using cx = typename cx_of<T>::type;
+template <typename C> struct real_of;
+template <> struct real_of<cf32> { using type = float; };
+template <> struct real_of<cf64> { using type = double; };
 
 template <typename T> __device__ __forceinline__ cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
-template <typename C> __device__ __forceinline__ C cadd(C a, C b) { a.x += b.x; a.y += b.y; return a; }
-template <typename C> __device__ __forceinline__ C csub(C a, C b) { a.x -= b.x; a.y -= b.y; return a; }
-// a * b
-template <typename C> __device__ __forceinline__ C cmul(C a, C b) {
-    C r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r;
-}
-// a * conj(b)
-template <typename C> __device__ __forceinline__ C cmulc(C a, C b) {
-    C r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r;
-}
-// Tables hold forward twiddles exp(-i*theta); DIR < 0 = forward, DIR > 0 = inverse (conjugate).
-template <int DIR, typename C> __device__ __forceinline__ C cmuld(C a, C w) {
-    return DIR < 0 ? cmul(a, w) : cmulc(a, w);
-}
-// multiply by -i (forward) or +i (inverse)
-template <int DIR, typename C> __device__ __forceinline__ C rot90(C a) {
-    C r;
-    if (DIR < 0) { r.x = a.y;  r.y = -a.x; }
-    else         { r.x = -a.y; r.y = a.x;  }
+
+// ---- generic (double) forms
+__device__ __forceinline__ cf64 cadd(cf64 a, cf64 b) { return a + b; }
+__device__ __forceinline__ cf64 csub(cf64 a, cf64 b) { return a - b; }
+__device__ __forceinline__ cf64 cmul(cf64 a, cf64 b) { cf64 r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r; }
+__device__ __forceinline__ cf64 cmulc(cf64 a, cf64 b) { cf64 r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r; }
+// a + (-i) d   and   a + (+i) d
+__device__ __forceinline__ cf64 add_mi(cf64 a, cf64 d) { cf64 r; r.x = a.x + d.y; r.y = a.y - d.x; return r; }
+__device__ __forceinline__ cf64 add_pi(cf64 a, cf64 d) { cf64 r; r.x = a.x - d.y; r.y = a.y + d.x; return r; }
+__device__ __forceinline__ cf64 mul_mi(cf64 a) { cf64 r; r.x = a.y; r.y = -a.x; return r; }
+__device__ __forceinline__ cf64 mul_pi(cf64 a) { cf64 r; r.x = -a.y; r.y = a.x; return r; }
+__device__ __forceinline__ cf64 scale2(cf64 a, cf64 s) { return a * s; }
+
+// ---- float forms: packed FP32 with modifiers (VOP3P).  op_sel[i] / op_sel_hi[i] pick the half of
+// source i that feeds the low / high result lane; neg_lo / neg_hi negate a source per lane.
+__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return a + b; }      // v_pk_add_f32
+__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return a - b; }      // v_pk_add_f32 neg
+__device__ __forceinline__ cf32 scale2(cf32 a, cf32 s) { return a * s; }    // v_pk_mul_f32
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 w) {
+    cf32 t, r;      // t = (ay wy, ay wx);  r = (ax wx - t.lo, ax wy + t.hi)
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
     return r;
 }
+__device__ __forceinline__ cf32 cmulc(cf32 a, cf32 w) {
+    cf32 t, r;      // t = (ay wy, ay wx);  r = (ax wx + t.lo, -ax wy + t.hi)
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r), "=&v"(t) : "v"(a), "v"(w));
+    return r;
+}
+__device__ __forceinline__ cf32 add_mi(cf32 a, cf32 d) {        // (a.x + d.y, a.y - d.x)
+    cf32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+__device__ __forceinline__ cf32 add_pi(cf32 a, cf32 d) {        // (a.x - d.y, a.y + d.x)
+    cf32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+__device__ __forceinline__ cf32 mul_mi(cf32 a) {                // (a.y, -a.x)
+    cf32 r;
+    asm("v_pk_mul_f32 %0, 1.0, %1 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ cf32 mul_pi(cf32 a) {                // (-a.y, a.x)
+    cf32 r;
+    asm("v_pk_mul_f32 %0, 1.0, %1 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+
+// Tables hold forward twiddles exp(-i*theta); DIR < 0 = forward, DIR > 0 = inverse (conjugate).
+template <int DIR, typename C> __device__ __forceinline__ C cmuld(C a, C w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
+// a + (DIR: -i forward, +i inverse) * d,  and the opposite sign
+template <int DIR, typename C> __device__ __forceinline__ C add_rot(C a, C d) { return DIR < 0 ? add_mi(a, d) : add_pi(a, d); }
+template <int DIR, typename C> __device__ __forceinline__ C sub_rot(C a, C d) { return DIR < 0 ? add_pi(a, d) : add_mi(a, d); }
+template <int DIR, typename C> __device__ __forceinline__ C rot90(C a) { return DIR < 0 ? mul_mi(a) : mul_pi(a); }
 
 // ---------------------------------------------------------------- small DFTs in registers
 template <int DIR, typename C> __device__ __forceinline__ void dft2(C& a, C& b) {
     C t = a; a = cadd(t, b); b = csub(t, b);
 }
 template <int DIR, typename C> __device__ __forceinline__ void dft4(C& x0, C& x1, C& x2, C& x3) {
-    C a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot90<DIR>(csub(x1, x3));
-    x0 = cadd(a0, a2); x1 = cadd(a1, a3); x2 = csub(a0, a2); x3 = csub(a1, a3);
+    const C a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), d = csub(x1, x3);
+    x0 = cadd(a0, a2); x2 = csub(a0, a2);
+    x1 = add_rot<DIR>(a1, d); x3 = sub_rot<DIR>(a1, d);       // a1 -+ i d
 }
 
 template <int R> struct Dft;
@@ -81,23 +131,17 @@ template <> struct RadixConst<double> {
     static constexpr double cA = 0.92387953251128675613, sA = 0.38268343236508977173;
     static constexpr double cB = cA, sB = sA;
 };
-// x * W8^1 (forward: (1-i)/sqrt2, inverse: (1+i)/sqrt2) and x * W8^3 (forward: (-1-i)/sqrt2).
+// x * W8^1 (forward (1-i)/sqrt2, inverse (1+i)/sqrt2) and x * W8^3 (forward (-1-i)/sqrt2, inverse
+// (-1+i)/sqrt2):  x (1 -+ i) = x -+ i x is one rotated add, then one scale by a constant pair.
 // VAR = 1: the imaginary component is scaled with the rounded-up constant.
 template <int DIR, int VAR, typename C> __device__ __forceinline__ C mul_w8_1(C a) {
-    using T = decltype(a.x);
-    const T sx = RadixConst<T>::R2D, sy = VAR ? RadixConst<T>::R2U : RadixConst<T>::R2D;
-    C r;
-    if (DIR < 0) { r.x = (a.x + a.y) * sx; r.y = (a.y - a.x) * sy; }
-    else         { r.x = (a.x - a.y) * sx; r.y = (a.x + a.y) * sy; }
-    return r;
+    using T = typename real_of<C>::type;
+    return scale2(add_rot<DIR>(a, a), mk<T>(RadixConst<T>::R2D, VAR ? RadixConst<T>::R2U : RadixConst<T>::R2D));
 }
 template <int DIR, int VAR, typename C> __device__ __forceinline__ C mul_w8_3(C a) {
-    using T = decltype(a.x);
-    const T sx = RadixConst<T>::R2D, sy = VAR ? RadixConst<T>::R2U : RadixConst<T>::R2D;
-    C r;
-    if (DIR < 0) { r.x = (a.y - a.x) * sx; r.y = -((a.x + a.y) * sy); }
-    else         { r.x = -((a.x + a.y) * sx); r.y = (a.x - a.y) * sy; }
-    return r;
+    using T = typename real_of<C>::type;
+    // forward: x(-1-i) = -(x + i x);  inverse: x(-1+i) = -(x - i x)
+    return scale2(sub_rot<DIR>(a, a), mk<T>(-RadixConst<T>::R2D, VAR ? -RadixConst<T>::R2U : -RadixConst<T>::R2D));
 }
 
 template <> struct Dft<8> {
@@ -105,32 +149,31 @@ template <> struct Dft<8> {
         // even / odd DFT-4, odd *= W8^k, combine
         dft4<DIR>(x[0], x[2], x[4], x[6]);
         dft4<DIR>(x[1], x[3], x[5], x[7]);
-        const C o0 = x[1], o1 = mul_w8_1<DIR, 1>(x[3]), o2 = rot90<DIR>(x[5]), o3 = mul_w8_3<DIR, 0>(x[7]);
-        const C e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+        const C o0 = x[1], o1 = mul_w8_1<DIR, 1>(x[3]), o3 = mul_w8_3<DIR, 0>(x[7]);
+        const C e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], o2 = x[5];
         x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
         x[1] = cadd(e1, o1); x[5] = csub(e1, o1);
-        x[2] = cadd(e2, o2); x[6] = csub(e2, o2);
+        x[2] = add_rot<DIR>(e2, o2); x[6] = sub_rot<DIR>(e2, o2);      // o2 * W8^2 = -+ i o2
         x[3] = cadd(e3, o3); x[7] = csub(e3, o3);
     }
 };
 template <> struct Dft<16> {
     template <int DIR, typename C> static __device__ __forceinline__ void run(C* x) {
-        using T = decltype(x[0].x);
+        using T = typename real_of<C>::type;
         using K = RadixConst<T>;
         // four DFT-4 over stride-4 subsequences: x[b + 4q] <- G_b[q]
 #pragma unroll
         for (int b = 0; b < 4; ++b) dft4<DIR>(x[b], x[b + 4], x[b + 8], x[b + 12]);
         // G_b[q] *= W16^(b*q); forward W16^k = (cos(k pi/8), -sin(k pi/8))
-        C w;
-        w.x = K::cA;  w.y = -K::sA;  x[1 + 4]  = cmuld<DIR>(x[1 + 4], w);     // b=1 q=1: W^1
-        x[1 + 8]  = mul_w8_1<DIR, 1>(x[1 + 8]);                                // b=1 q=2: W^2
-        w.x = K::sB;  w.y = -K::cB;  x[1 + 12] = cmuld<DIR>(x[1 + 12], w);    // b=1 q=3: W^3
-        x[2 + 4]  = mul_w8_1<DIR, 0>(x[2 + 4]);                                // b=2 q=1: W^2
-        x[2 + 8]  = rot90<DIR>(x[2 + 8]);                                      // b=2 q=2: W^4 = -i
-        x[2 + 12] = mul_w8_3<DIR, 1>(x[2 + 12]);                               // b=2 q=3: W^6
-        w.x = K::sB;  w.y = -K::cB;  x[3 + 4]  = cmuld<DIR>(x[3 + 4], w);     // b=3 q=1: W^3
-        x[3 + 8]  = mul_w8_3<DIR, 0>(x[3 + 8]);                                // b=3 q=2: W^6
-        w.x = -K::cB; w.y = K::sB;   x[3 + 12] = cmuld<DIR>(x[3 + 12], w);    // b=3 q=3: W^9 = -W^1
+        x[1 + 4]  = cmuld<DIR>(x[1 + 4], mk<T>(K::cA, -K::sA));      // b=1 q=1: W^1
+        x[1 + 8]  = mul_w8_1<DIR, 1>(x[1 + 8]);                       // b=1 q=2: W^2
+        x[1 + 12] = cmuld<DIR>(x[1 + 12], mk<T>(K::sB, -K::cB));     // b=1 q=3: W^3
+        x[2 + 4]  = mul_w8_1<DIR, 0>(x[2 + 4]);                       // b=2 q=1: W^2
+        x[2 + 8]  = rot90<DIR>(x[2 + 8]);                             // b=2 q=2: W^4 = -i
+        x[2 + 12] = mul_w8_3<DIR, 1>(x[2 + 12]);                      // b=2 q=3: W^6
+        x[3 + 4]  = cmuld<DIR>(x[3 + 4], mk<T>(K::sB, -K::cB));      // b=3 q=1: W^3
+        x[3 + 8]  = mul_w8_3<DIR, 0>(x[3 + 8]);                       // b=3 q=2: W^6
+        x[3 + 12] = cmuld<DIR>(x[3 + 12], mk<T>(-K::cB, K::sB));     // b=3 q=3: W^9 = -W^1
         // DFT-4 across b for every q; result p of group q is output q + 4p
         C y[16];
 #pragma unroll
