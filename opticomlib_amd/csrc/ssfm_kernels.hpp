@@ -52,7 +52,7 @@ template <typename T> struct AdaptState {
 
 template <typename T> struct TimeArgs {
     cx<T>* F;                 // field, batch rows of N
-    T* P;                     // stale |A|^2, same indexing as the time-domain field
+    T* P;                     // stale |A|^2, tile-major (private to k_time)
     const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]
     const cx<T>* tw1;         // W_N1^q
     AdaptState<T>* st;        // nullptr in fixed-step mode
@@ -173,7 +173,11 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
     const long long N = (long long)N1 * a.N2;
     // wave-uniform bases (SGPRs) + one 32-bit lane offset
     cx<T>* __restrict__ Fb = a.F + (long long)blockIdx.y * N + (long long)blockIdx.x * C;
-    T* __restrict__ Pb = a.P + (long long)blockIdx.y * N + (long long)blockIdx.x * C;
+    // |A|^2 is private to this kernel (written and read back by the same thread of the same tile),
+    // so it is stored tile-major as 4 x (4 values per thread): 16-byte accesses, 1 KiB per wave.
+    typedef T p4_t __attribute__((ext_vector_type(4)));
+    p4_t* __restrict__ Pb = reinterpret_cast<p4_t*>(a.P + (long long)blockIdx.y * N + (long long)blockIdx.x * (N1 * C)) + tid;
+    constexpr int PSTR = N1 * C / 16;     // threads per tile
     const cx<T>* __restrict__ Wb = a.twN + (long long)blockIdx.x * C;
     const int off = j * a.N2 + c;
     const int stride = Q * a.N2;
@@ -190,7 +194,11 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
     for (int t = 0; t < 16; ++t) w[t] = SSFM_ABL_NO_TWN ? mk<T>((T)1, (T)0) : Wb[off + t * stride];
     if (MODE != TM_BEGIN) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pold[t] = SSFM_ABL_NO_P ? (T)1e-3 : Pb[off + t * stride];
+        for (int g = 0; g < 4; ++g) {
+            p4_t q;
+            if (SSFM_ABL_NO_P) q = (T)1e-3; else q = Pb[g * PSTR];
+            pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
+        }
     }
     load_line_twiddles<T, N1>(tw, j, a.tw1);
 
@@ -205,17 +213,24 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
     // does not change |A|, so both phases are known here and are applied as ONE rotation.
     T pmax = (T)0;
     T phi[16];
+    T pnew[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const T p = v[t].x * v[t].x + v[t].y * v[t].y;
         T ph = (T)0;
         if (MODE != TM_BEGIN) ph = hh_prev * (a.gamma * pold[t]);
-        if (MODE != TM_END) {
-            if (!SSFM_ABL_NO_P) Pb[off + t * stride] = p;
-            ph += hh_next * (a.gamma * p);
-        }
+        if (MODE != TM_END) ph += hh_next * (a.gamma * p);
+        pnew[t] = p;
         phi[t] = ph;
         pmax = p > pmax ? p : pmax;
+    }
+    if (MODE != TM_END && !SSFM_ABL_NO_P) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            p4_t q;
+            q.x = pnew[4 * g]; q.y = pnew[4 * g + 1]; q.z = pnew[4 * g + 2]; q.w = pnew[4 * g + 3];
+            Pb[g * PSTR] = q;
+        }
     }
     if (!SSFM_ABL_NO_NL) rotate16(v, phi);
     else {
