@@ -1,0 +1,130 @@
+"""Sharding of INDEPENDENT propagations over the GPUs of one node.
+
+The reference has no parallelism of any kind; what shards naturally is the outer loop a user
+writes around ``FIBER``: one call per WDM channel (configuration C3) or per Monte-Carlo PRBS
+realisation (C4).  Those calls never exchange data, so there is NO collective on the data path:
+unit ``i`` goes to rank ``i % world``, every rank runs its units on its own GPU, and ONE gather at
+the end (RCCL over xGMI when the backend is ``nccl``; ``gloo`` on CPU in the tests) returns the
+results in unit order.  xGMI is point-to-point, so the gather is a single all-gather of equal
+chunks -- 16 MiB per 2^20 x 2 complex64 field -- not a ring of small messages.
+
+One process per GPU: launch with ``python -m torch.distributed.run --nproc-per-node N ...``; the
+device is ``LOCAL_RANK`` (``devices.default_device``).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence
+
+import numpy as np
+
+
+def world():
+    """(rank, world_size) of this process; (0, 1) when torch.distributed is not initialised."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def init(backend: str | None = None):
+    """Initialise the default process group from the torchrun environment (idempotent)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return world()
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, **kw)
+    return world()
+
+
+def shard(n_units: int, rank: int | None = None, world_size: int | None = None) -> List[int]:
+    """Unit indices owned by ``rank``: round-robin, so any prefix of the units is balanced."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    return list(range(rank, n_units, world_size))
+
+
+def gather_results(local: Sequence[np.ndarray], n_units: int, to_all: bool = True):
+    """Gather per-unit arrays (all of one shape and dtype) into unit order.
+
+    ``local[k]`` is the result of unit ``shard(n_units)[k]``.  Returns a list of ``n_units``
+    arrays on every rank (``to_all``) or on rank 0 only (others get ``None``).
+    """
+    rank, ws = world()
+    if ws == 1:
+        return list(local)
+    import torch
+    import torch.distributed as dist
+    per_rank = -(-n_units // ws)                       # ceil: ranks with fewer units pad
+    first = np.asarray(local[0]) if len(local) else None
+    # every rank owns at least one unit when n_units >= world; otherwise learn the shape from rank 0
+    meta = [None]
+    if rank == 0:
+        meta = [(first.shape, first.dtype.str)]
+    dist.broadcast_object_list(meta, src=0)
+    shape, dtstr = meta[0]
+    dt = np.dtype(dtstr)
+    buf = np.zeros((per_rank,) + tuple(shape), dtype=dt)
+    for k, a in enumerate(local):
+        buf[k] = a
+    # complex arrays travel as real pairs (NCCL has no complex types)
+    view = buf.view(np.float64 if dt == np.complex128 else np.float32) if dt.kind == "c" else buf
+    use_cuda = dist.get_backend() == "nccl"
+    t = torch.from_numpy(np.ascontiguousarray(view))
+    if use_cuda:
+        t = t.cuda()
+    if to_all:
+        outs = [torch.empty_like(t) for _ in range(ws)]
+        dist.all_gather(outs, t)
+    else:
+        outs = [torch.empty_like(t) for _ in range(ws)] if rank == 0 else None
+        dist.gather(t, outs, dst=0)
+        if rank != 0:
+            return None
+    res: List[np.ndarray] = [None] * n_units
+    for r in range(ws):
+        arr = outs[r].cpu().numpy()
+        if dt.kind == "c":
+            arr = arr.view(dt)
+        arr = arr.reshape((per_rank,) + tuple(shape))
+        for k, unit in enumerate(range(r, n_units, ws)):
+            res[unit] = arr[k]
+    return res
+
+
+def sharded_map(fn: Callable[[int], np.ndarray], n_units: int, to_all: bool = True):
+    """Run ``fn(unit)`` for this rank's units, then gather: the whole multi-GPU path."""
+    mine = shard(n_units)
+    local = [np.asarray(fn(u)) for u in mine]
+    return gather_results(local, n_units, to_all=to_all)
+
+
+def propagate_channels(fields, dt: float, to_all: bool = True, **fiber_kw):
+    """``FIBER`` on every field of ``fields`` (shape ``(F, [2,] N)``), sharded over the ranks.
+
+    Each field is an independent propagation with its own adaptive step size, exactly as F
+    separate ``FIBER`` calls of the reference would be.  Returns the list of F output arrays.
+    """
+    from .devices import FIBER
+    from .typing import gv, optical_signal
+
+    fields = np.asarray(fields)
+
+    def one(u):
+        gv.dt, gv.fs = dt, 1.0 / dt
+        return FIBER(optical_signal(fields[u]), **fiber_kw).signal
+
+    return sharded_map(one, fields.shape[0], to_all=to_all)
