@@ -132,7 +132,9 @@ def main():
     roofline = None
     cpu = None
     if rank == 0:
-        b_alg_launch = 2 * N_POL * 8 * n                     # field read once + written once per launch
+        lanes = plan.lanes
+        rows_per_launch = N_POL // lanes                     # a launch covers one lane's rows
+        b_alg_launch = 2 * rows_per_launch * 8 * n           # its rows read once + written once
         if not args.no_profile_pass:
             plan.set_profiling(True)
             one_step()
@@ -149,8 +151,20 @@ def main():
                 "avg_launch_us": avg_us,
                 "launch_us": {k: v[1] / max(v[0], 1) * 1e3 for k, v in kt.items()},
                 "algorithmic_bytes_per_launch": b_alg_launch,
+                "lanes": lanes, "rows_per_launch": rows_per_launch,
+                "note": "launch time = HIP-event interval on the launch's own stream (previous event -> event after "
+                        "the launch, so it includes the dependent-launch gap); with lanes > 1 launches of different "
+                        "row groups overlap on the chip, so the chip-level figure is step_frac",
                 "step_frac": 2 * N_POL * 8 * value / world / (HBM_PEAK_GBS * 1e9),
             }
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    t = json.load(open(pmc))
+                    roofline["traffic"] = t.get(dom, {}).get("bytes_per_launch")
+                    roofline["traffic_source"] = t.get("_source")
+                except Exception:
+                    pass
         if world == 1 and args.cpu_steps > 0:
             cpu = cpu_baseline(a, dt, fibre, args.cpu_steps)
 

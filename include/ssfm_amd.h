@@ -125,6 +125,9 @@ int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
  * from the previous event to the event after the launch, in ms (so a dependent-launch gap is
  * counted with the kernel that follows it). */
 int ssfm_set_profiling(ssfm_plan* plan, int enabled);
+/* Number of row groups ("lanes") a fixed-step run drives on separate streams (env SSFM_LANES,
+ * default 2, never more than the batch): one kernel launch covers batch/lanes rows. */
+int ssfm_num_lanes(ssfm_plan* plan, int* lanes);
 int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]);
 
 #ifdef __cplusplus

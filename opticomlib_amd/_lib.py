@@ -39,6 +39,7 @@ SYMBOLS = {
     "ssfm_last_propagate_ms": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(_I64)]),
     "ssfm_set_profiling": (_I, [_VP, _I]),
     "ssfm_kernel_times": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
+    "ssfm_num_lanes": (_I, [_VP, C.POINTER(_I)]),
 }
 
 
@@ -183,6 +184,12 @@ class Plan:
 
     def set_profiling(self, enabled: bool):
         _check(load().ssfm_set_profiling(self._h, int(bool(enabled))), "ssfm_set_profiling")
+
+    @property
+    def lanes(self) -> int:
+        n = _I(0)
+        _check(load().ssfm_num_lanes(self._h, C.byref(n)), "ssfm_num_lanes")
+        return n.value
 
     def kernel_times(self):
         """{'k_time': (launches, total_ms), 'k_freq': (launches, total_ms)} of the last profiled run."""

@@ -133,34 +133,41 @@ template <typename T> struct PlanT : PlanBase {
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
     hipEvent_t fork_ev = nullptr;
-    std::vector<hipEvent_t> pev;       // pool of per-launch events
-    std::vector<unsigned char> pcls;   // class of the launch that precedes event i+1
-    size_t pn = 0;                     // events recorded by the last propagate
+    // per-lane pools of per-launch events (profiling mode)
+    struct LaneProf {
+        std::vector<hipEvent_t> ev;
+        std::vector<unsigned char> cls;   // class of the launch that precedes event i (255 = opening)
+        size_t n = 0;
+    };
+    LaneProf prof[8];
 
-    int prof_mark(int cls) {           // cls < 0: opening event
+    int prof_mark(int cls, int lane = 0) {           // cls < 0: opening event
         if (!profiling) return SSFM_OK;
-        if (pn == pev.size()) {
+        LaneProf& p = prof[lane];
+        if (p.n == p.ev.size()) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
-            pev.push_back(e);
-            pcls.push_back(0);
+            p.ev.push_back(e);
+            p.cls.push_back(0);
         }
-        HIP_TRY(hipEventRecord(pev[pn], stream));
-        pcls[pn] = (unsigned char)(cls < 0 ? 255 : cls);
-        ++pn;
+        HIP_TRY(hipEventRecord(p.ev[p.n], lane_stream[lane]));
+        p.cls[p.n] = (unsigned char)(cls < 0 ? 255 : cls);
+        ++p.n;
         return SSFM_OK;
     }
     int kernel_times(int64_t counts[2], double total_ms[2]) {
         counts[0] = counts[1] = 0;
         total_ms[0] = total_ms[1] = 0.0;
-        if (pn < 2) return SSFM_OK;
-        HIP_TRY(hipEventSynchronize(pev[pn - 1]));
-        for (size_t i = 1; i < pn; ++i) {
-            if (pcls[i] > 1) continue;
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, pev[i - 1], pev[i]));
-            counts[pcls[i]] += 1;
-            total_ms[pcls[i]] += ms;
+        for (auto& p : prof) {
+            if (p.n < 2) continue;
+            HIP_TRY(hipEventSynchronize(p.ev[p.n - 1]));
+            for (size_t i = 1; i < p.n; ++i) {
+                if (p.cls[i] > 1) continue;
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, p.ev[i - 1], p.ev[i]));
+                counts[p.cls[i]] += 1;
+                total_ms[p.cls[i]] += ms;
+            }
         }
         return SSFM_OK;
     }
@@ -177,8 +184,10 @@ template <typename T> struct PlanT : PlanBase {
             if (lane_stream[g]) (void)hipStreamDestroy(lane_stream[g]);
         }
         if (fork_ev) (void)hipEventDestroy(fork_ev);
-        for (hipEvent_t e : pev) (void)hipEventDestroy(e);
-        pev.clear();
+        for (auto& p : prof) {
+            for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+            p.ev.clear();
+        }
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -311,24 +320,30 @@ template <typename T> struct PlanT : PlanBase {
         auto freq = [&](T hs) -> hipError_t { return freq_rows(hs, 0, batch, stream); };
         (void)nrows;
         const T half = (T)0.5;
-        pn = 0;
+        for (auto& p : prof) p.n = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
-        if (snapshots == nullptr && !profiling && nlanes > 1) {
+        if (snapshots == nullptr && nlanes > 1) {
             const int rows = batch / nlanes;
             HIP_TRY(hipEventRecord(fork_ev, stream));
             for (int g = 1; g < nlanes; ++g) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
             for (int g = 0; g < nlanes; ++g) {
+                if (int rc = prof_mark(-1, g)) return rc;
                 ++last_launches;
                 HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows))));
+                if (int rc = prof_mark(0, g)) return rc;
             }
             for (int64_t s = 0; s < nsteps; ++s) {
-                for (int g = 0; g < nlanes; ++g) HIP_TRY(freq_rows(h[s], g * rows, rows, lane_stream[g]));
+                for (int g = 0; g < nlanes; ++g) {
+                    HIP_TRY(freq_rows(h[s], g * rows, rows, lane_stream[g]));
+                    if (int rc = prof_mark(1, g)) return rc;
+                }
                 for (int g = 0; g < nlanes; ++g) {
                     ++last_launches;
                     if (s + 1 < nsteps)
                         HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows))));
                     else
                         HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows))));
+                    if (int rc = prof_mark(0, g)) return rc;
                 }
             }
             for (int g = 1; g < nlanes; ++g) {
@@ -630,6 +645,10 @@ void* ssfm_stream(ssfm_plan* plan) {
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches) { WITH_PLAN(plan, last_ms_impl(P_, ms, launches)); }
 
 int ssfm_set_profiling(ssfm_plan* plan, int enabled) { WITH_PLAN(plan, (P_->profiling = enabled != 0, (int)SSFM_OK)); }
+int ssfm_num_lanes(ssfm_plan* plan, int* lanes) {
+    if (!lanes) return fail(SSFM_ERR_INVALID, "NULL output");
+    WITH_PLAN(plan, (*lanes = P_->nlanes, (int)SSFM_OK));
+}
 int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]) {
     if (!counts || !total_ms) return fail(SSFM_ERR_INVALID, "NULL output");
     WITH_PLAN(plan, P_->kernel_times(counts, total_ms));
