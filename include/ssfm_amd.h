@@ -118,13 +118,15 @@ void* ssfm_stream(ssfm_plan* plan);
  * number of kernel launches it made.  Valid after ssfm_synchronize. */
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
 
-/* Per-kernel timing of ssfm_propagate_fixed.  When enabled, a HIP event is recorded on the plan's
- * stream before the first and after every kernel launch (measurement runs only: it costs host time
- * and a marker packet per launch).  After ssfm_synchronize, ssfm_kernel_times returns per kernel
- * class (index 0 = k_time begin/mid/end, 1 = k_freq) the number of launches and the summed time
- * from the previous event to the event after the launch, in ms (so a dependent-launch gap is
- * counted with the kernel that follows it). */
-int ssfm_set_profiling(ssfm_plan* plan, int enabled);
+/* Kernel timing of ssfm_propagate_fixed with HIP events on the streams the kernels are launched on.
+ *   mode 0  off
+ *   mode 1  an event after EVERY launch: per-class times (index 0 = k_time begin/mid/end, 1 = k_freq), but
+ *           the marker packets slow a launch-dense run noticeably (~30 % at 11 us per launch)
+ *   mode 2  an event after every 64th launch of a stream: negligible overhead; each interval is split
+ *           between the two classes by launch count (so both classes report the pooled average)
+ * After ssfm_synchronize, ssfm_kernel_times returns per class the number of launches and the summed
+ * event-to-event time in ms (a dependent-launch gap is counted with the launch that follows it). */
+int ssfm_set_profiling(ssfm_plan* plan, int mode);
 /* Number of row groups ("lanes") a fixed-step run drives on separate streams (env SSFM_LANES,
  * default 2, never more than the batch): one kernel launch covers batch/lanes rows. */
 int ssfm_num_lanes(ssfm_plan* plan, int* lanes);

@@ -182,8 +182,9 @@ class Plan:
     def synchronize(self):
         _check(load().ssfm_synchronize(self._h), "ssfm_synchronize")
 
-    def set_profiling(self, enabled: bool):
-        _check(load().ssfm_set_profiling(self._h, int(bool(enabled))), "ssfm_set_profiling")
+    def set_profiling(self, mode: int):
+        """0 off, 1 event per launch (per-class times, perturbs), 2 event per 64 launches (pooled, cheap)."""
+        _check(load().ssfm_set_profiling(self._h, int(mode)), "ssfm_set_profiling")
 
     @property
     def lanes(self) -> int:

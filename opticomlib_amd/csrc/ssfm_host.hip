@@ -50,7 +50,7 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
 template <typename T, int MODE, int N1>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = kColsPerTile;
-    constexpr size_t lds = fft_nstages(N1) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0;
+    constexpr size_t lds = (fft_nstages(N1) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)16 * C * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_time<T, N1, C, MODE>, lds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((k_time<T, N1, C, MODE>), grid, dim3(N1 * C / 16), lds, s, a);
@@ -110,6 +110,8 @@ template <typename T> struct PlanT : PlanBase {
     cx<T>* F = nullptr;        // batch * n
     T* P = nullptr;            // batch * n
     cx<T>* twN = nullptr;      // n
+    cx<T>* twA = nullptr;      // (N1/16)*N2: W_N^m
+    cx<T>* twB = nullptr;      // 16*N2: W_N^(m*N1/16)
     cx<T>* tw1 = nullptr;      // N1
     cx<T>* tw2 = nullptr;      // N2
     cx<T>* dnat = nullptr;     // n  (D~ or H, natural order, staging)
@@ -133,26 +135,42 @@ template <typename T> struct PlanT : PlanBase {
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
     hipEvent_t fork_ev = nullptr;
-    // per-lane pools of per-launch events (profiling mode)
+    // per-lane pools of events (profiling).  mode 1: an event after every launch (per-class times, but
+    // the marker packets slow a launch-dense run by ~30 %); mode 2: an event after every 64th launch
+    // (negligible overhead; the interval is split between the classes by launch count).
     struct LaneProf {
         std::vector<hipEvent_t> ev;
-        std::vector<unsigned char> cls;   // class of the launch that precedes event i (255 = opening)
+        std::vector<int> c0, c1;          // launches of class 0 / 1 between event i-1 and event i
         size_t n = 0;
+        int pend0 = 0, pend1 = 0;
     };
     LaneProf prof[8];
+    int prof_mode = 0;
+    static constexpr int kSparseStride = 64;
 
-    int prof_mark(int cls, int lane = 0) {           // cls < 0: opening event
-        if (!profiling) return SSFM_OK;
-        LaneProf& p = prof[lane];
+    int prof_record(LaneProf& p, int lane) {
         if (p.n == p.ev.size()) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             p.ev.push_back(e);
-            p.cls.push_back(0);
+            p.c0.push_back(0);
+            p.c1.push_back(0);
         }
         HIP_TRY(hipEventRecord(p.ev[p.n], lane_stream[lane]));
-        p.cls[p.n] = (unsigned char)(cls < 0 ? 255 : cls);
+        p.c0[p.n] = p.pend0; p.c1[p.n] = p.pend1;
+        p.pend0 = p.pend1 = 0;
         ++p.n;
+        return SSFM_OK;
+    }
+    // cls < 0: opening event; cls 0/1: a launch of that class was just enqueued; cls 2: closing
+    int prof_mark(int cls, int lane = 0) {
+        if (!profiling) return SSFM_OK;
+        LaneProf& p = prof[lane];
+        if (cls < 0) { p.pend0 = p.pend1 = 0; return prof_record(p, lane); }
+        if (cls == 0) ++p.pend0;
+        if (cls == 1) ++p.pend1;
+        if (cls == 2) return (p.pend0 + p.pend1) ? prof_record(p, lane) : (int)SSFM_OK;
+        if (prof_mode == 1 || p.pend0 + p.pend1 >= kSparseStride) return prof_record(p, lane);
         return SSFM_OK;
     }
     int kernel_times(int64_t counts[2], double total_ms[2]) {
@@ -162,11 +180,14 @@ template <typename T> struct PlanT : PlanBase {
             if (p.n < 2) continue;
             HIP_TRY(hipEventSynchronize(p.ev[p.n - 1]));
             for (size_t i = 1; i < p.n; ++i) {
-                if (p.cls[i] > 1) continue;
+                const int tot = p.c0[i] + p.c1[i];
+                if (tot == 0) continue;
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, p.ev[i - 1], p.ev[i]));
-                counts[p.cls[i]] += 1;
-                total_ms[p.cls[i]] += ms;
+                counts[0] += p.c0[i];
+                counts[1] += p.c1[i];
+                total_ms[0] += (double)ms * p.c0[i] / tot;
+                total_ms[1] += (double)ms * p.c1[i] / tot;
             }
         }
         return SSFM_OK;
@@ -176,7 +197,7 @@ template <typename T> struct PlanT : PlanBase {
 
     int free_all() {
         if (stream) (void)hipStreamSynchronize(stream);
-        void* bufs[] = {F, P, twN, tw1, tw2, dnat, dperm, scratch, st, zlog};
+        void* bufs[] = {F, P, twN, twA, twB, tw1, tw2, dnat, dperm, scratch, st, zlog};
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
         for (int g = 1; g < kMaxLanes; ++g) {
@@ -221,6 +242,9 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipMalloc(&F, cb * n * batch));
         HIP_TRY(hipMalloc(&P, sizeof(T) * n * batch));
         HIP_TRY(hipMalloc(&twN, cb * n));
+        const long long nA = (long long)(N1 / 16) * N2, nB = 16ll * N2;
+        HIP_TRY(hipMalloc(&twA, cb * nA));
+        HIP_TRY(hipMalloc(&twB, cb * nB));
         HIP_TRY(hipMalloc(&tw1, cb * N1));
         HIP_TRY(hipMalloc(&tw2, cb * N2));
         HIP_TRY(hipMalloc(&dnat, cb * n));
@@ -230,6 +254,8 @@ template <typename T> struct PlanT : PlanBase {
         hipLaunchKernelGGL(k_make_twL<T>, dim3((N1 + 255) / 256), dim3(256), 0, stream, tw1, N1);
         hipLaunchKernelGGL(k_make_twL<T>, dim3((N2 + 255) / 256), dim3(256), 0, stream, tw2, N2);
         hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2);
+        hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, nA, 1ll, (long long)n);
+        hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, nB, (long long)(N1 / 16), (long long)n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return SSFM_OK;
@@ -268,7 +294,7 @@ template <typename T> struct PlanT : PlanBase {
 
     TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s, int row0 = 0) const {
         TimeArgs<T> a;
-        a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.tw1 = tw1; a.st = s; a.gamma = gamma;
+        a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2;
         return a;
     }
@@ -346,6 +372,7 @@ template <typename T> struct PlanT : PlanBase {
                     if (int rc = prof_mark(0, g)) return rc;
                 }
             }
+            for (int g = 0; g < nlanes; ++g) if (int rc = prof_mark(2, g)) return rc;
             for (int g = 1; g < nlanes; ++g) {
                 HIP_TRY(hipEventRecord(lane_ev[g], lane_stream[g]));
                 HIP_TRY(hipStreamWaitEvent(stream, lane_ev[g], 0));
@@ -365,6 +392,7 @@ template <typename T> struct PlanT : PlanBase {
                     HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr))));
                 if (int rc = prof_mark(0)) return rc;
             }
+            if (int rc = prof_mark(2)) return rc;
         } else {
             const size_t fb = sizeof(cx<T>) * n * batch;
             char* snap = static_cast<char*>(snapshots);
@@ -644,7 +672,7 @@ void* ssfm_stream(ssfm_plan* plan) {
 
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches) { WITH_PLAN(plan, last_ms_impl(P_, ms, launches)); }
 
-int ssfm_set_profiling(ssfm_plan* plan, int enabled) { WITH_PLAN(plan, (P_->profiling = enabled != 0, (int)SSFM_OK)); }
+int ssfm_set_profiling(ssfm_plan* plan, int mode) { WITH_PLAN(plan, (P_->profiling = mode != 0, P_->prof_mode = mode, (int)SSFM_OK)); }
 int ssfm_num_lanes(ssfm_plan* plan, int* lanes) {
     if (!lanes) return fail(SSFM_ERR_INVALID, "NULL output");
     WITH_PLAN(plan, (*lanes = P_->nlanes, (int)SSFM_OK));

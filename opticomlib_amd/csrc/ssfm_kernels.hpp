@@ -31,6 +31,10 @@
 #ifndef SSFM_ABL_NO_NL
 #define SSFM_ABL_NO_NL 0
 #endif
+// 1: form the inter-pass twiddles in the kernel from two small tables; 0: stream the N-entry table
+#ifndef SSFM_TWN_COMPUTE
+#define SSFM_TWN_COMPUTE 0
+#endif
 
 namespace ssfm {
 
@@ -53,7 +57,9 @@ template <typename T> struct AdaptState {
 template <typename T> struct TimeArgs {
     cx<T>* F;                 // field, batch rows of N
     T* P;                     // stale |A|^2, tile-major (private to k_time)
-    const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]
+    const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]                      (SSFM_TWN_COMPUTE == 0)
+    const cx<T>* twA;         // W_N^m,          m < (N1/16)*N2   W_N^(k1*n2) = twA[j*n2] * twB[t*n2],
+    const cx<T>* twB;         // W_N^(m*N1/16),  m < 16*N2        k1 = j + t*N1/16  (SSFM_TWN_COMPUTE == 1)
     const cx<T>* tw1;         // W_N1^q
     AdaptState<T>* st;        // nullptr in fixed-step mode
     T gamma;
@@ -190,8 +196,16 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
     LineTw<T, N1> tw;
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = Fb[off + t * stride];
+#if SSFM_TWN_COMPUTE
+    // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
+    // the tile's 16 x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
+    cx<T>* Bs = lds + (fft_nstages(N1) > 1 ? N1 * C : 0);
+    for (int e = tid; e < 16 * C; e += N1 * C / 16) Bs[e] = a.twB[(e / C) * (blockIdx.x * C + (e % C))];
+    const cx<T> wA = a.twA[j * (blockIdx.x * C + c)];
+#else
 #pragma unroll
     for (int t = 0; t < 16; ++t) w[t] = SSFM_ABL_NO_TWN ? mk<T>((T)1, (T)0) : Wb[off + t * stride];
+#endif
     if (MODE != TM_BEGIN) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -201,6 +215,12 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
         }
     }
     load_line_twiddles<T, N1>(tw, j, a.tw1);
+#if SSFM_TWN_COMPUTE
+    __syncthreads();
+    w[0] = wA;
+#pragma unroll
+    for (int t = 1; t < 16; ++t) w[t] = cmul(wA, Bs[t * C + c]);
+#endif
 
     if (MODE != TM_BEGIN) {
 #pragma unroll
@@ -336,6 +356,15 @@ template <typename T> __global__ void k_make_twL(cx<T>* tab, int L) {
     double s, c;
     sincospi(-2.0 * (double)q / (double)L, &s, &c);
     tab[q] = mk<T>((T)c, (T)s);
+}
+// tab[m] = W_N^(m*mult) = exp(-2 pi i m mult / N), m < count
+template <typename T> __global__ void k_make_twpow(cx<T>* tab, long long count, long long mult, long long N) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= count) return;
+    const long long r = (m * mult) % N;
+    double s, c;
+    sincospi(-2.0 * (double)r / (double)N, &s, &c);
+    tab[m] = mk<T>((T)c, (T)s);
 }
 // W_N^(k1*n2) at [k1*N2 + n2]
 template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2) {
