@@ -39,7 +39,8 @@ constexpr int kLog2Min = 8, kLog2Max = 20;
 constexpr int kColsPerTile = 16;   // C: 128 B (c64) / 256 B (c128) contiguous per row segment
 constexpr int kMaxTables = 4;
 
-constexpr int freq_rows(int n2) { return n2 <= 64 ? 16 : (n2 == 128 ? 8 : (n2 == 256 ? 4 : (n2 == 512 ? 2 : 1))); }
+// rows per k_freq workgroup: at least 64 threads where the row count allows (N1 >= 16 rows per batch entry)
+constexpr int freq_rows(int n2, int e) { return (n2 / e) >= 64 ? 1 : ((64 * e / n2) > 16 ? 16 : (64 * e / n2)); }
 
 template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return hipSuccess;
@@ -47,51 +48,60 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
 }
 
 // ----------------------------------------------------------------------------- launchers
-template <typename T, int MODE, int N1>
+// E = points per thread: 8 (default for complex64: twice the waves, half the registers) or 16.
+template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = kColsPerTile;
-    constexpr size_t lds = (fft_nstages(N1) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)16 * C * sizeof(cx<T>);
-    static hipError_t attr = allow_lds(k_time<T, N1, C, MODE>, lds);
+    constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>);
+    static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE>, lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_time<T, N1, C, MODE>), grid, dim3(N1 * C / 16), lds, s, a);
+    hipLaunchKernelGGL((k_time<T, N1, C, E, MODE>), grid, dim3(N1 * C / E), lds, s, a);
     return hipGetLastError();
 }
-template <typename T, int MODE>
-hipError_t launch_time(int N1, int batch, hipStream_t s, const TimeArgs<T>& a) {
+template <typename T, int MODE, int E>
+hipError_t launch_time_e(int N1, int batch, hipStream_t s, const TimeArgs<T>& a) {
     const dim3 grid(a.N2 / kColsPerTile, batch);
     switch (N1) {
-        case 16:  return launch_time_n1<T, MODE, 16>(grid, s, a);
-        case 32:  return launch_time_n1<T, MODE, 32>(grid, s, a);
-        case 64:  return launch_time_n1<T, MODE, 64>(grid, s, a);
-        case 128: return launch_time_n1<T, MODE, 128>(grid, s, a);
-        case 256: return launch_time_n1<T, MODE, 256>(grid, s, a);
+        case 16:  return launch_time_n1<T, MODE, 16, E>(grid, s, a);
+        case 32:  return launch_time_n1<T, MODE, 32, E>(grid, s, a);
+        case 64:  return launch_time_n1<T, MODE, 64, E>(grid, s, a);
+        case 128: return launch_time_n1<T, MODE, 128, E>(grid, s, a);
+        case 256: return launch_time_n1<T, MODE, 256, E>(grid, s, a);
     }
     return hipErrorInvalidValue;
-}
-
-template <typename T, int MODE, int N2>
-hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
-    constexpr int ROWS = freq_rows(N2);
-    constexpr size_t lds = fft_nstages(N2) > 1 ? (size_t)ROWS * row_lds_elems(N2) * sizeof(cx<T>) : 0;
-    static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, MODE>, lds);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_freq<T, N2, ROWS, MODE>), dim3(nrows / ROWS), dim3(ROWS * N2 / 16), lds, s, a);
-    return hipGetLastError();
 }
 template <typename T, int MODE>
-hipError_t launch_freq(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a) {
+hipError_t launch_time(int N1, int batch, hipStream_t s, const TimeArgs<T>& a, int E) {
+    return E == 8 ? launch_time_e<T, MODE, 8>(N1, batch, s, a) : launch_time_e<T, MODE, 16>(N1, batch, s, a);
+}
+
+template <typename T, int MODE, int N2, int E>
+hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
+    constexpr int ROWS = freq_rows(N2, E);
+    constexpr size_t lds = fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0;
+    static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, E, MODE>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_freq<T, N2, ROWS, E, MODE>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, a);
+    return hipGetLastError();
+}
+template <typename T, int MODE, int E>
+hipError_t launch_freq_e(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a) {
     switch (N2) {
-        case 16:   return launch_freq_n2<T, MODE, 16>(nrows, s, a);
-        case 32:   return launch_freq_n2<T, MODE, 32>(nrows, s, a);
-        case 64:   return launch_freq_n2<T, MODE, 64>(nrows, s, a);
-        case 128:  return launch_freq_n2<T, MODE, 128>(nrows, s, a);
-        case 256:  return launch_freq_n2<T, MODE, 256>(nrows, s, a);
-        case 512:  return launch_freq_n2<T, MODE, 512>(nrows, s, a);
-        case 1024: return launch_freq_n2<T, MODE, 1024>(nrows, s, a);
-        case 2048: return launch_freq_n2<T, MODE, 2048>(nrows, s, a);
-        case 4096: return launch_freq_n2<T, MODE, 4096>(nrows, s, a);
+        case 16:   return launch_freq_n2<T, MODE, 16, E>(nrows, s, a);
+        case 32:   return launch_freq_n2<T, MODE, 32, E>(nrows, s, a);
+        case 64:   return launch_freq_n2<T, MODE, 64, E>(nrows, s, a);
+        case 128:  return launch_freq_n2<T, MODE, 128, E>(nrows, s, a);
+        case 256:  return launch_freq_n2<T, MODE, 256, E>(nrows, s, a);
+        case 512:  return launch_freq_n2<T, MODE, 512, E>(nrows, s, a);
+        case 1024: return launch_freq_n2<T, MODE, 1024, E>(nrows, s, a);
+        case 2048: return launch_freq_n2<T, MODE, 2048, E>(nrows, s, a);
+        case 4096: return launch_freq_n2<T, MODE, 4096, E>(nrows, s, a);
     }
     return hipErrorInvalidValue;
+}
+template <typename T, int MODE>
+hipError_t launch_freq(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a, int E) {
+    return E == 8 ? launch_freq_e<T, MODE, 8>(N2, nrows, s, a) : launch_freq_e<T, MODE, 16>(N2, nrows, s, a);
 }
 
 // ----------------------------------------------------------------------------- plan
@@ -132,6 +142,7 @@ template <typename T> struct PlanT : PlanBase {
     // hides launch gaps and lets one group compute while another waits for memory.
     static constexpr int kMaxLanes = 8;
     int nlanes = 1;
+    int E = 16;                // points per thread (env SSFM_E = 8 | 16)
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
     hipEvent_t fork_ev = nullptr;
@@ -227,6 +238,8 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
+        E = 16;                    // measured: E = 8 (twice the waves, one more exchange) is 10 % slower
+        if (const char* e = std::getenv("SSFM_E")) E = std::atoi(e) == 16 ? 16 : 8;
         int want = 2;
         if (const char* e = std::getenv("SSFM_LANES")) want = std::atoi(e);
         nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
@@ -339,9 +352,9 @@ template <typename T> struct PlanT : PlanBase {
                 const cx<T>* tp = nullptr;
                 for (size_t i = 0; i < distinct.size(); ++i)
                     if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
-                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0));
+                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0), E);
             }
-            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0));
+            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0), E);
         };
         auto freq = [&](T hs) -> hipError_t { return freq_rows(hs, 0, batch, stream); };
         (void)nrows;
@@ -355,7 +368,7 @@ template <typename T> struct PlanT : PlanBase {
             for (int g = 0; g < nlanes; ++g) {
                 if (int rc = prof_mark(-1, g)) return rc;
                 ++last_launches;
-                HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows))));
+                HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows), E)));
                 if (int rc = prof_mark(0, g)) return rc;
             }
             for (int64_t s = 0; s < nsteps; ++s) {
@@ -366,9 +379,9 @@ template <typename T> struct PlanT : PlanBase {
                 for (int g = 0; g < nlanes; ++g) {
                     ++last_launches;
                     if (s + 1 < nsteps)
-                        HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows))));
+                        HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows), E)));
                     else
-                        HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows))));
+                        HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows), E)));
                     if (int rc = prof_mark(0, g)) return rc;
                 }
             }
@@ -380,16 +393,16 @@ template <typename T> struct PlanT : PlanBase {
         } else if (snapshots == nullptr) {
             if (int rc = prof_mark(-1)) return rc;
             ++last_launches;
-            HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[0] * half, nullptr))));
+            HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[0] * half, nullptr), E)));
             if (int rc = prof_mark(0)) return rc;
             for (int64_t s = 0; s < nsteps; ++s) {
                 HIP_TRY(freq(h[s]));
                 if (int rc = prof_mark(1)) return rc;
                 ++last_launches;
                 if (s + 1 < nsteps)
-                    HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, targs(gamma, h[s] * half, h[s + 1] * half, nullptr))));
+                    HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, targs(gamma, h[s] * half, h[s + 1] * half, nullptr), E)));
                 else
-                    HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr))));
+                    HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr), E)));
                 if (int rc = prof_mark(0)) return rc;
             }
             if (int rc = prof_mark(2)) return rc;
@@ -399,9 +412,9 @@ template <typename T> struct PlanT : PlanBase {
             if (int rc = copy_field_out(snap, false, false)) return rc;
             for (int64_t s = 0; s < nsteps; ++s) {
                 last_launches += 2;
-                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[s] * half, nullptr))));
+                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[s] * half, nullptr), E)));
                 HIP_TRY(freq(h[s]));
-                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr))));
+                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr), E)));
                 if (int rc = copy_field_out(snap + fb * (s + 1), false, false)) return rc;
             }
         }
@@ -447,9 +460,9 @@ template <typename T> struct PlanT : PlanBase {
         int prev_steps = 0;
         for (;;) {
             for (int i = 0; i < chunk; ++i) {
-                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, 0, st))));
-                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, 0, st))));
-                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, 0, 0, st))));
+                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
+                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, 0, st), E)));
+                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
                 hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, st, zlog, 1, 0);
                 HIP_TRY(hipGetLastError());
                 last_launches += 4;
@@ -490,9 +503,9 @@ template <typename T> struct PlanT : PlanBase {
                            (const cx<T>*)dnat, hperm, N1, N2, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev0, stream));
-        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr))));
-        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr))));
-        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr))));
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), E)));
+        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
         HIP_TRY(hipEventRecord(ev1, stream));
         last_launches = 3;
         timed = true;
@@ -504,8 +517,8 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = use_device()) return rc;
         const int nrows = N1 * batch;
         if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
-        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr))));
-        HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, nrows, stream, fargs(dperm, 0, nullptr))));
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, nrows, stream, fargs(dperm, 0, nullptr), E)));
         const long long total = (long long)n * batch;
         hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)F, scratch, N1, N2, batch);

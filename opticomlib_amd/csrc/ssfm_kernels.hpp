@@ -110,30 +110,30 @@ template <bool BIG> __device__ __forceinline__ void sincos_f32(float x, float& s
     sincos_reduced(r, q, s, c);
     if (BIG && !(fabsf(x) < __builtin_inff())) s = c = __builtin_nanf("");
 }
-// rotate 16 values by their phases
-__device__ __forceinline__ void rotate16(cf32 (&v)[16], const float (&phi)[16]) {
+// rotate E values by their phases
+template <int E> __device__ __forceinline__ void rotate_all(cf32 (&v)[E], const float (&phi)[E]) {
     bool big = false;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) big = big || !(fabsf(phi[t]) <= kSincosSmallMax);
+    for (int t = 0; t < E; ++t) big = big || !(fabsf(phi[t]) <= kSincosSmallMax);
     if (__builtin_expect(big, 0)) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < E; ++t) {
             float s, c;
             sincos_f32<true>(phi[t], s, c);
             v[t] = cmul(v[t], mk<float>(c, s));
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < E; ++t) {
             float s, c;
             sincos_f32<false>(phi[t], s, c);
             v[t] = cmul(v[t], mk<float>(c, s));
         }
     }
 }
-__device__ __forceinline__ void rotate16(cf64 (&v)[16], const double (&phi)[16]) {
+template <int E> __device__ __forceinline__ void rotate_all(cf64 (&v)[E], const double (&phi)[E]) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < E; ++t) {
         double s, c;
         sincos(phi[t], &s, &c);
         v[t] = cmul(v[t], mk<double>(c, s));
@@ -151,20 +151,33 @@ template <int C> struct ColIdx {
     int c;
     __device__ __forceinline__ int operator()(int e) const { return e * C + c; }
 };
-struct RowIdx {
+// row layout in LDS: one pad element per 2^SH elements (SH = log2 of the first-stage radix), which
+// makes the stride-R first-stage writes and the contiguous later reads conflict-free
+template <int SH> struct RowIdx {
     int off;
-    __device__ __forceinline__ int operator()(int e) const { return off + e + (e >> 4); }
+    __device__ __forceinline__ int operator()(int e) const { return off + e + (e >> SH); }
 };
-__host__ __device__ constexpr int row_lds_elems(int n2) { return n2 + (n2 >> 4); }
+__host__ __device__ constexpr int row_pad_shift(int E) { return E == 16 ? 4 : 3; }
+__host__ __device__ constexpr int row_lds_elems(int n2, int E) { return n2 + (n2 >> row_pad_shift(E)); }
 
 template <typename T> __device__ __forceinline__ unsigned long long float_bits(T v);
 template <> __device__ __forceinline__ unsigned long long float_bits<float>(float v) { return (unsigned long long)__float_as_uint(v); }
 template <> __device__ __forceinline__ unsigned long long float_bits<double>(double v) { return (unsigned long long)__double_as_longlong(v); }
 
 // ------------------------------------------------------------------------------ k_time
-template <typename T, int N1, int C, int MODE>
-__global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 ? 2 : 1)) void k_time(const TimeArgs<T> a) {
-    constexpr int Q = N1 / 16;                     // threads per column
+// Alternating LDS exchanges between two buffers saves one barrier per exchange but doubles the LDS
+// footprint; measured on MI355X it is SLOWER (23.2 -> 25.6 us per step): fewer workgroups of the
+// concurrently running kernels fit a CU.  Kept selectable, off.
+#ifndef SSFM_LDS_DOUBLE_BUFFER
+#define SSFM_LDS_DOUBLE_BUFFER 0
+#endif
+template <typename T> __host__ __device__ constexpr bool lds_double_buffer() { return SSFM_LDS_DOUBLE_BUFFER != 0 && sizeof(T) == 4; }
+// waves per SIMD to ask for: enough for two workgroups of THREADS threads per CU in complex64
+__host__ __device__ constexpr int min_waves(int threads, int tsize) { return tsize == 4 && threads >= 256 ? threads / 128 : 1; }
+
+template <typename T, int N1, int C, int E, int MODE>
+__global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void k_time(const TimeArgs<T> a) {
+    constexpr int Q = N1 / E;                      // threads per column
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
@@ -183,59 +196,59 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
     // so it is stored tile-major as 4 x (4 values per thread): 16-byte accesses, 1 KiB per wave.
     typedef T p4_t __attribute__((ext_vector_type(4)));
     p4_t* __restrict__ Pb = reinterpret_cast<p4_t*>(a.P + (long long)blockIdx.y * N + (long long)blockIdx.x * (N1 * C)) + tid;
-    constexpr int PSTR = N1 * C / 16;     // threads per tile
+    constexpr int PSTR = N1 * C / E;      // threads per tile
     const cx<T>* __restrict__ Wb = a.twN + (long long)blockIdx.x * C;
     const int off = j * a.N2 + c;
     const int stride = Q * a.N2;
     const ColIdx<C> idx{c};
 
     // issue every global load of the tile up front
-    cx<T> v[16];
-    cx<T> w[16];
-    T pold[16];
-    LineTw<T, N1> tw;
+    cx<T> v[E];
+    cx<T> w[E];
+    T pold[E];
+    LineTw<T, N1, E> tw;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = Fb[off + t * stride];
+    for (int t = 0; t < E; ++t) v[t] = Fb[off + t * stride];
 #if SSFM_TWN_COMPUTE
     // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
     // the tile's 16 x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
-    cx<T>* Bs = lds + (fft_nstages(N1) > 1 ? N1 * C : 0);
-    for (int e = tid; e < 16 * C; e += N1 * C / 16) Bs[e] = a.twB[(e / C) * (blockIdx.x * C + (e % C))];
+    cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
+    for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(e / C) * (blockIdx.x * C + (e % C))];
     const cx<T> wA = a.twA[j * (blockIdx.x * C + c)];
 #else
 #pragma unroll
-    for (int t = 0; t < 16; ++t) w[t] = SSFM_ABL_NO_TWN ? mk<T>((T)1, (T)0) : Wb[off + t * stride];
+    for (int t = 0; t < E; ++t) w[t] = SSFM_ABL_NO_TWN ? mk<T>((T)1, (T)0) : Wb[off + t * stride];
 #endif
     if (MODE != TM_BEGIN) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < E / 4; ++g) {
             p4_t q;
             if (SSFM_ABL_NO_P) q = (T)1e-3; else q = Pb[g * PSTR];
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     }
-    load_line_twiddles<T, N1>(tw, j, a.tw1);
+    load_line_twiddles<T, N1, E>(tw, j, a.tw1);
 #if SSFM_TWN_COMPUTE
     __syncthreads();
     w[0] = wA;
 #pragma unroll
-    for (int t = 1; t < 16; ++t) w[t] = cmul(wA, Bs[t * C + c]);
+    for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
 #endif
 
     if (MODE != TM_BEGIN) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = cmulc(v[t], w[t]);
-        if (!SSFM_ABL_NO_FFT) fft_line<T, N1, +1, ColIdx<C>>(v, lds, j, idx, tw);
+        for (int t = 0; t < E; ++t) v[t] = cmulc(v[t], w[t]);
+        if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, ColIdx<C>>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
     }
     // v = time-domain samples A(n1, n2).  Nonlinear operator (reference devices.py:1175-1181):
     // the second half step of the step being finished uses the |A|^2 of its START (pold), the
     // first half step of the next one the |A|^2 of the field after that rotation -- a rotation
     // does not change |A|, so both phases are known here and are applied as ONE rotation.
     T pmax = (T)0;
-    T phi[16];
-    T pnew[16];
+    T phi[E];
+    T pnew[E];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < E; ++t) {
         const T p = v[t].x * v[t].x + v[t].y * v[t].y;
         T ph = (T)0;
         if (MODE != TM_BEGIN) ph = hh_prev * (a.gamma * pold[t]);
@@ -246,20 +259,20 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
     }
     if (MODE != TM_END && !SSFM_ABL_NO_P) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < E / 4; ++g) {
             p4_t q;
             q.x = pnew[4 * g]; q.y = pnew[4 * g + 1]; q.z = pnew[4 * g + 2]; q.w = pnew[4 * g + 3];
             Pb[g * PSTR] = q;
         }
     }
-    if (!SSFM_ABL_NO_NL) rotate16(v, phi);
+    if (!SSFM_ABL_NO_NL) rotate_all<E>(v, phi);
     else {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t].x += phi[t];
+        for (int t = 0; t < E; ++t) v[t].x += phi[t];
     }
     if (MODE == TM_END) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Fb[off + t * stride] = v[t];
+        for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
         if (a.st != nullptr && a.st->adaptive) {
             // wave-level max, then one atomic per wave
 #pragma unroll
@@ -271,10 +284,12 @@ __global__ __launch_bounds__(N1 * C / 16, (N1 * C / 16 >= 256 && sizeof(T) == 4 
         }
         return;
     }
-    if (MODE == TM_MID && fft_nstages(N1) > 1) __syncthreads();   // inverse transform's LDS reads are done
-    if (!SSFM_ABL_NO_FFT) fft_line<T, N1, -1, ColIdx<C>>(v, lds, j, idx, tw);
+    // exchanges alternate between two LDS buffers; the forward transform continues the count
+    constexpr int NX = fft_nstages(N1, E) - 1;      // exchanges of the inverse transform
+    constexpr int XP_FWD = (MODE != TM_MID || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, ColIdx<C>>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) Fb[off + t * stride] = cmul(v[t], w[t]);
+    for (int t = 0; t < E; ++t) Fb[off + t * stride] = cmul(v[t], w[t]);
 }
 
 // ------------------------------------------------------------------------------ k_freq
@@ -294,9 +309,9 @@ template <typename T> __device__ __forceinline__ T exp_acc(T x);
 template <> __device__ __forceinline__ float exp_acc<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double exp_acc<double>(double x) { return exp(x); }
 
-template <typename T, int N2, int ROWS, int MODE>
-__global__ __launch_bounds__(ROWS * N2 / 16, (ROWS * N2 / 16 >= 256 && sizeof(T) == 4 ? 2 : 1)) void k_freq(const FreqArgs<T> a) {
-    constexpr int Q = N2 / 16;
+template <typename T, int N2, int ROWS, int E, int MODE>
+__global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T))) void k_freq(const FreqArgs<T> a) {
+    constexpr int Q = N2 / E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
@@ -312,26 +327,27 @@ __global__ __launch_bounds__(ROWS * N2 / 16, (ROWS * N2 / 16 >= 256 && sizeof(T)
     const int k1 = (int)(row % a.N1);
     cx<T>* __restrict__ Frow = a.F + row * N2;
     const cx<T>* __restrict__ trow = a.tab + (long long)k1 * N2;
-    const RowIdx idx{rr * row_lds_elems(N2)};
+    using RI = RowIdx<row_pad_shift(E)>;
+    const RI idx{rr * row_lds_elems(N2, E)};
 
-    cx<T> v[16];
-    cx<T> m[16];
-    LineTw<T, N2> tw;
+    cx<T> v[E];
+    cx<T> m[E];
+    LineTw<T, N2, E> tw;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = Frow[j + t * Q];
-    load_line_twiddles<T, N2>(tw, j, a.tw2);
+    for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
+    load_line_twiddles<T, N2, E>(tw, j, a.tw2);
     if (MODE != FM_FWD_ONLY) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) m[t] = SSFM_ABL_NO_TAB ? mk<T>(a.inv_n, (T)0) : trow[j + t * Q];
+        for (int t = 0; t < E; ++t) m[t] = SSFM_ABL_NO_TAB ? mk<T>(a.inv_n, (T)0) : trow[j + t * Q];
     }
-    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, -1, RowIdx>(v, lds, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
+        for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
         return;
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < E; ++t) {
         cx<T> mm = m[t];
         if (MODE == FM_FLY) {
             // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
@@ -342,10 +358,9 @@ __global__ __launch_bounds__(ROWS * N2 / 16, (ROWS * N2 / 16 >= 256 && sizeof(T)
         }
         v[t] = cmul(v[t], mm);
     }
-    if (fft_nstages(N2) > 1) __syncthreads();
-    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, +1, RowIdx>(v, lds, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : (lds_double_buffer<T>() ? ((fft_nstages(N2, E) - 1) & 1) : 1)), RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) Frow[j + t * Q] = v[t];
+    for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
 }
 
 // ------------------------------------------------------------------------------ tables

@@ -1,12 +1,12 @@
 // wgfft.hpp -- workgroup-level power-of-two FFT building block for gfx950 (wave64).
 //
-// A "line" of L = 2^m complex points (16 <= L <= 4096) is transformed by Q = L/16
-// threads; every thread owns 16 points in registers.  Register slot t of thread j holds
+// A "line" of L = 2^m complex points (16 <= L <= 4096) is transformed by Q = L/E
+// threads; every thread owns E (16 or 8) points in registers.  Register slot t of thread j holds
 // line element j + t*Q on entry AND on exit ("pattern P"), so a forward and an inverse
 // transform can be chained without any data movement in between, and the global-memory
 // access pattern on both sides of a kernel is the same.
 //
-// The transform is a Stockham autosort: 1..3 radix-{16,8,4} stages.  The first stage works
+// The transform is a Stockham autosort: 1..4 radix-{16,8,4,2} stages.  The first stage works
 // straight out of registers, every later stage after one exchange through LDS, and the
 // last stage leaves its results in registers.  Stage twiddles W_L^q come from one table of
 // L entries per line length (generated in double, rounded once) and are kept in registers.
@@ -188,35 +188,43 @@ template <> struct Dft<16> {
 };
 
 // ---------------------------------------------------------------- stage plan
-__host__ __device__ constexpr int fft_nstages(int L) { return L <= 16 ? 1 : (L <= 256 ? 2 : 3); }
-// radix of stage s (0-based) for line length L
-__host__ __device__ constexpr int fft_radix(int L, int s) {
-    return L == 16   ? 16
-         : L == 32   ? (s == 0 ? 8 : 4)
-         : L == 64   ? 8
-         : L == 128  ? (s == 0 ? 16 : 8)
-         : L == 256  ? 16
-         : L == 512  ? 8
-         : L == 1024 ? (s == 0 ? 16 : 8)
-         : L == 2048 ? (s <= 1 ? 16 : 8)
-         :             16;   // 4096
+// E = points per thread (16 or 8).  E = 16: radix-16 stages, fewest LDS exchanges, ~200 VGPRs;
+// E = 8: radix-8 stages, one more exchange for most lengths but half the registers and twice the
+// waves for the same line -- what a small problem needs to keep two computing waves per SIMD.
+__host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+__host__ __device__ constexpr int fft_nstages(int L, int E) {
+    return E == 16 ? (L <= 16 ? 1 : (L <= 256 ? 2 : 3)) : (ilog2(L) + 2) / 3;
 }
-__host__ __device__ constexpr int fft_ls(int L, int s) {   // product of radices before stage s
-    return s == 0 ? 1 : fft_ls(L, s - 1) * fft_radix(L, s - 1);
+// radix of stage s (0-based) for line length L
+__host__ __device__ constexpr int fft_radix(int L, int s, int E) {
+    return E == 16 ? (L == 16   ? 16
+                    : L == 32   ? (s == 0 ? 8 : 4)
+                    : L == 64   ? 8
+                    : L == 128  ? (s == 0 ? 16 : 8)
+                    : L == 256  ? 16
+                    : L == 512  ? 8
+                    : L == 1024 ? (s == 0 ? 16 : 8)
+                    : L == 2048 ? (s <= 1 ? 16 : 8)
+                    :             16)   // 4096
+                   // E == 8: radix 8 while three bits remain, then the remainder
+                   : (s < ilog2(L) / 3 ? 8 : (1 << (ilog2(L) % 3)));
+}
+__host__ __device__ constexpr int fft_ls(int L, int s, int E) {   // product of radices before stage s
+    return s == 0 ? 1 : fft_ls(L, s - 1, E) * fft_radix(L, s - 1, E);
 }
 
 // Stage twiddles of one thread, loaded once per kernel and kept in registers: they depend only on
 // the thread's position in the line, and the forward and the inverse transform share them.
-template <typename T, int L> struct LineTw {
-    static constexpr int M = fft_nstages(L);
-    cx<T> w[M > 1 ? M - 1 : 1][15];
+template <typename T, int L, int E> struct LineTw {
+    static constexpr int M = fft_nstages(L, E);
+    cx<T> w[M > 1 ? M - 1 : 1][E - 1];
 };
-template <typename T, int L, int S>
-__device__ __forceinline__ void load_stage_twiddles(LineTw<T, L>& tw, const int j, const cx<T>* __restrict__ tab) {
-    constexpr int R  = fft_radix(L, S);
-    constexpr int NB = 16 / R;
-    constexpr int Q  = L / 16;
-    constexpr int LS = fft_ls(L, S);
+template <typename T, int L, int E, int S>
+__device__ __forceinline__ void load_stage_twiddles(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab) {
+    constexpr int R  = fft_radix(L, S, E);
+    constexpr int NB = E / R;
+    constexpr int Q  = L / E;
+    constexpr int LS = fft_ls(L, S, E);
     constexpr int STEP = L / (LS * R);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -225,30 +233,35 @@ __device__ __forceinline__ void load_stage_twiddles(LineTw<T, L>& tw, const int 
         for (int u = 1; u < R; ++u) tw.w[S - 1][i * (R - 1) + (u - 1)] = tab[k * u * STEP];
     }
 }
-template <typename T, int L>
-__device__ __forceinline__ void load_line_twiddles(LineTw<T, L>& tw, const int j, const cx<T>* __restrict__ tab) {
-    constexpr int M = fft_nstages(L);
-    if constexpr (M > 1) load_stage_twiddles<T, L, 1>(tw, j, tab);
-    if constexpr (M > 2) load_stage_twiddles<T, L, 2>(tw, j, tab);
+template <typename T, int L, int E>
+__device__ __forceinline__ void load_line_twiddles(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab) {
+    constexpr int M = fft_nstages(L, E);
+    if constexpr (M > 1) load_stage_twiddles<T, L, E, 1>(tw, j, tab);
+    if constexpr (M > 2) load_stage_twiddles<T, L, E, 2>(tw, j, tab);
+    if constexpr (M > 3) load_stage_twiddles<T, L, E, 3>(tw, j, tab);
 }
 
-// One Stockham stage.  IDX maps a line element index to an LDS element index.
-template <typename T, int L, int DIR, int S, typename IDX>
-__device__ __forceinline__ void fft_stage(cx<T> (&v)[16], cx<T>* lds, const int j, const IDX& idx,
-                                          const LineTw<T, L>& tw) {
-    constexpr int M  = fft_nstages(L);
-    constexpr int R  = fft_radix(L, S);
-    constexpr int NB = 16 / R;          // butterflies per thread
-    constexpr int Q  = L / 16;          // threads per line
-    constexpr int LS = fft_ls(L, S);
+// One Stockham stage.  IDX maps a line element index to an LDS element index.  Exchanges alternate
+// between two LDS buffers (`lds`, `lds + BUF`): exchange x uses buffer x & 1, so a buffer is rewritten
+// only after a full barrier has separated it from its last readers and ONE barrier per exchange
+// (between its writes and its reads) is enough.  XP = parity of this transform's first exchange.
+// BUF = 0 selects a single buffer (half the LDS) with a second barrier before every rewrite.
+template <typename T, int L, int E, int DIR, int S, int XP, typename IDX>
+__device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int BUF, const int j, const IDX& idx,
+                                          const LineTw<T, L, E>& tw) {
+    constexpr int M  = fft_nstages(L, E);
+    constexpr int R  = fft_radix(L, S, E);
+    constexpr int NB = E / R;           // butterflies per thread
+    constexpr int Q  = L / E;           // threads per line
+    constexpr int LS = fft_ls(L, S, E);
 
     if constexpr (S > 0) {
-        // all reads of the previous exchange happen here; writers finished before the barrier
+        const cx<T>* src = lds + ((XP + S - 1) & 1) * BUF;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int jb = j + i * Q;
 #pragma unroll
-            for (int u = 0; u < R; ++u) v[i + u * NB] = lds[idx(jb + u * (L / R))];
+            for (int u = 0; u < R; ++u) v[i + u * NB] = src[idx(jb + u * (L / R))];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -267,28 +280,30 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[16], cx<T>* lds, const int 
         for (int u = 0; u < R; ++u) v[i + u * NB] = tmp[u];
     }
     if constexpr (S < M - 1) {
-        if constexpr (S > 0) __syncthreads();     // every thread has read its inputs of this stage
+        cx<T>* dst = lds + ((XP + S) & 1) * BUF;
+        if (BUF == 0 && (S > 0 || XP != 0)) __syncthreads();   // single buffer: its readers must be done
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int jb = j + i * Q;
             const int k = jb & (LS - 1);
             const int base = (jb - k) * R + k;
 #pragma unroll
-            for (int u = 0; u < R; ++u) lds[idx(base + u * LS)] = v[i + u * NB];
+            for (int u = 0; u < R; ++u) dst[idx(base + u * LS)] = v[i + u * NB];
         }
         __syncthreads();
     }
 }
 
-// Full line transform.  The caller guarantees that nobody is still reading `lds` from an
-// earlier exchange when this is entered (i.e. there was a barrier since).
-template <typename T, int L, int DIR, typename IDX>
-__device__ __forceinline__ void fft_line(cx<T> (&v)[16], cx<T>* lds, const int j, const IDX& idx,
-                                         const LineTw<T, L>& tw) {
-    constexpr int M = fft_nstages(L);
-    fft_stage<T, L, DIR, 0, IDX>(v, lds, j, idx, tw);
-    if constexpr (M > 1) fft_stage<T, L, DIR, 1, IDX>(v, lds, j, idx, tw);
-    if constexpr (M > 2) fft_stage<T, L, DIR, 2, IDX>(v, lds, j, idx, tw);
+// Full line transform.  XP: parity of its first exchange (0 for the first transform of a kernel,
+// (number of exchanges so far) & 1 for a later one).
+template <typename T, int L, int E, int DIR, int XP, typename IDX>
+__device__ __forceinline__ void fft_line(cx<T> (&v)[E], cx<T>* lds, const int BUF, const int j, const IDX& idx,
+                                         const LineTw<T, L, E>& tw) {
+    constexpr int M = fft_nstages(L, E);
+    fft_stage<T, L, E, DIR, 0, XP, IDX>(v, lds, BUF, j, idx, tw);
+    if constexpr (M > 1) fft_stage<T, L, E, DIR, 1, XP, IDX>(v, lds, BUF, j, idx, tw);
+    if constexpr (M > 2) fft_stage<T, L, E, DIR, 2, XP, IDX>(v, lds, BUF, j, idx, tw);
+    if constexpr (M > 3) fft_stage<T, L, E, DIR, 3, XP, IDX>(v, lds, BUF, j, idx, tw);
 }
 
 }  // namespace ssfm
