@@ -107,6 +107,12 @@ int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double
  * (reference DM, devices.py:1027-1029) */
 int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host);
 
+/* DM with the transfer function generated on the device (reference devices.py:1025-1029):
+ * H(w_k) = exp(+1j w_k^2 D/2), w_k = 2 pi fftfreq(n, dt)[k] in float64 with the reference's operation
+ * order, D in s^2 (the caller has applied devices.py:1025's `D *= 1e-12**2`).  If H_out != NULL the
+ * natural-order H (n complex, precision's type, HOST) is returned as well (for retH). */
+int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out);
+
 /* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);
 

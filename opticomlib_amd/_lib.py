@@ -33,6 +33,7 @@ SYMBOLS = {
     "ssfm_propagate_fixed": (_I, [_VP, _D, _VP, _I64, _VP]),
     "ssfm_propagate_adaptive": (_I, [_VP, _D, _D, _D, _I, _I64, C.POINTER(_I64), C.POINTER(_D), _VP]),
     "ssfm_apply_transfer": (_I, [_VP, _VP]),
+    "ssfm_apply_dispersion": (_I, [_VP, _D, _D, _VP]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
@@ -173,6 +174,12 @@ class Plan:
         if h.shape != (self.n,):
             raise ValueError(f"H must have shape ({self.n},), got {h.shape}")
         _check(load().ssfm_apply_transfer(self._h, _ptr(h)), "ssfm_apply_transfer")
+
+    def apply_dispersion(self, dt: float, D_s2: float, want_H: bool = False):
+        """DM with H generated on the device; returns natural-order H if ``want_H``."""
+        H = np.empty(self.n, dtype=self.cdtype) if want_H else None
+        _check(load().ssfm_apply_dispersion(self._h, float(dt), float(D_s2), _ptr(H) if want_H else None), "ssfm_apply_dispersion")
+        return H
 
     def debug_fft(self) -> np.ndarray:
         out = np.empty((self.batch, self.n), dtype=self.cdtype)

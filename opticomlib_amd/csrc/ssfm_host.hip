@@ -513,6 +513,35 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
+    int apply_dispersion(double dt_s, double D_s2, void* H_out) {
+        if (int rc = use_device()) return rc;
+        const int nrows = N1 * batch;
+        if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
+        cx<T>* hperm = scratch;
+        cx<T>* hnat = nullptr;
+        if (H_out) {                       // dnat doubles as staging for the natural-order H
+            hnat = dnat;
+            have_op = false;
+            for (auto& t : tabs) t.valid = false;
+        }
+        const double val = 1.0 / ((double)n * dt_s);
+        hipLaunchKernelGGL(k_make_dm_table<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           hperm, hnat, N1, N2, val, D_s2, inv_n());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev0, stream));
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), E)));
+        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY(hipEventRecord(ev1, stream));
+        last_launches = 3;
+        timed = true;
+        if (H_out) {
+            HIP_TRY(hipMemcpyAsync(H_out, hnat, sizeof(cx<T>) * n, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return SSFM_OK;
+    }
+
     int debug_fft(void* dst) {
         if (int rc = use_device()) return rc;
         const int nrows = N1 * batch;
@@ -668,6 +697,11 @@ int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double
 int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host) {
     if (!H_host) return fail(SSFM_ERR_INVALID, "H_host is NULL");
     WITH_PLAN(plan, P_->apply_transfer(H_host));
+}
+
+int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out) {
+    if (!(dt_s > 0)) return fail(SSFM_ERR_INVALID, "dt_s must be positive");
+    WITH_PLAN(plan, P_->apply_dispersion(dt_s, D_s2, H_out));
 }
 
 int ssfm_debug_fft(ssfm_plan* plan, void* dst) {

@@ -173,7 +173,10 @@ template <> __device__ __forceinline__ unsigned long long float_bits<double>(dou
 #endif
 template <typename T> __host__ __device__ constexpr bool lds_double_buffer() { return SSFM_LDS_DOUBLE_BUFFER != 0 && sizeof(T) == 4; }
 // waves per SIMD to ask for: enough for two workgroups of THREADS threads per CU in complex64
-__host__ __device__ constexpr int min_waves(int threads, int tsize) { return tsize == 4 && threads >= 256 ? threads / 128 : 1; }
+#ifndef SSFM_MIN_WAVES_256
+#define SSFM_MIN_WAVES_256 2
+#endif
+__host__ __device__ constexpr int min_waves(int threads, int tsize) { return tsize == 4 && threads >= 256 ? (threads == 256 ? SSFM_MIN_WAVES_256 : threads / 128) : 1; }
 
 template <typename T, int N1, int C, int E, int MODE>
 __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void k_time(const TimeArgs<T> a) {
@@ -412,6 +415,24 @@ __global__ void k_make_freq_table(const cx<T>* __restrict__ src, cx<T>* __restri
         d.y = (e * (T)s) * inv_n;
     }
     out[o] = d;
+}
+// DM transfer function (reference devices.py:1025-1027): H_k = exp(1j * w_k^2 * D / 2), w_k = fftfreq(n, dt)[k] * 2 * pi,
+// every product in float64 in the reference's order.  Writes H/N in the transposed order and, if
+// `nat` != nullptr, H in natural order.
+template <typename T>
+__global__ void k_make_dm_table(cx<T>* __restrict__ perm, cx<T>* __restrict__ nat, int N1, int N2, double val, double D, T inv_n) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long N = (long long)N1 * N2;
+    if (o >= N) return;
+    const long long k1 = o / N2, k2 = o % N2;
+    const long long k = k1 + (long long)N1 * k2;
+    const long long ks = k < (N + 1) / 2 ? k : k - N;          // numpy.fft.fftfreq integer grid
+    const double w = ((double)ks * val) * 2.0 * 3.141592653589793;
+    const double ph = ((w * w) * D) / 2.0;
+    double s, c;
+    sincos(ph, &s, &c);
+    perm[o] = mk<T>((T)c * inv_n, (T)s * inv_n);
+    if (nat != nullptr) nat[k] = mk<T>((T)c, (T)s);
 }
 // natural[k1 + N1*k2] = perm[k1*N2 + k2]   (debug: spectrum back to natural order)
 template <typename T>

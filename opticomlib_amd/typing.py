@@ -101,10 +101,10 @@ class optical_signal:
             else:
                 noise = signal.noise
             signal = signal.signal
-        sig = np.array(signal)
+        sig = np.asarray(signal)
         noi = noise
         if noi is not NULL:
-            noi = np.array(noi)
+            noi = np.asarray(noi)
             common = np.result_type(sig, noi) if dtype is None else dtype
             sig, noi = sig.astype(common), noi.astype(common)
             if sig.shape != noi.shape:

@@ -129,7 +129,8 @@ def test_dm_golden(golden_dir, name):
     r = oa.DM(x, **case["kw"])
     if case["kw"].get("retH"):
         y, H = r
-        np.testing.assert_array_equal(H, g["H"])
+        assert H.dtype == np.complex128 and H.shape == g["H"].shape
+        np.testing.assert_allclose(H, g["H"], rtol=0, atol=1e-15)     # H is generated on the device (sincos within 1 ulp)
     else:
         y = r
     assert y.signal.dtype == np.complex128 and y.n_pol == x.n_pol
