@@ -113,6 +113,15 @@ int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host);
  * natural-order H (n complex, precision's type, HOST) is returned as well (for retH). */
 int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out);
 
+/* Zero-phase IIR filtering with a cascade of second-order sections = scipy.signal.sosfiltfilt(sos, x,
+ * axis=-1) (odd padding of 3*ntaps samples, steady-state initial conditions): the arithmetic of the
+ * reference's LPF (devices.py:1363-1368) and BPF (devices.py:814-823).  Plan-less.
+ *   sos  n_sections x 6 float64 (b0 b1 b2 a0 a1 a2, a0 == 1), HOST;  1 <= n_sections <= 4
+ *   zi   n_sections x 2 float64 = scipy.signal.sosfilt_zi(sos), HOST
+ *   x,y  HOST, batch x n float64 (is_complex = 0) or complex128 interleaved (is_complex = 1); y may alias x */
+int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
+                     int64_t n, int batch, int is_complex);
+
 /* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);
 

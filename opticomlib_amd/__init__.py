@@ -5,9 +5,9 @@ Drop-in for ``opticomlib.devices.FIBER`` / ``DBP`` / ``DM`` (and the slice of
 The arithmetic runs in hand-written HIP kernels (``csrc/``) behind the C ABI declared in
 ``include/ssfm_amd.h``.
 """
-from .typing import NULL, gv, optical_signal
-from .devices import DBP, DM, FIBER
+from .typing import NULL, electrical_signal, gv, optical_signal
+from .devices import BPF, DBP, DM, FIBER, LPF
 from ._lib import C64, C128, Plan, SsfmError, device_count
 
-__all__ = ["NULL", "gv", "optical_signal", "FIBER", "DBP", "DM", "Plan", "SsfmError", "device_count", "C64", "C128"]
+__all__ = ["NULL", "gv", "optical_signal", "electrical_signal", "FIBER", "DBP", "DM", "LPF", "BPF", "Plan", "SsfmError", "device_count", "C64", "C128"]
 __version__ = "0.1.0"

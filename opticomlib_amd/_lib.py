@@ -34,6 +34,7 @@ SYMBOLS = {
     "ssfm_propagate_adaptive": (_I, [_VP, _D, _D, _D, _I, _I64, C.POINTER(_I64), C.POINTER(_D), _VP]),
     "ssfm_apply_transfer": (_I, [_VP, _VP]),
     "ssfm_apply_dispersion": (_I, [_VP, _D, _D, _VP]),
+    "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
@@ -91,6 +92,21 @@ def supported_log2n(precision=C64):
 
 def _ptr(a: np.ndarray):
     return C.c_void_p(a.ctypes.data)
+
+
+def sosfiltfilt(sos: np.ndarray, zi: np.ndarray, x: np.ndarray, device: int = 0) -> np.ndarray:
+    """Zero-phase SOS filtering of the last axis of ``x`` (float64 or complex128) on the GPU."""
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    zi = np.ascontiguousarray(zi, dtype=np.float64)
+    x = np.asarray(x)
+    is_c = np.iscomplexobj(x)
+    xs = np.ascontiguousarray(x, dtype=np.complex128 if is_c else np.float64)
+    n = xs.shape[-1]
+    batch = int(xs.size // n) if n else 0
+    y = np.empty_like(xs)
+    _check(load().ssfm_sosfiltfilt(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _ptr(xs), _ptr(y), n, batch, int(is_c)),
+           "ssfm_sosfiltfilt")
+    return y
 
 
 class Plan:

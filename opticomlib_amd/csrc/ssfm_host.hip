@@ -11,29 +11,12 @@
 #include <vector>
 
 #include "ssfm_amd.h"
+#include "ssfm_common.hpp"
 #include "ssfm_kernels.hpp"
 
 using namespace ssfm;
 
 namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(SSFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
-                        __FILE__, __LINE__);                                                  \
-    } while (0)
 
 constexpr int kLog2Min = 8, kLog2Max = 20;
 constexpr int kColsPerTile = 16;   // C: 128 B (c64) / 256 B (c128) contiguous per row segment

@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from .typing import NULL, optical_signal
+from .typing import NULL, electrical_signal, gv, optical_signal
 
 _F32 = np.float32
 _PLANS: "OrderedDict[tuple, _lib.Plan]" = OrderedDict()
@@ -250,5 +250,59 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
     output = optical_signal(out_sig, out_noise, n_pol=input.n_pol)
     if retH:
         return output, np.fft.fftshift(H)
+    output.execution_time = time.time() - t0
+    return output
+
+
+# ------------------------------------------------------------------ LPF / BPF
+def _bessel_sos(n, cutoff_hz, fs):
+    """Filter DESIGN (O(order) host work, identical call to the reference's): Bessel low-pass as
+    second-order sections, magnitude-normalised, plus the steady-state initial conditions."""
+    from scipy import signal as sg
+    sos = sg.bessel(N=n, Wn=cutoff_hz, btype="low", fs=fs, output="sos", norm="mag")
+    return sos, sg.sosfilt_zi(sos)
+
+
+def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, device=None):
+    """Electrical low-pass filter: ``n``-th order Bessel, zero phase (``sosfiltfilt``), cutoff ``BW``
+    [Hz]; reference ``devices.py:1286-1375``.  ``input``: 1-D array or :class:`electrical_signal`;
+    signal and noise are filtered separately and the real part is kept.  With ``retH`` also returns
+    ``fftshift`` of the frequency response over ``input.size`` points."""
+    t0 = time.time()
+    if not isinstance(input, electrical_signal):
+        input = electrical_signal(input)
+    if input.ndim != 1:
+        raise ValueError("`input` must be a 1D-array.")
+    if not fs:
+        fs = gv.fs
+    sos, zi = _bessel_sos(n, BW, fs)
+    dev = default_device() if device is None else int(device)
+    # real coefficients: Re(filter(x)) == filter(Re(x)), so only the real channel is computed
+    has_noise = input.noise is not NULL
+    rows = [np.real(input.signal)] + ([np.real(input.noise)] if has_noise else [])
+    res = _lib.sosfiltfilt(sos, zi, np.stack(rows).astype(np.float64), dev)
+    output = electrical_signal(res[0], res[1] if has_noise else NULL)
+    if retH:
+        from scipy import signal as sg
+        _, H = sg.sosfreqz(sos, worN=input.size, fs=fs, whole=True)
+        return output, np.fft.fftshift(H)
+    output.execution_time = time.time() - t0
+    return output
+
+
+def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
+    """Optical band-pass filter: Bessel low-pass of cutoff ``BW/2`` on the complex envelope, zero phase;
+    reference ``devices.py:788-826``.  Signal and noise are filtered separately."""
+    t0 = time.time()
+    if not isinstance(input, optical_signal):
+        raise TypeError("`input` must be of type (optical_signal).")
+    sos, zi = _bessel_sos(n, BW / 2, gv.fs)
+    dev = default_device() if device is None else int(device)
+    sig = np.asarray(input.signal)
+    has_noise = input.noise is not NULL
+    stack = np.stack([sig] + ([np.asarray(input.noise)] if has_noise else []))
+    cplx = np.iscomplexobj(stack)
+    res = _lib.sosfiltfilt(sos, zi, stack.astype(np.complex128 if cplx else np.float64), dev)
+    output = optical_signal(res[0], res[1] if has_noise else NULL, n_pol=input.n_pol)
     output.execution_time = time.time() - t0
     return output

@@ -90,6 +90,52 @@ class _GlobalVars:
 gv = _GlobalVars()
 
 
+class electrical_signal:
+    """1-D electrical signal with optional noise (the slice ``LPF`` needs of reference
+    ``typing.py:1022-1165``)."""
+
+    def __init__(self, signal, noise=NULL, dtype=None):
+        if isinstance(signal, electrical_signal):
+            noise = signal.noise if noise is NULL else np.asarray(noise) + signal.noise
+            signal = signal.signal
+        sig = np.asarray(signal)
+        noi = noise
+        if noi is not NULL:
+            noi = np.asarray(noi)
+            common = np.result_type(sig, noi) if dtype is None else dtype
+            sig, noi = sig.astype(common), noi.astype(common)
+            if sig.shape != noi.shape:
+                raise ValueError(f"`signal` and `noise` must have the same shape, mismatch shapes {sig.shape} and {noi.shape}!")
+        elif dtype is not None:
+            sig = sig.astype(dtype)
+        if sig.ndim > 1 or sig.size < 1:
+            raise ValueError(f"Signal must be scalar or 1D array for electrical_signal, invalid shape {sig.shape}")
+        if sig.ndim == 0:
+            sig = sig[np.newaxis]
+            if noi is not NULL:
+                noi = noi[np.newaxis]
+        self.signal = sig
+        self.noise = noi
+        self.execution_time = 0.0
+
+    @property
+    def size(self) -> int:
+        return self.signal.size
+
+    @property
+    def ndim(self) -> int:
+        return self.signal.ndim
+
+    def __len__(self):
+        return self.size
+
+    def to_numpy(self) -> np.ndarray:
+        return np.asarray(self.signal + self.noise)
+
+    def __repr__(self):
+        return f"electrical_signal(size={self.size}, dtype={self.signal.dtype}, noise={'NULL' if self.noise is NULL else 'array'})"
+
+
 class optical_signal:
     """Optical field container: ``signal`` (and optional ``noise``) of shape ``(N,)`` for one
     polarisation or ``(2, N)`` for two."""

@@ -98,6 +98,19 @@ CASES = {
                           kw=dict(D=4000.0, retH=True)),
     "dm_1pol_8k": dict(func="DM", gv=GV_B, inp=("qpsk", 22, (8192,), "complex128", 0.03),
                        kw=dict(D=-21.7 * 80)),
+    # zero-phase Bessel filters (reference devices.py:1286-1375 LPF, :788-826 BPF)
+    "lpf_real_4k": dict(func="LPF", gv=GV_A, inp=("qpsk", 40, (4096,), "float64", 0.03),
+                        kw=dict(BW=10e9)),
+    "lpf_noise_n2_retH": dict(func="LPF", gv=GV_A, inp=("qpsk", 41, (2048,), "float64", 0.03),
+                              noise=("noise", 42, (2048,), "float64", 0.003), kw=dict(BW=5e9, n=2, retH=True)),
+    "lpf_complex_in_n6": dict(func="LPF", gv=GV_B, inp=("noise", 43, (8192,), "complex128", 0.03),
+                              kw=dict(BW=40e9, n=6)),
+    "bpf_2pol_4k": dict(func="BPF", gv=GV_A, inp=("noise", 44, (2, 4096), "complex128", 0.03),
+                        noise=("noise", 45, (2, 4096), "complex128", 0.003), kw=dict(BW=40e9)),
+    "bpf_1pol_8k": dict(func="BPF", gv=GV_B, inp=("qpsk", 46, (8192,), "complex128", 0.03),
+                        kw=dict(BW=50e9, n=4)),
+    "bpf_2pol_n3_3000": dict(func="BPF", gv=GV_B, inp=("noise", 47, (2, 3000), "complex128", 0.03),
+                             kw=dict(BW=100e9, n=3)),
     # float64 twin loop (reference devices.py:2425-2486), 1 polarisation only
     "twin_f64_1pol": dict(func="TWIN", gv=GV_A, inp=("noise", 30, (4096,), "complex128", 0.03),
                           kw=dict(length=10, h=1.0, **FIB)),

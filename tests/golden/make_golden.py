@@ -41,7 +41,9 @@ def run_case(name, case, devices, typing):
     sig, noi = case_input(case)
     kw = dict(case["kw"])
     func = case["func"]
-    if noi is None:
+    if func == "LPF":
+        x = None
+    elif noi is None:
         x = typing.optical_signal(sig)
     else:
         x = typing.optical_signal(sig, noi)
@@ -70,6 +72,22 @@ def run_case(name, case, devices, typing):
             out["H"] = H
         else:
             y = r
+        out["out"] = y.signal
+        if y.noise is not typing.NULL:
+            out["out_noise"] = y.noise
+    elif func == "LPF":
+        xe = typing.electrical_signal(sig) if noi is None else typing.electrical_signal(sig, noi)
+        r = devices.LPF(xe, **kw)
+        if kw.get("retH"):
+            y, H = r
+            out["H"] = H
+        else:
+            y = r
+        out["out"] = y.signal
+        if y.noise is not typing.NULL:
+            out["out_noise"] = y.noise
+    elif func == "BPF":
+        y = devices.BPF(x, **kw)
         out["out"] = y.signal
         if y.noise is not typing.NULL:
             out["out_noise"] = y.noise

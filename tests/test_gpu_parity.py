@@ -310,3 +310,65 @@ def test_full_size_c128_100_steps_roundtrip_structure():
     y = oa.FIBER(optical_signal(a), precision="complex128", **kw)
     back = oa.DBP(y, precision="complex128", **kw).signal
     assert 1e-7 < relmax(back, a) < 5e-2
+
+
+# ----------------------------------------------------------------------- LPF / BPF
+TOL_FILT = 1e-11      # float64 recursion; chunked start states differ from the serial loop at the 1e-16 level
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] in ("LPF", "BPF")])
+def test_bessel_filters_golden(golden_dir, name):
+    from opticomlib_amd.typing import electrical_signal
+    case = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    gv(**case["gv"])
+    sig, noi = case_input(case)
+    kw = dict(case["kw"])
+    if case["func"] == "LPF":
+        x = electrical_signal(sig) if noi is None else electrical_signal(sig, noi)
+        r = oa.LPF(x, **kw)
+        if kw.get("retH"):
+            y, H = r
+            np.testing.assert_allclose(H, g["H"], rtol=1e-12, atol=1e-15)
+        else:
+            y = r
+        assert isinstance(y, electrical_signal) and y.signal.dtype == np.float64
+    else:
+        x = optical_signal(sig) if noi is None else optical_signal(sig, noi)
+        y = oa.BPF(x, **kw)
+        assert isinstance(y, optical_signal) and y.n_pol == x.n_pol and y.signal.dtype == np.complex128
+    assert y.signal.shape == g["out"].shape
+    assert relmax(y.signal, g["out"]) < TOL_FILT
+    if "out_noise" in g:
+        assert relmax(y.noise, g["out_noise"]) < TOL_FILT
+    else:
+        assert y.noise is NULL
+
+
+def test_bessel_filters_full_size_against_oracle_and_scipy():
+    """2^20 x 2 complex BPF and 2^20 real LPF: the restated loop (oracle) on a 2^14 slice-sized case and
+    SciPy's own sosfiltfilt (the reference's dependency) at full size."""
+    from scipy import signal as sg
+    from oracle import filters_numpy as fo
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 20, seed=77)
+    y = oa.BPF(optical_signal(a), BW=60e9).signal
+    sos, zi = fo.bessel_sos(4, 30e9, gv.fs)
+    assert relmax(y, sg.sosfiltfilt(sos, a, axis=-1)) < TOL_FILT
+    p = np.abs(a[0]) ** 2
+    z = oa.LPF(p, BW=20e9).signal
+    sos, zi = fo.bessel_sos(4, 20e9, gv.fs)
+    assert relmax(z, sg.sosfiltfilt(sos, p)) < TOL_FILT
+    b = workloads.qpsk_field(1 << 14, seed=78)
+    out, _ = fo.bpf(b, 60e9, gv.fs)
+    assert relmax(oa.BPF(optical_signal(b), BW=60e9).signal, out) < TOL_FILT
+
+
+def test_bessel_filter_errors():
+    gv(sps=16, R=10e9)
+    with pytest.raises(TypeError, match=r"`input` must be of type \(optical_signal\)."):
+        oa.BPF(np.ones(64), 1e9)
+    with pytest.raises(ValueError, match="1D"):            # raised by the electrical_signal constructor, as in the reference
+        oa.LPF(np.ones((2, 64)), 1e9)
+    with pytest.raises(oa.SsfmError, match="greater than padlen"):
+        oa.LPF(np.ones(10), 1e9)

@@ -146,3 +146,17 @@ class TestOpticalSignal:
         gv(fs=8e9)
         assert gv.R == 1e9 and gv.sps == 8
         gv.default()
+
+
+def test_electrical_signal_and_filter_argument_errors():
+    from opticomlib_amd.typing import electrical_signal
+    x = electrical_signal([1, 2, 3], [0, 0, 1])
+    assert x.size == 3 and x.ndim == 1 and np.array_equal(x.to_numpy(), [1, 2, 4])
+    assert electrical_signal(2.0).signal.shape == (1,)
+    with pytest.raises(ValueError):
+        electrical_signal(np.ones((2, 3)))
+    with pytest.raises(ValueError):
+        electrical_signal([1, 2, 3], [1, 2])
+    # checked before anything touches the GPU (reference devices.py:811-812, :1355-1356)
+    with pytest.raises(TypeError, match=r"`input` must be of type \(optical_signal\)."):
+        oa.BPF(np.ones(64), 1e9)

@@ -130,3 +130,20 @@ def test_step_schedule_float32():
     assert len(orc.step_schedule_c64(1000, 1.0)) == 1000
     s = orc.step_schedule_c64(2, 0.3)
     assert len(s) == 7 and s[-1] < s[0]
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] in ("LPF", "BPF")])
+def test_bessel_filters_match_reference(golden_dir, name):
+    """LPF / BPF: restated sosfiltfilt (oracle/filters_numpy.py) vs outputs of the imported reference."""
+    from oracle import filters_numpy as fo
+    case = CASES[name]
+    g = _load(golden_dir, name)
+    exact = _same_numpy(g)
+    sig, noi = case_input(case)
+    fs = case["gv"]["sps"] * case["gv"]["R"]
+    kw = case["kw"]
+    fn = fo.lpf if case["func"] == "LPF" else fo.bpf
+    out, out_n = fn(sig, kw["BW"], fs, n=kw.get("n", 4), noise=noi)
+    _check(out, g["out"], exact, 1e-13)
+    if noi is not None:
+        _check(out_n, g["out_noise"], exact, 1e-13)
