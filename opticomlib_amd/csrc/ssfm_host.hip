@@ -126,6 +126,7 @@ template <typename T> struct PlanT : PlanBase {
     static constexpr int kMaxLanes = 8;
     int nlanes = 1;
     int E = 16;                // points per thread (env SSFM_E = 8 | 16)
+    bool stagger = false;      // env SSFM_STAGGER
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
     hipEvent_t fork_ev = nullptr;
@@ -223,6 +224,7 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipEventCreate(&ev1));
         E = 16;                    // measured: E = 8 (twice the waves, one more exchange) is 10 % slower
         if (const char* e = std::getenv("SSFM_E")) E = std::atoi(e) == 16 ? 16 : 8;
+        if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
         int want = 2;
         if (const char* e = std::getenv("SSFM_LANES")) want = std::atoi(e);
         nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
@@ -353,6 +355,12 @@ template <typename T> struct PlanT : PlanBase {
                 ++last_launches;
                 HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows), E)));
                 if (int rc = prof_mark(0, g)) return rc;
+                // stagger: lane g+1 starts once lane g has finished its first kernel, so that the lanes
+                // run DIFFERENT kernels at any time (one computes while the other streams)
+                if (stagger && g + 1 < nlanes) {
+                    HIP_TRY(hipEventRecord(fork_ev, lane_stream[g]));
+                    HIP_TRY(hipStreamWaitEvent(lane_stream[g + 1], fork_ev, 0));
+                }
             }
             for (int64_t s = 0; s < nsteps; ++s) {
                 for (int g = 0; g < nlanes; ++g) {

@@ -179,7 +179,7 @@ def FIBER(input: optical_signal,
                 _chain_fixed(plan, gamma, chunk)
                 plan.synchronize()
                 done += chunk.size
-                bar.update(100.0 * float(chunk.sum()) / float(L))
+                bar.update(min(100.0 * float(chunk.sum()) / float(L), max(0.0, 100.0 - bar.n)))
                 bar.set_postfix(FFTs=2 * done)
         elif steps:
             plan.propagate_fixed(gamma, hs)

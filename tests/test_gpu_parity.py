@@ -372,3 +372,83 @@ def test_bessel_filter_errors():
         oa.LPF(np.ones((2, 64)), 1e9)
     with pytest.raises(oa.SsfmError, match="greater than padlen"):
         oa.LPF(np.ones(10), 1e9)
+
+
+# ----------------------------------------------------------------------- API behaviour on the device
+def test_call_order_and_argument_errors():
+    p = _lib.Plan(4096, 2, _lib.C64)
+    try:
+        with pytest.raises(oa.SsfmError, match="ssfm_set_linear_operator first"):
+            p.propagate_fixed(1.3, np.ones(3, np.float32))
+        p.set_linear_operator(np.zeros(4096, np.complex64))
+        with pytest.raises(oa.SsfmError, match="must be finite and > 0"):
+            p.propagate_fixed(1.3, np.array([1.0, 0.0], np.float32))
+        with pytest.raises(ValueError):
+            p.set_linear_operator(np.zeros(100, np.complex64))
+    finally:
+        p.close()
+    with pytest.raises(oa.SsfmError, match="power of two"):
+        _lib.Plan(3000, 2, _lib.C64)
+    with pytest.raises(oa.SsfmError, match="not available"):
+        _lib.Plan(4096, 2, _lib.C64, device=99)
+
+
+def test_many_rows_equal_separate_runs():
+    """Rows never interact in fixed-step mode: 3 fields (6 rows, two lanes of 3) propagated in one plan
+    are bit-identical to 3 separate dual-pol calls; the plan/operator cache survives parameter changes."""
+    gv(**workloads.BENCH_GV)
+    n = 1 << 14
+    fields = [workloads.prbs_field(n, seed=s) for s in (1, 2, 3)]
+    kw = dict(length=6, h=0.5, **workloads.SMF)
+    sep = [oa.FIBER(optical_signal(f), **kw).signal for f in fields]
+    other = oa.FIBER(optical_signal(fields[0]), length=3, h=0.5, alpha=0.1, beta_2=-5.0, gamma=2.0).signal
+    again = oa.FIBER(optical_signal(fields[0]), **kw).signal
+    np.testing.assert_array_equal(again, sep[0])
+    assert relmax(other, sep[0]) > 1e-3
+    hs, _ = oa.devices.step_schedule(6, 0.5)
+    p = _lib.Plan(n, 6, _lib.C64)
+    try:
+        p.set_linear_operator(oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13))
+        p.set_field(np.concatenate(fields).astype(np.complex64))
+        p.propagate_fixed(1.3, hs)
+        out = p.get_field().reshape(3, 2, n)
+    finally:
+        p.close()
+    for k in range(3):
+        np.testing.assert_array_equal(out[k], sep[k])
+
+
+def test_fiber_then_dbp_prbs_realisations_against_oracle():
+    """Configuration C4 in miniature: FIBER(100 x 1 km) then DBP on LFSR-PRBS realisations; parity is
+    against the reference-semantics DBP output (the stale-N^ round trip is not the identity)."""
+    gv(**workloads.BENCH_GV)
+    kw = dict(length=20, h=1.0, **workloads.SMF)
+    for seed in (1, 2):
+        a = workloads.prbs_field(1 << 14, seed=seed, power_w=4e-3)
+        y = oa.FIBER(optical_signal(a), **kw)
+        x_hat = oa.DBP(y, **kw).signal
+        ref = orc.dbp_c64(orc.fiber_c64(a, gv.dt, **kw), gv.dt, **kw)
+        assert relmax(x_hat, ref) < TOL_100
+        assert relmax(x_hat, a.astype(np.complex64)) > 10 * relmax(x_hat, ref)
+
+
+def test_progress_bar_path_agrees():
+    """show_progress splits the run into chunks at sync points; at a chunk seam the two nonlinear half
+    rotations are applied separately instead of merged, so agreement is to rounding, not bitwise."""
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 13, seed=9)
+    kw = dict(length=30, h=0.3, **workloads.SMF)
+    y0 = oa.FIBER(optical_signal(a), **kw).signal
+    y1 = oa.FIBER(optical_signal(a), show_progress=True, **kw).signal
+    assert relmax(y1, y0) < 1e-5
+
+
+def test_zero_and_negative_length_return_the_cast_input():
+    """reference: the loop `while z < length` never runs (devices.py:1172) and the input comes back as complex64."""
+    gv(sps=16, R=10e9)
+    a = workloads.qpsk_field(1 << 10, seed=4)
+    for L in (0.0, -5.0):
+        y = oa.FIBER(optical_signal(a), length=L, h=1.0, alpha=0.2, beta_2=-20, gamma=2).signal
+        np.testing.assert_array_equal(y, a.astype(np.complex64))
+        z, A_z = oa.FIBER(optical_signal(a), length=L, h=1.0, gamma=2, return_steps=True)
+        assert z.tolist() == [0.0] and A_z.shape == (1, 2, 1 << 10)
