@@ -90,6 +90,19 @@ __device__ __forceinline__ void sincos_reduced(float r, int q, float& s, float& 
     c = ((q + 1) & 2) ? -b : b;
 }
 constexpr float kSincosSmallMax = 65000.0f;
+constexpr float kSincosTinyMax = 0.78f;       // |x| <= pi/4: the kernels apply without any reduction
+// |x| <= pi/4 (every nonlinear phase of a sane split-step run): no reduction, no quadrant select
+__device__ __forceinline__ void sincos_tiny(float r, float& s, float& c) {
+    const float z = r * r;
+    float ps = fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f);
+    ps = fmaf(z, ps, 8.3333293858894631756e-3f);
+    ps = fmaf(z, ps, -1.66666666416265235595e-1f);
+    s = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f);
+    pc = fmaf(z, pc, 4.16666233237390631894e-2f);
+    pc = fmaf(z, pc, -4.99999997251031003120e-1f);
+    c = fmaf(z, pc, 1.0f);
+}
 template <bool BIG> __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
     float r;
     int q;
@@ -112,10 +125,18 @@ template <bool BIG> __device__ __forceinline__ void sincos_f32(float x, float& s
 }
 // rotate E values by their phases
 template <int E> __device__ __forceinline__ void rotate_all(cf32 (&v)[E], const float (&phi)[E]) {
-    bool big = false;
+    float amax = 0.0f;
 #pragma unroll
-    for (int t = 0; t < E; ++t) big = big || !(fabsf(phi[t]) <= kSincosSmallMax);
-    if (__builtin_expect(big, 0)) {
+    for (int t = 0; t < E; ++t) amax = fmaxf(amax, fabsf(phi[t]));
+    const bool big = !(amax <= kSincosSmallMax);           // also true for NaN
+    if (__builtin_expect(amax <= kSincosTinyMax, 1)) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            float s, c;
+            sincos_tiny(phi[t], s, c);
+            v[t] = cmul(v[t], mk<float>(c, s));
+        }
+    } else if (__builtin_expect(big, 0)) {
 #pragma unroll
         for (int t = 0; t < E; ++t) {
             float s, c;
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     const int j = tid % Q;
     const int rr = tid / Q;
     const long long row = (long long)blockIdx.x * ROWS + rr;     // over batch*N1 rows
-    const int k1 = (int)(row % a.N1);
+    const int k1 = (int)(row & (a.N1 - 1));            // N1 is a power of two
     cx<T>* __restrict__ Frow = a.F + row * N2;
     const cx<T>* __restrict__ trow = a.tab + (long long)k1 * N2;
     using RI = RowIdx<row_pad_shift(E)>;

@@ -9,7 +9,7 @@ if [ "$1" = build ]; then
   mkdir -p $OUT
   for v in $VARIANTS; do
     name=${v%%:*}; flags=$(echo ${v#*:} | tr '@' ' ')
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include $flags -o $OUT/_ssfm_$name.so $ROOT/opticomlib_amd/csrc/ssfm_host.hip 2>/dev/null; echo built $name ) &
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include $flags -o $OUT/_ssfm_$name.so $ROOT/opticomlib_amd/csrc/ssfm_host.hip $ROOT/opticomlib_amd/csrc/sos_filter.hip 2>/dev/null; echo built $name ) &
   done; wait
 else
   for r in 1 2; do for v in $VARIANTS; do
