@@ -43,7 +43,7 @@ hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
 }
 template <typename T, int MODE, int E>
 hipError_t launch_time_e(int N1, int batch, hipStream_t s, const TimeArgs<T>& a) {
-    const dim3 grid(a.N2 / kColsPerTile, batch);
+    const dim3 grid((unsigned)(a.N2 / kColsPerTile) * batch);
     switch (N1) {
         case 16:  return launch_time_n1<T, MODE, 16, E>(grid, s, a);
         case 32:  return launch_time_n1<T, MODE, 32, E>(grid, s, a);
@@ -54,7 +54,8 @@ hipError_t launch_time_e(int N1, int batch, hipStream_t s, const TimeArgs<T>& a)
     return hipErrorInvalidValue;
 }
 template <typename T, int MODE>
-hipError_t launch_time(int N1, int batch, hipStream_t s, const TimeArgs<T>& a, int E) {
+hipError_t launch_time(int N1, int batch, hipStream_t s, TimeArgs<T> a, int E) {
+    a.rows = batch;
     return E == 8 ? launch_time_e<T, MODE, 8>(N1, batch, s, a) : launch_time_e<T, MODE, 16>(N1, batch, s, a);
 }
 
@@ -83,7 +84,8 @@ hipError_t launch_freq_e(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a)
     return hipErrorInvalidValue;
 }
 template <typename T, int MODE>
-hipError_t launch_freq(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a, int E) {
+hipError_t launch_freq(int N2, int nrows, hipStream_t s, FreqArgs<T> a, int E) {
+    a.rows = nrows / a.N1;
     return E == 8 ? launch_freq_e<T, MODE, 8>(N2, nrows, s, a) : launch_freq_e<T, MODE, 16>(N2, nrows, s, a);
 }
 
@@ -293,12 +295,12 @@ template <typename T> struct PlanT : PlanBase {
     TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s, int row0 = 0) const {
         TimeArgs<T> a;
         a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.gamma = gamma;
-        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2;
+        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0;
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0) const {
         FreqArgs<T> a;
-        a.F = F + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1;
+        a.F = F + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0;
         return a;
     }
 

@@ -54,6 +54,21 @@ template <typename T> struct AdaptState {
     unsigned long long maxbits;   // bit pattern of max |A|^2 (non-negative => monotone as integer)
 };
 
+// Block id -> (unit, row) so that the `rows` blocks working on the same unit (column tile / spectrum
+// row) share its read-only table through ONE XCD's L2: blocks are dealt round-robin over the 8 XCDs
+// (id % 8 labels the group, MI355X_MICROARCH.md), so the rows of a unit take consecutive slots of one
+// group.  Pure speed: any mapping that is a bijection is correct.
+__device__ __forceinline__ void xcd_unit_row(unsigned id, int units, int rows, int& unit, int& row) {
+    if ((units & 7) == 0) {
+        const unsigned xcd = id & 7, slot = id >> 3;
+        unit = (int)((slot / rows) * 8 + xcd);
+        row = (int)(slot % rows);
+    } else {
+        unit = (int)(id % units);
+        row = (int)(id / units);
+    }
+}
+
 template <typename T> struct TimeArgs {
     cx<T>* F;                 // field, batch rows of N
     T* P;                     // stale |A|^2, tile-major (private to k_time)
@@ -66,6 +81,7 @@ template <typename T> struct TimeArgs {
     T hh_prev;                // h/2 of the step being finished
     T hh_next;                // h/2 of the step being started
     int N2;
+    int rows;                 // rows covered by this launch (grid = N2/C * rows blocks)
 };
 
 // sin/cos of the nonlinear phase.  float: Cody-Waite reduction by pi/2 (three fma terms whose sum
@@ -214,14 +230,16 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     const int c = tid % C;
     const int j = tid / C;
     const long long N = (long long)N1 * a.N2;
+    int tile, brow;
+    xcd_unit_row(blockIdx.x, a.N2 / C, a.rows, tile, brow);
     // wave-uniform bases (SGPRs) + one 32-bit lane offset
-    cx<T>* __restrict__ Fb = a.F + (long long)blockIdx.y * N + (long long)blockIdx.x * C;
+    cx<T>* __restrict__ Fb = a.F + (long long)brow * N + (long long)tile * C;
     // |A|^2 is private to this kernel (written and read back by the same thread of the same tile),
     // so it is stored tile-major as 4 x (4 values per thread): 16-byte accesses, 1 KiB per wave.
     typedef T p4_t __attribute__((ext_vector_type(4)));
-    p4_t* __restrict__ Pb = reinterpret_cast<p4_t*>(a.P + (long long)blockIdx.y * N + (long long)blockIdx.x * (N1 * C)) + tid;
+    p4_t* __restrict__ Pb = reinterpret_cast<p4_t*>(a.P + (long long)brow * N + (long long)tile * (N1 * C)) + tid;
     constexpr int PSTR = N1 * C / E;      // threads per tile
-    const cx<T>* __restrict__ Wb = a.twN + (long long)blockIdx.x * C;
+    const cx<T>* __restrict__ Wb = a.twN + (long long)tile * C;
     const int off = j * a.N2 + c;
     const int stride = Q * a.N2;
     const ColIdx<C> idx{c};
@@ -237,8 +255,8 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
     // the tile's 16 x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
-    for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(e / C) * (blockIdx.x * C + (e % C))];
-    const cx<T> wA = a.twA[j * (blockIdx.x * C + c)];
+    for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(e / C) * (tile * C + (e % C))];
+    const cx<T> wA = a.twA[j * (tile * C + c)];
 #else
 #pragma unroll
     for (int t = 0; t < E; ++t) w[t] = SSFM_ABL_NO_TWN ? mk<T>((T)1, (T)0) : Wb[off + t * stride];
@@ -327,6 +345,7 @@ template <typename T> struct FreqArgs {
     T h;                     // FM_FLY with st == nullptr
     T inv_n;
     int N1;
+    int rows;                // batch rows covered by this launch
 };
 
 template <typename T> __device__ __forceinline__ T exp_acc(T x);
@@ -347,8 +366,11 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     const int tid = threadIdx.x;
     const int j = tid % Q;
     const int rr = tid / Q;
-    const long long row = (long long)blockIdx.x * ROWS + rr;     // over batch*N1 rows
-    const int k1 = (int)(row & (a.N1 - 1));            // N1 is a power of two
+    // block -> (group of ROWS consecutive k1, batch row); batch rows of one k1 group share an XCD
+    int kgrp, brow;
+    xcd_unit_row(blockIdx.x, a.N1 / ROWS, a.rows, kgrp, brow);
+    const int k1 = kgrp * ROWS + rr;
+    const long long row = (long long)brow * a.N1 + k1;
     cx<T>* __restrict__ Frow = a.F + row * N2;
     const cx<T>* __restrict__ trow = a.tab + (long long)k1 * N2;
     using RI = RowIdx<row_pad_shift(E)>;
