@@ -341,19 +341,44 @@ template <typename T> struct PlanT : PlanBase {
         const long long nA = (long long)(N1 / 16) * N2, nB = 16ll * N2;
         HIP_TRY(hipMalloc(&twA, cb * nA));
         HIP_TRY(hipMalloc(&twB, cb * nB));
-        HIP_TRY(hipMalloc(&tw1, cb * N1));
-        HIP_TRY(hipMalloc(&tw2, cb * N2));
+        if (int rc = make_line_table(&tw1, N1)) return rc;
+        if (int rc = make_line_table(&tw2, N2)) return rc;
         HIP_TRY(hipMalloc(&dnat, cb * n));
         HIP_TRY(hipMalloc(&dperm, cb * n));
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
-        hipLaunchKernelGGL(k_make_twL<T>, dim3((N1 + 255) / 256), dim3(256), 0, stream, tw1, N1);
-        hipLaunchKernelGGL(k_make_twL<T>, dim3((N2 + 255) / 256), dim3(256), 0, stream, tw2, N2);
         hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2);
         hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, nA, 1ll, (long long)n);
         hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, nB, (long long)(N1 / 16), (long long)n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
+        return SSFM_OK;
+    }
+
+    // stage twiddles of a line of length L in thread-load order (wgfft.hpp "Table layout"), computed
+    // in double on the host and rounded once
+    int make_line_table(cx<T>** out, int L) {
+        const int M = fft_nstages(L, E), Q = L / E;
+        const int slots = fft_tw_slots(L, E);
+        std::vector<cx<T>> tab((size_t)(slots > 0 ? slots : 1) * Q);
+        for (int S = 1; S < M; ++S) {
+            const int R = fft_radix(L, S, E), NB = E / R, base = fft_tw_slot_base(L, S, E);
+            for (int i = 0; i < NB; ++i)
+                for (int u = 1; u < R; ++u)
+                    for (int j = 0; j < Q; ++j) {
+                        const int q = fft_tw_exponent(L, E, S, i, u, j) % L;
+                        // exact octant reduction is unnecessary: |angle| <= 2 pi, double sin/cos err ~1e-16
+                        const double ang = -2.0 * 3.14159265358979323846 * (double)q / (double)L;
+                        cx<T> w; w.x = (T)std::cos(ang); w.y = (T)std::sin(ang);
+                        if (q == 0) { w.x = (T)1; w.y = (T)0; }
+                        if (4 * q == L) { w.x = (T)0; w.y = (T)-1; }
+                        if (2 * q == L) { w.x = (T)-1; w.y = (T)0; }
+                        if (4 * q == 3 * L) { w.x = (T)0; w.y = (T)1; }
+                        tab[(size_t)(base + i * (R - 1) + (u - 1)) * Q + j] = w;
+                    }
+        }
+        HIP_TRY(hipMalloc(out, sizeof(cx<T>) * tab.size()));
+        HIP_TRY(hipMemcpy(*out, tab.data(), sizeof(cx<T>) * tab.size(), hipMemcpyHostToDevice));
         return SSFM_OK;
     }
 

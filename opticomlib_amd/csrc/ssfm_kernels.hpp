@@ -36,6 +36,26 @@
 #define SSFM_TWN_COMPUTE 0
 #endif
 
+// In-kernel cycle stamps for tools/stamp_harness.hip (diagnostic builds only; the product never defines it)
+#ifndef SSFM_STAMPS
+#define SSFM_STAMPS 0
+#endif
+#if SSFM_STAMPS
+extern __device__ unsigned long long* g_stamp_buf;
+#define SSFM_STAMP(i)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (threadIdx.x == 0) {                                                               \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_stamp_buf[blockIdx.x * 16 + (i)] = t_;                                          \
+        }                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#else
+#define SSFM_STAMP(i) do { } while (0)
+#endif
+
 namespace ssfm {
 
 enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2 };
@@ -379,6 +399,7 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     cx<T> v[E];
     cx<T> m[E];
     LineTw<T, N2, E> tw;
+    SSFM_STAMP(0);
 #pragma unroll
     for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
     load_line_twiddles<T, N2, E>(tw, j, a.tw2);
@@ -386,12 +407,18 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
 #pragma unroll
         for (int t = 0; t < E; ++t) m[t] = SSFM_ABL_NO_TAB ? mk<T>(a.inv_n, (T)0) : trow[j + t * Q];
     }
+    SSFM_STAMP(1);
+#if SSFM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SSFM_STAMP(2);
+#endif
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
         for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
         return;
     }
+    SSFM_STAMP(3);
 #pragma unroll
     for (int t = 0; t < E; ++t) {
         cx<T> mm = m[t];
@@ -404,9 +431,15 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
         }
         v[t] = cmul(v[t], mm);
     }
+    SSFM_STAMP(4);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : (lds_double_buffer<T>() ? ((fft_nstages(N2, E) - 1) & 1) : 1)), RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
+    SSFM_STAMP(5);
 #pragma unroll
     for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
+#if SSFM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SSFM_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------ tables

@@ -219,18 +219,29 @@ template <typename T, int L, int E> struct LineTw {
     static constexpr int M = fft_nstages(L, E);
     cx<T> w[M > 1 ? M - 1 : 1][E - 1];
 };
+// Table layout: the twiddles are stored in the order the threads load them, slot-major:
+// entry (slot, j) = W_L^(k u STEP) for thread j, where slot enumerates (stage S >= 1, butterfly i, u >= 1).
+// Lanes with consecutive j then read consecutive entries (one coalesced 512-B access per wave
+// instruction; a gather from the natural W_L^q table cost ~100 cycles of issue per instruction).
+__host__ __device__ constexpr int fft_tw_slot_base(int L, int S, int E) {     // slots before stage S (S >= 1)
+    return S <= 1 ? 0 : fft_tw_slot_base(L, S - 1, E) + (E / fft_radix(L, S - 1, E)) * (fft_radix(L, S - 1, E) - 1);
+}
+__host__ __device__ constexpr int fft_tw_slots(int L, int E) { return fft_tw_slot_base(L, fft_nstages(L, E), E); }
+// exponent q of W_L for (stage S, butterfly i, factor u, thread j)
+__host__ __device__ constexpr int fft_tw_exponent(int L, int E, int S, int i, int u, int j) {
+    return ((j + i * (L / E)) & (fft_ls(L, S, E) - 1)) * u * (L / (fft_ls(L, S, E) * fft_radix(L, S, E)));
+}
+
 template <typename T, int L, int E, int S>
 __device__ __forceinline__ void load_stage_twiddles(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab) {
     constexpr int R  = fft_radix(L, S, E);
     constexpr int NB = E / R;
     constexpr int Q  = L / E;
-    constexpr int LS = fft_ls(L, S, E);
-    constexpr int STEP = L / (LS * R);
+    constexpr int BASE = fft_tw_slot_base(L, S, E);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int k = (j + i * Q) & (LS - 1);
 #pragma unroll
-        for (int u = 1; u < R; ++u) tw.w[S - 1][i * (R - 1) + (u - 1)] = tab[k * u * STEP];
+        for (int u = 1; u < R; ++u) tw.w[S - 1][i * (R - 1) + (u - 1)] = tab[(BASE + i * (R - 1) + (u - 1)) * Q + j];
     }
 }
 template <typename T, int L, int E>
