@@ -35,7 +35,8 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
 template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = kColsPerTile;
-    constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>);
+    constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+                         + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE>, lds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((k_time<T, N1, C, E, MODE>), grid, dim3(N1 * C / E), lds, s, a);
@@ -62,7 +63,8 @@ hipError_t launch_time(int N1, int batch, hipStream_t s, TimeArgs<T> a, int E) {
 template <typename T, int MODE, int N2, int E>
 hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
     constexpr int ROWS = freq_rows(N2, E);
-    constexpr size_t lds = fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0;
+    constexpr size_t lds = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+                         + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, E, MODE>, lds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((k_freq<T, N2, ROWS, E, MODE>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, a);
@@ -358,23 +360,22 @@ template <typename T> struct PlanT : PlanBase {
     // stage twiddles of a line of length L in thread-load order (wgfft.hpp "Table layout"), computed
     // in double on the host and rounded once
     int make_line_table(cx<T>** out, int L) {
-        const int M = fft_nstages(L, E), Q = L / E;
-        const int slots = fft_tw_slots(L, E);
-        std::vector<cx<T>> tab((size_t)(slots > 0 ? slots : 1) * Q);
+        const int M = fft_nstages(L, E);
+        const int total = fft_tw_entries(L, E);
+        std::vector<cx<T>> tab((size_t)(total > 0 ? total : 1));
         for (int S = 1; S < M; ++S) {
-            const int R = fft_radix(L, S, E), NB = E / R, base = fft_tw_slot_base(L, S, E);
+            const int R = fft_radix(L, S, E), NB = E / R, KU = fft_tw_ku(L, S, E), off = fft_tw_offset(L, S, E);
             for (int i = 0; i < NB; ++i)
                 for (int u = 1; u < R; ++u)
-                    for (int j = 0; j < Q; ++j) {
-                        const int q = fft_tw_exponent(L, E, S, i, u, j) % L;
-                        // exact octant reduction is unnecessary: |angle| <= 2 pi, double sin/cos err ~1e-16
+                    for (int ku = 0; ku < KU; ++ku) {
+                        const int q = fft_tw_exponent(L, E, S, i, u, ku) % L;
                         const double ang = -2.0 * 3.14159265358979323846 * (double)q / (double)L;
                         cx<T> w; w.x = (T)std::cos(ang); w.y = (T)std::sin(ang);
                         if (q == 0) { w.x = (T)1; w.y = (T)0; }
                         if (4 * q == L) { w.x = (T)0; w.y = (T)-1; }
                         if (2 * q == L) { w.x = (T)-1; w.y = (T)0; }
                         if (4 * q == 3 * L) { w.x = (T)0; w.y = (T)1; }
-                        tab[(size_t)(base + i * (R - 1) + (u - 1)) * Q + j] = w;
+                        tab[(size_t)off + (size_t)(i * (R - 1) + (u - 1)) * KU + ku] = w;
                     }
         }
         HIP_TRY(hipMalloc(out, sizeof(cx<T>) * tab.size()));

@@ -289,7 +289,9 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     }
-    load_line_twiddles<T, N1, E>(tw, j, a.tw1);
+    cx<T>* ldsT = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0) + (SSFM_TWN_COMPUTE ? E * C : 0);
+    line_twiddles_issue<T, N1, E>(tw, j, a.tw1, ldsT, tid, N1 * C / E);
+    if (fft_tw_lds_entries(N1, E) > 0 && !SSFM_TWN_COMPUTE) __syncthreads();
 #if SSFM_TWN_COMPUTE
     __syncthreads();
     w[0] = wA;
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
 #endif
 
+    line_twiddles_fetch<T, N1, E>(tw, j, ldsT);
     if (MODE != TM_BEGIN) {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmulc(v[t], w[t]);
@@ -402,7 +405,8 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     SSFM_STAMP(0);
 #pragma unroll
     for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
-    load_line_twiddles<T, N2, E>(tw, j, a.tw2);
+    cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
+    line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
     if (MODE != FM_FWD_ONLY) {
 #pragma unroll
         for (int t = 0; t < E; ++t) m[t] = SSFM_ABL_NO_TAB ? mk<T>(a.inv_n, (T)0) : trow[j + t * Q];
@@ -412,6 +416,8 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SSFM_STAMP(2);
 #endif
+    if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
+    line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll

@@ -219,37 +219,72 @@ template <typename T, int L, int E> struct LineTw {
     static constexpr int M = fft_nstages(L, E);
     cx<T> w[M > 1 ? M - 1 : 1][E - 1];
 };
-// Table layout: the twiddles are stored in the order the threads load them, slot-major:
-// entry (slot, j) = W_L^(k u STEP) for thread j, where slot enumerates (stage S >= 1, butterfly i, u >= 1).
-// Lanes with consecutive j then read consecutive entries (one coalesced 512-B access per wave
-// instruction; a gather from the natural W_L^q table cost ~100 cycles of issue per instruction).
-__host__ __device__ constexpr int fft_tw_slot_base(int L, int S, int E) {     // slots before stage S (S >= 1)
-    return S <= 1 ? 0 : fft_tw_slot_base(L, S - 1, E) + (E / fft_radix(L, S - 1, E)) * (fft_radix(L, S - 1, E) - 1);
+// Table layout: the twiddles are stored in the order the threads load them: for stage S >= 1,
+// entry (slot, ku) = W_L^(k u STEP), slot enumerating (butterfly i, factor u >= 1) and ku the thread
+// class: a stage's twiddles depend on the thread only through k = j mod LS, so there are KU = min(LS, Q)
+// classes.  The last stage has KU = Q (every thread its own set): lanes with consecutive j read
+// consecutive entries, one coalesced access per wave instruction (a gather from a natural W_L^q table
+// cost ~100 cycles of issue per instruction).  Earlier stages have few classes (16 for 4096 = 16^3):
+// their (R-1)*KU values go through LDS once per workgroup instead of 15 loads per thread -- the
+// per-thread copies were a quarter of a workgroup's whole load traffic.
+__host__ __device__ constexpr int fft_tw_slots_of(int L, int S, int E) { return (E / fft_radix(L, S, E)) * (fft_radix(L, S, E) - 1); }
+__host__ __device__ constexpr int fft_tw_ku(int L, int S, int E) { return fft_ls(L, S, E) < L / E ? fft_ls(L, S, E) : L / E; }
+__host__ __device__ constexpr int fft_tw_offset(int L, int S, int E) {       // first entry of stage S (S >= 1)
+    return S <= 1 ? 0 : fft_tw_offset(L, S - 1, E) + fft_tw_slots_of(L, S - 1, E) * fft_tw_ku(L, S - 1, E);
 }
-__host__ __device__ constexpr int fft_tw_slots(int L, int E) { return fft_tw_slot_base(L, fft_nstages(L, E), E); }
-// exponent q of W_L for (stage S, butterfly i, factor u, thread j)
-__host__ __device__ constexpr int fft_tw_exponent(int L, int E, int S, int i, int u, int j) {
-    return ((j + i * (L / E)) & (fft_ls(L, S, E) - 1)) * u * (L / (fft_ls(L, S, E) * fft_radix(L, S, E)));
+__host__ __device__ constexpr int fft_tw_entries(int L, int E) { return fft_tw_offset(L, fft_nstages(L, E), E); }
+// a stage whose table is small is staged through LDS (shared by the workgroup's lines too)
+__host__ __device__ constexpr bool fft_tw_via_lds(int L, int S, int E) { return fft_tw_slots_of(L, S, E) * fft_tw_ku(L, S, E) <= 512; }
+__host__ __device__ constexpr int fft_tw_lds_offset(int L, int S, int E) {   // position of stage S in the LDS copy
+    return S <= 1 ? 0 : fft_tw_lds_offset(L, S - 1, E) + (fft_tw_via_lds(L, S - 1, E) ? fft_tw_slots_of(L, S - 1, E) * fft_tw_ku(L, S - 1, E) : 0);
+}
+__host__ __device__ constexpr int fft_tw_lds_entries(int L, int E) { return fft_tw_lds_offset(L, fft_nstages(L, E), E); }
+// exponent q of W_L for (stage S, butterfly i, factor u, thread class ku)
+__host__ __device__ constexpr int fft_tw_exponent(int L, int E, int S, int i, int u, int ku) {
+    return ((ku + i * (L / E)) & (fft_ls(L, S, E) - 1)) * u * (L / (fft_ls(L, S, E) * fft_radix(L, S, E)));
 }
 
+// Phase 1 (before the workgroup's barrier): global -> LDS copy of the small stages, global -> register
+// loads of the large ones.  `tid`/`nthreads` enumerate the whole workgroup.
 template <typename T, int L, int E, int S>
-__device__ __forceinline__ void load_stage_twiddles(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab) {
-    constexpr int R  = fft_radix(L, S, E);
-    constexpr int NB = E / R;
-    constexpr int Q  = L / E;
-    constexpr int BASE = fft_tw_slot_base(L, S, E);
+__device__ __forceinline__ void tw_stage_issue(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab, cx<T>* ldsT,
+                                               const int tid, const int nthreads) {
+    constexpr int SLOTS = fft_tw_slots_of(L, S, E);
+    constexpr int KU = fft_tw_ku(L, S, E);
+    constexpr int OFF = fft_tw_offset(L, S, E);
+    if constexpr (fft_tw_via_lds(L, S, E)) {
+        constexpr int LOFF = fft_tw_lds_offset(L, S, E);
+        for (int e = tid; e < SLOTS * KU; e += nthreads) ldsT[LOFF + e] = tab[OFF + e];
+    } else {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
+        for (int sl = 0; sl < SLOTS; ++sl) tw.w[S - 1][sl] = tab[OFF + sl * KU + (j & (KU - 1))];
+    }
+}
+template <typename T, int L, int E, int S>
+__device__ __forceinline__ void tw_stage_fetch(LineTw<T, L, E>& tw, const int j, const cx<T>* ldsT) {
+    if constexpr (fft_tw_via_lds(L, S, E)) {
+        constexpr int SLOTS = fft_tw_slots_of(L, S, E);
+        constexpr int KU = fft_tw_ku(L, S, E);
+        constexpr int LOFF = fft_tw_lds_offset(L, S, E);
 #pragma unroll
-        for (int u = 1; u < R; ++u) tw.w[S - 1][i * (R - 1) + (u - 1)] = tab[(BASE + i * (R - 1) + (u - 1)) * Q + j];
+        for (int sl = 0; sl < SLOTS; ++sl) tw.w[S - 1][sl] = ldsT[LOFF + sl * KU + (j & (KU - 1))];
     }
 }
 template <typename T, int L, int E>
-__device__ __forceinline__ void load_line_twiddles(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab) {
+__device__ __forceinline__ void line_twiddles_issue(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab, cx<T>* ldsT,
+                                                    const int tid, const int nthreads) {
     constexpr int M = fft_nstages(L, E);
-    if constexpr (M > 1) load_stage_twiddles<T, L, E, 1>(tw, j, tab);
-    if constexpr (M > 2) load_stage_twiddles<T, L, E, 2>(tw, j, tab);
-    if constexpr (M > 3) load_stage_twiddles<T, L, E, 3>(tw, j, tab);
+    if constexpr (M > 1) tw_stage_issue<T, L, E, 1>(tw, j, tab, ldsT, tid, nthreads);
+    if constexpr (M > 2) tw_stage_issue<T, L, E, 2>(tw, j, tab, ldsT, tid, nthreads);
+    if constexpr (M > 3) tw_stage_issue<T, L, E, 3>(tw, j, tab, ldsT, tid, nthreads);
+}
+// Phase 2 (after the barrier): LDS -> registers
+template <typename T, int L, int E>
+__device__ __forceinline__ void line_twiddles_fetch(LineTw<T, L, E>& tw, const int j, const cx<T>* ldsT) {
+    constexpr int M = fft_nstages(L, E);
+    if constexpr (M > 1) tw_stage_fetch<T, L, E, 1>(tw, j, ldsT);
+    if constexpr (M > 2) tw_stage_fetch<T, L, E, 2>(tw, j, ldsT);
+    if constexpr (M > 3) tw_stage_fetch<T, L, E, 3>(tw, j, ldsT);
 }
 
 // One Stockham stage.  IDX maps a line element index to an LDS element index.  Exchanges alternate
