@@ -349,7 +349,7 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipMalloc(&dperm, cb * n));
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
-        hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2);
+        hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2, kColsPerTile, E);
         hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, nA, 1ll, (long long)n);
         hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, nB, (long long)(N1 / 16), (long long)n);
         HIP_TRY(hipGetLastError());
@@ -389,7 +389,7 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = use_device()) return rc;
         HIP_TRY(hipMemcpyAsync(dnat, host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dnat, dperm, N1, N2, (T)0, inv_n());
+                           (const cx<T>*)dnat, dperm, N1, N2, N2 / E, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         // host buffer may be reused by the caller right after return
         HIP_TRY(hipStreamSynchronize(stream));
@@ -406,7 +406,7 @@ template <typename T> struct PlanT : PlanBase {
         tab_rr = (tab_rr + 1) % kMaxTables;
         if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
         hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dperm_natural(), t.ptr, N1, N2, h, inv_n());
+                           (const cx<T>*)dperm_natural(), t.ptr, N1, N2, N2 / E, h, inv_n());
         HIP_TRY(hipGetLastError());
         t.h = h; t.valid = true;
         *out = t.ptr;
@@ -622,7 +622,7 @@ template <typename T> struct PlanT : PlanBase {
         have_op = false;
         for (auto& t : tabs) t.valid = false;
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dnat, hperm, N1, N2, (T)0, inv_n());
+                           (const cx<T>*)dnat, hperm, N1, N2, N2 / E, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev0, stream));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
@@ -648,7 +648,7 @@ template <typename T> struct PlanT : PlanBase {
         }
         const double val = 1.0 / ((double)n * dt_s);
         hipLaunchKernelGGL(k_make_dm_table<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           hperm, hnat, N1, N2, val, D_s2, inv_n());
+                           hperm, hnat, N1, N2, N2 / E, val, D_s2, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev0, stream));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));

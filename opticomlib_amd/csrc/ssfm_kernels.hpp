@@ -36,26 +36,6 @@
 #define SSFM_TWN_COMPUTE 0
 #endif
 
-// In-kernel cycle stamps for tools/stamp_harness.hip (diagnostic builds only; the product never defines it)
-#ifndef SSFM_STAMPS
-#define SSFM_STAMPS 0
-#endif
-#if SSFM_STAMPS
-extern __device__ unsigned long long* g_stamp_buf;
-#define SSFM_STAMP(i)                                                                         \
-    do {                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        if (threadIdx.x == 0) {                                                               \
-            unsigned long long t_;                                                            \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
-            g_stamp_buf[blockIdx.x * 16 + (i)] = t_;                                          \
-        }                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-    } while (0)
-#else
-#define SSFM_STAMP(i) do { } while (0)
-#endif
-
 namespace ssfm {
 
 enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2 };
@@ -87,6 +67,22 @@ __device__ __forceinline__ void xcd_unit_row(unsigned id, int units, int rows, i
         unit = (int)(id % units);
         row = (int)(id / units);
     }
+}
+
+// Read-only tables are stored in the order the consuming thread holds them, two register slots
+// interleaved, so that every access is 16 bytes per lane and coalesced (a vector-memory instruction
+// costs one wave ~70 cycles of issue whether it moves 8 or 16 bytes per lane, and with one wave per
+// SIMD that issue time is on the workgroup's critical path).
+// k_freq operator table, row k1: element k2 = j + t*Q  ->  ((t>>1)*Q + j)*2 + (t&1)
+__host__ __device__ __forceinline__ long long freq_tab_pos(long long k2, int Q) {
+    const long long j = k2 % Q, t = k2 / Q;
+    return ((t >> 1) * Q + j) * 2 + (t & 1);
+}
+// k_time inter-pass twiddle W_N^(k1 n2): tile = n2 / C, thread = (k1 % Q1) * C + n2 % C, slot t = k1 / Q1
+//   -> ((tile*(E/2) + (t>>1)) * NT + thread) * 2 + (t&1),   NT = Q1*C threads per tile
+__host__ __device__ __forceinline__ long long time_tw_pos(long long k1, long long n2, int Q1, int C, int E) {
+    const long long tile = n2 / C, thread = (k1 % Q1) * C + n2 % C, t = k1 / Q1;
+    return ((tile * (E / 2) + (t >> 1)) * ((long long)Q1 * C) + thread) * 2 + (t & 1);
 }
 
 template <typename T> struct TimeArgs {
@@ -259,7 +255,6 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     typedef T p4_t __attribute__((ext_vector_type(4)));
     p4_t* __restrict__ Pb = reinterpret_cast<p4_t*>(a.P + (long long)brow * N + (long long)tile * (N1 * C)) + tid;
     constexpr int PSTR = N1 * C / E;      // threads per tile
-    const cx<T>* __restrict__ Wb = a.twN + (long long)tile * C;
     const int off = j * a.N2 + c;
     const int stride = Q * a.N2;
     const ColIdx<C> idx{c};
@@ -278,8 +273,17 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(e / C) * (tile * C + (e % C))];
     const cx<T> wA = a.twA[j * (tile * C + c)];
 #else
+    {
+        typedef T w4_t __attribute__((ext_vector_type(4)));
+        const w4_t* __restrict__ W4 = reinterpret_cast<const w4_t*>(a.twN) + (long long)tile * (E / 2) * (N1 * C / E) + tid;
 #pragma unroll
-    for (int t = 0; t < E; ++t) w[t] = SSFM_ABL_NO_TWN ? mk<T>((T)1, (T)0) : Wb[off + t * stride];
+        for (int g = 0; g < E / 2; ++g) {
+            w4_t q;
+            if (SSFM_ABL_NO_TWN) { q.x = (T)1; q.y = (T)0; q.z = (T)1; q.w = (T)0; } else q = W4[g * (N1 * C / E)];
+            w[2 * g] = mk<T>(q.x, q.y);
+            w[2 * g + 1] = mk<T>(q.z, q.w);
+        }
+    }
 #endif
     if (MODE != TM_BEGIN) {
 #pragma unroll
@@ -408,8 +412,15 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
     if (MODE != FM_FWD_ONLY) {
+        typedef T m4_t __attribute__((ext_vector_type(4)));
+        const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(trow) + j;
 #pragma unroll
-        for (int t = 0; t < E; ++t) m[t] = SSFM_ABL_NO_TAB ? mk<T>(a.inv_n, (T)0) : trow[j + t * Q];
+        for (int g = 0; g < E / 2; ++g) {
+            m4_t q;
+            if (SSFM_ABL_NO_TAB) { q.x = a.inv_n; q.y = (T)0; q.z = a.inv_n; q.w = (T)0; } else q = T4[g * Q];
+            m[2 * g] = mk<T>(q.x, q.y);
+            m[2 * g + 1] = mk<T>(q.z, q.w);
+        }
     }
     SSFM_STAMP(1);
 #if SSFM_STAMPS
@@ -467,7 +478,7 @@ template <typename T> __global__ void k_make_twpow(cx<T>* tab, long long count, 
     tab[m] = mk<T>((T)c, (T)s);
 }
 // W_N^(k1*n2) at [k1*N2 + n2]
-template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2) {
+template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2, int C, int E) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long N = (long long)N1 * N2;
     if (o >= N) return;
@@ -475,11 +486,11 @@ template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2) {
     const long long m = (k1 * n2) % N;
     double s, c;
     sincospi(-2.0 * (double)m / (double)N, &s, &c);
-    tab[o] = mk<T>((T)c, (T)s);
+    tab[time_tw_pos(k1, n2, N1 / E, C, E)] = mk<T>((T)c, (T)s);
 }
-// out[k1*N2 + k2] = f(src[k1 + N1*k2]); MODE 0: copy, 1: * inv_n, 2: exp(src*h) * inv_n
+// out[k1*N2 + freq_tab_pos(k2)] = f(src[k1 + N1*k2]); MODE 0: copy, 1: * inv_n, 2: exp(src*h) * inv_n
 template <typename T, int MODE>
-__global__ void k_make_freq_table(const cx<T>* __restrict__ src, cx<T>* __restrict__ out, int N1, int N2, T h, T inv_n) {
+__global__ void k_make_freq_table(const cx<T>* __restrict__ src, cx<T>* __restrict__ out, int N1, int N2, int Q, T h, T inv_n) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long N = (long long)N1 * N2;
     if (o >= N) return;
@@ -496,13 +507,13 @@ __global__ void k_make_freq_table(const cx<T>* __restrict__ src, cx<T>* __restri
         d.x = (e * (T)c) * inv_n;
         d.y = (e * (T)s) * inv_n;
     }
-    out[o] = d;
+    out[k1 * N2 + freq_tab_pos(k2, Q)] = d;
 }
 // DM transfer function (reference devices.py:1025-1027): H_k = exp(1j * w_k^2 * D / 2), w_k = fftfreq(n, dt)[k] * 2 * pi,
 // every product in float64 in the reference's order.  Writes H/N in the transposed order and, if
 // `nat` != nullptr, H in natural order.
 template <typename T>
-__global__ void k_make_dm_table(cx<T>* __restrict__ perm, cx<T>* __restrict__ nat, int N1, int N2, double val, double D, T inv_n) {
+__global__ void k_make_dm_table(cx<T>* __restrict__ perm, cx<T>* __restrict__ nat, int N1, int N2, int Q, double val, double D, T inv_n) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long N = (long long)N1 * N2;
     if (o >= N) return;
@@ -513,7 +524,7 @@ __global__ void k_make_dm_table(cx<T>* __restrict__ perm, cx<T>* __restrict__ na
     const double ph = ((w * w) * D) / 2.0;
     double s, c;
     sincos(ph, &s, &c);
-    perm[o] = mk<T>((T)c * inv_n, (T)s * inv_n);
+    perm[k1 * N2 + freq_tab_pos(k2, Q)] = mk<T>((T)c * inv_n, (T)s * inv_n);
     if (nat != nullptr) nat[k] = mk<T>((T)c, (T)s);
 }
 // natural[k1 + N1*k2] = perm[k1*N2 + k2]   (debug: spectrum back to natural order)

@@ -19,6 +19,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// In-kernel cycle stamps for tools/stamp_harness.hip (diagnostic builds only; the product never defines it)
+#ifndef SSFM_STAMPS
+#define SSFM_STAMPS 0
+#endif
+#if SSFM_STAMPS
+extern __device__ unsigned long long* g_stamp_buf;
+#define SSFM_STAMP(i)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (threadIdx.x == 0) {                                                               \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_stamp_buf[blockIdx.x * 16 + (i)] = t_;                                          \
+        }                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#else
+#define SSFM_STAMP(i) do { } while (0)
+#endif
+
+
 namespace ssfm {
 
 typedef float  cf32 __attribute__((ext_vector_type(2)));
@@ -301,6 +322,9 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
     constexpr int Q  = L / E;           // threads per line
     constexpr int LS = fft_ls(L, S, E);
 
+#ifdef SSFM_STAMP_FFT
+    if (DIR < 0) SSFM_STAMP_FFT(7 + 3 * S);          // stage entry
+#endif
     if constexpr (S > 0) {
         const cx<T>* src = lds + ((XP + S - 1) & 1) * BUF;
 #pragma unroll
@@ -316,6 +340,9 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
                 v[i + u * NB] = cmuld<DIR>(v[i + u * NB], tw.w[S - 1][i * (R - 1) + (u - 1)]);
         }
     }
+#ifdef SSFM_STAMP_FFT
+    if (DIR < 0) SSFM_STAMP_FFT(8 + 3 * S);          // LDS read + twiddle done
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         cx<T> tmp[R];
@@ -325,6 +352,9 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
 #pragma unroll
         for (int u = 0; u < R; ++u) v[i + u * NB] = tmp[u];
     }
+#ifdef SSFM_STAMP_FFT
+    if (DIR < 0) SSFM_STAMP_FFT(9 + 3 * S);          // butterflies done
+#endif
     if constexpr (S < M - 1) {
         cx<T>* dst = lds + ((XP + S) & 1) * BUF;
         if (BUF == 0 && (S > 0 || XP != 0)) __syncthreads();   // single buffer: its readers must be done

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 __device__ unsigned long long* g_stamp_buf;
+#define SSFM_STAMP_FFT(i) SSFM_STAMP(i)
 #include "../opticomlib_amd/csrc/ssfm_kernels.hpp"
 using namespace ssfm;
 int main(int argc, char** argv) {
@@ -30,6 +31,13 @@ int main(int argc, char** argv) {
         for (int b = 0; b < 256 * rows; ++b) d.push_back(h[b * 16 + k + 1] - h[b * 16 + k]);
         std::sort(d.begin(), d.end());
         printf("  %-28s median %6llu  p10 %6llu  p90 %6llu\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+    }
+    const char* fn[] = {"s0 entry->pre-bfly", "s0 butterflies", "s0 write+barrier (to s1 entry)", "s1 LDS read+twiddle", "s1 butterflies", "s1 write+barrier", "s2 LDS read+twiddle", "s2 butterflies"};
+    for (int k = 0; k < 8; ++k) {
+        std::vector<unsigned long long> d;
+        for (int b = 0; b < 256 * rows; ++b) d.push_back(h[b * 16 + 8 + k] - h[b * 16 + 7 + k]);
+        std::sort(d.begin(), d.end());
+        printf("    fwd FFT %-32s median %6llu\n", fn[k], d[d.size() / 2]);
     }
     std::vector<unsigned long long> e, tot;
     for (int b = 0; b < 256 * rows; ++b) { e.push_back(h[b * 16] - tmin); tot.push_back(h[b * 16 + 6] - h[b * 16]); }
