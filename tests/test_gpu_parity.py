@@ -452,3 +452,21 @@ def test_zero_and_negative_length_return_the_cast_input():
         np.testing.assert_array_equal(y, a.astype(np.complex64))
         z, A_z = oa.FIBER(optical_signal(a), length=L, h=1.0, gamma=2, return_steps=True)
         assert z.tolist() == [0.0] and A_z.shape == (1, 2, 1 << 10)
+
+
+def test_propagate_channels_batches_fields_in_one_plan():
+    """dist.propagate_channels (single process): fixed-step fields go through one plan and equal
+    separate FIBER calls bit for bit; adaptive fields run one by one."""
+    from opticomlib_amd import dist as od
+    gv(**workloads.BENCH_GV)
+    n = 1 << 13
+    fields = np.stack([workloads.qpsk_field(n, seed=3000 + c) for c in range(3)])
+    kw = dict(length=8, h=0.5, **workloads.SMF)
+    outs = od.propagate_channels(fields, gv.dt, **kw)
+    assert len(outs) == 3
+    for c in range(3):
+        np.testing.assert_array_equal(outs[c], oa.FIBER(optical_signal(fields[c]), **kw).signal)
+    kwa = dict(length=8, **workloads.SMF)
+    outs = od.propagate_channels(fields, gv.dt, **kwa)
+    for c in range(3):
+        np.testing.assert_array_equal(outs[c], oa.FIBER(optical_signal(fields[c]), **kwa).signal)
