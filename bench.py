@@ -103,10 +103,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # plan set-up, not part of the protocol's warm-up: the library times a schedule eagerly (1st run)
-    # and as a hipGraph (2nd run: capture + instantiate) and uses the faster launch mode from the 3rd
-    # run on -- finish that selection before the W warm-up steps
-    for _ in range(3):
+    # plan set-up, not part of the protocol's warm-up: the library times a schedule eagerly (runs 1-2)
+    # and as a hipGraph (run 3: capture + instantiate) and uses the faster launch mode from run 4 on
+    # -- finish that selection before the W warm-up steps
+    for _ in range(4):
         one_step()
     fence()
     for _ in range(args.warmup):

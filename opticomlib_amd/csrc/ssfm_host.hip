@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -195,8 +196,11 @@ template <typename T> struct PlanT : PlanBase {
     // Launch mode of fixed-step runs.  A 1000-step run is 2000-4000 launches; they can be issued eagerly
     // or replayed as ONE hipGraph.  Neither is always faster: on an idle host eager launches win by ~4 %
     // (the graph serialises a little more), under torch.distributed.run with RCCL initialised the eager
-    // launch rate halves and the graph wins by 50 %.  So each schedule is timed both ways with the HIP
-    // events of the plan (call 1 eager, call 2 graph) and from call 3 on the faster mode is used.
+    // launch rate halves and the graph wins by 50 % -- and the host time of the enqueue loop does not
+    // show it (the launches return quickly; the runtime's submission is what is slow).  So both modes
+    // are MEASURED with the plan's HIP events: calls 1 and 2 of a schedule run eagerly (a caller that
+    // propagates once or twice never pays the ~10 ms capture + instantiate of 4000 nodes), call 3
+    // captures and replays a graph, and from call 4 on the faster mode is used.
     // SSFM_GRAPH=0 / 1 forces eager / graph.
     struct GraphEntry {
         unsigned long long key;
@@ -206,6 +210,7 @@ template <typename T> struct PlanT : PlanBase {
         unsigned long long age;
         int calls;                 // runs of this schedule so far
         float eager_ms, graph_ms;  // measured device time of the eager / graph run (< 0: not yet)
+        float host_ms;             // host time of the eager enqueue loop (< 0: not yet)
     };
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0;
@@ -245,7 +250,7 @@ template <typename T> struct PlanT : PlanBase {
                 if (graphs[old].graph) (void)hipGraphDestroy(graphs[old].graph);
                 graphs.erase(graphs.begin() + old);
             }
-            graphs.push_back(GraphEntry{key, nullptr, nullptr, 0, 0, 0, -1.f, -1.f});
+            graphs.push_back(GraphEntry{key, nullptr, nullptr, 0, 0, 0, -1.f, -1.f, -1.f});
             idx = (int)graphs.size() - 1;
         }
         GraphEntry& g = graphs[idx];
@@ -254,8 +259,8 @@ template <typename T> struct PlanT : PlanBase {
         // call 1: eager (a single FIBER call never pays for a capture); call 2: capture + replay
         bool want_graph;
         if (graph_policy == 1) want_graph = g.calls >= 2;
-        else if (g.calls == 1) want_graph = false;
-        else if (g.calls == 2) want_graph = true;
+        else if (g.calls <= 2) want_graph = false;
+        else if (g.calls == 3) want_graph = true;
         else want_graph = g.exec != nullptr && g.graph_ms >= 0.f && (g.eager_ms < 0.f || g.graph_ms < g.eager_ms);
         if (want_graph && g.exec == nullptr) {
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -282,7 +287,10 @@ template <typename T> struct PlanT : PlanBase {
             return SSFM_OK;
         }
         if (g.eager_ms < 0.f) { pending_entry = idx; pending_mode = 0; }
-        return enqueue();
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = enqueue();
+        if (g.host_ms < 0.f) g.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
     }
 
     T inv_n() const { return (T)1 / (T)n; }
