@@ -160,3 +160,21 @@ def test_electrical_signal_and_filter_argument_errors():
     # checked before anything touches the GPU (reference devices.py:811-812, :1355-1356)
     with pytest.raises(TypeError, match=r"`input` must be of type \(optical_signal\)."):
         oa.BPF(np.ones(64), 1e9)
+
+
+def test_missing_library_fails_loudly():
+    """No silent fallback: with the shared library absent every entry point raises SsfmError."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, opticomlib_amd as oa\n"
+        "from opticomlib_amd.typing import gv, optical_signal\n"
+        "gv(sps=16, R=10e9)\n"
+        "try:\n"
+        "    oa.FIBER(optical_signal(np.ones(4096, complex)), length=1, h=1.0)\n"
+        "except oa.SsfmError as e:\n"
+        "    assert 'missing' in str(e) and 'no CPU fallback' in str(e), e\n"
+        "    print('LOUD')\n")
+    env = dict(os.environ, SSFM_LIB="/nonexistent/_ssfm_amd.so", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "LOUD" in r.stdout, r.stderr[-2000:]
