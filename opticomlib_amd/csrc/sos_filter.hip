@@ -7,9 +7,9 @@
 // It is parallelised over time by chunking:
 //   k_chunk   every thread runs the recurrence over ITS chunk of L consecutive samples from a ZERO
 //             state and keeps the final state p_c (the chunk's particular solution);
-//   k_scan    one thread per row walks the chunks: s_{c+1} = A^L s_c + p_c, storing each chunk's true
-//             start state (A^L, the K x K homogeneous map over L samples, is built once on the host by
-//             running the same recurrence on unit states);
+//   k_scan_*  the chunk start states s_{c+1} = A^L s_c + p_c by a two-level scan (groups of 64 chunks);
+//             A^L, the K x K homogeneous map over L samples, is built once on the host by running the
+//             same recurrence on unit states, A^(64 L) by six squarings;
 //   k_apply   every thread re-runs its chunk from the true start state and writes the outputs.
 // Inside a chunk the operation order is exactly SciPy's sample loop; only the chunk start states see a
 // different summation order (relative 1e-16 effects).  Complex rows are two independent real channels
@@ -87,37 +87,85 @@ __global__ void k_chunk(SosCoefs c, SosPass p, int nchunks, int vrows, int chan,
     for (int s = 0; s < NS; ++s) { out[2 * s] = z[s][0]; out[2 * s + 1] = z[s][1]; }
 }
 
-// one thread per virtual row: start state of every chunk
-template <int NS>
-__global__ void k_scan(SosPass p, int nchunks, int vrows, int chan, const double* __restrict__ zi,
-                       const double* __restrict__ Amat, const double* __restrict__ pfinal, double* __restrict__ start) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= vrows) return;
-    constexpr int K = 2 * NS;
-    const double* base = row_base(p, v, chan);
-    const double u0 = sos_input(p, base, 0);
-    double s[K], A[K][K];
+// Chunk start states by a two-level scan of the affine maps s -> A s + p_c (A = A^kChunk):
+//   k_scan_group   thread per (row, group of kGroup chunks): the group's zero-state response
+//   k_scan_top     thread per row: walks the groups with AG = A^kGroup (n_chunks / kGroup steps)
+//   k_scan_starts  thread per (row, group): re-walks its chunks from the group's true start state
+// so the longest serial chain is 2*kGroup + n_chunks/kGroup matrix-vector steps instead of n_chunks.
+constexpr int kGroup = 64;
+
+template <int K> __device__ __forceinline__ void affine_step(const double (&A)[K][K], double (&s)[K], const double* __restrict__ p) {
+    double t[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) s[k] = zi[k] * u0;                  // zi * x_0 (sosfiltfilt)
+    for (int r = 0; r < K; ++r) {
+        double acc = p[r];
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc += A[r][q] * s[q];
+        t[r] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = t[k];
+}
+template <int K> __device__ __forceinline__ void load_mat(double (&A)[K][K], const double* __restrict__ M) {
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
-        for (int q = 0; q < K; ++q) A[r][q] = Amat[r * K + q];
-    for (int ch = 0; ch < nchunks; ++ch) {
-        double* st = start + ((long long)v * nchunks + ch) * K;
-        const double* pf = pfinal + ((long long)v * nchunks + ch) * K;
-        double t[K];
+        for (int q = 0; q < K; ++q) A[r][q] = M[r * K + q];
+}
+
+template <int NS>
+__global__ void k_scan_group(int nchunks, int ngroups, int vrows, const double* __restrict__ Amat,
+                             const double* __restrict__ pfinal, double* __restrict__ gfinal) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups * vrows) return;
+    constexpr int K = 2 * NS;
+    const int v = g / ngroups, gi = g % ngroups;
+    double A[K][K], s[K];
+    load_mat<K>(A, Amat);
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    const int c1 = (gi + 1) * kGroup < nchunks ? (gi + 1) * kGroup : nchunks;
+    for (int ch = gi * kGroup; ch < c1; ++ch) affine_step<K>(A, s, pfinal + ((long long)v * nchunks + ch) * K);
+#pragma unroll
+    for (int k = 0; k < K; ++k) gfinal[(long long)g * K + k] = s[k];
+}
+
+template <int NS>
+__global__ void k_scan_top(SosPass p, int ngroups, int vrows, int chan, const double* __restrict__ zi,
+                           const double* __restrict__ AGmat, const double* __restrict__ gfinal, double* __restrict__ gstart) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= vrows) return;
+    constexpr int K = 2 * NS;
+    const double u0 = sos_input(p, row_base(p, v, chan), 0);
+    double AG[K][K], s[K];
+    load_mat<K>(AG, AGmat);
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = zi[k] * u0;                  // zi * x_0 (sosfiltfilt)
+    for (int gi = 0; gi < ngroups; ++gi) {
+        double* st = gstart + ((long long)v * ngroups + gi) * K;
 #pragma unroll
         for (int k = 0; k < K; ++k) st[k] = s[k];
+        affine_step<K>(AG, s, gfinal + ((long long)v * ngroups + gi) * K);
+    }
+}
+
+template <int NS>
+__global__ void k_scan_starts(int nchunks, int ngroups, int vrows, const double* __restrict__ Amat,
+                              const double* __restrict__ pfinal, const double* __restrict__ gstart, double* __restrict__ start) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups * vrows) return;
+    constexpr int K = 2 * NS;
+    const int v = g / ngroups, gi = g % ngroups;
+    double A[K][K], s[K];
+    load_mat<K>(A, Amat);
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            double acc = pf[r];
+    for (int k = 0; k < K; ++k) s[k] = gstart[(long long)g * K + k];
+    const int c1 = (gi + 1) * kGroup < nchunks ? (gi + 1) * kGroup : nchunks;
+    for (int ch = gi * kGroup; ch < c1; ++ch) {
+        double* st = start + ((long long)v * nchunks + ch) * K;
 #pragma unroll
-            for (int q = 0; q < K; ++q) acc += A[r][q] * s[q];
-            t[r] = acc;
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) s[k] = t[k];
+        for (int k = 0; k < K; ++k) st[k] = s[k];
+        affine_step<K>(A, s, pfinal + ((long long)v * nchunks + ch) * K);
     }
 }
 
@@ -171,9 +219,23 @@ int run_filter(const SosCoefs& c, const double* zi_h, const double* x_h, double*
         }
         for (int r = 0; r < K; ++r) Amat[r * K + q] = z[r / 2][r % 2];
     }
+    // AG = A^kGroup: the homogeneous map over a whole group of chunks (kGroup = 2^6: six squarings)
+    double AG[K * K];
+    std::memcpy(AG, Amat, sizeof(AG));
+    for (int it = 0; (1 << it) < kGroup; ++it) {
+        double T2[K * K];
+        for (int r = 0; r < K; ++r)
+            for (int q = 0; q < K; ++q) {
+                double acc = 0.0;
+                for (int m2 = 0; m2 < K; ++m2) acc += AG[r * K + m2] * AG[m2 * K + q];
+                T2[r * K + q] = acc;
+            }
+        std::memcpy(AG, T2, sizeof(AG));
+    }
+    const int ngroups = (nchunks + kGroup - 1) / kGroup;
     const size_t xbytes = sizeof(double) * (size_t)n * vrows;
-    double *d_x = nullptr, *d_y1 = nullptr, *d_pf = nullptr, *d_st = nullptr, *d_zi = nullptr, *d_A = nullptr;
-    auto cleanup = [&]() { void* b[] = {d_x, d_y1, d_pf, d_st, d_zi, d_A}; for (void* q : b) (void)hipFree(q); };
+    double *d_x = nullptr, *d_y1 = nullptr, *d_pf = nullptr, *d_st = nullptr, *d_zi = nullptr, *d_A = nullptr, *d_AG = nullptr, *d_gf = nullptr, *d_gs = nullptr;
+    auto cleanup = [&]() { void* b[] = {d_x, d_y1, d_pf, d_st, d_zi, d_A, d_AG, d_gf, d_gs}; for (void* q : b) (void)hipFree(q); };
 #define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(SSFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
     TRY_OR_CLEAN(hipMalloc(&d_x, xbytes));
     TRY_OR_CLEAN(hipMalloc(&d_y1, sizeof(double) * (size_t)m * vrows));
@@ -181,6 +243,10 @@ int run_filter(const SosCoefs& c, const double* zi_h, const double* x_h, double*
     TRY_OR_CLEAN(hipMalloc(&d_st, sizeof(double) * (size_t)nchunks * vrows * K));
     TRY_OR_CLEAN(hipMalloc(&d_zi, sizeof(double) * K));
     TRY_OR_CLEAN(hipMalloc(&d_A, sizeof(double) * K * K));
+    TRY_OR_CLEAN(hipMalloc(&d_AG, sizeof(double) * K * K));
+    TRY_OR_CLEAN(hipMalloc(&d_gf, sizeof(double) * (size_t)ngroups * vrows * K));
+    TRY_OR_CLEAN(hipMalloc(&d_gs, sizeof(double) * (size_t)ngroups * vrows * K));
+    TRY_OR_CLEAN(hipMemcpy(d_AG, AG, sizeof(double) * K * K, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(d_x, x_h, xbytes, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(d_zi, zi_h, sizeof(double) * K, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(d_A, Amat, sizeof(double) * K * K, hipMemcpyHostToDevice));
@@ -193,7 +259,10 @@ int run_filter(const SosCoefs& c, const double* zi_h, const double* x_h, double*
         if (dir == 0) { p.src = d_x; p.row_pitch = n * chan; p.stride = chan; }
         else          { p.src = d_y1; p.row_pitch = m; p.stride = 1; }
         hipLaunchKernelGGL(k_chunk<NS>, gw, bw, 0, 0, c, p, nchunks, vrows, chan, d_pf);
-        hipLaunchKernelGGL(k_scan<NS>, dim3((vrows + 63) / 64), dim3(64), 0, 0, p, nchunks, vrows, chan, (const double*)d_zi, (const double*)d_A, (const double*)d_pf, d_st);
+        const dim3 gg((unsigned)((ngroups * vrows + 63) / 64)), bg(64);
+        hipLaunchKernelGGL(k_scan_group<NS>, gg, bg, 0, 0, nchunks, ngroups, vrows, (const double*)d_A, (const double*)d_pf, d_gf);
+        hipLaunchKernelGGL(k_scan_top<NS>, dim3((vrows + 63) / 64), dim3(64), 0, 0, p, ngroups, vrows, chan, (const double*)d_zi, (const double*)d_AG, (const double*)d_gf, d_gs);
+        hipLaunchKernelGGL(k_scan_starts<NS>, gg, bg, 0, 0, nchunks, ngroups, vrows, (const double*)d_A, (const double*)d_pf, (const double*)d_gs, d_st);
         // the backward pass writes the trimmed, re-reversed result over the input buffer
         hipLaunchKernelGGL(k_apply<NS>, gw, bw, 0, 0, c, p, nchunks, vrows, chan, (const double*)d_st, d_y1, d_x, n * chan, (long long)chan);
         TRY_OR_CLEAN(hipGetLastError());
