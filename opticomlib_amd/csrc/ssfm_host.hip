@@ -391,6 +391,51 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
+#if SSFM_TRACE
+    unsigned long long* trace_buf = nullptr;
+    int trace_cap = 0, trace_next = 0;
+    std::vector<int> trace_kind;        // per slot: kind*16 + lane
+    int trace_begin(int launches) {
+        if (!std::getenv("SSFM_TRACE_FILE")) return SSFM_OK;
+        if (trace_cap < launches) {
+            (void)hipFree(trace_buf);
+            HIP_TRY(hipMalloc(&trace_buf, sizeof(unsigned long long) * 512 * launches));
+            trace_cap = launches;
+        }
+        HIP_TRY(hipMemset(trace_buf, 0, sizeof(unsigned long long) * 512 * launches));
+        trace_next = 0;
+        trace_kind.assign(launches, 0);
+        return SSFM_OK;
+    }
+    template <typename A> void trace_tag(A& a, int kind, int lane) {
+        a.trace = nullptr; a.trace_slot = 0;
+        if (trace_buf && trace_next < trace_cap) { a.trace = trace_buf; a.trace_slot = trace_next; trace_kind[trace_next] = kind * 16 + lane; ++trace_next; }
+    }
+    int trace_dump() {
+        const char* path = std::getenv("SSFM_TRACE_FILE");
+        if (!path || !trace_buf) return SSFM_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> raw(512 * (size_t)trace_next), h(4 * (size_t)trace_next);
+        HIP_TRY(hipMemcpy(raw.data(), trace_buf, sizeof(unsigned long long) * raw.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < trace_next; ++i) {
+            unsigned long long fs = ~0ull, ls = 0, fe = ~0ull, le = 0;
+            for (int b = 0; b < 256; ++b) {
+                const unsigned long long s0 = raw[((size_t)i * 256 + b) * 2], e0 = raw[((size_t)i * 256 + b) * 2 + 1];
+                if (s0 == 0) continue;
+                fs = s0 < fs ? s0 : fs; ls = s0 > ls ? s0 : ls; fe = e0 < fe ? e0 : fe; le = e0 > le ? e0 : le;
+            }
+            h[4 * i] = fs; h[4 * i + 1] = ls; h[4 * i + 2] = fe; h[4 * i + 3] = le;
+        }
+        FILE* f = std::fopen(path, "w");
+        if (!f) return SSFM_OK;
+        std::fprintf(f, "slot,kind,lane,first_start,last_start,first_end,last_end\n");
+        for (int i = 0; i < trace_next; ++i)
+            std::fprintf(f, "%d,%d,%d,%llu,%llu,%llu,%llu\n", i, trace_kind[i] / 16, trace_kind[i] % 16, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+        std::fclose(f);
+        return SSFM_OK;
+    }
+#endif
+
     int use_device() { HIP_TRY(hipSetDevice(device)); return SSFM_OK; }
 
     int set_operator(const void* host) {
@@ -422,14 +467,22 @@ template <typename T> struct PlanT : PlanBase {
     }
     const cx<T>* dperm_natural() const { return dnat; }
 
-    TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s, int row0 = 0) const {
+    TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s, int row0 = 0, int lane = 0) {
         TimeArgs<T> a;
+#if SSFM_TRACE
+        trace_tag(a, 0, lane);
+#endif
+        (void)lane;
         a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0;
         return a;
     }
-    FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0) const {
+    FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
         FreqArgs<T> a;
+#if SSFM_TRACE
+        trace_tag(a, 1, lane);
+#endif
+        (void)lane;
         a.F = F + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0;
         return a;
     }
@@ -465,14 +518,15 @@ template <typename T> struct PlanT : PlanBase {
             for (size_t i = 0; i < distinct.size(); ++i)
                 if (int rc = table_for(distinct[i], &tabptr[i])) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
+            const int lane_ = rows > 0 ? row0 / rows : 0;
             ++last_launches;
             if (use_tables) {
                 const cx<T>* tp = nullptr;
                 for (size_t i = 0; i < distinct.size(); ++i)
                     if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
-                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0), E);
+                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0, lane_), E);
             }
-            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0), E);
+            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0, lane_), E);
         };
         auto freq = [&](T hs) -> hipError_t { return freq_rows(hs, 0, batch, stream); };
         (void)nrows;
@@ -487,7 +541,7 @@ template <typename T> struct PlanT : PlanBase {
                 for (int g = 0; g < nlanes; ++g) {
                     if (int rc = prof_mark(-1, g)) return rc;
                     ++last_launches;
-                    HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows), E)));
+                    HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows, g), E)));
                     if (int rc = prof_mark(0, g)) return rc;
                     // stagger: lane g+1 starts once lane g has finished its first kernel, so that the lanes
                     // run DIFFERENT kernels at any time (one computes while the other streams)
@@ -504,9 +558,9 @@ template <typename T> struct PlanT : PlanBase {
                     for (int g = 0; g < nlanes; ++g) {
                         ++last_launches;
                         if (s + 1 < nsteps)
-                            HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows), E)));
+                            HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows, g), E)));
                         else
-                            HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows), E)));
+                            HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows, g), E)));
                         if (int rc = prof_mark(0, g)) return rc;
                     }
                 }
@@ -535,7 +589,13 @@ template <typename T> struct PlanT : PlanBase {
             return SSFM_OK;
         };
         if (snapshots == nullptr) {
+#if SSFM_TRACE
+            if (int rc = trace_begin((int)(2 * nsteps + 1) * nlanes)) return rc;
+#endif
             if (int rc = run_steps_maybe_graph(enqueue_steps, gamma, h, nsteps, tabptr)) return rc;
+#if SSFM_TRACE
+            if (int rc = trace_dump()) return rc;
+#endif
         } else {
             const size_t fb = sizeof(cx<T>) * n * batch;
             char* snap = static_cast<char*>(snapshots);

@@ -36,6 +36,25 @@
 #define SSFM_TWN_COMPUTE 0
 #endif
 
+// Launch-level trace for tools/trace_timeline.py (diagnostic builds only: -DSSFM_TRACE=1).  Every
+// workgroup folds its start / end time (s_memrealtime, 100 MHz) into 4 words of its launch's slot.
+#ifndef SSFM_TRACE
+#define SSFM_TRACE 0
+#endif
+#if SSFM_TRACE
+#define SSFM_TRACE_ARGS unsigned long long* trace; int trace_slot;
+#define SSFM_TRACE_BEGIN(a)                                                                     \
+    if ((a).trace && threadIdx.x == 0)                                                          \
+        (a).trace[((long long)(a).trace_slot * 256 + (blockIdx.x & 255)) * 2 + 0] = __builtin_amdgcn_s_memrealtime();
+#define SSFM_TRACE_END(a)                                                                       \
+    if ((a).trace && threadIdx.x == 0)                                                          \
+        (a).trace[((long long)(a).trace_slot * 256 + (blockIdx.x & 255)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#else
+#define SSFM_TRACE_ARGS
+#define SSFM_TRACE_BEGIN(a)
+#define SSFM_TRACE_END(a)
+#endif
+
 namespace ssfm {
 
 enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2 };
@@ -98,6 +117,7 @@ template <typename T> struct TimeArgs {
     T hh_next;                // h/2 of the step being started
     int N2;
     int rows;                 // rows covered by this launch (grid = N2/C * rows blocks)
+    SSFM_TRACE_ARGS
 };
 
 // sin/cos of the nonlinear phase.  float: Cody-Waite reduction by pi/2 (three fma terms whose sum
@@ -200,6 +220,35 @@ template <> __device__ __forceinline__ void sincos_acc<float>(float x, float& s,
 }
 template <> __device__ __forceinline__ void sincos_acc<double>(double x, double& s, double& c) { sincos(x, &s, &c); }
 
+// Field / |A|^2 stores between kernels.  The consumer is always the NEXT kernel on other CUs (the
+// all-to-all between the two passes crosses XCDs), so nothing is gained by keeping the lines in this
+// XCD's L2 -- and a kernel that leaves megabytes dirty there pays for their write-back at its end:
+// dependent-launch gap = 1.45 us + dirty bytes / 6 TB/s (MI355X_MICROARCH.md, row "boundary"; measured
+// here 2.3-3.2 us behind 8-12 MB, tools/trace_timeline.py).  Write-through (sc1) or non-temporal stores
+// would stream the data out during the kernel -- but with the 8 bytes per lane this access pattern
+// allows they are slower than the write-back they avoid: measured 21.2 (plain) / 22.4 (sc1) / 23.3 (nt)
+// us per step.  SSFM_STORE_MODE: 0 plain (default), 1 write-through (sc1), 2 non-temporal.
+#ifndef SSFM_STORE_MODE
+#define SSFM_STORE_MODE 0
+#endif
+__device__ __forceinline__ void stream_store(cf32* p, cf32 v) {
+#if SSFM_STORE_MODE == 1
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+#elif SSFM_STORE_MODE == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void stream_store(cf64* p, cf64 v) {
+#if SSFM_STORE_MODE == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 template <int C> struct ColIdx {
     int c;
     __device__ __forceinline__ int operator()(int e) const { return e * C + c; }
@@ -242,6 +291,7 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
         if (a.st->done) return;
         hh_prev = hh_next = a.st->h * (T)0.5;
     }
+    SSFM_TRACE_BEGIN(a);
     const int tid = threadIdx.x;
     const int c = tid % C;
     const int j = tid / C;
@@ -341,7 +391,7 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     }
     if (MODE == TM_END) {
 #pragma unroll
-        for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
+        for (int t = 0; t < E; ++t) stream_store(&Fb[off + t * stride], v[t]);
         if (a.st != nullptr && a.st->adaptive) {
             // wave-level max, then one atomic per wave
 #pragma unroll
@@ -351,6 +401,7 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
             }
             if ((tid & 63) == 0) atomicMax(&a.st->maxbits, float_bits<T>(pmax));
         }
+        SSFM_TRACE_END(a);
         return;
     }
     // exchanges alternate between two LDS buffers; the forward transform continues the count
@@ -358,7 +409,11 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     constexpr int XP_FWD = (MODE != TM_MID || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, ColIdx<C>>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
 #pragma unroll
-    for (int t = 0; t < E; ++t) Fb[off + t * stride] = cmul(v[t], w[t]);
+    for (int t = 0; t < E; ++t) stream_store(&Fb[off + t * stride], cmul(v[t], w[t]));
+#if SSFM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SSFM_TRACE_END(a);
 }
 
 // ------------------------------------------------------------------------------ k_freq
@@ -373,6 +428,7 @@ template <typename T> struct FreqArgs {
     T inv_n;
     int N1;
     int rows;                // batch rows covered by this launch
+    SSFM_TRACE_ARGS
 };
 
 template <typename T> __device__ __forceinline__ T exp_acc(T x);
@@ -390,6 +446,7 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
         if (a.st->done) return;
         h = a.st->h;
     }
+    SSFM_TRACE_BEGIN(a);
     const int tid = threadIdx.x;
     const int j = tid % Q;
     const int rr = tid / Q;
@@ -432,7 +489,7 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
-        for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
+        for (int t = 0; t < E; ++t) stream_store(&Frow[j + t * Q], v[t]);
         return;
     }
     SSFM_STAMP(3);
@@ -452,11 +509,15 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : (lds_double_buffer<T>() ? ((fft_nstages(N2, E) - 1) & 1) : 1)), RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     SSFM_STAMP(5);
 #pragma unroll
-    for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
+    for (int t = 0; t < E; ++t) stream_store(&Frow[j + t * Q], v[t]);
 #if SSFM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     SSFM_STAMP(6);
+#if SSFM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SSFM_TRACE_END(a);
 }
 
 // ------------------------------------------------------------------------------ tables
