@@ -473,7 +473,7 @@ template <typename T> struct PlanT : PlanBase {
         trace_tag(a, 0, lane);
 #endif
         (void)lane;
-        a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.gamma = gamma;
+        a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0;
         return a;
     }
@@ -646,16 +646,14 @@ template <typename T> struct PlanT : PlanBase {
         const size_t fb = sizeof(cx<T>) * n * batch;
         char* snap = static_cast<char*>(snapshots);
         if (snap) if (int rc = copy_field_out(snap, false, false)) return rc;
-        const int chunk = snap ? 1 : 16;
+        int chunk = snap ? 1 : 16;
         int prev_steps = 0;
         for (;;) {
             for (int i = 0; i < chunk; ++i) {
                 HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
                 HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, 0, st), E)));
                 HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
-                hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, st, zlog, 1, 0);
-                HIP_TRY(hipGetLastError());
-                last_launches += 4;
+                last_launches += 3;
             }
             HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -663,6 +661,7 @@ template <typename T> struct PlanT : PlanBase {
                 if (int rc = copy_field_out(snap + fb * hs.steps, false, true)) return rc;
             prev_steps = hs.steps;
             if (hs.done) break;
+            if (!snap && chunk < 128) chunk *= 2;          // poll less often on long runs
         }
         HIP_TRY(hipEventRecord(ev1, stream));
         timed = true;

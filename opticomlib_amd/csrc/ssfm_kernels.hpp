@@ -71,6 +71,8 @@ template <typename T> struct AdaptState {
     int steps;
     int max_steps;
     unsigned long long maxbits;   // bit pattern of max |A|^2 (non-negative => monotone as integer)
+    unsigned int ticket;          // workgroups of k_time<END> that have contributed their maximum
+    unsigned int pad_;
 };
 
 // Block id -> (unit, row) so that the `rows` blocks working on the same unit (column tile / spectrum
@@ -112,6 +114,7 @@ template <typename T> struct TimeArgs {
     const cx<T>* twB;         // W_N^(m*N1/16),  m < 16*N2        k1 = j + t*N1/16  (SSFM_TWN_COMPUTE == 1)
     const cx<T>* tw1;         // W_N1^q
     AdaptState<T>* st;        // nullptr in fixed-step mode
+    T* zlog;                  // adaptive mode: z after every step
     T gamma;
     T hh_prev;                // h/2 of the step being finished
     T hh_next;                // h/2 of the step being started
@@ -212,7 +215,25 @@ template <int E> __device__ __forceinline__ void rotate_all(cf64 (&v)[E], const 
         v[t] = cmul(v[t], mk<double>(c, s));
     }
 }
-// scalar form (on-the-fly linear operator of the adaptive mode)
+// E sin/cos pairs with ONE path decision per thread (on-the-fly linear operator of the adaptive mode:
+// the dispersion phases reach tens of radians, so the plain Cody-Waite path is the common one)
+template <int E> __device__ __forceinline__ void sincos_all(const float (&phi)[E], float (&sn)[E], float (&cs)[E]) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < E; ++t) amax = fmaxf(amax, fabsf(phi[t]));
+    if (__builtin_expect(amax <= kSincosSmallMax, 1)) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) sincos_f32<false>(phi[t], sn[t], cs[t]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < E; ++t) sincos_f32<true>(phi[t], sn[t], cs[t]);
+    }
+}
+template <int E> __device__ __forceinline__ void sincos_all(const double (&phi)[E], double (&sn)[E], double (&cs)[E]) {
+#pragma unroll
+    for (int t = 0; t < E; ++t) sincos(phi[t], &sn[t], &cs[t]);
+}
+// scalar form
 template <typename T> __device__ __forceinline__ void sincos_acc(T x, T& s, T& c);
 template <> __device__ __forceinline__ void sincos_acc<float>(float x, float& s, float& c) {
     if (__builtin_expect(fabsf(x) <= kSincosSmallMax, 1)) sincos_f32<false>(x, s, c);
@@ -265,6 +286,28 @@ __host__ __device__ constexpr int row_lds_elems(int n2, int E) { return n2 + (n2
 template <typename T> __device__ __forceinline__ unsigned long long float_bits(T v);
 template <> __device__ __forceinline__ unsigned long long float_bits<float>(float v) { return (unsigned long long)__float_as_uint(v); }
 template <> __device__ __forceinline__ unsigned long long float_bits<double>(double v) { return (unsigned long long)__double_as_longlong(v); }
+
+template <typename T> __device__ __forceinline__ T bits_float(unsigned long long b);
+template <> __device__ __forceinline__ float bits_float<float>(unsigned long long b) { return __uint_as_float((unsigned)b); }
+template <> __device__ __forceinline__ double bits_float<double>(unsigned long long b) { return __longlong_as_double((long long)b); }
+
+// Step control, one thread.  phase 0: choose the first step (devices.py:1155-1161);
+// phase 1: account for the step just finished and choose the next (devices.py:1173,1193-1196).
+// account for the step just finished and choose the next one (reference devices.py:1173, 1193-1196)
+template <typename T> __device__ __forceinline__ void step_control_update(AdaptState<T>* st, T* zlog, unsigned long long maxbits) {
+    const T z = st->z + st->h;
+    T h = st->h;
+    if (st->adaptive) h = st->phi_max / (st->abs_gamma * bits_float<T>(maxbits));
+    const T rem = st->length - z;
+    h = h < rem ? h : rem;
+    st->z = z;
+    st->h = h;
+    st->steps += 1;
+    zlog[st->steps] = z;
+    st->maxbits = 0ull;
+    st->done = !(z < st->length) || st->steps >= st->max_steps;
+}
+
 
 // ------------------------------------------------------------------------------ k_time
 // Alternating LDS exchanges between two buffers saves one barrier per exchange but doubles the LDS
@@ -392,14 +435,27 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void 
     if (MODE == TM_END) {
 #pragma unroll
         for (int t = 0; t < E; ++t) stream_store(&Fb[off + t * stride], v[t]);
-        if (a.st != nullptr && a.st->adaptive) {
-            // wave-level max, then one atomic per wave
+        if (a.st != nullptr) {
+            // wave-level max, one atomic per wave; the LAST workgroup to arrive (ticket) then runs the
+            // step control, so an adaptive step is 3 launches (BEGIN, k_freq, END), not 4
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const T other = __shfl_xor(pmax, o);
                 pmax = other > pmax ? other : pmax;
             }
             if ((tid & 63) == 0) atomicMax(&a.st->maxbits, float_bits<T>(pmax));
+            __syncthreads();                       // every wave of this workgroup has contributed
+            if (tid == 0) {
+                __threadfence();
+                const unsigned arrived = atomicAdd(&a.st->ticket, 1u);
+                if (arrived == gridDim.x - 1) {
+                    __threadfence();
+                    const unsigned long long mb = atomicMax(&a.st->maxbits, 0ull);   // coherent read
+                    a.st->ticket = 0u;
+                    step_control_update<T>(a.st, a.zlog, mb);
+                    __threadfence();
+                }
+            }
         }
         SSFM_TRACE_END(a);
         return;
@@ -493,18 +549,20 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
         return;
     }
     SSFM_STAMP(3);
+    if (MODE == FM_FLY) {
+        // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
+        T ph[E], sn[E], cs[E];
 #pragma unroll
-    for (int t = 0; t < E; ++t) {
-        cx<T> mm = m[t];
-        if (MODE == FM_FLY) {
-            // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
-            const T e = exp_acc<T>(mm.x * h);
-            T s, co;
-            sincos_acc<T>(mm.y * h, s, co);
-            mm = mk<T>((e * co) * a.inv_n, (e * s) * a.inv_n);
+        for (int t = 0; t < E; ++t) ph[t] = m[t].y * h;
+        sincos_all<E>(ph, sn, cs);
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const T e = exp_acc<T>(m[t].x * h);
+            m[t] = mk<T>((e * cs[t]) * a.inv_n, (e * sn[t]) * a.inv_n);
         }
-        v[t] = cmul(v[t], mm);
     }
+#pragma unroll
+    for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
     SSFM_STAMP(4);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : (lds_double_buffer<T>() ? ((fft_nstages(N2, E) - 1) & 1) : 1)), RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     SSFM_STAMP(5);
@@ -615,12 +673,6 @@ template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long
     if ((threadIdx.x & 63) == 0) atomicMax(&st->maxbits, float_bits<T>(pmax));
 }
 
-template <typename T> __device__ __forceinline__ T bits_float(unsigned long long b);
-template <> __device__ __forceinline__ float bits_float<float>(unsigned long long b) { return __uint_as_float((unsigned)b); }
-template <> __device__ __forceinline__ double bits_float<double>(unsigned long long b) { return __longlong_as_double((long long)b); }
-
-// Step control, one thread.  phase 0: choose the first step (devices.py:1155-1161);
-// phase 1: account for the step just finished and choose the next (devices.py:1173,1193-1196).
 template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog, int phase, int single_step) {
     if (phase == 0) {
         T h;
@@ -636,17 +688,7 @@ template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog,
         return;
     }
     if (st->done) return;
-    const T z = st->z + st->h;
-    T h = st->h;
-    if (st->adaptive) h = st->phi_max / (st->abs_gamma * bits_float<T>(st->maxbits));
-    const T rem = st->length - z;
-    h = h < rem ? h : rem;
-    st->z = z;
-    st->h = h;
-    st->steps += 1;
-    zlog[st->steps] = z;
-    st->maxbits = 0ull;
-    st->done = !(z < st->length) || st->steps >= st->max_steps;
+    step_control_update<T>(st, zlog, st->maxbits);
 }
 
 }  // namespace ssfm
