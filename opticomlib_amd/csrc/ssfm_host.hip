@@ -32,7 +32,7 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
 }
 
 // ----------------------------------------------------------------------------- launchers
-// E = points per thread: 8 (default for complex64: twice the waves, half the registers) or 16.
+// E = points per thread: 16 (default) or 8 (twice the waves, half the registers, one more LDS exchange).
 template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = kColsPerTile;
@@ -459,13 +459,12 @@ template <typename T> struct PlanT : PlanBase {
         tab_rr = (tab_rr + 1) % kMaxTables;
         if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
         hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dperm_natural(), t.ptr, N1, N2, N2 / E, h, inv_n());
+                           (const cx<T>*)dnat, t.ptr, N1, N2, N2 / E, h, inv_n());
         HIP_TRY(hipGetLastError());
         t.h = h; t.valid = true;
         *out = t.ptr;
         return SSFM_OK;
     }
-    const cx<T>* dperm_natural() const { return dnat; }
 
     TimeArgs<T> targs(T gamma, T hh_prev, T hh_next, AdaptState<T>* s, int row0 = 0, int lane = 0) {
         TimeArgs<T> a;

@@ -579,14 +579,6 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T)))
 }
 
 // ------------------------------------------------------------------------------ tables
-// W_L^q = exp(-2 pi i q / L), generated in double, rounded once.
-template <typename T> __global__ void k_make_twL(cx<T>* tab, int L) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= L) return;
-    double s, c;
-    sincospi(-2.0 * (double)q / (double)L, &s, &c);
-    tab[q] = mk<T>((T)c, (T)s);
-}
 // tab[m] = W_N^(m*mult) = exp(-2 pi i m mult / N), m < count
 template <typename T> __global__ void k_make_twpow(cx<T>* tab, long long count, long long mult, long long N) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
