@@ -470,3 +470,33 @@ def test_propagate_channels_batches_fields_in_one_plan():
     outs = od.propagate_channels(fields, gv.dt, **kwa)
     for c in range(3):
         np.testing.assert_array_equal(outs[c], oa.FIBER(optical_signal(fields[c]), **kwa).signal)
+
+
+# ----------------------------------------------------------------------- symmetries of the propagator
+@pytest.mark.parametrize("prec,tol", [("complex64", 2e-5), ("complex128", 1e-11)])
+def test_symmetries_shift_and_global_phase(prec, tol):
+    """The scalar NLSE with periodic boundaries commutes with circular time shifts and with a global phase
+    (also numerically: every operator of the scheme does).  Size-independent properties, run at 2^18 x 2."""
+    gv(**workloads.BENCH_GV)
+    n = 1 << 18
+    a = workloads.qpsk_field(n, seed=21)
+    kw = dict(length=20, h=0.5, precision=prec, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    ys = oa.FIBER(optical_signal(np.roll(a, 12345, axis=-1)), **kw).signal
+    assert relmax(ys, np.roll(y, 12345, axis=-1)) < tol
+    ph = np.exp(0.7j)
+    yp = oa.FIBER(optical_signal(a * ph), **kw).signal
+    assert relmax(yp, y * ph) < tol
+
+
+def test_linearity_without_kerr_effect():
+    """gamma = 0: the fibre is linear -- FIBER(a x1 + b x2) = a FIBER(x1) + b FIBER(x2)."""
+    gv(**workloads.BENCH_GV)
+    n = 1 << 16
+    x1 = workloads.qpsk_field(n, seed=31)
+    x2 = workloads.qpsk_field(n, seed=32)
+    kw = dict(length=50, h=2.0, alpha=0.2, beta_2=-21.7, beta_3=0.13, precision="complex128")
+    f = lambda x: oa.FIBER(optical_signal(x), **kw).signal
+    lhs = f(0.3 * x1 + (0.2 - 0.9j) * x2)
+    rhs = 0.3 * f(x1) + (0.2 - 0.9j) * f(x2)
+    assert relmax(lhs, rhs) < 1e-12
