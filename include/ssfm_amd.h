@@ -61,7 +61,7 @@ int ssfm_abi_version(void);
 int ssfm_device_count(int* count);
 const char* ssfm_last_error(void);
 
-/* Smallest / largest supported log2(n) for a precision (currently 8..20). */
+/* Smallest / largest supported log2(n) for a precision (currently 8..22). */
 int ssfm_supported_log2n(int precision, int* lo, int* hi);
 
 /* Allocate every device buffer once: field, stale |A|^2, operator tables, twiddles. */

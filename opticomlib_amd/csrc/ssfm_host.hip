@@ -19,7 +19,7 @@ using namespace ssfm;
 
 namespace {
 
-constexpr int kLog2Min = 8, kLog2Max = 20;
+constexpr int kLog2Min = 8, kLog2Max = 22;
 constexpr int kColsPerTile = 16;   // C: 128 B (c64) / 256 B (c128) contiguous per row segment
 constexpr int kMaxTables = 4;
 
@@ -52,6 +52,7 @@ hipError_t launch_time_e(int N1, int batch, hipStream_t s, const TimeArgs<T>& a)
         case 64:  return launch_time_n1<T, MODE, 64, E>(grid, s, a);
         case 128: return launch_time_n1<T, MODE, 128, E>(grid, s, a);
         case 256: return launch_time_n1<T, MODE, 256, E>(grid, s, a);
+        case 512: if constexpr (E == 16) return launch_time_n1<T, MODE, 512, E>(grid, s, a); else break;
     }
     return hipErrorInvalidValue;
 }
@@ -83,6 +84,7 @@ hipError_t launch_freq_e(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a)
         case 1024: return launch_freq_n2<T, MODE, 1024, E>(nrows, s, a);
         case 2048: return launch_freq_n2<T, MODE, 2048, E>(nrows, s, a);
         case 4096: return launch_freq_n2<T, MODE, 4096, E>(nrows, s, a);
+        case 8192: if constexpr (E == 16) return launch_freq_n2<T, MODE, 8192, E>(nrows, s, a); else break;
     }
     return hipErrorInvalidValue;
 }
@@ -322,7 +324,8 @@ template <typename T> struct PlanT : PlanBase {
         device = dev; n = n_; batch = batch_;
         int k = 0;
         while ((1ll << k) < n) ++k;
-        const int k1 = k / 2 < 8 ? k / 2 : 8;
+        // N = N1 * N2: N1 = 2^floor(k/2) up to 256, N2 up to 4096; beyond 2^20: N1 = 512, N2 up to 8192
+        const int k1 = k <= 20 ? (k / 2 < 8 ? k / 2 : 8) : 9;
         N1 = 1 << k1;
         N2 = 1 << (k - k1);
         HIP_TRY(hipSetDevice(device));
@@ -331,6 +334,7 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipEventCreate(&ev1));
         E = 16;                    // measured: E = 8 (twice the waves, one more exchange) is 10 % slower
         if (const char* e = std::getenv("SSFM_E")) E = std::atoi(e) == 16 ? 16 : 8;
+        if (k > 20) E = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
         if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = std::atoi(e) != 0 ? 1 : 0;
         int want = 2;

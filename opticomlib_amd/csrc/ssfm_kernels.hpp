@@ -321,10 +321,13 @@ template <typename T> __host__ __device__ constexpr bool lds_double_buffer() { r
 #ifndef SSFM_MIN_WAVES_256
 #define SSFM_MIN_WAVES_256 2
 #endif
-__host__ __device__ constexpr int min_waves(int threads, int tsize) { return tsize == 4 && threads >= 256 ? (threads == 256 ? SSFM_MIN_WAVES_256 : threads / 128) : 1; }
+// (a 512-thread workgroup with 16 points per thread needs the full 256 registers: one workgroup per CU)
+__host__ __device__ constexpr int min_waves(int threads, int tsize, int e = 16) {
+    return tsize == 4 && threads >= 256 ? (threads == 256 ? SSFM_MIN_WAVES_256 : (e == 16 ? 2 : threads / 128)) : 1;
+}
 
 template <typename T, int N1, int C, int E, int MODE>
-__global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T))) void k_time(const TimeArgs<T> a) {
+__global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) void k_time(const TimeArgs<T> a) {
     constexpr int Q = N1 / E;                      // threads per column
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -492,7 +495,7 @@ template <> __device__ __forceinline__ float exp_acc<float>(float x) { return ex
 template <> __device__ __forceinline__ double exp_acc<double>(double x) { return exp(x); }
 
 template <typename T, int N2, int ROWS, int E, int MODE>
-__global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T))) void k_freq(const FreqArgs<T> a) {
+__global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T), E)) void k_freq(const FreqArgs<T> a) {
     constexpr int Q = N2 / E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);

@@ -1,6 +1,6 @@
 // wgfft.hpp -- workgroup-level power-of-two FFT building block for gfx950 (wave64).
 //
-// A "line" of L = 2^m complex points (16 <= L <= 4096) is transformed by Q = L/E
+// A "line" of L = 2^m complex points (16 <= L <= 8192) is transformed by Q = L/E
 // threads; every thread owns E (16 or 8) points in registers.  Register slot t of thread j holds
 // line element j + t*Q on entry AND on exit ("pattern P"), so a forward and an inverse
 // transform can be chained without any data movement in between, and the global-memory
@@ -214,7 +214,7 @@ template <> struct Dft<16> {
 // waves for the same line -- what a small problem needs to keep two computing waves per SIMD.
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 __host__ __device__ constexpr int fft_nstages(int L, int E) {
-    return E == 16 ? (L <= 16 ? 1 : (L <= 256 ? 2 : 3)) : (ilog2(L) + 2) / 3;
+    return E == 16 ? (L <= 16 ? 1 : (L <= 256 ? 2 : (L <= 4096 ? 3 : 4))) : (ilog2(L) + 2) / 3;
 }
 // radix of stage s (0-based) for line length L
 __host__ __device__ constexpr int fft_radix(int L, int s, int E) {
@@ -226,7 +226,8 @@ __host__ __device__ constexpr int fft_radix(int L, int s, int E) {
                     : L == 512  ? 8
                     : L == 1024 ? (s == 0 ? 16 : 8)
                     : L == 2048 ? (s <= 1 ? 16 : 8)
-                    :             16)   // 4096
+                    : L == 4096 ? 16
+                    :             (s <= 2 ? 16 : 2))   // 8192 = 16 * 16 * 16 * 2
                    // E == 8: radix 8 while three bits remain, then the remainder
                    : (s < ilog2(L) / 3 ? 8 : (1 << (ilog2(L) % 3)));
 }

@@ -49,7 +49,7 @@ def _need_gpu():
 
 
 # ----------------------------------------------------------------------- FFT building block
-@pytest.mark.parametrize("k", range(8, 21))
+@pytest.mark.parametrize("k", range(8, 23))
 @pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
 def test_fft_against_numpy(k, prec):
     n = 1 << k
@@ -500,3 +500,15 @@ def test_linearity_without_kerr_effect():
     lhs = f(0.3 * x1 + (0.2 - 0.9j) * x2)
     rhs = 0.3 * f(x1) + (0.2 - 0.9j) * f(x2)
     assert relmax(lhs, rhs) < 1e-12
+
+
+def test_two_to_the_22_against_oracle():
+    """Largest supported size (N1 = 512 column tiles, 8192-point rows): 2^22 x 1, three steps."""
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 22, seed=5, n_pol=1)[0]
+    kw = dict(length=3 * 0.25, h=0.25, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    ref = orc.fiber_c64(a, gv.dt, **kw)
+    assert relmax(y, ref) < TOL_100
+    y21 = oa.FIBER(optical_signal(a[: 1 << 21]), **kw).signal
+    assert relmax(y21, orc.fiber_c64(a[: 1 << 21], gv.dt, **kw)) < TOL_100

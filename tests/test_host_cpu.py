@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.ssfm_abi_version() == 1
-    assert _lib.supported_log2n(_lib.C64) == (8, 20)
+    assert _lib.supported_log2n(_lib.C64) == (8, 22)
 
 
 def test_no_cpu_fallback_without_device():
