@@ -73,10 +73,16 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     distributed = "RANK" in os.environ          # under torch.distributed.run, also with one rank
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")          # diagnostics only: gloo | none
+    if backend == "none":
+        distributed = False
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from opticomlib_amd import _lib, devices, workloads
 
@@ -118,7 +124,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -129,8 +135,9 @@ def main():
     # the only "exchange" of this path: gather one checksum per channel at the end
     checks = [power]
     if distributed:
-        g = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(g, torch.tensor([power], dtype=torch.float64, device="cuda"))
+        dev = "cuda" if backend == "nccl" else "cpu"
+        g = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([power], dtype=torch.float64, device=dev))
         checks = [float(v.item()) for v in g]
 
     value = world * n * SSFM_STEPS * args.steps / elapsed

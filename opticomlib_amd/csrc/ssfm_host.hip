@@ -344,8 +344,15 @@ template <typename T> struct PlanT : PlanBase {
         while (batch % nlanes) --nlanes;
         lane_stream[0] = stream;
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        // The lanes only overlap if their streams sit on DIFFERENT hardware queues.  The runtime multiplexes
+        // streams onto GPU_MAX_HW_QUEUES (default 4) queues per priority class; a process that also holds
+        // RCCL's streams (torch.distributed, backend nccl) had both lanes land on one queue and the run
+        // degrade from 21 to 35 us per step.  Streams of another priority class use queues of their own,
+        // so the extra lanes are created with the highest priority.
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         for (int g = 1; g < nlanes; ++g) {
-            HIP_TRY(hipStreamCreateWithFlags(&lane_stream[g], hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, (g & 1) ? prio_hi : prio_lo));
             HIP_TRY(hipEventCreateWithFlags(&lane_ev[g], hipEventDisableTiming));
         }
         const size_t cb = sizeof(cx<T>);
