@@ -195,15 +195,11 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
-    // Launch mode of fixed-step runs.  A 1000-step run is 2000-4000 launches; they can be issued eagerly
-    // or replayed as ONE hipGraph.  Neither is always faster: on an idle host eager launches win by ~4 %
-    // (the graph serialises a little more), under torch.distributed.run with RCCL initialised the eager
-    // launch rate halves and the graph wins by 50 % -- and the host time of the enqueue loop does not
-    // show it (the launches return quickly; the runtime's submission is what is slow).  So both modes
-    // are MEASURED with the plan's HIP events: calls 1 and 2 of a schedule run eagerly (a caller that
-    // propagates once or twice never pays the ~10 ms capture + instantiate of 4000 nodes), call 3
-    // captures and replays a graph, and from call 4 on the faster mode is used.
-    // SSFM_GRAPH=0 / 1 forces eager / graph.
+    // Launch mode of fixed-step runs.  A 1000-step run is 2000-4000 launches; they are issued eagerly by
+    // default.  SSFM_GRAPH=1 replays them as ONE captured hipGraph from the second run of a schedule on;
+    // SSFM_GRAPH=auto measures both with the plan's HIP events (runs 1-2 eager, run 3 capture + replay,
+    // ~10 ms once) and keeps the faster from run 4 on -- for hosts whose launch rate cannot keep up with
+    // the GPU.  (With the lanes on their own hardware queues, see init(), eager and graph are within 1 %.)
     struct GraphEntry {
         unsigned long long key;
         hipGraph_t graph;
@@ -216,7 +212,7 @@ template <typename T> struct PlanT : PlanBase {
     };
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0;
-    int graph_policy = -1;          // -1 auto, 0 never, 1 always
+    int graph_policy = 0;           // 0 eager (default), 1 always graph, -1 measure both and keep the faster
     int pending_entry = -1;         // entry whose last run still has to be read from ev0/ev1
     int pending_mode = 0;           // 0 eager, 1 graph
     static constexpr size_t kMaxGraphs = 4;
@@ -329,14 +325,23 @@ template <typename T> struct PlanT : PlanBase {
         N1 = 1 << k1;
         N2 = 1 << (k - k1);
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // All streams of a plan live in the HIGHEST priority class.  The lanes only overlap if their streams
+        // sit on different hardware queues; the runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default
+        // 4) queues per priority class, and in a process that also holds RCCL's (normal-priority) streams
+        // -- torch.distributed with backend nccl -- two normal-priority lanes landed on ONE queue: 35
+        // instead of 21 us per step.  A priority class of their own gives the lanes queues of their own;
+        // giving them the SAME priority keeps the arbitration between them fair (one high, one normal lane
+        // starved the normal one: 26 instead of 16 us per field-step with 4 fields).
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         E = 16;                    // measured: E = 8 (twice the waves, one more exchange) is 10 % slower
         if (const char* e = std::getenv("SSFM_E")) E = std::atoi(e) == 16 ? 16 : 8;
         if (k > 20) E = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
         if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = (e[0] == 'a' || e[0] == 'A') ? -1 : (std::atoi(e) != 0 ? 1 : 0);
         int want = 2;
         if (const char* e = std::getenv("SSFM_LANES")) want = std::atoi(e);
         nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
@@ -344,15 +349,8 @@ template <typename T> struct PlanT : PlanBase {
         while (batch % nlanes) --nlanes;
         lane_stream[0] = stream;
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-        // The lanes only overlap if their streams sit on DIFFERENT hardware queues.  The runtime multiplexes
-        // streams onto GPU_MAX_HW_QUEUES (default 4) queues per priority class; a process that also holds
-        // RCCL's streams (torch.distributed, backend nccl) had both lanes land on one queue and the run
-        // degrade from 21 to 35 us per step.  Streams of another priority class use queues of their own,
-        // so the extra lanes are created with the highest priority.
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         for (int g = 1; g < nlanes; ++g) {
-            HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, (g & 1) ? prio_hi : prio_lo));
+            HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, prio_hi));
             HIP_TRY(hipEventCreateWithFlags(&lane_ev[g], hipEventDisableTiming));
         }
         const size_t cb = sizeof(cx<T>);
