@@ -121,6 +121,13 @@ int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out
  *   x,y  HOST, batch x n float64 (is_complex = 0) or complex128 interleaved (is_complex = 1); y may alias x */
 int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
                      int64_t n, int batch, int is_complex);
+/* The same with x and y in DEVICE memory of `device` (complex buffers 16-byte aligned; y may alias x), so a
+ * field can be filtered where it was propagated.  sos and zi stay HOST arrays.  Synchronous. */
+int ssfm_sosfiltfilt_device(int device, const double* sos, const double* zi, int n_sections, const void* x_dev, void* y_dev,
+                            int64_t n, int batch, int is_complex);
+/* Device time [ms] of the six kernels of the last ssfm_sosfiltfilt* call on `device` (HIP events on the
+ * filter's stream, transfers excluded). */
+int ssfm_sosfiltfilt_last_ms(int device, float* ms);
 
 /* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);

@@ -35,6 +35,8 @@ SYMBOLS = {
     "ssfm_apply_transfer": (_I, [_VP, _VP]),
     "ssfm_apply_dispersion": (_I, [_VP, _D, _D, _VP]),
     "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
+    "ssfm_sosfiltfilt_device": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
+    "ssfm_sosfiltfilt_last_ms": (_I, [_I, C.POINTER(C.c_float)]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
@@ -107,6 +109,22 @@ def sosfiltfilt(sos: np.ndarray, zi: np.ndarray, x: np.ndarray, device: int = 0)
     _check(load().ssfm_sosfiltfilt(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _ptr(xs), _ptr(y), n, batch, int(is_c)),
            "ssfm_sosfiltfilt")
     return y
+
+
+def sosfiltfilt_device(sos: np.ndarray, zi: np.ndarray, x_ptr: int, y_ptr: int, n: int, batch: int, is_complex: bool,
+                       device: int = 0) -> None:
+    """The same on DEVICE buffers (raw pointers; float64 or interleaved complex128, ``batch`` rows of ``n``)."""
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    zi = np.ascontiguousarray(zi, dtype=np.float64)
+    _check(load().ssfm_sosfiltfilt_device(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _VP(x_ptr), _VP(y_ptr), int(n), int(batch),
+                                          int(bool(is_complex))), "ssfm_sosfiltfilt_device")
+
+
+def sosfiltfilt_last_ms(device: int = 0) -> float:
+    """Device time [ms] of the kernels of the last filter call on ``device``."""
+    ms = C.c_float()
+    _check(load().ssfm_sosfiltfilt_last_ms(int(device), C.byref(ms)), "ssfm_sosfiltfilt_last_ms")
+    return float(ms.value)
 
 
 class Plan:

@@ -3,20 +3,35 @@
 // scipy.signal.sosfiltfilt(sos, x, axis=-1) with its default odd padding of 3*ntaps samples and
 // steady-state initial conditions.
 //
-// A cascade of NS biquads in direct form II transposed is a linear recurrence with a K = 2*NS state.
-// It is parallelised over time by chunking:
-//   k_chunk   every thread runs the recurrence over ITS chunk of L consecutive samples from a ZERO
-//             state and keeps the final state p_c (the chunk's particular solution);
-//   k_scan_*  the chunk start states s_{c+1} = A^L s_c + p_c by a two-level scan (groups of 64 chunks);
-//             A^L, the K x K homogeneous map over L samples, is built once on the host by running the
-//             same recurrence on unit states, A^(64 L) by six squarings;
-//   k_apply   every thread re-runs its chunk from the true start state and writes the outputs.
-// Inside a chunk the operation order is exactly SciPy's sample loop; only the chunk start states see a
-// different summation order (relative 1e-16 effects).  Complex rows are two independent real channels
-// (real coefficients), addressed with stride 2.  float64 throughout, like SciPy.
+// A cascade of NS biquads in direct form II transposed is a linear recurrence with a K = 2*NS state
+// per channel.  It is parallelised over time by chunks of L = 16 samples, TWO launches per direction:
+//   k_chunk_scan  a thread runs the recurrence over ITS chunk from a ZERO state (the chunk's particular
+//                 solution p_c); the 64 chunks of a wavefront are combined by a shuffle scan of the affine
+//                 maps s -> M s + p_c (M = A^L, the homogeneous map over one chunk), the 4 wavefronts of
+//                 the workgroup through LDS: every chunk gets e_c = its start state if the workgroup's
+//                 GROUP of 256 chunks started from zero, the group its total T_g;
+//   k_apply       a workgroup first forms the true start state of its group,
+//                     S_g = (M^256)^g s_0 + sum_{j<g} (M^256)^(g-1-j) T_j,      s_0 = zi * x_0,
+//                 by a reduction over all earlier group totals (each lane multiplies by its own power
+//                 (M^256)^lane, a wavefront sums with shuffles and applies (M^16384)^a); then a thread
+//                 forms its chunk's start state M^(c mod 256) S_g + e_c, re-runs the chunk and writes
+//                 the outputs.  The reduction is O(groups^2) over the grid -- 257 groups per 2^20-sample
+//                 row, nothing against the sample work -- and replaces a separate, serial scan kernel
+//                 (measured 25 us of a 127 us call).
+// The powers M^j, (M^256)^j, (M^16384)^j, j = 0..64, are built once per filter on the host from M, which
+// itself comes from running the same recurrence on unit states.  A wavefront's 64 chunks are 1024
+// consecutive samples: they are read (and the outputs written) with coalesced accesses and transposed
+// through LDS, so that a thread still walks ITS chunk in order.  Inside a chunk the operation order is
+// exactly SciPy's sample loop (fp contraction off); only the chunk start states see a different
+// summation order (relative 1e-16 effects).  A complex row is two real channels with the same real
+// coefficients, carried by ONE thread (16-byte accesses).  float64 throughout, like SciPy.
+//
+// Traffic per real sample: forward 8 (chunk) + 8 + 8 (apply: read x, write y1), backward the same
+// = 48 B against the algorithmic 16 B (read x once, write y once).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ssfm_common.hpp"
@@ -25,30 +40,55 @@ using ssfm::fail;
 
 namespace {
 
-constexpr int kChunk = 256;        // samples per thread
+constexpr int kChunk = 16;         // samples per thread (measured at 2^20 x 2 complex: 16 -> 121 us, 32 -> 130 us, 64 -> 158 us per call)
+constexpr int kWave = 64;          // lanes per wavefront
+constexpr int kWaves = 4;          // wavefronts per workgroup
+constexpr int kGroup = kWave * kWaves;   // chunks per group = threads per workgroup
 constexpr int kMaxSections = 4;    // Bessel orders up to 8
 
 struct SosCoefs {
     double b0[kMaxSections], b1[kMaxSections], b2[kMaxSections], a1[kMaxSections], a2[kMaxSections];
 };
 
+// One direction of the forward-backward pass.  Rows hold CH interleaved channels.
 struct SosPass {
-    const double* src;      // forward: caller's x (first element of row 0); backward: y1 buffer
-    long long row_pitch;    // elements between consecutive virtual rows of src
-    long long stride;       // element stride inside a row (1 real, 2 complex)
+    const double* src;      // forward: caller's x; backward: y1 (padded forward output, [row][m][CH])
     long long n;            // original samples per row
     long long m;            // padded length n + 2*edge
     int edge;
     int backward;
 };
 
-// sample i of the pass input for a virtual row starting at `base`
-__device__ __forceinline__ double sos_input(const SosPass& p, const double* base, long long i) {
-    if (p.backward) return base[p.m - 1 - i];                                   // reversed forward output
-    if (i < p.edge) return 2.0 * base[0] - base[(p.edge - i) * p.stride];       // odd extension, left
-    if (i < p.edge + p.n) return base[(i - p.edge) * p.stride];
-    const long long r = i - p.edge - p.n;                                       // odd extension, right
-    return 2.0 * base[(p.n - 1) * p.stride] - base[(p.n - 2 - r) * p.stride];
+template <int CH> struct Smp { double v[CH]; };
+
+template <int CH> __device__ __forceinline__ Smp<CH> ld(const double* p, long long e) {
+    Smp<CH> r;
+    if constexpr (CH == 2) {
+        const double2 q = *reinterpret_cast<const double2*>(p + 2 * e);
+        r.v[0] = q.x; r.v[1] = q.y;
+    } else {
+        r.v[0] = p[e];
+    }
+    return r;
+}
+template <int CH> __device__ __forceinline__ void st(double* p, long long e, const Smp<CH>& s) {
+    if constexpr (CH == 2) *reinterpret_cast<double2*>(p + 2 * e) = make_double2(s.v[0], s.v[1]);
+    else p[e] = s.v[0];
+}
+
+// sample i of the pass input of the row starting at `base`
+template <int CH> __device__ __forceinline__ Smp<CH> sos_input(const SosPass& p, const double* base, long long i) {
+    if (p.backward) return ld<CH>(base, p.m - 1 - i);                            // reversed forward output
+    if (i >= p.edge && i < p.edge + p.n) return ld<CH>(base, i - p.edge);
+    Smp<CH> a, b;
+    if (i < p.edge) { a = ld<CH>(base, 0); b = ld<CH>(base, p.edge - i); }       // odd extension, left
+    else            { a = ld<CH>(base, p.n - 1); b = ld<CH>(base, p.n - 2 - (i - p.edge - p.n)); }   // right
+#pragma unroll
+    for (int c = 0; c < CH; ++c) a.v[c] = 2.0 * a.v[c] - b.v[c];
+    return a;
+}
+template <int CH> __device__ __forceinline__ const double* pass_row(const SosPass& p, int row) {
+    return p.src + (long long)row * (p.backward ? p.m : p.n) * CH;
 }
 
 template <int NS>
@@ -64,146 +104,394 @@ __device__ __forceinline__ double sos_step(const SosCoefs& c, double (&z)[NS][2]
     return x;
 }
 
-// virtual row v -> base pointer of the pass input
-__device__ __forceinline__ const double* row_base(const SosPass& p, int v, int chan_per_row) {
-    if (p.backward) return p.src + (long long)v * p.row_pitch;
-    return p.src + (long long)(v / chan_per_row) * p.row_pitch + (v % chan_per_row);
+// LDS staging of a wavefront's 64 x kChunk samples: element r = chunk * kChunk + t lives at r + r / kChunk
+// (one pad element per chunk: a lane's ds_read/ds_write of "its" sample t is bank-conflict free).
+constexpr int kWaveSamples = kWave * kChunk;
+constexpr int kLdsElems = kWaveSamples + kWave;
+__device__ __forceinline__ int lds_pos(int r) { return r + r / kChunk; }
+
+// Is the wavefront's sample range [w0, w0 + 64 * kChunk) of the padded sequence plain memory (no odd extension,
+// no ragged end)?  Wave-uniform.
+__device__ __forceinline__ bool wave_is_plain(const SosPass& p, long long w0) {
+    if (p.backward) return w0 + kWaveSamples <= p.m;
+    return w0 >= p.edge && w0 + kWaveSamples <= p.edge + p.n;
 }
 
-template <int NS>
-__global__ void k_chunk(SosCoefs c, SosPass p, int nchunks, int vrows, int chan, double* __restrict__ pfinal) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)nchunks * vrows) return;
-    const int v = (int)(g / nchunks), ch = (int)(g % nchunks);
-    const double* base = row_base(p, v, chan);
-    double z[NS][2];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) z[s][0] = z[s][1] = 0.0;
-    const long long i0 = (long long)ch * kChunk;
-    const long long i1 = i0 + kChunk < p.m ? i0 + kChunk : p.m;
-    for (long long i = i0; i < i1; ++i) sos_step<NS>(c, z, sos_input(p, base, i));
-    double* out = pfinal + g * (2 * NS);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { out[2 * s] = z[s][0]; out[2 * s + 1] = z[s][1]; }
+// A wavefront exchanges data through ITS slice of LDS only: DS instructions of one wavefront execute in
+// order, so no workgroup barrier is needed -- just keep the compiler from reordering across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Chunk start states by a two-level scan of the affine maps s -> A s + p_c (A = A^kChunk):
-//   k_scan_group   thread per (row, group of kGroup chunks): the group's zero-state response
-//   k_scan_top     thread per row: walks the groups with AG = A^kGroup (n_chunks / kGroup steps)
-//   k_scan_starts  thread per (row, group): re-walks its chunks from the group's true start state
-// so the longest serial chain is 2*kGroup + n_chunks/kGroup matrix-vector steps instead of n_chunks.
-constexpr int kGroup = 64;
-
-template <int K> __device__ __forceinline__ void affine_step(const double (&A)[K][K], double (&s)[K], const double* __restrict__ p) {
-    double t[K];
+// the kChunk input samples of the lane's chunk (all loads issued before the recurrence starts)
+template <int CH> __device__ __forceinline__ void load_chunk(const SosPass& p, const double* base, long long w0, int lane, int len, bool plain,
+                                                              Smp<CH>* lds, Smp<CH> (&xs)[kChunk]) {
+    if (plain) {
+        // coalesced: instruction t moves samples w0 + 64 t + lane
+        Smp<CH> tmp[kChunk];
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-        double acc = p[r];
+        for (int t = 0; t < kChunk; ++t) {
+            const long long i = w0 + t * kWave + lane;
+            tmp[t] = ld<CH>(base, p.backward ? p.m - 1 - i : i - p.edge);
+        }
 #pragma unroll
-        for (int q = 0; q < K; ++q) acc += A[r][q] * s[q];
-        t[r] = acc;
+        for (int t = 0; t < kChunk; ++t) lds[lds_pos(t * kWave + lane)] = tmp[t];
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) xs[t] = lds[lane * (kChunk + 1) + t];
+        wave_lds_sync();
+    } else {
+        const long long i0 = w0 + (long long)lane * kChunk;
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+            if (t < len) xs[t] = sos_input<CH>(p, base, i0 + t);
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) s[k] = t[k];
 }
-template <int K> __device__ __forceinline__ void load_mat(double (&A)[K][K], const double* __restrict__ M) {
+
+// y += M x  (M row-major K x K, wave-uniform address)
+template <int K, int CH> __device__ __forceinline__ void mat_acc(const double* M, const double (&x)[CH][K], double (&y)[CH][K]) {
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
-        for (int q = 0; q < K; ++q) A[r][q] = M[r * K + q];
+        for (int q = 0; q < K; ++q) {
+            const double mrq = M[r * K + q];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) y[c][r] += mrq * x[c][q];
+        }
 }
 
-template <int NS>
-__global__ void k_scan_group(int nchunks, int ngroups, int vrows, const double* __restrict__ Amat,
-                             const double* __restrict__ pfinal, double* __restrict__ gfinal) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups * vrows) return;
-    constexpr int K = 2 * NS;
-    const int v = g / ngroups, gi = g % ngroups;
-    double A[K][K], s[K];
-    load_mat<K>(A, Amat);
-#pragma unroll
-    for (int k = 0; k < K; ++k) s[k] = 0.0;
-    const int c1 = (gi + 1) * kGroup < nchunks ? (gi + 1) * kGroup : nchunks;
-    for (int ch = gi * kGroup; ch < c1; ++ch) affine_step<K>(A, s, pfinal + ((long long)v * nchunks + ch) * K);
-#pragma unroll
-    for (int k = 0; k < K; ++k) gfinal[(long long)g * K + k] = s[k];
-}
-
-template <int NS>
-__global__ void k_scan_top(SosPass p, int ngroups, int vrows, int chan, const double* __restrict__ zi,
-                           const double* __restrict__ AGmat, const double* __restrict__ gfinal, double* __restrict__ gstart) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= vrows) return;
-    constexpr int K = 2 * NS;
-    const double u0 = sos_input(p, row_base(p, v, chan), 0);
-    double AG[K][K], s[K];
-    load_mat<K>(AG, AGmat);
-#pragma unroll
-    for (int k = 0; k < K; ++k) s[k] = zi[k] * u0;                  // zi * x_0 (sosfiltfilt)
-    for (int gi = 0; gi < ngroups; ++gi) {
-        double* st = gstart + ((long long)v * ngroups + gi) * K;
-#pragma unroll
-        for (int k = 0; k < K; ++k) st[k] = s[k];
-        affine_step<K>(AG, s, gfinal + ((long long)v * ngroups + gi) * K);
+// The scan's doubling steps use M^1, M^2, M^4 ... M^32, the combination of the wavefronts M^64.  Fetching
+// them step by step from global memory puts dependent cache misses on the critical path of kernels that
+// only live for microseconds, so a workgroup copies the seven matrices to LDS up front (one latency,
+// overlapped with its data loads).
+constexpr int kScanSteps = 6;
+template <int K> __device__ __forceinline__ void stage_pow2(const double* __restrict__ pw, double* lds_pw, int tid) {
+    for (int e = tid; e < (kScanSteps + 1) * K * K; e += kGroup) {
+        const int k = e / (K * K);
+        lds_pw[e] = pw[((long long)1 << k) * K * K + e % (K * K)];
     }
 }
-
-template <int NS>
-__global__ void k_scan_starts(int nchunks, int ngroups, int vrows, const double* __restrict__ Amat,
-                              const double* __restrict__ pfinal, const double* __restrict__ gstart, double* __restrict__ start) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups * vrows) return;
-    constexpr int K = 2 * NS;
-    const int v = g / ngroups, gi = g % ngroups;
-    double A[K][K], s[K];
-    load_mat<K>(A, Amat);
+// Inclusive scan over the 64 lanes of a wavefront of the affine maps s -> M s + x_lane (same M in every
+// lane): afterwards x_lane = sum_{i <= lane} M^(lane - i) x_i.  lds_pw = stage_pow2's copy of the powers.
+template <int K, int CH> __device__ __forceinline__ void wave_scan(double (&x)[CH][K], const double* lds_pw) {
+    const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
-    for (int k = 0; k < K; ++k) s[k] = gstart[(long long)g * K + k];
-    const int c1 = (gi + 1) * kGroup < nchunks ? (gi + 1) * kGroup : nchunks;
-    for (int ch = gi * kGroup; ch < c1; ++ch) {
-        double* st = start + ((long long)v * nchunks + ch) * K;
+    for (int k = 0; k < kScanSteps; ++k) {
+        const int d = 1 << k;
+        double up[CH][K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) st[k] = s[k];
-        affine_step<K>(A, s, pfinal + ((long long)v * nchunks + ch) * K);
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const double o = __shfl_up(x[c][q], d, kWave);
+                up[c][q] = lane >= d ? o : 0.0;
+            }
+        mat_acc<K, CH>(lds_pw + k * K * K, up, x);
     }
 }
-
-template <int NS>
-__global__ void k_apply(SosCoefs c, SosPass p, int nchunks, int vrows, int chan, const double* __restrict__ start,
-                        double* __restrict__ y1, double* __restrict__ out, long long out_pitch, long long out_stride) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)nchunks * vrows) return;
-    const int v = (int)(g / nchunks), ch = (int)(g % nchunks);
-    const double* base = row_base(p, v, chan);
-    double z[NS][2];
-    const double* st = start + g * (2 * NS);
+// x <- M x
+template <int K, int CH> __device__ __forceinline__ void mat_apply(const double* M, double (&x)[CH][K]) {
+    double y[CH][K];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { z[s][0] = st[2 * s]; z[s][1] = st[2 * s + 1]; }
-    const long long i0 = (long long)ch * kChunk;
-    const long long i1 = i0 + kChunk < p.m ? i0 + kChunk : p.m;
-    if (!p.backward) {
-        double* dst = y1 + (long long)v * p.m;
-        for (long long i = i0; i < i1; ++i) dst[i] = sos_step<NS>(c, z, sos_input(p, base, i));
-    } else {
-        // y = reverse(y2)[edge : m - edge]  ->  out[n] = y2[m - 1 - (n + edge)]
-        double* dst = out + (long long)(v / chan) * out_pitch + (v % chan);
-        for (long long i = i0; i < i1; ++i) {
-            const double y = sos_step<NS>(c, z, sos_input(p, base, i));
-            const long long nn = p.m - 1 - i - p.edge;
-            if (nn >= 0 && nn < p.n) dst[nn * out_stride] = y;
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[c][k] = 0.0;
+    mat_acc<K, CH>(M, x, y);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[c][k] = y[c][k];
+}
+
+// state vector s[CH][K] <-> z[NS][2] per channel
+template <int NS, int CH>
+__global__ __launch_bounds__(kGroup) void k_chunk_scan(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ pw,
+                                                       double* __restrict__ E, double* __restrict__ T) {
+    constexpr int K = 2 * NS;
+    __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
+    __shared__ double lds_pw[(kScanSteps + 1) * K * K];
+    __shared__ double tot[kWaves][CH * K];
+    const int row = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    const int ch = g * kGroup + tid;
+    const long long w0 = ((long long)g * kGroup + wv * kWave) * kChunk;
+    const bool plain = wave_is_plain(p, w0);
+    stage_pow2<K>(pw, lds_pw, tid);
+    // this lane's M^lane, for the offset of its wavefront inside the group (fetched ahead of its use)
+    double Ml[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) Ml[r][q] = pw[(long long)lane * K * K + r * K + q];
+    double s[CH][K];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) s[a][k] = 0.0;
+    if (plain || ch < nchunks) {
+        const double* base = pass_row<CH>(p, row);
+        const long long i0 = (long long)ch * kChunk;
+        const int len = (int)(i0 + kChunk <= p.m ? kChunk : p.m - i0);
+        Smp<CH> xs[kChunk];
+        load_chunk<CH>(p, base, w0, lane, len, plain, lds_all[wv], xs);
+        double z[CH][NS][2];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) z[a][q][0] = z[a][q][1] = 0.0;
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+            if (t < len) {
+#pragma unroll
+                for (int a = 0; a < CH; ++a) sos_step<NS>(c, z[a], xs[t].v[a]);
+            }
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { s[a][2 * q] = z[a][q][0]; s[a][2 * q + 1] = z[a][q][1]; }
+    }
+    __syncthreads();                      // lds_pw staged
+    wave_scan<K, CH>(s, lds_pw);
+    // exclusive prefix = the chunk's start state if its WAVEFRONT started from zero
+    double ex[CH][K];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double prev = __shfl_up(s[a][k], 1, kWave);
+            ex[a][k] = lane ? prev : 0.0;
+            if (lane == kWave - 1) tot[wv][a * K + k] = s[a][k];
+        }
+    __syncthreads();
+    // start state of this wavefront if the GROUP started from zero: ws_{w+1} = M^64 ws_w + tot_w
+    const double* M64 = lds_pw + kScanSteps * K * K;
+    double ws[CH][K];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) ws[a][k] = 0.0;
+    for (int w = 0; w < wv; ++w) {
+        mat_apply<K, CH>(M64, ws);
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) ws[a][k] += tot[w][a * K + k];
+    }
+    // e_c = M^lane ws + (wavefront-local exclusive prefix)
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a) ex[a][r] += Ml[r][q] * ws[a][q];
+        }
+    double* Eo = E + ((long long)row * ngroups * kGroup + ch) * (CH * K);
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) Eo[a * K + k] = ex[a][k];
+    if (wv == kWaves - 1) {
+        // group total = state after the last wavefront
+        mat_apply<K, CH>(M64, ws);
+        if (lane == 0) {
+            double* To = T + ((long long)row * ngroups + g) * (CH * K);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) To[a * K + k] = ws[a][k] + tot[kWaves - 1][a * K + k];
         }
     }
 }
 
-template <int NS>
-int run_filter(const SosCoefs& c, const double* zi_h, const double* x_h, double* y_h, long long n, int batch, int chan, int edge) {
+template <int NS, int CH>
+__global__ __launch_bounds__(kGroup) void k_apply(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi,
+                                                  const double* __restrict__ pw, const double* __restrict__ pwG, const double* __restrict__ pwH,
+                                                  const double* __restrict__ E, const double* __restrict__ T,
+                                                  double* __restrict__ y1, double* __restrict__ out) {
     constexpr int K = 2 * NS;
-    const long long m = n + 2ll * edge;
-    const int vrows = batch * chan;
-    const int nchunks = (int)((m + kChunk - 1) / kChunk);
-    // A^kChunk: column q = state after kChunk zero-input steps from unit state e_q (host, same recurrence)
-    double Amat[K * K];
+    __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
+    __shared__ double lds_m64[K * K];
+    __shared__ double red[kWaves][CH * K];
+    const int row = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    const int ch = g * kGroup + tid;
+    const long long w0 = ((long long)g * kGroup + wv * kWave) * kChunk;
+    const bool plain = wave_is_plain(p, w0);
+    const bool active = plain || ch < nchunks;
+    const double* base = pass_row<CH>(p, row);
+    for (int e = tid; e < K * K; e += kGroup) lds_m64[e] = pw[(long long)kWave * K * K + e];
+    // operands fetched ahead of the samples: e_c, this lane's M^lane and (M^256)^lane
+    double s[CH][K], Ml[K][K], MG[K][K];
+    const double* Eo = E + ((long long)row * ngroups * kGroup + ch) * (CH * K);
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) s[a][k] = Eo[a * K + k];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) { Ml[r][q] = pw[(long long)lane * K * K + r * K + q]; MG[r][q] = pwG[(long long)lane * K * K + r * K + q]; }
+    const long long i0 = (long long)ch * kChunk;
+    const int len = (int)(i0 + kChunk <= p.m ? kChunk : p.m - i0);
+    Smp<CH> xs[kChunk];
+    if (active) load_chunk<CH>(p, base, w0, lane, len, plain, lds_all[wv], xs);
+
+    // ---- start state of the group: S_g = sum over distances d = 0..g of (M^256)^d v_d,
+    //      v_d = T_{g-1-d} for d < g, v_g = s_0 = zi * x_0.  d = 64 a + lane: lane power, then wavefront power.
+    double acc[CH][K];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[a][k] = 0.0;
+    for (int d0 = 0; d0 <= g; d0 += kGroup) {
+        const int d = d0 + tid;
+        double v[CH][K], u[CH][K];
+        if (d < g) {
+            const double* Tj = T + ((long long)row * ngroups + (g - 1 - d)) * (CH * K);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[a][k] = Tj[a * K + k];
+        } else if (d == g) {
+            const Smp<CH> u0 = sos_input<CH>(p, base, 0);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[a][k] = zi[k] * u0.v[a];          // zi * x_0 (sosfiltfilt)
+        } else {
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[a][k] = 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < K; ++q) t += MG[r][q] * v[a][q];
+                u[a][r] = t;
+            }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) u[a][k] += __shfl_xor(u[a][k], o, kWave);
+        if (d0 + wv * kWave <= g) mat_acc<K, CH>(pwH + (long long)(d0 / kWave + wv) * K * K, u, acc);      // wave-uniform
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[wv][a * K + k] = acc[a][k];
+    }
+    __syncthreads();
+    double sg[CH][K];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double t = red[0][a * K + k];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) t += red[w][a * K + k];
+            sg[a][k] = t;
+        }
+    if (!active) return;
+    // true start state of the chunk = M^lane (M^64)^wv S_g + e_c
+    for (int w = 0; w < wv; ++w) mat_apply<K, CH>(lds_m64, sg);
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a) s[a][r] += Ml[r][q] * sg[a][q];
+        }
+    double z[CH][NS][2];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { z[a][q][0] = s[a][2 * q]; z[a][q][1] = s[a][2 * q + 1]; }
+    Smp<CH>* lds = lds_all[wv];
+    double* const dst_f = y1 + (long long)row * p.m * CH;
+    double* const dst_b = out + (long long)row * p.n * CH;
+    if (plain) {
+        // outputs back through LDS, then coalesced stores
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            Smp<CH> y;
+#pragma unroll
+            for (int a = 0; a < CH; ++a) y.v[a] = sos_step<NS>(c, z[a], xs[t].v[a]);
+            lds[lane * (kChunk + 1) + t] = y;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            const Smp<CH> y = lds[lds_pos(t * kWave + lane)];
+            const long long i = w0 + t * kWave + lane;
+            if (!p.backward) st<CH>(dst_f, i, y);
+            else {
+                // y = reverse(y2)[edge : m - edge]  ->  out[nn] = y2[m - 1 - (nn + edge)]
+                const long long nn = p.m - 1 - i - p.edge;
+                if (nn >= 0 && nn < p.n) st<CH>(dst_b, nn, y);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t)
+        if (t < len) {
+            Smp<CH> y;
+#pragma unroll
+            for (int a = 0; a < CH; ++a) y.v[a] = sos_step<NS>(c, z[a], xs[t].v[a]);
+            if (!p.backward) st<CH>(dst_f, i0 + t, y);
+            else {
+                const long long nn = p.m - 1 - (i0 + t) - p.edge;
+                if (nn >= 0 && nn < p.n) st<CH>(dst_b, nn, y);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- host
+// Scratch memory of the filter, one set per device, grown on demand and kept (a hipMalloc/hipFree pair
+// per call cost more than the kernels).  Calls on one device are serialised by `mu`.
+struct Workspace {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // x staging, y1, E, T, (unused), tables
+    size_t cap[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<double> table_key;       // sos coefficients the device tables were built for
+    float last_ms = 0.f;
+    hipError_t need(int i, size_t bytes) {
+        if (bytes <= cap[i]) return hipSuccess;
+        if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+        hipError_t e = hipMalloc(&buf[i], bytes);
+        if (e == hipSuccess) cap[i] = bytes;
+        return e;
+    }
+};
+constexpr int kMaxDevices = 64;
+Workspace g_ws[kMaxDevices];
+
+template <int K> void matmul(const double* A, const double* B, double* C) {
+    for (int r = 0; r < K; ++r)
+        for (int q = 0; q < K; ++q) {
+            double acc = 0.0;
+            for (int m2 = 0; m2 < K; ++m2) acc += A[r * K + m2] * B[m2 * K + q];
+            C[r * K + q] = acc;
+        }
+}
+
+// tables[level][j] = (M_level)^j, j = 0..64; level 0: M = A^kChunk, level 1: M^256 (one group of 4 x 64
+// chunks), level 2: M^16384 (64 groups)
+template <int NS> void build_tables(const SosCoefs& c, std::vector<double>& tab) {
+    constexpr int K = 2 * NS;
+    double M[K * K];
+    // column q of A^kChunk = state after kChunk zero-input steps from the unit state e_q
     for (int q = 0; q < K; ++q) {
         double z[NS][2];
         for (int s = 0; s < NS; ++s) z[s][0] = z[s][1] = 0.0;
@@ -217,66 +505,95 @@ int run_filter(const SosCoefs& c, const double* zi_h, const double* x_h, double*
                 z[s][1] = c.b2[s] * xn - c.a2[s] * x;
             }
         }
-        for (int r = 0; r < K; ++r) Amat[r * K + q] = z[r / 2][r % 2];
+        for (int r = 0; r < K; ++r) M[r * K + q] = z[r / 2][r % 2];
     }
-    // AG = A^kGroup: the homogeneous map over a whole group of chunks (kGroup = 2^6: six squarings)
-    double AG[K * K];
-    std::memcpy(AG, Amat, sizeof(AG));
-    for (int it = 0; (1 << it) < kGroup; ++it) {
-        double T2[K * K];
-        for (int r = 0; r < K; ++r)
-            for (int q = 0; q < K; ++q) {
-                double acc = 0.0;
-                for (int m2 = 0; m2 < K; ++m2) acc += AG[r * K + m2] * AG[m2 * K + q];
-                T2[r * K + q] = acc;
-            }
-        std::memcpy(AG, T2, sizeof(AG));
+    tab.assign((size_t)3 * (kWave + 1) * K * K, 0.0);
+    for (int level = 0; level < 3; ++level) {
+        double* P = tab.data() + (size_t)level * (kWave + 1) * K * K;
+        for (int r = 0; r < K; ++r) P[r * K + r] = 1.0;
+        for (int j = 0; j < kWave; ++j) matmul<K>(M, P + (size_t)j * K * K, P + (size_t)(j + 1) * K * K);
+        std::memcpy(M, P + (size_t)kWave * K * K, sizeof(M));                 // M^64 of this level
+        if (level == 0) {                                                     // group map = (M^64)^kWaves
+            double A[K * K], B[K * K];
+            std::memcpy(A, M, sizeof(M));
+            for (int w = 1; w < kWaves; ++w) { matmul<K>(M, A, B); std::memcpy(A, B, sizeof(A)); }
+            std::memcpy(M, A, sizeof(M));
+        }
     }
+}
+
+#define WS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SSFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+template <int NS, int CH>
+int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const double* zi_h, const double* x, double* y,
+               long long n, int rows, int edge, bool on_device) {
+    constexpr int K = 2 * NS;
+    const long long m = n + 2ll * edge;
+    const long long nchunks_ll = (m + kChunk - 1) / kChunk;
+    if (nchunks_ll > (1ll << 30)) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_sosfiltfilt: n=%lld too long", n);
+    const int nchunks = (int)nchunks_ll;
     const int ngroups = (nchunks + kGroup - 1) / kGroup;
-    const size_t xbytes = sizeof(double) * (size_t)n * vrows;
-    double *d_x = nullptr, *d_y1 = nullptr, *d_pf = nullptr, *d_st = nullptr, *d_zi = nullptr, *d_A = nullptr, *d_AG = nullptr, *d_gf = nullptr, *d_gs = nullptr;
-    auto cleanup = [&]() { void* b[] = {d_x, d_y1, d_pf, d_st, d_zi, d_A, d_AG, d_gf, d_gs}; for (void* q : b) (void)hipFree(q); };
-#define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(SSFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    TRY_OR_CLEAN(hipMalloc(&d_x, xbytes));
-    TRY_OR_CLEAN(hipMalloc(&d_y1, sizeof(double) * (size_t)m * vrows));
-    TRY_OR_CLEAN(hipMalloc(&d_pf, sizeof(double) * (size_t)nchunks * vrows * K));
-    TRY_OR_CLEAN(hipMalloc(&d_st, sizeof(double) * (size_t)nchunks * vrows * K));
-    TRY_OR_CLEAN(hipMalloc(&d_zi, sizeof(double) * K));
-    TRY_OR_CLEAN(hipMalloc(&d_A, sizeof(double) * K * K));
-    TRY_OR_CLEAN(hipMalloc(&d_AG, sizeof(double) * K * K));
-    TRY_OR_CLEAN(hipMalloc(&d_gf, sizeof(double) * (size_t)ngroups * vrows * K));
-    TRY_OR_CLEAN(hipMalloc(&d_gs, sizeof(double) * (size_t)ngroups * vrows * K));
-    TRY_OR_CLEAN(hipMemcpy(d_AG, AG, sizeof(double) * K * K, hipMemcpyHostToDevice));
-    TRY_OR_CLEAN(hipMemcpy(d_x, x_h, xbytes, hipMemcpyHostToDevice));
-    TRY_OR_CLEAN(hipMemcpy(d_zi, zi_h, sizeof(double) * K, hipMemcpyHostToDevice));
-    TRY_OR_CLEAN(hipMemcpy(d_A, Amat, sizeof(double) * K * K, hipMemcpyHostToDevice));
-    const long long work = (long long)nchunks * vrows;
-    const dim3 gw((unsigned)((work + 127) / 128)), bw(128);
+    if (ngroups > kWave * kWave)
+        return fail(SSFM_ERR_UNSUPPORTED, "ssfm_sosfiltfilt: n=%lld exceeds %d samples per row", n, kWave * kWave * kGroup * kChunk - 2 * edge);
+    if ((long long)ngroups * rows > 0x7fffffffll) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_sosfiltfilt: %d rows of %lld samples exceed the grid", rows, n);
+    const size_t xbytes = sizeof(double) * (size_t)n * rows * CH;
+    if (!w.stream) {
+        WS_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        WS_TRY(hipEventCreate(&w.ev0));
+        WS_TRY(hipEventCreate(&w.ev1));
+    }
+    if (!on_device) WS_TRY(w.need(0, xbytes));
+    WS_TRY(w.need(1, sizeof(double) * (size_t)m * rows * CH));
+    WS_TRY(w.need(2, sizeof(double) * (size_t)ngroups * kGroup * rows * CH * K));
+    WS_TRY(w.need(3, sizeof(double) * (size_t)ngroups * rows * CH * K));
+    const size_t tab_doubles = (size_t)3 * (kWave + 1) * K * K;
+    WS_TRY(w.need(5, sizeof(double) * (tab_doubles + K)));
+    // tables + zi: rebuilt only when the filter changes
+    std::vector<double> key(sos_key, sos_key + 6 * NS);
+    key.insert(key.end(), zi_h, zi_h + K);
+    if (key != w.table_key) {
+        std::vector<double> tab;
+        build_tables<NS>(c, tab);
+        tab.insert(tab.end(), zi_h, zi_h + K);
+        WS_TRY(hipMemcpyAsync(w.buf[5], tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, w.stream));
+        WS_TRY(hipStreamSynchronize(w.stream));            // `tab` is a local
+        w.table_key = key;
+    }
+    const double* d_pw = w.buf[5];
+    const double* d_pwG = w.buf[5] + (size_t)(kWave + 1) * K * K;
+    const double* d_pwH = w.buf[5] + (size_t)2 * (kWave + 1) * K * K;
+    const double* d_zi = w.buf[5] + tab_doubles;
+    const double* d_x = x;
+    double* d_out = y;
+    if (!on_device) {
+        WS_TRY(hipMemcpyAsync(w.buf[0], x, xbytes, hipMemcpyHostToDevice, w.stream));
+        d_x = w.buf[0];
+        d_out = w.buf[0];          // the backward pass writes the trimmed result over the staged input
+    }
+    double *d_y1 = w.buf[1], *d_E = w.buf[2], *d_T = w.buf[3];
+    WS_TRY(hipEventRecord(w.ev0, w.stream));
+    // One stream: splitting the rows over two streams (as the propagator does) was measured SLOWER here
+    // (145 vs 121 us for 2 x 2^20 complex) -- every kernel is a short latency chain, not a bandwidth phase.
     SosPass p;
     p.n = n; p.m = m; p.edge = edge;
+    const dim3 grid((unsigned)(ngroups * rows)), block(kGroup);
     for (int dir = 0; dir < 2; ++dir) {
         p.backward = dir;
-        if (dir == 0) { p.src = d_x; p.row_pitch = n * chan; p.stride = chan; }
-        else          { p.src = d_y1; p.row_pitch = m; p.stride = 1; }
-        hipLaunchKernelGGL(k_chunk<NS>, gw, bw, 0, 0, c, p, nchunks, vrows, chan, d_pf);
-        const dim3 gg((unsigned)((ngroups * vrows + 63) / 64)), bg(64);
-        hipLaunchKernelGGL(k_scan_group<NS>, gg, bg, 0, 0, nchunks, ngroups, vrows, (const double*)d_A, (const double*)d_pf, d_gf);
-        hipLaunchKernelGGL(k_scan_top<NS>, dim3((vrows + 63) / 64), dim3(64), 0, 0, p, ngroups, vrows, chan, (const double*)d_zi, (const double*)d_AG, (const double*)d_gf, d_gs);
-        hipLaunchKernelGGL(k_scan_starts<NS>, gg, bg, 0, 0, nchunks, ngroups, vrows, (const double*)d_A, (const double*)d_pf, (const double*)d_gs, d_st);
-        // the backward pass writes the trimmed, re-reversed result over the input buffer
-        hipLaunchKernelGGL(k_apply<NS>, gw, bw, 0, 0, c, p, nchunks, vrows, chan, (const double*)d_st, d_y1, d_x, n * chan, (long long)chan);
-        TRY_OR_CLEAN(hipGetLastError());
+        p.src = dir == 0 ? d_x : d_y1;
+        hipLaunchKernelGGL((k_chunk_scan<NS, CH>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_pw, d_E, d_T);
+        hipLaunchKernelGGL((k_apply<NS, CH>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
+                           (const double*)d_T, d_y1, d_out);
+        WS_TRY(hipGetLastError());
     }
-    TRY_OR_CLEAN(hipMemcpy(y_h, d_x, xbytes, hipMemcpyDeviceToHost));
-#undef TRY_OR_CLEAN
-    cleanup();
+    WS_TRY(hipEventRecord(w.ev1, w.stream));
+    if (!on_device) WS_TRY(hipMemcpyAsync(y, w.buf[0], xbytes, hipMemcpyDeviceToHost, w.stream));
+    WS_TRY(hipStreamSynchronize(w.stream));
+    WS_TRY(hipEventElapsedTime(&w.last_ms, w.ev0, w.ev1));
     return SSFM_OK;
 }
 
-}  // namespace
-
-extern "C" int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
-                                int64_t n, int batch, int is_complex) {
+int sosfiltfilt_impl(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
+                     int64_t n, int batch, int is_complex, bool on_device) {
     if (!sos || !zi || !x || !y) return fail(SSFM_ERR_INVALID, "ssfm_sosfiltfilt: NULL argument");
     if (n_sections < 1 || n_sections > kMaxSections)
         return fail(SSFM_ERR_UNSUPPORTED, "ssfm_sosfiltfilt: %d sections (supported: 1..%d)", n_sections, kMaxSections);
@@ -293,17 +610,43 @@ extern "C" int ssfm_sosfiltfilt(int device, const double* sos, const double* zi,
     const int ntaps = 2 * n_sections + 1 - (zb < za ? zb : za);       // scipy sosfiltfilt
     const int edge = 3 * ntaps;
     if (n <= edge) return fail(SSFM_ERR_INVALID, "The length of the input vector x must be greater than padlen, which is %d.", edge);
+    if (is_complex && on_device && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15))
+        return fail(SSFM_ERR_INVALID, "ssfm_sosfiltfilt_device: complex buffers must be 16-byte aligned");
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count || device >= kMaxDevices)
         return fail(SSFM_ERR_NO_DEVICE, "ssfm_sosfiltfilt: device %d not available", device);
     HIP_TRY(hipSetDevice(device));
-    const int chan = is_complex ? 2 : 1;
-    const double* xh = static_cast<const double*>(x);
-    double* yh = static_cast<double*>(y);
+    Workspace& w = g_ws[device];
+    std::lock_guard<std::mutex> lock(w.mu);
+    const double* xd = static_cast<const double*>(x);
+    double* yd = static_cast<double*>(y);
+#define SOS_CASE(NS)                                                                                                  \
+    case NS: return is_complex ? run_filter<NS, 2>(w, c, sos, zi, xd, yd, n, batch, edge, on_device)                   \
+                               : run_filter<NS, 1>(w, c, sos, zi, xd, yd, n, batch, edge, on_device);
     switch (n_sections) {
-        case 1: return run_filter<1>(c, zi, xh, yh, n, batch, chan, edge);
-        case 2: return run_filter<2>(c, zi, xh, yh, n, batch, chan, edge);
-        case 3: return run_filter<3>(c, zi, xh, yh, n, batch, chan, edge);
-        default: return run_filter<4>(c, zi, xh, yh, n, batch, chan, edge);
+        SOS_CASE(1) SOS_CASE(2) SOS_CASE(3)
+        default: return is_complex ? run_filter<4, 2>(w, c, sos, zi, xd, yd, n, batch, edge, on_device)
+                                   : run_filter<4, 1>(w, c, sos, zi, xd, yd, n, batch, edge, on_device);
     }
+#undef SOS_CASE
+}
+
+}  // namespace
+
+extern "C" int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
+                                int64_t n, int batch, int is_complex) {
+    return sosfiltfilt_impl(device, sos, zi, n_sections, x, y, n, batch, is_complex, false);
+}
+
+extern "C" int ssfm_sosfiltfilt_device(int device, const double* sos, const double* zi, int n_sections, const void* x_dev, void* y_dev,
+                                       int64_t n, int batch, int is_complex) {
+    return sosfiltfilt_impl(device, sos, zi, n_sections, x_dev, y_dev, n, batch, is_complex, true);
+}
+
+extern "C" int ssfm_sosfiltfilt_last_ms(int device, float* ms) {
+    if (!ms) return fail(SSFM_ERR_INVALID, "ms is NULL");
+    if (device < 0 || device >= kMaxDevices) return fail(SSFM_ERR_NO_DEVICE, "ssfm_sosfiltfilt_last_ms: device %d", device);
+    std::lock_guard<std::mutex> lock(g_ws[device].mu);
+    *ms = g_ws[device].last_ms;
+    return SSFM_OK;
 }

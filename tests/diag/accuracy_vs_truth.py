@@ -1,7 +1,7 @@
 """How far are the complex64 results from the float64 solution -- ours (HIP) and the reference's (oracle)?"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from opticomlib_amd import FIBER, gv, optical_signal, workloads
 from oracle import ssfm_numpy as orc
 gv(**workloads.BENCH_GV)

@@ -8,7 +8,7 @@ import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "golden")]
 
 from opticomlib_amd import _lib, FIBER, DBP, DM, gv, optical_signal  # noqa: E402

@@ -364,6 +364,58 @@ def test_bessel_filters_full_size_against_oracle_and_scipy():
     assert relmax(oa.BPF(optical_signal(b), BW=60e9).signal, out) < TOL_FILT
 
 
+@pytest.mark.parametrize("order", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("n", [16, 31, 32, 33, 994, 995, 2047, 2048, 2049, 4066, 4067, 65599, (1 << 17) + 1])
+def test_sosfiltfilt_lengths_and_orders_against_scipy(order, n):
+    """Chunk (16), wavefront (64 chunks) and group (256 chunks) boundaries, odd lengths and every section count
+    against SciPy's sosfiltfilt (the reference's dependency, devices.py:1365-1368)."""
+    from scipy import signal as sg
+    sos = sg.bessel(order, 0.07 if n > 4096 else 0.2, "low", norm="mag", output="sos")
+    zi = sg.sosfilt_zi(sos)
+    ntaps = 2 * sos.shape[0] + 1 - min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum())
+    if n <= 3 * ntaps:
+        with pytest.raises(oa.SsfmError, match="greater than padlen"):
+            _lib.sosfiltfilt(sos, zi, np.ones(n))
+        return
+    rng = np.random.default_rng(order * 1000 + n)
+    x = rng.standard_normal(n).cumsum() * 0.05 + rng.standard_normal(n)
+    assert relmax(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x)) < TOL_FILT
+    xc = (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n)))
+    assert relmax(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1)) < TOL_FILT
+
+
+def test_sosfiltfilt_on_device_buffers():
+    """ssfm_sosfiltfilt_device on the field buffers of complex128 plans: same result as the host entry
+    point, out of place and in place (a propagated field is filtered where it lies)."""
+    from scipy import signal as sg
+    sos = sg.bessel(4, 0.1, "low", norm="mag", output="sos")
+    zi = sg.sosfilt_zi(sos)
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    x = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
+    want = _lib.sosfiltfilt(sos, zi, x)
+    p, q = _lib.Plan(n, 2, _lib.C128), _lib.Plan(n, 2, _lib.C128)
+    try:
+        p.set_field(x)
+        p.synchronize()
+        _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, q.field_device_ptr, n, 2, True)
+        assert np.array_equal(q.get_field(), want)
+        assert np.array_equal(p.get_field(), x)                        # input untouched
+        _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, p.field_device_ptr, n, 2, True)
+        assert np.array_equal(p.get_field(), want)
+        assert _lib.sosfiltfilt_last_ms() > 0
+        # the same bytes read as 4 real rows of 2n samples would be a different filter problem; as 2 x 2n
+        # REAL rows with interleaved re/im it is not valid either -- real mode is checked on its own data
+        p.set_field(x)
+        p.synchronize()
+        _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, p.field_device_ptr, 2 * n, 2, False)
+        got = p.get_field().view(np.float64)
+        assert np.array_equal(got, _lib.sosfiltfilt(sos, zi, x.view(np.float64)))
+    finally:
+        p.close()
+        q.close()
+
+
 def test_bessel_filter_errors():
     gv(sps=16, R=10e9)
     with pytest.raises(TypeError, match=r"`input` must be of type \(optical_signal\)."):
