@@ -129,6 +129,13 @@ int ssfm_sosfiltfilt_device(int device, const double* sos, const double* zi, int
  * filter's stream, transfers excluded). */
 int ssfm_sosfiltfilt_last_ms(int device, float* ms);
 
+/* Square-law detection of the reference's PD (devices.py:1512-1515): i_ph = r * (x * x.conj()).real summed
+ * over the polarisations, signal and noise kept apart as the reference's signal algebra does
+ * (typing.py:1337-1344): i_sig = r * sum_p |s_p|^2,  i_noise = r * sum_p Re(s_p n_p* + n_p s_p* + n_p n_p*).
+ *   sig, noise   HOST, n_pol x n complex128; noise may be NULL (then i_noise must be NULL)
+ *   i_sig, i_noise   HOST, n float64 */
+int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double* i_sig, double* i_noise);
+
 /* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);
 

@@ -37,6 +37,7 @@ SYMBOLS = {
     "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
     "ssfm_sosfiltfilt_device": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
     "ssfm_sosfiltfilt_last_ms": (_I, [_I, C.POINTER(C.c_float)]),
+    "ssfm_square_law": (_I, [_I, _VP, _VP, _I, _I64, _D, _VP, _VP]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
@@ -118,6 +119,24 @@ def sosfiltfilt_device(sos: np.ndarray, zi: np.ndarray, x_ptr: int, y_ptr: int, 
     zi = np.ascontiguousarray(zi, dtype=np.float64)
     _check(load().ssfm_sosfiltfilt_device(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _VP(x_ptr), _VP(y_ptr), int(n), int(batch),
                                           int(bool(is_complex))), "ssfm_sosfiltfilt_device")
+
+
+def square_law(signal: np.ndarray, noise, r: float, device: int = 0):
+    """``r * (x * x.conj()).real`` summed over the polarisations, signal and noise currents apart
+    (``noise`` may be None).  ``signal``: (N,) or (2, N) complex."""
+    s = np.ascontiguousarray(signal, dtype=np.complex128)
+    n = s.shape[-1]
+    n_pol = 1 if s.ndim == 1 else s.shape[0]
+    i_sig = np.empty(n, dtype=np.float64)
+    if noise is None:
+        _check(load().ssfm_square_law(int(device), _ptr(s), None, n_pol, n, float(r), _ptr(i_sig), None), "ssfm_square_law")
+        return i_sig, None
+    nz = np.ascontiguousarray(noise, dtype=np.complex128)
+    if nz.shape != s.shape:
+        raise ValueError(f"signal and noise shapes differ: {s.shape} vs {nz.shape}")
+    i_noise = np.empty(n, dtype=np.float64)
+    _check(load().ssfm_square_law(int(device), _ptr(s), _ptr(nz), n_pol, n, float(r), _ptr(i_sig), _ptr(i_noise)), "ssfm_square_law")
+    return i_sig, i_noise
 
 
 def sosfiltfilt_last_ms(device: int = 0) -> float:

@@ -306,3 +306,109 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
     output = optical_signal(res[0], res[1] if has_noise else NULL, n_pol=input.n_pol)
     output.execution_time = time.time() - t0
     return output
+
+
+# ----------------------------------------------------------------------------- receiver front-end
+# SURVEY.md 8(f) rank 2.  The random currents / fields are drawn on the host from the GLOBAL np.random
+# generator with the reference's calls in the reference's order, so a script that seeds np.random gets the
+# same realisation from either library; the O(N) arithmetic (square law, zero-phase filters) runs on the GPU.
+_PD_MODES = ("ase-only", "thermal-only", "shot-only", "ase-thermal", "ase-shot", "thermal-shot", "all", "none")
+
+
+def _idb(x):
+    """dB -> linear (reference ``utils.py:422-451``)."""
+    return 10 ** (x / 10)
+
+
+def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_load: float = 50.0,
+       include_noise: str = "all", i_dark: float = 10e-9, Fn=0, *, device=None) -> electrical_signal:
+    """P-I-N photodetector (reference ``devices.py:1378-1555``): ``v = R_load * (r * |E|^2 + noise)``
+    summed over the polarisations, low-pass filtered to ``BW`` [Hz].
+
+    The input's own noise (ASE) appears as signal-ASE and ASE-ASE beat currents in ``.noise``; thermal
+    (``4 kB T Fn fs/2 / R_load``) and shot (``2 e (mean(i_ph) + i_dark) fs/2``) currents are Gaussian.
+    ``include_noise`` selects the terms as in the reference ('all', 'none', 'ase-only', 'thermal-only',
+    'shot-only', 'ase-thermal', 'ase-shot', 'thermal-shot'; case-insensitive).
+    """
+    from numbers import Real
+    from scipy.constants import e, k as kB
+    t0 = time.time()
+    if not isinstance(input, optical_signal):
+        raise TypeError("`input` must be of type 'optical_signal'.")
+    if not isinstance(r, Real):
+        raise TypeError("`r` must be a scalar value.")
+    if r <= 0 or r > 1:
+        raise ValueError("`r` must be in the range (0,1]")
+    if not isinstance(T, Real):
+        raise TypeError("`T` must be a scalar value.")
+    if T < 0:
+        raise ValueError("`T` must be a positive value.")
+    if not isinstance(R_load, Real):
+        raise TypeError("`R_load` must be a scalar value.")
+    if R_load < 0:
+        raise ValueError("`R_load` must be a positive value.")
+    if not isinstance(include_noise, str):
+        raise TypeError("`include_noise` must be a string.")
+    mode = include_noise.lower()
+    dev = default_device() if device is None else int(device)
+    has_ase = input.noise is not NULL
+    i_sig, i_ase = _lib.square_law(input.signal, input.noise if has_ase else None, r, dev)
+    size = input.size
+    i_T = i_N = None
+    if "thermal" in mode or "all" in mode:
+        S_T = 4 * kB * T * gv.fs / 2 * _idb(Fn) / R_load
+        i_T = np.random.normal(0, S_T ** 0.5, size)
+    if "shot" in mode or "all" in mode:
+        mean = (i_sig + i_ase if has_ase else i_sig).mean()
+        S_N = 2 * e * (mean + i_dark) * gv.fs / 2
+        i_N = np.random.normal(0, S_N ** 0.5, size)
+    if mode not in _PD_MODES:
+        raise ValueError("The argument `include_noise` must be one of the following: 'ase-only','thermal-only','shot-only',"
+                         "'ase-thermal','ase-shot','thermal-shot','all', 'none'.")
+    i_noise = NULL
+    if mode != "none":
+        terms = []
+        if "ase" in mode or mode == "all":
+            terms.append(i_ase if has_ase else NULL)
+        if mode in ("all", "ase-shot", "shot-only"):
+            terms.append(i_N)
+        if "thermal" in mode or mode == "all":
+            terms.append(i_T)
+        if mode == "thermal-shot":
+            terms.append(i_N)
+        for t in terms:
+            i_noise = i_noise + t
+        i_noise = i_noise + i_dark
+        if np.ndim(i_noise) == 0:                      # 'ase-only' on a noiseless input: dark current alone
+            i_noise = np.full(size, float(i_noise))
+    output = electrical_signal(i_sig * R_load, NULL if i_noise is NULL else i_noise * R_load)
+    output = LPF(output, BW, device=dev)
+    output.execution_time = time.time() - t0
+    return output
+
+
+def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device=None) -> optical_signal:
+    """Erbium-doped fibre amplifier, simplest model (reference ``devices.py:829-942``): field gain
+    ``sqrt(G)``, ASE of power ``NF h f0 (G - 1) fs`` split over two polarisations x two quadratures
+    added to ``.noise``, then an optical ``BPF`` of bandwidth ``BW`` if given.  Output is always
+    dual-polarisation (a single-polarisation input gets an empty y signal, but ASE in both)."""
+    from scipy.constants import h
+    t0 = time.time()
+    if not isinstance(input, optical_signal):
+        raise TypeError("`input` must be of type 'optical_signal'.")
+    g = np.sqrt(_idb(G))
+    output = optical_signal(input.signal, input.noise, n_pol=2)
+    sig = output.signal * g
+    noi = NULL if output.noise is NULL else output.noise * g
+    if input.n_pol == 1:
+        sig[1] = np.zeros_like(sig[0])
+        if noi is not NULL:
+            noi[1] = np.zeros_like(noi[0])
+    P_ase = _idb(NF) * h * gv.f0 * (_idb(G) - 1) * gv.fs
+    ase = np.sqrt(P_ase / 4) * np.random.randn(4, input.size)
+    ase = ase[:2] + 1j * ase[2:]
+    output = optical_signal(sig, noi + ase, n_pol=2)
+    if BW is not None:
+        output = BPF(output, BW, device=device)
+    output.execution_time = time.time() - t0
+    return output

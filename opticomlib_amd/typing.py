@@ -15,6 +15,9 @@ from __future__ import annotations
 import numpy as np
 
 
+_C_LIGHT = 299792458.0       # scipy.constants.c
+
+
 class _NullType:
     """Additive identity that swallows everything else."""
 
@@ -47,7 +50,7 @@ NULL = _NullType()
 
 class _GlobalVars:
     """Sampling grid shared by all signals (reference ``typing.py:106-388``, the part the path
-    needs: ``sps``, ``R``, ``fs``, ``dt``)."""
+    needs: ``sps``, ``R``, ``fs``, ``dt``, and ``wavelength`` / ``f0`` for the EDFA's ASE power)."""
 
     def __init__(self):
         self.default()
@@ -57,9 +60,11 @@ class _GlobalVars:
         self.R = 1e9
         self.fs = self.R * self.sps
         self.dt = 1 / self.fs
+        self.wavelength = 1550e-9              # reference typing.py:207-209
+        self.f0 = _C_LIGHT / self.wavelength
         return self
 
-    def __call__(self, sps=None, R=None, fs=None, **extra):
+    def __call__(self, sps=None, R=None, fs=None, wavelength=1550e-9, **extra):
         # same precedence as the reference (typing.py:306-335)
         if sps:
             self.sps = int(np.round(sps))
@@ -82,6 +87,8 @@ class _GlobalVars:
             self.fs = fs
             self.sps = int(np.round(fs / self.R))
         self.dt = 1 / self.fs
+        self.wavelength = wavelength           # reset to the default on every call, like the reference (typing.py:340-341)
+        self.f0 = _C_LIGHT / wavelength
         for k, v in extra.items():
             setattr(self, k, v)
         return self

@@ -111,6 +111,28 @@ CASES = {
                         kw=dict(BW=50e9, n=4)),
     "bpf_2pol_n3_3000": dict(func="BPF", gv=GV_B, inp=("noise", 47, (2, 3000), "complex128", 0.03),
                              kw=dict(BW=100e9, n=3)),
+    # receiver front-end (reference devices.py:1378-1555 PD, :829-942 EDFA); the random terms come from the
+    # global np.random generator, seeded with `np_seed` right before the call
+    "pd_none_2pol": dict(func="PD", gv=GV_A, inp=("qpsk", 50, (2, 4096), "complex128", 0.03),
+                         kw=dict(BW=8e9, include_noise="none")),
+    "pd_ase_only_2pol": dict(func="PD", gv=GV_A, inp=("qpsk", 51, (2, 4096), "complex128", 0.03),
+                             noise=("noise", 52, (2, 4096), "complex128", 0.003),
+                             kw=dict(BW=8e9, r=0.8, R_load=75.0, include_noise="ase-only", i_dark=5e-9)),
+    "pd_all_2pol": dict(func="PD", gv=GV_A, inp=("qpsk", 53, (2, 4096), "complex128", 0.03),
+                        noise=("noise", 54, (2, 4096), "complex128", 0.003), np_seed=11,
+                        kw=dict(BW=8e9, include_noise="all")),
+    "pd_all_1pol_nonoise_in": dict(func="PD", gv=GV_B, inp=("qpsk", 55, (8192,), "complex128", 0.03), np_seed=12,
+                                   kw=dict(BW=20e9, r=0.9, T=350.0, include_noise="ALL", Fn=3)),
+    "pd_thermal_shot_1pol": dict(func="PD", gv=GV_A, inp=("noise", 56, (3000,), "complex128", 0.03),
+                                 noise=("noise", 57, (3000,), "complex128", 0.003), np_seed=13,
+                                 kw=dict(BW=5e9, include_noise="thermal-shot")),
+    "edfa_2pol_bw": dict(func="EDFA", gv=GV_A, inp=("qpsk", 60, (2, 4096), "complex128", 0.003),
+                         noise=("noise", 61, (2, 4096), "complex128", 0.0003), np_seed=21,
+                         kw=dict(G=20, NF=5, BW=40e9)),
+    "edfa_1pol_nobw": dict(func="EDFA", gv=GV_B, inp=("qpsk", 62, (8192,), "complex128", 0.003), np_seed=22,
+                           kw=dict(G=17.5, NF=4.5)),
+    "edfa_1pol_bw": dict(func="EDFA", gv=GV_B, inp=("qpsk", 63, (4096,), "complex128", 0.003), np_seed=23,
+                         kw=dict(G=25, NF=6, BW=100e9)),
     # float64 twin loop (reference devices.py:2425-2486), 1 polarisation only
     "twin_f64_1pol": dict(func="TWIN", gv=GV_A, inp=("noise", 30, (4096,), "complex128", 0.03),
                           kw=dict(length=10, h=1.0, **FIB)),

@@ -86,6 +86,13 @@ def run_case(name, case, devices, typing):
         out["out"] = y.signal
         if y.noise is not typing.NULL:
             out["out_noise"] = y.noise
+    elif func in ("PD", "EDFA"):
+        if "np_seed" in case:
+            np.random.seed(case["np_seed"])
+        y = getattr(devices, func)(x, **kw)
+        out["out"] = y.signal
+        if y.noise is not typing.NULL:
+            out["out_noise"] = y.noise
     elif func == "BPF":
         y = devices.BPF(x, **kw)
         out["out"] = y.signal

@@ -426,6 +426,77 @@ def test_bessel_filter_errors():
         oa.LPF(np.ones(10), 1e9)
 
 
+# ----------------------------------------------------------------------- PD / EDFA
+TOL_FRONT = 1e-11     # square law to 1 ulp (the reference's complex multiply fuses one product), then the filter
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] in ("PD", "EDFA")])
+def test_receiver_front_end_golden(golden_dir, name):
+    """Same np.random seed as the capture (tests/golden/make_golden.py): the realisation is the reference's."""
+    from opticomlib_amd.typing import electrical_signal
+    case = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    x = _signal(case)
+    if "np_seed" in case:
+        np.random.seed(case["np_seed"])
+    y = getattr(oa, case["func"])(x, **case["kw"])
+    if case["func"] == "PD":
+        assert isinstance(y, electrical_signal) and y.signal.dtype == np.float64
+    else:
+        assert isinstance(y, optical_signal) and y.n_pol == 2 and y.signal.dtype == np.complex128
+    assert y.execution_time > 0
+    assert y.signal.shape == g["out"].shape
+    assert relmax(y.signal, g["out"]) < TOL_FRONT
+    if "out_noise" in g:
+        assert relmax(y.noise, g["out_noise"]) < TOL_FRONT
+    else:
+        assert y.noise is NULL
+
+
+def test_square_law_against_oracle_full_size():
+    """2^20 x 2 with noise: the device square law against the restated reference algebra."""
+    from oracle import frontend_numpy as fe
+    rng = np.random.default_rng(9)
+    n = 1 << 20
+    s = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))) * 0.03
+    nz = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))) * 0.003
+    for sig, noi in ((s, nz), (s[0], nz[0]), (s, None)):
+        got_s, got_n = _lib.square_law(sig, noi, 0.7)
+        want_s, want_n = fe.square_law(sig, noi, 0.7)
+        np.testing.assert_allclose(got_s, want_s, rtol=1e-15, atol=0)
+        if noi is None:
+            assert got_n is None
+        else:
+            np.testing.assert_allclose(got_n, want_n, rtol=0, atol=1e-15 * np.max(np.abs(want_n)))
+
+
+def test_pd_statistics_and_modes():
+    """Noise terms: variances of the thermal / shot currents as specified (devices.py:1521-1527), every mode
+    accepted in any letter case, the reference's errors."""
+    from scipy.constants import e, k as kB
+    gv(sps=16, R=10e9)
+    n = 1 << 16
+    x = optical_signal(np.full(n, np.sqrt(1e-3), complex))             # 1 mW CW
+    from scipy import signal as sg
+    BW = 0.3 * gv.fs
+    sos = sg.bessel(4, BW, "low", fs=gv.fs, norm="mag", output="sos")
+    _, H = sg.sosfreqz(sos, worN=4096, fs=gv.fs, whole=True)
+    keep = np.mean(np.abs(H) ** 4)                                      # zero-phase filter: |H|^2 in amplitude
+    np.random.seed(1)
+    y = oa.PD(x, BW=BW, include_noise="Thermal-Only", i_dark=0.0)
+    S_T = 4 * kB * 300.0 * gv.fs / 2 / 50.0
+    assert abs(np.var(y.noise) / (S_T * 50.0 ** 2 * keep) - 1) < 0.05
+    np.testing.assert_allclose(y.signal[100:-100], 1e-3 * 50.0, rtol=1e-9)
+    y = oa.PD(x, BW=BW, include_noise="shot-only", i_dark=0.0)
+    S_N = 2 * e * 1e-3 * gv.fs / 2
+    assert abs(np.var(y.noise) / (S_N * 50.0 ** 2 * keep) - 1) < 0.05
+    for mode in ("ase-only", "ase-thermal", "ase-shot", "thermal-shot", "ALL", "none"):
+        y = oa.PD(x, BW=10e9, include_noise=mode)
+        assert (y.noise is NULL) == (mode == "none")
+    with pytest.raises(ValueError, match="must be one of the following"):
+        oa.PD(x, BW=10e9, include_noise="everything")
+
+
 # ----------------------------------------------------------------------- API behaviour on the device
 def test_call_order_and_argument_errors():
     p = _lib.Plan(4096, 2, _lib.C64)

@@ -178,3 +178,33 @@ def test_missing_library_fails_loudly():
     env = dict(os.environ, SSFM_LIB="/nonexistent/_ssfm_amd.so", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "LOUD" in r.stdout, r.stderr[-2000:]
+
+
+def test_front_end_argument_errors_need_no_gpu():
+    """PD / EDFA validate their arguments before touching the device (reference devices.py:1490-1510, :915-916)."""
+    import opticomlib_amd as oa
+    x = oa.optical_signal(np.ones(64, complex))
+    with pytest.raises(TypeError, match="`input` must be of type 'optical_signal'."):
+        oa.PD(np.ones(64), 1e9)
+    with pytest.raises(TypeError, match="`input` must be of type 'optical_signal'."):
+        oa.EDFA(np.ones(64), 20, 5)
+    with pytest.raises(ValueError, match=r"`r` must be in the range \(0,1\]"):
+        oa.PD(x, 1e9, r=1.5)
+    with pytest.raises(TypeError, match="`r` must be a scalar value."):
+        oa.PD(x, 1e9, r="1")
+    with pytest.raises(ValueError, match="`T` must be a positive value."):
+        oa.PD(x, 1e9, T=-1.0)
+    with pytest.raises(ValueError, match="`R_load` must be a positive value."):
+        oa.PD(x, 1e9, R_load=-50.0)
+    with pytest.raises(TypeError, match="`include_noise` must be a string."):
+        oa.PD(x, 1e9, include_noise=None)
+
+
+def test_gv_optical_carrier():
+    from opticomlib_amd.typing import gv
+    gv(sps=8, R=1e9)
+    assert gv.wavelength == 1550e-9 and abs(gv.f0 - 299792458.0 / 1550e-9) < 1
+    gv(sps=8, R=1e9, wavelength=1310e-9)
+    assert abs(gv.f0 - 299792458.0 / 1310e-9) < 1
+    gv(sps=8, R=1e9)
+    assert gv.wavelength == 1550e-9

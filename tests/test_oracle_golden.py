@@ -147,3 +147,27 @@ def test_bessel_filters_match_reference(golden_dir, name):
     _check(out, g["out"], exact, 1e-13)
     if noi is not None:
         _check(out_n, g["out_noise"], exact, 1e-13)
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] in ("PD", "EDFA")])
+def test_receiver_front_end_matches_reference(golden_dir, name):
+    """PD / EDFA: restated front-end (oracle/frontend_numpy.py) vs outputs of the imported reference, the
+    global np.random generator seeded as in tests/golden/make_golden.py."""
+    from oracle import frontend_numpy as fe
+    case = CASES[name]
+    g = _load(golden_dir, name)
+    exact = _same_numpy(g)
+    sig, noi = case_input(case)
+    fs = case["gv"]["sps"] * case["gv"]["R"]
+    if "np_seed" in case:
+        np.random.seed(case["np_seed"])
+    if case["func"] == "PD":
+        out, out_n = fe.pd(sig, noi, fs, **case["kw"])
+    else:
+        out, out_n = fe.edfa(sig, noi, fs, fe.default_f0(), **case["kw"])
+    assert out.shape == g["out"].shape and out.dtype == g["out"].dtype
+    _check(out, g["out"], exact, 1e-13)
+    if "out_noise" in g:
+        _check(out_n, g["out_noise"], exact, 1e-12)
+    else:
+        assert out_n is None

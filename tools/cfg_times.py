@@ -43,3 +43,8 @@ print(f"BPF() 2^20 x 2 c128 host-inclusive: {t*1e3:.1f} ms (scipy on this host: 
 pw = np.abs(a[0]) ** 2
 t = timeit(lambda: LPF(pw, BW=20e9)); t0 = time.perf_counter(); sg.sosfiltfilt(sos, pw); tc = time.perf_counter() - t0
 print(f"LPF() 2^20 real host-inclusive: {t*1e3:.1f} ms (scipy: {tc*1e3:.0f} ms)")
+from opticomlib_amd import PD, EDFA
+xn = optical_signal(a, 0.1 * a[::-1].copy())
+np.random.seed(0); t = timeit(lambda: PD(xn, BW=20e9, include_noise="none")); print(f"PD(include_noise='none') 2^20 x 2 host-inclusive: {t*1e3:.1f} ms")
+t = timeit(lambda: PD(xn, BW=20e9)); print(f"PD('all': 2 x 2^20 host normal variates) host-inclusive: {t*1e3:.1f} ms")
+t = timeit(lambda: EDFA(xn, G=20, NF=5, BW=100e9)); print(f"EDFA(G, NF, BW) 2^20 x 2 host-inclusive (4 x 2^20 host normal variates): {t*1e3:.1f} ms")
