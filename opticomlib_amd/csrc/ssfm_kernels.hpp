@@ -252,6 +252,18 @@ template <> __device__ __forceinline__ void sincos_acc<double>(double x, double&
 #ifndef SSFM_STORE_MODE
 #define SSFM_STORE_MODE 0
 #endif
+// SSFM_NT_LOADS: 1 = read the streamed data (field, |A|^2) with non-temporal loads so that the read-only
+// tables, which the OTHER lane's launch re-reads a few microseconds later, survive in the XCD's L2.
+#ifndef SSFM_NT_LOADS
+#define SSFM_NT_LOADS 0
+#endif
+template <typename V> __device__ __forceinline__ V stream_load(const V* p) {
+#if SSFM_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ void stream_store(cf32* p, cf32 v) {
 #if SSFM_STORE_MODE == 1
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
     T pold[E];
     LineTw<T, N1, E> tw;
 #pragma unroll
-    for (int t = 0; t < E; ++t) v[t] = Fb[off + t * stride];
+    for (int t = 0; t < E; ++t) v[t] = stream_load(&Fb[off + t * stride]);
 #if SSFM_TWN_COMPUTE
     // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
     // the tile's 16 x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
-            if (SSFM_ABL_NO_P) q = (T)1e-3; else q = Pb[g * PSTR];
+            if (SSFM_ABL_NO_P) q = (T)1e-3; else q = stream_load(&Pb[g * PSTR]);
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     }
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T), 
     LineTw<T, N2, E> tw;
     SSFM_STAMP(0);
 #pragma unroll
-    for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
+    for (int t = 0; t < E; ++t) v[t] = stream_load(&Frow[j + t * Q]);
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
     if (MODE != FM_FWD_ONLY) {
