@@ -278,9 +278,9 @@ def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, d
     sos, zi = _bessel_sos(n, BW, fs)
     dev = default_device() if device is None else int(device)
     # real coefficients: Re(filter(x)) == filter(Re(x)), so only the real channel is computed
+    # (signal and noise go to the device as they lie: no stacked host copy)
     has_noise = input.noise is not NULL
-    rows = [np.real(input.signal)] + ([np.real(input.noise)] if has_noise else [])
-    res = _lib.sosfiltfilt(sos, zi, np.stack(rows).astype(np.float64), dev)
+    res = [_lib.sosfiltfilt(sos, zi, np.real(a), dev) for a in ([input.signal, input.noise] if has_noise else [input.signal])]
     output = electrical_signal(res[0], res[1] if has_noise else NULL)
     if retH:
         from scipy import signal as sg
@@ -298,11 +298,8 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
         raise TypeError("`input` must be of type (optical_signal).")
     sos, zi = _bessel_sos(n, BW / 2, gv.fs)
     dev = default_device() if device is None else int(device)
-    sig = np.asarray(input.signal)
     has_noise = input.noise is not NULL
-    stack = np.stack([sig] + ([np.asarray(input.noise)] if has_noise else []))
-    cplx = np.iscomplexobj(stack)
-    res = _lib.sosfiltfilt(sos, zi, stack.astype(np.complex128 if cplx else np.float64), dev)
+    res = [_lib.sosfiltfilt(sos, zi, np.asarray(a), dev) for a in ([input.signal, input.noise] if has_noise else [input.signal])]
     output = optical_signal(res[0], res[1] if has_noise else NULL, n_pol=input.n_pol)
     output.execution_time = time.time() - t0
     return output

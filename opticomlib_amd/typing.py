@@ -110,11 +110,11 @@ class electrical_signal:
         if noi is not NULL:
             noi = np.asarray(noi)
             common = np.result_type(sig, noi) if dtype is None else dtype
-            sig, noi = sig.astype(common), noi.astype(common)
+            sig, noi = sig.astype(common, copy=False), noi.astype(common, copy=False)
             if sig.shape != noi.shape:
                 raise ValueError(f"`signal` and `noise` must have the same shape, mismatch shapes {sig.shape} and {noi.shape}!")
         elif dtype is not None:
-            sig = sig.astype(dtype)
+            sig = sig.astype(dtype, copy=False)
         if sig.ndim > 1 or sig.size < 1:
             raise ValueError(f"Signal must be scalar or 1D array for electrical_signal, invalid shape {sig.shape}")
         if sig.ndim == 0:
@@ -159,11 +159,11 @@ class optical_signal:
         if noi is not NULL:
             noi = np.asarray(noi)
             common = np.result_type(sig, noi) if dtype is None else dtype
-            sig, noi = sig.astype(common), noi.astype(common)
+            sig, noi = sig.astype(common, copy=False), noi.astype(common, copy=False)
             if sig.shape != noi.shape:
                 raise ValueError(f"`signal` and `noise` must have the same shape, mismatch shapes {sig.shape} and {noi.shape}!")
         elif dtype is not None:
-            sig = sig.astype(dtype)
+            sig = sig.astype(dtype, copy=False)
 
         if sig.ndim > 2 or (sig.ndim > 1 and sig.shape[0] > 2) or sig.size < 1:
             raise ValueError(f"Signal must be a scalar, 1D or 2D array for optical_signal, invalid shape {sig.shape}")
