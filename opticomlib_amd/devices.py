@@ -68,13 +68,34 @@ def _precision_code(precision) -> int:
 
 
 # ------------------------------------------------------------------ operator coefficients
+_OPERATORS: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
+_MAX_OPERATORS = 4            # 8-16 MiB each at 2^20
+
+
 def linear_operator(n, dt, alpha, beta_2, beta_3, precision=_lib.C64):
     """D~(w) = -alpha/2 + j beta_2/2 w^2 + j beta_3/6 w^3 in FFT order.
 
     complex64: every factor is rounded to float32 in the reference's own order
     (``devices.py:1137-1145``) so both sides start from identical coefficients.
     complex128: the float64 form of ``devices.py:2440-2442``.
+
+    The last few operators are kept (read-only): NumPy's ``w**3`` costs ~0.1 s at 2^20 points, and a link
+    simulation calls FIBER / DBP with the same fibre again and again.
     """
+    key = (int(n), float(dt), float(alpha), float(beta_2), float(beta_3), int(precision))
+    hit = _OPERATORS.get(key)
+    if hit is not None:
+        _OPERATORS.move_to_end(key)
+        return hit
+    d = _linear_operator(n, dt, alpha, beta_2, beta_3, precision)
+    d.flags.writeable = False
+    _OPERATORS[key] = d
+    while len(_OPERATORS) > _MAX_OPERATORS:
+        _OPERATORS.popitem(last=False)
+    return d
+
+
+def _linear_operator(n, dt, alpha, beta_2, beta_3, precision):
     w = np.fft.fftfreq(n, dt) * 2 * np.pi * 1e-12            # rad/ps
     if precision == _lib.C64:
         a = np.array(alpha / 4.343, dtype=_F32)

@@ -112,8 +112,10 @@ def sharded_map(fn: Callable[[int], np.ndarray], n_units: int, to_all: bool = Tr
     return gather_results(local, n_units, to_all=to_all)
 
 
-def propagate_channels(fields, dt: float, to_all: bool = True, **fiber_kw):
-    """``FIBER`` on every field of ``fields`` (shape ``(F, [2,] N)``), sharded over the ranks.
+def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False, **fiber_kw):
+    """``FIBER`` on every field of ``fields`` (shape ``(F, [2,] N)``), sharded over the ranks; with
+    ``dbp=True`` followed by ``DBP`` with the same parameters (configuration C4: forward + digital
+    back-propagation per Monte-Carlo realisation) without the field leaving the GPU in between.
 
     Each field is an independent propagation, exactly as F separate ``FIBER`` calls of the reference
     would be.  With a fixed step ``h`` the rows of different fields never interact, so all fields of
@@ -135,7 +137,7 @@ def propagate_channels(fields, dt: float, to_all: bool = True, **fiber_kw):
     if fixed and len(mine) > 1:
         prec = _precision_code(kw.get("precision", "complex64"))
         cdt = np.complex64 if prec == _lib.C64 else np.complex128
-        stack = np.ascontiguousarray(fields[mine], dtype=cdt)
+        stack = np.ascontiguousarray(fields if len(mine) == n_units else fields[mine], dtype=cdt)     # one process: no copy
         unit_shape = stack.shape[1:]
         n = unit_shape[-1]
         _check_size(n, prec)
@@ -147,10 +149,15 @@ def propagate_channels(fields, dt: float, to_all: bool = True, **fiber_kw):
         hs, _ = step_schedule(kw["length"], kw["h"], prec)
         if hs.size:
             plan.propagate_fixed(kw.get("gamma", 0.0), hs)
+            if dbp:                                   # DBP = FIBER with negated parameters (devices.py:1280-1283)
+                plan.set_linear_operator(linear_operator(n, dt, -kw.get("alpha", 0.0), -kw.get("beta_2", 0.0), -kw.get("beta_3", 0.0), prec))
+                plan.propagate_fixed(-kw.get("gamma", 0.0), hs)
         out = plan.get_field().reshape((len(mine),) + unit_shape)
         local = [out[k] for k in range(len(mine))]
     else:
+        from .devices import DBP
         for u in mine:
             gv.dt, gv.fs = dt, 1.0 / dt
-            local.append(FIBER(optical_signal(fields[u]), **kw).signal)
+            y = FIBER(optical_signal(fields[u]), **kw)
+            local.append((DBP(y, **kw) if dbp else y).signal)
     return gather_results(local, n_units, to_all=to_all)

@@ -595,6 +595,25 @@ def test_propagate_channels_batches_fields_in_one_plan():
         np.testing.assert_array_equal(outs[c], oa.FIBER(optical_signal(fields[c]), **kwa).signal)
 
 
+def test_propagate_channels_fiber_then_dbp_on_device():
+    """C4's chain with dbp=True: forward and back-propagation of all realisations in one plan, the field
+    never leaving the GPU in between -- bit-identical to DBP(FIBER(x)) through the host API, and within
+    tolerance of the oracle's DBP(FIBER(x))."""
+    from opticomlib_amd import dist as od
+    gv(**workloads.BENCH_GV)
+    n = 1 << 13
+    fields = np.stack([workloads.prbs_field(n, seed=s, power_w=4e-3) for s in (1, 2, 3)])
+    kw = dict(length=10, h=0.5, **workloads.SMF)
+    outs = od.propagate_channels(fields, gv.dt, dbp=True, **kw)
+    for c in range(3):
+        via_host = oa.DBP(oa.FIBER(optical_signal(fields[c]), **kw), **kw).signal
+        np.testing.assert_array_equal(outs[c], via_host)
+    ref = orc.dbp_c64(orc.fiber_c64(fields[0], gv.dt, **kw), gv.dt, **kw)
+    assert relmax(outs[0], ref) < TOL_100
+    one = od.propagate_channels(fields[:1], gv.dt, dbp=True, **kw)             # single unit: host-API branch
+    np.testing.assert_array_equal(one[0], outs[0])
+
+
 # ----------------------------------------------------------------------- symmetries of the propagator
 @pytest.mark.parametrize("prec,tol", [("complex64", 2e-5), ("complex128", 1e-11)])
 def test_symmetries_shift_and_global_phase(prec, tol):
