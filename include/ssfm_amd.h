@@ -34,6 +34,7 @@
 #ifndef SSFM_AMD_H
 #define SSFM_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -133,8 +134,27 @@ int ssfm_sosfiltfilt_last_ms(int device, float* ms);
  * over the polarisations, signal and noise kept apart as the reference's signal algebra does
  * (typing.py:1337-1344): i_sig = r * sum_p |s_p|^2,  i_noise = r * sum_p Re(s_p n_p* + n_p s_p* + n_p n_p*).
  *   sig, noise   HOST, n_pol x n complex128; noise may be NULL (then i_noise must be NULL)
+ *   post   factor applied to the summed currents (1 for currents; R_load of devices.py:1547 for voltages)
  *   i_sig, i_noise   HOST, n float64 */
-int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double* i_sig, double* i_noise);
+int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise);
+
+/* The same on DEVICE buffers (16-byte aligned).  Synchronous. */
+int ssfm_square_law_device(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise);
+
+/* ---- device-resident signals ----------------------------------------------------------------------
+ * Raw HBM buffers that a host-side signal object can own between calls, so that a chain such as
+ * FIBER -> DBP -> BPF -> PD moves nothing over PCIe until a result is looked at.  The reference keeps
+ * every signal as a NumPy array (typing.py:1022-1165, :2124-2196); the host mirror's `.signal` /
+ * `.noise` are materialised lazily from these.  All calls are synchronous.
+ *   ssfm_device_alloc / _free   pooled per (device, size); pass the allocation size to _free
+ *   ssfm_device_copy            kind 0 host->device, 1 device->host, 2 device->device
+ *   ssfm_device_convert         complex64 <-> complex128, `count` complex elements
+ *   ssfm_device_add             dst = a + b, `count` complex elements of `precision` */
+int ssfm_device_alloc(int device, size_t bytes, void** out);
+int ssfm_device_free(int device, void* ptr, size_t bytes);
+int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind);
+int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
+int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
 
 /* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);

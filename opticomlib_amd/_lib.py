@@ -37,7 +37,13 @@ SYMBOLS = {
     "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
     "ssfm_sosfiltfilt_device": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
     "ssfm_sosfiltfilt_last_ms": (_I, [_I, C.POINTER(C.c_float)]),
-    "ssfm_square_law": (_I, [_I, _VP, _VP, _I, _I64, _D, _VP, _VP]),
+    "ssfm_square_law": (_I, [_I, _VP, _VP, _I, _I64, _D, _D, _VP, _VP]),
+    "ssfm_square_law_device": (_I, [_I, _VP, _VP, _I, _I64, _D, _D, _VP, _VP]),
+    "ssfm_device_alloc": (_I, [_I, C.c_size_t, C.POINTER(_VP)]),
+    "ssfm_device_free": (_I, [_I, _VP, C.c_size_t]),
+    "ssfm_device_copy": (_I, [_I, _VP, _VP, C.c_size_t, _I]),
+    "ssfm_device_convert": (_I, [_I, _VP, _I, _VP, _I, _I64]),
+    "ssfm_device_add": (_I, [_I, _VP, _VP, _VP, _I, _I64]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
@@ -129,13 +135,13 @@ def square_law(signal: np.ndarray, noise, r: float, device: int = 0):
     n_pol = 1 if s.ndim == 1 else s.shape[0]
     i_sig = np.empty(n, dtype=np.float64)
     if noise is None:
-        _check(load().ssfm_square_law(int(device), _ptr(s), None, n_pol, n, float(r), _ptr(i_sig), None), "ssfm_square_law")
+        _check(load().ssfm_square_law(int(device), _ptr(s), None, n_pol, n, float(r), 1.0, _ptr(i_sig), None), "ssfm_square_law")
         return i_sig, None
     nz = np.ascontiguousarray(noise, dtype=np.complex128)
     if nz.shape != s.shape:
         raise ValueError(f"signal and noise shapes differ: {s.shape} vs {nz.shape}")
     i_noise = np.empty(n, dtype=np.float64)
-    _check(load().ssfm_square_law(int(device), _ptr(s), _ptr(nz), n_pol, n, float(r), _ptr(i_sig), _ptr(i_noise)), "ssfm_square_law")
+    _check(load().ssfm_square_law(int(device), _ptr(s), _ptr(nz), n_pol, n, float(r), 1.0, _ptr(i_sig), _ptr(i_noise)), "ssfm_square_law")
     return i_sig, i_noise
 
 
@@ -144,6 +150,114 @@ def sosfiltfilt_last_ms(device: int = 0) -> float:
     ms = C.c_float()
     _check(load().ssfm_sosfiltfilt_last_ms(int(device), C.byref(ms)), "ssfm_sosfiltfilt_last_ms")
     return float(ms.value)
+
+
+# ----------------------------------------------------------------------------- device-resident arrays
+TRANSFERS = {"h2d": 0, "d2h": 0}        # counts of DeviceArray host<->device copies (tests check laziness with it)
+
+
+class DeviceArray:
+    """A C-contiguous array in the HBM of one GPU: what a signal object holds between device calls.
+
+    ``dtype`` is complex64, complex128 or float64.  The buffer goes back to the library's pool when the
+    object is collected."""
+
+    def __init__(self, shape, dtype, device: int = 0):
+        self.shape = tuple(int(d) for d in np.atleast_1d(shape)) if not isinstance(shape, tuple) else tuple(int(d) for d in shape)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.complex64), np.dtype(np.complex128), np.dtype(np.float64)):
+            raise TypeError(f"DeviceArray supports complex64, complex128 and float64, not {self.dtype}")
+        self.device = int(device)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = 0
+        p = _VP()
+        _check(load().ssfm_device_alloc(self.device, self.nbytes, C.byref(p)), "ssfm_device_alloc")
+        self.ptr = int(p.value)
+
+    # numpy-like metadata (no transfer)
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def free(self):
+        if self.ptr and _lib is not None:
+            _lib.ssfm_device_free(self.device, _VP(self.ptr), self.nbytes)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_host(cls, a: np.ndarray, dtype=None, device: int = 0) -> "DeviceArray":
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = cls(a.shape, a.dtype, device)
+        _check(load().ssfm_device_copy(d.device, _VP(d.ptr), _ptr(a), d.nbytes, 0), "ssfm_device_copy")
+        TRANSFERS["h2d"] += 1
+        return d
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        _check(load().ssfm_device_copy(self.device, _ptr(out), _VP(self.ptr), self.nbytes, 1), "ssfm_device_copy")
+        TRANSFERS["d2h"] += 1
+        return out
+
+    def copy(self) -> "DeviceArray":
+        d = DeviceArray(self.shape, self.dtype, self.device)
+        _check(load().ssfm_device_copy(self.device, _VP(d.ptr), _VP(self.ptr), self.nbytes, 2), "ssfm_device_copy")
+        return d
+
+    def reshape(self, *shape) -> "DeviceArray":
+        """The same buffer under another shape is not supported (one owner per buffer): returns a copy."""
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        d = self.copy()
+        if int(np.prod(shape)) != self.size:
+            raise ValueError(f"cannot reshape {self.shape} to {shape}")
+        d.shape = tuple(int(x) for x in shape)
+        return d
+
+    def astype(self, dtype) -> "DeviceArray":
+        """complex64 <-> complex128 on the device (a copy when the type already matches)."""
+        dtype = np.dtype(dtype)
+        if dtype == self.dtype:
+            return self.copy()
+        codes = {np.dtype(np.complex64): C64, np.dtype(np.complex128): C128}
+        if self.dtype not in codes or dtype not in codes:
+            raise TypeError(f"DeviceArray.astype: {self.dtype} -> {dtype} is not supported")
+        d = DeviceArray(self.shape, dtype, self.device)
+        _check(load().ssfm_device_convert(self.device, _VP(self.ptr), codes[self.dtype], _VP(d.ptr), codes[dtype], self.size), "ssfm_device_convert")
+        return d
+
+    def __add__(self, other: "DeviceArray") -> "DeviceArray":
+        if not isinstance(other, DeviceArray) or other.shape != self.shape or other.dtype != self.dtype or other.device != self.device:
+            raise TypeError("DeviceArray + DeviceArray needs equal shapes, types and devices")
+        codes = {np.dtype(np.complex64): C64, np.dtype(np.complex128): C128}
+        d = DeviceArray(self.shape, self.dtype, self.device)
+        _check(load().ssfm_device_add(self.device, _VP(d.ptr), _VP(self.ptr), _VP(other.ptr), codes[self.dtype], self.size), "ssfm_device_add")
+        return d
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.device})"
+
+
+def square_law_device(signal: DeviceArray, noise, r: float, post: float = 1.0):
+    """:func:`square_law` on device-resident complex128 fields; returns float64 DeviceArrays (times ``post``)."""
+    n = signal.shape[-1]
+    n_pol = 1 if signal.ndim == 1 else signal.shape[0]
+    i_sig = DeviceArray((n,), np.float64, signal.device)
+    i_noise = None if noise is None else DeviceArray((n,), np.float64, signal.device)
+    _check(load().ssfm_square_law_device(signal.device, _VP(signal.ptr), None if noise is None else _VP(noise.ptr), n_pol, n, float(r), float(post),
+                                         _VP(i_sig.ptr), None if noise is None else _VP(i_noise.ptr)), "ssfm_square_law_device")
+    return i_sig, i_noise
 
 
 class Plan:
@@ -191,6 +305,18 @@ class Plan:
 
     def get_field_device(self, dev_ptr: int):
         _check(load().ssfm_get_field(self._h, C.c_void_p(dev_ptr), 1), "ssfm_get_field")
+
+    def copy_into_field(self, byte_offset: int, src_ptr: int, nbytes: int, on_device: bool):
+        """Raw copy into the plan's field buffer at ``byte_offset`` (rows of several arrays side by side)."""
+        _check(load().ssfm_synchronize(self._h), "ssfm_synchronize")
+        _check(load().ssfm_device_copy(self.device, _VP(self.field_device_ptr + byte_offset), _VP(src_ptr), nbytes, 2 if on_device else 0),
+               "ssfm_device_copy")
+        TRANSFERS["h2d"] += 0 if on_device else 1
+
+    def copy_from_field(self, byte_offset: int, dst_dev_ptr: int, nbytes: int):
+        """Raw device-to-device copy out of the plan's field buffer."""
+        _check(load().ssfm_synchronize(self._h), "ssfm_synchronize")
+        _check(load().ssfm_device_copy(self.device, _VP(dst_dev_ptr), _VP(self.field_device_ptr + byte_offset), nbytes, 2), "ssfm_device_copy")
 
     @property
     def field_device_ptr(self) -> int:

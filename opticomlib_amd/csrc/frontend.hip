@@ -1,6 +1,7 @@
 // frontend.hip -- receiver front-end arithmetic on gfx950: the square-law detection at the heart of the
 // reference's PD (devices.py:1512-1515)
-//     i_ph = r * (x * x.conj()).real,  summed over the polarisations,
+//     i_ph = r * (x * x.conj()).real,  summed over the polarisations  (then `post`, the load resistance
+//     of devices.py:1547, applied to the sum),
 // with the reference's signal / noise bookkeeping (typing.py:1337-1344): the signal current is r |s|^2,
 // the noise current r Re(s n* + n s* + n n*) -- the beat terms kept separate from the signal so that the
 // detector's low-pass filter (ssfm_sosfiltfilt) runs on both.  One pass, 16-byte loads, float64.
@@ -17,7 +18,7 @@ namespace {
 
 // the sums are formed in the reference's order without fused multiply-adds
 template <bool NOISE>
-__global__ __launch_bounds__(256) void k_square_law(const double2* __restrict__ s, const double2* __restrict__ nz, int n_pol, long long n, double r,
+__global__ __launch_bounds__(256) void k_square_law(const double2* __restrict__ s, const double2* __restrict__ nz, int n_pol, long long n, double r, double post,
                                                     double* __restrict__ i_sig, double* __restrict__ i_noise) {
 #pragma clang fp contract(off)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -33,8 +34,8 @@ __global__ __launch_bounds__(256) void k_square_law(const double2* __restrict__ 
                 acc_n = p ? acc_n + pn : pn;
             }
         }
-        i_sig[i] = acc_s;
-        if (NOISE) i_noise[i] = acc_n;
+        i_sig[i] = acc_s * post;
+        if (NOISE) i_noise[i] = acc_n * post;
     }
 }
 
@@ -55,7 +56,26 @@ Scratch g_scratch[kMaxDevices];
 
 }  // namespace
 
-extern "C" int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double* i_sig, double* i_noise) {
+extern "C" int ssfm_square_law_device(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise) {
+    if (!sig || !i_sig) return fail(SSFM_ERR_INVALID, "ssfm_square_law_device: NULL argument");
+    if ((noise == nullptr) != (i_noise == nullptr)) return fail(SSFM_ERR_INVALID, "ssfm_square_law_device: noise and i_noise must be given together");
+    if (n_pol < 1 || n_pol > 2 || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_square_law_device: n_pol=%d n=%lld", n_pol, (long long)n);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(SSFM_ERR_NO_DEVICE, "ssfm_square_law_device: device %d not available", device);
+    HIP_TRY(hipSetDevice(device));
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (noise)
+        hipLaunchKernelGGL(k_square_law<true>, dim3(blocks), dim3(256), 0, 0, (const double2*)sig, (const double2*)noise, n_pol, (long long)n, r, post, i_sig, i_noise);
+    else
+        hipLaunchKernelGGL(k_square_law<false>, dim3(blocks), dim3(256), 0, 0, (const double2*)sig, (const double2*)nullptr, n_pol, (long long)n, r, post, i_sig,
+                           (double*)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise) {
     if (!sig || !i_sig) return fail(SSFM_ERR_INVALID, "ssfm_square_law: NULL argument");
     if ((noise == nullptr) != (i_noise == nullptr)) return fail(SSFM_ERR_INVALID, "ssfm_square_law: noise and i_noise must be given together");
     if (n_pol < 1 || n_pol > 2 || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_square_law: n_pol=%d n=%lld", n_pol, (long long)n);
@@ -76,10 +96,10 @@ extern "C" int ssfm_square_law(int device, const void* sig, const void* noise, i
     }
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     if (noise)
-        hipLaunchKernelGGL(k_square_law<true>, dim3(blocks), dim3(256), 0, 0, (const double2*)w.buf[0], (const double2*)w.buf[1], n_pol, (long long)n, r,
+        hipLaunchKernelGGL(k_square_law<true>, dim3(blocks), dim3(256), 0, 0, (const double2*)w.buf[0], (const double2*)w.buf[1], n_pol, (long long)n, r, post,
                            (double*)w.buf[2], (double*)w.buf[3]);
     else
-        hipLaunchKernelGGL(k_square_law<false>, dim3(blocks), dim3(256), 0, 0, (const double2*)w.buf[0], (const double2*)nullptr, n_pol, (long long)n, r,
+        hipLaunchKernelGGL(k_square_law<false>, dim3(blocks), dim3(256), 0, 0, (const double2*)w.buf[0], (const double2*)nullptr, n_pol, (long long)n, r, post,
                            (double*)w.buf[2], (double*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(i_sig, w.buf[2], out_bytes, hipMemcpyDeviceToHost));

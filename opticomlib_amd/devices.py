@@ -67,6 +67,36 @@ def _precision_code(precision) -> int:
     raise ValueError("precision must be complex64 or complex128")
 
 
+# ------------------------------------------------------------------ device residency
+# Results of FIBER / DBP / DM / BPF / LPF stay in GPU memory (``signal`` / ``noise`` backed by a
+# ``_lib.DeviceArray``) until somebody reads them on the host; the next device call of a chain takes them
+# from there.  ``KEEP_ON_DEVICE = False`` restores eager host arrays.
+KEEP_ON_DEVICE = True
+
+
+def _on_device(a) -> bool:
+    return isinstance(a, _lib.DeviceArray)
+
+
+def _dev_array(x, dtype, dev: int) -> "_lib.DeviceArray":
+    """``x`` (host array or DeviceArray) as a DeviceArray of ``dtype`` on GPU ``dev``; no transfer and no
+    copy when it already is one."""
+    dtype = np.dtype(dtype)
+    if _on_device(x):
+        if x.device != dev:                                 # other GPU: through the host
+            return _lib.DeviceArray.from_host(x.to_host(), dtype, dev)
+        return x if x.dtype == dtype else x.astype(dtype)
+    return _lib.DeviceArray.from_host(np.asarray(x), dtype, dev)
+
+
+def _wrap_out(cls, sig, noi, **kw):
+    """Signal object around device results; materialised at once when KEEP_ON_DEVICE is off."""
+    out = cls.from_device(sig, noi, **kw)
+    if not KEEP_ON_DEVICE:
+        out.signal, out.noise                               # noqa: B018 -- the attribute reads download
+    return out
+
+
 # ------------------------------------------------------------------ operator coefficients
 _OPERATORS: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
 _MAX_OPERATORS = 4            # 8-16 MiB each at 2^20
@@ -162,19 +192,35 @@ def FIBER(input: optical_signal,
     plan_dtype = np.complex64 if prec == _lib.C64 else np.complex128
     rt = _F32 if prec == _lib.C64 else np.float64
 
-    A = np.ascontiguousarray(input.to_numpy(), dtype=plan_dtype)
-    shape = A.shape
+    raw_s, raw_n = input._raw("signal"), input._raw("noise")
+    dev = default_device() if device is None else int(device)
+    A = A_dev = None
+    if _on_device(raw_s) or _on_device(raw_n):
+        # signal + noise in their common type, then the cast -- NumPy's own order (devices.py:1147)
+        if raw_n is NULL:
+            A_dev = _dev_array(raw_s, plan_dtype, dev)
+        else:
+            common = np.result_type(raw_s.dtype, raw_n.dtype, np.complex64)
+            total = _dev_array(raw_s, common, dev) + _dev_array(raw_n, common, dev)
+            A_dev = total if total.dtype == plan_dtype else total.astype(plan_dtype)
+        shape = tuple(A_dev.shape)
+    else:
+        A = np.ascontiguousarray(input.to_numpy(), dtype=plan_dtype)
+        shape = A.shape
     n = shape[-1]
-    batch = 1 if A.ndim == 1 else shape[0]
+    batch = 1 if len(shape) == 1 else shape[0]
     _check_size(n, prec)
 
     L = rt(length)
-    plan = get_plan(n, batch, prec, device)
+    plan = get_plan(n, batch, prec, dev)
     op_key = (float(input.dt), float(alpha), float(beta_2), float(beta_3))
     if getattr(plan, "_op_key", None) != op_key:          # D~ is O(N) host work + an upload: reuse it
         plan.set_linear_operator(linear_operator(n, input.dt, alpha, beta_2, beta_3, prec))
         plan._op_key = op_key
-    plan.set_field(A)
+    if A_dev is not None:
+        plan.set_field_device(A_dev.ptr)
+    else:
+        plan.set_field(A)
 
     bar = None
     if show_progress:
@@ -193,7 +239,7 @@ def FIBER(input: optical_signal,
         steps = hs.size
         snaps = None
         if return_steps:
-            snaps = plan.propagate_fixed(gamma, hs, snapshots=True) if steps else A.reshape(1, batch, n).copy()
+            snaps = plan.propagate_fixed(gamma, hs, snapshots=True) if steps else plan.get_field().reshape(1, batch, n)
         elif bar is not None and steps:
             done = 0
             for chunk in np.array_split(hs, min(20, steps)):      # progress needs sync points
@@ -213,8 +259,12 @@ def FIBER(input: optical_signal,
     if return_steps:
         A_z = snaps.reshape((snaps.shape[0],) + shape)
         return np.asarray(z, dtype=np.float64), A_z
-    out = plan.get_field().reshape(shape)
-    output = optical_signal(out)
+    if KEEP_ON_DEVICE:
+        out = _lib.DeviceArray(shape, plan_dtype, dev)
+        plan.get_field_device(out.ptr)
+        output = optical_signal.from_device(out)
+    else:
+        output = optical_signal(plan.get_field().reshape(shape))
     output.execution_time = time.time() - t0
     return output
 
@@ -252,23 +302,31 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
         raise TypeError("`input` must be of type 'optical_signal'.")
     D = D * 1e-12**2          # ps^2 -> s^2 (devices.py:1025); H(w) is generated on the device
 
-    sig = np.ascontiguousarray(input.signal, dtype=np.complex128)
-    shape = sig.shape
+    raw_s, raw_n = input._raw("signal"), input._raw("noise")
+    dev = default_device() if device is None else int(device)
+    shape = tuple(raw_s.shape)
     n = shape[-1]
-    rows = 1 if sig.ndim == 1 else shape[0]
+    rows = 1 if len(shape) == 1 else shape[0]
     _check_size(n, _lib.C128)
-    has_noise = input.noise is not NULL
-    stack = sig.reshape(rows, n)
-    if has_noise:
-        stack = np.concatenate([stack, np.ascontiguousarray(input.noise, dtype=np.complex128).reshape(rows, n)])
-    plan = get_plan(n, stack.shape[0], _lib.C128, device)
-    plan.set_field(stack)
+    has_noise = raw_n is not NULL
+    plan = get_plan(n, rows * (2 if has_noise else 1), _lib.C128, dev)
     plan._op_key = None                                   # DM may reuse the operator staging buffer
+    # signal rows, then noise rows, straight into the plan's field buffer
+    row_bytes = rows * n * 16
+    for k, a in enumerate([raw_s, raw_n] if has_noise else [raw_s]):
+        if _on_device(a):
+            d = _dev_array(a, np.complex128, dev)
+            plan.copy_into_field(k * row_bytes, d.ptr, row_bytes, on_device=True)
+        else:
+            h = np.ascontiguousarray(a, dtype=np.complex128)
+            plan.copy_into_field(k * row_bytes, h.ctypes.data, row_bytes, on_device=False)
     H = plan.apply_dispersion(input.dt, D, want_H=retH)
-    res = plan.get_field()
-    out_sig = res[:rows].reshape(shape)
-    out_noise = res[rows:].reshape(shape) if has_noise else NULL
-    output = optical_signal(out_sig, out_noise, n_pol=input.n_pol)
+    outs = []
+    for k in range(2 if has_noise else 1):
+        o = _lib.DeviceArray(shape, np.complex128, dev)
+        plan.copy_from_field(k * row_bytes, o.ptr, row_bytes)
+        outs.append(o)
+    output = _wrap_out(optical_signal, outs[0], outs[1] if has_noise else NULL, n_pol=input.n_pol)
     if retH:
         return output, np.fft.fftshift(H)
     output.execution_time = time.time() - t0
@@ -300,9 +358,16 @@ def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, d
     dev = default_device() if device is None else int(device)
     # real coefficients: Re(filter(x)) == filter(Re(x)), so only the real channel is computed
     # (signal and noise go to the device as they lie: no stacked host copy)
-    has_noise = input.noise is not NULL
-    res = [_lib.sosfiltfilt(sos, zi, np.real(a), dev) for a in ([input.signal, input.noise] if has_noise else [input.signal])]
-    output = electrical_signal(res[0], res[1] if has_noise else NULL)
+    has_noise = input._raw("noise") is not NULL
+    res = []
+    for a in ([input._raw("signal"), input._raw("noise")] if has_noise else [input._raw("signal")]):
+        if _on_device(a) and a.dtype != np.float64:
+            a = a.to_host()                                  # complex on the device: take the real part on the host
+        x = a if _on_device(a) else _lib.DeviceArray.from_host(np.real(a), np.float64, dev)
+        y = _lib.DeviceArray(x.shape, np.float64, dev)
+        _lib.sosfiltfilt_device(sos, zi, x.ptr, y.ptr, x.shape[-1], 1, False, dev)
+        res.append(y)
+    output = _wrap_out(electrical_signal, res[0], res[1] if has_noise else NULL)
     if retH:
         from scipy import signal as sg
         _, H = sg.sosfreqz(sos, worN=input.size, fs=fs, whole=True)
@@ -319,9 +384,15 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
         raise TypeError("`input` must be of type (optical_signal).")
     sos, zi = _bessel_sos(n, BW / 2, gv.fs)
     dev = default_device() if device is None else int(device)
-    has_noise = input.noise is not NULL
-    res = [_lib.sosfiltfilt(sos, zi, np.asarray(a), dev) for a in ([input.signal, input.noise] if has_noise else [input.signal])]
-    output = optical_signal(res[0], res[1] if has_noise else NULL, n_pol=input.n_pol)
+    has_noise = input._raw("noise") is not NULL
+    res = []
+    for a in ([input._raw("signal"), input._raw("noise")] if has_noise else [input._raw("signal")]):
+        cplx = _on_device(a) or np.iscomplexobj(a)
+        x = _dev_array(a, np.complex128 if cplx else np.float64, dev)
+        y = _lib.DeviceArray(x.shape, x.dtype, dev)
+        _lib.sosfiltfilt_device(sos, zi, x.ptr, y.ptr, x.shape[-1], x.size // x.shape[-1], cplx, dev)
+        res.append(y)
+    output = _wrap_out(optical_signal, res[0], res[1] if has_noise else NULL, n_pol=input.n_pol)
     output.execution_time = time.time() - t0
     return output
 
@@ -369,8 +440,19 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
         raise TypeError("`include_noise` must be a string.")
     mode = include_noise.lower()
     dev = default_device() if device is None else int(device)
-    has_ase = input.noise is not NULL
-    i_sig, i_ase = _lib.square_law(input.signal, input.noise if has_ase else None, r, dev)
+    raw_s, raw_n = input._raw("signal"), input._raw("noise")
+    has_ase = raw_n is not NULL
+    if mode == "none" and (_on_device(raw_s) or _on_device(raw_n)):
+        # nothing random to add: detector and filter back to back on the device
+        v, _ = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), None, r, post=R_load)
+        output = LPF(electrical_signal.from_device(v), BW, device=dev)
+        output.execution_time = time.time() - t0
+        return output
+    if _on_device(raw_s) or _on_device(raw_n):            # the field is already in HBM: only the currents come back
+        ds, dn = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), _dev_array(raw_n, np.complex128, dev) if has_ase else None, r)
+        i_sig, i_ase = ds.to_host(), (dn.to_host() if has_ase else None)
+    else:
+        i_sig, i_ase = _lib.square_law(raw_s, raw_n if has_ase else None, r, dev)
     size = input.size
     i_T = i_N = None
     if "thermal" in mode or "all" in mode:

@@ -97,9 +97,54 @@ class _GlobalVars:
 gv = _GlobalVars()
 
 
+def _is_device(a) -> bool:
+    """A ``_lib.DeviceArray`` (checked by duck typing so that this module never imports the HIP binding)."""
+    return hasattr(a, "to_host") and hasattr(a, "ptr")
+
+
+class _LazyArray:
+    """``signal`` / ``noise`` attribute that may be backed by a device-resident array.
+
+    Device calls hand their results over as ``DeviceArray``; the first host access downloads the data and
+    the object is an ordinary NumPy-backed signal from then on (a host array may be modified in place, so
+    the device copy is dropped rather than kept in sync).  Device-aware callers read ``obj._raw(name)``
+    instead, which never transfers anything."""
+
+    def __set_name__(self, owner, name):
+        self.slot = "_" + name
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        a = obj.__dict__.get(self.slot, NULL)
+        if _is_device(a):
+            a = a.to_host()
+            obj.__dict__[self.slot] = a
+        return a
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.slot] = value
+
+
 class electrical_signal:
     """1-D electrical signal with optional noise (the slice ``LPF`` needs of reference
     ``typing.py:1022-1165``)."""
+
+    signal = _LazyArray()
+    noise = _LazyArray()
+
+    @classmethod
+    def from_device(cls, signal, noise=NULL):
+        """Wrap device-resident 1-D arrays without copying them to the host."""
+        self = cls.__new__(cls)
+        if signal.ndim != 1 or (noise is not NULL and noise.shape != signal.shape):
+            raise ValueError(f"Signal must be 1D array for electrical_signal, invalid shape {signal.shape}")
+        self.signal, self.noise = signal, noise
+        self.execution_time = 0.0
+        return self
+
+    def _raw(self, name):
+        return self.__dict__.get("_" + name, NULL)
 
     def __init__(self, signal, noise=NULL, dtype=None):
         if isinstance(signal, electrical_signal):
@@ -127,11 +172,11 @@ class electrical_signal:
 
     @property
     def size(self) -> int:
-        return self.signal.size
+        return int(self._raw("signal").size)
 
     @property
     def ndim(self) -> int:
-        return self.signal.ndim
+        return self._raw("signal").ndim
 
     def __len__(self):
         return self.size
@@ -140,15 +185,42 @@ class electrical_signal:
         return np.asarray(self.signal + self.noise)
 
     def __repr__(self):
-        return f"electrical_signal(size={self.size}, dtype={self.signal.dtype}, noise={'NULL' if self.noise is NULL else 'array'})"
+        return f"electrical_signal(size={self.size}, dtype={self._raw('signal').dtype}, noise={'NULL' if self._raw('noise') is NULL else 'array'})"
 
 
 class optical_signal:
     """Optical field container: ``signal`` (and optional ``noise``) of shape ``(N,)`` for one
     polarisation or ``(2, N)`` for two."""
 
+    signal = _LazyArray()
+    noise = _LazyArray()
+
+    @classmethod
+    def from_device(cls, signal, noise=NULL, n_pol=None):
+        """Wrap device-resident arrays of shape ``(N,)`` or ``(2, N)`` without copying them to the host."""
+        self = cls.__new__(cls)
+        if signal.ndim not in (1, 2) or (signal.ndim == 2 and signal.shape[0] != 2):
+            raise ValueError(f"device-resident optical_signal needs shape (N,) or (2, N), got {signal.shape}")
+        if noise is not NULL and tuple(noise.shape) != tuple(signal.shape):
+            raise ValueError(f"`signal` and `noise` must have the same shape, mismatch shapes {signal.shape} and {noise.shape}!")
+        self.signal, self.noise = signal, noise
+        self.n_pol = signal.ndim if n_pol is None else n_pol
+        self.execution_time = 0.0
+        return self
+
+    def _raw(self, name):
+        return self.__dict__.get("_" + name, NULL)
+
+    @property
+    def on_device(self) -> bool:
+        """True while ``signal`` still lives in GPU memory only (no host copy has been asked for)."""
+        return _is_device(self._raw("signal"))
+
     def __init__(self, signal, noise=NULL, n_pol=None, dtype=None):
         if isinstance(signal, optical_signal):
+            if noise is NULL and n_pol in (None, signal.n_pol) and dtype is None:      # plain re-wrap: keep device residency
+                self.signal, self.noise, self.n_pol, self.execution_time = signal._raw("signal"), signal._raw("noise"), signal.n_pol, 0.0
+                return
             if noise is not NULL:
                 noise = np.asarray(noise) + signal.noise
             else:
@@ -205,14 +277,14 @@ class optical_signal:
     @property
     def size(self) -> int:
         """Samples per polarisation (reference ``typing.py:2313-2320``)."""
-        return self.signal.size if self.n_pol == 1 else self.signal[0].size
+        return int(self._raw("signal").shape[-1])
 
     def __len__(self):
         return self.size
 
     @property
     def shape(self):
-        return self.signal.shape
+        return tuple(self._raw("signal").shape)
 
     @property
     def dt(self):
@@ -232,4 +304,5 @@ class optical_signal:
         return np.mean(np.abs(self.to_numpy()) ** 2, axis=-1)
 
     def __repr__(self):
-        return f"optical_signal(n_pol={self.n_pol}, size={self.size}, dtype={self.signal.dtype}, noise={'NULL' if self.noise is NULL else 'array'})"
+        where = " [device]" if self.on_device else ""
+        return f"optical_signal(n_pol={self.n_pol}, size={self.size}, dtype={self._raw('signal').dtype}, noise={'NULL' if self._raw('noise') is NULL else 'array'}){where}"

@@ -497,6 +497,89 @@ def test_pd_statistics_and_modes():
         oa.PD(x, BW=10e9, include_noise="everything")
 
 
+# ----------------------------------------------------------------------- device-resident signals
+def _chain(x, keep):
+    """FIBER -> EDFA-like noise loading -> FIBER -> DBP -> DM -> BPF -> PD, as a link script would write it."""
+    from opticomlib_amd import devices as od
+    old = od.KEEP_ON_DEVICE
+    od.KEEP_ON_DEVICE = keep
+    try:
+        kw = dict(length=4, h=0.5, **workloads.SMF)
+        y = oa.FIBER(x, **kw)
+        rng = np.random.default_rng(1)
+        ase = (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape)) * 1e-4
+        y2 = optical_signal.from_device(y._raw("signal"), ase) if y.on_device else optical_signal(y.signal, ase)
+        z = oa.FIBER(y2, **kw)                               # complex64 signal + complex128 noise, summed then cast
+        b = oa.DBP(z, **kw)
+        d = oa.DM(b, D=-30.0)
+        f = oa.BPF(d, BW=80e9)
+        p = oa.PD(f, BW=20e9, include_noise="none")
+        return y, z, b, d, f, p
+    finally:
+        od.KEEP_ON_DEVICE = old
+
+
+def test_device_resident_chain_is_bit_identical_and_lazy():
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 14, seed=31)
+    host = _chain(optical_signal(a), keep=False)
+    assert not any(getattr(o, "on_device", False) for o in host[:5])
+    before = dict(_lib.TRANSFERS)
+    devc = _chain(optical_signal(a), keep=True)
+    after = dict(_lib.TRANSFERS)
+    y, z, b, d, f, p = devc
+    assert all(o.on_device for o in (y, z, b, d, f)) and _lib._lib is not None and isinstance(p._raw("signal"), _lib.DeviceArray)
+    assert z.shape == (2, 1 << 14) and z.size == 1 << 14 and z.n_pol == 2 and "device" in repr(z)
+    # from the first upload to the detector output nothing crossed PCIe except the host-made noise (1 upload)
+    assert after["h2d"] - before["h2d"] == 1 and after["d2h"] - before["d2h"] == 0
+    for got, want in zip(devc, host):
+        np.testing.assert_array_equal(got.signal, want.signal)
+    assert not z.on_device                                   # reading .signal made it a host signal
+    assert z.signal.dtype == np.complex64 and d.signal.dtype == np.complex128 and p.signal.dtype == np.float64
+    assert y.noise is NULL and p.noise is NULL
+
+
+def test_device_resident_signal_semantics():
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 12, seed=32)
+    y = oa.FIBER(optical_signal(a[0]), length=2, h=1.0, **workloads.SMF)
+    assert y.on_device and y.n_pol == 1 and y.shape == (1 << 12,) and len(y) == 1 << 12
+    w = optical_signal(y)                                    # re-wrapping keeps the data where it is
+    assert w.on_device
+    ref = y.signal.copy()
+    assert not y.on_device and isinstance(y.signal, np.ndarray)
+    y.signal[0] = 0                                          # a host signal now: in-place edits are the user's
+    np.testing.assert_array_equal(w.signal, ref)             # ... and do not leak into other wrappers' downloads
+    # noise on the device, DM keeps signal and noise apart
+    s = oa.FIBER(optical_signal(a), length=1, h=1.0, **workloads.SMF)
+    nz = oa.FIBER(optical_signal(0.1 * a[::-1]), length=1, h=1.0, **workloads.SMF)
+    both = optical_signal.from_device(s._raw("signal"), nz._raw("signal"))
+    out = oa.DM(both, D=50.0)
+    want = oa.DM(optical_signal(s.signal, nz.signal), D=50.0)
+    np.testing.assert_array_equal(out.signal, want.signal)
+    np.testing.assert_array_equal(out.noise, want.noise)
+    e = oa.EDFA(s, G=10, NF=5)                               # host-side device (np.random): materialises its input
+    assert e.n_pol == 2 and e.signal.shape == (2, 1 << 12)
+
+
+def test_device_array_basics():
+    x = (np.arange(24).reshape(2, 12) * (1 + 0.5j)).astype(np.complex64)
+    d = _lib.DeviceArray.from_host(x)
+    assert d.shape == (2, 12) and d.dtype == np.complex64 and d.size == 24 and d.ndim == 2
+    np.testing.assert_array_equal(d.to_host(), x)
+    d128 = d.astype(np.complex128)
+    np.testing.assert_array_equal(d128.to_host(), x.astype(np.complex128))
+    np.testing.assert_array_equal(d128.astype(np.complex64).to_host(), x)
+    np.testing.assert_array_equal((d + d).to_host(), x + x)
+    ptr = d.ptr
+    d.free()
+    assert d.ptr == 0
+    e = _lib.DeviceArray((2, 12), np.complex64)              # same size: comes back from the pool
+    assert e.ptr == ptr
+    with pytest.raises(TypeError):
+        _lib.DeviceArray((4,), np.float32)
+
+
 # ----------------------------------------------------------------------- API behaviour on the device
 def test_call_order_and_argument_errors():
     p = _lib.Plan(4096, 2, _lib.C64)

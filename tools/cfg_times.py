@@ -48,3 +48,13 @@ xn = optical_signal(a, 0.1 * a[::-1].copy())
 np.random.seed(0); t = timeit(lambda: PD(xn, BW=20e9, include_noise="none")); print(f"PD(include_noise='none') 2^20 x 2 host-inclusive: {t*1e3:.1f} ms")
 t = timeit(lambda: PD(xn, BW=20e9)); print(f"PD('all': 2 x 2^20 host normal variates) host-inclusive: {t*1e3:.1f} ms")
 t = timeit(lambda: EDFA(xn, G=20, NF=5, BW=100e9)); print(f"EDFA(G, NF, BW) 2^20 x 2 host-inclusive (4 x 2^20 host normal variates): {t*1e3:.1f} ms")
+# a short link as a script writes it: host array in, detector voltage read at the end
+from opticomlib_amd import devices as od
+def link():
+    y = FIBER(x, length=100, h=1.0, **workloads.SMF)
+    z = DBP(y, length=100, h=1.0, **workloads.SMF)
+    f = BPF(z, BW=100e9)
+    return PD(f, BW=20e9, include_noise="none").signal
+for keep in (False, True):
+    od.KEEP_ON_DEVICE = keep
+    t = timeit(link); print(f"FIBER(100) -> DBP(100) -> BPF -> PD, 2^20 x 2, results {'kept on the device' if keep else 'returned to the host after every call'}: {t*1e3:.1f} ms")
