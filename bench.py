@@ -180,6 +180,23 @@ def main():
                         "of different row groups overlap on the chip; the chip-level figure is step_frac",
                 "step_frac": 2 * N_POL * 8 * value / world / (HBM_PEAK_GBS * 1e9),
             }
+            # the committed rocprofv3 --kernel-trace --stats summary of this command, for comparison: its
+            # averages are kernel begin -> end only, the event-based launch_us additionally contains the
+            # dependent-launch gap that follows every kernel on its stream (1.5-2 us)
+            stats = os.path.join(ROOT, "profiles", "r01_final_kernel_stats.csv")
+            if os.path.exists(stats):
+                try:
+                    import csv
+                    acc = {}
+                    for row in csv.DictReader(open(stats)):
+                        for k in launch_us:
+                            if k + "<" in row["Name"]:
+                                c, tns = acc.get(k, (0, 0.0))
+                                acc[k] = (c + int(row["Calls"]), tns + float(row["TotalDurationNs"]))
+                    roofline["rocprof_kernel_us"] = {k: tns / c / 1e3 for k, (c, tns) in acc.items() if c}
+                    roofline["rocprof_source"] = "profiles/r01_final_kernel_stats.csv (kernel begin->end, no launch gap)"
+                except Exception:
+                    pass
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:

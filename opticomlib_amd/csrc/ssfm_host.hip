@@ -2,6 +2,7 @@
 // operator tables, launch sequences.  Pure HIP runtime; no torch types anywhere.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -607,16 +608,36 @@ template <typename T> struct PlanT : PlanBase {
             if (int rc = trace_dump()) return rc;
 #endif
         } else {
+            // z-resolved capture (reference devices.py:1150-1152, 1184-1186).  The field after every step is
+            // copied device-to-device into a block of up to kSnapBlock snapshots -- asynchronous, the step loop
+            // never waits for the host -- and a block goes to the host in one transfer.
             const size_t fb = sizeof(cx<T>) * n * batch;
             char* snap = static_cast<char*>(snapshots);
-            if (int rc = copy_field_out(snap, false, false)) return rc;
-            for (int64_t s = 0; s < nsteps; ++s) {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            int64_t block = (int64_t)std::min<size_t>((size_t)(nsteps + 1), std::max<size_t>(1, std::min<size_t>(free_b / 2, size_t(8) << 30) / fb));
+            char* dsnap = nullptr;
+            HIP_TRY(hipMalloc(&dsnap, fb * (size_t)block));
+            auto flush = [&](int64_t first, int64_t count) -> int {
+                hipError_t e = hipMemcpyAsync(snap + fb * first, dsnap, fb * (size_t)count, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) { (void)hipFree(dsnap); return fail(SSFM_ERR_HIP, "snapshot download failed: %s", hipGetErrorString(e)); }
+                return SSFM_OK;
+            };
+            int64_t first = 0, held = 0;                    // snapshots [first, first + held) are in dsnap
+            auto capture = [&]() -> hipError_t { return hipMemcpyAsync(dsnap + fb * held++, F, fb, hipMemcpyDeviceToDevice, stream); };
+            hipError_t ce = capture();
+            for (int64_t s = 0; s < nsteps && ce == hipSuccess; ++s) {
+                if (held == block) { if (int rc = flush(first, held)) return rc; first += held; held = 0; }
                 last_launches += 2;
-                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[s] * half, nullptr), E)));
-                HIP_TRY(freq(h[s]));
-                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr), E)));
-                if (int rc = copy_field_out(snap + fb * (s + 1), false, false)) return rc;
+                ce = launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, h[s] * half, nullptr), E);
+                if (ce == hipSuccess) ce = freq(h[s]);
+                if (ce == hipSuccess) ce = launch_time<T, TM_END>(N1, batch, stream, targs(gamma, h[s] * half, 0, nullptr), E);
+                if (ce == hipSuccess) ce = capture();
             }
+            if (ce != hipSuccess) { (void)hipFree(dsnap); return fail(SSFM_ERR_HIP, "snapshot run failed: %s", hipGetErrorString(ce)); }
+            if (int rc = flush(first, held)) return rc;
+            HIP_TRY(hipFree(dsnap));
         }
         HIP_TRY(hipEventRecord(ev1, stream));
         timed = true;
