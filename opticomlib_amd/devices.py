@@ -97,6 +97,42 @@ def _wrap_out(cls, sig, noi, **kw):
     return out
 
 
+# ------------------------------------------------------------------ signals of the reference library itself
+# A script written against opticomlib can swap single devices: `from opticomlib_amd import FIBER` and keep
+# opticomlib's own PRBS / DAC / MZM / DSP around it.  Its signal objects are recognised by layout (class name,
+# `.signal`, `.noise`), the sampling grid is read from THAT library's `gv` (the one the script configured), and
+# the result is handed back as an object of the caller's class, so the next opticomlib device accepts it.
+def _adopt(input, kind: str):
+    """-> (our signal object, sampling grid, back) ; ``back(result)`` converts to the caller's class.
+
+    ``kind``: 'optical_signal' or 'electrical_signal'.  Our own objects pass through with the global ``gv``."""
+    ours = optical_signal if kind == "optical_signal" else electrical_signal
+    if isinstance(input, ours):
+        return input, gv, lambda out: out
+    if type(input).__name__ != kind or not hasattr(input, "signal") or not hasattr(input, "noise"):
+        return input, gv, lambda out: out                  # not a signal: the device raises its TypeError
+    import sys
+    mod = sys.modules.get(type(input).__module__)
+    grid = getattr(mod, "gv", None)
+    if grid is None or not all(hasattr(grid, a) for a in ("fs", "dt")):
+        raise TypeError(f"cannot find the sampling grid (`gv`) of {type(input).__module__}")
+    noise = input.noise if isinstance(input.noise, np.ndarray) else NULL
+    mine = ours(np.asarray(input.signal), noise)
+    if kind == "optical_signal" and mine.n_pol != getattr(input, "n_pol", mine.n_pol):
+        mine = ours(np.asarray(input.signal), noise, n_pol=input.n_pol)
+
+    def back(out):
+        if isinstance(out, tuple):                          # (signal, H) or (z, A_z)
+            return (back(out[0]),) + tuple(out[1:]) if isinstance(out[0], (optical_signal, electrical_signal)) else out
+        cls = getattr(mod, type(out).__name__, None)
+        if cls is None:
+            return out
+        res = cls(out.signal) if out.noise is NULL else cls(out.signal, out.noise)
+        res.execution_time = out.execution_time
+        return res
+    return mine, grid, back
+
+
 # ------------------------------------------------------------------ operator coefficients
 _OPERATORS: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
 _MAX_OPERATORS = 4            # 8-16 MiB each at 2^20
@@ -186,6 +222,7 @@ def FIBER(input: optical_signal,
     ``"complex64"`` (the reference's arithmetic) or ``"complex128"``; ``device`` index.
     """
     t0 = time.time()
+    input, grid, back = _adopt(input, "optical_signal")
     if not isinstance(input, optical_signal):
         raise TypeError("`input` must be of type 'optical_signal'.")
     prec = _precision_code(precision)
@@ -213,9 +250,10 @@ def FIBER(input: optical_signal,
 
     L = rt(length)
     plan = get_plan(n, batch, prec, dev)
-    op_key = (float(input.dt), float(alpha), float(beta_2), float(beta_3))
+    dt = float(grid.dt)
+    op_key = (dt, float(alpha), float(beta_2), float(beta_3))
     if getattr(plan, "_op_key", None) != op_key:          # D~ is O(N) host work + an upload: reuse it
-        plan.set_linear_operator(linear_operator(n, input.dt, alpha, beta_2, beta_3, prec))
+        plan.set_linear_operator(linear_operator(n, dt, alpha, beta_2, beta_3, prec))
         plan._op_key = op_key
     if A_dev is not None:
         plan.set_field_device(A_dev.ptr)
@@ -266,7 +304,7 @@ def FIBER(input: optical_signal,
     else:
         output = optical_signal(plan.get_field().reshape(shape))
     output.execution_time = time.time() - t0
-    return output
+    return back(output)
 
 
 def _chain_fixed(plan, gamma, hs):
@@ -298,6 +336,7 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
     (``devices.py:1019-1035``).  complex128; signal and noise are filtered separately and stay
     separate.  With ``retH`` also returns ``fftshift(H)``."""
     t0 = time.time()
+    input, grid, back = _adopt(input, "optical_signal")
     if not isinstance(input, optical_signal):
         raise TypeError("`input` must be of type 'optical_signal'.")
     D = D * 1e-12**2          # ps^2 -> s^2 (devices.py:1025); H(w) is generated on the device
@@ -320,7 +359,7 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
         else:
             h = np.ascontiguousarray(a, dtype=np.complex128)
             plan.copy_into_field(k * row_bytes, h.ctypes.data, row_bytes, on_device=False)
-    H = plan.apply_dispersion(input.dt, D, want_H=retH)
+    H = plan.apply_dispersion(float(grid.dt), D, want_H=retH)
     outs = []
     for k in range(2 if has_noise else 1):
         o = _lib.DeviceArray(shape, np.complex128, dev)
@@ -328,9 +367,9 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
         outs.append(o)
     output = _wrap_out(optical_signal, outs[0], outs[1] if has_noise else NULL, n_pol=input.n_pol)
     if retH:
-        return output, np.fft.fftshift(H)
+        return back(output), np.fft.fftshift(H)
     output.execution_time = time.time() - t0
-    return output
+    return back(output)
 
 
 # ------------------------------------------------------------------ LPF / BPF
@@ -348,12 +387,13 @@ def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, d
     signal and noise are filtered separately and the real part is kept.  With ``retH`` also returns
     ``fftshift`` of the frequency response over ``input.size`` points."""
     t0 = time.time()
+    input, grid, back = _adopt(input, "electrical_signal")
     if not isinstance(input, electrical_signal):
         input = electrical_signal(input)
     if input.ndim != 1:
         raise ValueError("`input` must be a 1D-array.")
     if not fs:
-        fs = gv.fs
+        fs = grid.fs
     sos, zi = _bessel_sos(n, BW, fs)
     dev = default_device() if device is None else int(device)
     # real coefficients: Re(filter(x)) == filter(Re(x)), so only the real channel is computed
@@ -371,18 +411,31 @@ def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, d
     if retH:
         from scipy import signal as sg
         _, H = sg.sosfreqz(sos, worN=input.size, fs=fs, whole=True)
-        return output, np.fft.fftshift(H)
+        return back(output), np.fft.fftshift(H)
     output.execution_time = time.time() - t0
-    return output
+    return back(output)
+
+
+def _bpf_on_grid(x, BW, grid, device):
+    """BPF of one of OUR signals on another library's sampling grid (EDFA of an adopted input)."""
+    if grid is gv:
+        return BPF(x, BW, device=device)
+    saved = (gv.fs, gv.dt)
+    gv.fs, gv.dt = grid.fs, grid.dt
+    try:
+        return BPF(x, BW, device=device)
+    finally:
+        gv.fs, gv.dt = saved
 
 
 def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
     """Optical band-pass filter: Bessel low-pass of cutoff ``BW/2`` on the complex envelope, zero phase;
     reference ``devices.py:788-826``.  Signal and noise are filtered separately."""
     t0 = time.time()
+    input, grid, back = _adopt(input, "optical_signal")
     if not isinstance(input, optical_signal):
         raise TypeError("`input` must be of type (optical_signal).")
-    sos, zi = _bessel_sos(n, BW / 2, gv.fs)
+    sos, zi = _bessel_sos(n, BW / 2, grid.fs)
     dev = default_device() if device is None else int(device)
     has_noise = input._raw("noise") is not NULL
     res = []
@@ -394,7 +447,7 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
         res.append(y)
     output = _wrap_out(optical_signal, res[0], res[1] if has_noise else NULL, n_pol=input.n_pol)
     output.execution_time = time.time() - t0
-    return output
+    return back(output)
 
 
 # ----------------------------------------------------------------------------- receiver front-end
@@ -422,6 +475,7 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
     from numbers import Real
     from scipy.constants import e, k as kB
     t0 = time.time()
+    input, grid, back = _adopt(input, "optical_signal")
     if not isinstance(input, optical_signal):
         raise TypeError("`input` must be of type 'optical_signal'.")
     if not isinstance(r, Real):
@@ -445,9 +499,9 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
     if mode == "none" and (_on_device(raw_s) or _on_device(raw_n)):
         # nothing random to add: detector and filter back to back on the device
         v, _ = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), None, r, post=R_load)
-        output = LPF(electrical_signal.from_device(v), BW, device=dev)
+        output = LPF(electrical_signal.from_device(v), BW, fs=grid.fs, device=dev)
         output.execution_time = time.time() - t0
-        return output
+        return back(output)
     if _on_device(raw_s) or _on_device(raw_n):            # the field is already in HBM: only the currents come back
         ds, dn = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), _dev_array(raw_n, np.complex128, dev) if has_ase else None, r)
         i_sig, i_ase = ds.to_host(), (dn.to_host() if has_ase else None)
@@ -456,11 +510,11 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
     size = input.size
     i_T = i_N = None
     if "thermal" in mode or "all" in mode:
-        S_T = 4 * kB * T * gv.fs / 2 * _idb(Fn) / R_load
+        S_T = 4 * kB * T * grid.fs / 2 * _idb(Fn) / R_load
         i_T = np.random.normal(0, S_T ** 0.5, size)
     if "shot" in mode or "all" in mode:
         mean = (i_sig + i_ase if has_ase else i_sig).mean()
-        S_N = 2 * e * (mean + i_dark) * gv.fs / 2
+        S_N = 2 * e * (mean + i_dark) * grid.fs / 2
         i_N = np.random.normal(0, S_N ** 0.5, size)
     if mode not in _PD_MODES:
         raise ValueError("The argument `include_noise` must be one of the following: 'ase-only','thermal-only','shot-only',"
@@ -482,9 +536,9 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
         if np.ndim(i_noise) == 0:                      # 'ase-only' on a noiseless input: dark current alone
             i_noise = np.full(size, float(i_noise))
     output = electrical_signal(i_sig * R_load, NULL if i_noise is NULL else i_noise * R_load)
-    output = LPF(output, BW, device=dev)
+    output = LPF(output, BW, fs=grid.fs, device=dev)
     output.execution_time = time.time() - t0
-    return output
+    return back(output)
 
 
 def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device=None) -> optical_signal:
@@ -494,6 +548,7 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
     dual-polarisation (a single-polarisation input gets an empty y signal, but ASE in both)."""
     from scipy.constants import h
     t0 = time.time()
+    input, grid, back = _adopt(input, "optical_signal")
     if not isinstance(input, optical_signal):
         raise TypeError("`input` must be of type 'optical_signal'.")
     g = np.sqrt(_idb(G))
@@ -504,11 +559,11 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
         sig[1] = np.zeros_like(sig[0])
         if noi is not NULL:
             noi[1] = np.zeros_like(noi[0])
-    P_ase = _idb(NF) * h * gv.f0 * (_idb(G) - 1) * gv.fs
+    P_ase = _idb(NF) * h * grid.f0 * (_idb(G) - 1) * grid.fs
     ase = np.sqrt(P_ase / 4) * np.random.randn(4, input.size)
     ase = ase[:2] + 1j * ase[2:]
     output = optical_signal(sig, noi + ase, n_pol=2)
     if BW is not None:
-        output = BPF(output, BW, device=device)
+        output = _bpf_on_grid(output, BW, grid, device)
     output.execution_time = time.time() - t0
-    return output
+    return back(output)

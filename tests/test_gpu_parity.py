@@ -580,6 +580,30 @@ def test_device_array_basics():
         _lib.DeviceArray((4,), np.float32)
 
 
+def test_devices_accept_the_reference_librarys_own_objects():
+    """A script written against opticomlib swaps single devices: objects with the reference's layout go in,
+    objects of the caller's class come out, and the sampling grid is the caller's gv (not ours)."""
+    import foreign_types as ft
+    ft.gv.set(**workloads.BENCH_GV)
+    gv(sps=4, R=1e9)                                            # our own gv deliberately different
+    a = workloads.qpsk_field(1 << 12, seed=33)
+    kw = dict(length=3, h=1.0, **workloads.SMF)
+    y = oa.FIBER(ft.optical_signal(a), **kw)
+    assert type(y) is ft.optical_signal and isinstance(y.signal, np.ndarray) and y.noise is ft.NULL and y.execution_time > 0
+    b = oa.BPF(oa.DBP(y, **kw), BW=100e9)
+    v = oa.PD(b, BW=20e9, include_noise="none")
+    assert type(b) is ft.optical_signal and type(v) is ft.electrical_signal
+    d, H = oa.DM(ft.optical_signal(a[0]), D=10.0, retH=True)
+    assert type(d) is ft.optical_signal and H.shape == (1 << 12,)
+    gv(**workloads.BENCH_GV)                                    # the native path on the same grid gives the same numbers
+    yn = oa.FIBER(optical_signal(a), **kw)
+    np.testing.assert_array_equal(y.signal, yn.signal)
+    vn = oa.PD(oa.BPF(oa.DBP(yn, **kw), BW=100e9), BW=20e9, include_noise="none")
+    np.testing.assert_array_equal(v.signal, vn.signal)
+    with pytest.raises(TypeError, match="`input` must be of type 'optical_signal'."):
+        oa.FIBER(ft.electrical_signal(np.ones(256)), length=1)
+
+
 # ----------------------------------------------------------------------- API behaviour on the device
 def test_call_order_and_argument_errors():
     p = _lib.Plan(4096, 2, _lib.C64)

@@ -208,3 +208,33 @@ def test_gv_optical_carrier():
     assert abs(gv.f0 - 299792458.0 / 1310e-9) < 1
     gv(sps=8, R=1e9)
     assert gv.wavelength == 1550e-9
+
+
+def test_foreign_signal_objects_are_adopted():
+    """devices._adopt: an object with the reference library's layout is converted, the sampling grid comes from
+    ITS module's gv, and results go back as the caller's class (tests/foreign_types.py stands in for opticomlib)."""
+    import foreign_types as ft
+    from opticomlib_amd import devices as od
+    from opticomlib_amd.typing import NULL, gv, optical_signal, electrical_signal
+    gv(sps=8, R=1e9)
+    ft.gv.set(16, 32e9)
+    x = ft.optical_signal(np.ones((2, 64), complex), 0.1 * np.ones((2, 64), complex))
+    mine, grid, back = od._adopt(x, "optical_signal")
+    assert isinstance(mine, optical_signal) and mine.n_pol == 2 and grid is ft.gv and grid.fs == 512e9
+    np.testing.assert_array_equal(mine.noise, x.noise)
+    out = optical_signal(2 * mine.signal)
+    out.execution_time = 1.5
+    res = back(out)
+    assert type(res) is ft.optical_signal and res.noise is ft.NULL and res.execution_time == 1.5
+    res2, H = back((optical_signal(mine.signal, mine.noise), np.ones(3)))
+    assert type(res2) is ft.optical_signal and isinstance(res2.noise, np.ndarray) and H.shape == (3,)
+    e = back(electrical_signal(np.ones(64)))                   # PD: optical in, electrical out
+    assert type(e) is ft.electrical_signal
+    z = back((np.zeros(3), np.zeros((3, 2, 64))))              # return_steps tuple passes through
+    assert isinstance(z[0], np.ndarray)
+    # our own objects and non-signals pass through untouched
+    own = optical_signal(np.ones(8, complex))
+    assert od._adopt(own, "optical_signal")[0] is own and od._adopt(own, "optical_signal")[1] is gv
+    assert od._adopt(np.ones(4), "optical_signal")[0].shape == (4,)
+    y = ft.optical_signal(np.ones(64, complex))
+    assert od._adopt(y, "optical_signal")[0].noise is NULL and od._adopt(y, "optical_signal")[0].n_pol == 1
