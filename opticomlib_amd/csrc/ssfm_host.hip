@@ -345,7 +345,10 @@ template <typename T> struct PlanT : PlanBase {
         if (k > 20) E = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
         if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = (e[0] == 'a' || e[0] == 'A') ? -1 : (std::atoi(e) != 0 ? 1 : 0);
-        int want = 2;
+        // two lanes pay off once a launch is long enough to hide the other lane's gap; below ~2^20 points in
+        // all a step is launch-bound and the second stream only doubles the launches (2^14 x 2: 8.1 us per
+        // step with one lane, 12.0 with two; 2^18 x 2: 14.1 / 14.2; 2^20 x 2: 25.6 / 22.9 in a 200-step run)
+        int want = (long long)batch * n >= (1ll << 20) ? 2 : 1;
         if (const char* e = std::getenv("SSFM_LANES")) want = std::atoi(e);
         nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
         if (nlanes > batch) nlanes = batch;
