@@ -243,16 +243,17 @@ def FIBER(input: optical_signal,
         shape = tuple(A_dev.shape)
     else:
         A = np.asarray(input.to_numpy())
-        if A.dtype == np.complex128 and plan_dtype == np.complex64 and A.flags.c_contiguous and A.ndim in (1, 2):
+        shape = A.shape
+    n = shape[-1]
+    batch = 1 if len(shape) == 1 else shape[0]
+    _check_size(n, prec)
+    if A is not None:
+        if A.dtype == np.complex128 and plan_dtype == np.complex64 and A.flags.c_contiguous:
             # the usual case (NumPy signals are complex128): upload as it lies and round to complex64 on the
             # device -- the same round-to-nearest cast, without a 32 -> 16 MiB conversion pass on the host
             A_dev = _lib.DeviceArray.from_host(A, np.complex128, dev).astype(np.complex64)
         else:
             A = np.ascontiguousarray(A, dtype=plan_dtype)
-        shape = A.shape
-    n = shape[-1]
-    batch = 1 if len(shape) == 1 else shape[0]
-    _check_size(n, prec)
 
     L = rt(length)
     plan = get_plan(n, batch, prec, dev)
