@@ -6,9 +6,9 @@ the receiver front-end ``PD`` / ``EDFA`` (and the slice of ``optical_signal`` / 
 The arithmetic runs in hand-written HIP kernels (``csrc/``) behind the C ABI declared in
 ``include/ssfm_amd.h``.
 """
-from .typing import NULL, electrical_signal, gv, optical_signal
-from .devices import BPF, DBP, DM, EDFA, FIBER, LPF, PD
+from .typing import NULL, binary_sequence, electrical_signal, gv, optical_signal
+from .devices import BPF, DBP, DM, EDFA, FIBER, LPF, PD, PRBS
 from ._lib import C64, C128, Plan, SsfmError, device_count
 
-__all__ = ["NULL", "gv", "optical_signal", "electrical_signal", "FIBER", "DBP", "DM", "LPF", "BPF", "PD", "EDFA", "Plan", "SsfmError", "device_count", "C64", "C128"]
+__all__ = ["NULL", "gv", "optical_signal", "electrical_signal", "FIBER", "DBP", "DM", "LPF", "BPF", "PD", "EDFA", "PRBS", "binary_sequence", "Plan", "SsfmError", "device_count", "C64", "C128"]
 __version__ = "0.1.0"

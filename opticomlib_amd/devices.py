@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from .typing import NULL, electrical_signal, gv, optical_signal
+from .typing import NULL, binary_sequence, electrical_signal, gv, optical_signal
 
 _F32 = np.float32
 _PLANS: "OrderedDict[tuple, _lib.Plan]" = OrderedDict()
@@ -574,3 +574,60 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
         output = _bpf_on_grid(output, BW, grid, device)
     output.execution_time = time.time() - t0
     return back(output)
+
+
+# ----------------------------------------------------------------------------- PRBS
+_PRBS_TAPS = {7: (7, 6), 9: (9, 5), 11: (11, 9), 15: (15, 14), 20: (20, 3), 23: (23, 18), 31: (31, 28)}
+
+
+def PRBS(order: int, len: int = None, seed: int = None, return_seed: bool = False):
+    """Pseudo-random binary sequence of the reference's LFSR (``devices.py:63-182``), bit for bit: polynomial
+    ``x^order + x^t2 + 1`` (PRBS-7/9/11/15/20/23/31), state seeded with ``seed % 2**order`` (default all ones;
+    0 becomes 1 with a UserWarning), output = bit 0 of the state before every shift.  With ``return_seed`` also
+    the final state, to continue the sequence.
+
+    The reference walks the register one bit per Python iteration; here the output recurrence
+    ``o[j] = o[j-p] ^ o[j-q]`` (p = order, q = t2) is advanced in blocks: over GF(2) it implies
+    ``o[j] = o[j-Lp] ^ o[j-Lq]`` for every L = 2^k, so a block of L*q bits is one vector XOR.  Host integer
+    work (a 2^20-bit sequence takes about a millisecond); the bits feed the host-side pulse shaping.
+    """
+    import builtins
+    import warnings
+    t0 = time.time()
+    if seed is not None:
+        seed = seed % (2 ** order)
+    else:
+        seed = (1 << order) - 1
+    if seed == 0:
+        seed = 1
+        warnings.warn("The seed can't be 0 or a multiple of 2**order. It has been changed to 1.", UserWarning)
+    if len is not None:
+        if not isinstance(len, int):
+            raise TypeError("The parameter `len` must be an integer.")
+        if len <= 0:
+            raise ValueError("The parameter `len` must be an integer greater than cero.")
+    else:
+        len = 2 ** order - 1
+    if order not in _PRBS_TAPS:
+        raise ValueError("The parameter `order` must be one of the following values (7, 9, 11, 15, 20, 23, 31).")
+    p, q = _PRBS_TAPS[order]
+    s = order - 1                                           # b[s + j] = o[j]; b[s - m] = seed bit m ("outputs" before time 0)
+    b = np.empty(s + len + 1, dtype=np.uint8)
+    for m in range(order):
+        b[s - m] = (seed >> m) & 1
+    J = 1                                                   # o[j] known for j < J
+    while J <= len:
+        L = 1                                               # largest power of two with L*p - s <= J and (L-1)*p + 1 <= J
+        while 2 * L * p - s <= J and (2 * L - 1) * p + 1 <= J:
+            L *= 2
+        blk = builtins.min(L * q, len + 1 - J)
+        b[s + J: s + J + blk] = b[s + J - L * p: s + J - L * p + blk] ^ b[s + J - L * q: s + J - L * q + blk]
+        J += blk
+    output = binary_sequence(b[s: s + len])
+    output.execution_time = time.time() - t0
+    if not return_seed:
+        return output
+    last = 0
+    for k in range(order):                                  # state after `len` shifts: bit k = o[len - k]
+        last |= int(b[s + len - k]) << k
+    return output, last

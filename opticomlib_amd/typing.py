@@ -126,6 +126,62 @@ class _LazyArray:
         obj.__dict__[self.slot] = value
 
 
+class binary_sequence:
+    """Bit sequence container: the slice of reference ``typing.py:402-1020`` that ``PRBS`` returns and a DAC
+    consumes -- ``.data`` (uint8 0/1), ``.size``, ``len()``, ``.to_numpy()``, comparison with array-likes."""
+
+    def __init__(self, data):
+        if isinstance(data, binary_sequence):
+            data = data.data
+        if isinstance(data, str):
+            data = [int(ch) for ch in data.replace(" ", "").replace(",", "")]
+        d = np.asarray(data)
+        if d.ndim == 0:
+            d = d[np.newaxis]
+        if d.ndim != 1:
+            raise ValueError(f"Binary sequence must be 1D, invalid shape {d.shape}")
+        if not np.all((d == 0) | (d == 1)):
+            raise ValueError("Binary sequence must contain only 0 and 1 values.")
+        self.data = d.astype(np.uint8)
+        self.execution_time = 0.0
+
+    @property
+    def size(self) -> int:
+        return int(self.data.size)
+
+    @property
+    def type(self):
+        return binary_sequence
+
+    @property
+    def ones(self) -> int:
+        return int(self.data.sum())
+
+    @property
+    def zeros(self) -> int:
+        return self.size - self.ones
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, key):
+        r = self.data[key]
+        return binary_sequence(r) if isinstance(r, np.ndarray) else int(r)
+
+    def __eq__(self, other):
+        other = other.data if isinstance(other, binary_sequence) else np.asarray(other)
+        return self.data == other
+
+    def __array__(self, dtype=None, copy=None):
+        return self.data if dtype is None else self.data.astype(dtype)
+
+    def to_numpy(self) -> np.ndarray:
+        return self.data
+
+    def __repr__(self):
+        return f"binary_sequence({np.array2string(self.data, threshold=20)})"
+
+
 class electrical_signal:
     """1-D electrical signal with optional noise (the slice ``LPF`` needs of reference
     ``typing.py:1022-1165``)."""

@@ -28,16 +28,13 @@ def qpsk_field(n: int, seed: int, n_pol: int = 2, sps: int = 16, power_w: float 
 
 
 def lfsr_bits(order: int, length: int, seed: int) -> np.ndarray:
-    """Fibonacci LFSR bit sequence (PRBS-7/9/11/15/20/23/31 taps), for the Monte-Carlo
-    realisations of configuration C4."""
-    taps = {7: (7, 6), 9: (9, 5), 11: (11, 9), 15: (15, 14), 20: (20, 3), 23: (23, 18), 31: (31, 28)}[order]
-    state = seed & ((1 << order) - 1) or 1
-    out = np.empty(length, dtype=np.uint8)
-    for i in range(length):
-        bit = ((state >> (taps[0] - 1)) ^ (state >> (taps[1] - 1))) & 1
-        state = ((state << 1) | bit) & ((1 << order) - 1)
-        out[i] = bit
-    return out
+    """``PRBS(order, length, seed)`` as a uint8 array (the reference's LFSR, ``devices.py:166-175``), for the
+    Monte-Carlo realisations of configuration C4."""
+    from .devices import PRBS
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)          # seed 0 -> 1
+        return PRBS(order, int(length), int(seed)).data
 
 
 def prbs_field(n: int, seed: int, n_pol: int = 2, sps: int = 16, power_w: float = 1e-3, order: int = 15) -> np.ndarray:

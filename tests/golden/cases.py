@@ -133,6 +133,14 @@ CASES = {
                            kw=dict(G=17.5, NF=4.5)),
     "edfa_1pol_bw": dict(func="EDFA", gv=GV_B, inp=("qpsk", 63, (4096,), "complex128", 0.003), np_seed=23,
                          kw=dict(G=25, NF=6, BW=100e9)),
+    # pseudo-random bit sequences (reference devices.py:63-182): integer LFSR, bit-exact; out = bits, seed_out = final state
+    "prbs7_two_periods": dict(func="PRBS", gv=GV_A, kw=dict(order=7, len=254)),
+    "prbs9_seed": dict(func="PRBS", gv=GV_A, kw=dict(order=9, len=1500, seed=124)),
+    "prbs15_seed": dict(func="PRBS", gv=GV_A, kw=dict(order=15, len=70000, seed=12345)),
+    "prbs20_default": dict(func="PRBS", gv=GV_A, kw=dict(order=20, len=5000)),
+    "prbs23_seed_wraps": dict(func="PRBS", gv=GV_A, kw=dict(order=23, len=3000, seed=(1 << 23) + 77)),
+    "prbs31_seed": dict(func="PRBS", gv=GV_A, kw=dict(order=31, len=4000, seed=0x5EED5EED)),
+    "prbs11_short": dict(func="PRBS", gv=GV_A, kw=dict(order=11, len=5, seed=3)),
     # float64 twin loop (reference devices.py:2425-2486), 1 polarisation only
     "twin_f64_1pol": dict(func="TWIN", gv=GV_A, inp=("noise", 30, (4096,), "complex128", 0.03),
                           kw=dict(length=10, h=1.0, **FIB)),
@@ -147,6 +155,8 @@ def case_dt(case) -> float:
 
 
 def case_input(case):
+    if "inp" not in case:
+        return None, None
     sig = make_input(*case["inp"][:4], amp=case["inp"][4])
     noi = None
     if case.get("noise"):

@@ -41,6 +41,9 @@ def run_case(name, case, devices, typing):
     sig, noi = case_input(case)
     kw = dict(case["kw"])
     func = case["func"]
+    if func == "PRBS":
+        seq, last = devices.PRBS(return_seed=True, **kw)
+        return {"out": np.asarray(seq.data, dtype=np.uint8), "seed_out": np.array(last, dtype=np.int64)}
     if func == "LPF":
         x = None
     elif noi is None:

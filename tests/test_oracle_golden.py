@@ -171,3 +171,35 @@ def test_receiver_front_end_matches_reference(golden_dir, name):
         _check(out_n, g["out_noise"], exact, 1e-12)
     else:
         assert out_n is None
+
+
+# reference tests/devices_test.py:52-71 (literal vectors of its own PRBS test)
+REF_PRBS_20 = {
+    7: [1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 1],
+    9: [1, 0, 0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 0, 1],
+    11: [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1],
+    15: [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0],
+    20: [1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0],
+    23: [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1],
+    31: [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+}
+
+
+def test_prbs_oracle_against_the_references_own_test_vectors():
+    from oracle import prbs_numpy as po
+    for order, want in REF_PRBS_20.items():
+        bits, _ = po.prbs(order, 20)
+        assert bits.tolist() == want
+    assert po.prbs(7, 10, seed=0)[0].tolist() == [1, 0, 0, 0, 0, 0, 1, 1, 0, 0]          # seed 0 -> 1 (devices_test.py:57)
+    two, _ = po.prbs(7, 254)
+    assert two.tolist() == po.prbs(7, 127)[0].tolist() * 2                                  # longer than one period (:71)
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] == "PRBS"])
+def test_prbs_oracle_matches_reference(golden_dir, name):
+    from oracle import prbs_numpy as po
+    g = _load(golden_dir, name)
+    kw = CASES[name]["kw"]
+    bits, last = po.prbs(kw["order"], kw.get("len"), kw.get("seed"))
+    np.testing.assert_array_equal(bits, g["out"])
+    assert last == int(g["seed_out"])
