@@ -19,7 +19,12 @@
  *   devices.py:1155-1156,1193-1196 h=None          ssfm_propagate_adaptive (step control on device)
  *   devices.py:1150-1152,1184-1186 return_steps    `snapshots` argument of both propagate calls
  *   devices.py:1204 (.get() / wrap)                ssfm_get_field
- *   devices.py:1027-1029 (DM: ifft(fft(x)*H))      ssfm_apply_transfer
+ *   devices.py:1027-1029 (DM: ifft(fft(x)*H))      ssfm_apply_transfer / ssfm_apply_dispersion (H generated on the device)
+ *   devices.py:1363-1368, :814-823 (LPF / BPF:     ssfm_sosfiltfilt, ssfm_sosfiltfilt_device
+ *     scipy.signal.sosfiltfilt)
+ *   devices.py:1512-1515 (PD: r * |x|^2, pol sum)  ssfm_square_law, ssfm_square_law_device
+ *   (none: NumPy arrays are the reference's only   ssfm_device_alloc / _free / _copy / _convert / _add
+ *     data format)                                 -- device-resident signals between calls
  *
  * Conventions: plain C types, caller-owned buffers, every call returns an int status
  * (0 = SSFM_OK), no exceptions cross the ABI, no global mutable state except the
