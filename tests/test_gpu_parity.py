@@ -497,6 +497,49 @@ def test_pd_statistics_and_modes():
         oa.PD(x, BW=10e9, include_noise="everything")
 
 
+# ----------------------------------------------------------------------- randomised parameters
+def _fuzz_cases(count=24):
+    rng = np.random.default_rng(2025)
+    cases = []
+    for i in range(count):
+        k = int(rng.integers(8, 14))
+        npol = int(rng.integers(1, 3))
+        adaptive = bool(rng.integers(0, 2))
+        sign = -1.0 if rng.integers(0, 4) == 0 else 1.0                 # a quarter are back-propagations
+        fib = dict(alpha=sign * float(rng.uniform(0, 0.4)), beta_2=sign * float(rng.uniform(-25, 25)),
+                   beta_3=sign * float(rng.choice([0.0, rng.uniform(-0.3, 0.3)])), gamma=sign * float(rng.choice([0.0, rng.uniform(0.5, 3)])))
+        length = float(rng.uniform(1, 30))
+        kw = dict(length=length, **fib)
+        if adaptive:
+            kw["phi_max"] = float(rng.choice([0.01, 0.03, 0.05]))
+        else:
+            kw["h"] = float(rng.choice([length / 7.3, 0.5, 1.0, length * 2]))          # incl. short last step and h > length
+        cases.append((i, k, npol, float(rng.choice([1e-3, 5e-3, 2e-2])), kw))
+    return cases
+
+
+@pytest.mark.parametrize("i,k,npol,power,kw", _fuzz_cases(), ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_random_parameters_against_oracle(i, k, npol, power, kw):
+    """Random sizes, polarisation counts, fibres (incl. negated = DBP, gamma = 0, beta_3 = 0), fixed steps
+    (incl. a short last step and h > length) and adaptive steps against the oracle."""
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << k, seed=500 + i, n_pol=npol, power_w=power)
+    a = a[0] if npol == 1 else a
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)                 # gamma = 0 in adaptive mode divides by zero, as in the reference
+        zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+        z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+        y = oa.FIBER(optical_signal(a), **kw).signal
+    steps = len(zr) - 1
+    tol = TOL_100 if steps <= 100 else TOL_1000
+    if "h" in kw:
+        np.testing.assert_array_equal(z, zr)
+    else:
+        assert abs(len(z) - len(zr)) <= 1
+    assert relmax(A_z[-1], Ar[-1]) < tol and relmax(y, Ar[-1]) < tol
+    assert y.shape == a.shape and y.dtype == np.complex64
+
+
 # ----------------------------------------------------------------------- device-resident signals
 def _chain(x, keep):
     """FIBER -> EDFA-like noise loading -> FIBER -> DBP -> DM -> BPF -> PD, as a link script would write it."""
