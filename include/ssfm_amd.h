@@ -161,6 +161,23 @@ int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int k
 int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
 int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
 
+/* ---- lengths that are not powers of two (the reference takes any N: numpy.fft, devices.py:1178-1180) --------
+ * Bluestein's identity maps a length-N transform onto the circular convolution of a power-of-two plan of length
+ * M >= 2N - 1 (complex128).  ssfm_transfer_table keeps a transfer function H (HOST, M complex, the plan's type) on
+ * the device in slot 0 or 1; ssfm_apply_table does x <- ifft(fft(x) * H) on the plan's field WITHOUT waiting for the
+ * host; the chirp kernels move a caller-owned DEVICE field A (batch x N complex128, natural order) into and out of
+ * the plan's field buffer and apply the step's elementwise operators (csrc/chirpz.hip has the algebra):
+ *   ssfm_chirp_pre   F = A exp(i gamma |A|^2 hh) c, zero-padded; P (nullable) receives |A|^2
+ *   ssfm_chirp_mid   F = F exp(tab h) (mode 0, tab = D~)  or  F tab (mode 1, tab = a transfer function), N entries
+ *   ssfm_chirp_post  A = F conj(c) / N exp(i gamma P hh); maxbits_dev (nullable, 8 bytes) = bit pattern of max |A|^2
+ * `plan_n` / `batch` are the plan's own length and batch; all asynchronous on the plan's stream. */
+int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot);
+int ssfm_apply_table(ssfm_plan* plan, int slot);
+int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh);
+int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode);
+int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh,
+                    void* maxbits_dev);
+
 /* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);
 

@@ -44,6 +44,11 @@ SYMBOLS = {
     "ssfm_device_copy": (_I, [_I, _VP, _VP, C.c_size_t, _I]),
     "ssfm_device_convert": (_I, [_I, _VP, _I, _VP, _I, _I64]),
     "ssfm_device_add": (_I, [_I, _VP, _VP, _VP, _I, _I64]),
+    "ssfm_transfer_table": (_I, [_VP, _VP, _I]),
+    "ssfm_apply_table": (_I, [_VP, _I]),
+    "ssfm_chirp_pre": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D]),
+    "ssfm_chirp_mid": (_I, [_VP, _I64, _I, _VP, _I64, _D, _I]),
+    "ssfm_chirp_post": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D, _VP]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
@@ -359,6 +364,27 @@ class Plan:
         H = np.empty(self.n, dtype=self.cdtype) if want_H else None
         _check(load().ssfm_apply_dispersion(self._h, float(dt), float(D_s2), _ptr(H) if want_H else None), "ssfm_apply_dispersion")
         return H
+
+    # -- building blocks of the chirp-z path (lengths that are not powers of two)
+    def transfer_table(self, H: np.ndarray, slot: int):
+        h = np.ascontiguousarray(H, dtype=self.cdtype)
+        if h.shape != (self.n,):
+            raise ValueError(f"H must have shape ({self.n},), got {h.shape}")
+        _check(load().ssfm_transfer_table(self._h, _ptr(h), int(slot)), "ssfm_transfer_table")
+
+    def apply_table(self, slot: int):
+        _check(load().ssfm_apply_table(self._h, int(slot)), "ssfm_apply_table")
+
+    def chirp_pre(self, A: "DeviceArray", P, chirp: "DeviceArray", gamma: float, hh: float):
+        _check(load().ssfm_chirp_pre(self._h, self.n, self.batch, _VP(A.ptr), None if P is None else _VP(P.ptr), _VP(chirp.ptr), A.shape[-1],
+                                     float(gamma), float(hh)), "ssfm_chirp_pre")
+
+    def chirp_mid(self, tab: "DeviceArray", h: float, mode: int):
+        _check(load().ssfm_chirp_mid(self._h, self.n, self.batch, _VP(tab.ptr), tab.shape[-1], float(h), int(mode)), "ssfm_chirp_mid")
+
+    def chirp_post(self, A: "DeviceArray", P, chirp: "DeviceArray", gamma: float, hh: float, maxbits=None):
+        _check(load().ssfm_chirp_post(self._h, self.n, self.batch, _VP(A.ptr), None if P is None else _VP(P.ptr), _VP(chirp.ptr), A.shape[-1],
+                                      float(gamma), float(hh), None if maxbits is None else _VP(maxbits.ptr)), "ssfm_chirp_post")
 
     def debug_fft(self) -> np.ndarray:
         out = np.empty((self.batch, self.n), dtype=self.cdtype)

@@ -1,0 +1,146 @@
+// chirpz.hip -- fields whose length N is NOT a power of two (the reference takes any N: numpy.fft).
+//
+// Bluestein's identity turns a length-N DFT into a circular convolution of length M = 2^m >= 2N - 1, which the
+// power-of-two engine already does in three launches (ssfm_apply_table: x <- ifft(fft(x) H)):
+//     c_n = exp(-i pi n^2 / N)
+//     fft_N(x)_k  = c_k       sum_n (x_n c_n)        conj(c)_{k-n}
+//     ifft_N(X)_n = conj(c_n) sum_k (X_k conj(c_k))  c_{n-k}  / N
+// One split step (reference devices.py:1172-1181) becomes
+//     chirp_pre   y_n = A_n exp(i gamma |A_n|^2 h/2) c_n, zero-padded to M     (also stores |A_n|^2: the stale N^)
+//     apply_table (slot 0: fft_M of conj(c))
+//     chirp_mid   y_k = z_k exp(D~_k h)            -- c_k conj(c_k) = 1: the two chirps between the transforms cancel
+//     apply_table (slot 1: fft_M of c)
+//     chirp_post  A_n = z_n conj(c_n) / N * exp(i gamma |A_n|^2_stale h/2),  max |A|^2 for the adaptive step
+// All of it in complex128 on a complex128 plan of length M, whatever the caller's precision: the result then differs
+// from the reference's complex64 arithmetic only by the reference's own rounding (stated tolerance), and the
+// chirp's n^2 phase is exact.  These kernels run on the plan's stream, between caller-owned device arrays
+// (batch x N, natural order) and the plan's field buffer (batch x M); nothing synchronises with the host.
+#include <hip/hip_runtime.h>
+
+#include "ssfm_amd.h"
+#include "ssfm_common.hpp"
+
+using ssfm::fail;
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_chirp_pre(const double2* __restrict__ A, double* __restrict__ P, const double2* __restrict__ chirp,
+                                                   double2* __restrict__ F, long long n, long long M, int batch, double gamma, double hh) {
+    const long long total = M * batch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / M, m = i - r * M;
+        double2 y = make_double2(0.0, 0.0);
+        if (m < n) {
+            double2 a = A[r * n + m];
+            const double p = a.x * a.x + a.y * a.y;
+            if (P) P[r * n + m] = p;
+            if (gamma != 0.0) {
+                double s, c;
+                sincos(gamma * p * hh, &s, &c);
+                a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+            }
+            const double2 w = chirp[m];
+            y = make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+        }
+        F[i] = y;
+    }
+}
+
+// mode 0: multiply by exp(D~ h) (D~ in `tab`); mode 1: multiply by tab itself (a transfer function, e.g. DM's H)
+__global__ __launch_bounds__(256) void k_chirp_mid(const double2* __restrict__ tab, double2* __restrict__ F, long long n, long long M, int batch, double h, int mode) {
+    const long long total = M * batch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i % M;
+        double2 y = make_double2(0.0, 0.0);
+        if (m < n) {
+            const double2 z = F[i];
+            double2 e = tab[m];
+            if (mode == 0) {
+                double s, c;
+                sincos(e.y * h, &s, &c);
+                const double g = exp(e.x * h);
+                e = make_double2(g * c, g * s);
+            }
+            y = make_double2(z.x * e.x - z.y * e.y, z.x * e.y + z.y * e.x);
+        }
+        F[i] = y;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chirp_post(double2* __restrict__ A, const double* __restrict__ P, const double2* __restrict__ chirp,
+                                                    const double2* __restrict__ F, long long n, long long M, int batch, double gamma, double hh,
+                                                    double scale, unsigned long long* __restrict__ maxbits) {
+    const long long total = n * batch;
+    double pmax = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / n, m = i - r * n;
+        const double2 z = F[r * M + m];
+        const double2 w = chirp[m];
+        double2 a = make_double2((z.x * w.x + z.y * w.y) * scale, (z.y * w.x - z.x * w.y) * scale);     // z * conj(c) / N
+        if (gamma != 0.0) {
+            double s, c;
+            sincos(gamma * P[i] * hh, &s, &c);
+            a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+        }
+        A[i] = a;
+        const double p = a.x * a.x + a.y * a.y;
+        pmax = p > pmax ? p : pmax;
+    }
+    if (maxbits) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(pmax, o);
+            pmax = other > pmax ? other : pmax;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(maxbits, (unsigned long long)__double_as_longlong(pmax));   // non-negative doubles order like integers
+    }
+}
+
+unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+struct Target {
+    double2* F;
+    hipStream_t stream;
+    long long M;
+};
+int target_of(ssfm_plan* plan, long long n, long long M, Target* t) {
+    if (!plan) return fail(SSFM_ERR_INVALID, "null plan");
+    t->F = static_cast<double2*>(ssfm_field_device_ptr(plan));
+    t->stream = static_cast<hipStream_t>(ssfm_stream(plan));
+    t->M = M;
+    if (!t->F) return fail(SSFM_ERR_INVALID, "plan has no field buffer");
+    if (n < 2 || M < 2 * n - 1) return fail(SSFM_ERR_INVALID, "chirp-z: plan length %lld is shorter than 2 * %lld - 1", M, n);
+    return SSFM_OK;
+}
+
+}  // namespace
+
+extern "C" int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh) {
+    Target t;
+    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (!A || !chirp) return fail(SSFM_ERR_INVALID, "ssfm_chirp_pre: NULL argument");
+    hipLaunchKernelGGL(k_chirp_pre, dim3(blocks_for(t.M * batch)), dim3(256), 0, t.stream, (const double2*)A, (double*)P, (const double2*)chirp, t.F,
+                       (long long)n, t.M, batch, gamma, hh);
+    HIP_TRY(hipGetLastError());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode) {
+    Target t;
+    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (!tab || mode < 0 || mode > 1) return fail(SSFM_ERR_INVALID, "ssfm_chirp_mid: bad argument");
+    hipLaunchKernelGGL(k_chirp_mid, dim3(blocks_for(t.M * batch)), dim3(256), 0, t.stream, (const double2*)tab, t.F, (long long)n, t.M, batch, h, mode);
+    HIP_TRY(hipGetLastError());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh,
+                               void* maxbits_dev) {
+    Target t;
+    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (!A || !chirp || (gamma != 0.0 && !P)) return fail(SSFM_ERR_INVALID, "ssfm_chirp_post: NULL argument");
+    if (maxbits_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), t.stream));
+    hipLaunchKernelGGL(k_chirp_post, dim3(blocks_for((long long)n * batch)), dim3(256), 0, t.stream, (double2*)A, (const double*)P, (const double2*)chirp,
+                       (const double2*)t.F, (long long)n, t.M, batch, gamma, hh, 1.0 / (double)n, (unsigned long long*)maxbits_dev);
+    HIP_TRY(hipGetLastError());
+    return SSFM_OK;
+}

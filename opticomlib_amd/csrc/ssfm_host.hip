@@ -118,6 +118,7 @@ template <typename T> struct PlanT : PlanBase {
     cx<T>* dnat = nullptr;     // n  (D~ or H, natural order, staging)
     cx<T>* dperm = nullptr;    // n  (D~ transposed order)
     cx<T>* scratch = nullptr;  // batch * n, lazily
+    cx<T>* xfer_tab[2] = {nullptr, nullptr};   // resident transfer functions of ssfm_transfer_table (n each, lazily)
     struct Tab { T h; cx<T>* ptr; bool valid; };
     Tab tabs[kMaxTables] = {};
     int tab_rr = 0;
@@ -296,7 +297,7 @@ template <typename T> struct PlanT : PlanBase {
 
     int free_all() {
         if (stream) (void)hipStreamSynchronize(stream);
-        void* bufs[] = {F, P, twN, twA, twB, tw1, tw2, dnat, dperm, scratch, st, zlog};
+        void* bufs[] = {F, P, twN, twA, twB, tw1, tw2, dnat, dperm, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
         for (int g = 1; g < kMaxLanes; ++g) {
@@ -765,6 +766,31 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
+    // A transfer function kept on the device (slot 0 / 1), and its application x <- ifft(fft(x) * H) WITHOUT a
+    // host synchronisation: the building block of the chirp-z path for sizes that are not powers of two.
+    int transfer_table(const void* H_host, int slot) {
+        if (slot < 0 || slot > 1) return fail(SSFM_ERR_INVALID, "ssfm_transfer_table: slot %d", slot);
+        if (int rc = use_device()) return rc;
+        if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
+        HIP_TRY(hipMemcpyAsync(dnat, H_host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));      // dnat = staging
+        have_op = false;
+        for (auto& t : tabs) t.valid = false;
+        hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const cx<T>*)dnat, xfer_tab[slot], N1, N2, N2 / E, (T)0, inv_n());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));                  // H_host may be released by the caller
+        return SSFM_OK;
+    }
+    int apply_table(int slot) {
+        if (slot < 0 || slot > 1 || !xfer_tab[slot]) return fail(SSFM_ERR_STATE, "ssfm_apply_table: slot %d holds no table", slot);
+        if (int rc = use_device()) return rc;
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[slot], 0, nullptr), E)));
+        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        last_launches += 3;
+        return SSFM_OK;
+    }
+
     int debug_fft(void* dst) {
         if (int rc = use_device()) return rc;
         const int nrows = N1 * batch;
@@ -932,6 +958,11 @@ int ssfm_debug_fft(ssfm_plan* plan, void* dst) {
     WITH_PLAN(plan, P_->debug_fft(dst));
 }
 
+int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot) {
+    if (!H_host) return fail(SSFM_ERR_INVALID, "H_host is NULL");
+    WITH_PLAN(plan, P_->transfer_table(H_host, slot));
+}
+int ssfm_apply_table(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->apply_table(slot)); }
 int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }
 
 void* ssfm_stream(ssfm_plan* plan) {

@@ -50,12 +50,22 @@ def release_plans():
         p.close()
 
 
-def _check_size(n: int, precision: int):
+def _is_fast_size(n: int, precision: int) -> bool:
+    """Power of two within the fused two-kernel engine's range."""
     lo, hi = _lib.supported_log2n(precision)
-    if n < (1 << lo) or n > (1 << hi) or n & (n - 1):
+    return (1 << lo) <= n <= (1 << hi) and n & (n - 1) == 0
+
+
+def _check_size(n: int, precision: int):
+    """Any length from 2 up to 2^21 samples per polarisation runs on the GPU: powers of two in [2^8, 2^22] through
+    the fused engine, every other length through the chirp-z path on a power-of-two plan of >= 2n - 1 points."""
+    if _is_fast_size(n, precision):
+        return
+    _, hi = _lib.supported_log2n(_lib.C128)
+    if n < 2 or 2 * n - 1 > (1 << hi):
         raise ValueError(
-            f"the MI355X fibre path needs a power-of-two number of samples in [2^{lo}, 2^{hi}] per polarisation, "
-            f"got {n} (pad or resample the signal; there is no CPU fallback)")
+            f"the MI355X fibre path takes 2 ... 2^{hi - 1} samples per polarisation (powers of two up to 2^{hi}), "
+            f"got {n} (there is no CPU fallback)")
 
 
 def _precision_code(precision) -> int:
@@ -196,6 +206,113 @@ def step_schedule(length, h, precision=_lib.C64):
     return np.array(hlist, dtype=rt), np.array(zlist, dtype=rt)
 
 
+# ------------------------------------------------------------------ chirp-z engine (any length)
+class _ChirpZ:
+    """Split-step / single-transfer engine for fields of ANY length n on a power-of-two complex128 plan of
+    M >= 2n - 1 points (Bluestein; algebra in csrc/chirpz.hip).  The field lives in a device array in natural
+    order; all arithmetic is complex128 whatever the caller's precision."""
+
+    def __init__(self, n: int, batch: int, dev: int):
+        self.n, self.batch, self.dev = int(n), int(batch), int(dev)
+        M = 1 << max(8, (2 * n - 2).bit_length())
+        self.plan = get_plan(M, batch, _lib.C128, dev)
+        self.plan._op_key = None                                # the plan's operator staging is reused
+        if getattr(self.plan, "_chirp_n", None) != n:
+            m = np.arange(n, dtype=np.int64)
+            c = np.exp(-1j * np.pi * ((m * m) % (2 * n)) / n)          # exp(-i pi m^2 / n), phase reduced exactly
+            v = np.zeros(M, dtype=np.complex128)
+            v[:n] = np.conj(c)
+            v[M - n + 1:] = np.conj(c[1:][::-1])                        # v[-m] = v[m]
+            self.plan.transfer_table(np.fft.fft(v), 0)                  # forward transform: convolve with conj(c)
+            self.plan.transfer_table(np.fft.fft(np.conj(v)), 1)         # inverse transform: convolve with c
+            self.plan._chirp = _lib.DeviceArray.from_host(c, np.complex128, dev)
+            self.plan._chirp_n = n
+        self.chirp = self.plan._chirp
+
+    def step(self, A, P, Dt, gamma: float, h: float, maxbits=None):
+        """One symmetric split step of size ``h`` on the device array ``A`` (batch, n), in place."""
+        pl = self.plan
+        pl.chirp_pre(A, P, self.chirp, gamma, 0.5 * h)
+        pl.apply_table(0)
+        pl.chirp_mid(Dt, h, 0)
+        pl.apply_table(1)
+        pl.chirp_post(A, P, self.chirp, gamma, 0.5 * h, maxbits)
+
+    def transfer(self, A, H):
+        """``A <- ifft(fft(A) * H)`` for a device transfer function ``H`` of n entries, in place."""
+        pl = self.plan
+        pl.chirp_pre(A, None, self.chirp, 0.0, 0.0)
+        pl.apply_table(0)
+        pl.chirp_mid(H, 0.0, 1)
+        pl.apply_table(1)
+        pl.chirp_post(A, None, self.chirp, 0.0, 0.0, None)
+
+
+def _max_abs2(maxbits: "_lib.DeviceArray", plan) -> float:
+    plan.synchronize()
+    return float(maxbits.to_host().view(np.float64)[0])
+
+
+def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar):
+    """FIBER for a length that is not a power of two (same semantics as the fused engine: float32 coefficients
+    and step arithmetic in complex64 mode, reference devices.py:1137-1161, 1172-1196)."""
+    n = shape[-1]
+    batch = 1 if len(shape) == 1 else shape[0]
+    rt = _F32 if prec == _lib.C64 else np.float64
+    eng = _ChirpZ(n, batch, dev)
+    A = A_dev if A_dev.dtype == np.complex128 else A_dev.astype(np.complex128)
+    if A is A_dev:
+        A = A.copy()                                            # the caller's array is never modified
+    A.shape = (batch, n)
+    P = _lib.DeviceArray((batch, n), np.float64, dev)
+    Dt = _lib.DeviceArray.from_host(np.asarray(linear_operator(n, dt, alpha, beta_2, beta_3, prec), dtype=np.complex128), np.complex128, dev)
+    mb = _lib.DeviceArray((1,), np.float64, dev)
+    g = float(rt(gamma))
+    L = rt(length)
+    zs, snaps = [rt(0)], ([A.copy()] if return_steps else None)
+    steps = 0
+    if h is None:
+        b2, b3 = rt(beta_2), rt(beta_3)
+        single = bool((b2 == 0 and b3 == 0) or rt(gamma) == 0)
+
+        def next_h(amax):
+            with np.errstate(divide="ignore"):
+                return rt(phi_max) / (abs(rt(gamma)) * rt(amax))
+        if single:
+            hcur = L
+        else:
+            a0 = A.to_host()                                    # max |A|^2 of the input (one download)
+            hcur = next_h(np.max(a0.real ** 2 + a0.imag ** 2))
+        hcur = rt(min(hcur, L))
+        z = rt(0)
+        while z < L:
+            z = rt(z + hcur)
+            eng.step(A, P, Dt, g, float(hcur), mb)
+            steps += 1
+            zs.append(z)
+            if return_steps:
+                eng.plan.synchronize()                          # copies run on the default stream
+                snaps.append(A.copy())
+            if bar is not None:
+                bar.update(min(100.0 * float(hcur) / float(L), max(0.0, 100.0 - bar.n)))
+                bar.set_postfix(FFTs=2 * steps)
+            hcur = rt(min(next_h(_max_abs2(mb, eng.plan)), rt(L - z)))
+    else:
+        hs, z_all = step_schedule(length, h, prec)
+        for k, hk in enumerate(hs):
+            eng.step(A, P, Dt, g, float(hk))
+            if return_steps:
+                eng.plan.synchronize()
+                snaps.append(A.copy())
+        steps = hs.size
+        zs = list(z_all)
+        if bar is not None:
+            bar.update(100)
+            bar.set_postfix(FFTs=2 * int(steps))
+    eng.plan.synchronize()
+    return A, zs, snaps
+
+
 # ------------------------------------------------------------------ FIBER / DBP
 def FIBER(input: optical_signal,
           length: float,
@@ -247,13 +364,36 @@ def FIBER(input: optical_signal,
     n = shape[-1]
     batch = 1 if len(shape) == 1 else shape[0]
     _check_size(n, prec)
-    if A is not None:
+    if A is not None and _is_fast_size(n, prec):
         if A.dtype == np.complex128 and plan_dtype == np.complex64 and A.flags.c_contiguous:
             # the usual case (NumPy signals are complex128): upload as it lies and round to complex64 on the
             # device -- the same round-to-nearest cast, without a 32 -> 16 MiB conversion pass on the host
             A_dev = _lib.DeviceArray.from_host(A, np.complex128, dev).astype(np.complex64)
         else:
             A = np.ascontiguousarray(A, dtype=plan_dtype)
+
+    if not _is_fast_size(n, prec):
+        # any other length: chirp-z path (complex128 arithmetic on a power-of-two plan of >= 2n - 1 points)
+        bar = None
+        if show_progress:
+            try:
+                from tqdm.auto import tqdm
+                bar = tqdm(total=100, desc="Propagating", bar_format="{l_bar}{bar}|[{elapsed}{postfix}]", postfix={"FFTs": 0})
+            except ImportError:
+                bar = None
+        if A_dev is None:
+            A_dev = _lib.DeviceArray.from_host(np.ascontiguousarray(A, dtype=np.complex128), np.complex128, dev)
+        out, zs, snaps = _fiber_chirpz(A_dev, shape, float(grid.dt), length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar)
+        if bar is not None:
+            bar.close()
+        if return_steps:
+            A_z = np.stack([s_.to_host() for s_ in snaps]).astype(plan_dtype).reshape((len(snaps),) + tuple(shape))
+            return np.asarray(zs, dtype=np.float64), A_z
+        res = out if out.dtype == plan_dtype else out.astype(plan_dtype)
+        res.shape = tuple(shape)
+        output = _wrap_out(optical_signal, res, NULL)
+        output.execution_time = time.time() - t0
+        return back(output)
 
     L = rt(length)
     plan = get_plan(n, batch, prec, dev)
@@ -355,6 +495,30 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
     rows = 1 if len(shape) == 1 else shape[0]
     _check_size(n, _lib.C128)
     has_noise = raw_n is not NULL
+    if not _is_fast_size(n, _lib.C128):
+        # any other length: chirp-z path with H = exp(+j w^2 D / 2) formed on the host in the reference's own
+        # float64 expression (devices.py:1025-1027)
+        w = np.fft.fftfreq(n, float(grid.dt)) * 2 * np.pi           # typing.py:1641
+        H = np.exp(1j * w ** 2 * D / 2)
+        Hd = _lib.DeviceArray.from_host(H, np.complex128, dev)
+        nrow = rows * (2 if has_noise else 1)
+        eng = _ChirpZ(n, nrow, dev)
+        buf = _lib.DeviceArray((nrow, n), np.complex128, dev)
+        for k, a in enumerate([raw_s, raw_n] if has_noise else [raw_s]):
+            d = _dev_array(a, np.complex128, dev)
+            _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(buf.ptr + k * rows * n * 16), _lib._VP(d.ptr), rows * n * 16, 2), "ssfm_device_copy")
+        eng.transfer(buf, Hd)
+        eng.plan.synchronize()
+        outs = []
+        for k in range(2 if has_noise else 1):
+            o = _lib.DeviceArray(shape, np.complex128, dev)
+            _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(o.ptr), _lib._VP(buf.ptr + k * rows * n * 16), rows * n * 16, 2), "ssfm_device_copy")
+            outs.append(o)
+        output = _wrap_out(optical_signal, outs[0], outs[1] if has_noise else NULL, n_pol=input.n_pol)
+        if retH:
+            return back(output), np.fft.fftshift(H)
+        output.execution_time = time.time() - t0
+        return back(output)
     plan = get_plan(n, rows * (2 if has_noise else 1), _lib.C128, dev)
     plan._op_key = None                                   # DM may reuse the operator staging buffer
     # signal rows, then noise rows, straight into the plan's field buffer

@@ -73,7 +73,7 @@ def test_fft_against_numpy(k, prec):
 
 
 # ----------------------------------------------------------------------- golden vectors
-POW2 = [n for n, c in CASES.items() if _npts(c) and _npts(c) & (_npts(c) - 1) == 0]
+POW2 = [n for n, c in CASES.items() if _npts(c)]          # every captured case: other lengths take the chirp-z path
 
 
 @pytest.mark.parametrize("name", [n for n in POW2 if CASES[n]["func"] in ("FIBER", "DBP")])
@@ -153,10 +153,58 @@ def test_c128_against_reference_twin(golden_dir, name):
     assert relmax(y.signal, want) < TOL_C128
 
 
-def test_non_power_of_two_is_rejected():
+# ----------------------------------------------------------------------- lengths that are not powers of two
+@pytest.mark.parametrize("n,npol", [(3000, 1), (1000, 2), (257, 1), (64, 2), (12345, 2), (100003, 1), (2, 1), (3, 2)])
+def test_any_length_fixed_step_against_oracle(n, npol):
+    """Chirp-z path (complex128 arithmetic on a power-of-two plan): composite, prime, tiny and small power-of-two
+    lengths against the oracle's complex64 run -- the difference is the reference's own float32 rounding."""
+    gv(**workloads.BENCH_GV)
+    rng = np.random.default_rng(n)
+    a = (rng.standard_normal((npol, n)) + 1j * rng.standard_normal((npol, n))) * 0.03
+    a = a[0] if npol == 1 else a
+    kw = dict(length=6, h=0.7, **workloads.SMF)                       # 9 steps, the last one short
+    y = oa.FIBER(optical_signal(a), **kw)
+    assert y.signal.dtype == np.complex64 and y.signal.shape == a.shape and y.n_pol == npol
+    ref = orc.fiber_c64(a, gv.dt, **kw)
+    assert relmax(y.signal, ref) < TOL_100
+    z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+    zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+    np.testing.assert_array_equal(z, zr)
+    assert A_z.shape == Ar.shape and A_z.dtype == np.complex64 and relmax(A_z, Ar) < TOL_100
+    back = oa.DBP(y, **kw)                                             # device-resident input of odd length
+    assert relmax(back.signal, orc.dbp_c64(ref, gv.dt, **kw)) < TOL_100
+
+
+@pytest.mark.parametrize("n", [3000, 5001])
+def test_any_length_adaptive_complex128_and_dm(n):
+    gv(**workloads.BENCH_GV)
+    rng = np.random.default_rng(n + 1)
+    a = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))) * 0.07
+    kw = dict(length=10, phi_max=0.02, **workloads.SMF)
+    z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+    zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+    assert abs(len(z) - len(zr)) <= 1 and abs(z[-1] - 10.0) < 1e-4
+    m = min(len(z), len(zr)) - 1
+    np.testing.assert_allclose(z[:m], zr[:m], rtol=2e-4)
+    assert relmax(A_z[-1], Ar[-1]) < TOL_100
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    assert relmax(y, Ar[-1]) < TOL_100
+    # complex128 extension against the float64 restatement
+    kwf = dict(length=5, h=0.5, **workloads.SMF)
+    y128 = oa.FIBER(optical_signal(a), precision="complex128", **kwf).signal
+    assert y128.dtype == np.complex128 and relmax(y128, orc.fiber_c128(a, gv.dt, **kwf)) < TOL_C128
+    # DM: signal and noise apart, H as the reference forms it
+    nz = 0.1 * a[::-1].copy()
+    d, H = oa.DM(optical_signal(a, nz), D=-150.0, retH=True)
+    ds, dn = orc.dm_c128(a, gv.dt, -150.0, noise=nz)
+    assert relmax(d.signal, ds) < 1e-12 and relmax(d.noise, dn) < 1e-12
+    np.testing.assert_allclose(H, np.fft.fftshift(orc.dm_transfer(n, gv.dt, -150.0)), rtol=0, atol=1e-15)
+
+
+def test_lengths_beyond_the_range_are_rejected():
     gv(sps=16, R=10e9)
-    with pytest.raises(ValueError, match="power-of-two"):
-        oa.FIBER(optical_signal(np.ones(3000, complex)), length=1, h=1.0)
+    with pytest.raises(ValueError, match="samples per polarisation"):
+        oa.FIBER(optical_signal(np.ones((1 << 21) + 1, complex)), length=1, h=1.0)
 
 
 # ----------------------------------------------------------------------- oracle, seeded inputs

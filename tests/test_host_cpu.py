@@ -53,13 +53,16 @@ def test_type_errors_match_reference():
 
 
 def test_unsupported_size_raises_value_error():
-    if _lib.device_count() == 0:
-        # size is validated against the library's range before a plan is created
-        x = optical_signal(np.ones(3000, complex))
-        with pytest.raises(ValueError, match="power-of-two"):
-            oa.FIBER(x, length=1, h=1.0)
-        with pytest.raises(ValueError, match="power-of-two"):
-            oa.FIBER(optical_signal(np.ones(128, complex)), length=1, h=1.0)
+    """Sizes are validated before anything touches the device: 2 ... 2^21 samples (chirp-z path for lengths that
+    are not powers of two), powers of two up to 2^22."""
+    for n in ((1 << 21) + 1, (1 << 22) + 2, 3 << 20):
+        with pytest.raises(ValueError, match="samples per polarisation"):
+            devices._check_size(n, _lib.C64)
+    with pytest.raises(ValueError, match="samples per polarisation"):
+        devices._check_size(1, _lib.C64)
+    for n in (2, 3, 64, 255, 256, 3000, 100003, 1 << 21, 1 << 22):
+        devices._check_size(n, _lib.C64)                            # accepted
+    assert devices._is_fast_size(4096, _lib.C64) and not devices._is_fast_size(3000, _lib.C64) and not devices._is_fast_size(128, _lib.C64)
 
 
 def test_bad_step_rejected():
