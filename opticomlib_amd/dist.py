@@ -125,7 +125,7 @@ def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False
     Returns the list of F output arrays (complex64, or complex128 with ``precision="complex128"``).
     """
     from . import _lib
-    from .devices import FIBER, _check_size, _precision_code, get_plan, linear_operator, step_schedule
+    from .devices import FIBER, _check_size, _is_fast_size, _precision_code, get_plan, linear_operator, step_schedule
     from .typing import gv, optical_signal
 
     fields = np.asarray(fields)
@@ -133,6 +133,7 @@ def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False
     mine = shard(n_units)
     kw = dict(fiber_kw)
     fixed = kw.get("h") is not None and not kw.get("return_steps") and not kw.get("show_progress")
+    fixed = fixed and _is_fast_size(fields.shape[-1], _precision_code(kw.get("precision", "complex64")))     # other lengths: one by one (chirp-z)
     local: List[np.ndarray] = []
     if fixed and len(mine) > 1:
         prec = _precision_code(kw.get("precision", "complex64"))

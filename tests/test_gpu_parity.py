@@ -810,6 +810,9 @@ def test_propagate_channels_fiber_then_dbp_on_device():
     assert relmax(outs[0], ref) < TOL_100
     one = od.propagate_channels(fields[:1], gv.dt, dbp=True, **kw)             # single unit: host-API branch
     np.testing.assert_array_equal(one[0], outs[0])
+    odd = fields[:2, :, :3000]                                                 # not a power of two: one by one, chirp-z
+    got = od.propagate_channels(odd, gv.dt, **kw)
+    assert relmax(got[1], orc.fiber_c64(odd[1], gv.dt, **kw)) < TOL_100
 
 
 # ----------------------------------------------------------------------- symmetries of the propagator
