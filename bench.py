@@ -55,6 +55,33 @@ def cpu_baseline(a, dt, fibre, sample_steps):
     }
 
 
+def _manycore_worker(job):
+    seed, dt, fibre, steps = job
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from opticomlib_amd import workloads
+    from oracle import ssfm_numpy as orc
+    a = workloads.qpsk_field(1 << LOG2N, seed=seed).astype(np.complex64)
+    t = time.perf_counter()
+    orc.fiber_c64_tidy(a, dt, length=LENGTH_KM, h=H_KM, max_steps=steps, **fibre)
+    return time.perf_counter() - t
+
+
+def cpu_baseline_manycore(dt, fibre, procs, sample_steps):
+    """the tidied NumPy variant, one single-threaded process per independent field
+    (how a CPU user would run configurations C3 / C4), `procs` fields at once."""
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(procs) as pool:
+        t = time.perf_counter()
+        times = pool.map(_manycore_worker, [(3000 + i, dt, fibre, sample_steps) for i in range(procs)])
+        wall = time.perf_counter() - t
+    return {
+        "value": procs * (1 << LOG2N) * sample_steps / max(times), "unit": "sample*steps/s", "cores": procs, "kind": "port",
+        "sample": f"{procs} processes x {sample_steps} SSFM steps of independent 2^{LOG2N} x {N_POL} complex64 fields, "
+                  f"oracle/ssfm_numpy.fiber_c64_tidy (tabulated exp(D~h), one nonlinear exp per step, in place), slowest worker "
+                  f"{max(times):.1f} s, pool wall {wall:.1f} s incl. start-up, host has {os.cpu_count()} cores",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=48, help="SSFM steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--cpu-manycore", type=int, default=0, help="also time the tidied CPU variant on this many processes (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +171,7 @@ def main():
 
     roofline = None
     cpu = None
+    cpu_many = None
     if rank == 0:
         lanes = plan.lanes
         rows_per_launch = N_POL // lanes                     # a launch covers one lane's rows
@@ -207,6 +236,8 @@ def main():
                     pass
         if world == 1 and args.cpu_steps > 0:
             cpu = cpu_baseline(a, dt, fibre, args.cpu_steps)
+        if world == 1 and args.cpu_manycore > 0:
+            cpu_many = cpu_baseline_manycore(dt, fibre, args.cpu_manycore, max(8, args.cpu_steps // 4))
 
     if distributed:
         dist.barrier()
@@ -238,6 +269,7 @@ def main():
         "output_power_W_per_rank": checks,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        **({"cpu_baseline_manycore": cpu_many} if cpu_many else {}),
     }))
 
 

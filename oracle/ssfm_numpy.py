@@ -114,6 +114,38 @@ def fiber_c64(field, dt, length, alpha=0.0, beta_2=0.0, beta_3=0.0, gamma=0.0,
     return A
 
 
+def fiber_c64_tidy(field, dt, length, alpha=0.0, beta_2=0.0, beta_3=0.0, gamma=0.0, h=1.0, max_steps=None):
+    """The same fixed-step arithmetic written the way a CPU user who cares about speed would (SURVEY.md 8(d),
+    "fair many-core" baseline): ``exp(D~ h)`` tabulated per distinct step size instead of recomputed every
+    step, the nonlinear factor ``exp(h/2 N^)`` evaluated once per step and applied twice, products in place.
+    Every value is produced by the same expression as in :func:`ssfm_step_c64`, so the result is bit-identical
+    to :func:`fiber_c64`; only the amount of work differs."""
+    c = _Coeffs32(length, alpha, beta_2, beta_3, gamma, 0.01)
+    n = np.shape(field)[-1]
+    D = linear_operator_c64(n, dt, alpha, beta_2, beta_3)
+    A = np.array(field, dtype=np.complex64)
+    tables = {}
+    h_ = first_step_c64(A, c, h)
+    z = np.array(0, dtype=F32)
+    steps = 0
+    while z < c.length:
+        z += h_
+        key = h_.tobytes()
+        if key not in tables:
+            tables[key] = np.exp(D * h_)
+        rot = np.exp(h_ / 2 * (1j * c.gamma * np.abs(A) ** 2))
+        A *= rot
+        A = np.fft.fft(A)
+        A *= tables[key]
+        A = np.fft.ifft(A)
+        A *= rot
+        steps += 1
+        h_ = np.array(min(h_, c.length - z), dtype=F32)
+        if max_steps is not None and steps >= max_steps:
+            break
+    return A
+
+
 def dbp_c64(field, dt, length, alpha=0.0, beta_2=0.0, beta_3=0.0, gamma=0.0,
             phi_max=0.01, h=None, return_steps=False):
     """``DBP`` = ``FIBER`` with negated operators -- reference ``devices.py:1280-1283``."""

@@ -203,3 +203,11 @@ def test_prbs_oracle_matches_reference(golden_dir, name):
     bits, last = po.prbs(kw["order"], kw.get("len"), kw.get("seed"))
     np.testing.assert_array_equal(bits, g["out"])
     assert last == int(g["seed_out"])
+
+
+def test_tidied_cpu_variant_is_bit_identical():
+    """oracle.fiber_c64_tidy (the many-core CPU baseline of bench.py --cpu-manycore) computes the same values."""
+    rng = np.random.default_rng(4)
+    a = (rng.standard_normal((2, 2048)) + 1j * rng.standard_normal((2, 2048))) * 0.03
+    kw = dict(length=3.3, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3, h=0.5)
+    np.testing.assert_array_equal(orc.fiber_c64_tidy(a, 1.953125e-12, **kw), orc.fiber_c64(a, 1.953125e-12, **kw))
