@@ -696,7 +696,14 @@ template <typename T> struct PlanT : PlanBase {
                 if (int rc = copy_field_out(snap + fb * hs.steps, false, true)) return rc;
             prev_steps = hs.steps;
             if (hs.done) break;
-            if (!snap && chunk < 128) chunk *= 2;          // poll less often on long runs
+            if (!snap) {
+                // poll less often on long runs, but do not queue far beyond the end: at the current step size
+                // about (L - z) / h steps remain (the step only shrinks towards the clamp at L)
+                if (chunk < 128) chunk *= 2;
+                const double remain = hs.h > (T)0 ? ((double)hs.length - (double)hs.z) / (double)hs.h : 1.0;
+                const int est = remain > 1e6 ? 128 : (int)(0.75 * remain) + 1;
+                if (chunk > est) chunk = est < 2 ? 2 : est;
+            }
         }
         HIP_TRY(hipEventRecord(ev1, stream));
         timed = true;

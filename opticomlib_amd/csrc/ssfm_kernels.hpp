@@ -71,9 +71,15 @@ template <typename T> struct AdaptState {
     int steps;
     int max_steps;
     unsigned long long maxbits;   // bit pattern of max |A|^2 (non-negative => monotone as integer)
-    unsigned int ticket;          // workgroups of k_time<END> that have contributed their maximum
+    unsigned int ticket;          // slots of k_time<END> whose workgroups have all contributed
     unsigned int pad_;
+    // k_time<END> reduces in two levels: 2048 waves hitting ONE address with atomicMax serialise (about
+    // 13 ns each: the kernel took 38 us instead of 12), so a workgroup reduces through LDS and publishes to
+    // slot (block id mod 64); the last workgroup of a slot raises `ticket`, the last slot runs the step control.
+    unsigned long long slot_max[64];
+    unsigned int slot_ticket[64];
 };
+constexpr int kAdaptSlots = 64;
 
 // Block id -> (unit, row) so that the `rows` blocks working on the same unit (column tile / spectrum
 // row) share its read-only table through ONE XCD's L2: blocks are dealt round-robin over the 8 XCDs
@@ -451,24 +457,52 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
 #pragma unroll
         for (int t = 0; t < E; ++t) stream_store(&Fb[off + t * stride], v[t]);
         if (a.st != nullptr) {
-            // wave-level max, one atomic per wave; the LAST workgroup to arrive (ticket) then runs the
-            // step control, so an adaptive step is 3 launches (BEGIN, k_freq, END), not 4
+            // workgroup maximum through LDS, one atomic per workgroup on its slot; the LAST workgroup to arrive
+            // (two-level ticket) then runs the step control, so an adaptive step is 3 launches (BEGIN, k_freq,
+            // END), not 4
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const T other = __shfl_xor(pmax, o);
                 pmax = other > pmax ? other : pmax;
             }
-            if ((tid & 63) == 0) atomicMax(&a.st->maxbits, float_bits<T>(pmax));
-            __syncthreads();                       // every wave of this workgroup has contributed
+            __shared__ T wave_max[16];
+            __shared__ int last_arrival;
+            constexpr int NWAVES = (N1 * C / E + 63) / 64;
+            const unsigned nslots = gridDim.x < (unsigned)kAdaptSlots ? gridDim.x : (unsigned)kAdaptSlots;
+            if ((tid & 63) == 0) wave_max[tid >> 6] = pmax;
+            __syncthreads();
             if (tid == 0) {
-                __threadfence();
-                const unsigned arrived = atomicAdd(&a.st->ticket, 1u);
-                if (arrived == gridDim.x - 1) {
-                    __threadfence();
-                    const unsigned long long mb = atomicMax(&a.st->maxbits, 0ull);   // coherent read
-                    a.st->ticket = 0u;
+                T m = wave_max[0];
+#pragma unroll
+                for (int w = 1; w < NWAVES; ++w) m = wave_max[w] > m ? wave_max[w] : m;
+                const unsigned slot = blockIdx.x % kAdaptSlots;
+                const unsigned in_slot = (gridDim.x + kAdaptSlots - 1 - slot) / kAdaptSlots;     // workgroups sharing this slot
+                // No __threadfence() here: a release fence writes back the 32 KiB of field data this workgroup has
+                // just stored (the XCD's dirty L2 lines) -- 512 of them made this kernel 48 us instead of 10.  The
+                // step control only needs the ATOMICS ordered, and an atomic that returns a value has been performed
+                // at the point of coherence: each ticket increment carries a data dependency on the atomic before
+                // it.  The field itself becomes visible at the kernel boundary, as for every other kernel.
+                const unsigned long long old = atomicMax(&a.st->slot_max[slot], float_bits<T>(m));
+                const unsigned dep0 = (unsigned)(old >> 63);                         // always 0: |A|^2 >= 0
+                int last = 0;
+                if (atomicAdd(&a.st->slot_ticket[slot], 1u + dep0) == in_slot - 1) {
+                    const unsigned dep1 = atomicExch(&a.st->slot_ticket[slot], 0u) >> 31;    // reset for the next step; always 0
+                    last = atomicAdd(&a.st->ticket, 1u + dep1) == nslots - 1;
+                }
+                last_arrival = last;
+            }
+            __syncthreads();
+            if (last_arrival && tid < 64) {
+                // the last workgroup of the grid: one wavefront collects (and clears) the slots in parallel
+                unsigned long long mb = (unsigned)tid < nslots ? atomicExch(&a.st->slot_max[tid], 0ull) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(mb, o);
+                    mb = other > mb ? other : mb;
+                }
+                if (tid == 0) {
+                    atomicExch(&a.st->ticket, 0u);
                     step_control_update<T>(a.st, a.zlog, mb);
-                    __threadfence();
                 }
             }
         }
