@@ -545,6 +545,22 @@ def test_pd_statistics_and_modes():
         oa.PD(x, BW=10e9, include_noise="everything")
 
 
+def test_adaptive_large_grid_against_oracle():
+    """Adaptive step control with a grid of hundreds of workgroups (two-level slot reduction): 2^18 x 2 and
+    2^19 x 1, step positions and field against the oracle."""
+    gv(**workloads.BENCH_GV)
+    for k, npol in ((18, 2), (19, 1)):
+        a = workloads.qpsk_field(1 << k, seed=40 + k, n_pol=npol, power_w=8e-3)
+        a = a[0] if npol == 1 else a
+        kw = dict(length=6, phi_max=0.005, **workloads.SMF)
+        z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+        zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+        assert len(z) == len(zr) and len(z) > 10
+        np.testing.assert_allclose(z, zr, rtol=2e-5)
+        assert relmax(A_z[-1], Ar[-1]) < TOL_100
+        assert relmax(oa.FIBER(optical_signal(a), **kw).signal, Ar[-1]) < TOL_100
+
+
 # ----------------------------------------------------------------------- randomised parameters
 def _fuzz_cases(count=24):
     rng = np.random.default_rng(2025)
