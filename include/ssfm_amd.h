@@ -160,6 +160,8 @@ int ssfm_device_free(int device, void* ptr, size_t bytes);
 int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind);
 int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
 int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
+/* Free / total HBM of the device and the bytes held in the library's buffer pool (nullable). */
+int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes);
 
 /* ---- lengths that are not powers of two (the reference takes any N: numpy.fft, devices.py:1178-1180) --------
  * Bluestein's identity maps a length-N transform onto the circular convolution of a power-of-two plan of length

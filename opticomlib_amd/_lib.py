@@ -44,6 +44,7 @@ SYMBOLS = {
     "ssfm_device_copy": (_I, [_I, _VP, _VP, C.c_size_t, _I]),
     "ssfm_device_convert": (_I, [_I, _VP, _I, _VP, _I, _I64]),
     "ssfm_device_add": (_I, [_I, _VP, _VP, _VP, _I, _I64]),
+    "ssfm_device_mem_info": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ssfm_transfer_table": (_I, [_VP, _VP, _I]),
     "ssfm_apply_table": (_I, [_VP, _I]),
     "ssfm_chirp_pre": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D]),
@@ -252,6 +253,13 @@ class DeviceArray:
 
     def __repr__(self):
         return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.device})"
+
+
+def device_mem_info(device: int = 0):
+    """(free, total, pooled) bytes of HBM on ``device``; ``pooled`` = freed buffers the library keeps for reuse."""
+    f, t, p = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _check(load().ssfm_device_mem_info(int(device), C.byref(f), C.byref(t), C.byref(p)), "ssfm_device_mem_info")
+    return int(f.value), int(t.value), int(p.value)
 
 
 def square_law_device(signal: DeviceArray, noise, r: float, post: float = 1.0):

@@ -128,3 +128,14 @@ extern "C" int ssfm_device_add(int device, void* dst, const void* a, const void*
     HIP_TRY(hipDeviceSynchronize());
     return SSFM_OK;
 }
+
+extern "C" int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes) {
+    if (!free_bytes || !total_bytes) return fail(SSFM_ERR_INVALID, "ssfm_device_mem_info: NULL argument");
+    if (int rc = use(device)) return rc;
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    if (pooled_bytes) {
+        std::lock_guard<std::mutex> lock(g_pool[device].mu);
+        *pooled_bytes = g_pool[device].cached_bytes;
+    }
+    return SSFM_OK;
+}

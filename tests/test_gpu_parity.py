@@ -711,6 +711,32 @@ def test_devices_accept_the_reference_librarys_own_objects():
         oa.FIBER(ft.electrical_signal(np.ones(256)), length=1)
 
 
+def test_repeated_calls_do_not_leak_device_memory():
+    """200 link chains of changing sizes: device buffers go back to the pool, plans are reused; free HBM does not
+    drift by more than the pool's cap."""
+    import gc
+    gv(**workloads.BENCH_GV)
+    kw = dict(length=2, h=1.0, **workloads.SMF)
+
+    def chain(k, odd):
+        n = (1 << k) - (17 if odd else 0)
+        a = workloads.qpsk_field(1 << k, seed=k)[:, :n]
+        y = oa.DBP(oa.FIBER(optical_signal(a), **kw), **kw)
+        return oa.PD(oa.BPF(y, BW=100e9), BW=20e9, include_noise="none").signal
+
+    for k in (10, 12, 13):
+        chain(k, False), chain(k, True)                          # warm-up: plans and tables exist
+    gc.collect()
+    free0, total, pooled0 = _lib.device_mem_info()
+    for i in range(200):
+        chain((10, 12, 13)[i % 3], i % 2 == 1)
+    gc.collect()
+    free1, _, pooled1 = _lib.device_mem_info()
+    assert total > 100 * 2 ** 30
+    assert pooled1 <= 2 * 2 ** 30
+    assert free0 - free1 < 256 * 2 ** 20, (free0, free1, pooled0, pooled1)
+
+
 # ----------------------------------------------------------------------- API behaviour on the device
 def test_call_order_and_argument_errors():
     p = _lib.Plan(4096, 2, _lib.C64)
