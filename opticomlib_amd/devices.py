@@ -22,7 +22,7 @@ from .typing import NULL, binary_sequence, electrical_signal, gv, optical_signal
 
 _F32 = np.float32
 _PLANS: "OrderedDict[tuple, _lib.Plan]" = OrderedDict()
-_MAX_PLANS = 4
+_MAX_PLANS = 12           # a 2^20 x 2 plan holds ~0.1 GB of the 288 GB; a link script cycles through a handful of shapes
 
 
 def default_device() -> int:
