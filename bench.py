@@ -55,6 +55,33 @@ def cpu_baseline(a, dt, fibre, sample_steps):
     }
 
 
+def secondary_c1(a, dt, fibre, device):
+    """Configuration C1 of BASELINE.json (the same 2^20 x 2 field, complex128, 100 x 1 km), reported beside the
+    headline C2 figure: measured after the timed region, outside `value`."""
+    from opticomlib_amd import _lib, devices
+    n = a.shape[-1]
+    hs, _ = devices.step_schedule(100.0, 1.0, _lib.C128)
+    p = _lib.Plan(n, N_POL, _lib.C128, device=device)
+    try:
+        p.set_linear_operator(devices.linear_operator(n, dt, fibre["alpha"], fibre["beta_2"], fibre["beta_3"], _lib.C128))
+        p.set_field(a)
+        p.propagate_fixed(fibre["gamma"], hs)
+        p.synchronize()
+        reps = 5
+        t = time.perf_counter()
+        for _ in range(reps):
+            p.propagate_fixed(fibre["gamma"], hs)
+        p.synchronize()
+        el = (time.perf_counter() - t) / reps
+    finally:
+        p.close()
+    rate = n * hs.size / el
+    return {"workload": "C1: the same 2^20-sample dual-pol field, complex128, FIBER(length=100, h=1.0) = 100 SSFM steps", "dtype": "c128",
+            "value": rate, "unit": "sample*steps/s", "us_per_ssfm_step": el / hs.size * 1e6,
+            "step_frac": 2 * N_POL * 16 * rate / (HBM_PEAK_GBS * 1e9),
+            "note": "algorithmic bytes 64 B per sample*step (complex128); not part of `value`"}
+
+
 def _manycore_worker(job):
     seed, dt, fibre, steps = job
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -172,6 +199,7 @@ def main():
     roofline = None
     cpu = None
     cpu_many = None
+    other = None
     if rank == 0:
         lanes = plan.lanes
         rows_per_launch = N_POL // lanes                     # a launch covers one lane's rows
@@ -234,6 +262,8 @@ def main():
                     roofline["traffic_source"] = t.get("_source")
                 except Exception:
                     pass
+        if world == 1:
+            other = secondary_c1(a, dt, fibre, local_rank)
         if world == 1 and args.cpu_steps > 0:
             cpu = cpu_baseline(a, dt, fibre, args.cpu_steps)
         if world == 1 and args.cpu_manycore > 0:
@@ -270,6 +300,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         **({"cpu_baseline_manycore": cpu_many} if cpu_many else {}),
+        **({"secondary": other} if other else {}),
     }))
 
 
