@@ -21,7 +21,12 @@ using namespace ssfm;
 namespace {
 
 constexpr int kLog2Min = 8, kLog2Max = 22;
-constexpr int kColsPerTile = 16;   // C: 128 B (c64) / 256 B (c128) contiguous per row segment
+// C, columns per k_time tile: one 128-byte line per row segment in either precision.  (complex128 used 16 as well
+// at first: 512-thread workgroups, one per CU; with 8 the two precisions have the same workgroup shape, two per CU.)
+#ifndef SSFM_COLS_C128
+#define SSFM_COLS_C128 8
+#endif
+template <typename T> constexpr int cols_per_tile() { return sizeof(T) == 8 ? SSFM_COLS_C128 : 16; }
 constexpr int kMaxTables = 4;
 
 // rows per k_freq workgroup: at least 64 threads where the row count allows (N1 >= 16 rows per batch entry)
@@ -36,7 +41,7 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
 // E = points per thread: 16 (default) or 8 (twice the waves, half the registers, one more LDS exchange).
 template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
-    constexpr int C = kColsPerTile;
+    constexpr int C = cols_per_tile<T>();
     constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                          + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE>, lds);
@@ -46,7 +51,7 @@ hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
 }
 template <typename T, int MODE, int E>
 hipError_t launch_time_e(int N1, int batch, hipStream_t s, const TimeArgs<T>& a) {
-    const dim3 grid((unsigned)(a.N2 / kColsPerTile) * batch);
+    const dim3 grid((unsigned)(a.N2 / cols_per_tile<T>()) * batch);
     switch (N1) {
         case 16:  return launch_time_n1<T, MODE, 16, E>(grid, s, a);
         case 32:  return launch_time_n1<T, MODE, 32, E>(grid, s, a);
@@ -373,7 +378,7 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipMalloc(&dperm, cb * n));
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
-        hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2, kColsPerTile, E);
+        hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2, cols_per_tile<T>(), E);
         hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, nA, 1ll, (long long)n);
         hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, nB, (long long)(N1 / 16), (long long)n);
         HIP_TRY(hipGetLastError());
