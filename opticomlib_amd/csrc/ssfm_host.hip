@@ -26,7 +26,10 @@ constexpr int kLog2Min = 8, kLog2Max = 22;
 #ifndef SSFM_COLS_C128
 #define SSFM_COLS_C128 8
 #endif
-template <typename T> constexpr int cols_per_tile() { return sizeof(T) == 8 ? SSFM_COLS_C128 : 16; }
+#ifndef SSFM_COLS_C64
+#define SSFM_COLS_C64 16
+#endif
+template <typename T> constexpr int cols_per_tile() { return sizeof(T) == 8 ? SSFM_COLS_C128 : SSFM_COLS_C64; }
 constexpr int kMaxTables = 4;
 
 // rows per k_freq workgroup: at least 64 threads where the row count allows (N1 >= 16 rows per batch entry)
