@@ -237,9 +237,26 @@ __host__ __device__ constexpr int fft_ls(int L, int s, int E) {   // product of 
 
 // Stage twiddles of one thread, loaded once per kernel and kept in registers: they depend only on
 // the thread's position in the line, and the forward and the inverse transform share them.
-template <typename T, int L, int E> struct LineTw {
+//
+// complex128 cannot afford that: 3 x 15 twiddles of 4 registers each are 180 of the 256 a thread can have, and
+// the 16-point kernels spilled to AGPRs and scratch.  There (SSFM_TW_LAZY_C128) a thread keeps only WHERE its
+// twiddles are -- the workgroup's LDS copy of a small stage, its own column of the global table for a large
+// one -- and loads each factor when a stage needs it (twice per kernel: forward and inverse transform).
+#ifndef SSFM_TW_LAZY_C128
+#define SSFM_TW_LAZY_C128 1
+#endif
+// (Only with 16 points per thread, i.e. the 2^21 / 2^22 plans: with 8 points per thread the registers suffice and
+// keeping the twiddles is 2 % faster -- C1 46.6 vs 47.6 us per step.)
+template <typename T, int E> __host__ __device__ constexpr bool tw_lazy() { return SSFM_TW_LAZY_C128 != 0 && sizeof(T) == 8 && E == 16; }
+
+template <typename T, int L, int E, bool LAZY = tw_lazy<T, E>()> struct LineTw {
     static constexpr int M = fft_nstages(L, E);
     cx<T> w[M > 1 ? M - 1 : 1][E - 1];
+};
+template <typename T, int L, int E> struct LineTw<T, L, E, true> {
+    static constexpr int M = fft_nstages(L, E);
+    const cx<T>* g[M > 1 ? M - 1 : 1];      // stage read from the global table: this thread's first entry
+    const cx<T>* l[M > 1 ? M - 1 : 1];      // stage staged through LDS: this thread's first entry there
 };
 // Table layout: the twiddles are stored in the order the threads load them: for stage S >= 1,
 // entry (slot, ku) = W_L^(k u STEP), slot enumerating (butterfly i, factor u >= 1) and ku the thread
@@ -277,6 +294,8 @@ __device__ __forceinline__ void tw_stage_issue(LineTw<T, L, E>& tw, const int j,
     if constexpr (fft_tw_via_lds(L, S, E)) {
         constexpr int LOFF = fft_tw_lds_offset(L, S, E);
         for (int e = tid; e < SLOTS * KU; e += nthreads) ldsT[LOFF + e] = tab[OFF + e];
+    } else if constexpr (tw_lazy<T, E>()) {
+        tw.g[S - 1] = tab + OFF + (j & (KU - 1));
     } else {
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) tw.w[S - 1][sl] = tab[OFF + sl * KU + (j & (KU - 1))];
@@ -288,8 +307,23 @@ __device__ __forceinline__ void tw_stage_fetch(LineTw<T, L, E>& tw, const int j,
         constexpr int SLOTS = fft_tw_slots_of(L, S, E);
         constexpr int KU = fft_tw_ku(L, S, E);
         constexpr int LOFF = fft_tw_lds_offset(L, S, E);
+        if constexpr (tw_lazy<T, E>()) {
+            tw.l[S - 1] = ldsT + LOFF + (j & (KU - 1));
+        } else {
 #pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) tw.w[S - 1][sl] = ldsT[LOFF + sl * KU + (j & (KU - 1))];
+            for (int sl = 0; sl < SLOTS; ++sl) tw.w[S - 1][sl] = ldsT[LOFF + sl * KU + (j & (KU - 1))];
+        }
+    }
+}
+// twiddle `slot` of stage S (S >= 1) of this thread
+template <typename T, int L, int E, int S>
+__device__ __forceinline__ cx<T> tw_get(const LineTw<T, L, E>& tw, const int slot) {
+    if constexpr (tw_lazy<T, E>()) {
+        constexpr int KU = fft_tw_ku(L, S, E);
+        if constexpr (fft_tw_via_lds(L, S, E)) return tw.l[S - 1][slot * KU];
+        else return tw.g[S - 1][slot * KU];
+    } else {
+        return tw.w[S - 1][slot];
     }
 }
 template <typename T, int L, int E>
@@ -338,7 +372,7 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
         for (int i = 0; i < NB; ++i) {
 #pragma unroll
             for (int u = 1; u < R; ++u)
-                v[i + u * NB] = cmuld<DIR>(v[i + u * NB], tw.w[S - 1][i * (R - 1) + (u - 1)]);
+                v[i + u * NB] = cmuld<DIR>(v[i + u * NB], tw_get<T, L, E, S>(tw, i * (R - 1) + (u - 1)));
         }
     }
 #ifdef SSFM_STAMP_FFT
