@@ -247,7 +247,12 @@ __host__ __device__ constexpr int fft_ls(int L, int s, int E) {   // product of 
 #endif
 // (Only with 16 points per thread, i.e. the 2^21 / 2^22 plans: with 8 points per thread the registers suffice and
 // keeping the twiddles is 2 % faster -- C1 46.6 vs 47.6 us per step.)
-template <typename T, int E> __host__ __device__ constexpr bool tw_lazy() { return SSFM_TW_LAZY_C128 != 0 && sizeof(T) == 8 && E == 16; }
+#ifndef SSFM_TW_LAZY_C64
+#define SSFM_TW_LAZY_C64 0      // experiment: frees ~90 registers of k_freq; see DESIGN.md
+#endif
+template <typename T, int E> __host__ __device__ constexpr bool tw_lazy() {
+    return sizeof(T) == 8 ? (SSFM_TW_LAZY_C128 != 0 && E == 16) : SSFM_TW_LAZY_C64 != 0;
+}
 
 template <typename T, int L, int E, bool LAZY = tw_lazy<T, E>()> struct LineTw {
     static constexpr int M = fft_nstages(L, E);
