@@ -683,7 +683,7 @@ template <typename T> struct PlanT : PlanBase {
             hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, (const cx<T>*)F, (long long)n * batch, st);
             ++last_launches;
         }
-        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, st, zlog, 0, single_step);
+        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 0, single_step);
         ++last_launches;
         HIP_TRY(hipGetLastError());
         const size_t fb = sizeof(cx<T>) * n * batch;

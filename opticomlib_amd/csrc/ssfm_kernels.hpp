@@ -711,11 +711,28 @@ template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long
         const T o = __shfl_xor(pmax, off);
         pmax = o > pmax ? o : pmax;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(&st->maxbits, float_bits<T>(pmax));
+    // one atomic per workgroup, spread over the slots (thousands of waves on one address serialise)
+    __shared__ T wave_max[16];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = pmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T m = wave_max[0];
+        for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) m = wave_max[w] > m ? wave_max[w] : m;
+        atomicMax(&st->slot_max[blockIdx.x % kAdaptSlots], float_bits<T>(m));
+    }
 }
 
+// launched with one wavefront: the lanes collect (and clear) k_absmax's slots, lane 0 decides
 template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog, int phase, int single_step) {
     if (phase == 0) {
+        unsigned long long mb = threadIdx.x < (unsigned)kAdaptSlots ? atomicExch(&st->slot_max[threadIdx.x], 0ull) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(mb, o);
+            mb = other > mb ? other : mb;
+        }
+        if (threadIdx.x != 0) return;
+        st->maxbits = mb;
         T h;
         if (single_step) h = st->length;
         else h = st->phi_max / (st->abs_gamma * bits_float<T>(st->maxbits));
@@ -728,7 +745,7 @@ template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog,
         zlog[0] = (T)0;
         return;
     }
-    if (st->done) return;
+    if (threadIdx.x != 0 || st->done) return;
     step_control_update<T>(st, zlog, st->maxbits);
 }
 
