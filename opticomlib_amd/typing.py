@@ -273,6 +273,14 @@ class optical_signal:
         return _is_device(self._raw("signal"))
 
     def __init__(self, signal, noise=NULL, n_pol=None, dtype=None):
+        if _is_device(signal) and (noise is NULL or _is_device(noise)) and dtype is None:      # device arrays: no copy to the host
+            other = optical_signal.from_device(signal, noise, n_pol)
+            self.__dict__.update(other.__dict__)
+            return
+        if _is_device(signal):
+            signal = signal.to_host()
+        if _is_device(noise):
+            noise = noise.to_host()
         if isinstance(signal, optical_signal):
             if noise is NULL and n_pol in (None, signal.n_pol) and dtype is None:      # plain re-wrap: keep device residency
                 self.signal, self.noise, self.n_pol, self.execution_time = signal._raw("signal"), signal._raw("noise"), signal.n_pol, 0.0

@@ -665,6 +665,11 @@ def test_device_resident_signal_semantics():
     want = oa.DM(optical_signal(s.signal, nz.signal), D=50.0)
     np.testing.assert_array_equal(out.signal, want.signal)
     np.testing.assert_array_equal(out.noise, want.noise)
+    fresh = oa.FIBER(optical_signal(a), length=1, h=1.0, **workloads.SMF)
+    direct = optical_signal(fresh._raw("signal"))            # the constructor takes device arrays as they are
+    assert direct.on_device and direct.n_pol == 2
+    mixed = optical_signal(fresh._raw("signal"), 0.1 * a)    # device signal + host noise: an ordinary host signal
+    assert not mixed.on_device and mixed.noise.shape == (2, 1 << 12)
     e = oa.EDFA(s, G=10, NF=5)                               # host-side device (np.random): materialises its input
     assert e.n_pol == 2 and e.signal.shape == (2, 1 << 12)
 
