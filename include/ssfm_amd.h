@@ -160,6 +160,16 @@ int ssfm_device_free(int device, void* ptr, size_t bytes);
 int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind);
 int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
 int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
+/* Device random numbers and the few float64 array operations the receiver front-end needs around them.
+ * ssfm_device_randn: out[i] = mean + std * N(0,1), Philox4x32-10 keyed by `seed`, counter = (pair index, `stream`),
+ * Box-Muller on two 53-bit uniforms per pair -- the documented generator behind PD / EDFA with rng="device" (the
+ * reference draws from NumPy's global generator, devices.py:1521-1527, :930; the default rng="numpy" reproduces
+ * those draws on the host).  sum3: out = (a + b + c + offset) * scale (a, b, c nullable); scale_add: dst = a*factor
+ * (+ b); mean: mean of a (+ b).  All on `n` float64 elements in DEVICE memory, synchronous. */
+int ssfm_device_randn(int device, double* out_dev, int64_t n, uint64_t seed, uint64_t stream, double mean, double std);
+int ssfm_device_sum3(int device, double* out_dev, const double* a, const double* b, const double* c, double offset, double scale, int64_t n);
+int ssfm_device_scale_add(int device, double* dst, const double* a, double factor, const double* b, int64_t n);
+int ssfm_device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out);
 /* Free / total HBM of the device and the bytes held in the library's buffer pool (nullable). */
 int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes);
 

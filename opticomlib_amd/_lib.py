@@ -44,6 +44,10 @@ SYMBOLS = {
     "ssfm_device_copy": (_I, [_I, _VP, _VP, C.c_size_t, _I]),
     "ssfm_device_convert": (_I, [_I, _VP, _I, _VP, _I, _I64]),
     "ssfm_device_add": (_I, [_I, _VP, _VP, _VP, _I, _I64]),
+    "ssfm_device_randn": (_I, [_I, _VP, _I64, C.c_uint64, C.c_uint64, _D, _D]),
+    "ssfm_device_sum3": (_I, [_I, _VP, _VP, _VP, _VP, _D, _D, _I64]),
+    "ssfm_device_scale_add": (_I, [_I, _VP, _VP, _D, _VP, _I64]),
+    "ssfm_device_mean": (_I, [_I, _VP, _VP, _I64, C.POINTER(_D)]),
     "ssfm_device_mem_info": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ssfm_transfer_table": (_I, [_VP, _VP, _I]),
     "ssfm_apply_table": (_I, [_VP, _I]),
@@ -253,6 +257,38 @@ class DeviceArray:
 
     def __repr__(self):
         return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.device})"
+
+
+def randn_device(shape, std: float, seed: int, stream: int, dtype=np.float64, device: int = 0) -> DeviceArray:
+    """``std * N(0, 1)`` from the library's Philox4x32-10 generator (``ssfm_device_randn``).  For a complex dtype
+    real and imaginary parts are independent, each of standard deviation ``std``."""
+    out = DeviceArray(shape, dtype, device)
+    count = out.size * (2 if out.dtype.kind == "c" else 1)
+    _check(load().ssfm_device_randn(out.device, _VP(out.ptr), count, int(seed) & (2 ** 64 - 1), int(stream) & (2 ** 64 - 1), 0.0, float(std)),
+           "ssfm_device_randn")
+    return out
+
+
+def sum3_device(a, b, c, offset: float, scale: float, like: DeviceArray) -> DeviceArray:
+    """``(a + b + c + offset) * scale`` on float64 device arrays (any of a, b, c may be None)."""
+    out = DeviceArray(like.shape, np.float64, like.device)
+    p = lambda x: None if x is None else _VP(x.ptr)
+    _check(load().ssfm_device_sum3(like.device, _VP(out.ptr), p(a), p(b), p(c), float(offset), float(scale), out.size), "ssfm_device_sum3")
+    return out
+
+
+def scale_add_device(a: DeviceArray, factor: float, b=None) -> DeviceArray:
+    """``a * factor (+ b)`` for float64 / complex128 device arrays (real ``factor``)."""
+    out = DeviceArray(a.shape, a.dtype, a.device)
+    count = a.size * (2 if a.dtype.kind == "c" else 1)
+    _check(load().ssfm_device_scale_add(a.device, _VP(out.ptr), _VP(a.ptr), float(factor), None if b is None else _VP(b.ptr), count), "ssfm_device_scale_add")
+    return out
+
+
+def mean_device(a: DeviceArray, b=None) -> float:
+    m = _D()
+    _check(load().ssfm_device_mean(a.device, _VP(a.ptr), None if b is None else _VP(b.ptr), a.size, C.byref(m)), "ssfm_device_mean")
+    return float(m.value)
 
 
 def device_mem_info(device: int = 0):

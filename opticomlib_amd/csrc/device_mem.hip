@@ -139,3 +139,114 @@ extern "C" int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* tota
     }
     return SSFM_OK;
 }
+
+// ------------------------------------------------------------------------------------- device random numbers
+// The reference draws its thermal / shot / ASE noise from NumPy's global generator (devices.py:1521-1527, :930);
+// the host mirror reproduces those draws on the host when asked for seed-for-seed parity.  For Monte-Carlo runs
+// that only need the statistics, this is the documented device generator: Philox4x32-10 (Salmon et al., SC'11)
+// with key = the 64-bit seed and counter = (pair index, stream); one call yields 128 random bits = two 53-bit
+// uniforms u1, u2 in (0, 1) = one Box-Muller pair  sqrt(-2 ln u1) * (cos, sin)(2 pi u2).  Element 2p and 2p+1 of
+// the output come from pair p, so a buffer's content depends only on (seed, stream), not on the launch shape.
+namespace {
+
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_randn(double* __restrict__ out, long long n, unsigned long long seed, unsigned long long stream, double mean, double std) {
+    const long long pairs = (n + 1) / 2;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (long long)gridDim.x * blockDim.x) {
+        unsigned c[4] = {(unsigned)p, (unsigned)((unsigned long long)p >> 32), (unsigned)stream, (unsigned)(stream >> 32)};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        const double u1 = ((double)(((unsigned long long)(c[0] >> 5) << 26) | (c[1] >> 6)) + 0.5) * 0x1p-53;
+        const double u2 = ((double)(((unsigned long long)(c[2] >> 5) << 26) | (c[3] >> 6)) + 0.5) * 0x1p-53;
+        const double r = sqrt(-2.0 * log(u1));
+        double s, co;
+        sincospi(2.0 * u2, &s, &co);
+        out[2 * p] = mean + std * r * co;
+        if (2 * p + 1 < n) out[2 * p + 1] = mean + std * r * s;
+    }
+}
+
+// out = (a + b + c + offset) * scale over `n` doubles; a, b, c nullable (PD's noise current, devices.py:1529-1547)
+__global__ __launch_bounds__(256) void k_sum3(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c,
+                                              double offset, double scale, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        bool any = false;
+        if (a) { v = a[i]; any = true; }
+        if (b) { v = any ? v + b[i] : b[i]; any = true; }
+        if (c) { v = any ? v + c[i] : c[i]; any = true; }
+        out[i] = (any ? v + offset : offset) * scale;
+    }
+}
+
+// dst = a * factor (+ b) over `n` doubles (complex arrays are passed as 2n doubles); b nullable
+__global__ __launch_bounds__(256) void k_scale_add(double* __restrict__ dst, const double* __restrict__ a, double factor, const double* __restrict__ b, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = b ? a[i] * factor + b[i] : a[i] * factor;
+}
+
+__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ a, const double* __restrict__ b, long long n, double* __restrict__ partial) {
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += b ? a[i] + b[i] : a[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+}  // namespace
+
+extern "C" int ssfm_device_randn(int device, double* out_dev, int64_t n, uint64_t seed, uint64_t stream, double mean, double std) {
+    if (!out_dev || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_randn: bad argument");
+    if (int rc = use(device)) return rc;
+    hipLaunchKernelGGL(k_randn, dim3(blocks_for((n + 1) / 2)), dim3(256), 0, 0, out_dev, (long long)n, (unsigned long long)seed, (unsigned long long)stream, mean, std);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_sum3(int device, double* out_dev, const double* a, const double* b, const double* c, double offset, double scale, int64_t n) {
+    if (!out_dev || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_sum3: bad argument");
+    if (int rc = use(device)) return rc;
+    hipLaunchKernelGGL(k_sum3, dim3(blocks_for(n)), dim3(256), 0, 0, out_dev, a, b, c, offset, scale, (long long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_scale_add(int device, double* dst, const double* a, double factor, const double* b, int64_t n) {
+    if (!dst || !a || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_scale_add: bad argument");
+    if (int rc = use(device)) return rc;
+    hipLaunchKernelGGL(k_scale_add, dim3(blocks_for(n)), dim3(256), 0, 0, dst, a, factor, b, (long long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out) {
+    if (!a || !mean_out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_mean: bad argument");
+    if (int rc = use(device)) return rc;
+    constexpr int kBlocks = 1024;
+    double* partial = nullptr;
+    HIP_TRY(hipMalloc(&partial, sizeof(double) * kBlocks));
+    hipLaunchKernelGGL(k_sum, dim3(kBlocks), dim3(256), 0, 0, a, b, (long long)n, partial);
+    double host[kBlocks];
+    hipError_t e = hipMemcpy(host, partial, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(partial);
+    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_mean: %s", hipGetErrorString(e));
+    double acc = 0.0;
+    for (int i = 0; i < kBlocks; ++i) acc += host[i];
+    *mean_out = acc / (double)n;
+    return SSFM_OK;
+}

@@ -625,6 +625,27 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
 # SURVEY.md 8(f) rank 2.  The random currents / fields are drawn on the host from the GLOBAL np.random
 # generator with the reference's calls in the reference's order, so a script that seeds np.random gets the
 # same realisation from either library; the O(N) arithmetic (square law, zero-phase filters) runs on the GPU.
+# rng="device": the library's Philox4x32-10 generator (csrc/device_mem.hip) instead of NumPy's global one -- no
+# seed-for-seed parity with the reference then, only its statistics, but nothing leaves the GPU.  Every draw
+# takes the next stream of the current seed; `device_rng_seed` restarts the sequence (default: OS entropy).
+_DEVICE_RNG = {"seed": int.from_bytes(os.urandom(8), "little"), "stream": 0}
+
+
+def device_rng_seed(seed: int):
+    """Seed the device generator used by ``PD`` / ``EDFA`` with ``rng="device"``."""
+    _DEVICE_RNG["seed"], _DEVICE_RNG["stream"] = int(seed), 0
+
+
+def _device_randn(shape, std, dtype, dev):
+    _DEVICE_RNG["stream"] += 1
+    return _lib.randn_device(shape, std, _DEVICE_RNG["seed"], _DEVICE_RNG["stream"], dtype, dev)
+
+
+def _check_rng(rng):
+    if rng not in ("numpy", "device"):
+        raise ValueError("`rng` must be 'numpy' (the reference's draws, on the host) or 'device'")
+
+
 _PD_MODES = ("ase-only", "thermal-only", "shot-only", "ase-thermal", "ase-shot", "thermal-shot", "all", "none")
 
 
@@ -634,7 +655,7 @@ def _idb(x):
 
 
 def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_load: float = 50.0,
-       include_noise: str = "all", i_dark: float = 10e-9, Fn=0, *, device=None) -> electrical_signal:
+       include_noise: str = "all", i_dark: float = 10e-9, Fn=0, *, device=None, rng: str = "numpy") -> electrical_signal:
     """P-I-N photodetector (reference ``devices.py:1378-1555``): ``v = R_load * (r * |E|^2 + noise)``
     summed over the polarisations, low-pass filtered to ``BW`` [Hz].
 
@@ -642,6 +663,10 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
     (``4 kB T Fn fs/2 / R_load``) and shot (``2 e (mean(i_ph) + i_dark) fs/2``) currents are Gaussian.
     ``include_noise`` selects the terms as in the reference ('all', 'none', 'ase-only', 'thermal-only',
     'shot-only', 'ase-thermal', 'ase-shot', 'thermal-shot'; case-insensitive).
+
+    ``rng`` (extension): ``"numpy"`` draws the Gaussian currents from NumPy's global generator with the
+    reference's calls in the reference's order (seed-for-seed identical output); ``"device"`` uses the library's
+    Philox generator on the GPU (same statistics, the whole detector stays on the device, ~50x faster at 2^20).
     """
     from numbers import Real
     from scipy.constants import e, k as kB
@@ -664,6 +689,7 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
     if not isinstance(include_noise, str):
         raise TypeError("`include_noise` must be a string.")
     mode = include_noise.lower()
+    _check_rng(rng)
     dev = default_device() if device is None else int(device)
     raw_s, raw_n = input._raw("signal"), input._raw("noise")
     has_ase = raw_n is not NULL
@@ -671,6 +697,22 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
         # nothing random to add: detector and filter back to back on the device
         v, _ = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), None, r, post=R_load)
         output = LPF(electrical_signal.from_device(v), BW, fs=grid.fs, device=dev)
+        output.execution_time = time.time() - t0
+        return back(output)
+    if rng == "device" and mode in _PD_MODES and mode != "none":
+        ds, dn = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), _dev_array(raw_n, np.complex128, dev) if has_ase else None, r)
+        d_T = d_N = None
+        if "thermal" in mode or mode == "all":
+            d_T = _device_randn(ds.shape, (4 * kB * T * grid.fs / 2 * _idb(Fn) / R_load) ** 0.5, np.float64, dev)
+        if "shot" in mode or mode == "all":
+            mean = _lib.mean_device(ds, dn if has_ase else None)
+            d_N = _device_randn(ds.shape, (2 * e * (mean + i_dark) * grid.fs / 2) ** 0.5, np.float64, dev)
+        d_ase = dn if (has_ase and ("ase" in mode or mode == "all")) else None
+        if d_ase is None and d_T is None and d_N is None:          # 'ase-only' on a noiseless input: dark current alone
+            d_N = _lib.randn_device(ds.shape, 0.0, 0, 0, np.float64, dev)
+        v_noise = _lib.sum3_device(d_ase, d_N, d_T, i_dark, R_load, ds)
+        v_sig = _lib.sum3_device(ds, None, None, 0.0, R_load, ds)
+        output = LPF(electrical_signal.from_device(v_sig, v_noise), BW, fs=grid.fs, device=dev)
         output.execution_time = time.time() - t0
         return back(output)
     if _on_device(raw_s) or _on_device(raw_n):            # the field is already in HBM: only the currents come back
@@ -712,7 +754,7 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
     return back(output)
 
 
-def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device=None) -> optical_signal:
+def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device=None, rng: str = "numpy") -> optical_signal:
     """Erbium-doped fibre amplifier, simplest model (reference ``devices.py:829-942``): field gain
     ``sqrt(G)``, ASE of power ``NF h f0 (G - 1) fs`` split over two polarisations x two quadratures
     added to ``.noise``, then an optical ``BPF`` of bandwidth ``BW`` if given.  Output is always
@@ -722,7 +764,31 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
     input, grid, back = _adopt(input, "optical_signal")
     if not isinstance(input, optical_signal):
         raise TypeError("`input` must be of type 'optical_signal'.")
+    _check_rng(rng)
     g = np.sqrt(_idb(G))
+    if rng == "device":
+        # gain, ASE loading and the optical filter without leaving the GPU (statistics of the reference, not its draws)
+        dev = default_device() if device is None else int(device)
+        raw_s, raw_n = input._raw("signal"), input._raw("noise")
+        n = input.size
+
+        def two_rows(a):                                  # (N,) -> (2, N) with an empty y polarisation; (2, N) as it is
+            d = _dev_array(a, np.complex128, dev)
+            if d.ndim == 2:
+                return _lib.scale_add_device(d, g)
+            out2 = _lib.randn_device((2, n), 0.0, 0, 0, np.complex128, dev)          # zeros
+            x = _lib.scale_add_device(d, g)
+            _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(out2.ptr), _lib._VP(x.ptr), n * 16, 2), "ssfm_device_copy")
+            return out2
+        sig = two_rows(raw_s)
+        P_ase = _idb(NF) * h * grid.f0 * (_idb(G) - 1) * grid.fs
+        ase = _device_randn((2, n), np.sqrt(P_ase / 4), np.complex128, dev)
+        noi = ase if raw_n is NULL else two_rows(raw_n) + ase
+        output = optical_signal.from_device(sig, noi, n_pol=2)
+        if BW is not None:
+            output = _bpf_on_grid(output, BW, grid, device)
+        output.execution_time = time.time() - t0
+        return back(output)
     output = optical_signal(input.signal, input.noise, n_pol=2)
     sig = output.signal * g
     noi = NULL if output.noise is NULL else output.noise * g

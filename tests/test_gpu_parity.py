@@ -604,6 +604,95 @@ def test_random_parameters_against_oracle(i, k, npol, power, kw):
     assert y.shape == a.shape and y.dtype == np.complex64
 
 
+# ----------------------------------------------------------------------- device random numbers (rng="device")
+def _philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11) in plain Python integers."""
+    c = list(ctr)
+    k0, k1 = key
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[0]
+        p1 = 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c
+
+
+def test_device_generator_known_answers_and_statistics():
+    # Random123's published known-answer vectors for philox4x32_10
+    assert _philox4x32_10((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert _philox4x32_10((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    seed, stream = 0x0123456789ABCDEF, 7
+    x = _lib.randn_device((1001,), 2.0, seed, stream).to_host()
+    for p in (0, 1, 250, 500):                                   # pair p -> elements 2p, 2p+1 (the last pair is cut)
+        c = _philox4x32_10((p, 0, stream, 0), (seed & 0xFFFFFFFF, seed >> 32))
+        u1 = (((c[0] >> 5) << 26 | (c[1] >> 6)) + 0.5) * 2.0 ** -53
+        u2 = (((c[2] >> 5) << 26 | (c[3] >> 6)) + 0.5) * 2.0 ** -53
+        r = np.sqrt(-2 * np.log(u1))
+        assert abs(x[2 * p] - 2.0 * r * np.cos(2 * np.pi * u2)) < 1e-12
+        if 2 * p + 1 < x.size:
+            assert abs(x[2 * p + 1] - 2.0 * r * np.sin(2 * np.pi * u2)) < 1e-12
+    n = 1 << 20
+    a = _lib.randn_device((n,), 1.0, 42, 1).to_host()
+    b = _lib.randn_device((n,), 1.0, 42, 2).to_host()
+    np.testing.assert_array_equal(a, _lib.randn_device((n,), 1.0, 42, 1).to_host())       # reproducible
+    assert abs(a.mean()) < 4e-3 and abs(a.var() - 1) < 6e-3 and abs(np.mean(a ** 4) - 3) < 0.05
+    assert abs(np.mean(a * b)) < 4e-3 and abs(np.mean(a[:-1] * a[1:])) < 4e-3             # streams / neighbours uncorrelated
+    assert abs(np.mean(np.abs(a) > 3) - 0.0027) < 4e-4
+    z = _lib.randn_device((2, 1 << 16), 0.5, 1, 1, np.complex128).to_host()
+    assert z.dtype == np.complex128 and abs(z.real.var() - 0.25) < 0.01 and abs(z.imag.var() - 0.25) < 0.01
+    assert abs(np.mean(z.real * z.imag)) < 0.005
+
+
+def test_pd_and_edfa_with_the_device_generator():
+    """rng="device": the reference's statistics (not its draws), everything stays on the GPU."""
+    from scipy import signal as sg
+    from scipy.constants import e, h, k as kB
+    gv(sps=16, R=10e9)
+    n = 1 << 17
+    x = optical_signal(np.full(n, np.sqrt(1e-3), complex))
+    BW = 0.3 * gv.fs
+    sos = sg.bessel(4, BW, "low", fs=gv.fs, norm="mag", output="sos")
+    _, H = sg.sosfreqz(sos, worN=4096, fs=gv.fs, whole=True)
+    keep = np.mean(np.abs(H) ** 4)
+    oa.device_rng_seed(2024)
+    y = oa.PD(x, BW=BW, include_noise="thermal-only", i_dark=0.0, rng="device")
+    assert isinstance(y._raw("signal"), _lib.DeviceArray) and isinstance(y._raw("noise"), _lib.DeviceArray)
+    S_T = 4 * kB * 300.0 * gv.fs / 2 / 50.0
+    assert abs(np.var(y.noise) / (S_T * 50.0 ** 2 * keep) - 1) < 0.05
+    np.testing.assert_allclose(y.signal[100:-100], 1e-3 * 50.0, rtol=1e-9)
+    y2 = oa.PD(x, BW=BW, include_noise="shot-only", i_dark=0.0, rng="device")
+    assert abs(np.var(y2.noise) / (2 * e * 1e-3 * gv.fs / 2 * 50.0 ** 2 * keep) - 1) < 0.05
+    oa.device_rng_seed(2024)
+    np.testing.assert_array_equal(oa.PD(x, BW=BW, include_noise="thermal-only", i_dark=0.0, rng="device").noise, y.noise)
+    # all terms, noisy dual-pol input: signal part identical to the host-generator path, noise mean = beat + dark terms
+    a = workloads.qpsk_field(1 << 14, seed=3)
+    xin = optical_signal(a, 0.05 * a[::-1].copy())
+    yd = oa.PD(xin, BW=20e9, rng="device")
+    np.random.seed(0)
+    yh = oa.PD(xin, BW=20e9)
+    assert relmax(yd.signal, yh.signal) < 1e-12
+    assert abs(np.mean(yd.noise) - np.mean(yh.noise)) < 0.05 * np.std(yh.noise) and abs(np.std(yd.noise) / np.std(yh.noise) - 1) < 0.05
+    for mode in ("ase-only", "ase-thermal", "ase-shot", "thermal-shot", "ALL"):
+        assert oa.PD(xin, BW=20e9, include_noise=mode, rng="device").noise.shape == (1 << 14,)
+    assert oa.PD(optical_signal(a), BW=20e9, include_noise="ase-only", rng="device").noise.shape == (1 << 14,)
+    with pytest.raises(ValueError, match="`rng` must be"):
+        oa.PD(xin, BW=20e9, rng="cuda")
+    # EDFA: gain, ASE power h f0 NF (G - 1) fs over two polarisations, y polarisation of a 1-pol input empty
+    G, NF = 20.0, 5.0
+    x1 = optical_signal(np.full(n, np.sqrt(1e-4), complex))
+    ed = oa.EDFA(x1, G=G, NF=NF, rng="device")
+    assert ed.on_device and ed.n_pol == 2 and ed.shape == (2, n)
+    np.testing.assert_allclose(ed.signal[0], np.sqrt(1e-4) * 10.0, rtol=1e-14)
+    assert not ed.signal[1].any()
+    P_ase = 10 ** (NF / 10) * h * gv.f0 * (10 ** (G / 10) - 1) * gv.fs
+    assert abs(np.mean(np.abs(ed.noise) ** 2, axis=-1).sum() / P_ase - 1) < 0.02
+    np.random.seed(1)
+    eh = oa.EDFA(xin, G=G, NF=NF, BW=60e9)
+    edv = oa.EDFA(xin, G=G, NF=NF, BW=60e9, rng="device")
+    assert relmax(edv.signal, eh.signal) < 1e-12
+    assert abs(np.mean(np.abs(edv.noise) ** 2) / np.mean(np.abs(eh.noise) ** 2) - 1) < 0.05
+
+
 # ----------------------------------------------------------------------- device-resident signals
 def _chain(x, keep):
     """FIBER -> EDFA-like noise loading -> FIBER -> DBP -> DM -> BPF -> PD, as a link script would write it."""

@@ -58,3 +58,6 @@ def link():
 for keep in (False, True):
     od.KEEP_ON_DEVICE = keep
     t = timeit(link); print(f"FIBER(100) -> DBP(100) -> BPF -> PD, 2^20 x 2, results {'kept on the device' if keep else 'returned to the host after every call'}: {t*1e3:.1f} ms")
+od.KEEP_ON_DEVICE = True
+t = timeit(lambda: PD(xn, BW=20e9, rng="device").signal); print(f"PD('all', rng='device') 2^20 x 2 host-inclusive, voltage read: {t*1e3:.1f} ms")
+t = timeit(lambda: EDFA(xn, G=20, NF=5, BW=100e9, rng="device")); print(f"EDFA(G, NF, BW, rng='device') 2^20 x 2 (result left on the device): {t*1e3:.1f} ms")
