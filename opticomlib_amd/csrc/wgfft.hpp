@@ -250,11 +250,14 @@ __host__ __device__ constexpr int fft_ls(int L, int s, int E) {   // product of 
 #ifndef SSFM_TW_LAZY_C64
 #define SSFM_TW_LAZY_C64 0      // experiment: frees ~90 registers of k_freq; see DESIGN.md
 #endif
-template <typename T, int E> __host__ __device__ constexpr bool tw_lazy() {
-    return sizeof(T) == 8 ? (SSFM_TW_LAZY_C128 != 0 && E == 16) : SSFM_TW_LAZY_C64 != 0;
+#ifndef SSFM_TW_LAZY_C128_ROWS
+#define SSFM_TW_LAZY_C128_ROWS 0      // experiment: also for 8-point-per-thread lines of >= 2048 points (k_freq of C1)
+#endif
+template <typename T, int E, int L = 0> __host__ __device__ constexpr bool tw_lazy() {
+    return sizeof(T) == 8 ? (SSFM_TW_LAZY_C128 != 0 && (E == 16 || (SSFM_TW_LAZY_C128_ROWS != 0 && L >= 2048))) : SSFM_TW_LAZY_C64 != 0;
 }
 
-template <typename T, int L, int E, bool LAZY = tw_lazy<T, E>()> struct LineTw {
+template <typename T, int L, int E, bool LAZY = tw_lazy<T, E, L>()> struct LineTw {
     static constexpr int M = fft_nstages(L, E);
     cx<T> w[M > 1 ? M - 1 : 1][E - 1];
 };
@@ -299,7 +302,7 @@ __device__ __forceinline__ void tw_stage_issue(LineTw<T, L, E>& tw, const int j,
     if constexpr (fft_tw_via_lds(L, S, E)) {
         constexpr int LOFF = fft_tw_lds_offset(L, S, E);
         for (int e = tid; e < SLOTS * KU; e += nthreads) ldsT[LOFF + e] = tab[OFF + e];
-    } else if constexpr (tw_lazy<T, E>()) {
+    } else if constexpr (tw_lazy<T, E, L>()) {
         tw.g[S - 1] = tab + OFF + (j & (KU - 1));
     } else {
 #pragma unroll
@@ -312,7 +315,7 @@ __device__ __forceinline__ void tw_stage_fetch(LineTw<T, L, E>& tw, const int j,
         constexpr int SLOTS = fft_tw_slots_of(L, S, E);
         constexpr int KU = fft_tw_ku(L, S, E);
         constexpr int LOFF = fft_tw_lds_offset(L, S, E);
-        if constexpr (tw_lazy<T, E>()) {
+        if constexpr (tw_lazy<T, E, L>()) {
             tw.l[S - 1] = ldsT + LOFF + (j & (KU - 1));
         } else {
 #pragma unroll
@@ -323,7 +326,7 @@ __device__ __forceinline__ void tw_stage_fetch(LineTw<T, L, E>& tw, const int j,
 // twiddle `slot` of stage S (S >= 1) of this thread
 template <typename T, int L, int E, int S>
 __device__ __forceinline__ cx<T> tw_get(const LineTw<T, L, E>& tw, const int slot) {
-    if constexpr (tw_lazy<T, E>()) {
+    if constexpr (tw_lazy<T, E, L>()) {
         constexpr int KU = fft_tw_ku(L, S, E);
         if constexpr (fft_tw_via_lds(L, S, E)) return tw.l[S - 1][slot * KU];
         else return tw.g[S - 1][slot * KU];
