@@ -142,7 +142,8 @@ template <typename T> struct PlanT : PlanBase {
     // hides launch gaps and lets one group compute while another waits for memory.
     static constexpr int kMaxLanes = 8;
     int nlanes = 1;
-    int E = 16;                // points per thread (env SSFM_E = 8 | 16)
+    int E = 16;                // points per thread of k_time (env SSFM_E = 8 | 16)
+    int Ef = 16;               // ... and of k_freq (env SSFM_EF); the two kernels only share the field layout
     bool stagger = false;      // env SSFM_STAGGER
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
@@ -247,7 +248,7 @@ template <typename T> struct PlanT : PlanBase {
         };
         mix(&gamma, sizeof(T)); mix(&nsteps, sizeof(nsteps)); mix(h, sizeof(T) * (size_t)nsteps);
         for (auto tp : tabptr) mix(&tp, sizeof(tp));
-        mix(&nlanes, sizeof(nlanes)); mix(&E, sizeof(E));
+        mix(&nlanes, sizeof(nlanes)); mix(&E, sizeof(E)); mix(&Ef, sizeof(Ef));
         int idx = -1;
         for (size_t i = 0; i < graphs.size(); ++i) if (graphs[i].key == key) idx = (int)i;
         if (idx < 0) {
@@ -351,7 +352,12 @@ template <typename T> struct PlanT : PlanBase {
         // complex128 is 5 % FASTER with 8 (16 need the whole register file: 1 wave per SIMD, AGPR spills)
         E = sizeof(T) == 8 ? 8 : 16;
         if (const char* e = std::getenv("SSFM_E")) E = std::atoi(e) == 16 ? 16 : 8;
-        if (k > 20) E = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
+        // k_freq: complex128 rows run best with 16 points per thread and load-at-use twiddles (256-thread workgroups,
+        // two per CU; C1 46.8 -> 44.7 us per step), complex64 rows with 16 and register twiddles (8: 22.2 vs 21.4 us)
+        Ef = 16;
+        if (std::getenv("SSFM_E")) Ef = E;
+        if (const char* e = std::getenv("SSFM_EF")) Ef = std::atoi(e) == 16 ? 16 : 8;
+        if (k > 20) E = Ef = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
         if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = (e[0] == 'a' || e[0] == 'A') ? -1 : (std::atoi(e) != 0 ? 1 : 0);
         // two lanes pay off once a launch is long enough to hide the other lane's gap; below ~2^20 points in
@@ -375,8 +381,8 @@ template <typename T> struct PlanT : PlanBase {
         const long long nA = (long long)(N1 / 16) * N2, nB = 16ll * N2;
         HIP_TRY(hipMalloc(&twA, cb * nA));
         HIP_TRY(hipMalloc(&twB, cb * nB));
-        if (int rc = make_line_table(&tw1, N1)) return rc;
-        if (int rc = make_line_table(&tw2, N2)) return rc;
+        if (int rc = make_line_table(&tw1, N1, E)) return rc;
+        if (int rc = make_line_table(&tw2, N2, Ef)) return rc;
         HIP_TRY(hipMalloc(&dnat, cb * n));
         HIP_TRY(hipMalloc(&dperm, cb * n));
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
@@ -391,7 +397,7 @@ template <typename T> struct PlanT : PlanBase {
 
     // stage twiddles of a line of length L in thread-load order (wgfft.hpp "Table layout"), computed
     // in double on the host and rounded once
-    int make_line_table(cx<T>** out, int L) {
+    int make_line_table(cx<T>** out, int L, int E) {
         const int M = fft_nstages(L, E);
         const int total = fft_tw_entries(L, E);
         std::vector<cx<T>> tab((size_t)(total > 0 ? total : 1));
@@ -466,7 +472,7 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = use_device()) return rc;
         HIP_TRY(hipMemcpyAsync(dnat, host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dnat, dperm, N1, N2, N2 / E, (T)0, inv_n());
+                           (const cx<T>*)dnat, dperm, N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         // host buffer may be reused by the caller right after return
         HIP_TRY(hipStreamSynchronize(stream));
@@ -483,7 +489,7 @@ template <typename T> struct PlanT : PlanBase {
         tab_rr = (tab_rr + 1) % kMaxTables;
         if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
         hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dnat, t.ptr, N1, N2, N2 / E, h, inv_n());
+                           (const cx<T>*)dnat, t.ptr, N1, N2, N2 / Ef, h, inv_n());
         HIP_TRY(hipGetLastError());
         t.h = h; t.valid = true;
         *out = t.ptr;
@@ -547,9 +553,9 @@ template <typename T> struct PlanT : PlanBase {
                 const cx<T>* tp = nullptr;
                 for (size_t i = 0; i < distinct.size(); ++i)
                     if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
-                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0, lane_), E);
+                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0, lane_), Ef);
             }
-            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0, lane_), E);
+            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0, lane_), Ef);
         };
         auto freq = [&](T hs) -> hipError_t { return freq_rows(hs, 0, batch, stream); };
         (void)nrows;
@@ -694,7 +700,7 @@ template <typename T> struct PlanT : PlanBase {
         for (;;) {
             for (int i = 0; i < chunk; ++i) {
                 HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
-                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, 0, st), E)));
+                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, 0, st), Ef)));
                 HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
                 last_launches += 3;
             }
@@ -739,11 +745,11 @@ template <typename T> struct PlanT : PlanBase {
         have_op = false;
         for (auto& t : tabs) t.valid = false;
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dnat, hperm, N1, N2, N2 / E, (T)0, inv_n());
+                           (const cx<T>*)dnat, hperm, N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev0, stream));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
-        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), Ef)));
         HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
         HIP_TRY(hipEventRecord(ev1, stream));
         last_launches = 3;
@@ -765,11 +771,11 @@ template <typename T> struct PlanT : PlanBase {
         }
         const double val = 1.0 / ((double)n * dt_s);
         hipLaunchKernelGGL(k_make_dm_table<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           hperm, hnat, N1, N2, N2 / E, val, D_s2, inv_n());
+                           hperm, hnat, N1, N2, N2 / Ef, val, D_s2, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev0, stream));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
-        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), Ef)));
         HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
         HIP_TRY(hipEventRecord(ev1, stream));
         last_launches = 3;
@@ -791,7 +797,7 @@ template <typename T> struct PlanT : PlanBase {
         have_op = false;
         for (auto& t : tabs) t.valid = false;
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dnat, xfer_tab[slot], N1, N2, N2 / E, (T)0, inv_n());
+                           (const cx<T>*)dnat, xfer_tab[slot], N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));                  // H_host may be released by the caller
         return SSFM_OK;
@@ -800,7 +806,7 @@ template <typename T> struct PlanT : PlanBase {
         if (slot < 0 || slot > 1 || !xfer_tab[slot]) return fail(SSFM_ERR_STATE, "ssfm_apply_table: slot %d holds no table", slot);
         if (int rc = use_device()) return rc;
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
-        HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[slot], 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[slot], 0, nullptr), Ef)));
         HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
         last_launches += 3;
         return SSFM_OK;
@@ -811,7 +817,7 @@ template <typename T> struct PlanT : PlanBase {
         const int nrows = N1 * batch;
         if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
-        HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, nrows, stream, fargs(dperm, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, nrows, stream, fargs(dperm, 0, nullptr), Ef)));
         const long long total = (long long)n * batch;
         hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)F, scratch, N1, N2, batch);
