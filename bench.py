@@ -247,7 +247,7 @@ def main():
                     acc = {}
                     for row in csv.DictReader(open(stats)):
                         for k in launch_us:
-                            if k + "<" in row["Name"]:
+                            if k + "<float" in row["Name"]:          # the C2 kernels (the file also holds C1's complex128 ones)
                                 c, tns = acc.get(k, (0, 0.0))
                                 acc[k] = (c + int(row["Calls"]), tns + float(row["TotalDurationNs"]))
                     roofline["rocprof_kernel_us"] = {k: tns / c / 1e3 for k, (c, tns) in acc.items() if c}
