@@ -260,6 +260,10 @@ template <> __device__ __forceinline__ void sincos_acc<double>(double x, double&
 #endif
 // SSFM_NT_LOADS: 1 = read the streamed data (field, |A|^2) with non-temporal loads so that the read-only
 // tables, which the OTHER lane's launch re-reads a few microseconds later, survive in the XCD's L2.
+// SSFM_P_NT: 1 = write the |A|^2 buffer with non-temporal stores (fewer dirty L2 lines at the kernel boundary)
+#ifndef SSFM_P_NT
+#define SSFM_P_NT 0
+#endif
 #ifndef SSFM_NT_LOADS
 #define SSFM_NT_LOADS 0
 #endif
@@ -445,7 +449,11 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
             q.x = pnew[4 * g]; q.y = pnew[4 * g + 1]; q.z = pnew[4 * g + 2]; q.w = pnew[4 * g + 3];
+#if SSFM_P_NT
+            __builtin_nontemporal_store(q, &Pb[g * PSTR]);
+#else
             Pb[g * PSTR] = q;
+#endif
         }
     }
     if (!SSFM_ABL_NO_NL) rotate_all<E>(v, phi);
