@@ -861,3 +861,214 @@ def PRBS(order: int, len: int = None, seed: int = None, return_seed: bool = Fals
     for k in range(order):                                  # state after `len` shifts: bit k = o[len - k]
         last |= int(b[s + len - k]) << k
     return output, last
+
+
+# ----------------------------------------------------------------------------- DAC
+_DAC_SHAPES = ["nrz", "gaussian", "rcos"]
+
+
+def _nrz_pulse(span, sps, T):
+    """reference ``utils.py:1924-1947``"""
+    t = np.linspace(-span / 2, span / 2, span * sps + 1)
+    return np.where((t >= -T / 2) & (t < T / 2), 1.0, 0.0)
+
+
+def _gauss_pulse(span, sps, T=1, m=1, c=0.0):
+    """reference ``utils.py:1880-1922``"""
+    t = np.linspace(-span / 2, span / 2, span * sps + 1)
+    alpha = 2 * np.sqrt(np.log(2)) / T
+    return np.exp(-(alpha * (1 + 1j * c) * t) ** (2 * m))
+
+
+def _rcos_pulse(beta, span, sps, shape="sqrt"):
+    """reference ``utils.py:1791-1878`` (MATLAB ``rcosdesign`` without the energy normalisation)"""
+    if not (0 <= beta <= 1):
+        raise ValueError("beta must be in [0, 1]")
+    if shape not in ("sqrt", "normal"):
+        raise ValueError("shape must be 'sqrt' or 'normal'")
+    t = np.linspace(-span / 2, span / 2, span * sps + 1)
+    if beta == 0:
+        return np.sinc(t)
+    if shape == "normal":
+        den = 1 - (2 * beta * t) ** 2
+        p = np.divide(np.sinc(t) * np.cos(np.pi * beta * t), den, out=np.zeros_like(den), where=den != 0)
+        special = np.abs(den) < 1e-8
+        if np.any(special):
+            p[special] = (np.pi / 4) * np.sinc(1 / (2 * beta))
+        return p
+    t_abs = np.abs(t)
+    p = np.zeros_like(t)
+    zero = t_abs < 1e-8
+    p[zero] = (1 - beta) + 4 * beta / np.pi
+    special = np.abs(t_abs - 1 / (4 * beta)) < 1e-8
+    if np.any(special):
+        p[special] = (beta / np.sqrt(2)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * beta)) + (1 - 2 / np.pi) * np.cos(np.pi / (4 * beta)))
+    general = ~zero & ~special
+    if np.any(general):
+        ti = t[general]
+        p[general] = (np.sin(np.pi * ti * (1 - beta)) + 4 * beta * ti * np.cos(np.pi * ti * (1 + beta))) / (np.pi * ti * (1 - (4 * beta * ti) ** 2))
+    return p
+
+
+def _upfir_device(bits: np.ndarray, h: np.ndarray, up: int, dev: int) -> np.ndarray:
+    """``upfir`` of the reference (``utils.py:1949-1981``): zero-stuffing at offset ``up//2`` and the 'same' part of
+    the linear convolution with ``h`` -- as ONE circular convolution on a power-of-two complex128 plan
+    (``x <- ifft(fft(x) * fft(h))``, three launches); SciPy's ``fftconvolve`` does the same on the host."""
+    n = bits.size * up
+    h = np.asarray(h)
+    full = n + h.size - 1
+    M = 1 << max(8, (full - 1).bit_length())
+    lo, hi = _lib.supported_log2n(_lib.C128)
+    if M > (1 << hi):
+        raise ValueError(f"DAC: {bits.size} bits x {up} samples with a {h.size}-tap pulse exceed the device path (2^{hi} points)")
+    plan = get_plan(M, 1, _lib.C128, dev)
+    plan._op_key = None
+    plan._chirp_n = None                                    # the table slots are taken over
+    buf = np.zeros(M, dtype=np.complex128)
+    buf[:h.size] = h
+    plan.set_field(buf)
+    plan.transfer_table(plan.debug_fft()[0], 0)             # fft(h) stays on the device
+    buf[:] = 0
+    buf[up // 2: n: up] = bits
+    plan.set_field(buf)
+    plan.apply_table(0)
+    y = plan.get_field()[0]
+    start = (h.size - 1) // 2                               # 'same': centred with respect to the full output
+    y = y[start: start + n]
+    return y if np.iscomplexobj(h) else np.ascontiguousarray(y.real)
+
+
+def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0, offset: float = 0.0, h=None, BW: float = None,
+        *, device=None, **kwargs) -> electrical_signal:
+    """Digital-to-analog converter (reference ``devices.py:185-350``): a bit sequence becomes ``gv.sps`` samples
+    per bit of the chosen pulse (``'nrz'`` with ``T``; ``'gaussian'`` with ``T``, ``m``, ``c``; ``'rcos'`` with
+    ``beta``, ``rcos_type``; or an explicit impulse response ``h``), scaled by ``Vpp``, shifted by ``offset``,
+    optionally AC-coupled and band-limited by ``LPF(BW)``.  The pulse spans ``max(4, bits - 4)`` symbols, i.e. the
+    shaping is a convolution as long as the signal: it runs as an FFT convolution on the GPU."""
+    t0 = time.time()
+    seq = binary_sequence(input)
+    bits = seq.size
+    sps = gv.sps
+    data = seq.to_numpy()
+    dev = default_device() if device is None else int(device)
+    span = max(4, bits - 4)
+    if h is not None:
+        pulse = np.asarray(h)
+    elif pulse_shape.lower() not in _DAC_SHAPES:
+        raise ValueError(f"The parameter `pulse_shape` must be one of the following values {_DAC_SHAPES}")
+    elif pulse_shape.lower() == "nrz":
+        T = kwargs.get("T", 1)
+        if not isinstance(T, int):
+            raise TypeError("The parameter `T` must be an integer.")
+        if T <= 0:
+            raise ValueError("The parameter `T` must be greater than 0.")
+        if T > 2 * sps:
+            raise ValueError("The parameter `T` must be less than 2*sps.")
+        pulse = _nrz_pulse(span, sps, T)
+    elif pulse_shape.lower() == "gaussian":
+        c, m, T = kwargs.get("c", 0.0), kwargs.get("m", 1), kwargs.get("T", 1)
+        if not isinstance(c, (int, float)):
+            raise TypeError("The parameter `c` must be a real number.")
+        if not isinstance(m, int):
+            raise TypeError("The parameter `m` must be an integer.")
+        if not isinstance(T, int):
+            raise TypeError("The parameter `T` must be an integer.")
+        if m <= 0:
+            raise ValueError("The parameter `m` must be greater than 0.")
+        if T <= 0:
+            raise ValueError("The parameter `T` must be greater than 0.")
+        if T > 2 * sps:
+            raise ValueError("The parameter `T` must be less than 2*sps.")
+        pulse = _gauss_pulse(span, sps, T=T, m=m, c=c)
+    else:
+        pulse = _rcos_pulse(kwargs.get("beta", 0.25), span, sps, shape=kwargs.get("rcos_type", "normal"))
+    if Vpp is not None:
+        if not isinstance(Vpp, (int, float)):
+            raise TypeError("The parameter `Vpp` must be a scalar value.")
+        if Vpp <= 0 or Vpp > 48:
+            raise ValueError("The parameter `Vpp` must be in the range (0, 48] Volts.")
+    if offset is not None:
+        if not isinstance(offset, (int, float)):
+            raise TypeError("The parameter `offset` must be a scalar value.")
+        if np.abs(offset) > 48:
+            raise ValueError("The parameter `offset` must be in the range [-48, 48] Volts.")
+    if coupling.upper() not in ("AC", "DC"):
+        raise ValueError("The parameter `coupling` must be either 'AC' or 'DC'.")
+    x = _upfir_device(data, pulse, sps, dev)
+    if Vpp is not None:
+        x = x * Vpp
+    if offset is not None:
+        x = x + offset
+    if coupling.upper() == "AC":
+        x = x - np.mean(x)
+    output = electrical_signal(x)
+    if BW is not None:
+        output = LPF(output, BW, device=dev)
+    output.execution_time = time.time() - t0
+    return output
+
+
+# ----------------------------------------------------------------------------- LASER / MZM (SURVEY.md 8(f) rank 4)
+# Elementwise host arithmetic in the reference's own expressions (and its np.random calls, so a seeded script gets the
+# same laser noise); only MZM's optional optical filter is device work.  They complete the transmitter chain
+# PRBS -> DAC -> MZM(LASER) in front of FIBER.
+def LASER(P0: float, lw: float = None, rin: float = None, df: float = None) -> optical_signal:
+    """CW laser of ``P0`` dBm over ``gv.t`` (reference ``devices.py:353-510``): optional linewidth ``lw`` [Hz] (Wiener
+    phase noise), relative intensity noise ``rin`` [dB/Hz] and frequency offset ``df`` [Hz]; single polarisation."""
+    t0 = time.time()
+    t = gv.t
+    out = np.ones_like(t) * np.sqrt(10 ** (P0 / 10 - 3))
+    if lw is not None:
+        phase_noise = np.cumsum(np.random.normal(0, np.sqrt(2 * np.pi * lw * gv.dt), t.size))
+        out = out * np.exp(1j * phase_noise)
+    if rin is not None:
+        rin_noise = np.random.normal(0, np.sqrt(_idb(rin) * gv.fs), t.size)
+        if rin_noise.min() < -1:
+            raise ValueError("Noise power is to high, try decrease RIN parameter.")
+        out = out * np.sqrt(1 + rin_noise)
+    if df is not None:
+        if np.abs(df) > gv.fs / 2:
+            raise ValueError("The laser frequency is out of the Nyquist range. Try increase the sampling frequency.")
+        out = out * np.exp(1j * 2 * np.pi * df * t)
+    output = optical_signal(out)
+    output.execution_time = time.time() - t0
+    return output
+
+
+def MZM(op_input: optical_signal, el_input, bias: float = 0.0, Vpi: float = 5.0, loss_dB: float = 0.0, ER_dB: float = 26.0,
+        pol: str = "x", BW: float = None, *, device=None) -> optical_signal:
+    """Mach-Zehnder modulator (reference ``devices.py:620-786``): ``out = in * sqrt(loss) (cos g + j eta/2 sin g)``,
+    ``g = pi/(2 Vpi) (v + bias)``, ``eta = 2 sqrt(1/ER)``; the drive voltage's own noise enters ``g``, optical
+    signal and optical noise are both multiplied; of a dual-polarisation input only ``pol`` survives; ``BW`` adds
+    a ``BPF``."""
+    t0 = time.time()
+    op_input, grid, back = _adopt(op_input, "optical_signal")
+    if not isinstance(op_input, optical_signal):
+        raise TypeError("`op_input` must be of type 'optical_signal'.")
+    if isinstance(el_input, electrical_signal) or type(el_input).__name__ == "electrical_signal":
+        el_input = _adopt(el_input, "electrical_signal")[0]
+    else:
+        el_input = electrical_signal(el_input)
+    if el_input.ndim > 1:
+        raise ValueError("`el_input` must be a scalar or 1D-array.")
+    if pol not in ["x", "y"]:
+        raise ValueError("The parameter `pol` must be one of the following values ('x', 'y').")
+    loss = _idb(-loss_dB)
+    eta = 2 * _idb(-ER_dB) ** 0.5
+    k = np.pi / 2 / Vpi
+    g_t = k * (el_input.signal + bias)
+    if el_input.noise is not NULL:
+        g_t = g_t + k * el_input.noise
+    h_t = loss ** 0.5 * (np.cos(g_t) + 1j * eta / 2 * np.sin(g_t))
+    sig = op_input.signal * h_t
+    noi = NULL if op_input.noise is NULL else op_input.noise * h_t
+    if op_input.n_pol == 2:
+        dead = 1 if pol == "x" else 0
+        sig[dead] = np.zeros_like(sig[dead])
+        if noi is not NULL:
+            noi[dead] = np.zeros_like(noi[dead])
+    output = optical_signal(sig, noi, n_pol=op_input.n_pol)
+    if BW is not None:
+        output = _bpf_on_grid(output, BW, grid, device)
+    output.execution_time = time.time() - t0
+    return back(output)

@@ -62,9 +62,11 @@ class _GlobalVars:
         self.dt = 1 / self.fs
         self.wavelength = 1550e-9              # reference typing.py:207-209
         self.f0 = _C_LIGHT / self.wavelength
+        self.N = 128                           # number of bit slots (typing.py:211); only LASER reads it, through `t`
+        self.t = np.linspace(0, self.N * self.sps * self.dt, self.N * self.sps, endpoint=True)      # typing.py:213
         return self
 
-    def __call__(self, sps=None, R=None, fs=None, wavelength=1550e-9, **extra):
+    def __call__(self, sps=None, R=None, fs=None, wavelength=1550e-9, N=None, **extra):
         # same precedence as the reference (typing.py:306-335)
         if sps:
             self.sps = int(np.round(sps))
@@ -87,6 +89,8 @@ class _GlobalVars:
             self.fs = fs
             self.sps = int(np.round(fs / self.R))
         self.dt = 1 / self.fs
+        self.N = N if N is not None else self.N
+        self.t = np.linspace(0, self.N * self.sps / self.fs, self.N * self.sps, endpoint=True)      # typing.py:357
         self.wavelength = wavelength           # reset to the default on every call, like the reference (typing.py:340-341)
         self.f0 = _C_LIGHT / wavelength
         for k, v in extra.items():

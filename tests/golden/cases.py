@@ -43,6 +43,8 @@ def make_input(kind: str, seed: int, shape, dtype="complex128", amp=0.03):
 GV_A = dict(sps=16, R=10e9)       # dt = 6.25 ps
 GV_B = dict(sps=16, R=32e9)       # dt = 1.953125 ps (bench grid)
 
+GV_N = dict(sps=16, R=10e9, N=64)   # with a slot count: gv.t has 1024 samples
+
 FIB = dict(alpha=0.2, beta_2=-20.0, beta_3=0.1, gamma=2.0)
 SMF = dict(alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
 
@@ -141,6 +143,24 @@ CASES = {
     "prbs23_seed_wraps": dict(func="PRBS", gv=GV_A, kw=dict(order=23, len=3000, seed=(1 << 23) + 77)),
     "prbs31_seed": dict(func="PRBS", gv=GV_A, kw=dict(order=31, len=4000, seed=0x5EED5EED)),
     "prbs11_short": dict(func="PRBS", gv=GV_A, kw=dict(order=11, len=5, seed=3)),
+    # DAC pulse shaping (reference devices.py:185-350); input bits = PRBS(order, len) of the case, gv.sps from `gv`
+    "dac_nrz_default": dict(func="DAC", gv=GV_A, bits=(7, 100), kw=dict()),
+    "dac_nrz_T2_ac": dict(func="DAC", gv=GV_A, bits=(9, 64), kw=dict(pulse_shape="nrz", T=2, Vpp=2.5, offset=-1.0, coupling="AC")),
+    "dac_gauss": dict(func="DAC", gv=GV_A, bits=(9, 128), kw=dict(pulse_shape="gaussian", Vpp=5.0, offset=-2.5)),
+    "dac_gauss_chirp": dict(func="DAC", gv=GV_A, bits=(11, 77), kw=dict(pulse_shape="gaussian", T=2, c=0.7)),
+    "dac_supergauss_m2": dict(func="DAC", gv=GV_A, bits=(11, 90), kw=dict(pulse_shape="gaussian", m=2, Vpp=3.0)),
+    "dac_rcos_normal": dict(func="DAC", gv=GV_A, bits=(15, 200), kw=dict(pulse_shape="rcos", beta=0.25)),
+    "dac_rcos_sqrt_bw": dict(func="DAC", gv=GV_A, bits=(15, 150), kw=dict(pulse_shape="rcos", beta=0.5, rcos_type="sqrt", BW=8e9)),
+    "dac_custom_h": dict(func="DAC", gv=GV_A, bits=(7, 50), kw=dict(h=[0.25, 0.5, 1.0, 0.5, 0.25])),
+    "dac_short": dict(func="DAC", gv=GV_A, bits=(7, 3), kw=dict(pulse_shape="gaussian")),
+    # LASER (devices.py:353-510) and MZM (:620-786); `el` / `el_noise` = seeded drive voltage (and its noise)
+    "laser_cw": dict(func="LASER", gv=GV_N, kw=dict(P0=10)),
+    "laser_lw_rin_df": dict(func="LASER", gv=GV_N, np_seed=31, kw=dict(P0=5, lw=1e6, rin=-140, df=1e9)),
+    "mzm_2pol_noise": dict(func="MZM", gv=GV_N, inp=("noise", 70, (2, 1024), "complex128", 0.03), noise=("noise", 71, (2, 1024), "complex128", 0.003),
+                           el=(72, 2.0), el_noise=(73, 0.1), kw=dict(bias=-2.5, Vpi=5.0, loss_dB=3, ER_dB=26)),
+    "mzm_1pol_scalar_y": dict(func="MZM", gv=GV_N, inp=("qpsk", 74, (1024,), "complex128", 0.03), el=2.0, kw=dict(pol="y", Vpi=4.0)),
+    "mzm_2pol_y_bw": dict(func="MZM", gv=GV_N, inp=("qpsk", 75, (2, 1024), "complex128", 0.03), el=(76, 1.5),
+                          kw=dict(bias=1.0, loss_dB=2, ER_dB=40, pol="y", BW=40e9)),
     # float64 twin loop (reference devices.py:2425-2486), 1 polarisation only
     "twin_f64_1pol": dict(func="TWIN", gv=GV_A, inp=("noise", 30, (4096,), "complex128", 0.03),
                           kw=dict(length=10, h=1.0, **FIB)),
@@ -162,3 +182,16 @@ def case_input(case):
     if case.get("noise"):
         noi = make_input(*case["noise"][:4], amp=case["noise"][4])
     return sig, noi
+
+
+def case_drive(case):
+    """Drive voltage of an MZM case: ``(signal, noise | None)``; a scalar drive is returned as it is."""
+    el = case["el"]
+    if not isinstance(el, tuple):
+        return el, None
+    n = case["inp"][2][-1]
+    v = np.random.default_rng(el[0]).standard_normal(n) * el[1]
+    vn = None
+    if case.get("el_noise"):
+        vn = np.random.default_rng(case["el_noise"][0]).standard_normal(n) * case["el_noise"][1]
+    return v, vn

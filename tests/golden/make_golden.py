@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 
 import numpy as np  # noqa: E402
 
-from cases import CASES, case_input  # noqa: E402
+from cases import CASES, case_drive, case_input  # noqa: E402
 
 
 def import_reference(path):
@@ -44,6 +44,29 @@ def run_case(name, case, devices, typing):
     if func == "PRBS":
         seq, last = devices.PRBS(return_seed=True, **kw)
         return {"out": np.asarray(seq.data, dtype=np.uint8), "seed_out": np.array(last, dtype=np.int64)}
+    if func == "DAC":
+        seq = devices.PRBS(order=case["bits"][0], len=case["bits"][1])
+        kw2 = dict(kw)
+        if "h" in kw2:
+            kw2["h"] = np.asarray(kw2["h"], dtype=float)
+        y = devices.DAC(seq, **kw2)
+        assert y.noise is typing.NULL
+        return {"out": y.signal, "bits": np.asarray(seq.data, dtype=np.uint8)}
+    if func == "LASER":
+        if "np_seed" in case:
+            np.random.seed(case["np_seed"])
+        y = devices.LASER(**kw)
+        assert y.noise is typing.NULL
+        return {"out": y.signal}
+    if func == "MZM":
+        v, vn = case_drive(case)
+        el = v if vn is None else typing.electrical_signal(v, vn)
+        x = typing.optical_signal(sig) if noi is None else typing.optical_signal(sig, noi)
+        y = devices.MZM(x, el, **kw)
+        out = {"out": y.signal}
+        if y.noise is not typing.NULL:
+            out["out_noise"] = y.noise
+        return out
     if func == "LPF":
         x = None
     elif noi is None:

@@ -693,6 +693,80 @@ def test_pd_and_edfa_with_the_device_generator():
     assert abs(np.mean(np.abs(edv.noise) ** 2) / np.mean(np.abs(eh.noise) ** 2) - 1) < 0.05
 
 
+# ----------------------------------------------------------------------- DAC
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] == "DAC"])
+def test_dac_golden(golden_dir, name):
+    from opticomlib_amd.typing import electrical_signal
+    case = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    gv(**case["gv"])
+    seq = oa.PRBS(order=case["bits"][0], len=case["bits"][1])
+    np.testing.assert_array_equal(seq.data, g["bits"])
+    kw = dict(case["kw"])
+    if "h" in kw:
+        kw["h"] = np.asarray(kw["h"], dtype=float)
+    y = oa.DAC(seq, **kw)
+    assert isinstance(y, electrical_signal) and y.noise is NULL and y.execution_time > 0
+    assert y.signal.shape == g["out"].shape and y.signal.dtype == g["out"].dtype
+    assert relmax(y.signal, g["out"]) < 1e-12
+
+
+def test_dac_inputs_errors_and_long_sequence():
+    from oracle import transmitter_numpy as tx
+    gv(sps=16, R=10e9)
+    want = oa.DAC([0, 1, 0, 1, 1], Vpp=2.0).signal
+    for form in ("01011", "0 1 0 1 1", (0, 1, 0, 1, 1), np.array([0, 1, 0, 1, 1], bool), oa.binary_sequence([0, 1, 0, 1, 1])):
+        np.testing.assert_array_equal(oa.DAC(form, Vpp=2.0).signal, want)
+    with pytest.raises(ValueError, match="pulse_shape"):
+        oa.DAC("010", pulse_shape="triangle")
+    with pytest.raises(ValueError, match="Vpp"):
+        oa.DAC("010", Vpp=50)
+    with pytest.raises(ValueError, match="offset"):
+        oa.DAC("010", offset=50)
+    with pytest.raises(ValueError, match="greater than 0"):
+        oa.DAC("010", pulse_shape="gaussian", T=0)
+    with pytest.raises(ValueError, match="less than 2\\*sps"):
+        oa.DAC("010", pulse_shape="gaussian", T=3 * 16)
+    with pytest.raises(ValueError, match="`m` must be greater than 0"):
+        oa.DAC("010", pulse_shape="gaussian", T=8, m=0)
+    with pytest.raises(ValueError, match="coupling"):
+        oa.DAC("010", coupling="XX")
+    bits = oa.PRBS(15, len=1 << 15).data                          # 2^19 samples: a convolution of 2^20 points
+    y = oa.DAC(bits, pulse_shape="gaussian", Vpp=5.0, offset=-2.5).signal
+    assert relmax(y, tx.dac(bits, 16, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5)) < 1e-12
+
+
+def test_mzm_with_filter_and_the_transmitter_chain(golden_dir):
+    """MZM(BW=...) against the reference vector, then PRBS -> DAC -> MZM(LASER) -> FIBER -> PD as the reference's
+    example script chains them (examples/ook_transmission_fiber_simulation.py), checked against the oracles."""
+    from cases import case_drive
+    from oracle import transmitter_numpy as tx, frontend_numpy as fe
+    case = CASES["mzm_2pol_y_bw"]
+    g = np.load(os.path.join(golden_dir, "mzm_2pol_y_bw.npz"))
+    gv(**case["gv"])
+    sig, _ = case_input(case)
+    v, _ = case_drive(case)
+    y = oa.MZM(optical_signal(sig), v, **case["kw"])
+    assert relmax(y.signal, g["out"]) < TOL_FILT and not y.signal[0].any()
+    gv(sps=64, R=10e9, N=1 << 10)
+    seq = oa.PRBS(order=9, len=gv.N)
+    drive = oa.DAC(seq, Vpp=5.0, offset=-2.5, pulse_shape="gaussian")
+    mod = oa.MZM(oa.LASER(P0=5), drive, bias=-2.5, Vpi=5.0, loss_dB=3, ER_dB=26)
+    bits = seq.data
+    want_v = tx.dac(bits, 64, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5)
+    want_m, _ = tx.mzm(tx.laser(gv.t, gv.dt, gv.fs, 5), None, want_v, None, gv.fs, bias=-2.5, Vpi=5.0, loss_dB=3, ER_dB=26)
+    assert mod.signal.shape == (1 << 16,) and relmax(mod.signal, want_m) < 1e-12
+    kw = dict(length=50, alpha=0.2, beta_2=-20, gamma=2)
+    out = oa.FIBER(mod, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        ref = orc.fiber_c64(want_m, gv.dt, **kw)
+    assert relmax(out.signal, ref) < TOL_100
+    rx = oa.PD(out, BW=gv.R * 0.75, include_noise="none")
+    want_rx, _ = fe.pd(ref, None, gv.fs, gv.R * 0.75, include_noise="none")
+    assert relmax(rx.signal, want_rx) < 1e-4                            # |E|^2 of fields that agree to 2e-5
+
+
 # ----------------------------------------------------------------------- device-resident signals
 def _chain(x, keep):
     """FIBER -> EDFA-like noise loading -> FIBER -> DBP -> DM -> BPF -> PD, as a link script would write it."""

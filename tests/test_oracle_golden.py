@@ -8,7 +8,7 @@ import warnings
 import numpy as np
 import pytest
 
-from cases import CASES, case_dt, case_input
+from cases import CASES, case_drive, case_dt, case_input
 from oracle import ssfm_numpy as orc
 
 
@@ -211,3 +211,45 @@ def test_tidied_cpu_variant_is_bit_identical():
     a = (rng.standard_normal((2, 2048)) + 1j * rng.standard_normal((2, 2048))) * 0.03
     kw = dict(length=3.3, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3, h=0.5)
     np.testing.assert_array_equal(orc.fiber_c64_tidy(a, 1.953125e-12, **kw), orc.fiber_c64(a, 1.953125e-12, **kw))
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] == "DAC"])
+def test_dac_oracle_matches_reference(golden_dir, name):
+    """DAC: restated pulses + upfir (oracle/transmitter_numpy.py) vs outputs of the imported reference."""
+    from oracle import prbs_numpy as po, transmitter_numpy as tx
+    case = CASES[name]
+    g = _load(golden_dir, name)
+    bits, _ = po.prbs(*case["bits"])
+    np.testing.assert_array_equal(bits, g["bits"])
+    kw = dict(case["kw"])
+    if "h" in kw:
+        kw["h"] = np.asarray(kw["h"], dtype=float)
+    out = tx.dac(bits, case["gv"]["sps"], case["gv"]["sps"] * case["gv"]["R"], **kw)
+    assert out.shape == g["out"].shape and out.dtype == g["out"].dtype
+    _check(out, g["out"], _same_numpy(g), 1e-13)
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["func"] in ("LASER", "MZM")])
+def test_laser_mzm_oracle_matches_reference(golden_dir, name):
+    from cases import case_drive
+    from oracle import transmitter_numpy as tx
+    case = CASES[name]
+    g = _load(golden_dir, name)
+    exact = _same_numpy(g)
+    gvk = case["gv"]
+    fs = gvk["sps"] * gvk["R"]
+    if case["func"] == "LASER":
+        if "np_seed" in case:
+            np.random.seed(case["np_seed"])
+        out = tx.laser(tx.time_vector(gvk["N"], gvk["sps"], fs), 1 / fs, fs, **case["kw"])
+        assert out.dtype == g["out"].dtype
+        _check(out, g["out"], exact, 1e-13)
+        return
+    sig, noi = case_input(case)
+    v, vn = case_drive(case)
+    out, out_n = tx.mzm(sig, noi, v, vn, fs, **case["kw"])
+    _check(out, g["out"], exact, 1e-13)
+    if "out_noise" in g:
+        _check(out_n, g["out_noise"], exact, 1e-13)
+    else:
+        assert out_n is None
