@@ -185,6 +185,13 @@ int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, si
  * `plan_n` / `batch` are the plan's own length and batch; all asynchronous on the plan's stream. */
 int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot);
 int ssfm_apply_table(ssfm_plan* plan, int slot);
+/* Pulse shaping of the reference's DAC (upfir, utils.py:1949-1981) on a complex128 plan of batch 1: ssfm_load_padded
+ * writes `n_src` float64 (src_complex = 0) or complex128 (1) samples from DEVICE memory into the field, zero-padded;
+ * ssfm_table_from_field makes slot <- fft(field) (the field is consumed); ssfm_load_symbols writes `nsym` float64
+ * amplitudes (DEVICE; the bits as 0.0 / 1.0) zero-stuffed to `up` samples per symbol with the sample at up / 2; ssfm_apply_table then convolves.  Asynchronous. */
+int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src);
+int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const double* sym_dev, int64_t nsym, int up);
+int ssfm_table_from_field(ssfm_plan* plan, int slot);
 int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh);
 int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode);
 int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh,

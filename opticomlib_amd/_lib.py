@@ -51,6 +51,9 @@ SYMBOLS = {
     "ssfm_device_mem_info": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ssfm_transfer_table": (_I, [_VP, _VP, _I]),
     "ssfm_apply_table": (_I, [_VP, _I]),
+    "ssfm_load_padded": (_I, [_VP, _I64, _VP, _I, _I64]),
+    "ssfm_load_symbols": (_I, [_VP, _I64, _VP, _I64, _I]),
+    "ssfm_table_from_field": (_I, [_VP, _I]),
     "ssfm_chirp_pre": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D]),
     "ssfm_chirp_mid": (_I, [_VP, _I64, _I, _VP, _I64, _D, _I]),
     "ssfm_chirp_post": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D, _VP]),
@@ -418,6 +421,17 @@ class Plan:
 
     def apply_table(self, slot: int):
         _check(load().ssfm_apply_table(self._h, int(slot)), "ssfm_apply_table")
+
+    def load_padded(self, src: "DeviceArray"):
+        """field <- the float64 / complex128 device array ``src``, zero-padded to the plan length (batch 1)."""
+        _check(load().ssfm_load_padded(self._h, self.n, _VP(src.ptr), int(src.dtype.kind == "c"), src.size), "ssfm_load_padded")
+
+    def load_symbols(self, sym: "DeviceArray", up: int):
+        """field <- the float64 amplitudes ``sym`` zero-stuffed to ``up`` samples per symbol (sample at ``up // 2``)."""
+        _check(load().ssfm_load_symbols(self._h, self.n, _VP(sym.ptr), sym.size, int(up)), "ssfm_load_symbols")
+
+    def table_from_field(self, slot: int):
+        _check(load().ssfm_table_from_field(self._h, int(slot)), "ssfm_table_from_field")
 
     def chirp_pre(self, A: "DeviceArray", P, chirp: "DeviceArray", gamma: float, hh: float):
         _check(load().ssfm_chirp_pre(self._h, self.n, self.batch, _VP(A.ptr), None if P is None else _VP(P.ptr), _VP(chirp.ptr), A.shape[-1],

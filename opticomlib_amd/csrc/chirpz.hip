@@ -144,3 +144,46 @@ extern "C" int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void*
     HIP_TRY(hipGetLastError());
     return SSFM_OK;
 }
+
+// --------------------------------------------------------------------------------- pulse shaping (DAC)
+// The reference's upfir (utils.py:1949-1981): bits zero-stuffed to `up` samples per bit (sample at up/2), linear
+// convolution with the pulse h, 'same' part.  On the plan: ssfm_load_padded writes h (zero-padded) into the field,
+// ssfm_table_from_field turns the field into its transfer function fft(h) (slot), ssfm_load_symbols writes the
+// zero-stuffed symbol amplitudes (the bits as 0.0 / 1.0), ssfm_apply_table convolves; the caller copies the 'same' window out of the field buffer.
+namespace {
+
+__global__ __launch_bounds__(256) void k_load_padded(const double* __restrict__ src, int src_complex, long long n_src, double2* __restrict__ F, long long M) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+        double2 v = make_double2(0.0, 0.0);
+        if (i < n_src) v = src_complex ? make_double2(src[2 * i], src[2 * i + 1]) : make_double2(src[i], 0.0);
+        F[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_load_symbols(const double* __restrict__ sym, long long nsym, int up, double2* __restrict__ F, long long M) {
+    const int at = up / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / up;
+        F[i] = make_double2((b < nsym && i - b * up == at) ? sym[b] : 0.0, 0.0);
+    }
+}
+
+}  // namespace
+
+extern "C" int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src) {
+    Target t;
+    if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
+    if (!src_dev || n_src < 1 || n_src > plan_n) return fail(SSFM_ERR_INVALID, "ssfm_load_padded: %lld source samples for a plan of %lld", (long long)n_src, (long long)plan_n);
+    hipLaunchKernelGGL(k_load_padded, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double*)src_dev, src_complex, (long long)n_src, t.F, t.M);
+    HIP_TRY(hipGetLastError());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const double* sym_dev, int64_t nsym, int up) {
+    Target t;
+    if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
+    if (!sym_dev || nsym < 1 || up < 1 || nsym * up > plan_n) return fail(SSFM_ERR_INVALID, "ssfm_load_symbols: %lld symbols x %d samples for a plan of %lld", (long long)nsym, up, (long long)plan_n);
+    hipLaunchKernelGGL(k_load_symbols, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, sym_dev, (long long)nsym, up, t.F, t.M);
+    HIP_TRY(hipGetLastError());
+    return SSFM_OK;
+}

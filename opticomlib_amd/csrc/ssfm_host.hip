@@ -802,6 +802,24 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipStreamSynchronize(stream));                  // H_host may be released by the caller
         return SSFM_OK;
     }
+    // slot <- fft(field): the field itself becomes a resident transfer function (row 0; the field is consumed)
+    int table_from_field(int slot) {
+        if (slot < 0 || slot > 1) return fail(SSFM_ERR_INVALID, "ssfm_table_from_field: slot %d", slot);
+        if (int rc = use_device()) return rc;
+        if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
+        if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
+        have_op = false;
+        for (auto& t : tabs) t.valid = false;
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, N1 * batch, stream, fargs(dperm, 0, nullptr), Ef)));
+        const long long total = (long long)n * batch;
+        hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)F, scratch, N1, N2, batch);
+        hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const cx<T>*)scratch, xfer_tab[slot], N1, N2, N2 / Ef, (T)0, inv_n());
+        HIP_TRY(hipGetLastError());
+        last_launches += 4;
+        return SSFM_OK;
+    }
     int apply_table(int slot) {
         if (slot < 0 || slot > 1 || !xfer_tab[slot]) return fail(SSFM_ERR_STATE, "ssfm_apply_table: slot %d holds no table", slot);
         if (int rc = use_device()) return rc;
@@ -984,6 +1002,7 @@ int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot) {
     WITH_PLAN(plan, P_->transfer_table(H_host, slot));
 }
 int ssfm_apply_table(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->apply_table(slot)); }
+int ssfm_table_from_field(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->table_from_field(slot)); }
 int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }
 
 void* ssfm_stream(ssfm_plan* plan) {

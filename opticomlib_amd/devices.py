@@ -924,17 +924,15 @@ def _upfir_device(bits: np.ndarray, h: np.ndarray, up: int, dev: int) -> np.ndar
     plan = get_plan(M, 1, _lib.C128, dev)
     plan._op_key = None
     plan._chirp_n = None                                    # the table slots are taken over
-    buf = np.zeros(M, dtype=np.complex128)
-    buf[:h.size] = h
-    plan.set_field(buf)
-    plan.transfer_table(plan.debug_fft()[0], 0)             # fft(h) stays on the device
-    buf[:] = 0
-    buf[up // 2: n: up] = bits
-    plan.set_field(buf)
+    hd = _lib.DeviceArray.from_host(np.ascontiguousarray(h, dtype=np.complex128 if np.iscomplexobj(h) else np.float64), None, dev)
+    plan.load_padded(hd)                                    # field <- h, zero-padded
+    plan.table_from_field(0)                                # slot 0 <- fft(h)
+    bd = _lib.DeviceArray.from_host(np.ascontiguousarray(bits, dtype=np.float64), np.float64, dev)
+    plan.load_symbols(bd, up)                               # field <- zero-stuffed bits
     plan.apply_table(0)
-    y = plan.get_field()[0]
-    start = (h.size - 1) // 2                               # 'same': centred with respect to the full output
-    y = y[start: start + n]
+    out = _lib.DeviceArray((n,), np.complex128, dev)
+    plan.copy_from_field(((h.size - 1) // 2) * 16, out.ptr, n * 16)          # 'same': centred with respect to the full output
+    y = out.to_host()
     return y if np.iscomplexobj(h) else np.ascontiguousarray(y.real)
 
 
