@@ -974,6 +974,19 @@ def test_progress_bar_path_agrees():
     assert relmax(y1, y0) < 1e-5
 
 
+def test_progress_bar_on_every_engine(capsys):
+    """show_progress with fixed and adaptive steps, power-of-two and other lengths: same results as without."""
+    gv(**workloads.BENCH_GV)
+    for n in (1 << 12, 3000):
+        a = workloads.qpsk_field(1 << 12, seed=8, power_w=5e-3)[:, :n]
+        for kw in (dict(length=5, h=0.5, **workloads.SMF), dict(length=5, phi_max=0.02, **workloads.SMF)):
+            y0 = oa.FIBER(optical_signal(a), **kw).signal
+            y1 = oa.FIBER(optical_signal(a), show_progress=True, **kw).signal
+            assert relmax(y1, y0) < 1e-5
+            z, A_z = oa.FIBER(optical_signal(a), show_progress=True, return_steps=True, **kw)
+            assert relmax(A_z[-1], y0) < 1e-5 and len(z) == A_z.shape[0]
+
+
 def test_zero_and_negative_length_return_the_cast_input():
     """reference: the loop `while z < length` never runs (devices.py:1172) and the input comes back as complex64."""
     gv(sps=16, R=10e9)
