@@ -346,6 +346,19 @@ def test_full_size_properties_1000_steps():
     assert relmax(y, y128) < TOL_1000
 
 
+def test_full_size_c2_against_the_strided_fixture(golden_dir):
+    """Configuration C2 itself (2^20 x 2, complex64, 1000 steps) against the committed full-size fixture: every 257th
+    sample, the per-polarisation power and the total energy of the oracle's run (tests/golden/make_c2_strided.py)."""
+    g = np.load(os.path.join(golden_dir, "c2_full_strided.npz"))
+    y = oa.FIBER(optical_signal(_bench_field()), length=125, h=0.125, **workloads.SMF).signal
+    assert y.shape == (2, 1 << 20) and y.dtype == np.complex64
+    peak = np.max(np.abs(g["samples"]))
+    assert np.max(np.abs(y[:, ::257] - g["samples"])) / peak < TOL_1000
+    y2 = np.abs(y.astype(np.complex128)) ** 2
+    np.testing.assert_allclose(np.mean(y2, axis=-1), g["power"], rtol=1e-4)
+    np.testing.assert_allclose(np.sum(y2), float(g["energy"]), rtol=1e-4)
+
+
 def test_full_size_c128_100_steps_roundtrip_structure():
     """C1 (2^20 x 2, complex128, 100 x 1 km): FIBER then DBP returns the input up to the known
     stale-N^ asymmetry, and linear-only propagation is exactly invertible."""
