@@ -25,3 +25,10 @@ out = orc.fiber_c64(a, dt, length=125, h=0.125, **workloads.SMF)
 print(f"oracle C2: {time.time() - t:.0f} s")
 np.savez(os.path.join(HERE, "c2_full_strided.npz"), samples=out[:, ::257], power=np.mean(np.abs(out.astype(np.complex128)) ** 2, axis=-1),
          energy=np.sum(np.abs(out.astype(np.complex128)) ** 2), _versions=np.array([np.__version__]))
+
+# configuration C1 (the same field, complex128, 100 x 1 km) from the float64 restatement
+t = time.time()
+out1 = orc.fiber_c128(a, dt, length=100, h=1.0, **workloads.SMF)
+print(f"oracle C1: {time.time() - t:.0f} s")
+np.savez(os.path.join(HERE, "c1_full_strided.npz"), samples=out1[:, ::257], power=np.mean(np.abs(out1) ** 2, axis=-1), energy=np.sum(np.abs(out1) ** 2),
+         _versions=np.array([np.__version__]))

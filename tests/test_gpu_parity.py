@@ -359,6 +359,16 @@ def test_full_size_c2_against_the_strided_fixture(golden_dir):
     np.testing.assert_allclose(np.sum(y2), float(g["energy"]), rtol=1e-4)
 
 
+def test_full_size_c1_against_the_strided_fixture(golden_dir):
+    """Configuration C1 (2^20 x 2, complex128, 100 x 1 km) against the float64 restatement's full-size run."""
+    g = np.load(os.path.join(golden_dir, "c1_full_strided.npz"))
+    y = oa.FIBER(optical_signal(_bench_field()), length=100, h=1.0, precision="complex128", **workloads.SMF).signal
+    assert y.shape == (2, 1 << 20) and y.dtype == np.complex128
+    assert np.max(np.abs(y[:, ::257] - g["samples"])) / np.max(np.abs(g["samples"])) < TOL_C128
+    np.testing.assert_allclose(np.mean(np.abs(y) ** 2, axis=-1), g["power"], rtol=1e-11)
+    np.testing.assert_allclose(np.sum(np.abs(y) ** 2), float(g["energy"]), rtol=1e-11)
+
+
 def test_full_size_c128_100_steps_roundtrip_structure():
     """C1 (2^20 x 2, complex128, 100 x 1 km): FIBER then DBP returns the input up to the known
     stale-N^ asymmetry, and linear-only propagation is exactly invertible."""
