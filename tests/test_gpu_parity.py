@@ -369,6 +369,24 @@ def test_full_size_c1_against_the_strided_fixture(golden_dir):
     np.testing.assert_allclose(np.sum(np.abs(y) ** 2), float(g["energy"]), rtol=1e-11)
 
 
+def test_full_size_c3_batch_and_c4_chain():
+    """C3 at full size: 4 WDM channels of 2^20 x 2 batched in one plan are bit-identical to 4 separate FIBER calls.
+    C4 at full size: FIBER then DBP of a PRBS realisation on the device against the oracle's chain (4 + 4 steps)."""
+    from opticomlib_amd import dist as od
+    gv(**workloads.BENCH_GV)
+    n = 1 << 20
+    fields = np.stack([workloads.qpsk_field(n, seed=3000 + c) for c in range(4)]).astype(np.complex64)
+    kw = dict(length=5, h=0.125, **workloads.SMF)                       # 40 of C2's steps
+    outs = od.propagate_channels(fields, gv.dt, **kw)
+    for c in (0, 3):
+        np.testing.assert_array_equal(outs[c], oa.FIBER(optical_signal(fields[c]), **kw).signal)
+    a = workloads.prbs_field(n, seed=7, power_w=1e-3)
+    kw4 = dict(length=4, h=1.0, **workloads.SMF)
+    got = od.propagate_channels(np.stack([a, a]), gv.dt, dbp=True, **kw4)[1]
+    ref = orc.dbp_c64(orc.fiber_c64(a, gv.dt, **kw4), gv.dt, **kw4)
+    assert relmax(got, ref) < TOL_100
+
+
 def test_full_size_c128_100_steps_roundtrip_structure():
     """C1 (2^20 x 2, complex128, 100 x 1 km): FIBER then DBP returns the input up to the known
     stale-N^ asymmetry, and linear-only propagation is exactly invertible."""
