@@ -229,15 +229,6 @@ class DeviceArray:
         _check(load().ssfm_device_copy(self.device, _VP(d.ptr), _VP(self.ptr), self.nbytes, 2), "ssfm_device_copy")
         return d
 
-    def reshape(self, *shape) -> "DeviceArray":
-        """The same buffer under another shape is not supported (one owner per buffer): returns a copy."""
-        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
-        d = self.copy()
-        if int(np.prod(shape)) != self.size:
-            raise ValueError(f"cannot reshape {self.shape} to {shape}")
-        d.shape = tuple(int(x) for x in shape)
-        return d
-
     def astype(self, dtype) -> "DeviceArray":
         """complex64 <-> complex128 on the device (a copy when the type already matches)."""
         dtype = np.dtype(dtype)
