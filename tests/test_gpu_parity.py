@@ -946,6 +946,19 @@ def test_repeated_calls_do_not_leak_device_memory():
     assert free0 - free1 < 256 * 2 ** 20, (free0, free1, pooled0, pooled1)
 
 
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/c_abi_demo.c: the shared library used from C with nothing but include/ssfm_amd.h."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.join(root, "opticomlib_amd")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"), "-o", exe,
+                    "-L" + libdir, "-l:_ssfm_amd.so", "-lm", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ABI version 1" in r.stdout and "back-propagated" in r.stdout
+
+
 # ----------------------------------------------------------------------- API behaviour on the device
 def test_call_order_and_argument_errors():
     p = _lib.Plan(4096, 2, _lib.C64)
