@@ -367,9 +367,66 @@ class optical_signal:
         w = np.fft.fftfreq(self.size, gv.dt) * 2 * np.pi
         return np.fft.fftshift(w, axes=-1) if shift else w
 
-    def power(self):
-        """Mean power per polarisation [W] of ``signal + noise``."""
-        return np.mean(np.abs(self.to_numpy()) ** 2, axis=-1)
+    # -- the little signal algebra a link script uses around the devices (reference typing.py:1308-1344, :1599-1608,
+    #    :1663-1720); host arithmetic on materialised arrays
+    def abs(self, of: str = "all") -> np.ndarray:
+        """``|signal|``, ``|noise|`` (zeros without noise) or ``|signal + noise|``."""
+        of = of.lower()
+        if of == "signal":
+            return np.abs(self.signal)
+        if of == "noise":
+            return np.zeros_like(np.real(self.signal)) if self.noise is NULL else np.abs(self.noise)
+        if of == "all":
+            return np.abs(self.to_numpy())
+        raise ValueError('`of` must be one of the following values ("signal", "noise", "all")')
+
+    def power(self, unit: str = "W", of: str = "all"):
+        """Mean power per polarisation of the signal, the noise or both, in W or dBm."""
+        p = np.mean(self.abs(of) ** 2, axis=-1)
+        unit = unit.lower()
+        if unit == "w":
+            return p
+        if unit == "dbm":
+            return 10 * np.log10(p) + 30
+        raise ValueError('`unit` must be one of the following values ("W", "dBm")')
+
+    def phase(self) -> np.ndarray:
+        return np.unwrap(np.angle(self.to_numpy()))
+
+    def conj(self):
+        return optical_signal(np.conj(self.signal), NULL if self.noise is NULL else np.conj(self.noise), n_pol=self.n_pol)
+
+    def _other(self, other):
+        return (other.signal, other.noise) if isinstance(other, (optical_signal, electrical_signal)) else (np.asarray(other), NULL)
+
+    def __add__(self, other):
+        s, n = self._other(other)
+        return optical_signal(self.signal + s, self.noise + n, n_pol=self.n_pol)
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return optical_signal(-self.signal, NULL if self.noise is NULL else -self.noise, n_pol=self.n_pol)
+
+    def __sub__(self, other):
+        s, n = self._other(other)
+        return optical_signal(self.signal - s, self.noise - n if n is not NULL else self.noise, n_pol=self.n_pol)
+
+    def __mul__(self, other):
+        """``(s1 + n1)(s2 + n2)``: the signal is ``s1 s2``, everything that contains a noise factor is noise."""
+        s, n = self._other(other)
+        sig = self.signal * s
+        noi = NULL
+        for term in ((self.signal * n) if n is not NULL else NULL, (self.noise * s) if self.noise is not NULL else NULL,
+                     (self.noise * n) if (self.noise is not NULL and n is not NULL) else NULL):
+            noi = noi + term
+        return optical_signal(sig, noi, n_pol=self.n_pol)
+
+    __rmul__ = __mul__
+
+    def __getitem__(self, key):
+        return optical_signal(self.signal[..., key] if self.n_pol == 2 else self.signal[key],
+                              NULL if self.noise is NULL else (self.noise[..., key] if self.n_pol == 2 else self.noise[key]), n_pol=self.n_pol)
 
     def __repr__(self):
         where = " [device]" if self.on_device else ""

@@ -326,3 +326,28 @@ def test_laser_and_mzm_against_golden(golden_dir):
         oa.MZM(optical_signal(np.ones(8, complex)), 1.0, pol="z")
     with pytest.raises(ValueError, match="Nyquist"):
         oa.LASER(P0=0, df=1e12)
+
+
+def test_optical_signal_algebra():
+    """The few operators a link script uses around the devices (reference typing.py:1308-1344, 1663-1720)."""
+    from opticomlib_amd.typing import NULL, optical_signal
+    rng = np.random.default_rng(0)
+    s1, n1 = rng.standard_normal((2, 32)) + 0j, 0.1 * rng.standard_normal((2, 32)) + 0j
+    x = optical_signal(s1, n1)
+    y = optical_signal(2 * s1)
+    p = x * y
+    np.testing.assert_array_equal(p.signal, s1 * (2 * s1))
+    np.testing.assert_array_equal(p.noise, n1 * (2 * s1))
+    q = x * x.conj()
+    np.testing.assert_array_equal(q.noise, s1 * n1.conj() + n1 * s1.conj() + n1 * n1.conj())
+    assert (y * 3.0).noise is NULL and np.array_equal((3.0 * y).signal, 6 * s1)
+    np.testing.assert_array_equal((x + y).signal, 3 * s1)
+    np.testing.assert_array_equal((x + y).noise, n1)
+    np.testing.assert_array_equal((x - y).signal, -s1)
+    np.testing.assert_array_equal((-x).noise, -n1)
+    np.testing.assert_allclose(x.power(), np.mean(np.abs(s1 + n1) ** 2, axis=-1))
+    np.testing.assert_allclose(x.power("dBm", "signal"), 10 * np.log10(np.mean(np.abs(s1) ** 2, axis=-1)) + 30)
+    assert not y.abs("noise").any() and x.abs("noise").shape == (2, 32)
+    assert x[4:10].signal.shape == (2, 6) and optical_signal(s1[0])[::2].size == 16
+    with pytest.raises(ValueError):
+        x.power("mW")
