@@ -21,20 +21,25 @@ length = float(sys.argv[2]) if len(sys.argv) > 2 else 50.0
 Vpi = 5.0
 gv(sps=64, R=10e9, N=bits)
 
-t0 = time.perf_counter()
-tx = PRBS(order=15, len=bits)
-drive = DAC(tx, Vpp=Vpi, offset=-Vpi / 2, pulse_shape="gaussian")
-field = MZM(LASER(P0=5), drive, bias=-Vpi / 2, Vpi=Vpi, loss_dB=3, ER_dB=26)
-t1 = time.perf_counter()
-out = FIBER(field, length=length, alpha=0.2, beta_2=-20, gamma=2)          # adaptive step, phi_max = 0.01
-rx = PD(out, BW=0.75 * gv.R, r=1.0, include_noise="all")
-v = rx.signal + rx.noise                                                    # the only download
-t2 = time.perf_counter()
+def link():
+    t0 = time.perf_counter()
+    tx = PRBS(order=15, len=bits)
+    drive = DAC(tx, Vpp=Vpi, offset=-Vpi / 2, pulse_shape="gaussian")
+    field = MZM(LASER(P0=5), drive, bias=-Vpi / 2, Vpi=Vpi, loss_dB=3, ER_dB=26)
+    t1 = time.perf_counter()
+    out = FIBER(field, length=length, alpha=0.2, beta_2=-20, gamma=2)          # adaptive step, phi_max = 0.01
+    rx = PD(out, BW=0.75 * gv.R, r=1.0, include_noise="all")
+    v = rx.signal + rx.noise                                                    # the only download
+    return tx, out, v, t1 - t0, time.perf_counter() - t1
+
+
+link()                                  # first call: plans, tables and code objects are created
+tx, out, v, t_tx, t_rx = link()
 
 # decisions at the bit centres against the mid-level threshold
 samples = v[gv.sps // 2::gv.sps]
 threshold = 0.5 * (samples[tx.data == 1].mean() + samples[tx.data == 0].mean())
 errors = int(np.count_nonzero((samples > threshold) != (tx.data == 1)))
 power_dbm = 10 * np.log10(np.mean(np.abs(out.signal) ** 2) / 1e-3)
-print(f"{bits} bits, {bits * gv.sps} samples, {length:g} km: transmitter {1e3 * (t1 - t0):.1f} ms, fibre + detector {1e3 * (t2 - t1):.1f} ms")
+print(f"{bits} bits, {bits * gv.sps} samples, {length:g} km: transmitter {1e3 * t_tx:.1f} ms, fibre + detector {1e3 * t_rx:.1f} ms (second call)")
 print(f"received power {power_dbm:.2f} dBm, threshold {threshold * 1e3:.2f} mV, {errors} errors in {bits} bits")
