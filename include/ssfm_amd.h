@@ -170,6 +170,16 @@ int ssfm_device_randn(int device, double* out_dev, int64_t n, uint64_t seed, uin
 int ssfm_device_sum3(int device, double* out_dev, const double* a, const double* b, const double* c, double offset, double scale, int64_t n);
 int ssfm_device_scale_add(int device, double* dst, const double* a, double factor, const double* b, int64_t n);
 int ssfm_device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out);
+/* Elementwise transmitter work on DEVICE arrays (csrc/transmitter.hip), synchronous:
+ * ssfm_mzm: the Mach-Zehnder transfer of devices.py:762-778 -- g = k (drive + bias) [+ k drive_noise], h = sqrt_loss (cos g +
+ *   j half_eta sin g), out = in * h for signal and (nullable) noise, n_pol x n complex128; polarisation `dead_pol` of a
+ *   dual-polarisation input is emptied; the drive is n float64 (drive_complex = 0) or complex128 (1);
+ * ssfm_device_axpb: dst = src * alpha + beta on n float64 (is_complex = 0) or complex128 (1; beta to the real part);
+ * ssfm_device_real: dst (float64) = real part of src (complex128). */
+int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, const void* in_noise, int n_pol, int64_t n, const void* drive,
+             const void* drive_noise, int drive_complex, double k, double bias, double sqrt_loss, double half_eta, int dead_pol);
+int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, double beta, int64_t n, int is_complex);
+int ssfm_device_real(int device, double* dst, const void* src, int64_t n);
 /* Free / total HBM of the device and the bytes held in the library's buffer pool (nullable). */
 int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes);
 

@@ -48,6 +48,9 @@ SYMBOLS = {
     "ssfm_device_sum3": (_I, [_I, _VP, _VP, _VP, _VP, _D, _D, _I64]),
     "ssfm_device_scale_add": (_I, [_I, _VP, _VP, _D, _VP, _I64]),
     "ssfm_device_mean": (_I, [_I, _VP, _VP, _I64, C.POINTER(_D)]),
+    "ssfm_mzm": (_I, [_I, _VP, _VP, _VP, _VP, _I, _I64, _VP, _VP, _I, _D, _D, _D, _D, _I]),
+    "ssfm_device_axpb": (_I, [_I, _VP, _VP, _D, _D, _I64, _I]),
+    "ssfm_device_real": (_I, [_I, _VP, _VP, _I64]),
     "ssfm_device_mem_info": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ssfm_transfer_table": (_I, [_VP, _VP, _I]),
     "ssfm_apply_table": (_I, [_VP, _I]),
@@ -283,6 +286,31 @@ def mean_device(a: DeviceArray, b=None) -> float:
     m = _D()
     _check(load().ssfm_device_mean(a.device, _VP(a.ptr), None if b is None else _VP(b.ptr), a.size, C.byref(m)), "ssfm_device_mean")
     return float(m.value)
+
+
+def axpb_device(a: DeviceArray, alpha: float, beta: float) -> DeviceArray:
+    """``a * alpha + beta`` (float64 or complex128 device array; ``beta`` real)."""
+    out = DeviceArray(a.shape, a.dtype, a.device)
+    _check(load().ssfm_device_axpb(a.device, _VP(out.ptr), _VP(a.ptr), float(alpha), float(beta), a.size, int(a.dtype.kind == "c")), "ssfm_device_axpb")
+    return out
+
+
+def real_device(a: DeviceArray) -> DeviceArray:
+    out = DeviceArray(a.shape, np.float64, a.device)
+    _check(load().ssfm_device_real(a.device, _VP(out.ptr), _VP(a.ptr), a.size), "ssfm_device_real")
+    return out
+
+
+def mzm_device(sig: DeviceArray, noise, drive: DeviceArray, drive_noise, k, bias, sqrt_loss, half_eta, dead_pol: int):
+    """Mach-Zehnder transfer on device arrays (complex128 field(s), float64 or complex128 drive)."""
+    n = sig.shape[-1]
+    n_pol = 1 if sig.ndim == 1 else sig.shape[0]
+    out_s = DeviceArray(sig.shape, np.complex128, sig.device)
+    out_n = None if noise is None else DeviceArray(sig.shape, np.complex128, sig.device)
+    p = lambda x: None if x is None else _VP(x.ptr)
+    _check(load().ssfm_mzm(sig.device, _VP(out_s.ptr), p(out_n), _VP(sig.ptr), p(noise), n_pol, n, _VP(drive.ptr), p(drive_noise),
+                           int(drive.dtype.kind == "c"), float(k), float(bias), float(sqrt_loss), float(half_eta), int(dead_pol)), "ssfm_mzm")
+    return out_s, out_n
 
 
 def device_mem_info(device: int = 0):

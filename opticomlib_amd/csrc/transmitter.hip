@@ -1,0 +1,103 @@
+// transmitter.hip -- the elementwise device work of the transmitter chain, so that PRBS -> DAC -> MZM(LASER) -> FIBER
+// stays in GPU memory: the Mach-Zehnder transfer (reference devices.py:762-767)
+//     g = pi/(2 Vpi) (v + bias) [+ pi/(2 Vpi) v_noise],   h = sqrt(loss) (cos g + j eta/2 sin g),   out = in * h
+// for the optical signal and the optical noise alike, with the unused polarisation emptied (:771-778), and the two
+// array operations DAC needs after its convolution (devices.py:319-336): a x + b, and the real part of a complex array.
+#include <hip/hip_runtime.h>
+
+#include "ssfm_amd.h"
+#include "ssfm_common.hpp"
+
+using ssfm::fail;
+
+namespace {
+
+int use_dev(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(SSFM_ERR_NO_DEVICE, "device %d not available", device);
+    HIP_TRY(hipSetDevice(device));
+    return SSFM_OK;
+}
+unsigned blocks_of(long long n) { return (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+// drive: float64 (drive_complex = 0) or complex128 (1: a chirped / Gaussian DAC output); noise of the drive likewise
+__global__ __launch_bounds__(256) void k_mzm(double2* __restrict__ out_s, double2* __restrict__ out_n, const double2* __restrict__ in_s, const double2* __restrict__ in_n,
+                                             int n_pol, long long n, const double* __restrict__ v, const double* __restrict__ vn, int drive_complex, double k,
+                                             double bias, double sqrt_loss, double half_eta, int dead_pol) {
+#pragma clang fp contract(off)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double gr, gi = 0.0;
+        if (drive_complex) {
+            gr = k * (v[2 * i] + bias);
+            gi = k * v[2 * i + 1];
+            if (vn) { gr += k * vn[2 * i]; gi += k * vn[2 * i + 1]; }
+        } else {
+            gr = k * (v[i] + bias);
+            if (vn) gr += k * vn[i];
+        }
+        double s, c;
+        sincos(gr, &s, &c);
+        double cr = c, ci = 0.0, sr = s, si = 0.0;              // cos g, sin g (complex for a complex drive)
+        if (drive_complex && gi != 0.0) {
+            const double ch = cosh(gi), sh = sinh(gi);
+            cr = c * ch; ci = -s * sh;
+            sr = s * ch; si = c * sh;
+        }
+        // h = sqrt_loss * (cos g + j half_eta sin g)
+        const double hr = sqrt_loss * (cr - half_eta * si), hi = sqrt_loss * (ci + half_eta * sr);
+        for (int p = 0; p < n_pol; ++p) {
+            const long long o = (long long)p * n + i;
+            const bool dead = n_pol == 2 && p == dead_pol;
+            const double2 a = in_s[o];
+            out_s[o] = dead ? make_double2(0.0, 0.0) : make_double2(a.x * hr - a.y * hi, a.x * hi + a.y * hr);
+            if (in_n) {
+                const double2 b = in_n[o];
+                out_n[o] = dead ? make_double2(0.0, 0.0) : make_double2(b.x * hr - b.y * hi, b.x * hi + b.y * hr);
+            }
+        }
+    }
+}
+
+// dst = src * alpha + beta; complex: both parts scaled, beta added to the real part
+__global__ __launch_bounds__(256) void k_axpb(double* __restrict__ dst, const double* __restrict__ src, double alpha, double beta, long long n, int is_complex) {
+#pragma clang fp contract(off)
+    const long long total = is_complex ? 2 * n : n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (is_complex && (i & 1)) ? src[i] * alpha : src[i] * alpha + beta;
+}
+
+__global__ __launch_bounds__(256) void k_real(double* __restrict__ dst, const double2* __restrict__ src, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i].x;
+}
+
+}  // namespace
+
+extern "C" int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, const void* in_noise, int n_pol, int64_t n, const void* drive,
+                        const void* drive_noise, int drive_complex, double k, double bias, double sqrt_loss, double half_eta, int dead_pol) {
+    if (!out_sig || !in_sig || !drive || n < 1 || n_pol < 1 || n_pol > 2) return fail(SSFM_ERR_INVALID, "ssfm_mzm: bad argument");
+    if ((in_noise == nullptr) != (out_noise == nullptr)) return fail(SSFM_ERR_INVALID, "ssfm_mzm: in_noise and out_noise must be given together");
+    if (int rc = use_dev(device)) return rc;
+    hipLaunchKernelGGL(k_mzm, dim3(blocks_of(n)), dim3(256), 0, 0, (double2*)out_sig, (double2*)out_noise, (const double2*)in_sig, (const double2*)in_noise, n_pol,
+                       (long long)n, (const double*)drive, (const double*)drive_noise, drive_complex, k, bias, sqrt_loss, half_eta, dead_pol);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, double beta, int64_t n, int is_complex) {
+    if (!dst || !src || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_axpb: bad argument");
+    if (int rc = use_dev(device)) return rc;
+    hipLaunchKernelGGL(k_axpb, dim3(blocks_of(n)), dim3(256), 0, 0, (double*)dst, (const double*)src, alpha, beta, (long long)n, is_complex);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_real(int device, double* dst, const void* src, int64_t n) {
+    if (!dst || !src || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_real: bad argument");
+    if (int rc = use_dev(device)) return rc;
+    hipLaunchKernelGGL(k_real, dim3(blocks_of(n)), dim3(256), 0, 0, dst, (const double2*)src, (long long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}

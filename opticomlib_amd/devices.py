@@ -910,7 +910,7 @@ def _rcos_pulse(beta, span, sps, shape="sqrt"):
     return p
 
 
-def _upfir_device(bits: np.ndarray, h: np.ndarray, up: int, dev: int) -> np.ndarray:
+def _upfir_device(bits: np.ndarray, h: np.ndarray, up: int, dev: int) -> "_lib.DeviceArray":
     """``upfir`` of the reference (``utils.py:1949-1981``): zero-stuffing at offset ``up//2`` and the 'same' part of
     the linear convolution with ``h`` -- as ONE circular convolution on a power-of-two complex128 plan
     (``x <- ifft(fft(x) * fft(h))``, three launches); SciPy's ``fftconvolve`` does the same on the host."""
@@ -932,8 +932,7 @@ def _upfir_device(bits: np.ndarray, h: np.ndarray, up: int, dev: int) -> np.ndar
     plan.apply_table(0)
     out = _lib.DeviceArray((n,), np.complex128, dev)
     plan.copy_from_field(((h.size - 1) // 2) * 16, out.ptr, n * 16)          # 'same': centred with respect to the full output
-    y = out.to_host()
-    return y if np.iscomplexobj(h) else np.ascontiguousarray(y.real)
+    return out if np.iscomplexobj(h) else _lib.real_device(out)
 
 
 def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0, offset: float = 0.0, h=None, BW: float = None,
@@ -992,14 +991,18 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
             raise ValueError("The parameter `offset` must be in the range [-48, 48] Volts.")
     if coupling.upper() not in ("AC", "DC"):
         raise ValueError("The parameter `coupling` must be either 'AC' or 'DC'.")
-    x = _upfir_device(data, pulse, sps, dev)
+    x = _upfir_device(data, pulse, sps, dev)                # stays on the device: float64, or complex128 for a complex pulse
     if Vpp is not None:
-        x = x * Vpp
+        x = _lib.axpb_device(x, Vpp, 0.0)
     if offset is not None:
-        x = x + offset
+        x = _lib.axpb_device(x, 1.0, offset)
     if coupling.upper() == "AC":
-        x = x - np.mean(x)
-    output = electrical_signal(x)
+        if x.dtype.kind == "c":
+            xh = x.to_host()
+            x = _lib.DeviceArray.from_host(xh - np.mean(xh), np.complex128, dev)
+        else:
+            x = _lib.axpb_device(x, 1.0, -_lib.mean_device(x))
+    output = _wrap_out(electrical_signal, x, NULL)
     if BW is not None:
         output = LPF(output, BW, device=dev)
     output.execution_time = time.time() - t0
@@ -1054,6 +1057,22 @@ def MZM(op_input: optical_signal, el_input, bias: float = 0.0, Vpi: float = 5.0,
     loss = _idb(-loss_dB)
     eta = 2 * _idb(-ER_dB) ** 0.5
     k = np.pi / 2 / Vpi
+    raw_s, raw_n = op_input._raw("signal"), op_input._raw("noise")
+    raw_v, raw_vn = el_input._raw("signal"), el_input._raw("noise")
+    same_kind = raw_vn is NULL or raw_vn.dtype.kind == raw_v.dtype.kind
+    if KEEP_ON_DEVICE and (_on_device(raw_s) or _on_device(raw_v)) and tuple(raw_v.shape)[-1:] == tuple(raw_s.shape)[-1:] and same_kind \
+            and raw_v.dtype.kind in "fc":
+        # the modulator between a device-resident drive (DAC) or carrier and the fibre: elementwise on the GPU
+        dev = default_device() if device is None else int(device)
+        vdt = np.complex128 if raw_v.dtype.kind == "c" else np.float64
+        out_s, out_n = _lib.mzm_device(_dev_array(raw_s, np.complex128, dev), None if raw_n is NULL else _dev_array(raw_n, np.complex128, dev),
+                                       _dev_array(raw_v, vdt, dev), None if raw_vn is NULL else _dev_array(raw_vn, vdt, dev),
+                                       k, bias, loss ** 0.5, eta / 2, 1 if pol == "x" else 0)
+        output = optical_signal.from_device(out_s, NULL if out_n is None else out_n, n_pol=op_input.n_pol)
+        if BW is not None:
+            output = _bpf_on_grid(output, BW, grid, device)
+        output.execution_time = time.time() - t0
+        return back(output)
     g_t = k * (el_input.signal + bias)
     if el_input.noise is not NULL:
         g_t = g_t + k * el_input.noise

@@ -752,6 +752,36 @@ def test_dac_golden(golden_dir, name):
     assert relmax(y.signal, g["out"]) < 1e-12
 
 
+def test_transmitter_stays_on_the_device():
+    """DAC hands its result over in GPU memory, MZM multiplies it onto the carrier there: same numbers as the host
+    arithmetic (to the last bits of cos / sin), nothing downloaded before the fibre output is read."""
+    from opticomlib_amd import devices as od
+    gv(sps=16, R=10e9, N=256)
+    bits = oa.PRBS(9, len=256)
+    before = dict(_lib.TRANSFERS)
+    drive = oa.DAC(bits, Vpp=5.0, offset=-2.5, pulse_shape="gaussian")
+    drive_r = oa.DAC(bits, Vpp=2.0, pulse_shape="nrz", coupling="AC")
+    assert isinstance(drive._raw("signal"), _lib.DeviceArray) and drive._raw("signal").dtype == np.complex128
+    assert isinstance(drive_r._raw("signal"), _lib.DeviceArray) and drive_r._raw("signal").dtype == np.float64
+    cw = oa.LASER(P0=3)
+    rng = np.random.default_rng(2)
+    carrier2 = optical_signal(np.stack([cw.signal, 0.5 * cw.signal]).astype(complex), 1e-3 * (rng.standard_normal((2, cw.size)) + 0j))
+    m1 = oa.MZM(cw, drive, bias=-2.5, Vpi=5.0, loss_dB=3)
+    m2 = oa.MZM(carrier2, drive_r, bias=0.3, Vpi=4.0, ER_dB=30, pol="y")
+    y = oa.FIBER(m1, length=10, h=1.0, **workloads.SMF)
+    assert m1.on_device and m2.on_device and y.on_device
+    assert _lib.TRANSFERS["d2h"] == before["d2h"]
+    old = od.KEEP_ON_DEVICE
+    od.KEEP_ON_DEVICE = False
+    try:
+        h1 = oa.MZM(cw, drive.signal, bias=-2.5, Vpi=5.0, loss_dB=3)
+        h2 = oa.MZM(carrier2, drive_r.signal, bias=0.3, Vpi=4.0, ER_dB=30, pol="y")
+    finally:
+        od.KEEP_ON_DEVICE = old
+    assert relmax(m1.signal, h1.signal) < 1e-14
+    assert relmax(m2.signal, h2.signal) < 1e-14 and relmax(m2.noise, h2.noise) < 1e-14 and not m2.signal[0].any()
+
+
 def test_dac_inputs_errors_and_long_sequence():
     from oracle import transmitter_numpy as tx
     gv(sps=16, R=10e9)
