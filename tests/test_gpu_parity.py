@@ -602,6 +602,29 @@ def test_adaptive_large_grid_against_oracle():
         assert relmax(oa.FIBER(optical_signal(a), **kw).signal, Ar[-1]) < TOL_100
 
 
+def test_arbitrary_step_schedule_through_the_abi():
+    """ssfm_propagate_fixed takes ANY float32 schedule: few distinct sizes use one operator table each, many distinct
+    sizes evaluate exp(D~ h) in the kernel -- both against the oracle's single steps."""
+    gv(**workloads.BENCH_GV)
+    n = 1 << 13
+    a = workloads.qpsk_field(n, seed=77, power_w=3e-3)
+    D = orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13)
+    rng = np.random.default_rng(5)
+    for hs in (np.array([0.5, 0.25, 0.5, 0.25, 1.0, 0.5], np.float32), rng.uniform(0.05, 0.6, 14).astype(np.float32)):
+        p = _lib.Plan(n, 2, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            p.set_field(a)
+            p.propagate_fixed(1.3, hs)
+            got = p.get_field()
+        finally:
+            p.close()
+        A = a.astype(np.complex64)
+        for h_ in hs:
+            A = orc.ssfm_step_c64(A, D, np.float32(1.3), h_)
+        assert relmax(got, A) < TOL_100
+
+
 # ----------------------------------------------------------------------- randomised parameters
 def _fuzz_cases(count=24):
     rng = np.random.default_rng(2025)
