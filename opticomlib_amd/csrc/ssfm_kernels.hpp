@@ -493,7 +493,10 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
                 const unsigned long long old = atomicMax(&a.st->slot_max[slot], float_bits<T>(m));
                 const unsigned dep0 = (unsigned)(old >> 63);                         // always 0: |A|^2 >= 0
                 int last = 0;
-                if (atomicAdd(&a.st->slot_ticket[slot], 1u + dep0) == in_slot - 1) {
+                if (in_slot == 1) {
+                    // small grids (<= 64 workgroups): the slot is this workgroup's own, two atomics fewer in the chain
+                    last = atomicAdd(&a.st->ticket, 1u + dep0) == nslots - 1;
+                } else if (atomicAdd(&a.st->slot_ticket[slot], 1u + dep0) == in_slot - 1) {
                     const unsigned dep1 = atomicExch(&a.st->slot_ticket[slot], 0u) >> 31;    // reset for the next step; always 0
                     last = atomicAdd(&a.st->ticket, 1u + dep1) == nslots - 1;
                 }
