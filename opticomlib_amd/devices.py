@@ -544,6 +544,17 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
 
 
 # ------------------------------------------------------------------ LPF / BPF
+def _warn_narrow(cutoff_hz, fs, what):
+    """The time-parallel scan behind the zero-phase filters propagates filter states over thousands of samples with
+    powers of the state matrix; for a cutoff far below the sampling rate those powers are ill-conditioned and the
+    result drifts away from SciPy's sample-by-sample recursion: about 5e-20 (fs / cutoff)^3 relative -- 6e-14 at
+    cutoff = fs / 100, 1e-11 at fs / 500, 5e-8 at fs / 10000 (tests/diag/filter_conditioning.py)."""
+    if cutoff_hz < 2e-3 * fs:
+        import warnings
+        warnings.warn(f"{what}: cutoff {cutoff_hz:.3g} Hz is below fs/500 ({fs / 500:.3g} Hz); the device filter then differs from "
+                      f"scipy.signal.sosfiltfilt by about {5e-20 * (fs / cutoff_hz) ** 3:.1e} (relative)", RuntimeWarning, stacklevel=3)
+
+
 def _bessel_sos(n, cutoff_hz, fs):
     """Filter DESIGN (O(order) host work, identical call to the reference's): Bessel low-pass as
     second-order sections, magnitude-normalised, plus the steady-state initial conditions."""
@@ -566,6 +577,7 @@ def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, d
     if not fs:
         fs = grid.fs
     sos, zi = _bessel_sos(n, BW, fs)
+    _warn_narrow(BW, fs, "LPF")
     dev = default_device() if device is None else int(device)
     # real coefficients: Re(filter(x)) == filter(Re(x)), so only the real channel is computed
     # (signal and noise go to the device as they lie: no stacked host copy)
@@ -607,6 +619,7 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
     if not isinstance(input, optical_signal):
         raise TypeError("`input` must be of type (optical_signal).")
     sos, zi = _bessel_sos(n, BW / 2, grid.fs)
+    _warn_narrow(BW / 2, grid.fs, "BPF")
     dev = default_device() if device is None else int(device)
     has_noise = input._raw("noise") is not NULL
     res = []

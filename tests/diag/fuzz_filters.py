@@ -1,0 +1,55 @@
+"""One-off stress of the zero-phase filters and DM against SciPy / the oracle: random orders, cutoffs from 1e-5 to
+0.49 of the sampling rate, lengths across chunk / group boundaries, real and complex, batches."""
+import os, sys
+import numpy as np
+from scipy import signal as sg
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import opticomlib_amd as oa
+from opticomlib_amd import _lib
+from opticomlib_amd.typing import gv, optical_signal
+from oracle import ssfm_numpy as orc
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
+worst = []
+for i in range(250):
+    order = int(rng.integers(1, 9))
+    wn = float(10 ** rng.uniform(-5, np.log10(0.49))) * 2          # scipy's Wn is relative to Nyquist
+    wn = min(wn, 0.98)
+    sos = sg.bessel(order, wn, "low", norm="mag", output="sos")
+    zi = sg.sosfilt_zi(sos)
+    ntaps = 2 * sos.shape[0] + 1 - min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum())
+    n = int(rng.choice([rng.integers(3 * ntaps + 1, 200), rng.integers(200, 5000), rng.integers(5000, 300000)]))
+    rows = int(rng.integers(1, 4))
+    cplx = bool(rng.integers(0, 2))
+    x = rng.standard_normal((rows, n)).cumsum(axis=-1) * 0.01 + rng.standard_normal((rows, n))
+    if cplx:
+        x = x + 1j * rng.standard_normal((rows, n))
+    want = sg.sosfiltfilt(sos, x, axis=-1)
+    got = _lib.sosfiltfilt(sos, zi, x)
+    err = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+    worst.append((err, order, wn / 2, n, rows, cplx))
+worst.sort(key=lambda w: -w[0])
+print("filters, worst cases (err, order, cutoff/fs, n, rows, complex):")
+for w in worst[:5]:
+    print("  %.2e" % w[0], w[1:])
+for lo, hi in ((1e-5, 1e-4), (1e-4, 1e-3), (1e-3, 1e-2), (1e-2, 1e-1), (1e-1, 0.5)):
+    sel = [w for w in worst if lo <= w[2] < hi]
+    if sel:
+        print(f"  cutoff/fs in [{lo:g}, {hi:g}): {len(sel)} cases, worst {max(w[0] for w in sel):.1e} (order {max(sel, key=lambda w: w[0])[1]})")
+bad = sum(w[0] > 1e-11 for w in worst if w[2] >= 1e-3)
+# DM: random lengths and dispersions
+gv(sps=16, R=32e9)
+wd = []
+for i in range(60):
+    n = int(rng.choice([1 << int(rng.integers(8, 17)), rng.integers(2, 50000)]))
+    a = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))) * 0.03
+    D = float(rng.uniform(-3000, 3000))
+    y = oa.DM(optical_signal(a), D=D).signal
+    ref, _ = orc.dm_c128(a, gv.dt, D)
+    wd.append((float(np.max(np.abs(y - ref)) / np.max(np.abs(ref))), n, D))
+wd.sort(key=lambda w: -w[0])
+print("DM, worst cases:", ["%.1e n=%d D=%.0f" % w for w in wd[:4]])
+bad += sum(w[0] > 1e-11 for w in wd)
+print("violations:", bad)
+sys.exit(1 if bad else 0)

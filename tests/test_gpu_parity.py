@@ -505,6 +505,20 @@ def test_sosfiltfilt_on_device_buffers():
         q.close()
 
 
+def test_narrow_filters_warn_and_stay_within_the_documented_bound():
+    from scipy import signal as sg
+    gv(sps=16, R=10e9)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(60000).cumsum() * 0.01 + rng.standard_normal(60000)
+    with pytest.warns(RuntimeWarning, match="below fs/500"):
+        y = oa.LPF(x, BW=gv.fs / 2000).signal
+    sos = sg.bessel(4, gv.fs / 2000, "low", fs=gv.fs, norm="mag", output="sos")
+    assert relmax(y, sg.sosfiltfilt(sos, x)) < 5 * 5e-20 * 2000 ** 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        oa.LPF(x, BW=gv.fs / 300)                                      # no warning in the usual range
+
+
 def test_bessel_filter_errors():
     gv(sps=16, R=10e9)
     with pytest.raises(TypeError, match=r"`input` must be of type \(optical_signal\)."):
