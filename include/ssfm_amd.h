@@ -58,6 +58,7 @@ enum ssfm_status {
 };
 
 enum ssfm_precision { SSFM_C64 = 0, SSFM_C128 = 1 };
+#define SSFM_F64_REAL 2   /* ssfm_device_convert only: a real float64 source (a CW laser, a drive voltage) */
 
 typedef struct ssfm_plan ssfm_plan;
 
@@ -153,7 +154,7 @@ int ssfm_square_law_device(int device, const void* sig, const void* noise, int n
  * `.noise` are materialised lazily from these.  All calls are synchronous.
  *   ssfm_device_alloc / _free   pooled per (device, size); pass the allocation size to _free
  *   ssfm_device_copy            kind 0 host->device, 1 device->host, 2 device->device
- *   ssfm_device_convert         complex64 <-> complex128, `count` complex elements
+ *   ssfm_device_convert         complex64 <-> complex128, or SSFM_F64_REAL -> either (zero imaginary part); `count` elements
  *   ssfm_device_add             dst = a + b, `count` complex elements of `precision` */
 int ssfm_device_alloc(int device, size_t bytes, void** out);
 int ssfm_device_free(int device, void* ptr, size_t bytes);
@@ -178,6 +179,10 @@ int ssfm_device_mean(int device, const double* a, const double* b, int64_t n, do
  * ssfm_device_real: dst (float64) = real part of src (complex128). */
 int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, const void* in_noise, int n_pol, int64_t n, const void* drive,
              const void* drive_noise, int drive_complex, double k, double bias, double sqrt_loss, double half_eta, int dead_pol);
+/* LASER (devices.py:353-510) over t = linspace(0, stop, n) (t_i = i*step): out = amp [exp(j phase)] [sqrt(1 + rin)] [exp(j w t)],
+ * the factors in the reference's order; `phase` (running sum of the Wiener increments) and `rin` are nullable float64 DEVICE
+ * arrays drawn by the caller, `w` = 2 pi df with has_df.  `out`: n float64 when neither phase nor df is given, else n complex128. */
+int ssfm_laser(int device, void* out, int64_t n, double amp, const double* phase, const double* rin, int has_df, double w, double step, double stop);
 int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, double beta, int64_t n, int is_complex);
 int ssfm_device_real(int device, double* dst, const void* src, int64_t n);
 /* Free / total HBM of the device and the bytes held in the library's buffer pool (nullable). */
@@ -201,6 +206,12 @@ int ssfm_apply_table(ssfm_plan* plan, int slot);
  * amplitudes (DEVICE; the bits as 0.0 / 1.0) zero-stuffed to `up` samples per symbol with the sample at up / 2; ssfm_apply_table then convolves.  Asynchronous. */
 int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src);
 int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const double* sym_dev, int64_t nsym, int up);
+/* The DAC's built-in pulses (utils.py:1791-1947) generated in the field instead of uploaded: `npts` samples over
+ * t_i = i*step + start (t_{npts-1} = stop: numpy.linspace), zero-padded.  kind 0 nrz (params: -T/2, T/2); 1 gaussian
+ * exp(-((p0 + j p1) t)^pow2m) with (p0, p1) = alpha (1 + j c); 2 raised cosine (2 beta, pi beta, value where
+ * 1 - (2 beta t)^2 ~ 0); 3 root raised cosine (beta, 4 beta, 1 - beta, 1 + beta, 1/(4 beta), value at 0, value at
+ * 1/(4 beta)); 4 sinc.  `params`: 7 doubles on the HOST.  Asynchronous. */
+int ssfm_load_pulse(ssfm_plan* plan, int64_t plan_n, int kind, int64_t npts, double start, double step, double stop, int pow2m, const double* params);
 int ssfm_table_from_field(ssfm_plan* plan, int slot);
 int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh);
 int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode);

@@ -56,6 +56,8 @@ SYMBOLS = {
     "ssfm_apply_table": (_I, [_VP, _I]),
     "ssfm_load_padded": (_I, [_VP, _I64, _VP, _I, _I64]),
     "ssfm_load_symbols": (_I, [_VP, _I64, _VP, _I64, _I]),
+    "ssfm_laser": (_I, [_I, _VP, _I64, _D, _VP, _VP, _I, _D, _D, _D]),
+    "ssfm_load_pulse": (_I, [_VP, _I64, _I, _I64, _D, _D, _D, _I, _VP]),
     "ssfm_table_from_field": (_I, [_VP, _I]),
     "ssfm_chirp_pre": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D]),
     "ssfm_chirp_mid": (_I, [_VP, _I64, _I, _VP, _I64, _D, _I]),
@@ -233,12 +235,12 @@ class DeviceArray:
         return d
 
     def astype(self, dtype) -> "DeviceArray":
-        """complex64 <-> complex128 on the device (a copy when the type already matches)."""
+        """complex64 <-> complex128, float64 -> either, on the device (a copy when the type already matches)."""
         dtype = np.dtype(dtype)
         if dtype == self.dtype:
             return self.copy()
-        codes = {np.dtype(np.complex64): C64, np.dtype(np.complex128): C128}
-        if self.dtype not in codes or dtype not in codes:
+        codes = {np.dtype(np.complex64): C64, np.dtype(np.complex128): C128, np.dtype(np.float64): 2}
+        if self.dtype not in codes or dtype not in codes or codes[dtype] == 2:
             raise TypeError(f"DeviceArray.astype: {self.dtype} -> {dtype} is not supported")
         d = DeviceArray(self.shape, dtype, self.device)
         _check(load().ssfm_device_convert(self.device, _VP(self.ptr), codes[self.dtype], _VP(d.ptr), codes[dtype], self.size), "ssfm_device_convert")
@@ -311,6 +313,14 @@ def mzm_device(sig: DeviceArray, noise, drive: DeviceArray, drive_noise, k, bias
     _check(load().ssfm_mzm(sig.device, _VP(out_s.ptr), p(out_n), _VP(sig.ptr), p(noise), n_pol, n, _VP(drive.ptr), p(drive_noise),
                            int(drive.dtype.kind == "c"), float(k), float(bias), float(sqrt_loss), float(half_eta), int(dead_pol)), "ssfm_mzm")
     return out_s, out_n
+
+
+def laser_device(n: int, amp: float, phase, rin, w, step: float, stop: float, device: int = 0) -> DeviceArray:
+    """``ssfm_laser``: the CW field with optional phase noise / intensity noise (float64 DeviceArrays) / frequency offset ``w``."""
+    out = DeviceArray((n,), np.complex128 if (phase is not None or w is not None) else np.float64, device)
+    p = lambda x: None if x is None else _VP(x.ptr)
+    _check(load().ssfm_laser(int(device), _VP(out.ptr), int(n), float(amp), p(phase), p(rin), int(w is not None), float(w or 0.0), float(step), float(stop)), "ssfm_laser")
+    return out
 
 
 def device_mem_info(device: int = 0):
@@ -448,6 +458,11 @@ class Plan:
     def load_symbols(self, sym: "DeviceArray", up: int):
         """field <- the float64 amplitudes ``sym`` zero-stuffed to ``up`` samples per symbol (sample at ``up // 2``)."""
         _check(load().ssfm_load_symbols(self._h, self.n, _VP(sym.ptr), sym.size, int(up)), "ssfm_load_symbols")
+
+    def load_pulse(self, kind: int, npts: int, start: float, step: float, stop: float, pow2m: int, params):
+        """field <- one of the DAC's built-in pulses over ``linspace(start, stop, npts)``, zero-padded (``ssfm_load_pulse``)."""
+        p = (C.c_double * 7)(*(list(params) + [0.0] * (7 - len(params))))
+        _check(load().ssfm_load_pulse(self._h, self.n, int(kind), int(npts), float(start), float(step), float(stop), int(pow2m), p), "ssfm_load_pulse")
 
     def table_from_field(self, slot: int):
         _check(load().ssfm_table_from_field(self._h, int(slot)), "ssfm_table_from_field")

@@ -168,6 +168,89 @@ __global__ __launch_bounds__(256) void k_load_symbols(const double* __restrict__
     }
 }
 
+
+// The DAC's built-in pulses generated where they are used (reference utils.py:1791-1947: nrz_pulse, gauss_pulse,
+// rcos_pulse over t = linspace(-span/2, span/2, span*sps + 1)); the pulse is as long as the signal, so building it
+// with NumPy and uploading it cost more than the whole convolution.  Every expression keeps the reference's order of
+// operations (no fused multiply-add: the grid t_i = i*step + start is then NumPy's linspace bit for bit, and the
+// values differ from NumPy's only by the last-bit differences of exp / sin / cos).
+struct PulseSpec {
+    int kind;            // 0 nrz, 1 gaussian, 2 raised cosine ('normal'), 3 root raised cosine ('sqrt'), 4 sinc (beta = 0)
+    int pow2m;           // gaussian: the exponent 2 m
+    long long npts;
+    double start, step, stop;
+    double a, b, c, d, e, f, g;      // per kind, see k_load_pulse
+};
+
+// One rounding per operation: HIP's __dmul_rn / __dadd_rn are plain operators the compiler may still fuse into an
+// fma, so the products and sums that must round like NumPy's are written under an explicit no-contraction pragma.
+__device__ __forceinline__ double mul_r(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double add_r(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double sub_r(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
+__device__ __forceinline__ double2 cmul_plain(double2 x, double2 y) {
+    return make_double2(sub_r(mul_r(x.x, y.x), mul_r(x.y, y.y)), add_r(mul_r(x.x, y.y), mul_r(x.y, y.x)));
+}
+
+__device__ __forceinline__ double np_sinc(double t) {            // numpy.sinc: sin(y) / y, y = pi * (t == 0 ? 1e-20 : t)
+    const double y = mul_r(3.141592653589793, t == 0.0 ? 1.0e-20 : t);
+    return sin(y) / y;
+}
+
+__global__ __launch_bounds__(256) void k_load_pulse(PulseSpec ps, double2* __restrict__ F, long long M) {
+    const double pi = 3.141592653589793;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+        double2 v = make_double2(0.0, 0.0);
+        if (i < ps.npts) {
+            const double t = (i == ps.npts - 1 && ps.npts > 1) ? ps.stop : add_r(mul_r((double)i, ps.step), ps.start);
+            if (ps.kind == 0) {                                   // a = -T/2, b = T/2
+                v.x = (t >= ps.a && t < ps.b) ? 1.0 : 0.0;
+            } else if (ps.kind == 1) {                            // (a, b) = alpha (1 + j c): exp(-((a + j b) t)^(2m))
+                const double2 z = make_double2(mul_r(ps.a, t), mul_r(ps.b, t));
+                double2 acc = make_double2(1.0, 0.0), p = z;      // NumPy's integer complex power: binary powering
+                if (ps.pow2m == 2) acc = cmul_plain(z, z);
+                else if (z.x == 0.0 && z.y == 0.0) acc = make_double2(0.0, 0.0);
+                else for (int mask = 1;;) {
+                    if (ps.pow2m & mask) acc = cmul_plain(acc, p);
+                    mask <<= 1;
+                    if (ps.pow2m < mask) break;
+                    p = cmul_plain(p, p);
+                }
+                const double ex = exp(-acc.x);
+                double sn, cs;
+                sincos(-acc.y, &sn, &cs);
+                v = make_double2(ex * cs, ex * sn);
+            } else if (ps.kind == 2) {                            // a = 2 beta, b = pi beta, c = value where den ~ 0
+                const double u = mul_r(ps.a, t);
+                const double den = sub_r(1.0, mul_r(u, u));
+                if (fabs(den) < 1e-8) v.x = ps.c;
+                else v.x = mul_r(np_sinc(t), cos(mul_r(ps.b, t))) / den;
+            } else if (ps.kind == 3) {                            // a = beta, b = 4 beta, c = 1 - beta, d = 1 + beta, e = 1/(4 beta), f = value at 0, g = value at 1/(4 beta)
+                const double ta = fabs(t);
+                if (ta < 1e-8) v.x = ps.f;
+                else if (fabs(sub_r(ta, ps.e)) < 1e-8) v.x = ps.g;
+                else {
+                    const double pt = mul_r(pi, t), bt = mul_r(ps.b, t);
+                    const double num = add_r(sin(mul_r(pt, ps.c)), mul_r(bt, cos(mul_r(pt, ps.d))));
+                    v.x = num / mul_r(pt, sub_r(1.0, mul_r(bt, bt)));
+                }
+            } else {
+                v.x = np_sinc(t);
+            }
+        }
+        F[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src) {
@@ -184,6 +267,17 @@ extern "C" int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const double* 
     if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
     if (!sym_dev || nsym < 1 || up < 1 || nsym * up > plan_n) return fail(SSFM_ERR_INVALID, "ssfm_load_symbols: %lld symbols x %d samples for a plan of %lld", (long long)nsym, up, (long long)plan_n);
     hipLaunchKernelGGL(k_load_symbols, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, sym_dev, (long long)nsym, up, t.F, t.M);
+    HIP_TRY(hipGetLastError());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_load_pulse(ssfm_plan* plan, int64_t plan_n, int kind, int64_t npts, double start, double step, double stop, int pow2m, const double* params) {
+    Target t;
+    if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
+    if (kind < 0 || kind > 4 || npts < 1 || npts > plan_n || !params) return fail(SSFM_ERR_INVALID, "ssfm_load_pulse: kind %d, %lld points for a plan of %lld", kind, (long long)npts, (long long)plan_n);
+    if (kind == 1 && (pow2m < 2 || pow2m > 98 || (pow2m & 1))) return fail(SSFM_ERR_INVALID, "ssfm_load_pulse: gaussian order 2m = %d outside 2 ... 98", pow2m);
+    PulseSpec ps{kind, pow2m, (long long)npts, start, step, stop, params[0], params[1], params[2], params[3], params[4], params[5], params[6]};
+    hipLaunchKernelGGL(k_load_pulse, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, ps, t.F, t.M);
     HIP_TRY(hipGetLastError());
     return SSFM_OK;
 }

@@ -38,6 +38,13 @@ template <typename S, typename D>
 __global__ __launch_bounds__(256) void k_convert(const S* __restrict__ src, D* __restrict__ dst, long long count2) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count2; i += (long long)gridDim.x * blockDim.x) dst[i] = (D)src[i];
 }
+template <typename D>
+__global__ __launch_bounds__(256) void k_widen(const double* __restrict__ src, D* __restrict__ dst, long long count) {      // real -> complex
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        dst[2 * i] = (D)src[i];
+        dst[2 * i + 1] = (D)0;
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_add(T* __restrict__ dst, const T* __restrict__ a, const T* __restrict__ b, long long count2) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count2; i += (long long)gridDim.x * blockDim.x) dst[i] = a[i] + b[i];
@@ -110,6 +117,10 @@ extern "C" int ssfm_device_convert(int device, const void* src, int src_precisio
         hipLaunchKernelGGL((k_convert<float, double>), dim3(blocks_for(c2)), dim3(256), 0, 0, (const float*)src, (double*)dst, c2);
     else if (src_precision == SSFM_C128 && dst_precision == SSFM_C64)
         hipLaunchKernelGGL((k_convert<double, float>), dim3(blocks_for(c2)), dim3(256), 0, 0, (const double*)src, (float*)dst, c2);
+    else if (src_precision == SSFM_F64_REAL && dst_precision == SSFM_C128)
+        hipLaunchKernelGGL((k_widen<double>), dim3(blocks_for(count)), dim3(256), 0, 0, (const double*)src, (double*)dst, (long long)count);
+    else if (src_precision == SSFM_F64_REAL && dst_precision == SSFM_C64)
+        hipLaunchKernelGGL((k_widen<float>), dim3(blocks_for(count)), dim3(256), 0, 0, (const double*)src, (float*)dst, (long long)count);
     else
         return fail(SSFM_ERR_INVALID, "ssfm_device_convert: precisions %d -> %d", src_precision, dst_precision);
     HIP_TRY(hipGetLastError());

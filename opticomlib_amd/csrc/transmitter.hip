@@ -58,6 +58,37 @@ __global__ __launch_bounds__(256) void k_mzm(double2* __restrict__ out_s, double
     }
 }
 
+// LASER (reference devices.py:353-510) over t = linspace(0, stop, n): out = amp [exp(j phase)] [sqrt(1 + rin)] [exp(j w t)],
+// each factor applied in the reference's order and only when present; real output (n doubles) while no phase factor
+// has been applied, complex otherwise.  `phase` is the running sum of the Wiener increments and `rin` the intensity
+// noise, both drawn by the caller (NumPy's generator, so that a seeded script gets the reference's realisation).
+__global__ __launch_bounds__(256) void k_laser(double* __restrict__ out, long long n, double amp, const double* __restrict__ phase, const double* __restrict__ rin,
+                                               int has_df, double w, double step, double stop) {
+#pragma clang fp contract(off)
+    const bool cplx = phase || has_df;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double re = amp, im = 0.0;
+        if (phase) {
+            double s, c;
+            sincos(phase[i], &s, &c);
+            re = amp * c; im = amp * s;
+        }
+        if (rin) {
+            const double q = sqrt(1.0 + rin[i]);
+            re = re * q; im = im * q;
+        }
+        if (has_df) {
+            const double t = (i == n - 1 && n > 1) ? stop : (double)i * step;
+            double s, c;
+            sincos(w * t, &s, &c);
+            const double r2 = re * c - im * s, i2 = re * s + im * c;
+            re = r2; im = i2;
+        }
+        if (cplx) { out[2 * i] = re; out[2 * i + 1] = im; }
+        else out[i] = re;
+    }
+}
+
 // dst = src * alpha + beta; complex: both parts scaled, beta added to the real part
 __global__ __launch_bounds__(256) void k_axpb(double* __restrict__ dst, const double* __restrict__ src, double alpha, double beta, long long n, int is_complex) {
 #pragma clang fp contract(off)
@@ -97,6 +128,15 @@ extern "C" int ssfm_device_real(int device, double* dst, const void* src, int64_
     if (!dst || !src || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_real: bad argument");
     if (int rc = use_dev(device)) return rc;
     hipLaunchKernelGGL(k_real, dim3(blocks_of(n)), dim3(256), 0, 0, dst, (const double2*)src, (long long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_laser(int device, void* out, int64_t n, double amp, const double* phase, const double* rin, int has_df, double w, double step, double stop) {
+    if (!out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_laser: bad argument");
+    if (int rc = use_dev(device)) return rc;
+    hipLaunchKernelGGL(k_laser, dim3(blocks_of(n)), dim3(256), 0, 0, (double*)out, (long long)n, amp, phase, rin, has_df, w, step, stop);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return SSFM_OK;

@@ -624,7 +624,7 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
     has_noise = input._raw("noise") is not NULL
     res = []
     for a in ([input._raw("signal"), input._raw("noise")] if has_noise else [input._raw("signal")]):
-        cplx = _on_device(a) or np.iscomplexobj(a)
+        cplx = np.dtype(a.dtype).kind == "c"                # a real envelope (a CW laser) stays real, as in SciPy
         x = _dev_array(a, np.complex128 if cplx else np.float64, dev)
         y = _lib.DeviceArray(x.shape, x.dtype, dev)
         _lib.sosfiltfilt_device(sos, zi, x.ptr, y.ptr, x.shape[-1], x.size // x.shape[-1], cplx, dev)
@@ -832,7 +832,7 @@ def PRBS(order: int, len: int = None, seed: int = None, return_seed: bool = Fals
     The reference walks the register one bit per Python iteration; here the output recurrence
     ``o[j] = o[j-p] ^ o[j-q]`` (p = order, q = t2) is advanced in blocks: over GF(2) it implies
     ``o[j] = o[j-Lp] ^ o[j-Lq]`` for every L = 2^k, so a block of L*q bits is one vector XOR.  Host integer
-    work (a 2^20-bit sequence takes about a millisecond); the bits feed the host-side pulse shaping.
+    work (a 2^20-bit sequence takes about a millisecond); the bits feed the DAC.
     """
     import builtins
     import warnings
@@ -880,72 +880,74 @@ def PRBS(order: int, len: int = None, seed: int = None, return_seed: bool = Fals
 _DAC_SHAPES = ["nrz", "gaussian", "rcos"]
 
 
-def _nrz_pulse(span, sps, T):
-    """reference ``utils.py:1924-1947``"""
-    t = np.linspace(-span / 2, span / 2, span * sps + 1)
-    return np.where((t >= -T / 2) & (t < T / 2), 1.0, 0.0)
+def _pulse_grid(span, sps):
+    """``t = linspace(-span/2, span/2, span*sps + 1)`` as (npts, start, step, stop), NumPy's own arithmetic."""
+    npts = span * sps + 1
+    start, stop = -span / 2, span / 2
+    return npts, start, (stop - start) / (npts - 1), stop
 
 
-def _gauss_pulse(span, sps, T=1, m=1, c=0.0):
-    """reference ``utils.py:1880-1922``"""
-    t = np.linspace(-span / 2, span / 2, span * sps + 1)
-    alpha = 2 * np.sqrt(np.log(2)) / T
-    return np.exp(-(alpha * (1 + 1j * c) * t) ** (2 * m))
+def _nrz_spec(span, sps, T):
+    """reference ``utils.py:1924-1947``: 1 on [-T/2, T/2)."""
+    return (0,) + _pulse_grid(span, sps) + (0, [-T / 2, T / 2]), False
 
 
-def _rcos_pulse(beta, span, sps, shape="sqrt"):
+def _gauss_spec(span, sps, T=1, m=1, c=0.0):
+    """reference ``utils.py:1880-1922``: ``exp(-(alpha (1 + j c) t)^(2m))``, ``alpha = 2 sqrt(ln 2) / T``; complex."""
+    if 2 * m > 98:
+        raise ValueError("The parameter `m` must be below 50.")
+    k = 2 * np.sqrt(np.log(2)) / T * (1 + 1j * c)
+    return (1,) + _pulse_grid(span, sps) + (2 * m, [k.real, k.imag]), True
+
+
+def _rcos_spec(beta, span, sps, shape="sqrt"):
     """reference ``utils.py:1791-1878`` (MATLAB ``rcosdesign`` without the energy normalisation)"""
     if not (0 <= beta <= 1):
         raise ValueError("beta must be in [0, 1]")
     if shape not in ("sqrt", "normal"):
         raise ValueError("shape must be 'sqrt' or 'normal'")
-    t = np.linspace(-span / 2, span / 2, span * sps + 1)
+    grid = _pulse_grid(span, sps)
     if beta == 0:
-        return np.sinc(t)
+        return (4,) + grid + (0, []), False
     if shape == "normal":
-        den = 1 - (2 * beta * t) ** 2
-        p = np.divide(np.sinc(t) * np.cos(np.pi * beta * t), den, out=np.zeros_like(den), where=den != 0)
-        special = np.abs(den) < 1e-8
-        if np.any(special):
-            p[special] = (np.pi / 4) * np.sinc(1 / (2 * beta))
-        return p
-    t_abs = np.abs(t)
-    p = np.zeros_like(t)
-    zero = t_abs < 1e-8
-    p[zero] = (1 - beta) + 4 * beta / np.pi
-    special = np.abs(t_abs - 1 / (4 * beta)) < 1e-8
-    if np.any(special):
-        p[special] = (beta / np.sqrt(2)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * beta)) + (1 - 2 / np.pi) * np.cos(np.pi / (4 * beta)))
-    general = ~zero & ~special
-    if np.any(general):
-        ti = t[general]
-        p[general] = (np.sin(np.pi * ti * (1 - beta)) + 4 * beta * ti * np.cos(np.pi * ti * (1 + beta))) / (np.pi * ti * (1 - (4 * beta * ti) ** 2))
-    return p
+        return (2,) + grid + (0, [2 * beta, np.pi * beta, (np.pi / 4) * np.sinc(1 / (2 * beta))]), False
+    at_zero = (1 - beta) + 4 * beta / np.pi
+    at_special = (beta / np.sqrt(2)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * beta)) + (1 - 2 / np.pi) * np.cos(np.pi / (4 * beta)))
+    return (3,) + grid + (0, [beta, 4 * beta, 1 - beta, 1 + beta, 1 / (4 * beta), at_zero, at_special]), False
 
 
-def _upfir_device(bits: np.ndarray, h: np.ndarray, up: int, dev: int) -> "_lib.DeviceArray":
+def _upfir_device(bits: np.ndarray, h, up: int, dev: int, spec=None) -> "_lib.DeviceArray":
     """``upfir`` of the reference (``utils.py:1949-1981``): zero-stuffing at offset ``up//2`` and the 'same' part of
-    the linear convolution with ``h`` -- as ONE circular convolution on a power-of-two complex128 plan
-    (``x <- ifft(fft(x) * fft(h))``, three launches); SciPy's ``fftconvolve`` does the same on the host."""
+    the linear convolution with the pulse -- as ONE circular convolution on a power-of-two complex128 plan
+    (``x <- ifft(fft(x) * fft(h))``, three launches); SciPy's ``fftconvolve`` does the same on the host.
+    The pulse is either an explicit impulse response ``h`` (uploaded) or ``spec = (args of Plan.load_pulse, complex?)``
+    of a built-in shape, generated on the device."""
     n = bits.size * up
-    h = np.asarray(h)
-    full = n + h.size - 1
+    if spec is None:
+        h = np.asarray(h)
+        taps, cplx = h.size, np.iscomplexobj(h)
+    else:
+        taps, cplx = spec[0][1], spec[1]
+    full = n + taps - 1
     M = 1 << max(8, (full - 1).bit_length())
     lo, hi = _lib.supported_log2n(_lib.C128)
     if M > (1 << hi):
-        raise ValueError(f"DAC: {bits.size} bits x {up} samples with a {h.size}-tap pulse exceed the device path (2^{hi} points)")
+        raise ValueError(f"DAC: {bits.size} bits x {up} samples with a {taps}-tap pulse exceed the device path (2^{hi} points)")
     plan = get_plan(M, 1, _lib.C128, dev)
     plan._op_key = None
     plan._chirp_n = None                                    # the table slots are taken over
-    hd = _lib.DeviceArray.from_host(np.ascontiguousarray(h, dtype=np.complex128 if np.iscomplexobj(h) else np.float64), None, dev)
-    plan.load_padded(hd)                                    # field <- h, zero-padded
+    if spec is None:
+        hd = _lib.DeviceArray.from_host(np.ascontiguousarray(h, dtype=np.complex128 if cplx else np.float64), None, dev)
+        plan.load_padded(hd)                                # field <- h, zero-padded
+    else:
+        plan.load_pulse(*spec[0])                           # field <- the pulse, generated in place
     plan.table_from_field(0)                                # slot 0 <- fft(h)
     bd = _lib.DeviceArray.from_host(np.ascontiguousarray(bits, dtype=np.float64), np.float64, dev)
     plan.load_symbols(bd, up)                               # field <- zero-stuffed bits
     plan.apply_table(0)
     out = _lib.DeviceArray((n,), np.complex128, dev)
-    plan.copy_from_field(((h.size - 1) // 2) * 16, out.ptr, n * 16)          # 'same': centred with respect to the full output
-    return out if np.iscomplexobj(h) else _lib.real_device(out)
+    plan.copy_from_field(((taps - 1) // 2) * 16, out.ptr, n * 16)          # 'same': centred with respect to the full output
+    return out if cplx else _lib.real_device(out)
 
 
 def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0, offset: float = 0.0, h=None, BW: float = None,
@@ -962,8 +964,9 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
     data = seq.to_numpy()
     dev = default_device() if device is None else int(device)
     span = max(4, bits - 4)
+    spec = None
     if h is not None:
-        pulse = np.asarray(h)
+        h = np.asarray(h)
     elif pulse_shape.lower() not in _DAC_SHAPES:
         raise ValueError(f"The parameter `pulse_shape` must be one of the following values {_DAC_SHAPES}")
     elif pulse_shape.lower() == "nrz":
@@ -974,7 +977,7 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
             raise ValueError("The parameter `T` must be greater than 0.")
         if T > 2 * sps:
             raise ValueError("The parameter `T` must be less than 2*sps.")
-        pulse = _nrz_pulse(span, sps, T)
+        spec = _nrz_spec(span, sps, T)
     elif pulse_shape.lower() == "gaussian":
         c, m, T = kwargs.get("c", 0.0), kwargs.get("m", 1), kwargs.get("T", 1)
         if not isinstance(c, (int, float)):
@@ -989,9 +992,9 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
             raise ValueError("The parameter `T` must be greater than 0.")
         if T > 2 * sps:
             raise ValueError("The parameter `T` must be less than 2*sps.")
-        pulse = _gauss_pulse(span, sps, T=T, m=m, c=c)
+        spec = _gauss_spec(span, sps, T=T, m=m, c=c)
     else:
-        pulse = _rcos_pulse(kwargs.get("beta", 0.25), span, sps, shape=kwargs.get("rcos_type", "normal"))
+        spec = _rcos_spec(kwargs.get("beta", 0.25), span, sps, shape=kwargs.get("rcos_type", "normal"))
     if Vpp is not None:
         if not isinstance(Vpp, (int, float)):
             raise TypeError("The parameter `Vpp` must be a scalar value.")
@@ -1004,7 +1007,7 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
             raise ValueError("The parameter `offset` must be in the range [-48, 48] Volts.")
     if coupling.upper() not in ("AC", "DC"):
         raise ValueError("The parameter `coupling` must be either 'AC' or 'DC'.")
-    x = _upfir_device(data, pulse, sps, dev)                # stays on the device: float64, or complex128 for a complex pulse
+    x = _upfir_device(data, h, sps, dev, spec)              # stays on the device: float64, or complex128 for a complex pulse
     if Vpp is not None:
         x = _lib.axpb_device(x, Vpp, 0.0)
     if offset is not None:
@@ -1023,28 +1026,32 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
 
 
 # ----------------------------------------------------------------------------- LASER / MZM
-# Elementwise host arithmetic in the reference's own expressions (and its np.random calls, so a seeded script gets the
-# same laser noise); only MZM's optional optical filter is device work.  They complete the transmitter chain
-# PRBS -> DAC -> MZM(LASER) in front of FIBER.
-def LASER(P0: float, lw: float = None, rin: float = None, df: float = None) -> optical_signal:
+# Elementwise HIP kernels (csrc/transmitter.hip) in the reference's own order of operations; the laser's random
+# increments are drawn from NumPy's global generator with the reference's calls, so a seeded script gets the same laser
+# noise.  They complete the transmitter chain PRBS -> DAC -> MZM(LASER) in front of FIBER, which stays in GPU memory.
+def LASER(P0: float, lw: float = None, rin: float = None, df: float = None, *, device=None) -> optical_signal:
     """CW laser of ``P0`` dBm over ``gv.t`` (reference ``devices.py:353-510``): optional linewidth ``lw`` [Hz] (Wiener
-    phase noise), relative intensity noise ``rin`` [dB/Hz] and frequency offset ``df`` [Hz]; single polarisation."""
+    phase noise), relative intensity noise ``rin`` [dB/Hz] and frequency offset ``df`` [Hz]; single polarisation.
+    Real-valued (float64) unless ``lw`` or ``df`` is given, as in the reference."""
     t0 = time.time()
     t = gv.t
-    out = np.ones_like(t) * np.sqrt(10 ** (P0 / 10 - 3))
+    n = t.size
+    dev = default_device() if device is None else int(device)
+    amp = float(np.sqrt(10 ** (P0 / 10 - 3)))
+    phase = rin_noise = w = None
     if lw is not None:
-        phase_noise = np.cumsum(np.random.normal(0, np.sqrt(2 * np.pi * lw * gv.dt), t.size))
-        out = out * np.exp(1j * phase_noise)
+        phase = _lib.DeviceArray.from_host(np.cumsum(np.random.normal(0, np.sqrt(2 * np.pi * lw * gv.dt), n)), np.float64, dev)
     if rin is not None:
-        rin_noise = np.random.normal(0, np.sqrt(_idb(rin) * gv.fs), t.size)
-        if rin_noise.min() < -1:
+        r = np.random.normal(0, np.sqrt(_idb(rin) * gv.fs), n)
+        if r.min() < -1:
             raise ValueError("Noise power is to high, try decrease RIN parameter.")
-        out = out * np.sqrt(1 + rin_noise)
+        rin_noise = _lib.DeviceArray.from_host(r, np.float64, dev)
     if df is not None:
         if np.abs(df) > gv.fs / 2:
             raise ValueError("The laser frequency is out of the Nyquist range. Try increase the sampling frequency.")
-        out = out * np.exp(1j * 2 * np.pi * df * t)
-    output = optical_signal(out)
+        w = 2 * np.pi * df                                   # exp(1j*2*pi*df*t): the phase is (2 pi df) * t_i
+    out = _lib.laser_device(n, amp, phase, rin_noise, w, float(t[1]) if n > 1 else 0.0, float(t[-1]), dev)
+    output = _wrap_out(optical_signal, out, NULL)
     output.execution_time = time.time() - t0
     return output
 
@@ -1072,32 +1079,23 @@ def MZM(op_input: optical_signal, el_input, bias: float = 0.0, Vpi: float = 5.0,
     k = np.pi / 2 / Vpi
     raw_s, raw_n = op_input._raw("signal"), op_input._raw("noise")
     raw_v, raw_vn = el_input._raw("signal"), el_input._raw("noise")
-    same_kind = raw_vn is NULL or raw_vn.dtype.kind == raw_v.dtype.kind
-    if KEEP_ON_DEVICE and (_on_device(raw_s) or _on_device(raw_v)) and tuple(raw_v.shape)[-1:] == tuple(raw_s.shape)[-1:] and same_kind \
-            and raw_v.dtype.kind in "fc":
-        # the modulator between a device-resident drive (DAC) or carrier and the fibre: elementwise on the GPU
-        dev = default_device() if device is None else int(device)
-        vdt = np.complex128 if raw_v.dtype.kind == "c" else np.float64
-        out_s, out_n = _lib.mzm_device(_dev_array(raw_s, np.complex128, dev), None if raw_n is NULL else _dev_array(raw_n, np.complex128, dev),
-                                       _dev_array(raw_v, vdt, dev), None if raw_vn is NULL else _dev_array(raw_vn, vdt, dev),
-                                       k, bias, loss ** 0.5, eta / 2, 1 if pol == "x" else 0)
-        output = optical_signal.from_device(out_s, NULL if out_n is None else out_n, n_pol=op_input.n_pol)
-        if BW is not None:
-            output = _bpf_on_grid(output, BW, grid, device)
-        output.execution_time = time.time() - t0
-        return back(output)
-    g_t = k * (el_input.signal + bias)
-    if el_input.noise is not NULL:
-        g_t = g_t + k * el_input.noise
-    h_t = loss ** 0.5 * (np.cos(g_t) + 1j * eta / 2 * np.sin(g_t))
-    sig = op_input.signal * h_t
-    noi = NULL if op_input.noise is NULL else op_input.noise * h_t
-    if op_input.n_pol == 2:
-        dead = 1 if pol == "x" else 0
-        sig[dead] = np.zeros_like(sig[dead])
-        if noi is not NULL:
-            noi[dead] = np.zeros_like(noi[dead])
-    output = optical_signal(sig, noi, n_pol=op_input.n_pol)
+    dev = default_device() if device is None else int(device)
+    n = tuple(raw_s.shape)[-1]
+    # one HIP kernel (ssfm_mzm, csrc/transmitter.hip) whatever the inputs are: a DAC output or a carrier that is
+    # already in GPU memory is used where it lies, host arrays are uploaded (a scalar drive is spread over the grid)
+    cplx = any(a is not NULL and a.dtype.kind == "c" for a in (raw_v, raw_vn))
+    vdt = np.complex128 if cplx else np.float64
+
+    def drive(a):
+        if a is NULL:
+            return None
+        if _on_device(a) and tuple(a.shape) == (n,) and a.dtype == vdt:
+            return _dev_array(a, vdt, dev)
+        host = a.to_host() if _on_device(a) else np.asarray(a)
+        return _lib.DeviceArray.from_host(np.broadcast_to(host, (n,)), vdt, dev)     # ValueError when the lengths disagree
+    out_s, out_n = _lib.mzm_device(_dev_array(raw_s, np.complex128, dev), None if raw_n is NULL else _dev_array(raw_n, np.complex128, dev),
+                                   drive(raw_v), drive(raw_vn), k, bias, loss ** 0.5, eta / 2, 1 if pol == "x" else 0)
+    output = _wrap_out(optical_signal, out_s, NULL if out_n is None else out_n, n_pol=op_input.n_pol)
     if BW is not None:
         output = _bpf_on_grid(output, BW, grid, device)
     output.execution_time = time.time() - t0

@@ -789,34 +789,125 @@ def test_dac_golden(golden_dir, name):
     assert relmax(y.signal, g["out"]) < 1e-12
 
 
-def test_transmitter_stays_on_the_device():
-    """DAC hands its result over in GPU memory, MZM multiplies it onto the carrier there: same numbers as the host
-    arithmetic (to the last bits of cos / sin), nothing downloaded before the fibre output is read."""
+def test_laser_and_mzm_against_golden(golden_dir):
+    """LASER and MZM are HIP kernels in the reference's order of operations: against the reference's own vectors they
+    differ by the last bits of cos / sin / sqrt (device math library against NumPy's)."""
+    from cases import case_drive
+    from opticomlib_amd.typing import electrical_signal
+    for name, case in CASES.items():
+        if case["func"] not in ("LASER", "MZM") or case["kw"].get("BW"):
+            continue
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        gv(**case["gv"])
+        if case["func"] == "LASER":
+            if "np_seed" in case:
+                np.random.seed(case["np_seed"])
+            y = oa.LASER(**case["kw"])
+            assert y.on_device and y.n_pol == 1 and y.noise is NULL and y.signal.dtype == g["out"].dtype
+            assert relmax(y.signal, g["out"]) < 1e-14
+            continue
+        sig, noi = case_input(case)
+        v, vn = case_drive(case)
+        x = optical_signal(sig) if noi is None else optical_signal(sig, noi)
+        y = oa.MZM(x, v if vn is None else electrical_signal(v, vn), **case["kw"])
+        assert y.signal.shape == g["out"].shape and relmax(y.signal, g["out"]) < 1e-14
+        if "out_noise" in g:
+            assert relmax(y.noise, g["out_noise"]) < 1e-14
+        else:
+            assert y.noise is NULL
+        np.testing.assert_array_equal(x.signal, sig)                  # the input is not modified
+    # CW laser: exact (one sqrt on the host, a fill on the device); scalar and integer drives are spread / cast
+    gv(sps=16, R=10e9, N=64)
+    cw = oa.LASER(P0=10)
+    np.testing.assert_array_equal(cw.signal, np.full(1024, np.sqrt(10 ** (10 / 10 - 3))))
+    k, loss = np.pi / 2 / 5.0, 10 ** (-0.3)
+    for drive in (1.25, np.arange(1024) % 3, np.linspace(0, 5, 1024) + 0.1j):
+        got = oa.MZM(cw, drive, bias=0.5, loss_dB=3).signal
+        gt = k * (np.asarray(drive) + 0.5)
+        want = cw.signal * (loss ** 0.5 * (np.cos(gt) + 1j * (2 * (10 ** -2.6) ** 0.5) / 2 * np.sin(gt)))
+        assert relmax(got, want) < 1e-14
+    with pytest.raises(ValueError):
+        oa.MZM(cw, np.ones(100))                                      # lengths that do not broadcast
+    # all options of the laser at 2^20 samples, seeded: same draws as the oracle
+    from oracle import transmitter_numpy as tx
+    gv(sps=16, R=10e9, N=1 << 16)
+    np.random.seed(5); got = oa.LASER(P0=3, lw=1e5, rin=-150, df=2e9).signal
+    np.random.seed(5); want = tx.laser(gv.t, gv.dt, gv.fs, 3, lw=1e5, rin=-150, df=2e9)
+    assert got.dtype == want.dtype == np.complex128 and relmax(got, want) < 1e-13
+
+
+def test_device_pulses_match_the_reference_expressions():
+    """ssfm_load_pulse: the DAC's built-in pulses generated in GPU memory.  The time grid is NumPy's linspace bit for
+    bit (the rectangular pulse is therefore exact); the others differ by the last bits of exp / sin / cos."""
+    from oracle import transmitter_numpy as tx
     from opticomlib_amd import devices as od
+    plan = od.get_plan(1 << 16, 1, _lib.C128, 0)
+
+    def device_pulse(spec):
+        npts = spec[0][1]
+        plan.load_pulse(*spec[0])
+        out = _lib.DeviceArray((1 << 16,), np.complex128, 0)
+        plan.copy_from_field(0, out.ptr, (1 << 16) * 16)
+        h = out.to_host()
+        assert not h[npts:].any()                                  # zero-padded
+        return (h if spec[1] else h.real)[:npts], h[:npts].imag
+
+    for span, sps in ((4, 16), (7, 9), (1020, 32), (4092, 16), (60, 1000)):
+        for T in (1, 2):
+            got, im = device_pulse(od._nrz_spec(span, sps, T))
+            np.testing.assert_array_equal(got, tx.nrz_pulse(span, sps, T)); assert not im.any()
+        for T, m, c in ((1, 1, 0.0), (2, 1, 0.5), (1, 2, 0.0), (1, 3, 0.0), (2, 1, -0.8)):
+            got, _ = device_pulse(od._gauss_spec(span, sps, T=T, m=m, c=c))
+            want = tx.gauss_pulse(span, sps, T=T, m=m, c=c)
+            assert got.dtype == want.dtype == np.complex128
+            # exp amplifies the last bit of its argument by |argument| (NumPy's own complex square is SIMD-dependent
+            # in that bit): a relative bound that grows with -ln|pulse|, i.e. 1e-15 at the peak, 3e-13 at 1e-300
+            mag = np.abs(want)
+            assert np.all(np.abs(got - want) <= 4e-16 * (2 + np.abs(np.log(mag + 1e-320))) * mag + 1e-300)
+        for beta in (0.0, 0.05, 0.25, 0.5, 1.0, 1 / 3):
+            for shape in ("normal", "sqrt"):
+                got, im = device_pulse(od._rcos_spec(beta, span, sps, shape))
+                want = tx.rcos_pulse(beta, span, sps, shape)
+                # unit-peak pulses compared on their own scale: next to the removable singularities (1 - (2 beta t)^2 -> 0,
+                # cos -> 0) the quotient amplifies the last bit of NumPy's SIMD cos / sin by 1/den (seen: 2e-14)
+                np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13); assert not im.any()
+    with pytest.raises(_lib.SsfmError):
+        plan.load_pulse(7, 10, 0.0, 1.0, 9.0, 0, [])
+    with pytest.raises(_lib.SsfmError):
+        plan.load_pulse(1, 10, 0.0, 1.0, 9.0, 3, [1.0, 0.0])
+    with pytest.raises(_lib.SsfmError):
+        plan.load_pulse(0, (1 << 16) + 1, 0.0, 1.0, 9.0, 0, [-0.5, 0.5])
+
+
+def test_transmitter_stays_on_the_device():
+    """LASER and DAC leave their results in GPU memory, MZM multiplies them there, FIBER takes the product from there:
+    nothing is downloaded before somebody reads a result, and the numbers are the oracle's (to the last bits of cos / sin)."""
+    from oracle import transmitter_numpy as tx
     gv(sps=16, R=10e9, N=256)
     bits = oa.PRBS(9, len=256)
+    rng = np.random.default_rng(2)
+    amp = np.sqrt(10 ** (3 / 10 - 3))
+    c2_sig, c2_noi = np.stack([np.full(4096, amp), np.full(4096, 0.5 * amp)]).astype(complex), 1e-3 * (rng.standard_normal((2, 4096)) + 0j)
+    carrier2 = optical_signal(c2_sig, c2_noi)
     before = dict(_lib.TRANSFERS)
     drive = oa.DAC(bits, Vpp=5.0, offset=-2.5, pulse_shape="gaussian")
     drive_r = oa.DAC(bits, Vpp=2.0, pulse_shape="nrz", coupling="AC")
     assert isinstance(drive._raw("signal"), _lib.DeviceArray) and drive._raw("signal").dtype == np.complex128
     assert isinstance(drive_r._raw("signal"), _lib.DeviceArray) and drive_r._raw("signal").dtype == np.float64
     cw = oa.LASER(P0=3)
-    rng = np.random.default_rng(2)
-    carrier2 = optical_signal(np.stack([cw.signal, 0.5 * cw.signal]).astype(complex), 1e-3 * (rng.standard_normal((2, cw.size)) + 0j))
+    assert cw.on_device and cw._raw("signal").dtype == np.float64
     m1 = oa.MZM(cw, drive, bias=-2.5, Vpi=5.0, loss_dB=3)
     m2 = oa.MZM(carrier2, drive_r, bias=0.3, Vpi=4.0, ER_dB=30, pol="y")
     y = oa.FIBER(m1, length=10, h=1.0, **workloads.SMF)
-    assert m1.on_device and m2.on_device and y.on_device
+    f = oa.BPF(cw, 20e9)
+    assert m1.on_device and m2.on_device and y.on_device and f.on_device
     assert _lib.TRANSFERS["d2h"] == before["d2h"]
-    old = od.KEEP_ON_DEVICE
-    od.KEEP_ON_DEVICE = False
-    try:
-        h1 = oa.MZM(cw, drive.signal, bias=-2.5, Vpi=5.0, loss_dB=3)
-        h2 = oa.MZM(carrier2, drive_r.signal, bias=0.3, Vpi=4.0, ER_dB=30, pol="y")
-    finally:
-        od.KEEP_ON_DEVICE = old
-    assert relmax(m1.signal, h1.signal) < 1e-14
-    assert relmax(m2.signal, h2.signal) < 1e-14 and relmax(m2.noise, h2.noise) < 1e-14 and not m2.signal[0].any()
+    w1, _ = tx.mzm(np.full(4096, amp), None, tx.dac(bits.data, 16, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5), None, gv.fs, bias=-2.5, Vpi=5.0, loss_dB=3)
+    w2, w2n = tx.mzm(c2_sig, c2_noi, tx.dac(bits.data, 16, gv.fs, pulse_shape="nrz", Vpp=2.0, coupling="AC"), None, gv.fs, bias=0.3, Vpi=4.0, ER_dB=30, pol="y")
+    assert relmax(m1.signal, w1) < 1e-14
+    assert relmax(m2.signal, w2) < 1e-14 and relmax(m2.noise, w2n) < 1e-14 and not m2.signal[0].any()
+    assert f.signal.dtype == np.float64 and relmax(f.signal, np.full(4096, amp)) < 1e-12     # a real envelope stays real through the filter
+    assert relmax(y.signal, orc.fiber_c64(w1, gv.dt, length=10, h=1.0, **workloads.SMF)) < 2e-5
 
 
 def test_dac_inputs_errors_and_long_sequence():

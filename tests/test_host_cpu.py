@@ -291,33 +291,11 @@ def test_prbs_errors_and_warning():
     assert oa.PRBS(7).size == 127
 
 
-# ------------------------------------------------------------------ LASER / MZM without a filter: host arithmetic
-def test_laser_and_mzm_against_golden(golden_dir):
+# ------------------------------------------------------------------ LASER / MZM: argument checks (the arithmetic is HIP: tests/test_gpu_parity.py)
+def test_laser_and_mzm_argument_checks_and_no_cpu_path():
     import opticomlib_amd as oa
-    from cases import CASES, case_drive, case_input
-    from opticomlib_amd.typing import NULL, electrical_signal, gv, optical_signal
-    for name, case in CASES.items():
-        if case["func"] not in ("LASER", "MZM") or case["kw"].get("BW"):
-            continue
-        g = np.load(os.path.join(golden_dir, name + ".npz"))
-        gv(**case["gv"])
-        if case["func"] == "LASER":
-            if "np_seed" in case:
-                np.random.seed(case["np_seed"])
-            y = oa.LASER(**case["kw"])
-            assert y.n_pol == 1 and y.noise is NULL and y.signal.dtype == g["out"].dtype
-            np.testing.assert_array_equal(y.signal, g["out"])
-            continue
-        sig, noi = case_input(case)
-        v, vn = case_drive(case)
-        x = optical_signal(sig) if noi is None else optical_signal(sig, noi)
-        y = oa.MZM(x, v if vn is None else electrical_signal(v, vn), **case["kw"])
-        np.testing.assert_array_equal(y.signal, g["out"])
-        if "out_noise" in g:
-            np.testing.assert_array_equal(y.noise, g["out_noise"])
-        else:
-            assert y.noise is NULL
-        np.testing.assert_array_equal(x.signal, sig)                  # the input is not modified
+    from opticomlib_amd import _lib
+    from opticomlib_amd.typing import gv, optical_signal
     gv(sps=16, R=10e9, N=64)
     assert gv.t.size == 1024 and gv.N == 64
     with pytest.raises(TypeError, match="`op_input` must be of type 'optical_signal'."):
@@ -326,6 +304,11 @@ def test_laser_and_mzm_against_golden(golden_dir):
         oa.MZM(optical_signal(np.ones(8, complex)), 1.0, pol="z")
     with pytest.raises(ValueError, match="Nyquist"):
         oa.LASER(P0=0, df=1e12)
+    if _lib.device_count() == 0:                                      # no GPU: no silent host arithmetic either
+        with pytest.raises(_lib.SsfmError):
+            oa.LASER(P0=0)
+        with pytest.raises(_lib.SsfmError):
+            oa.MZM(optical_signal(np.ones(8, complex)), np.ones(8))
 
 
 def test_optical_signal_algebra():
