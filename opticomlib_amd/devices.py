@@ -637,7 +637,8 @@ def BPF(input: optical_signal, BW: float, n: int = 4, *, device=None):
 # ----------------------------------------------------------------------------- receiver front-end
 # SURVEY.md 8(f) rank 2.  The random currents / fields are drawn on the host from the GLOBAL np.random
 # generator with the reference's calls in the reference's order, so a script that seeds np.random gets the
-# same realisation from either library; the O(N) arithmetic (square law, zero-phase filters) runs on the GPU.
+# same realisation from either library, and uploaded; all arithmetic (square law, gain, the sums, the zero-phase
+# filters) runs on the GPU and the results stay there.
 # rng="device": the library's Philox4x32-10 generator (csrc/device_mem.hip) instead of NumPy's global one -- no
 # seed-for-seed parity with the reference then, only its statistics, but nothing leaves the GPU.  Every draw
 # takes the next stream of the current seed; `device_rng_seed` restarts the sequence (default: OS entropy).
@@ -703,66 +704,39 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
         raise TypeError("`include_noise` must be a string.")
     mode = include_noise.lower()
     _check_rng(rng)
-    dev = default_device() if device is None else int(device)
-    raw_s, raw_n = input._raw("signal"), input._raw("noise")
-    has_ase = raw_n is not NULL
-    if mode == "none" and (_on_device(raw_s) or _on_device(raw_n)):
-        # nothing random to add: detector and filter back to back on the device
-        v, _ = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), None, r, post=R_load)
-        output = LPF(electrical_signal.from_device(v), BW, fs=grid.fs, device=dev)
-        output.execution_time = time.time() - t0
-        return back(output)
-    if rng == "device" and mode in _PD_MODES and mode != "none":
-        ds, dn = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), _dev_array(raw_n, np.complex128, dev) if has_ase else None, r)
-        d_T = d_N = None
-        if "thermal" in mode or mode == "all":
-            d_T = _device_randn(ds.shape, (4 * kB * T * grid.fs / 2 * _idb(Fn) / R_load) ** 0.5, np.float64, dev)
-        if "shot" in mode or mode == "all":
-            mean = _lib.mean_device(ds, dn if has_ase else None)
-            d_N = _device_randn(ds.shape, (2 * e * (mean + i_dark) * grid.fs / 2) ** 0.5, np.float64, dev)
-        d_ase = dn if (has_ase and ("ase" in mode or mode == "all")) else None
-        if d_ase is None and d_T is None and d_N is None:          # 'ase-only' on a noiseless input: dark current alone
-            d_N = _lib.randn_device(ds.shape, 0.0, 0, 0, np.float64, dev)
-        v_noise = _lib.sum3_device(d_ase, d_N, d_T, i_dark, R_load, ds)
-        v_sig = _lib.sum3_device(ds, None, None, 0.0, R_load, ds)
-        output = LPF(electrical_signal.from_device(v_sig, v_noise), BW, fs=grid.fs, device=dev)
-        output.execution_time = time.time() - t0
-        return back(output)
-    if _on_device(raw_s) or _on_device(raw_n):            # the field is already in HBM: only the currents come back
-        ds, dn = _lib.square_law_device(_dev_array(raw_s, np.complex128, dev), _dev_array(raw_n, np.complex128, dev) if has_ase else None, r)
-        i_sig, i_ase = ds.to_host(), (dn.to_host() if has_ase else None)
-    else:
-        i_sig, i_ase = _lib.square_law(raw_s, raw_n if has_ase else None, r, dev)
-    size = input.size
-    i_T = i_N = None
-    if "thermal" in mode or "all" in mode:
-        S_T = 4 * kB * T * grid.fs / 2 * _idb(Fn) / R_load
-        i_T = np.random.normal(0, S_T ** 0.5, size)
-    if "shot" in mode or "all" in mode:
-        mean = (i_sig + i_ase if has_ase else i_sig).mean()
-        S_N = 2 * e * (mean + i_dark) * grid.fs / 2
-        i_N = np.random.normal(0, S_N ** 0.5, size)
     if mode not in _PD_MODES:
         raise ValueError("The argument `include_noise` must be one of the following: 'ase-only','thermal-only','shot-only',"
                          "'ase-thermal','ase-shot','thermal-shot','all', 'none'.")
-    i_noise = NULL
-    if mode != "none":
-        terms = []
-        if "ase" in mode or mode == "all":
-            terms.append(i_ase if has_ase else NULL)
-        if mode in ("all", "ase-shot", "shot-only"):
-            terms.append(i_N)
-        if "thermal" in mode or mode == "all":
-            terms.append(i_T)
-        if mode == "thermal-shot":
-            terms.append(i_N)
-        for t in terms:
-            i_noise = i_noise + t
-        i_noise = i_noise + i_dark
-        if np.ndim(i_noise) == 0:                      # 'ase-only' on a noiseless input: dark current alone
-            i_noise = np.full(size, float(i_noise))
-    output = electrical_signal(i_sig * R_load, NULL if i_noise is NULL else i_noise * R_load)
-    output = LPF(output, BW, fs=grid.fs, device=dev)
+    dev = default_device() if device is None else int(device)
+    raw_s, raw_n = input._raw("signal"), input._raw("noise")
+    has_ase = raw_n is not NULL
+    sig_d = _dev_array(raw_s, np.complex128, dev)
+    if mode == "none":
+        # nothing random to add: detector and filter back to back
+        v, _ = _lib.square_law_device(sig_d, None, r, post=R_load)
+        output = LPF(electrical_signal.from_device(v), BW, fs=grid.fs, device=dev)
+        output.execution_time = time.time() - t0
+        return back(output)
+    # photocurrents r |E|^2 (signal) and the signal-ASE / ASE-ASE beat terms, summed over the polarisations
+    ds, dn = _lib.square_law_device(sig_d, _dev_array(raw_n, np.complex128, dev) if has_ase else None, r)
+
+    def normal(std):
+        """Gaussian current of the given standard deviation: the device generator, or NumPy's global one with the
+        reference's call (devices.py:1521-1527) uploaded as it is."""
+        if rng == "device":
+            return _device_randn(ds.shape, std, np.float64, dev)
+        return _lib.DeviceArray.from_host(np.random.normal(0, std, input.size), np.float64, dev)
+    d_T = d_N = None
+    if "thermal" in mode or mode == "all":
+        d_T = normal((4 * kB * T * grid.fs / 2 * _idb(Fn) / R_load) ** 0.5)
+    if "shot" in mode or mode == "all":
+        mean = _lib.mean_device(ds, dn if has_ase else None)
+        d_N = normal((2 * e * (mean + i_dark) * grid.fs / 2) ** 0.5)
+    d_ase = dn if (has_ase and ("ase" in mode or mode == "all")) else None
+    # (ase + shot) + thermal + dark current, times the load: the reference's order of additions (devices.py:1530-1549)
+    v_noise = _lib.sum3_device(d_ase, d_N, d_T, i_dark, R_load, ds)       # all three absent ('ase-only', noiseless input): dark current alone
+    v_sig = _lib.sum3_device(ds, None, None, 0.0, R_load, ds)
+    output = LPF(electrical_signal.from_device(v_sig, v_noise), BW, fs=grid.fs, device=dev)
     output.execution_time = time.time() - t0
     return back(output)
 
@@ -779,40 +753,28 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
         raise TypeError("`input` must be of type 'optical_signal'.")
     _check_rng(rng)
     g = np.sqrt(_idb(G))
-    if rng == "device":
-        # gain, ASE loading and the optical filter without leaving the GPU (statistics of the reference, not its draws)
-        dev = default_device() if device is None else int(device)
-        raw_s, raw_n = input._raw("signal"), input._raw("noise")
-        n = input.size
+    # gain, ASE loading and the optical filter on the GPU; only the source of the Gaussian field differs with `rng`
+    dev = default_device() if device is None else int(device)
+    raw_s, raw_n = input._raw("signal"), input._raw("noise")
+    n = input.size
 
-        def two_rows(a):                                  # (N,) -> (2, N) with an empty y polarisation; (2, N) as it is
-            d = _dev_array(a, np.complex128, dev)
-            if d.ndim == 2:
-                return _lib.scale_add_device(d, g)
-            out2 = _lib.randn_device((2, n), 0.0, 0, 0, np.complex128, dev)          # zeros
-            x = _lib.scale_add_device(d, g)
-            _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(out2.ptr), _lib._VP(x.ptr), n * 16, 2), "ssfm_device_copy")
-            return out2
-        sig = two_rows(raw_s)
-        P_ase = _idb(NF) * h * grid.f0 * (_idb(G) - 1) * grid.fs
-        ase = _device_randn((2, n), np.sqrt(P_ase / 4), np.complex128, dev)
-        noi = ase if raw_n is NULL else two_rows(raw_n) + ase
-        output = optical_signal.from_device(sig, noi, n_pol=2)
-        if BW is not None:
-            output = _bpf_on_grid(output, BW, grid, device)
-        output.execution_time = time.time() - t0
-        return back(output)
-    output = optical_signal(input.signal, input.noise, n_pol=2)
-    sig = output.signal * g
-    noi = NULL if output.noise is NULL else output.noise * g
-    if input.n_pol == 1:
-        sig[1] = np.zeros_like(sig[0])
-        if noi is not NULL:
-            noi[1] = np.zeros_like(noi[0])
+    def two_rows(a):                                      # (N,) -> (2, N) with an empty y polarisation; (2, N) as it is
+        d = _dev_array(a, np.complex128, dev)
+        if d.ndim == 2:
+            return _lib.scale_add_device(d, g)
+        out2 = _lib.randn_device((2, n), 0.0, 0, 0, np.complex128, dev)          # zeros
+        x = _lib.scale_add_device(d, g)
+        _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(out2.ptr), _lib._VP(x.ptr), n * 16, 2), "ssfm_device_copy")
+        return out2
+    sig = two_rows(raw_s)
     P_ase = _idb(NF) * h * grid.f0 * (_idb(G) - 1) * grid.fs
-    ase = np.sqrt(P_ase / 4) * np.random.randn(4, input.size)
-    ase = ase[:2] + 1j * ase[2:]
-    output = optical_signal(sig, noi + ase, n_pol=2)
+    if rng == "device":
+        ase = _device_randn((2, n), np.sqrt(P_ase / 4), np.complex128, dev)
+    else:                                                 # the reference's draws (devices.py:930-931), uploaded as they are
+        draws = np.sqrt(P_ase / 4) * np.random.randn(4, n)
+        ase = _lib.DeviceArray.from_host(draws[:2] + 1j * draws[2:], np.complex128, dev)
+    noi = ase if raw_n is NULL else two_rows(raw_n) + ase
+    output = _wrap_out(optical_signal, sig, noi, n_pol=2)
     if BW is not None:
         output = _bpf_on_grid(output, BW, grid, device)
     output.execution_time = time.time() - t0
