@@ -42,7 +42,10 @@ namespace {
 
 constexpr int kChunk = 16;         // samples per thread (measured at 2^20 x 2 complex: 16 -> 121 us, 32 -> 130 us, 64 -> 158 us per call)
 constexpr int kWave = 64;          // lanes per wavefront
-constexpr int kWaves = 4;          // wavefronts per workgroup
+#ifndef SOS_WAVES
+#define SOS_WAVES 4
+#endif
+constexpr int kWaves = SOS_WAVES;  // wavefronts per workgroup (measured, BPF 2^20 x 2 complex: 4 -> 97 us, 2 -> 95 us, 1 -> 131 us per call)
 constexpr int kGroup = kWave * kWaves;   // chunks per group = threads per workgroup
 constexpr int kMaxSections = 4;    // Bessel orders up to 8
 
