@@ -1267,6 +1267,41 @@ def test_symmetries_shift_and_global_phase(prec, tol):
     assert relmax(yp, y * ph) < tol
 
 
+def test_gaussian_broadening_and_soliton_closed_forms():
+    """Analytic solutions of the equation the fibre solves (not taken from the reference): a Gaussian pulse in a linear
+    dispersive fibre, A(z,t) = T0/sqrt(q) exp(-t^2 / 2q), q = T0^2 - j beta_2 z; the fundamental soliton
+    sqrt(P0) sech(t/T0) with gamma P0 T0^2 = |beta_2|, which only acquires the phase gamma P0 z / 2 -- reproduced with
+    the second-order accuracy of the symmetric split step; and energy conservation without attenuation."""
+    N, dt = 1 << 14, 0.5e-12
+    gv(sps=16, R=1 / (16 * dt))
+    assert gv.dt == pytest.approx(dt, rel=1e-12)
+    t = (np.arange(N) - N // 2) * gv.dt * 1e12                     # ps
+    T0, b2, g = 10.0, -21.7, 1.3
+    q = T0 ** 2 - 1j * b2 * 20.0
+    pulse = np.exp(-t ** 2 / (2 * T0 ** 2)).astype(complex)
+    want = T0 / np.sqrt(q) * np.exp(-t ** 2 / (2 * q))
+    for prec, tol in (("complex128", 1e-12), ("complex64", 5e-6)):
+        got = oa.FIBER(optical_signal(pulse), length=20.0, h=1.0, beta_2=b2, precision=prec).signal
+        assert np.max(np.abs(got - want)) < tol
+        got = oa.FIBER(optical_signal(pulse), length=20.0, beta_2=b2, precision=prec).signal      # adaptive: one step
+        assert np.max(np.abs(got - want)) < tol
+    assert np.max(np.abs(oa.DM(optical_signal(pulse), D=b2 * 20.0).signal - want)) < 1e-12
+    P0 = abs(b2) / (g * T0 ** 2)
+    sol = (np.sqrt(P0) / np.cosh(t / T0)).astype(complex)
+    want = sol * np.exp(1j * g * P0 * 10.0 / 2)
+    err = {}
+    for h in (0.1, 0.05):
+        got = oa.FIBER(optical_signal(sol), length=10.0, h=h, beta_2=b2, gamma=g, precision="complex128").signal
+        err[h] = np.max(np.abs(got - want)) / np.sqrt(P0)
+        assert abs(np.sum(np.abs(got) ** 2) / np.sum(np.abs(sol) ** 2) - 1) < 1e-12
+    assert err[0.1] < 2e-4 and 3.5 < err[0.1] / err[0.05] < 4.5    # second order in the step size
+    got = oa.FIBER(optical_signal(sol), length=10.0, h=0.05, beta_2=b2, gamma=g).signal
+    assert np.max(np.abs(got - want)) / np.sqrt(P0) < 2e-4 and abs(np.sum(np.abs(got) ** 2) / np.sum(np.abs(sol) ** 2) - 1) < 1e-4
+    back = oa.DBP(oa.FIBER(optical_signal(sol), length=10.0, h=0.05, beta_2=b2, gamma=g, precision="complex128"),
+                  length=10.0, h=0.05, beta_2=b2, gamma=g, precision="complex128").signal
+    assert np.max(np.abs(back - sol)) / np.sqrt(P0) < 1e-4          # back-propagation undoes the fibre (to the splitting error)
+
+
 def test_linearity_without_kerr_effect():
     """gamma = 0: the fibre is linear -- FIBER(a x1 + b x2) = a FIBER(x1) + b FIBER(x2)."""
     gv(**workloads.BENCH_GV)
