@@ -23,6 +23,12 @@
  *   devices.py:1363-1368, :814-823 (LPF / BPF:     ssfm_sosfiltfilt, ssfm_sosfiltfilt_device
  *     scipy.signal.sosfiltfilt)
  *   devices.py:1512-1515 (PD: r * |x|^2, pol sum)  ssfm_square_law, ssfm_square_law_device
+ *   devices.py:1521-1549, :930-936 (PD / EDFA      ssfm_device_randn (rng = "device"), _mean, _sum3, _scale_add
+ *     noise currents, gain and ASE loading)
+ *   numpy.fft of any N (devices.py:1178-1180)      ssfm_chirp_pre / _mid / _post on a power-of-two plan
+ *   utils.py:1791-1981 (DAC: pulses, upfir)        ssfm_load_pulse / _load_padded / _load_symbols, ssfm_table_from_field,
+ *                                                  ssfm_apply_table, ssfm_device_axpb / _real
+ *   devices.py:480-510 (LASER), :762-778 (MZM)     ssfm_laser (+ ssfm_device_cumsum / _min), ssfm_mzm
  *   (none: NumPy arrays are the reference's only   ssfm_device_alloc / _free / _copy / _convert / _add
  *     data format)                                 -- device-resident signals between calls
  *
@@ -171,6 +177,9 @@ int ssfm_device_randn(int device, double* out_dev, int64_t n, uint64_t seed, uin
 int ssfm_device_sum3(int device, double* out_dev, const double* a, const double* b, const double* c, double offset, double scale, int64_t n);
 int ssfm_device_scale_add(int device, double* dst, const double* a, double factor, const double* b, int64_t n);
 int ssfm_device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out);
+/* dst = running sum of src (numpy.cumsum; the laser's Wiener phase, devices.py:490) and the minimum of a, n float64 on the DEVICE. */
+int ssfm_device_cumsum(int device, double* dst, const double* src, int64_t n);
+int ssfm_device_min(int device, const double* a, int64_t n, double* min_out);
 /* Elementwise transmitter work on DEVICE arrays (csrc/transmitter.hip), synchronous:
  * ssfm_mzm: the Mach-Zehnder transfer of devices.py:762-778 -- g = k (drive + bias) [+ k drive_noise], h = sqrt_loss (cos g +
  *   j half_eta sin g), out = in * h for signal and (nullable) noise, n_pol x n complex128; polarisation `dead_pol` of a

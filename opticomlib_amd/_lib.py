@@ -48,6 +48,8 @@ SYMBOLS = {
     "ssfm_device_sum3": (_I, [_I, _VP, _VP, _VP, _VP, _D, _D, _I64]),
     "ssfm_device_scale_add": (_I, [_I, _VP, _VP, _D, _VP, _I64]),
     "ssfm_device_mean": (_I, [_I, _VP, _VP, _I64, C.POINTER(_D)]),
+    "ssfm_device_cumsum": (_I, [_I, _VP, _VP, _I64]),
+    "ssfm_device_min": (_I, [_I, _VP, _I64, C.POINTER(_D)]),
     "ssfm_mzm": (_I, [_I, _VP, _VP, _VP, _VP, _I, _I64, _VP, _VP, _I, _D, _D, _D, _D, _I]),
     "ssfm_device_axpb": (_I, [_I, _VP, _VP, _D, _D, _I64, _I]),
     "ssfm_device_real": (_I, [_I, _VP, _VP, _I64]),
@@ -313,6 +315,19 @@ def mzm_device(sig: DeviceArray, noise, drive: DeviceArray, drive_noise, k, bias
     _check(load().ssfm_mzm(sig.device, _VP(out_s.ptr), p(out_n), _VP(sig.ptr), p(noise), n_pol, n, _VP(drive.ptr), p(drive_noise),
                            int(drive.dtype.kind == "c"), float(k), float(bias), float(sqrt_loss), float(half_eta), int(dead_pol)), "ssfm_mzm")
     return out_s, out_n
+
+
+def cumsum_device(a: DeviceArray) -> DeviceArray:
+    """``numpy.cumsum`` of a 1-D float64 device array."""
+    out = DeviceArray(a.shape, np.float64, a.device)
+    _check(load().ssfm_device_cumsum(a.device, _VP(out.ptr), _VP(a.ptr), a.size), "ssfm_device_cumsum")
+    return out
+
+
+def min_device(a: DeviceArray) -> float:
+    m = C.c_double()
+    _check(load().ssfm_device_min(a.device, _VP(a.ptr), a.size, C.byref(m)), "ssfm_device_min")
+    return float(m.value)
 
 
 def laser_device(n: int, amp: float, phase, rin, w, step: float, stop: float, device: int = 0) -> DeviceArray:

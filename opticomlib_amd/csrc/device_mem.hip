@@ -51,6 +51,79 @@ __global__ __launch_bounds__(256) void k_add(T* __restrict__ dst, const T* __res
 }
 unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
+
+// Running sum (numpy.cumsum) of n doubles in three launches: every workgroup scans a tile of 256 x 16 samples and
+// leaves its total; one workgroup turns the totals into offsets; the offsets are added.  A thread sums its 16
+// samples in order, the tile's 256 partial sums are scanned through LDS (Hillis-Steele), so the additions are grouped
+// differently from NumPy's left-to-right loop: equal to rounding (~1e-16 of the largest partial sum per level).
+constexpr int kScanItems = 16;
+constexpr int kScanTile = 256 * kScanItems;
+
+__device__ __forceinline__ double block_exclusive_scan(double v, double* lds, double* total) {
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const double add = t >= o ? lds[t - o] : 0.0;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    if (total) *total = lds[255];
+    return lds[t] - v;
+}
+
+__global__ __launch_bounds__(256) void k_cumsum_tiles(const double* __restrict__ src, double* __restrict__ dst, long long n, double* __restrict__ totals) {
+    __shared__ double lds[256];
+    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    double x[kScanItems], run = 0.0;
+    for (int k = 0; k < kScanItems; ++k) {
+        x[k] = base + k < n ? src[base + k] : 0.0;
+        run += x[k];
+        x[k] = run;
+    }
+    double total;
+    const double before = block_exclusive_scan(run, lds, &total);
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) dst[base + k] = before + x[k];
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_cumsum_totals(double* __restrict__ totals, int ntiles) {      // one workgroup: exclusive scan in place
+    __shared__ double lds[256];
+    __shared__ double carry_s;
+    if (threadIdx.x == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int b0 = 0; b0 < ntiles; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const double v = i < ntiles ? totals[i] : 0.0;
+        double total;
+        const double before = block_exclusive_scan(v, lds, &total);
+        const double carry = carry_s;
+        __syncthreads();
+        if (i < ntiles) totals[i] = carry + before;
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cumsum_add(double* __restrict__ dst, long long n, const double* __restrict__ offsets) {
+    const double off = offsets[blockIdx.x];
+    const long long base = (long long)blockIdx.x * kScanTile;
+    for (int k = threadIdx.x; k < kScanTile; k += 256)
+        if (base + k < n) dst[base + k] += off;
+}
+
+__global__ __launch_bounds__(256) void k_min(const double* __restrict__ a, long long n, double* __restrict__ partial) {
+    double m = __builtin_inf();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmin(m, a[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
+    __shared__ double w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = fmin(fmin(w[0], w[1]), fmin(w[2], w[3]));
+}
+
 }  // namespace
 
 extern "C" int ssfm_device_alloc(int device, size_t bytes, void** out) {
@@ -259,5 +332,40 @@ extern "C" int ssfm_device_mean(int device, const double* a, const double* b, in
     double acc = 0.0;
     for (int i = 0; i < kBlocks; ++i) acc += host[i];
     *mean_out = acc / (double)n;
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_cumsum(int device, double* dst, const double* src, int64_t n) {
+    if (!dst || !src || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_cumsum: bad argument");
+    if (int rc = use(device)) return rc;
+    const int ntiles = (int)((n + kScanTile - 1) / kScanTile);
+    double* totals = nullptr;
+    HIP_TRY(hipMalloc(&totals, sizeof(double) * ntiles));
+    hipLaunchKernelGGL(k_cumsum_tiles, dim3(ntiles), dim3(256), 0, 0, src, dst, (long long)n, totals);
+    if (ntiles > 1) {
+        hipLaunchKernelGGL(k_cumsum_totals, dim3(1), dim3(256), 0, 0, totals, ntiles);
+        hipLaunchKernelGGL(k_cumsum_add, dim3(ntiles), dim3(256), 0, 0, dst, (long long)n, totals);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(totals);
+    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_cumsum: %s", hipGetErrorString(e));
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_min(int device, const double* a, int64_t n, double* min_out) {
+    if (!a || !min_out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_min: bad argument");
+    if (int rc = use(device)) return rc;
+    constexpr int kBlocks = 1024;
+    double* partial = nullptr;
+    HIP_TRY(hipMalloc(&partial, sizeof(double) * kBlocks));
+    hipLaunchKernelGGL(k_min, dim3(kBlocks), dim3(256), 0, 0, a, (long long)n, partial);
+    double host[kBlocks];
+    hipError_t e = hipMemcpy(host, partial, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(partial);
+    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_min: %s", hipGetErrorString(e));
+    double m = host[0];
+    for (int i = 1; i < kBlocks; ++i) m = host[i] < m ? host[i] : m;
+    *min_out = m;
     return SSFM_OK;
 }

@@ -669,7 +669,7 @@ _DEVICE_RNG = {"seed": int.from_bytes(os.urandom(8), "little"), "stream": 0}
 
 
 def device_rng_seed(seed: int):
-    """Seed the device generator used by ``PD`` / ``EDFA`` with ``rng="device"``."""
+    """Seed the device generator used by ``PD`` / ``EDFA`` / ``LASER`` with ``rng="device"``."""
     _DEVICE_RNG["seed"], _DEVICE_RNG["stream"] = int(seed), 0
 
 
@@ -1014,23 +1014,36 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
 # Elementwise HIP kernels (csrc/transmitter.hip) in the reference's own order of operations; the laser's random
 # increments are drawn from NumPy's global generator with the reference's calls, so a seeded script gets the same laser
 # noise.  They complete the transmitter chain PRBS -> DAC -> MZM(LASER) in front of FIBER, which stays in GPU memory.
-def LASER(P0: float, lw: float = None, rin: float = None, df: float = None, *, device=None) -> optical_signal:
+def LASER(P0: float, lw: float = None, rin: float = None, df: float = None, *, device=None, rng: str = "numpy") -> optical_signal:
     """CW laser of ``P0`` dBm over ``gv.t`` (reference ``devices.py:353-510``): optional linewidth ``lw`` [Hz] (Wiener
     phase noise), relative intensity noise ``rin`` [dB/Hz] and frequency offset ``df`` [Hz]; single polarisation.
-    Real-valued (float64) unless ``lw`` or ``df`` is given, as in the reference."""
+    Real-valued (float64) unless ``lw`` or ``df`` is given, as in the reference.  ``rng`` as in :func:`PD`:
+    ``"numpy"`` draws the noise from NumPy's global generator with the reference's calls, ``"device"`` from the
+    library's Philox generator (the running sum of the phase increments is then a device scan too)."""
     t0 = time.time()
+    _check_rng(rng)
     t = gv.t
     n = t.size
     dev = default_device() if device is None else int(device)
     amp = float(np.sqrt(10 ** (P0 / 10 - 3)))
     phase = rin_noise = w = None
     if lw is not None:
-        phase = _lib.DeviceArray.from_host(np.cumsum(np.random.normal(0, np.sqrt(2 * np.pi * lw * gv.dt), n)), np.float64, dev)
+        std = np.sqrt(2 * np.pi * lw * gv.dt)
+        if rng == "device":
+            phase = _lib.cumsum_device(_device_randn((n,), std, np.float64, dev))
+        else:
+            phase = _lib.DeviceArray.from_host(np.cumsum(np.random.normal(0, std, n)), np.float64, dev)
     if rin is not None:
-        r = np.random.normal(0, np.sqrt(_idb(rin) * gv.fs), n)
-        if r.min() < -1:
+        std = np.sqrt(_idb(rin) * gv.fs)
+        if rng == "device":
+            rin_noise = _device_randn((n,), std, np.float64, dev)
+            lowest = _lib.min_device(rin_noise)
+        else:
+            r = np.random.normal(0, std, n)
+            lowest = r.min()
+            rin_noise = _lib.DeviceArray.from_host(r, np.float64, dev) if lowest >= -1 else None
+        if lowest < -1:
             raise ValueError("Noise power is to high, try decrease RIN parameter.")
-        rin_noise = _lib.DeviceArray.from_host(r, np.float64, dev)
     if df is not None:
         if np.abs(df) > gv.fs / 2:
             raise ValueError("The laser frequency is out of the Nyquist range. Try increase the sampling frequency.")

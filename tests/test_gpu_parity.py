@@ -836,6 +836,50 @@ def test_laser_and_mzm_against_golden(golden_dir):
     assert got.dtype == want.dtype == np.complex128 and relmax(got, want) < 1e-13
 
 
+def test_device_cumsum_min_and_laser_with_the_device_generator():
+    """ssfm_device_cumsum against numpy.cumsum (tile edges, one tile, many tiles), ssfm_device_min, and the laser's
+    phase / intensity noise from the device generator: the statistics of the reference's model."""
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 255, 4096, 4097, 3 * 4096 - 1, 300_000, (1 << 20) + 7, 1 << 21):
+        x = rng.standard_normal(n)
+        d = _lib.DeviceArray.from_host(x, np.float64, 0)
+        exact = np.cumsum(x.astype(np.longdouble))                   # 64-bit mantissa: the yardstick for both
+        got = _lib.cumsum_device(d).to_host()
+        scale = max(1.0, float(np.max(np.abs(exact))))
+        # the tiled scan groups the additions as a tree (error ~ log n), NumPy's loop adds left to right (~ sqrt n .. n)
+        assert np.max(np.abs(got - exact)) <= 4e-16 * scale * np.log2(n + 2)
+        assert np.max(np.abs(got - np.cumsum(x))) <= 4e-16 * scale * (np.log2(n + 2) + np.sqrt(n))
+        assert _lib.min_device(d) == x.min()
+    ones = _lib.cumsum_device(_lib.DeviceArray.from_host(np.ones(1 << 20), np.float64, 0)).to_host()
+    np.testing.assert_array_equal(ones, np.arange(1, (1 << 20) + 1, dtype=float))      # exact where the sums are exact
+    gv(sps=16, R=10e9, N=1 << 16)
+    n = gv.t.size
+    oa.device_rng_seed(7)
+    a = oa.LASER(P0=3, lw=1e6, rng="device")
+    b = oa.LASER(P0=3, lw=1e6, rng="device")
+    oa.device_rng_seed(7)
+    a2 = oa.LASER(P0=3, lw=1e6, rng="device")
+    assert a.on_device and a.signal.dtype == np.complex128
+    np.testing.assert_array_equal(a.signal, a2.signal)             # same seed, same realisation
+    assert np.max(np.abs(a.signal - b.signal)) > 1e-3               # the next draw is another one
+    amp = np.sqrt(10 ** (3 / 10 - 3))
+    assert np.max(np.abs(np.abs(a.signal) - amp)) < 1e-15           # pure phase noise
+    steps = np.diff(np.unwrap(np.angle(a.signal)))
+    var = 2 * np.pi * 1e6 * gv.dt                                    # Wiener increments of variance 2 pi lw dt
+    assert abs(steps.var() / var - 1) < 0.01 and abs(steps.mean()) < 4 * np.sqrt(var / n)
+    assert abs(np.corrcoef(steps[:-1], steps[1:])[0, 1]) < 0.01     # independent increments
+    r = oa.LASER(P0=3, rin=-150, rng="device").signal
+    assert r.dtype == np.float64
+    x = (r / amp) ** 2 - 1                                          # the intensity noise itself
+    assert abs(x.var() / (10 ** -15 * gv.fs) - 1) < 0.01 and abs(x.mean()) < 4 * np.sqrt(10 ** -15 * gv.fs / n)
+    with pytest.raises(ValueError, match="RIN"):
+        oa.LASER(P0=3, rin=-90, rng="device")
+    with pytest.raises(ValueError, match="rng"):
+        oa.LASER(P0=3, rng="cuda")
+    all3 = oa.LASER(P0=0, lw=1e5, rin=-150, df=1e9, rng="device").signal
+    assert all3.dtype == np.complex128 and abs(np.mean(np.abs(all3) ** 2) / 1e-3 - 1) < 1e-3
+
+
 def test_device_pulses_match_the_reference_expressions():
     """ssfm_load_pulse: the DAC's built-in pulses generated in GPU memory.  The time grid is NumPy's linspace bit for
     bit (the rectangular pulse is therefore exact); the others differ by the last bits of exp / sin / cos."""

@@ -23,6 +23,7 @@ timed("DAC rcos", lambda: oa.DAC(bits, Vpp=5.0, offset=-2.5, pulse_shape="rcos",
 cw = timed("LASER(P0)", lambda: oa.LASER(P0=3))
 timed("LASER(P0, df)", lambda: oa.LASER(P0=3, df=1e9))
 timed("LASER(P0, lw)", lambda: oa.LASER(P0=3, lw=1e5))
+timed("LASER(P0, lw, rin, rng=device)", lambda: oa.LASER(P0=3, lw=1e5, rin=-150, rng="device"))
 mod = timed("MZM(cw, drive)", lambda: oa.MZM(cw, drive, bias=-2.5, Vpi=5.0))
 timed("whole transmitter", lambda: oa.MZM(oa.LASER(P0=3), oa.DAC(oa.PRBS(15, len=1 << 16), Vpp=5.0, offset=-2.5, pulse_shape="gaussian"), bias=-2.5, Vpi=5.0))
 out = timed("FIBER 80 km, h = 1 km", lambda: oa.FIBER(mod, length=80, alpha=0.2, beta_2=-21.7, gamma=1.3, h=1.0))
