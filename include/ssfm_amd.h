@@ -165,6 +165,9 @@ int ssfm_square_law_device(int device, const void* sig, const void* noise, int n
 int ssfm_device_alloc(int device, size_t bytes, void** out);
 int ssfm_device_free(int device, void* ptr, size_t bytes);
 int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind);
+/* Page-locked host buffers (pooled by size) for results that are read back: the destination of a device-to-host copy. */
+int ssfm_host_alloc(size_t bytes, void** out);
+int ssfm_host_free(void* ptr, size_t bytes);
 int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
 int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
 /* Device random numbers and the few float64 array operations the receiver front-end needs around them.

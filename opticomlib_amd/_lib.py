@@ -47,6 +47,8 @@ SYMBOLS = {
     "ssfm_device_randn": (_I, [_I, _VP, _I64, C.c_uint64, C.c_uint64, _D, _D]),
     "ssfm_device_sum3": (_I, [_I, _VP, _VP, _VP, _VP, _D, _D, _I64]),
     "ssfm_device_scale_add": (_I, [_I, _VP, _VP, _D, _VP, _I64]),
+    "ssfm_host_alloc": (_I, [C.c_size_t, C.POINTER(_VP)]),
+    "ssfm_host_free": (_I, [_VP, C.c_size_t]),
     "ssfm_device_mean": (_I, [_I, _VP, _VP, _I64, C.POINTER(_D)]),
     "ssfm_device_cumsum": (_I, [_I, _VP, _VP, _I64]),
     "ssfm_device_min": (_I, [_I, _VP, _I64, C.POINTER(_D)]),
@@ -176,6 +178,39 @@ def sosfiltfilt_last_ms(device: int = 0) -> float:
 TRANSFERS = {"h2d": 0, "d2h": 0}        # counts of DeviceArray host<->device copies (tests check laziness with it)
 
 
+class _PinnedBlock:
+    """Page-locked host memory from the library's pool, exposed through the array interface: ``np.asarray(block)`` is
+    an ordinary writable NumPy array that keeps the block alive; the block returns to the pool when the array dies."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = _VP()
+        _check(load().ssfm_host_alloc(self.nbytes, C.byref(p)), "ssfm_host_alloc")
+        self.ptr = int(p.value)
+        self.__array_interface__ = {"data": (self.ptr, False), "shape": tuple(shape), "typestr": np.dtype(dtype).str, "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.ssfm_host_free(_VP(self.ptr), self.nbytes)
+            self.ptr = 0
+        except Exception:
+            pass
+
+
+def host_empty(shape, dtype) -> np.ndarray:
+    """Uninitialised array for a device-to-host copy: page-locked when that is available (no page faults, no on-the-fly
+    locking of the destination by the runtime), plain ``np.empty`` otherwise or for empty shapes."""
+    shape = tuple(int(d) for d in shape)
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if nbytes == 0 or nbytes > (256 << 20):                  # (z-resolved captures of many GiB stay pageable)
+        return np.empty(shape, dtype=dtype)
+    try:
+        return np.asarray(_PinnedBlock(shape, dtype))
+    except SsfmError:
+        return np.empty(shape, dtype=dtype)
+
+
 class DeviceArray:
     """A C-contiguous array in the HBM of one GPU: what a signal object holds between device calls.
 
@@ -226,7 +261,7 @@ class DeviceArray:
         return d
 
     def to_host(self) -> np.ndarray:
-        out = np.empty(self.shape, dtype=self.dtype)
+        out = host_empty(self.shape, self.dtype)
         _check(load().ssfm_device_copy(self.device, _ptr(out), _VP(self.ptr), self.nbytes, 1), "ssfm_device_copy")
         TRANSFERS["d2h"] += 1
         return out
@@ -395,7 +430,7 @@ class Plan:
         _check(load().ssfm_set_field(self._h, C.c_void_p(dev_ptr), 1), "ssfm_set_field")
 
     def get_field(self) -> np.ndarray:
-        out = np.empty((self.batch, self.n), dtype=self.cdtype)
+        out = host_empty((self.batch, self.n), self.cdtype)
         _check(load().ssfm_get_field(self._h, _ptr(out), 0), "ssfm_get_field")
         return out
 
@@ -494,7 +529,7 @@ class Plan:
                                       float(gamma), float(hh), None if maxbits is None else _VP(maxbits.ptr)), "ssfm_chirp_post")
 
     def debug_fft(self) -> np.ndarray:
-        out = np.empty((self.batch, self.n), dtype=self.cdtype)
+        out = host_empty((self.batch, self.n), self.cdtype)
         _check(load().ssfm_debug_fft(self._h, _ptr(out)), "ssfm_debug_fft")
         return out
 

@@ -25,6 +25,8 @@ struct Pool {
 constexpr int kMaxDevices = 64;
 constexpr size_t kMaxCachedBytes = size_t(2) << 30;        // per device
 Pool g_pool[kMaxDevices];
+Pool g_host_pool;                                          // page-locked host buffers (ssfm_host_alloc)
+constexpr size_t kMaxCachedHostBytes = size_t(1) << 30;
 
 int use(int device) {
     int count = 0;
@@ -169,6 +171,40 @@ extern "C" int ssfm_device_free(int device, void* ptr, size_t bytes) {
         }
     }
     HIP_TRY(hipFree(ptr));
+    return SSFM_OK;
+}
+
+// Page-locked host memory for results that are read back: a device-to-host copy into fresh pageable memory makes the
+// runtime lock and later unlock the destination pages (measured on the MI355X box: two 2 MiB read-backs leave the NEXT
+// transfer of the process stalled for 20 ms) and takes page faults on every first touch; into a pooled page-locked
+// buffer it is one DMA at link speed.  Pooled by size like the device buffers.
+extern "C" int ssfm_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(SSFM_ERR_INVALID, "ssfm_host_alloc: bytes=%zu", bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_host_pool.mu);
+        auto it = g_host_pool.free_by_size.find(bytes);
+        if (it != g_host_pool.free_by_size.end() && !it->second.empty()) {
+            *out = it->second.back();
+            it->second.pop_back();
+            g_host_pool.cached_bytes -= bytes;
+            return SSFM_OK;
+        }
+    }
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_host_free(void* ptr, size_t bytes) {
+    if (!ptr) return SSFM_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_host_pool.mu);
+        if (bytes > 0 && g_host_pool.cached_bytes + bytes <= kMaxCachedHostBytes) {
+            g_host_pool.free_by_size[bytes].push_back(ptr);
+            g_host_pool.cached_bytes += bytes;
+            return SSFM_OK;
+        }
+    }
+    HIP_TRY(hipHostFree(ptr));
     return SSFM_OK;
 }
 
