@@ -359,11 +359,11 @@ extern "C" int ssfm_device_mean(int device, const double* a, const double* b, in
     if (int rc = use(device)) return rc;
     constexpr int kBlocks = 1024;
     double* partial = nullptr;
-    HIP_TRY(hipMalloc(&partial, sizeof(double) * kBlocks));
+    if (int rc = ssfm_device_alloc(device, sizeof(double) * kBlocks, (void**)&partial)) return rc;
     hipLaunchKernelGGL(k_sum, dim3(kBlocks), dim3(256), 0, 0, a, b, (long long)n, partial);
     double host[kBlocks];
     hipError_t e = hipMemcpy(host, partial, sizeof(host), hipMemcpyDeviceToHost);
-    (void)hipFree(partial);
+    (void)ssfm_device_free(device, partial, sizeof(double) * kBlocks);
     if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_mean: %s", hipGetErrorString(e));
     double acc = 0.0;
     for (int i = 0; i < kBlocks; ++i) acc += host[i];
@@ -376,7 +376,7 @@ extern "C" int ssfm_device_cumsum(int device, double* dst, const double* src, in
     if (int rc = use(device)) return rc;
     const int ntiles = (int)((n + kScanTile - 1) / kScanTile);
     double* totals = nullptr;
-    HIP_TRY(hipMalloc(&totals, sizeof(double) * ntiles));
+    if (int rc = ssfm_device_alloc(device, sizeof(double) * ntiles, (void**)&totals)) return rc;
     hipLaunchKernelGGL(k_cumsum_tiles, dim3(ntiles), dim3(256), 0, 0, src, dst, (long long)n, totals);
     if (ntiles > 1) {
         hipLaunchKernelGGL(k_cumsum_totals, dim3(1), dim3(256), 0, 0, totals, ntiles);
@@ -384,7 +384,7 @@ extern "C" int ssfm_device_cumsum(int device, double* dst, const double* src, in
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipFree(totals);
+    (void)ssfm_device_free(device, totals, sizeof(double) * ntiles);
     if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_cumsum: %s", hipGetErrorString(e));
     return SSFM_OK;
 }
@@ -394,11 +394,11 @@ extern "C" int ssfm_device_min(int device, const double* a, int64_t n, double* m
     if (int rc = use(device)) return rc;
     constexpr int kBlocks = 1024;
     double* partial = nullptr;
-    HIP_TRY(hipMalloc(&partial, sizeof(double) * kBlocks));
+    if (int rc = ssfm_device_alloc(device, sizeof(double) * kBlocks, (void**)&partial)) return rc;
     hipLaunchKernelGGL(k_min, dim3(kBlocks), dim3(256), 0, 0, a, (long long)n, partial);
     double host[kBlocks];
     hipError_t e = hipMemcpy(host, partial, sizeof(host), hipMemcpyDeviceToHost);
-    (void)hipFree(partial);
+    (void)ssfm_device_free(device, partial, sizeof(double) * kBlocks);
     if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_min: %s", hipGetErrorString(e));
     double m = host[0];
     for (int i = 1; i < kBlocks; ++i) m = host[i] < m ? host[i] : m;

@@ -1080,6 +1080,40 @@ def test_device_resident_signal_semantics():
     assert e.n_pol == 2 and e.signal.shape == (2, 1 << 12)
 
 
+def test_read_back_arrays_are_ordinary_numpy_arrays():
+    """Results are read back into pooled page-locked buffers wrapped as NumPy arrays: they must behave like any other
+    array (writable, survive the device object and the plan, usable after the buffer of another result was recycled)."""
+    import gc
+    from opticomlib_amd import devices as od
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 4096)) + 1j * rng.standard_normal((2, 4096))
+    d = _lib.DeviceArray.from_host(x, np.complex128, 0)
+    a = d.to_host()
+    assert type(a) is np.ndarray and a.flags.writeable and a.flags.c_contiguous and a.dtype == np.complex128
+    np.testing.assert_array_equal(a, x)
+    del d
+    gc.collect()
+    a *= 2                                                          # the array owns its memory through its base
+    np.testing.assert_array_equal(a, 2 * x)
+    b = a[1, 10:20].copy()
+    view = a[0]
+    del a
+    gc.collect()
+    other = _lib.DeviceArray.from_host(np.zeros((2, 4096), complex), np.complex128, 0).to_host()    # same size: must not reuse the live block
+    np.testing.assert_array_equal(view, 2 * x[0])
+    np.testing.assert_array_equal(b, 2 * x[1, 10:20])
+    assert not other.any()
+    del view, other
+    gc.collect()
+    y = oa.FIBER(optical_signal(x * 0.01), length=5, h=1.0, **workloads.SMF)
+    s1 = y.signal
+    od.release_plans()
+    assert relmax(s1, orc.fiber_c64((x * 0.01), gv.dt, length=5, h=1.0, **workloads.SMF)) < 2e-5
+    assert _lib.host_empty((0,), np.float64).size == 0
+    import pickle
+    np.testing.assert_array_equal(pickle.loads(pickle.dumps(s1)), s1)
+
+
 def test_device_array_basics():
     x = (np.arange(24).reshape(2, 12) * (1 + 0.5j)).astype(np.complex64)
     d = _lib.DeviceArray.from_host(x)
