@@ -40,7 +40,11 @@ using ssfm::fail;
 
 namespace {
 
-constexpr int kChunk = 16;         // samples per thread (measured at 2^20 x 2 complex: 16 -> 121 us, 32 -> 130 us, 64 -> 158 us per call)
+#ifndef SOS_CHUNK
+#define SOS_CHUNK 16
+#endif
+constexpr int kChunk = SOS_CHUNK;  // samples per thread (measured at 2^20 x 2 complex, first version: 16 -> 121 us, 32 -> 130 us, 64 -> 158 us per call;
+                                   // this version: 8 -> 101 us, 12 -> 90 us, 16 -> 97 us)
 constexpr int kWave = 64;          // lanes per wavefront
 #ifndef SOS_WAVES
 #define SOS_WAVES 4
