@@ -1114,6 +1114,36 @@ def test_read_back_arrays_are_ordinary_numpy_arrays():
     np.testing.assert_array_equal(pickle.loads(pickle.dumps(s1)), s1)
 
 
+def test_real_valued_device_signal_feeds_every_device():
+    """A CW laser is a float64 array in GPU memory (as it is a float64 NumPy array in the reference): every device
+    must take it from there and agree with the same call on the host array."""
+    from opticomlib_amd import devices as od
+    gv(sps=16, R=10e9, N=256)
+    cw = oa.LASER(P0=3)
+    assert cw.on_device and cw._raw("signal").dtype == np.float64
+    host = optical_signal(np.full(gv.t.size, np.sqrt(10 ** (3 / 10 - 3))))
+    before = _lib.TRANSFERS["d2h"]
+    outs = {
+        "FIBER": lambda x: oa.FIBER(x, length=3, h=1.0, **workloads.SMF),
+        "FIBER128": lambda x: oa.FIBER(x, length=3, h=1.0, precision="complex128", **workloads.SMF),
+        "DM": lambda x: oa.DM(x, D=-300),
+        "BPF": lambda x: oa.BPF(x, 40e9),
+        "PD": lambda x: oa.PD(x, BW=8e9, include_noise="none"),
+        "MZM": lambda x: oa.MZM(x, 1.5, bias=0.5),
+    }
+    dev = {k: f(cw) for k, f in outs.items()}
+    np.random.seed(3); dev["EDFA"] = oa.EDFA(cw, G=10, NF=5)
+    assert _lib.TRANSFERS["d2h"] == before and cw.on_device            # nothing was downloaded on the way
+    ref = {k: f(host) for k, f in outs.items()}
+    np.random.seed(3); ref["EDFA"] = oa.EDFA(host, G=10, NF=5)
+    for k in ref:
+        assert dev[k].signal.dtype == ref[k].signal.dtype and dev[k].signal.shape == ref[k].signal.shape, k
+        np.testing.assert_array_equal(dev[k].signal, ref[k].signal, err_msg=k)
+        if ref[k].noise is not NULL:
+            np.testing.assert_array_equal(dev[k].noise, ref[k].noise, err_msg=k)
+    assert dev["BPF"].signal.dtype == np.float64 and dev["DM"].signal.dtype == np.complex128
+
+
 def test_device_array_basics():
     x = (np.arange(24).reshape(2, 12) * (1 + 0.5j)).astype(np.complex64)
     d = _lib.DeviceArray.from_host(x)
