@@ -11,11 +11,15 @@ a = workloads.qpsk_field(n, seed=2024).astype(np.complex128)
 x = optical_signal(a)
 pw = np.abs(a[0]) ** 2
 for name, f in (("BPF 2^20 x 2 complex128", lambda: BPF(x, BW=60e9)), ("LPF 2^20 float64", lambda: LPF(pw, BW=20e9))):
-    f()
+    f().signal
     t = time.perf_counter()
     for _ in range(3):
         f()
-    print(f"{name}: {(time.perf_counter() - t) / 3 * 1e3:.2f} ms host-inclusive, kernels {_lib.sosfiltfilt_last_ms() * 1e3:.1f} us")
+    left = (time.perf_counter() - t) / 3
+    t = time.perf_counter()
+    for _ in range(3):
+        f().signal
+    print(f"{name}: {(time.perf_counter() - t) / 3 * 1e3:.2f} ms host array to host array ({left * 1e3:.2f} ms with the result left in HBM), kernels {_lib.sosfiltfilt_last_ms() * 1e3:.1f} us")
 
 # device-resident, back to back (clocks ramped): the kernels alone
 from scipy import signal as sg
