@@ -355,10 +355,11 @@ template <typename T> struct PlanT : PlanBase {
         // k_freq: complex128 rows run best with 16 points per thread and load-at-use twiddles (256-thread workgroups,
         // two per CU; C1 46.8 -> 44.7 us per step), complex64 rows with 16 and register twiddles (8: 22.2 vs 21.4 us)
         Ef = 16;
-        // up to 2^17 complex64 points a step is bound by launch and instruction latency, not by the exchanges: 8 points
+        // up to 2^17 points a step is bound by launch and instruction latency, not by the exchanges: 8 points
         // per thread in both kernels (twice the wavefronts per workgroup) is 5-19 % faster there (tools/small_n.py:
         // 7.0 -> 5.7 us per step at 2^10..2^12, 8.6 -> 7.9 at 2^15, 11.3 -> 10.3 at 2^17; equal at 2^18, slower above)
-        if (sizeof(T) == 4 && k <= 17) E = Ef = 8;
+        // (complex128 likewise in k_freq: 9.0 -> 7.7 us per step at 2^10, 13.2 -> 12.3 at 2^16, 17.1 -> 15.2 at 2^17 x 2)
+        if (k <= 17) E = Ef = 8;
         if (std::getenv("SSFM_E")) Ef = E;
         if (const char* e = std::getenv("SSFM_EF")) Ef = std::atoi(e) == 16 ? 16 : 8;
         if (k > 20) E = Ef = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
