@@ -462,7 +462,7 @@ class Plan:
         hs = np.ascontiguousarray(h_schedule, dtype=self.rdtype)
         snap = None
         if snapshots:
-            snap = np.empty((hs.size + 1, self.batch, self.n), dtype=self.cdtype)
+            snap = host_empty((hs.size + 1, self.batch, self.n), self.cdtype)
         _check(load().ssfm_propagate_fixed(self._h, float(gamma), _ptr(hs), hs.size,
                                            _ptr(snap) if snap is not None else None), "ssfm_propagate_fixed")
         return snap
@@ -472,7 +472,7 @@ class Plan:
         z = np.zeros(max_steps + 1, dtype=np.float64)
         snap = None
         if snapshots:
-            snap = np.empty((max_steps + 1, self.batch, self.n), dtype=self.cdtype)
+            snap = host_empty((max_steps + 1, self.batch, self.n), self.cdtype)
         _check(load().ssfm_propagate_adaptive(self._h, float(gamma), float(length), float(phi_max), int(bool(single_step)),
                                               int(max_steps), C.byref(steps), z.ctypes.data_as(C.POINTER(_D)),
                                               _ptr(snap) if snap is not None else None), "ssfm_propagate_adaptive")
