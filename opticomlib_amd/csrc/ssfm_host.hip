@@ -359,7 +359,7 @@ template <typename T> struct PlanT : PlanBase {
         // per thread in both kernels (twice the wavefronts per workgroup) is 5-19 % faster there (tools/small_n.py:
         // 7.0 -> 5.7 us per step at 2^10..2^12, 8.6 -> 7.9 at 2^15, 11.3 -> 10.3 at 2^17; equal at 2^18, slower above)
         // (complex128 likewise in k_freq: 9.0 -> 7.7 us per step at 2^10, 13.2 -> 12.3 at 2^16, 17.1 -> 15.2 at 2^17 x 2)
-        if (k <= 17) E = Ef = 8;
+        if (k <= 17 && !std::getenv("SSFM_E")) E = Ef = 8;        // (the environment knobs below still override)
         if (std::getenv("SSFM_E")) Ef = E;
         if (const char* e = std::getenv("SSFM_EF")) Ef = std::atoi(e) == 16 ? 16 : 8;
         if (k > 20) E = Ef = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
