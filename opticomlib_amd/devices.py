@@ -249,8 +249,9 @@ class _ChirpZ:
             self.plan.transfer_table(np.fft.fft(v), 0)                  # forward transform: convolve with conj(c)
             self.plan.transfer_table(np.fft.fft(np.conj(v)), 1)         # inverse transform: convolve with c
             self.plan._chirp = _lib.DeviceArray.from_host(c, np.complex128, dev)
+            self.plan._chirp_conj = _lib.DeviceArray.from_host(np.conj(c), np.complex128, dev)
             self.plan._chirp_n = n
-        self.chirp = self.plan._chirp
+        self.chirp, self.chirp_conj = self.plan._chirp, self.plan._chirp_conj
 
     def step(self, A, P, Dt, gamma: float, h: float, maxbits=None):
         """One symmetric split step of size ``h`` on the device array ``A`` (batch, n), in place."""
@@ -269,6 +270,65 @@ class _ChirpZ:
         pl.chirp_mid(H, 1.0 if exponent else 0.0, 0 if exponent else 1)
         pl.apply_table(1)
         pl.chirp_post(A, None, self.chirp, 0.0, 0.0, None)
+
+
+    def fourier(self, A, inverse: bool):
+        """``fft`` (or ``ifft``) of every row of the device array ``A`` (batch, n); returns a new device array.
+        fft(x)_k = c_k sum_n (x_n c_n) conj(c)_{k-n};  ifft(X)_n = conj(c_n) / N sum_k (X_k conj(c_k)) c_{n-k}."""
+        pl = self.plan
+        if inverse:
+            pl.chirp_pre(A, None, self.chirp_conj, 0.0, 0.0)
+            pl.apply_table(1)
+            pl.chirp_post(A, None, self.chirp, 0.0, 0.0, None)        # * conj(c) / N
+            pl.synchronize()
+            return A
+        pl.chirp_pre(A, None, self.chirp, 0.0, 0.0)
+        pl.apply_table(0)
+        pl.chirp_post(A, None, self.chirp_conj, 0.0, 0.0, None)       # * c / N
+        pl.synchronize()
+        return _lib.axpb_device(A, float(self.n), 0.0)                # fft carries no 1/N
+
+
+def _fourier(obj, domain, shift=False):
+    """``signal('w')`` / ``signal('t')`` of the reference's signal classes (``typing.py:1421-1462``): fft or ifft of
+    signal and noise along the last axis -- on the device, for any length from 2 to 2^21 (complex128 chirp-z
+    transform), the result stays in GPU memory.  ``shift`` applies fftshift / ifftshift (two device copies per row)."""
+    if domain not in ("t", "w", "f"):
+        raise ValueError("`domain` must be one of the following values ('t', 'w', 'f')")
+    inverse = domain == "t"
+    dev = default_device()
+    raws = [obj._raw("signal")] + ([] if obj._raw("noise") is NULL else [obj._raw("noise")])
+    shape = tuple(raws[0].shape)
+    n = shape[-1]
+    rows = 1 if len(shape) == 1 else shape[0]
+    _, hi = _lib.supported_log2n(_lib.C128)
+    if n < 2 or 2 * n - 1 > (1 << hi):
+        raise ValueError(f"the device transform takes 2 ... 2^{hi - 1} samples per row, got {n} (there is no CPU fallback)")
+    single = all(np.dtype(a.dtype) in (np.dtype(np.complex64), np.dtype(np.float32)) for a in raws)   # NumPy >= 2 keeps single precision
+    eng = _ChirpZ(n, rows * len(raws), dev)
+    buf = _lib.DeviceArray((rows * len(raws), n), np.complex128, dev)
+    row_bytes = rows * n * 16
+    cp = lambda dst, src, nbytes: _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(dst), _lib._VP(src), nbytes, 2), "ssfm_device_copy")
+    for k, a in enumerate(raws):
+        cp(buf.ptr + k * row_bytes, _dev_array(a, np.complex128, dev).ptr, row_bytes)
+    res = eng.fourier(buf, inverse)
+    outs = []
+    s_ = n // 2
+    for k in range(len(raws)):
+        o = _lib.DeviceArray(shape, np.complex128, dev)
+        for r in range(rows):
+            src, dst = res.ptr + k * row_bytes + r * n * 16, o.ptr + r * n * 16
+            if not shift:
+                cp(dst, src, n * 16)
+            elif not inverse:                                   # fftshift: out[(i + n//2) % n] = in[i]
+                cp(dst + s_ * 16, src, (n - s_) * 16)
+                cp(dst, src + (n - s_) * 16, s_ * 16)
+            else:                                               # ifftshift: out[i] = in[(i + n//2) % n]
+                cp(dst, src + s_ * 16, (n - s_) * 16)
+                cp(dst + (n - s_) * 16, src, s_ * 16)
+        outs.append(o.astype(np.complex64) if single else o)
+    kw = {"n_pol": obj.n_pol} if isinstance(obj, optical_signal) else {}
+    return _wrap_out(type(obj), outs[0], outs[1] if len(outs) > 1 else NULL, **kw)
 
 
 def _max_abs2(maxbits: "_lib.DeviceArray", plan) -> float:

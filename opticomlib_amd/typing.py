@@ -241,6 +241,12 @@ class electrical_signal:
     def __len__(self):
         return self.size
 
+    def __call__(self, domain, shift: bool = False):
+        """New object holding the FFT (``'w'`` / ``'f'``) or inverse FFT (``'t'``) of signal and noise along the last axis
+        (reference ``typing.py:1421-1462``); ``shift`` applies fftshift / ifftshift.  Computed on the GPU."""
+        from . import devices
+        return devices._fourier(self, domain, shift)
+
     def to_numpy(self) -> np.ndarray:
         return np.asarray(self.signal + self.noise)
 
@@ -357,6 +363,12 @@ class optical_signal:
     @property
     def dt(self):
         return gv.dt
+
+    def __call__(self, domain, shift: bool = False):
+        """New object holding the FFT (``'w'`` / ``'f'``) or inverse FFT (``'t'``) of signal and noise along the last axis
+        (reference ``typing.py:1421-1462``); ``shift`` applies fftshift / ifftshift.  Computed on the GPU."""
+        from . import devices
+        return devices._fourier(self, domain, shift)
 
     def to_numpy(self) -> np.ndarray:
         """``signal + noise`` (reference ``typing.py:1593-1597``)."""

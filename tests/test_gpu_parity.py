@@ -1144,6 +1144,41 @@ def test_real_valued_device_signal_feeds_every_device():
     assert dev["BPF"].signal.dtype == np.float64 and dev["DM"].signal.dtype == np.complex128
 
 
+def test_signal_call_is_the_fourier_transform_on_the_device():
+    """``x('w')`` / ``x('t')`` of both signal classes (reference typing.py:1421-1462 and its tests
+    tests/typing_test.py:1140-1209): fft / ifft of signal and noise, with and without the shifts, any length."""
+    from opticomlib_amd.typing import electrical_signal
+    rng = np.random.default_rng(12)
+    for n in (2, 7, 8, 100, 3000, 4096, 65537, 1 << 17):
+        for shape in ((n,), (2, n)):
+            sig = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+            noi = 0.1 * (rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
+            x = optical_signal(sig, noi)
+            for shift in (False, True):
+                W = x("w", shift=shift)
+                assert isinstance(W, optical_signal) and W.on_device and W.n_pol == x.n_pol
+                ws, wn = np.fft.fft(sig, axis=-1), np.fft.fft(noi, axis=-1)
+                if shift:
+                    ws, wn = np.fft.fftshift(ws, axes=-1), np.fft.fftshift(wn, axes=-1)
+                assert W.signal.dtype == np.complex128 and W.signal.shape == shape
+                assert relmax(W.signal, ws) < 1e-13 and relmax(W.noise, wn) < 1e-13
+                T = x("t", shift=shift)
+                ts = np.fft.ifft(sig, axis=-1)
+                assert relmax(T.signal, np.fft.ifftshift(ts, axes=-1) if shift else ts) < 1e-13
+            back = x("f")("t")                                         # device-resident all the way
+            assert relmax(back.signal, sig) < 1e-13 and relmax(back.noise, noi) < 1e-13
+    v = rng.standard_normal(1000)
+    E = electrical_signal(v)("w")
+    assert isinstance(E, electrical_signal) and E.noise is NULL and relmax(E.signal, np.fft.fft(v)) < 1e-13
+    c64 = optical_signal((rng.standard_normal(512) + 1j * rng.standard_normal(512)).astype(np.complex64))
+    assert c64("w").signal.dtype == np.fft.fft(c64.signal).dtype == np.complex64
+    assert relmax(c64("w").signal, np.fft.fft(c64.signal.astype(complex))) < 1e-6
+    with pytest.raises(ValueError, match="domain"):
+        c64("x")
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        optical_signal(np.ones(1, complex))("w")
+
+
 def test_device_array_basics():
     x = (np.arange(24).reshape(2, 12) * (1 + 0.5j)).astype(np.complex64)
     d = _lib.DeviceArray.from_host(x)
