@@ -411,7 +411,20 @@ class optical_signal:
     def _other(self, other):
         return (other.signal, other.noise) if isinstance(other, (optical_signal, electrical_signal)) else (np.asarray(other), NULL)
 
+    def _device_pair(self, other):
+        """Both operands entirely in the memory of one GPU, same shape and complex type: the sum can stay there."""
+        if not isinstance(other, optical_signal):
+            return False
+        a, b = self._raw("signal"), other._raw("signal")
+        if not (_is_device(a) and _is_device(b)) or tuple(a.shape) != tuple(b.shape) or a.dtype != b.dtype or a.dtype.kind != "c" or a.device != b.device:
+            return False
+        return all(x is NULL or (_is_device(x) and x.dtype == a.dtype and x.device == a.device) for x in (self._raw("noise"), other._raw("noise")))
+
     def __add__(self, other):
+        if self._device_pair(other):                          # e.g. two WDM channels coming out of their modulators
+            n1, n2 = self._raw("noise"), other._raw("noise")
+            noise = n2 if n1 is NULL else (n1 if n2 is NULL else n1 + n2)
+            return optical_signal.from_device(self._raw("signal") + other._raw("signal"), noise, n_pol=self.n_pol)
         s, n = self._other(other)
         return optical_signal(self.signal + s, self.noise + n, n_pol=self.n_pol)
 
@@ -426,6 +439,12 @@ class optical_signal:
 
     def __mul__(self, other):
         """``(s1 + n1)(s2 + n2)``: the signal is ``s1 s2``, everything that contains a noise factor is noise."""
+        raw_s, raw_n = self._raw("signal"), self._raw("noise")
+        if isinstance(other, (int, float)) and not isinstance(other, bool) and _is_device(raw_s) and raw_s.dtype in (np.complex128, np.float64) \
+                and (raw_n is NULL or (_is_device(raw_n) and raw_n.dtype == raw_s.dtype)):
+            from . import _lib                                 # a real gain / loss factor on a device-resident signal
+            return optical_signal.from_device(_lib.scale_add_device(raw_s, float(other)),
+                                              NULL if raw_n is NULL else _lib.scale_add_device(raw_n, float(other)), n_pol=self.n_pol)
         s, n = self._other(other)
         sig = self.signal * s
         noi = NULL

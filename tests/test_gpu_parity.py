@@ -1179,6 +1179,38 @@ def test_signal_call_is_the_fourier_transform_on_the_device():
         optical_signal(np.ones(1, complex))("w")
 
 
+def test_sum_and_real_gain_of_device_resident_signals_stay_on_the_device():
+    """Combining two modulated carriers (``a + b``) and a real gain / loss factor (``0.5 * a``) are the two operators a
+    link script applies between devices: on device-resident signals they run on the GPU, bit-identical to NumPy."""
+    gv(sps=16, R=10e9, N=256)
+    rng = np.random.default_rng(8)
+    bits1, bits2 = oa.PRBS(9, len=256, seed=3), oa.PRBS(9, len=256, seed=77)
+    ch = []
+    for bits, df in ((bits1, -2e10), (bits2, 2e10)):
+        drive = oa.DAC(bits, Vpp=5.0, offset=-2.5, pulse_shape="gaussian")
+        ch.append(oa.MZM(oa.LASER(P0=3, df=df), drive, bias=-2.5, Vpi=5.0))
+    noisy = optical_signal.from_device(ch[1]._raw("signal"), _lib.DeviceArray.from_host(1e-3 * (rng.standard_normal(4096) + 0j), np.complex128, 0))
+    before = _lib.TRANSFERS["d2h"]
+    both = ch[0] + ch[1]
+    with_noise = ch[0] + noisy
+    half = 0.5 * both
+    atten = with_noise * 10 ** (-0.3)
+    out = oa.FIBER(half, length=5, h=1.0, **workloads.SMF)
+    assert all(x.on_device for x in (both, with_noise, half, atten, out)) and _lib.TRANSFERS["d2h"] == before
+    a, b = ch[0].signal, ch[1].signal
+    np.testing.assert_array_equal(both.signal, a + b)
+    assert both.noise is NULL
+    np.testing.assert_array_equal(with_noise.signal, a + b)
+    np.testing.assert_array_equal(with_noise.noise, noisy.noise)
+    np.testing.assert_array_equal(half.signal, 0.5 * (a + b))
+    np.testing.assert_array_equal(atten.signal, (a + b) * 10 ** (-0.3))
+    np.testing.assert_array_equal(atten.noise, noisy.noise * 10 ** (-0.3))
+    assert relmax(out.signal, orc.fiber_c64(0.5 * (a + b), gv.dt, length=5, h=1.0, **workloads.SMF)) < 2e-5
+    # everything else keeps the host path: other types, shapes, complex factors
+    np.testing.assert_array_equal((both * (1 + 1j)).signal, (a + b) * (1 + 1j))
+    np.testing.assert_array_equal((both + 1.0).signal, (a + b) + 1.0)
+
+
 def test_device_array_basics():
     x = (np.arange(24).reshape(2, 12) * (1 + 0.5j)).astype(np.complex64)
     d = _lib.DeviceArray.from_host(x)
