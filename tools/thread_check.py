@@ -1,0 +1,30 @@
+"""Two host threads driving the library at once (separate plans): results must equal the single-threaded ones."""
+import sys, threading; sys.path.insert(0, '.')
+import numpy as np
+import opticomlib_amd as oa
+from opticomlib_amd import workloads
+from opticomlib_amd.typing import gv, optical_signal
+gv(**workloads.BENCH_GV)
+cases = [(1 << 14, 2, 11), (1 << 15, 1, 12), (3000, 2, 13), (1 << 16, 2, 14)]
+def run(case):
+    n, npol, seed = case
+    a = workloads.qpsk_field(1 << max(8, (n - 1).bit_length()), seed=seed, n_pol=2)[:npol, :n]
+    a = a[0] if npol == 1 else a
+    y = oa.FIBER(optical_signal(a), length=20, h=1.0, **workloads.SMF)
+    v = oa.PD(oa.BPF(y, 200e9), BW=40e9, include_noise="none")
+    return y.signal, v.signal
+want = [run(c) for c in cases]
+got = [None] * len(cases)
+errs = []
+def worker(idx):
+    try:
+        for _ in range(10):
+            for i in idx:
+                got[i] = run(cases[i])
+    except Exception as e:       # noqa: BLE001
+        errs.append(repr(e))
+ts = [threading.Thread(target=worker, args=(idx,)) for idx in ([0, 2], [1, 3])]
+[t.start() for t in ts]; [t.join() for t in ts]
+ok = not errs and all(np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]) for g, w in zip(got, want))
+print("threads:", "identical to the single-threaded results" if ok else f"MISMATCH / errors: {errs}")
+sys.exit(0 if ok else 1)
