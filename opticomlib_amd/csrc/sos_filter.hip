@@ -4,7 +4,7 @@
 // steady-state initial conditions.
 //
 // A cascade of NS biquads in direct form II transposed is a linear recurrence with a K = 2*NS state
-// per channel.  It is parallelised over time by chunks of L = 16 samples, TWO launches per direction:
+// per channel.  It is parallelised over time by chunks of L = 12 samples, TWO launches per direction:
 //   k_chunk_scan  a thread runs the recurrence over ITS chunk from a ZERO state (the chunk's particular
 //                 solution p_c); the 64 chunks of a wavefront are combined by a shuffle scan of the affine
 //                 maps s -> M s + p_c (M = A^L, the homogeneous map over one chunk), the 4 wavefronts of
@@ -19,7 +19,7 @@
 //                 row, nothing against the sample work -- and replaces a separate, serial scan kernel
 //                 (measured 25 us of a 127 us call).
 // The powers M^j, (M^256)^j, (M^16384)^j, j = 0..64, are built once per filter on the host from M, which
-// itself comes from running the same recurrence on unit states.  A wavefront's 64 chunks are 1024
+// itself comes from running the same recurrence on unit states.  A wavefront's 64 chunks are 768
 // consecutive samples: they are read (and the outputs written) with coalesced accesses and transposed
 // through LDS, so that a thread still walks ITS chunk in order.  Inside a chunk the operation order is
 // exactly SciPy's sample loop (fp contraction off); only the chunk start states see a different
@@ -41,10 +41,10 @@ using ssfm::fail;
 namespace {
 
 #ifndef SOS_CHUNK
-#define SOS_CHUNK 16
+#define SOS_CHUNK 12
 #endif
 constexpr int kChunk = SOS_CHUNK;  // samples per thread (measured at 2^20 x 2 complex, first version: 16 -> 121 us, 32 -> 130 us, 64 -> 158 us per call;
-                                   // this version: 8 -> 101 us, 12 -> 90 us, 16 -> 97 us)
+                                   // this version: 8 -> 101 us, 12 -> 90 us, 16 -> 97 us; 12 is 4-14 % faster than 16 for every shape from 2^14 to 2^20 x 2)
 constexpr int kWave = 64;          // lanes per wavefront
 #ifndef SOS_WAVES
 #define SOS_WAVES 4
