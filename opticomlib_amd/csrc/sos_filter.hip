@@ -15,7 +15,7 @@
 //                 by a reduction over all earlier group totals (each lane multiplies by its own power
 //                 (M^256)^lane, a wavefront sums with shuffles and applies (M^16384)^a); then a thread
 //                 forms its chunk's start state M^(c mod 256) S_g + e_c, re-runs the chunk and writes
-//                 the outputs.  The reduction is O(groups^2) over the grid -- 257 groups per 2^20-sample
+//                 the outputs.  The reduction is O(groups^2) over the grid -- 342 groups per 2^20-sample
 //                 row, nothing against the sample work -- and replaces a separate, serial scan kernel
 //                 (measured 25 us of a 127 us call).
 // The powers M^j, (M^256)^j, (M^16384)^j, j = 0..64, are built once per filter on the host from M, which
