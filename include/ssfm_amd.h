@@ -197,6 +197,28 @@ int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, con
 int ssfm_laser(int device, void* out, int64_t n, double amp, const double* phase, const double* rin, int has_df, double w, double step, double stop);
 int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, double beta, int64_t n, int is_complex);
 int ssfm_device_real(int device, double* dst, const void* src, int64_t n);
+/* Small DEVICE-array helpers that keep the transmitter / amplifier off the host, synchronous:
+ * ssfm_device_mean2: numpy.mean of n float64 (out[0]) or complex128 values (out[0] + j out[1]) -- the DC level that
+ *   AC coupling removes (DAC, devices.py:339-340);  ssfm_device_shift: dst = src + (re + j im);
+ * ssfm_device_zero: `bytes` zero bytes (the empty y polarisation an EDFA gives a single-polarisation input, devices.py:924);
+ * ssfm_device_power: mean |x|^2 of each of `rows` rows of n float64 / complex128 values -> out[rows] (HOST). */
+int ssfm_device_mean2(int device, const void* src, int64_t n, int is_complex, double* out);
+int ssfm_device_shift(int device, void* dst, const void* src, int64_t n, int is_complex, double re, double im);
+int ssfm_device_zero(int device, void* dst, size_t bytes);
+int ssfm_device_power(int device, const void* src, int rows, int64_t n, int is_complex, double* out);
+/* PRBS (reference devices.py:63-182): `len` bits of the Fibonacci LFSR x^order + x^t2 + 1 (orders 7, 9, 11, 15, 20,
+ * 23, 31; taps of devices.py:134-142) started from the non-zero state `seed` (the caller has applied devices.py:143-149:
+ * modulo 2^order, default all ones, 0 -> 1), one uint8 0/1 per bit in DEVICE memory; the sequence and the register state
+ * after `len` shifts (`final_state`, nullable HOST word: return_seed, devices.py:181) are bit for bit the reference's.
+ * Every thread jumps to its 256-bit chunk with powers of the shift matrix over GF(2) and walks it as devices.py:170-175.
+ * ssfm_load_bits: plan field (complex128, batch 1) <- the bits as amplitudes 0.0 / 1.0 zero-stuffed to `up` samples per
+ * bit (ssfm_load_symbols for bits that are already on the device: PRBS -> DAC without a host copy).
+ * ssfm_load_qpsk: plan field (complex128, `rows` rows of plan_n) <- the QPSK-like test symbols of the benchmark
+ * configurations: row r, symbol k = ((2 b0 - 1) + j (2 b1 - 1)) / sqrt(2) from bits 2 (r nsym + k) and
+ * + 1, at sample k sps + sps / 2, zeros elsewhere.  The two loaders are asynchronous on the plan's stream. */
+int ssfm_prbs(int device, void* bits_dev, int64_t len, int order, uint32_t seed, uint32_t* final_state);
+int ssfm_load_bits(ssfm_plan* plan, int64_t plan_n, const void* bits_dev, int64_t nbits, int up);
+int ssfm_load_qpsk(ssfm_plan* plan, int64_t plan_n, int rows, const void* bits_dev, int64_t nsym, int sps);
 /* Free / total HBM of the device and the bytes held in the library's buffer pool (nullable). */
 int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes);
 
@@ -212,6 +234,13 @@ int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, si
  * `plan_n` / `batch` are the plan's own length and batch; all asynchronous on the plan's stream. */
 int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot);
 int ssfm_apply_table(ssfm_plan* plan, int slot);
+/* The chirp c_m = exp(-i pi m^2 / n) of that identity, generated on the device with its phase reduced exactly in
+ * integers: ssfm_device_chirp writes c (conj = 0) or conj(c) (1), n complex128, into DEVICE memory (synchronous);
+ * ssfm_load_chirp_kernel writes the convolution kernel v[m] = v[plan_n - m] = conj(c_m) (which = 0, forward transform) or
+ * c_m (which = 1, inverse) into the plan's field, from where ssfm_table_from_field makes it the resident transfer
+ * function of a slot -- neither a host transform nor an upload (the reference: numpy.fft, devices.py:1178-1180). */
+int ssfm_device_chirp(int device, void* out_dev, int64_t n, int conj);
+int ssfm_load_chirp_kernel(ssfm_plan* plan, int64_t plan_n, int64_t n, int which);
 /* Pulse shaping of the reference's DAC (upfir, utils.py:1949-1981) on a complex128 plan of batch 1: ssfm_load_padded
  * writes `n_src` float64 (src_complex = 0) or complex128 (1) samples from DEVICE memory into the field, zero-padded;
  * ssfm_table_from_field makes slot <- fft(field) (the field is consumed); ssfm_load_symbols writes `nsym` float64
@@ -253,6 +282,14 @@ int ssfm_set_profiling(ssfm_plan* plan, int mode);
 /* Number of row groups ("lanes") a fixed-step run drives on separate streams (env SSFM_LANES,
  * default 2, never more than the batch): one kernel launch covers batch/lanes rows. */
 int ssfm_num_lanes(ssfm_plan* plan, int* lanes);
+/* What the plan's staging buffers hold, owned by the plan: `which` 0 labels the linear operator set with
+ * ssfm_set_linear_operator, 1 / 2 the resident transfer function of slot 0 / 1.  A caller labels what it has staged
+ * (any non-zero 64-bit tag, e.g. a hash of the fibre parameters) and asks later whether it is still there; EVERY entry
+ * point that overwrites or reuses the buffer (a new operator, ssfm_apply_transfer, ssfm_apply_dispersion with H_out,
+ * ssfm_transfer_table, ssfm_table_from_field) clears the label, so a cached operator can never be stale.  0 = unknown.
+ * (The reference recomputes D~ on every call, devices.py:1137-1145; this only saves the O(N) set-up of a repeated call.) */
+int ssfm_plan_set_tag(ssfm_plan* plan, int which, uint64_t tag);
+int ssfm_plan_get_tag(ssfm_plan* plan, int which, uint64_t* tag);
 int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]);
 
 #ifdef __cplusplus

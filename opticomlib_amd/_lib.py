@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -73,6 +74,17 @@ SYMBOLS = {
     "ssfm_set_profiling": (_I, [_VP, _I]),
     "ssfm_kernel_times": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
     "ssfm_num_lanes": (_I, [_VP, C.POINTER(_I)]),
+    "ssfm_plan_set_tag": (_I, [_VP, _I, C.c_uint64]),
+    "ssfm_plan_get_tag": (_I, [_VP, _I, C.POINTER(C.c_uint64)]),
+    "ssfm_device_chirp": (_I, [_I, _VP, _I64, _I]),
+    "ssfm_load_chirp_kernel": (_I, [_VP, _I64, _I64, _I]),
+    "ssfm_device_mean2": (_I, [_I, _VP, _I64, _I, C.POINTER(_D)]),
+    "ssfm_device_shift": (_I, [_I, _VP, _VP, _I64, _I, _D, _D]),
+    "ssfm_device_zero": (_I, [_I, _VP, C.c_size_t]),
+    "ssfm_device_power": (_I, [_I, _VP, _I, _I64, _I, C.POINTER(_D)]),
+    "ssfm_prbs": (_I, [_I, _VP, _I64, _I, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ssfm_load_bits": (_I, [_VP, _I64, _VP, _I64, _I]),
+    "ssfm_load_qpsk": (_I, [_VP, _I64, _I, _VP, _I64, _I]),
 }
 
 
@@ -214,14 +226,14 @@ def host_empty(shape, dtype) -> np.ndarray:
 class DeviceArray:
     """A C-contiguous array in the HBM of one GPU: what a signal object holds between device calls.
 
-    ``dtype`` is complex64, complex128 or float64.  The buffer goes back to the library's pool when the
-    object is collected."""
+    ``dtype`` is complex64, complex128, float64 or uint8 (bit sequences).  The buffer goes back to the library's
+    pool when the object is collected.  ``__cuda_array_interface__`` lets torch / RCCL use the memory where it lies."""
 
     def __init__(self, shape, dtype, device: int = 0):
         self.shape = tuple(int(d) for d in np.atleast_1d(shape)) if not isinstance(shape, tuple) else tuple(int(d) for d in shape)
         self.dtype = np.dtype(dtype)
-        if self.dtype not in (np.dtype(np.complex64), np.dtype(np.complex128), np.dtype(np.float64)):
-            raise TypeError(f"DeviceArray supports complex64, complex128 and float64, not {self.dtype}")
+        if self.dtype not in (np.dtype(np.complex64), np.dtype(np.complex128), np.dtype(np.float64), np.dtype(np.uint8)):
+            raise TypeError(f"DeviceArray supports complex64, complex128, float64 and uint8, not {self.dtype}")
         self.device = int(device)
         self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
         self.ptr = 0
@@ -233,6 +245,10 @@ class DeviceArray:
     @property
     def ndim(self):
         return len(self.shape)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2, "strides": None}
 
     @property
     def size(self):
@@ -334,6 +350,50 @@ def axpb_device(a: DeviceArray, alpha: float, beta: float) -> DeviceArray:
     return out
 
 
+def chirp_device(n: int, conj: bool, device: int = 0) -> DeviceArray:
+    """``exp(-i pi m^2 / n)`` (or its conjugate), m < n, complex128, generated on the device."""
+    out = DeviceArray((int(n),), np.complex128, device)
+    _check(load().ssfm_device_chirp(int(device), _VP(out.ptr), int(n), int(bool(conj))), "ssfm_device_chirp")
+    return out
+
+
+def mean2_device(a: DeviceArray):
+    """``numpy.mean`` of a float64 / complex128 device array (a Python float or complex)."""
+    m = (_D * 2)()
+    cplx = a.dtype.kind == "c"
+    _check(load().ssfm_device_mean2(a.device, _VP(a.ptr), a.size, int(cplx), m), "ssfm_device_mean2")
+    return complex(m[0], m[1]) if cplx else float(m[0])
+
+
+def shift_device(a: DeviceArray, value) -> DeviceArray:
+    """``a + value`` (float64 / complex128 device array; complex ``value`` for a complex array)."""
+    out = DeviceArray(a.shape, a.dtype, a.device)
+    v = complex(value)
+    _check(load().ssfm_device_shift(a.device, _VP(out.ptr), _VP(a.ptr), a.size, int(a.dtype.kind == "c"), v.real, v.imag), "ssfm_device_shift")
+    return out
+
+
+def zeros_device(shape, dtype, device: int = 0) -> DeviceArray:
+    out = DeviceArray(shape, dtype, device)
+    _check(load().ssfm_device_zero(out.device, _VP(out.ptr), out.nbytes), "ssfm_device_zero")
+    return out
+
+
+def power_device(ptr: int, rows: int, n: int, is_complex: bool, device: int = 0) -> np.ndarray:
+    """Mean ``|x|^2`` of each of ``rows`` rows of ``n`` values at device address ``ptr``."""
+    out = (_D * int(rows))()
+    _check(load().ssfm_device_power(int(device), _VP(ptr), int(rows), int(n), int(bool(is_complex)), out), "ssfm_device_power")
+    return np.array(out[:], dtype=np.float64)
+
+
+def prbs_device(order: int, length: int, seed: int, device: int = 0):
+    """The reference's LFSR on the device: ``(bits DeviceArray uint8 (length,), final register state)``."""
+    out = DeviceArray((int(length),), np.uint8, device)
+    last = C.c_uint32(0)
+    _check(load().ssfm_prbs(int(device), _VP(out.ptr), int(length), int(order), C.c_uint32(int(seed)), C.byref(last)), "ssfm_prbs")
+    return out, int(last.value)
+
+
 def real_device(a: DeviceArray) -> DeviceArray:
     out = DeviceArray(a.shape, np.float64, a.device)
     _check(load().ssfm_device_real(a.device, _VP(out.ptr), _VP(a.ptr), a.size), "ssfm_device_real")
@@ -403,6 +463,19 @@ class Plan:
         self.n, self.batch, self.precision, self.device = int(n), int(batch), int(precision), int(device)
         self.cdtype = _CDTYPE[precision]
         self.rdtype = _RDTYPE[precision]
+        # A plan is ONE field buffer, one set of staging tables and one stream: a sequence such as set_field ...
+        # propagate ... get_field must not interleave with another thread's on the same plan (ctypes releases the
+        # GIL during calls).  The device functions hold this lock for their whole sequence; re-entrant because they nest.
+        self.lock = threading.RLock()
+
+    # what the staging buffers hold is the C plan's knowledge (ssfm_plan_set_tag / _get_tag): 0 operator, 1 / 2 table slots
+    def tag(self, which: int) -> int:
+        t = C.c_uint64(0)
+        _check(load().ssfm_plan_get_tag(self._h, int(which), C.byref(t)), "ssfm_plan_get_tag")
+        return int(t.value)
+
+    def set_tag(self, which: int, tag: int):
+        _check(load().ssfm_plan_set_tag(self._h, int(which), C.c_uint64(int(tag) & (2 ** 64 - 1))), "ssfm_plan_set_tag")
 
     def close(self):
         if self._h is not None and _lib is not None:
@@ -508,6 +581,18 @@ class Plan:
     def load_symbols(self, sym: "DeviceArray", up: int):
         """field <- the float64 amplitudes ``sym`` zero-stuffed to ``up`` samples per symbol (sample at ``up // 2``)."""
         _check(load().ssfm_load_symbols(self._h, self.n, _VP(sym.ptr), sym.size, int(up)), "ssfm_load_symbols")
+
+    def load_bits(self, bits: "DeviceArray", up: int):
+        """field <- device-resident bits (uint8) as amplitudes 0.0 / 1.0, zero-stuffed to ``up`` samples per bit."""
+        _check(load().ssfm_load_bits(self._h, self.n, _VP(bits.ptr), bits.size, int(up)), "ssfm_load_bits")
+
+    def load_qpsk(self, bits: "DeviceArray", nsym: int, sps: int):
+        """field rows <- QPSK-like symbols from device-resident bits (``ssfm_load_qpsk``)."""
+        _check(load().ssfm_load_qpsk(self._h, self.n, self.batch, _VP(bits.ptr), int(nsym), int(sps)), "ssfm_load_qpsk")
+
+    def load_chirp_kernel(self, n: int, which: int):
+        """field <- Bluestein's convolution kernel for length ``n`` (0: forward, 1: inverse), generated on the device."""
+        _check(load().ssfm_load_chirp_kernel(self._h, self.n, int(n), int(which)), "ssfm_load_chirp_kernel")
 
     def load_pulse(self, kind: int, npts: int, start: float, step: float, stop: float, pow2m: int, params):
         """field <- one of the DAC's built-in pulses over ``linspace(start, stop, npts)``, zero-padded (``ssfm_load_pulse``)."""

@@ -281,3 +281,49 @@ extern "C" int ssfm_load_pulse(ssfm_plan* plan, int64_t plan_n, int kind, int64_
     HIP_TRY(hipGetLastError());
     return SSFM_OK;
 }
+
+// ---------------------------------------------------------------------------------- the chirp itself
+// c_m = exp(-i pi m^2 / n): the phase is reduced exactly in integers (m^2 mod 2n) and taken with sincospi, so
+// the chirp carries no argument-rounding error at all.  k_chirp: out[m] = c_m or conj(c_m), m < n.  k_chirp_kernel:
+// the convolution kernel of Bluestein's identity in the plan's field (row 0, length M): v[m] = v[M - m] = conj(c_m)
+// (which = 0: forward transform) or c_m (which = 1: inverse), zero elsewhere; ssfm_table_from_field turns it into
+// the resident transfer function of a slot -- no host transform, no upload.
+namespace {
+
+__device__ __forceinline__ double2 chirp_value(long long m, long long n, int conj) {
+    const long long r = (m * m) % (2 * n);
+    double s, c;
+    sincospi(-(double)r / (double)n, &s, &c);
+    return make_double2(c, conj ? -s : s);
+}
+
+__global__ __launch_bounds__(256) void k_chirp(double2* __restrict__ out, long long n, int conj) {
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (long long)gridDim.x * blockDim.x) out[m] = chirp_value(m, n, conj);
+}
+
+__global__ __launch_bounds__(256) void k_chirp_kernel(double2* __restrict__ F, long long n, long long M, int which) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i < n ? i : (M - i < n ? M - i : -1);
+        F[i] = m < 0 ? make_double2(0.0, 0.0) : chirp_value(m, n, which == 0);
+    }
+}
+
+}  // namespace
+
+extern "C" int ssfm_device_chirp(int device, void* out_dev, int64_t n, int conj) {
+    if (!out_dev || n < 2 || n > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_device_chirp: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_chirp, dim3(blocks_for(n)), dim3(256), 0, 0, (double2*)out_dev, (long long)n, conj);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_load_chirp_kernel(ssfm_plan* plan, int64_t plan_n, int64_t n, int which) {
+    Target t;
+    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (which < 0 || which > 1 || n > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_load_chirp_kernel: bad argument");
+    hipLaunchKernelGGL(k_chirp_kernel, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, t.F, (long long)n, t.M, which);
+    HIP_TRY(hipGetLastError());
+    return SSFM_OK;
+}

@@ -45,11 +45,12 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
 template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = cols_per_tile<T>();
+    constexpr bool U16 = u16_layout<T>(N1, C, E);          // the field layout between the kernels (ssfm_kernels.hpp "U16")
     constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                          + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
-    static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE>, lds);
+    static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_time<T, N1, C, E, MODE>), grid, dim3(N1 * C / E), lds, s, a);
+    hipLaunchKernelGGL((k_time<T, N1, C, E, MODE, U16>), grid, dim3(N1 * C / E), lds, s, a);
     return hipGetLastError();
 }
 template <typename T, int MODE, int E>
@@ -71,15 +72,23 @@ hipError_t launch_time(int N1, int batch, hipStream_t s, TimeArgs<T> a, int E) {
     return E == 8 ? launch_time_e<T, MODE, 8>(N1, batch, s, a) : launch_time_e<T, MODE, 16>(N1, batch, s, a);
 }
 
-template <typename T, int MODE, int N2, int E>
-hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
+template <typename T, int MODE, int N2, int E, bool U16>
+hipError_t launch_freq_u(int nrows, hipStream_t s, const FreqArgs<T>& a) {
     constexpr int ROWS = freq_rows(N2, E);
     constexpr size_t lds = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
                          + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
-    static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, E, MODE>, lds);
+    static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_freq<T, N2, ROWS, E, MODE>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, a);
+    hipLaunchKernelGGL((k_freq<T, N2, ROWS, E, MODE, U16>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, a);
     return hipGetLastError();
+}
+template <typename T, int MODE, int N2, int E>
+hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
+    // the layout is the plan's (it follows from k_time's tile shape); complex128 plans never use it, and the
+    // forward-only transform writes the plain transposed spectrum for its consumers
+    if constexpr (sizeof(T) == 4)
+        if (a.u16) return launch_freq_u<T, MODE, N2, E, true>(nrows, s, a);
+    return launch_freq_u<T, MODE, N2, E, false>(nrows, s, a);
 }
 template <typename T, int MODE, int E>
 hipError_t launch_freq_e(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a) {
@@ -117,6 +126,7 @@ template <typename T> struct PlanT : PlanBase {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     cx<T>* F = nullptr;        // batch * n
+    cx<T>* Y = nullptr;        // the field between the kernels: == F (plain layout, in place) or a buffer of its own (U16 layout)
     T* P = nullptr;            // batch * n
     cx<T>* twN = nullptr;      // n
     cx<T>* twA = nullptr;      // (N1/16)*N2: W_N^m
@@ -134,6 +144,12 @@ template <typename T> struct PlanT : PlanBase {
     T* zlog = nullptr;
     int64_t zlog_cap = 0;
     bool have_op = false;
+    // What the staging buffers hold is the PLAN's knowledge, not the caller's: tags[0] labels the linear operator in
+    // dnat / dperm, tags[1 + slot] the resident transfer function of a slot.  A caller that has staged something
+    // labels it (ssfm_plan_set_tag) and asks later whether it is still there (ssfm_plan_get_tag); every entry point
+    // that overwrites or reuses a buffer clears its label here, so a stale label cannot survive.  0 = nothing known.
+    uint64_t tags[3] = {0, 0, 0};
+    void drop_operator() { have_op = false; tags[0] = 0; for (auto& t : tabs) t.valid = false; }
     bool timed = false;
     int64_t last_launches = 0;
     bool profiling = false;
@@ -142,6 +158,7 @@ template <typename T> struct PlanT : PlanBase {
     // hides launch gaps and lets one group compute while another waits for memory.
     static constexpr int kMaxLanes = 8;
     int nlanes = 1;
+    bool u16 = false;          // field layout between the kernels: 16-byte units (ssfm_kernels.hpp "U16")
     int E = 16;                // points per thread of k_time (env SSFM_E = 8 | 16)
     int Ef = 16;               // ... and of k_freq (env SSFM_EF); the two kernels only share the field layout
     bool stagger = false;      // env SSFM_STAGGER
@@ -306,7 +323,7 @@ template <typename T> struct PlanT : PlanBase {
 
     int free_all() {
         if (stream) (void)hipStreamSynchronize(stream);
-        void* bufs[] = {F, P, twN, twA, twB, tw1, tw2, dnat, dperm, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
+        void* bufs[] = {F, Y != F ? Y : nullptr, P, twN, twA, twB, tw1, tw2, dnat, dperm, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
         for (int g = 1; g < kMaxLanes; ++g) {
@@ -382,19 +399,27 @@ template <typename T> struct PlanT : PlanBase {
         const size_t cb = sizeof(cx<T>);
         HIP_TRY(hipMalloc(&F, cb * n * batch));
         HIP_TRY(hipMalloc(&P, sizeof(T) * n * batch));
-        HIP_TRY(hipMalloc(&twN, cb * n));
-        const long long nA = (long long)(N1 / 16) * N2, nB = 16ll * N2;
-        HIP_TRY(hipMalloc(&twA, cb * nA));
-        HIP_TRY(hipMalloc(&twB, cb * nB));
+        u16 = u16_layout<T>(N1, cols_per_tile<T>(), E);
+        Y = F;
+        if (u16) HIP_TRY(hipMalloc(&Y, cb * n * batch));
+        // inter-pass twiddles W_N^(k1 n2): either the n-entry table in k_time's thread order, or (U16 plans) the two
+        // small factor tables the kernel multiplies (ssfm_kernels.hpp SSFM_TWN_COMPUTE)
+        if (u16 && SSFM_TWN_COMPUTE) {
+            const long long nA = (long long)(N1 / E) * N2, nB = (long long)E * N2;      // W_N^(j n2), j < N1/E;  W_N^(t n2 N1/E), t < E
+            HIP_TRY(hipMalloc(&twA, cb * nA));
+            HIP_TRY(hipMalloc(&twB, cb * nB));
+            hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, nA, 1ll, (long long)n);
+            hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, nB, (long long)(N1 / E), (long long)n);
+        } else {
+            HIP_TRY(hipMalloc(&twN, cb * n));
+            hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2, cols_per_tile<T>(), E, (int)u16, N2 / Ef);
+        }
         if (int rc = make_line_table(&tw1, N1, E)) return rc;
         if (int rc = make_line_table(&tw2, N2, Ef)) return rc;
         HIP_TRY(hipMalloc(&dnat, cb * n));
         HIP_TRY(hipMalloc(&dperm, cb * n));
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
-        hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2, cols_per_tile<T>(), E);
-        hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, nA, 1ll, (long long)n);
-        hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, nB, (long long)(N1 / 16), (long long)n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return SSFM_OK;
@@ -483,6 +508,7 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipStreamSynchronize(stream));
         for (auto& t : tabs) t.valid = false;
         have_op = true;
+        tags[0] = 0;
         return SSFM_OK;
     }
 
@@ -507,8 +533,8 @@ template <typename T> struct PlanT : PlanBase {
         trace_tag(a, 0, lane);
 #endif
         (void)lane;
-        a.F = F + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
-        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0;
+        a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
+        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef;
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
@@ -517,7 +543,7 @@ template <typename T> struct PlanT : PlanBase {
         trace_tag(a, 1, lane);
 #endif
         (void)lane;
-        a.F = F + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0;
+        a.F = Y + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0; a.u16 = u16 ? 1 : 0;
         return a;
     }
 
@@ -747,8 +773,7 @@ template <typename T> struct PlanT : PlanBase {
         cx<T>* hperm = scratch;   // n entries are enough
         // dnat is a staging buffer: the propagator's own D~ must be re-set after a DM call
         HIP_TRY(hipMemcpyAsync(dnat, H_host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
-        have_op = false;
-        for (auto& t : tabs) t.valid = false;
+        drop_operator();
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)dnat, hperm, N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
@@ -771,8 +796,7 @@ template <typename T> struct PlanT : PlanBase {
         cx<T>* hnat = nullptr;
         if (H_out) {                       // dnat doubles as staging for the natural-order H
             hnat = dnat;
-            have_op = false;
-            for (auto& t : tabs) t.valid = false;
+            drop_operator();
         }
         const double val = 1.0 / ((double)n * dt_s);
         hipLaunchKernelGGL(k_make_dm_table<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
@@ -799,8 +823,8 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = use_device()) return rc;
         if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
         HIP_TRY(hipMemcpyAsync(dnat, H_host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));      // dnat = staging
-        have_op = false;
-        for (auto& t : tabs) t.valid = false;
+        drop_operator();
+        tags[1 + slot] = 0;
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)dnat, xfer_tab[slot], N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
@@ -813,12 +837,11 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = use_device()) return rc;
         if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
         if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
-        have_op = false;
-        for (auto& t : tabs) t.valid = false;
+        tags[1 + slot] = 0;
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
         HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, N1 * batch, stream, fargs(dperm, 0, nullptr), Ef)));
         const long long total = (long long)n * batch;
-        hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)F, scratch, N1, N2, batch);
+        hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)Y, scratch, N1, N2, batch);
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)scratch, xfer_tab[slot], N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
@@ -843,7 +866,7 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, nrows, stream, fargs(dperm, 0, nullptr), Ef)));
         const long long total = (long long)n * batch;
         hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)F, scratch, N1, N2, batch);
+                           (const cx<T>*)Y, scratch, N1, N2, batch);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(dst, scratch, sizeof(cx<T>) * total, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -933,11 +956,13 @@ int ssfm_plan_create(ssfm_plan** out, int device, int64_t n, int batch, int prec
     int rc;
     if (precision == SSFM_C64) {
         auto* impl = new (std::nothrow) PlanT<float>();
+        if (!impl) { delete p; return fail(SSFM_ERR_INVALID, "out of host memory"); }
         impl->precision = precision;
         p->impl = impl;
         rc = impl->init(device, n, batch);
     } else {
         auto* impl = new (std::nothrow) PlanT<double>();
+        if (!impl) { delete p; return fail(SSFM_ERR_INVALID, "out of host memory"); }
         impl->precision = precision;
         p->impl = impl;
         rc = impl->init(device, n, batch);
@@ -1022,6 +1047,14 @@ int ssfm_set_profiling(ssfm_plan* plan, int mode) { WITH_PLAN(plan, (P_->profili
 int ssfm_num_lanes(ssfm_plan* plan, int* lanes) {
     if (!lanes) return fail(SSFM_ERR_INVALID, "NULL output");
     WITH_PLAN(plan, (*lanes = P_->nlanes, (int)SSFM_OK));
+}
+int ssfm_plan_set_tag(ssfm_plan* plan, int which, uint64_t tag) {
+    if (which < 0 || which > 2) return fail(SSFM_ERR_INVALID, "ssfm_plan_set_tag: which = %d", which);
+    WITH_PLAN(plan, (P_->tags[which] = tag, (int)SSFM_OK));
+}
+int ssfm_plan_get_tag(ssfm_plan* plan, int which, uint64_t* tag) {
+    if (which < 0 || which > 2 || !tag) return fail(SSFM_ERR_INVALID, "ssfm_plan_get_tag: bad argument");
+    WITH_PLAN(plan, (*tag = (which == 0 && !P_->have_op) ? 0 : P_->tags[which], (int)SSFM_OK));
 }
 int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]) {
     if (!counts || !total_ms) return fail(SSFM_ERR_INVALID, "NULL output");

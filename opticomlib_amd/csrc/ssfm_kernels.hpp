@@ -31,10 +31,13 @@
 #ifndef SSFM_ABL_NO_NL
 #define SSFM_ABL_NO_NL 0
 #endif
-// 1: form the inter-pass twiddles in the kernel from two small tables; 0: stream the N-entry table
+// 1: form the inter-pass twiddles in the kernel from two small tables (U16 plans); 0: stream the N-entry table.
+// One complex multiply per point against 8 bytes per point of table traffic: 20.8 vs 21.6 us per step alone, 18.1 vs
+// 20.7 together with the memory policy below (profiles/r02_ab_u16_sc1_twnc.txt)
 #ifndef SSFM_TWN_COMPUTE
-#define SSFM_TWN_COMPUTE 0
+#define SSFM_TWN_COMPUTE 1
 #endif
+template <bool U16> __host__ __device__ constexpr bool twn_compute() { return SSFM_TWN_COMPUTE != 0 && U16; }
 
 // Launch-level trace for tools/trace_timeline.py (diagnostic builds only: -DSSFM_TRACE=1).  Every
 // workgroup folds its start / end time (s_memrealtime, 100 MHz) into 4 words of its launch's slot.
@@ -112,12 +115,57 @@ __host__ __device__ __forceinline__ long long time_tw_pos(long long k1, long lon
     return ((tile * (E / 2) + (t >> 1)) * ((long long)Q1 * C) + thread) * 2 + (t & 1);
 }
 
+// ---- "U16" field layout between the two kernels (complex64): 16-byte units.
+// A vector-memory instruction costs a wave about the same issue time whether a lane moves 8 or 16 bytes, a
+// write-through (sc1) store only runs at the plain rate with 16 bytes per lane, and a kernel's loads and stores
+// are on its critical path (one wave per SIMD, every workgroup of a launch in step).  k_freq's thread j holds row
+// elements n2 = j + Qf t: the elements of register slots t = 2g and 2g+1 are stored side by side as ONE 16-byte
+// unit at position freq_tab_pos(n2, Qf) of the row -- the operator table's own order.  A k_time tile is then 8
+// consecutive units = one 128-byte line per row k1 = the columns {jf .. jf+7} + Qf (2 gf + h), h = 0, 1; its lane
+// (h, j mod 4, c8) loads the unit of row j + Q1 (2g + h), and ONE v_permlane32_swap per dword hands the h = 1
+// column's half to lane + 32 and takes that lane's h = 0 half (wavefront shuffle instead of a second pass
+// through memory): afterwards every thread holds rows 2g and 2g+1 of ITS column, as in the plain layout.
+#ifndef SSFM_U16
+#define SSFM_U16 1
+#endif
+template <typename T> __host__ __device__ constexpr bool u16_layout(int N1, int C, int E) {
+    return SSFM_U16 != 0 && sizeof(T) == 4 && C == 16 && ((N1 / E) % 4) == 0 && N1 / E >= 4;
+}
+// natural column of position `pos` of a row in the U16 order (inverse of freq_tab_pos)
+__host__ __device__ __forceinline__ long long u16_col_of_pos(long long pos, int Qf) {
+    const long long u = pos >> 1, g = u / Qf, j = u % Qf;
+    return j + (long long)Qf * (2 * g + (pos & 1));
+}
+// tile order: tiles 2m and 2m+1 share every 128-byte line of the NATURAL-order side (8 + 8 columns), so they
+// take consecutive slots of one XCD (block ids b and b + 8): the second finds the line in that XCD's L2
+__host__ __device__ __forceinline__ int u16_tile_of_unit(int t, int ntiles) {
+    return (ntiles & 15) == 0 ? ((t & ~15) | ((t & 7) << 1) | ((t >> 3) & 1)) : t;
+}
+// lanes 32-63 of `lo` <-> lanes 0-31 of `hi` (v_permlane32_swap_b32), both components of a complex pair
+__device__ __forceinline__ void lane32_swap(cf32& lo, cf32& hi) {
+    const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
+    lo = mk<float>(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+    hi = mk<float>(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+}
+__device__ __forceinline__ void lane32_swap(cf64&, cf64&) {}      // (complex128 elements are 16 bytes already)
+// k_time inter-pass twiddle in the U16 order: the tile and the column inside it follow the row position
+__host__ __device__ __forceinline__ long long time_tw_pos_u16(long long k1, long long n2, int Q1, int E, int Qf, int ntiles) {
+    const long long pos = freq_tab_pos(n2, Qf);
+    const long long tile = pos / 16, c = ((pos & 1) << 3) | ((pos >> 1) & 7), thread = (k1 % Q1) * 16 + c, t = k1 / Q1;
+    (void)ntiles;
+    return ((tile * (E / 2) + (t >> 1)) * ((long long)Q1 * 16) + thread) * 2 + (t & 1);
+}
+
 template <typename T> struct TimeArgs {
-    cx<T>* F;                 // field, batch rows of N
+    cx<T>* F;                 // field in time order, batch rows of N (read by BEGIN, written by END)
+    cx<T>* Y;                 // field in the half-transformed layout between the kernels.  Plain layout: Y == F, a tile
+                              // reads and writes the same columns, every kernel works in place.  U16 layout: a tile's
+                              // columns and its positions in the row order differ, so BEGIN / END go from one buffer to the other
     T* P;                     // stale |A|^2, tile-major (private to k_time)
     const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]                      (SSFM_TWN_COMPUTE == 0)
-    const cx<T>* twA;         // W_N^m,          m < (N1/16)*N2   W_N^(k1*n2) = twA[j*n2] * twB[t*n2],
-    const cx<T>* twB;         // W_N^(m*N1/16),  m < 16*N2        k1 = j + t*N1/16  (SSFM_TWN_COMPUTE == 1)
+    const cx<T>* twA;         // W_N^m,          m < (N1/E)*N2   W_N^(k1*n2) = twA[j*n2] * twB[t*n2],
+    const cx<T>* twB;         // W_N^(m*N1/E),   m < E*N2        k1 = j + t*N1/E  (SSFM_TWN_COMPUTE == 1)
     const cx<T>* tw1;         // W_N1^q
     AdaptState<T>* st;        // nullptr in fixed-step mode
     T* zlog;                  // adaptive mode: z after every step
@@ -126,6 +174,7 @@ template <typename T> struct TimeArgs {
     T hh_next;                // h/2 of the step being started
     int N2;
     int rows;                 // rows covered by this launch (grid = N2/C * rows blocks)
+    int Qf;                   // threads per row of k_freq (U16 layout: which columns form a tile)
     SSFM_TRACE_ARGS
 };
 
@@ -247,50 +296,55 @@ template <> __device__ __forceinline__ void sincos_acc<float>(float x, float& s,
 }
 template <> __device__ __forceinline__ void sincos_acc<double>(double x, double& s, double& c) { sincos(x, &s, &c); }
 
-// Field / |A|^2 stores between kernels.  The consumer is always the NEXT kernel on other CUs (the
-// all-to-all between the two passes crosses XCDs), so nothing is gained by keeping the lines in this
-// XCD's L2 -- and a kernel that leaves megabytes dirty there pays for their write-back at its end:
-// dependent-launch gap = 1.45 us + dirty bytes / 6 TB/s (MI355X_MICROARCH.md, row "boundary"; measured
-// here 2.3-3.2 us behind 8-12 MB, tools/trace_timeline.py).  Write-through (sc1) or non-temporal stores
-// would stream the data out during the kernel -- but with the 8 bytes per lane this access pattern
-// allows they are slower than the write-back they avoid: measured 21.2 (plain) / 22.4 (sc1) / 23.3 (nt)
-// us per step.  SSFM_STORE_MODE: 0 plain (default), 1 write-through (sc1), 2 non-temporal.
+// Memory policy of the streamed data (field, |A|^2) of the U16 plans.  The consumer of every store is the NEXT
+// kernel on other CUs -- the all-to-all between the two passes crosses XCDs -- so nothing is gained by keeping the
+// lines in this XCD's L2, and a kernel that leaves megabytes dirty there pays for their write-back at its end:
+// dependent-launch gap = 1.45 us + dirty bytes / 6 TB/s (MI355X_MICROARCH.md, row "boundary").  Measured
+// (tools/trace_timeline.py, profiles/r02_launch_timeline.txt): gap 2.4 us behind plain stores, 1.5 us behind
+// write-through ones; timing-only ablations that REMOVE the table loads make the kernels slower (23.5 vs 21.2 us per
+// step, profiles/r02_ablation_lanes2.txt): with less read traffic fewer dirty lines are evicted while the kernel runs.
+//   SSFM_STORE_MODE 1: field stores write-through (sc1).  Needs the 16-byte units of the U16 layout: an 8-byte sc1
+//                      store runs at 0.4x the rate (round 1 measured 22.4 vs 21.2 us per step with it).
+//   SSFM_P_WT 1:       the |A|^2 buffer likewise (its 16-byte tile-major stores).
+//   SSFM_NT_LOADS 1:   field and |A|^2 are read once per kernel: non-temporal loads.  Only together with the
+//                      write-through stores (alone it LOSES: 23.7 vs 21.6 us per step -- again the dirty lines).
+// A/B on MI355X, C2 single field / 4 fields resident, us per (field-)step (profiles/r02_ab_u16_sc1_twnc.txt, r02_ab_policy.txt):
+//   plain 21.6 / 15.0   sc1 22.3 / 15.7   sc1 + P 20.7 / 15.4   + in-kernel twiddles 19.7 / 15.0   + nt loads 18.1 / 15.1
+// Everything outside the U16 path (complex128, the small 8-byte layouts, the time-order side) keeps plain accesses.
 #ifndef SSFM_STORE_MODE
-#define SSFM_STORE_MODE 0
+#define SSFM_STORE_MODE 1
 #endif
-// SSFM_NT_LOADS: 1 = read the streamed data (field, |A|^2) with non-temporal loads so that the read-only
-// tables, which the OTHER lane's launch re-reads a few microseconds later, survive in the XCD's L2.
-// SSFM_P_NT: 1 = write the |A|^2 buffer with non-temporal stores (fewer dirty L2 lines at the kernel boundary)
 #ifndef SSFM_P_NT
 #define SSFM_P_NT 0
 #endif
+#ifndef SSFM_P_WT
+#define SSFM_P_WT 1
+#endif
 #ifndef SSFM_NT_LOADS
-#define SSFM_NT_LOADS 0
+#define SSFM_NT_LOADS 1
 #endif
-template <typename V> __device__ __forceinline__ V stream_load(const V* p) {
-#if SSFM_NT_LOADS
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
+template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V* p) {
+    if constexpr (NT && SSFM_NT_LOADS != 0) return __builtin_nontemporal_load(p);
+    else return *p;
 }
-__device__ __forceinline__ void stream_store(cf32* p, cf32 v) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// 16-byte unit of the U16 layout
+__device__ __forceinline__ void stream_store(f32x4* p, f32x4 v) {
 #if SSFM_STORE_MODE == 1
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    // The s_nop 1 are the two wait states a VALU write to the data registers of a > 8-byte store needs after it on
+    // gfx940+: the compiler inserts them for its own stores but cannot see into an asm statement (without them the
+    // next address computation overwrote the data of the store before it had been read)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 #elif SSFM_STORE_MODE == 2
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
 #endif
 }
-__device__ __forceinline__ void stream_store(cf64* p, cf64 v) {
-#if SSFM_STORE_MODE == 2
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void stream_store(f64x4* p, f64x4 v) { *p = v; }
+__device__ __forceinline__ void stream_store(cf32* p, cf32 v) { *p = v; }
+__device__ __forceinline__ void stream_store(cf64* p, cf64 v) { *p = v; }
 
 template <int C> struct ColIdx {
     int c;
@@ -348,9 +402,22 @@ __host__ __device__ constexpr int min_waves(int threads, int tsize, int e = 16) 
     return tsize == 4 && threads >= 256 ? (threads == 256 ? SSFM_MIN_WAVES_256 : (e == 16 ? 2 : threads / 128)) : 1;
 }
 
-template <typename T, int N1, int C, int E, int MODE>
-__global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) void k_time(const TimeArgs<T> a) {
+// (SSFM_CAP_WAVES: complex64 workgroups of 256 threads are meant to sit two per CU -- a launch of one lane is 256 of
+// them, both lanes together fill the chip evenly.  A kernel that needs fewer than 171 registers would be admitted
+// three per CU and the dispatcher packs them unevenly; the attribute pins the register budget to two waves per SIMD.)
+#ifndef SSFM_CAP_WAVES
+#define SSFM_CAP_WAVES 1
+#endif
+#if SSFM_CAP_WAVES
+#define SSFM_KERNEL_BOUNDS(threads, tsize, e) \
+    __launch_bounds__(threads) __attribute__((amdgpu_waves_per_eu(min_waves(threads, tsize, e), (tsize) == 4 && (threads) == 256 ? 2 : 8)))
+#else
+#define SSFM_KERNEL_BOUNDS(threads, tsize, e) __launch_bounds__(threads, min_waves(threads, tsize, e))
+#endif
+template <typename T, int N1, int C, int E, int MODE, bool U16 = false>
+__global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeArgs<T> a) {
     constexpr int Q = N1 / E;                      // threads per column
+    static_assert(!U16 || (sizeof(T) == 4 && C == 16 && Q % 4 == 0 && E % 2 == 0), "U16 layout: complex64, 16 columns, whole waves of 4 j");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
@@ -361,20 +428,29 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
     }
     SSFM_TRACE_BEGIN(a);
     const int tid = threadIdx.x;
-    const int c = tid % C;
-    const int j = tid / C;
+    // plain: thread = j * C + c.  U16: lane = h * 32 + (j mod 4) * 8 + c8, column c = h * 8 + c8 (see "U16" above)
+    const int c = U16 ? (((tid >> 5) & 1) << 3) | (tid & 7) : tid % C;
+    const int j = U16 ? ((tid >> 6) << 2) | ((tid >> 3) & 3) : tid / C;
+    const int ltid = U16 ? j * C + c : tid;       // thread index the tables are laid out by
     const long long N = (long long)N1 * a.N2;
     int tile, brow;
     xcd_unit_row(blockIdx.x, a.N2 / C, a.rows, tile, brow);
+    if (U16) tile = u16_tile_of_unit(tile, a.N2 / C);
+    // natural (time-order) column of this thread: the tile's columns are contiguous in the row ORDER of the layout
+    const int ncol = U16 ? (int)u16_col_of_pos((long long)tile * C + 2 * (c & 7) + (c >> 3), a.Qf) : tile * C + c;
     // wave-uniform bases (SGPRs) + one 32-bit lane offset
-    cx<T>* __restrict__ Fb = a.F + (long long)brow * N + (long long)tile * C;
+    cx<T>* __restrict__ Fb = a.F + (long long)brow * N;
+    cx<T>* __restrict__ Yb = a.Y + (long long)brow * N;
     // |A|^2 is private to this kernel (written and read back by the same thread of the same tile),
     // so it is stored tile-major as 4 x (4 values per thread): 16-byte accesses, 1 KiB per wave.
     typedef T p4_t __attribute__((ext_vector_type(4)));
     p4_t* __restrict__ Pb = reinterpret_cast<p4_t*>(a.P + (long long)brow * N + (long long)tile * (N1 * C)) + tid;
     constexpr int PSTR = N1 * C / E;      // threads per tile
-    const int off = j * a.N2 + c;
+    const int off = j * a.N2 + ncol;             // time-order side: element (n1 = j + Q t, n2 = ncol)
     const int stride = Q * a.N2;
+    // half-transformed side, U16: the 16-byte unit of row j + Q (2g + h) at columns (c8, h = 0 | 1) of the tile
+    typedef T u4_t __attribute__((ext_vector_type(4)));
+    const int offy = U16 ? (j + Q * (c >> 3)) * a.N2 + tile * C + 2 * (c & 7) : off;
     const ColIdx<C> idx{c};
 
     // issue every global load of the tile up front
@@ -382,18 +458,33 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
     cx<T> w[E];
     T pold[E];
     LineTw<T, N1, E> tw;
+    if (U16 && MODE != TM_BEGIN) {
 #pragma unroll
-    for (int t = 0; t < E; ++t) v[t] = stream_load(&Fb[off + t * stride]);
-#if SSFM_TWN_COMPUTE
-    // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
-    // the tile's 16 x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
+        for (int g = 0; g < E / 2; ++g) {
+            const u4_t q = stream_load<true>(reinterpret_cast<const u4_t*>(&Yb[offy + 2 * g * stride]));
+            v[2 * g] = mk<T>(q.x, q.y);
+            v[2 * g + 1] = mk<T>(q.z, q.w);
+        }
+    } else {
+        const cx<T>* __restrict__ src = MODE == TM_BEGIN ? Fb : Yb;
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = stream_load<false>(&src[off + t * stride]);
+    }
+    constexpr bool TWC = twn_compute<U16>();
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
-    for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(e / C) * (tile * C + (e % C))];
-    const cx<T> wA = a.twA[j * (tile * C + c)];
-#else
-    {
+    cx<T> wA = mk<T>((T)1, (T)0);
+    if constexpr (TWC) {
+        // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
+        // the tile's E x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
+        for (int e = tid; e < E * C; e += N1 * C / E) {
+            const int ce = e % C;
+            const int ne = U16 ? (int)u16_col_of_pos((long long)tile * C + 2 * (ce & 7) + (ce >> 3), a.Qf) : tile * C + ce;
+            Bs[e] = a.twB[(e / C) * ne];
+        }
+        wA = a.twA[j * ncol];
+    } else {
         typedef T w4_t __attribute__((ext_vector_type(4)));
-        const w4_t* __restrict__ W4 = reinterpret_cast<const w4_t*>(a.twN) + (long long)tile * (E / 2) * (N1 * C / E) + tid;
+        const w4_t* __restrict__ W4 = reinterpret_cast<const w4_t*>(a.twN) + (long long)tile * (E / 2) * (N1 * C / E) + ltid;
 #pragma unroll
         for (int g = 0; g < E / 2; ++g) {
             w4_t q;
@@ -402,27 +493,32 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
             w[2 * g + 1] = mk<T>(q.z, q.w);
         }
     }
-#endif
     if (MODE != TM_BEGIN) {
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
-            if (SSFM_ABL_NO_P) q = (T)1e-3; else q = stream_load(&Pb[g * PSTR]);
+            if (SSFM_ABL_NO_P) q = (T)1e-3; else q = stream_load<U16>(&Pb[g * PSTR]);
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     }
-    cx<T>* ldsT = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0) + (SSFM_TWN_COMPUTE ? E * C : 0);
+    cx<T>* ldsT = Bs + (TWC ? E * C : 0);
     line_twiddles_issue<T, N1, E>(tw, j, a.tw1, ldsT, tid, N1 * C / E);
-    if (fft_tw_lds_entries(N1, E) > 0 && !SSFM_TWN_COMPUTE) __syncthreads();
-#if SSFM_TWN_COMPUTE
-    __syncthreads();
-    w[0] = wA;
+    if (fft_tw_lds_entries(N1, E) > 0 || TWC) __syncthreads();
+    if constexpr (TWC) {
+        w[0] = wA;
 #pragma unroll
-    for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
-#endif
+        for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
+    }
 
     line_twiddles_fetch<T, N1, E>(tw, j, ldsT);
     if (MODE != TM_BEGIN) {
+        if (U16) {
+            // lane h = 0 keeps its low half and takes lane + 32's low half; lane h = 1 takes lane - 32's high half
+#pragma unroll
+            for (int g = 0; g < E / 2; ++g) {
+                lane32_swap(v[2 * g], v[2 * g + 1]);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmulc(v[t], w[t]);
         if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, ColIdx<C>>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
@@ -451,6 +547,9 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
             q.x = pnew[4 * g]; q.y = pnew[4 * g + 1]; q.z = pnew[4 * g + 2]; q.w = pnew[4 * g + 3];
 #if SSFM_P_NT
             __builtin_nontemporal_store(q, &Pb[g * PSTR]);
+#elif SSFM_P_WT
+            if constexpr (sizeof(T) == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(&Pb[g * PSTR]), "v"(q) : "memory");
+            else Pb[g * PSTR] = q;
 #else
             Pb[g * PSTR] = q;
 #endif
@@ -462,8 +561,9 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
         for (int t = 0; t < E; ++t) v[t].x += phi[t];
     }
     if (MODE == TM_END) {
+        // (time-order output: plain stores -- it is read by whatever comes after the run, not by the next pass)
 #pragma unroll
-        for (int t = 0; t < E; ++t) stream_store(&Fb[off + t * stride], v[t]);
+        for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
         if (a.st != nullptr) {
             // workgroup maximum through LDS, one atomic per workgroup on its slot; the LAST workgroup to arrive
             // (two-level ticket) then runs the step control, so an adaptive step is 3 launches (BEGIN, k_freq,
@@ -524,8 +624,20 @@ __global__ __launch_bounds__(N1 * C / E, min_waves(N1 * C / E, sizeof(T), E)) vo
     constexpr int NX = fft_nstages(N1, E) - 1;      // exchanges of the inverse transform
     constexpr int XP_FWD = (MODE != TM_MID || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, ColIdx<C>>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
+    if (U16) {
 #pragma unroll
-    for (int t = 0; t < E; ++t) stream_store(&Fb[off + t * stride], cmul(v[t], w[t]));
+        for (int t = 0; t < E; ++t) v[t] = cmul(v[t], w[t]);
+#pragma unroll
+        for (int g = 0; g < E / 2; ++g) {
+            lane32_swap(v[2 * g], v[2 * g + 1]);           // (the exchange is its own inverse)
+            u4_t q;
+            q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
+            stream_store(reinterpret_cast<u4_t*>(&Yb[offy + 2 * g * stride]), q);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < E; ++t) stream_store(&Yb[off + t * stride], cmul(v[t], w[t]));
+    }
 #if SSFM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -544,6 +656,7 @@ template <typename T> struct FreqArgs {
     T inv_n;
     int N1;
     int rows;                // batch rows covered by this launch
+    int u16;                 // field rows in the 16-byte-unit order (host side picks the kernel variant)
     SSFM_TRACE_ARGS
 };
 
@@ -551,8 +664,8 @@ template <typename T> __device__ __forceinline__ T exp_acc(T x);
 template <> __device__ __forceinline__ float exp_acc<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double exp_acc<double>(double x) { return exp(x); }
 
-template <typename T, int N2, int ROWS, int E, int MODE>
-__global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T), E)) void k_freq(const FreqArgs<T> a) {
+template <typename T, int N2, int ROWS, int E, int MODE, bool U16 = false>
+__global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const FreqArgs<T> a) {
     constexpr int Q = N2 / E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -580,8 +693,19 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T), 
     cx<T> m[E];
     LineTw<T, N2, E> tw;
     SSFM_STAMP(0);
+    typedef T u4_t __attribute__((ext_vector_type(4)));
+    if (U16) {
+        // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
 #pragma unroll
-    for (int t = 0; t < E; ++t) v[t] = stream_load(&Frow[j + t * Q]);
+        for (int g = 0; g < E / 2; ++g) {
+            const u4_t q = stream_load<true>(reinterpret_cast<const u4_t*>(Frow) + g * Q + j);
+            v[2 * g] = mk<T>(q.x, q.y);
+            v[2 * g + 1] = mk<T>(q.z, q.w);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = stream_load<false>(&Frow[j + t * Q]);
+    }
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
     if (MODE != FM_FWD_ONLY) {
@@ -626,8 +750,17 @@ __global__ __launch_bounds__(ROWS * N2 / E, min_waves(ROWS * N2 / E, sizeof(T), 
     SSFM_STAMP(4);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : (lds_double_buffer<T>() ? ((fft_nstages(N2, E) - 1) & 1) : 1)), RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     SSFM_STAMP(5);
+    if (U16) {
 #pragma unroll
-    for (int t = 0; t < E; ++t) stream_store(&Frow[j + t * Q], v[t]);
+        for (int g = 0; g < E / 2; ++g) {
+            u4_t q;
+            q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
+            stream_store(reinterpret_cast<u4_t*>(Frow) + g * Q + j, q);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < E; ++t) stream_store(&Frow[j + t * Q], v[t]);
+    }
 #if SSFM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -649,7 +782,7 @@ template <typename T> __global__ void k_make_twpow(cx<T>* tab, long long count, 
     tab[m] = mk<T>((T)c, (T)s);
 }
 // W_N^(k1*n2) at [k1*N2 + n2]
-template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2, int C, int E) {
+template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2, int C, int E, int u16, int Qf) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long N = (long long)N1 * N2;
     if (o >= N) return;
@@ -657,7 +790,7 @@ template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2, int
     const long long m = (k1 * n2) % N;
     double s, c;
     sincospi(-2.0 * (double)m / (double)N, &s, &c);
-    tab[time_tw_pos(k1, n2, N1 / E, C, E)] = mk<T>((T)c, (T)s);
+    tab[u16 ? time_tw_pos_u16(k1, n2, N1 / E, E, Qf, N2 / C) : time_tw_pos(k1, n2, N1 / E, C, E)] = mk<T>((T)c, (T)s);
 }
 // out[k1*N2 + freq_tab_pos(k2)] = f(src[k1 + N1*k2]); MODE 0: copy, 1: * inv_n, 2: exp(src*h) * inv_n
 template <typename T, int MODE>

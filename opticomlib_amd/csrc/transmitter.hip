@@ -141,3 +141,91 @@ extern "C" int ssfm_laser(int device, void* out, int64_t n, double amp, const do
     HIP_TRY(hipDeviceSynchronize());
     return SSFM_OK;
 }
+
+// ---------------------------------------------------------------------------------- small array helpers
+// ssfm_device_mean2: mean of a float64 array (out[0]) or of the real and imaginary parts of a complex128 one
+// (out[0], out[1]); ssfm_device_shift: dst = src + (re + j im) (AC coupling of a complex pulse, devices.py:339-340);
+// ssfm_device_zero: `bytes` zero bytes (an empty polarisation, devices.py:924); ssfm_device_power: mean |x|^2 of
+// each of `rows` rows of n complex128 (float64: x^2) values.
+namespace {
+
+__global__ __launch_bounds__(256) void k_sum_strided(const double* __restrict__ a, long long n, int stride, int offset, int square, double* __restrict__ partial) {
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (square) {
+            double v = 0.0;
+            for (int k = 0; k < stride; ++k) { const double x = a[i * stride + k]; v += x * x; }
+            acc += v;
+        } else {
+            acc += a[i * stride + offset];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+__global__ __launch_bounds__(256) void k_shift(double* __restrict__ dst, const double* __restrict__ src, long long n, int is_complex, double re, double im) {
+    const long long total = is_complex ? 2 * n : n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = src[i] + ((is_complex && (i & 1)) ? im : re);
+}
+
+int reduce_sum(int device, const double* a, long long n, int stride, int offset, int square, double* sum_out) {
+    constexpr int kBlocks = 512;
+    double* partial = nullptr;
+    if (int rc = ssfm_device_alloc(device, sizeof(double) * kBlocks, (void**)&partial)) return rc;
+    hipLaunchKernelGGL(k_sum_strided, dim3(kBlocks), dim3(256), 0, 0, a, n, stride, offset, square, partial);
+    double host[kBlocks];
+    hipError_t e = hipMemcpy(host, partial, sizeof(host), hipMemcpyDeviceToHost);
+    (void)ssfm_device_free(device, partial, sizeof(double) * kBlocks);
+    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "device reduction: %s", hipGetErrorString(e));
+    double acc = 0.0;
+    for (int i = 0; i < kBlocks; ++i) acc += host[i];
+    *sum_out = acc;
+    return SSFM_OK;
+}
+
+}  // namespace
+
+extern "C" int ssfm_device_mean2(int device, const void* src, int64_t n, int is_complex, double* out) {
+    if (!src || !out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_mean2: bad argument");
+    if (int rc = use_dev(device)) return rc;
+    const int stride = is_complex ? 2 : 1;
+    for (int k = 0; k < stride; ++k) {
+        double s = 0.0;
+        if (int rc = reduce_sum(device, (const double*)src, (long long)n, stride, k, 0, &s)) return rc;
+        out[k] = s / (double)n;
+    }
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_power(int device, const void* src, int rows, int64_t n, int is_complex, double* out) {
+    if (!src || !out || n < 1 || rows < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_power: bad argument");
+    if (int rc = use_dev(device)) return rc;
+    const int stride = is_complex ? 2 : 1;
+    for (int r = 0; r < rows; ++r) {
+        double s = 0.0;
+        if (int rc = reduce_sum(device, (const double*)src + (size_t)r * n * stride, (long long)n, stride, 0, 1, &s)) return rc;
+        out[r] = s / (double)n;
+    }
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_shift(int device, void* dst, const void* src, int64_t n, int is_complex, double re, double im) {
+    if (!dst || !src || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_shift: bad argument");
+    if (int rc = use_dev(device)) return rc;
+    hipLaunchKernelGGL(k_shift, dim3(blocks_of(n)), dim3(256), 0, 0, (double*)dst, (const double*)src, (long long)n, is_complex, re, im);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SSFM_OK;
+}
+
+extern "C" int ssfm_device_zero(int device, void* dst, size_t bytes) {
+    if (!dst) return fail(SSFM_ERR_INVALID, "ssfm_device_zero: NULL");
+    if (int rc = use_dev(device)) return rc;
+    HIP_TRY(hipMemset(dst, 0, bytes));
+    return SSFM_OK;
+}

@@ -50,6 +50,12 @@ def release_plans():
         p.close()
 
 
+def _tag(*key) -> int:
+    """Non-zero 64-bit label of what a caller stages in a plan (``Plan.set_tag`` / ``Plan.tag``): the plan itself
+    clears the label whenever the buffer is overwritten, so a matching label means the content is still there."""
+    return (hash(key) & (2 ** 64 - 1)) | 1
+
+
 def _is_fast_size(n: int, precision: int) -> bool:
     """Power of two within the fused two-kernel engine's range."""
     lo, hi = _lib.supported_log2n(precision)
@@ -230,6 +236,9 @@ def step_schedule(length, h, precision=_lib.C64):
 
 
 # ------------------------------------------------------------------ chirp-z engine (any length)
+_CHIRPS: "OrderedDict[tuple, tuple]" = OrderedDict()      # (device, n) -> (c, conj c) on the device; content-addressed, never stale
+
+
 class _ChirpZ:
     """Split-step / single-transfer engine for fields of ANY length n on a power-of-two complex128 plan of
     M >= 2n - 1 points (Bluestein; algebra in csrc/chirpz.hip).  The field lives in a device array in natural
@@ -239,19 +248,19 @@ class _ChirpZ:
         self.n, self.batch, self.dev = int(n), int(batch), int(dev)
         M = 1 << max(8, (2 * n - 2).bit_length())
         self.plan = get_plan(M, batch, _lib.C128, dev)
-        self.plan._op_key = None                                # the plan's operator staging is reused
-        if getattr(self.plan, "_chirp_n", None) != n:
-            m = np.arange(n, dtype=np.int64)
-            c = np.exp(-1j * np.pi * ((m * m) % (2 * n)) / n)          # exp(-i pi m^2 / n), phase reduced exactly
-            v = np.zeros(M, dtype=np.complex128)
-            v[:n] = np.conj(c)
-            v[M - n + 1:] = np.conj(c[1:][::-1])                        # v[-m] = v[m]
-            self.plan.transfer_table(np.fft.fft(v), 0)                  # forward transform: convolve with conj(c)
-            self.plan.transfer_table(np.fft.fft(np.conj(v)), 1)         # inverse transform: convolve with c
-            self.plan._chirp = _lib.DeviceArray.from_host(c, np.complex128, dev)
-            self.plan._chirp_conj = _lib.DeviceArray.from_host(np.conj(c), np.complex128, dev)
-            self.plan._chirp_n = n
-        self.chirp, self.chirp_conj = self.plan._chirp, self.plan._chirp_conj
+        want = _tag("chirp", n)
+        if self.plan.tag(1) != want or self.plan.tag(2) != want:
+            # both convolution kernels are generated AND transformed on the device (csrc/chirpz.hip): no host FFT, no upload
+            for slot in (0, 1):
+                self.plan.load_chirp_kernel(n, slot)
+                self.plan.table_from_field(slot)
+                self.plan.set_tag(1 + slot, want)
+        key = (dev, n)
+        if key not in _CHIRPS:
+            _CHIRPS[key] = (_lib.chirp_device(n, False, dev), _lib.chirp_device(n, True, dev))
+            while len(_CHIRPS) > 4:
+                _CHIRPS.pop(next(iter(_CHIRPS)))
+        self.chirp, self.chirp_conj = _CHIRPS[key]
 
     def step(self, A, P, Dt, gamma: float, h: float, maxbits=None):
         """One symmetric split step of size ``h`` on the device array ``A`` (batch, n), in place."""
@@ -480,11 +489,20 @@ def FIBER(input: optical_signal,
 
     L = rt(length)
     plan = get_plan(n, batch, prec, dev)
-    dt = float(grid.dt)
-    op_key = (dt, float(alpha), float(beta_2), float(beta_3))
-    if getattr(plan, "_op_key", None) != op_key:          # D~ is O(N) host work + an upload: reuse it
+    with plan.lock:
+        return back(_fiber_on_plan(plan, A, A_dev, shape, float(grid.dt), L, length, alpha, beta_2, beta_3, gamma, phi_max, h,
+                                   show_progress, return_steps, prec, plan_dtype, rt, dev, t0))
+
+
+def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, gamma, phi_max, h, show_progress, return_steps,
+                   prec, plan_dtype, rt, dev, t0):
+    """The fused two-kernel engine behind ``FIBER`` (the caller holds the plan's lock for the whole sequence)."""
+    n = shape[-1]
+    batch = 1 if len(shape) == 1 else shape[0]
+    op_tag = _tag("fibre", dt, float(alpha), float(beta_2), float(beta_3))
+    if plan.tag(0) != op_tag:                             # D~ is O(N) host work + an upload: reuse it while the plan still holds it
         plan.set_linear_operator(linear_operator(n, dt, alpha, beta_2, beta_3, prec))
-        plan._op_key = op_key
+        plan.set_tag(0, op_tag)
     if A_dev is not None:
         plan.set_field_device(A_dev.ptr)
     else:
@@ -511,7 +529,7 @@ def FIBER(input: optical_signal,
         elif bar is not None and steps:
             done = 0
             for chunk in np.array_split(hs, min(20, steps)):      # progress needs sync points
-                _chain_fixed(plan, gamma, chunk)
+                plan.propagate_fixed(gamma, chunk)
                 plan.synchronize()
                 done += chunk.size
                 bar.update(min(100.0 * float(chunk.sum()) / float(L), max(0.0, 100.0 - bar.n)))
@@ -534,11 +552,7 @@ def FIBER(input: optical_signal,
     else:
         output = optical_signal(plan.get_field().reshape(shape))
     output.execution_time = time.time() - t0
-    return back(output)
-
-
-def _chain_fixed(plan, gamma, hs):
-    plan.propagate_fixed(gamma, hs)
+    return output
 
 
 def DBP(input: optical_signal,
@@ -603,22 +617,22 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
             return back(output), np.fft.fftshift(np.exp(phase))
         return back(output)
     plan = get_plan(n, rows * (2 if has_noise else 1), _lib.C128, dev)
-    plan._op_key = None                                   # DM may reuse the operator staging buffer
     # signal rows, then noise rows, straight into the plan's field buffer
     row_bytes = rows * n * 16
-    for k, a in enumerate([raw_s, raw_n] if has_noise else [raw_s]):
-        if _on_device(a):
-            d = _dev_array(a, np.complex128, dev)
-            plan.copy_into_field(k * row_bytes, d.ptr, row_bytes, on_device=True)
-        else:
-            h = np.ascontiguousarray(a, dtype=np.complex128)
-            plan.copy_into_field(k * row_bytes, h.ctypes.data, row_bytes, on_device=False)
-    H = plan.apply_dispersion(float(grid.dt), D, want_H=retH)
-    outs = []
-    for k in range(2 if has_noise else 1):
-        o = _lib.DeviceArray(shape, np.complex128, dev)
-        plan.copy_from_field(k * row_bytes, o.ptr, row_bytes)
-        outs.append(o)
+    with plan.lock:
+        for k, a in enumerate([raw_s, raw_n] if has_noise else [raw_s]):
+            if _on_device(a):
+                d = _dev_array(a, np.complex128, dev)
+                plan.copy_into_field(k * row_bytes, d.ptr, row_bytes, on_device=True)
+            else:
+                h = np.ascontiguousarray(a, dtype=np.complex128)
+                plan.copy_into_field(k * row_bytes, h.ctypes.data, row_bytes, on_device=False)
+        H = plan.apply_dispersion(float(grid.dt), D, want_H=retH)
+        outs = []
+        for k in range(2 if has_noise else 1):
+            o = _lib.DeviceArray(shape, np.complex128, dev)
+            plan.copy_from_field(k * row_bytes, o.ptr, row_bytes)
+            outs.append(o)
     output = _wrap_out(optical_signal, outs[0], outs[1] if has_noise else NULL, n_pol=input.n_pol)
     output.execution_time = time.time() - t0
     if retH:
@@ -668,7 +682,7 @@ def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, d
     res = []
     for a in ([input._raw("signal"), input._raw("noise")] if has_noise else [input._raw("signal")]):
         if _on_device(a) and a.dtype != np.float64:
-            a = a.to_host()                                  # complex on the device: take the real part on the host
+            a = _lib.real_device(a if a.dtype == np.complex128 else a.astype(np.complex128))     # complex on the device: its real part, there
         x = a if _on_device(a) else _lib.DeviceArray.from_host(np.real(a), np.float64, dev)
         y = _lib.DeviceArray(x.shape, np.float64, dev)
         _lib.sosfiltfilt_device(sos, zi, x.ptr, y.ptr, x.shape[-1], 1, False, dev)
@@ -845,7 +859,7 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
         d = _dev_array(a, np.complex128, dev)
         if d.ndim == 2:
             return _lib.scale_add_device(d, g)
-        out2 = _lib.randn_device((2, n), 0.0, 0, 0, np.complex128, dev)          # zeros
+        out2 = _lib.zeros_device((2, n), np.complex128, dev)                      # empty y polarisation
         x = _lib.scale_add_device(d, g)
         _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(out2.ptr), _lib._VP(x.ptr), n * 16, 2), "ssfm_device_copy")
         return out2
@@ -868,18 +882,17 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
 _PRBS_TAPS = {7: (7, 6), 9: (9, 5), 11: (11, 9), 15: (15, 14), 20: (20, 3), 23: (23, 18), 31: (31, 28)}
 
 
-def PRBS(order: int, len: int = None, seed: int = None, return_seed: bool = False):
+def PRBS(order: int, len: int = None, seed: int = None, return_seed: bool = False, *, device=None):
     """Pseudo-random binary sequence of the reference's LFSR (``devices.py:63-182``), bit for bit: polynomial
     ``x^order + x^t2 + 1`` (PRBS-7/9/11/15/20/23/31), state seeded with ``seed % 2**order`` (default all ones;
     0 becomes 1 with a UserWarning), output = bit 0 of the state before every shift.  With ``return_seed`` also
     the final state, to continue the sequence.
 
-    The reference walks the register one bit per Python iteration; here the output recurrence
-    ``o[j] = o[j-p] ^ o[j-q]`` (p = order, q = t2) is advanced in blocks: over GF(2) it implies
-    ``o[j] = o[j-Lp] ^ o[j-Lq]`` for every L = 2^k, so a block of L*q bits is one vector XOR.  Host integer
-    work (a 2^20-bit sequence takes about a millisecond); the bits feed the DAC.
+    The reference walks the register one bit per Python iteration.  Here the bits are generated by a HIP kernel
+    (``ssfm_prbs``, csrc/prbs.hip): a shift is a linear map over GF(2), so every thread jumps to its chunk of the
+    sequence with powers of the shift matrix and walks it exactly as the reference does.  The sequence stays in GPU
+    memory (``binary_sequence.from_device``) until somebody reads ``.data``; a ``DAC`` takes it from there.
     """
-    import builtins
     import warnings
     t0 = time.time()
     if seed is not None:
@@ -898,26 +911,14 @@ def PRBS(order: int, len: int = None, seed: int = None, return_seed: bool = Fals
         len = 2 ** order - 1
     if order not in _PRBS_TAPS:
         raise ValueError("The parameter `order` must be one of the following values (7, 9, 11, 15, 20, 23, 31).")
-    p, q = _PRBS_TAPS[order]
-    s = order - 1                                           # b[s + j] = o[j]; b[s - m] = seed bit m ("outputs" before time 0)
-    b = np.empty(s + len + 1, dtype=np.uint8)
-    for m in range(order):
-        b[s - m] = (seed >> m) & 1
-    J = 1                                                   # o[j] known for j < J
-    while J <= len:
-        L = 1                                               # largest power of two with L*p - s <= J and (L-1)*p + 1 <= J
-        while 2 * L * p - s <= J and (2 * L - 1) * p + 1 <= J:
-            L *= 2
-        blk = builtins.min(L * q, len + 1 - J)
-        b[s + J: s + J + blk] = b[s + J - L * p: s + J - L * p + blk] ^ b[s + J - L * q: s + J - L * q + blk]
-        J += blk
-    output = binary_sequence(b[s: s + len])
+    dev = default_device() if device is None else int(device)
+    bits, last = _lib.prbs_device(order, len, seed, dev)
+    output = binary_sequence.from_device(bits)
+    if not KEEP_ON_DEVICE:
+        output.data                                         # noqa: B018 -- the attribute read downloads
     output.execution_time = time.time() - t0
     if not return_seed:
         return output
-    last = 0
-    for k in range(order):                                  # state after `len` shifts: bit k = o[len - k]
-        last |= int(b[s + len - k]) << k
     return output, last
 
 
@@ -961,13 +962,14 @@ def _rcos_spec(beta, span, sps, shape="sqrt"):
     return (3,) + grid + (0, [beta, 4 * beta, 1 - beta, 1 + beta, 1 / (4 * beta), at_zero, at_special]), False
 
 
-def _upfir_device(bits: np.ndarray, h, up: int, dev: int, spec=None) -> "_lib.DeviceArray":
+def _upfir_device(bits, h, up: int, dev: int, spec=None) -> "_lib.DeviceArray":
     """``upfir`` of the reference (``utils.py:1949-1981``): zero-stuffing at offset ``up//2`` and the 'same' part of
     the linear convolution with the pulse -- as ONE circular convolution on a power-of-two complex128 plan
     (``x <- ifft(fft(x) * fft(h))``, three launches); SciPy's ``fftconvolve`` does the same on the host.
     The pulse is either an explicit impulse response ``h`` (uploaded) or ``spec = (args of Plan.load_pulse, complex?)``
-    of a built-in shape, generated on the device."""
-    n = bits.size * up
+    of a built-in shape, generated on the device.  ``bits``: a host array, or the uint8 device array a ``PRBS`` left
+    in GPU memory (then nothing is uploaded at all)."""
+    n = int(bits.size) * up
     if spec is None:
         h = np.asarray(h)
         taps, cplx = h.size, np.iscomplexobj(h)
@@ -979,19 +981,21 @@ def _upfir_device(bits: np.ndarray, h, up: int, dev: int, spec=None) -> "_lib.De
     if M > (1 << hi):
         raise ValueError(f"DAC: {bits.size} bits x {up} samples with a {taps}-tap pulse exceed the device path (2^{hi} points)")
     plan = get_plan(M, 1, _lib.C128, dev)
-    plan._op_key = None
-    plan._chirp_n = None                                    # the table slots are taken over
-    if spec is None:
-        hd = _lib.DeviceArray.from_host(np.ascontiguousarray(h, dtype=np.complex128 if cplx else np.float64), None, dev)
-        plan.load_padded(hd)                                # field <- h, zero-padded
-    else:
-        plan.load_pulse(*spec[0])                           # field <- the pulse, generated in place
-    plan.table_from_field(0)                                # slot 0 <- fft(h)
-    bd = _lib.DeviceArray.from_host(np.ascontiguousarray(bits, dtype=np.float64), np.float64, dev)
-    plan.load_symbols(bd, up)                               # field <- zero-stuffed bits
-    plan.apply_table(0)
-    out = _lib.DeviceArray((n,), np.complex128, dev)
-    plan.copy_from_field(((taps - 1) // 2) * 16, out.ptr, n * 16)          # 'same': centred with respect to the full output
+    with plan.lock:
+        if spec is None:
+            hd = _lib.DeviceArray.from_host(np.ascontiguousarray(h, dtype=np.complex128 if cplx else np.float64), None, dev)
+            plan.load_padded(hd)                                # field <- h, zero-padded
+        else:
+            plan.load_pulse(*spec[0])                           # field <- the pulse, generated in place
+        plan.table_from_field(0)                                # slot 0 <- fft(h)  (the plan drops the slot's old label itself)
+        if _on_device(bits) and bits.dtype == np.uint8:
+            plan.load_bits(bits, up)                            # field <- zero-stuffed bits, where the generator left them
+        else:
+            bd = _lib.DeviceArray.from_host(np.ascontiguousarray(bits, dtype=np.float64), np.float64, dev)
+            plan.load_symbols(bd, up)                           # field <- zero-stuffed bits
+        plan.apply_table(0)
+        out = _lib.DeviceArray((n,), np.complex128, dev)
+        plan.copy_from_field(((taps - 1) // 2) * 16, out.ptr, n * 16)          # 'same': centred with respect to the full output
     return out if cplx else _lib.real_device(out)
 
 
@@ -1003,11 +1007,13 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
     optionally AC-coupled and band-limited by ``LPF(BW)``.  The pulse spans ``max(4, bits - 4)`` symbols, i.e. the
     shaping is a convolution as long as the signal: it runs as an FFT convolution on the GPU."""
     t0 = time.time()
-    seq = binary_sequence(input)
+    seq = input if isinstance(input, binary_sequence) else binary_sequence(input)
     bits = seq.size
     sps = gv.sps
-    data = seq.to_numpy()
     dev = default_device() if device is None else int(device)
+    data = seq._raw()                                       # host bits, or the device array a PRBS left in GPU memory
+    if _on_device(data) and data.device != dev:
+        data = seq.to_numpy()
     span = max(4, bits - 4)
     spec = None
     if h is not None:
@@ -1058,11 +1064,7 @@ def DAC(input, pulse_shape: str = "nrz", coupling: str = "DC", Vpp: float = 1.0,
     if offset is not None:
         x = _lib.axpb_device(x, 1.0, offset)
     if coupling.upper() == "AC":
-        if x.dtype.kind == "c":
-            xh = x.to_host()
-            x = _lib.DeviceArray.from_host(xh - np.mean(xh), np.complex128, dev)
-        else:
-            x = _lib.axpb_device(x, 1.0, -_lib.mean_device(x))
+        x = _lib.shift_device(x, -_lib.mean2_device(x))       # x - mean(x), real or complex, on the device
     output = _wrap_out(electrical_signal, x, NULL)
     if BW is not None:
         output = LPF(output, BW, device=dev)

@@ -4,15 +4,22 @@ The reference has no parallelism of any kind; what shards naturally is the outer
 writes around ``FIBER``: one call per WDM channel (configuration C3) or per Monte-Carlo PRBS
 realisation (C4).  Those calls never exchange data, so there is NO collective on the data path:
 unit ``i`` goes to rank ``i % world``, every rank runs its units on its own GPU, and ONE gather at
-the end (RCCL over xGMI when the backend is ``nccl``; ``gloo`` on CPU in the tests) returns the
-results in unit order.  xGMI is point-to-point, so the gather is a single all-gather of equal
-chunks -- 16 MiB per 2^20 x 2 complex64 field -- not a ring of small messages.
+the end returns the results in unit order.
+
+The gather works on DEVICE memory: each rank's results already lie side by side in GPU memory (the
+plan's field buffer of a batched run, or the device arrays the calls returned); they are handed to
+RCCL where they lie (``__cuda_array_interface__``, no copy), one ``all_gather_into_tensor`` (or
+``gather`` to rank 0) moves them over xGMI -- point-to-point links, so one collective of equal
+chunks, 16 MiB per 2^20 x 2 complex64 field, not a ring of small messages -- and the consumer
+downloads the gathered block ONCE (or keeps it on the GPU: ``on_device=True``).  With the ``gloo``
+backend (CPU tests of the harness) the same functions gather host arrays.
 
 One process per GPU: launch with ``python -m torch.distributed.run --nproc-per-node N ...``; the
 device is ``LOCAL_RANK`` (``devices.default_device``).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Callable, List, Sequence
 
@@ -36,7 +43,7 @@ def init(backend: str | None = None):
     import torch.distributed as dist
     if dist.is_initialized():
         return world()
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    if "RANK" not in os.environ:
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
@@ -57,35 +64,126 @@ def shard(n_units: int, rank: int | None = None, world_size: int | None = None) 
     return list(range(rank, n_units, world_size))
 
 
-def gather_results(local: Sequence[np.ndarray], n_units: int, to_all: bool = True):
-    """Gather per-unit arrays (all of one shape and dtype) into unit order.
+def _device_backend() -> bool:
+    import torch.distributed as dist
+    return dist.is_initialized() and dist.get_backend() == "nccl"
 
-    ``local[k]`` is the result of unit ``shard(n_units)[k]``.  Returns a list of ``n_units``
-    arrays on every rank (``to_all``) or on rank 0 only (others get ``None``).
-    """
-    rank, ws = world()
-    if ws == 1:
-        return list(local)
+
+class _RawDeviceView:
+    """A raw device pointer as a real-valued CUDA array (what torch / RCCL can take without a copy)."""
+
+    def __init__(self, ptr: int, count: int, real_dtype, owner=None):
+        self._owner = owner                                   # keeps the memory alive
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": np.dtype(real_dtype).str, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _torch_view(ptr: int, count: int, real_dtype, device: int, owner=None):
+    """1-D real torch tensor over ``count`` numbers at device address ``ptr`` (no copy)."""
+    import torch
+    return torch.as_tensor(_RawDeviceView(ptr, count, real_dtype, owner), device=torch.device("cuda", device))
+
+
+def _real_dtype(dt: np.dtype):
+    dt = np.dtype(dt)
+    return (np.dtype(np.float64) if dt == np.complex128 else np.dtype(np.float32)) if dt.kind == "c" else dt
+
+
+def gather_device(local_ptr: int, n_local: int, unit_shape, dtype, n_units: int, device: int, to_all: bool = True, owner=None):
+    """Gather per-unit results that lie side by side in the memory of GPU ``device`` (``n_local`` units of
+    ``unit_shape`` and ``dtype`` at ``local_ptr``; unit k is unit ``shard(n_units)[k]``) into ONE device array of
+    shape ``(n_units,) + unit_shape`` in unit order: ``_lib.DeviceArray`` on every rank (``to_all``) or on rank 0
+    (others get ``None``).  One collective on device memory; nothing crosses PCIe."""
     import torch
     import torch.distributed as dist
-    per_rank = -(-n_units // ws)                       # ceil: ranks with fewer units pad
-    first = np.asarray(local[0]) if len(local) else None
-    # every rank owns at least one unit when n_units >= world; otherwise learn the shape from rank 0
+    from . import _lib
+    rank, ws = world()
+    dtype = np.dtype(dtype)
+    rdt = _real_dtype(dtype)
+    per_unit = int(np.prod(unit_shape)) * (2 if dtype.kind == "c" else 1)          # real numbers per unit
+    per_rank = -(-n_units // ws)                                                    # ceil: ranks with fewer units pad
+    dev = torch.device("cuda", device)
+    tdt = torch.float64 if rdt == np.float64 else torch.float32
+    if n_local == per_rank:
+        send = _torch_view(local_ptr, per_rank * per_unit, rdt, device, owner)      # as it lies
+    else:
+        send = torch.zeros(per_rank * per_unit, dtype=tdt, device=dev)
+        if n_local:
+            send[: n_local * per_unit].copy_(_torch_view(local_ptr, n_local * per_unit, rdt, device, owner))
+    need = to_all or rank == 0
+    if ws == 1:
+        got = send
+    elif to_all:
+        got = torch.empty(ws * per_rank * per_unit, dtype=tdt, device=dev)
+        dist.all_gather_into_tensor(got, send)
+    else:
+        parts = [torch.empty(per_rank * per_unit, dtype=tdt, device=dev) for _ in range(ws)] if rank == 0 else None
+        dist.gather(send, parts, dst=0)
+        got = torch.cat(parts) if rank == 0 else None
+    if not need:
+        return None
+    out = _lib.DeviceArray((n_units,) + tuple(unit_shape), dtype, device)
+    dst = _torch_view(out.ptr, n_units * per_unit, rdt, device, out)
+    # got[r, k] is unit k * ws + r: rank-major -> unit order (a strided device copy)
+    dst.view(n_units, per_unit).copy_(got.view(ws, per_rank, per_unit).transpose(0, 1).reshape(ws * per_rank, per_unit)[:n_units])
+    torch.cuda.synchronize(dev)
+    return out
+
+
+def gather_results(local: Sequence, n_units: int, to_all: bool = True, on_device: bool = False):
+    """Gather per-unit arrays (all of one shape and dtype) into unit order.
+
+    ``local[k]`` is the result of unit ``shard(n_units)[k]``: NumPy arrays, or ``_lib.DeviceArray`` s.  Device arrays
+    under the ``nccl`` backend are gathered in GPU memory (:func:`gather_device`); the result is downloaded once
+    (list of ``n_units`` NumPy arrays) unless ``on_device``.  Returns the list on every rank (``to_all``) or on rank 0
+    only (others get ``None``).
+    """
+    from . import _lib
+    rank, ws = world()
+    is_dev = len(local) > 0 and all(isinstance(a, _lib.DeviceArray) for a in local)
+    if ws == 1:
+        if on_device or not is_dev:
+            return list(local)
+        return [a.to_host() for a in local]
+    import torch
+    import torch.distributed as dist
+    if _device_backend():
+        from .devices import default_device
+        dev = local[0].device if is_dev else default_device()
+        meta = [None]
+        if rank == 0:
+            first = local[0]
+            meta = [(tuple(first.shape), np.dtype(first.dtype).str)]
+        dist.broadcast_object_list(meta, src=0, device=torch.device("cuda", dev))
+        shape, dtstr = meta[0]
+        dt = np.dtype(dtstr)
+        # this rank's units side by side in one device block
+        block = _lib.DeviceArray((max(len(local), 1),) + tuple(shape), dt, dev)
+        nb = int(np.prod(shape)) * dt.itemsize
+        for k, a in enumerate(local):
+            d = a if isinstance(a, _lib.DeviceArray) else _lib.DeviceArray.from_host(np.asarray(a), dt, dev)
+            _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(block.ptr + k * nb), _lib._VP(d.ptr), nb, 2), "ssfm_device_copy")
+        out = gather_device(block.ptr, len(local), shape, dt, n_units, dev, to_all=to_all, owner=block)
+        if out is None:
+            return None
+        if on_device:
+            return out
+        host = out.to_host()
+        return [host[u] for u in range(n_units)]
+    # host arrays over gloo (the CPU tests of the harness)
+    local = [a.to_host() if isinstance(a, _lib.DeviceArray) else np.asarray(a) for a in local]
+    per_rank = -(-n_units // ws)
     meta = [None]
     if rank == 0:
-        meta = [(first.shape, first.dtype.str)]
+        meta = [(local[0].shape, local[0].dtype.str)]
     dist.broadcast_object_list(meta, src=0)
     shape, dtstr = meta[0]
     dt = np.dtype(dtstr)
     buf = np.zeros((per_rank,) + tuple(shape), dtype=dt)
     for k, a in enumerate(local):
         buf[k] = a
-    # complex arrays travel as real pairs (NCCL has no complex types)
-    view = buf.view(np.float64 if dt == np.complex128 else np.float32) if dt.kind == "c" else buf
-    use_cuda = dist.get_backend() == "nccl"
+    view = buf.view(_real_dtype(dt)) if dt.kind == "c" else buf        # complex arrays travel as real pairs
     t = torch.from_numpy(np.ascontiguousarray(view))
-    if use_cuda:
-        t = t.cuda()
     if to_all:
         outs = [torch.empty_like(t) for _ in range(ws)]
         dist.all_gather(outs, t)
@@ -96,7 +194,7 @@ def gather_results(local: Sequence[np.ndarray], n_units: int, to_all: bool = Tru
             return None
     res: List[np.ndarray] = [None] * n_units
     for r in range(ws):
-        arr = outs[r].cpu().numpy()
+        arr = outs[r].numpy()
         if dt.kind == "c":
             arr = arr.view(dt)
         arr = arr.reshape((per_rank,) + tuple(shape))
@@ -107,12 +205,27 @@ def gather_results(local: Sequence[np.ndarray], n_units: int, to_all: bool = Tru
 
 def sharded_map(fn: Callable[[int], np.ndarray], n_units: int, to_all: bool = True):
     """Run ``fn(unit)`` for this rank's units, then gather: the whole multi-GPU path."""
+    from . import _lib
     mine = shard(n_units)
-    local = [np.asarray(fn(u)) for u in mine]
+    local = [fn(u) for u in mine]
+    local = [a if isinstance(a, _lib.DeviceArray) else np.asarray(a) for a in local]
     return gather_results(local, n_units, to_all=to_all)
 
 
-def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False, **fiber_kw):
+@contextlib.contextmanager
+def _sampling_grid(dt: float):
+    """The global sampling grid set to ``dt`` for the calls inside, and put back afterwards (``FIBER`` reads
+    ``gv.dt`` at call time, reference ``typing.py:1641``; the caller's grid is not ours to change)."""
+    from .typing import gv
+    saved = (gv.dt, gv.fs)
+    gv.dt, gv.fs = dt, 1.0 / dt
+    try:
+        yield
+    finally:
+        gv.dt, gv.fs = saved
+
+
+def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False, on_device: bool = False, **fiber_kw):
     """``FIBER`` on every field of ``fields`` (shape ``(F, [2,] N)``), sharded over the ranks; with
     ``dbp=True`` followed by ``DBP`` with the same parameters (configuration C4: forward + digital
     back-propagation per Monte-Carlo realisation) without the field leaving the GPU in between.
@@ -120,45 +233,100 @@ def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False
     Each field is an independent propagation, exactly as F separate ``FIBER`` calls of the reference
     would be.  With a fixed step ``h`` the rows of different fields never interact, so all fields of
     this rank are propagated together in ONE plan (their rows are just more batch rows; several
-    fields resident on a GPU run at 15.5 instead of 21 us per field-step).  With the adaptive step
+    fields resident on a GPU run at 15 instead of 21 us per field-step).  With the adaptive step
     (``h=None``) every field keeps its own step-size sequence, so they run one after the other.
-    Returns the list of F output arrays (complex64, or complex128 with ``precision="complex128"``).
+    The results are gathered in GPU memory (module docstring) and downloaded once: a list of F output
+    arrays (complex64, or complex128 with ``precision="complex128"``) on every rank (``to_all``) or on
+    rank 0; with ``on_device`` one ``_lib.DeviceArray`` of shape ``(F, [2,] N)`` instead.
+    ``fields`` may also be a ``_lib.DeviceArray`` holding THIS rank's units (generated on the device).
     """
     from . import _lib
-    from .devices import FIBER, _check_size, _is_fast_size, _precision_code, get_plan, linear_operator, step_schedule
-    from .typing import gv, optical_signal
+    from .devices import DBP, FIBER, _check_size, _is_fast_size, _precision_code, default_device, get_plan, linear_operator, step_schedule
+    from .typing import optical_signal
 
-    fields = np.asarray(fields)
-    n_units = fields.shape[0]
-    mine = shard(n_units)
     kw = dict(fiber_kw)
-    fixed = kw.get("h") is not None and not kw.get("return_steps") and not kw.get("show_progress")
-    fixed = fixed and _is_fast_size(fields.shape[-1], _precision_code(kw.get("precision", "complex64")))     # other lengths: one by one (chirp-z)
-    local: List[np.ndarray] = []
-    if fixed and len(mine) > 1:
-        prec = _precision_code(kw.get("precision", "complex64"))
-        cdt = np.complex64 if prec == _lib.C64 else np.complex128
-        stack = np.ascontiguousarray(fields if len(mine) == n_units else fields[mine], dtype=cdt)     # one process: no copy
-        unit_shape = stack.shape[1:]
-        n = unit_shape[-1]
-        _check_size(n, prec)
-        rows = stack.reshape(-1, n)
-        plan = get_plan(n, rows.shape[0], prec, kw.get("device"))
-        plan.set_linear_operator(linear_operator(n, dt, kw.get("alpha", 0.0), kw.get("beta_2", 0.0), kw.get("beta_3", 0.0), prec))
-        plan._op_key = None
-        plan.set_field(rows)
-        hs, _ = step_schedule(kw["length"], kw["h"], prec)
-        if hs.size:
-            plan.propagate_fixed(kw.get("gamma", 0.0), hs)
-            if dbp:                                   # DBP = FIBER with negated parameters (devices.py:1280-1283)
-                plan.set_linear_operator(linear_operator(n, dt, -kw.get("alpha", 0.0), -kw.get("beta_2", 0.0), -kw.get("beta_3", 0.0), prec))
-                plan.propagate_fixed(-kw.get("gamma", 0.0), hs)
-        out = plan.get_field().reshape((len(mine),) + unit_shape)
-        local = [out[k] for k in range(len(mine))]
+    prec = _precision_code(kw.get("precision", "complex64"))
+    cdt = np.dtype(np.complex64 if prec == _lib.C64 else np.complex128)
+    dev = default_device() if kw.get("device") is None else int(kw["device"])
+    rank, ws = world()
+    local_dev = isinstance(fields, _lib.DeviceArray)             # this rank's units, already in GPU memory
+    if local_dev:
+        n_mine = fields.shape[0]
+        counts = [n_mine]
+        if ws > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([n_mine], device=torch.device("cuda", dev) if _device_backend() else "cpu")
+            g = [torch.zeros_like(t) for _ in range(ws)]
+            dist.all_gather(g, t)
+            counts = [int(x.item()) for x in g]
+        n_units = sum(counts)
+        if counts != [len(shard(n_units, r, ws)) for r in range(ws)]:
+            raise ValueError(f"device-resident units must follow the round-robin partition: got {counts} units per rank")
+        mine = shard(n_units)
+        unit_shape = tuple(fields.shape[1:])
     else:
-        from .devices import DBP
-        for u in mine:
-            gv.dt, gv.fs = dt, 1.0 / dt
-            y = FIBER(optical_signal(fields[u]), **kw)
-            local.append((DBP(y, **kw) if dbp else y).signal)
-    return gather_results(local, n_units, to_all=to_all)
+        fields = np.asarray(fields)
+        n_units = fields.shape[0]
+        mine = shard(n_units)
+        unit_shape = tuple(fields.shape[1:])
+    n = unit_shape[-1]
+    fixed = kw.get("h") is not None and not kw.get("return_steps") and not kw.get("show_progress")
+    fixed = fixed and _is_fast_size(n, prec)                      # other lengths: one by one (chirp-z)
+    if fixed and len(mine) >= 1:
+        _check_size(n, prec)
+        rows = len(mine) * (int(np.prod(unit_shape[:-1])) if len(unit_shape) > 1 else 1)
+        plan = get_plan(n, rows, prec, dev)
+        with plan.lock:
+            plan.set_linear_operator(linear_operator(n, dt, kw.get("alpha", 0.0), kw.get("beta_2", 0.0), kw.get("beta_3", 0.0), prec))
+            if local_dev:
+                src = fields if fields.dtype == cdt else fields.astype(cdt)
+                plan.set_field_device(src.ptr)
+            else:
+                stack = np.ascontiguousarray(fields if len(mine) == n_units else fields[mine], dtype=cdt)     # one process: no copy
+                plan.set_field(stack.reshape(rows, n))
+            hs, _ = step_schedule(kw["length"], kw["h"], prec)
+            if hs.size:
+                plan.propagate_fixed(kw.get("gamma", 0.0), hs)
+                if dbp:                                   # DBP = FIBER with negated parameters (devices.py:1280-1283)
+                    plan.set_linear_operator(linear_operator(n, dt, -kw.get("alpha", 0.0), -kw.get("beta_2", 0.0), -kw.get("beta_3", 0.0), prec))
+                    plan.propagate_fixed(-kw.get("gamma", 0.0), hs)
+            plan.synchronize()
+            if ws > 1 and _device_backend():
+                # the plan's field buffer IS the send buffer
+                out = gather_device(plan.field_device_ptr, len(mine), unit_shape, cdt, n_units, dev, to_all=to_all, owner=plan)
+            else:
+                out = _lib.DeviceArray((len(mine),) + unit_shape, cdt, dev)
+                plan.get_field_device(out.ptr)
+                plan.synchronize()
+        if ws > 1 and not _device_backend():
+            return gather_results([out.to_host()[k] for k in range(len(mine))], n_units, to_all=to_all)
+        if out is None:
+            return None
+        if on_device:
+            return out
+        host = out.to_host()
+        return [host[u] for u in range(n_units)]
+    local = []
+    kw.pop("device", None)
+    with _sampling_grid(dt):
+        for k, u in enumerate(mine):
+            if local_dev:
+                nb = int(np.prod(unit_shape)) * fields.dtype.itemsize
+                d = _lib.DeviceArray(unit_shape, fields.dtype, dev)
+                _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(d.ptr), _lib._VP(fields.ptr + k * nb), nb, 2), "ssfm_device_copy")
+                x = optical_signal.from_device(d)
+            else:
+                x = optical_signal(fields[u])
+            y = FIBER(x, device=dev, **kw)
+            if dbp:
+                y = DBP(y, device=dev, **kw)
+            local.append(y._raw("signal"))
+    if ws == 1 and on_device:
+        blk = _lib.DeviceArray((n_units,) + unit_shape, cdt, dev)
+        nb = int(np.prod(unit_shape)) * cdt.itemsize
+        for k, a in enumerate(local):
+            d = a if isinstance(a, _lib.DeviceArray) else _lib.DeviceArray.from_host(np.asarray(a), cdt, dev)
+            _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(blk.ptr + k * nb), _lib._VP(d.ptr), nb, 2), "ssfm_device_copy")
+        return blk
+    return gather_results(local, n_units, to_all=to_all, on_device=on_device)

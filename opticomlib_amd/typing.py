@@ -132,7 +132,23 @@ class _LazyArray:
 
 class binary_sequence:
     """Bit sequence container: the slice of reference ``typing.py:402-1020`` that ``PRBS`` returns and a DAC
-    consumes -- ``.data`` (uint8 0/1), ``.size``, ``len()``, ``.to_numpy()``, comparison with array-likes."""
+    consumes -- ``.data`` (uint8 0/1), ``.size``, ``len()``, ``.to_numpy()``, comparison with array-likes.
+    ``PRBS`` leaves its bits in GPU memory (``from_device``); ``.data`` downloads them on first access."""
+
+    data = _LazyArray()
+
+    @classmethod
+    def from_device(cls, bits):
+        """Wrap a device-resident uint8 array of 0 / 1 values without copying it to the host."""
+        self = cls.__new__(cls)
+        if bits.ndim != 1 or np.dtype(bits.dtype) != np.uint8:
+            raise ValueError(f"Binary sequence must be a 1D uint8 array, got {bits.dtype} {bits.shape}")
+        self.data = bits
+        self.execution_time = 0.0
+        return self
+
+    def _raw(self):
+        return self.__dict__.get("_data")
 
     def __init__(self, data):
         if isinstance(data, binary_sequence):
@@ -151,7 +167,7 @@ class binary_sequence:
 
     @property
     def size(self) -> int:
-        return int(self.data.size)
+        return int(self._raw().size)
 
     @property
     def type(self):
@@ -183,6 +199,8 @@ class binary_sequence:
         return self.data
 
     def __repr__(self):
+        if _is_device(self._raw()):
+            return f"binary_sequence(size={self.size}, on GPU {self._raw().device})"
         return f"binary_sequence({np.array2string(self.data, threshold=20)})"
 
 

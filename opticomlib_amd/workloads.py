@@ -1,5 +1,7 @@
-"""Synthetic link inputs of the benchmark configurations.  Host-side input
-generation only -- not on the hot path."""
+"""Synthetic link inputs of the benchmark configurations.  ``qpsk_field`` / ``prbs_field`` build
+them with NumPy on the host (seeded ``default_rng`` symbols cannot be generated anywhere else);
+``prbs_field_device`` builds the Monte-Carlo realisations of configuration C4 in GPU memory from nothing but the
+LFSR seed, so a realisation costs no host time and no upload."""
 from __future__ import annotations
 
 import numpy as np
@@ -43,3 +45,33 @@ def prbs_field(n: int, seed: int, n_pol: int = 2, sps: int = 16, power_w: float 
     bits = lfsr_bits(order, 2 * n_pol * nsym, seed).reshape(n_pol, nsym, 2).astype(np.int64)
     sym = ((2 * bits[..., 0] - 1) + 1j * (2 * bits[..., 1] - 1)) / np.sqrt(2)
     return _shape_pulses(sym, n, sps, power_w)
+
+
+def prbs_field_device(n: int, seed: int, n_pol: int = 2, sps: int = 16, power_w: float = 1e-3, order: int = 15, device=None):
+    """:func:`prbs_field` generated where it is used: the LFSR bits (``ssfm_prbs``), the QPSK-like symbols
+    (``ssfm_load_qpsk``), the Gaussian spectral shaping (one resident transfer function on a complex128 plan) and the
+    power normalisation all run on the GPU; returns a ``_lib.DeviceArray`` of shape ``(n_pol, n)``, complex64.
+    Agrees with the host version to the rounding of the two FFT implementations (1e-15 relative before the cast)."""
+    from . import _lib
+    from .devices import _tag, default_device, get_plan
+    dev = default_device() if device is None else int(device)
+    nsym = n // sps
+    s0 = int(seed) % (1 << order) or 1                            # PRBS(): seed modulo 2^order, 0 -> 1
+    bits, _ = _lib.prbs_device(order, 2 * n_pol * nsym, s0, dev)
+    plan = get_plan(n, n_pol, _lib.C128, dev)
+    with plan.lock:
+        tag = _tag("gauss-shape", n, sps)
+        if plan.tag(1) != tag:
+            f = np.fft.fftfreq(n) * sps                           # in symbol rates
+            plan.transfer_table(np.exp(-(f / 0.6) ** 2 * np.log(2)).astype(np.complex128), 0)
+            plan.set_tag(1, tag)
+        plan.load_qpsk(bits, nsym, sps)
+        plan.apply_table(0)
+        plan.synchronize()
+        src = plan.field_device_ptr
+        pw = _lib.power_device(src, n_pol, n, True, dev)
+        out = _lib.DeviceArray((n_pol, n), np.complex128, dev)
+        for r in range(n_pol):
+            _lib._check(_lib.load().ssfm_device_scale_add(dev, _lib._VP(out.ptr + r * n * 16), _lib._VP(src + r * n * 16),
+                                                          float(np.sqrt(power_w / pw[r])), None, 2 * n), "ssfm_device_scale_add")
+    return out.astype(np.complex64)

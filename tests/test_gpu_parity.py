@@ -1500,3 +1500,249 @@ def test_two_to_the_22_against_oracle():
     assert relmax(y, ref) < TOL_100
     y21 = oa.FIBER(optical_signal(a[: 1 << 21]), **kw).signal
     assert relmax(y21, orc.fiber_c64(a[: 1 << 21], gv.dt, **kw)) < TOL_100
+
+
+# ----------------------------------------------------------------------- PRBS on the device
+def test_prbs_bit_exact_against_golden_and_oracle(golden_dir):
+    """The HIP generator (ssfm_prbs) against vectors captured from the reference, the reference's own literal test
+    vectors (tests/devices_test.py:52-71) and the serial oracle on random orders / seeds / lengths, incl. the final
+    register state (return_seed) and every chunk boundary of the kernel (256 bits per thread)."""
+    from oracle import prbs_numpy as po
+    from test_oracle_golden import REF_PRBS_20
+    for name, case in CASES.items():
+        if case["func"] != "PRBS":
+            continue
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        seq, last = oa.PRBS(return_seed=True, **case["kw"])
+        assert isinstance(seq, oa.binary_sequence) and seq.type is oa.binary_sequence
+        assert isinstance(seq._raw(), _lib.DeviceArray) and len(seq) == g["out"].size          # still on the device, size known
+        assert seq.data.dtype == np.uint8
+        np.testing.assert_array_equal(seq.data, g["out"])
+        assert last == int(g["seed_out"])
+    for order, want in REF_PRBS_20.items():
+        assert oa.PRBS(order=order, len=20).data.tolist() == want
+    rng = np.random.default_rng(7)
+    for order in po.TAPS:
+        for _ in range(12):
+            n, seed = int(rng.integers(1, 4000)), int(rng.integers(1, 1 << 40))
+            if seed % (1 << order) == 0:
+                continue
+            a, la = oa.PRBS(order, n, seed, return_seed=True)
+            b, lb = po.prbs(order, n, seed)
+            np.testing.assert_array_equal(a.data, b)
+            assert la == lb
+    for n in (1, 255, 256, 257, 511, 512, 65536, 65537, (1 << 18) + 3):
+        a, la = oa.PRBS(23, n, seed=0x2f3a1, return_seed=True)
+        b, lb = po.prbs(23, n, 0x2f3a1)
+        np.testing.assert_array_equal(a.data, b)
+        assert la == lb
+    # continuing from the returned state reproduces the uninterrupted sequence
+    a, st = oa.PRBS(15, 1000, seed=99, return_seed=True)
+    b = oa.PRBS(15, 500, seed=st)
+    np.testing.assert_array_equal(np.concatenate([a.data, b.data]), oa.PRBS(15, 1500, seed=99).data)
+    assert np.all(oa.PRBS(7, len=2 * 127) == oa.PRBS(7, len=127).data.tolist() * 2)
+    with pytest.warns(UserWarning, match="changed to 1"):
+        assert oa.PRBS(7, len=10, seed=0).data.tolist() == [1, 0, 0, 0, 0, 0, 1, 1, 0, 0]          # devices_test.py:57
+    assert oa.PRBS(7).size == 127
+    with pytest.raises(oa.SsfmError, match="not a state"):
+        _lib.prbs_device(7, 10, 0)
+
+
+def test_prbs_feeds_the_dac_without_leaving_the_gpu():
+    """PRBS -> DAC: the bits go from the generator's kernel into the pulse shaper's input in GPU memory -- no
+    upload, no download -- and the drive signal equals the one shaped from the same bits given as a host array."""
+    gv(sps=16, R=10e9, N=512)
+    before = dict(_lib.TRANSFERS)
+    bits = oa.PRBS(15, len=512, seed=77)
+    v = oa.DAC(bits, Vpp=2.0, pulse_shape="rcos", beta=0.3)
+    assert _lib.TRANSFERS == before and isinstance(v._raw("signal"), _lib.DeviceArray)
+    v_host = oa.DAC(bits.data.copy(), Vpp=2.0, pulse_shape="rcos", beta=0.3)
+    np.testing.assert_array_equal(v.signal, v_host.signal)
+
+
+def test_c4_realisation_generated_on_the_device():
+    """workloads.prbs_field_device (LFSR bits, symbols, Gaussian shaping, power normalisation: all HIP) against the
+    host construction from the oracle's LFSR: equal to the rounding of the two FFTs, exact power, nothing uploaded
+    per realisation once the shaping filter is resident."""
+    from oracle import prbs_numpy as po
+    n, sps = 1 << 14, 16
+    for seed in (1, 5, 1 << 15):                                  # (2^15 is 0 modulo 2^order: becomes 1)
+        bits, _ = po.prbs(15, 4 * (n // sps), seed)
+        b = bits.reshape(2, n // sps, 2).astype(np.int64)
+        sym = ((2 * b[..., 0] - 1) + 1j * (2 * b[..., 1] - 1)) / np.sqrt(2)
+        want = workloads._shape_pulses(sym, n, sps, 1e-3)
+        before = _lib.TRANSFERS["h2d"]
+        got = workloads.prbs_field_device(n, seed=seed)
+        if seed != 1:
+            assert _lib.TRANSFERS["h2d"] == before               # (the first call uploads the shaping filter once)
+        assert got.shape == (2, n) and got.dtype == np.complex64
+        g = got.to_host()
+        assert relmax(g, want) < 3e-7
+        np.testing.assert_allclose(np.mean(np.abs(g.astype(np.complex128)) ** 2, axis=-1), 1e-3, rtol=1e-6)
+    np.testing.assert_array_equal(workloads.prbs_field(n, seed=5).astype(np.complex64).shape, (2, n))
+
+
+def test_full_size_c4_against_the_strided_fixture(golden_dir):
+    """Configuration C4 at its stated size: a realisation generated on the device from the LFSR seed, FIBER(100 x 1 km)
+    then DBP(100 x 1 km) without leaving the GPU, against the committed fixture of the oracle's chain
+    (tests/golden/make_c4_strided.py): every 257th sample, power and energy after FIBER and after DBP."""
+    from opticomlib_amd import dist as od
+    g = np.load(os.path.join(golden_dir, "c4_full_strided.npz"))
+    gv(**workloads.BENCH_GV)
+    n = 1 << 20
+    a = workloads.prbs_field_device(n, seed=int(g["seed"]))
+    assert relmax(a.to_host()[:, ::257], g["input_samples"]) < 3e-7
+    kw = dict(length=100, h=1.0, **workloads.SMF)
+    y = oa.FIBER(optical_signal.from_device(a), **kw)
+    x = oa.DBP(y, **kw)
+    for got, key in ((y.signal, "fiber"), (x.signal, "dbp")):
+        peak = np.max(np.abs(g[key + "_samples"]))
+        assert np.max(np.abs(got[:, ::257] - g[key + "_samples"])) / peak < 6e-5          # 100 / 200 steps: between the 2e-5 @ 100 and 3e-4 @ 1000 bounds
+        p2 = np.abs(got.astype(np.complex128)) ** 2
+        np.testing.assert_allclose(np.mean(p2, axis=-1), g[key + "_power"], rtol=1e-4)
+        np.testing.assert_allclose(np.sum(p2), float(g[key + "_energy"]), rtol=1e-4)
+    # the sharded entry point on device-resident units gives the same bits (one unit, one rank)
+    stacked = _lib.DeviceArray((1, 2, n), np.complex64)
+    _lib._check(_lib.load().ssfm_device_copy(0, _lib._VP(stacked.ptr), _lib._VP(a.ptr), a.nbytes, 2), "ssfm_device_copy")
+    out = od.propagate_channels(stacked, gv.dt, dbp=True, **kw)
+    np.testing.assert_array_equal(out[0], x.signal)
+
+
+# ----------------------------------------------------------------------- what a plan holds is the plan's knowledge
+def test_interleaved_users_of_one_plan_never_see_a_stale_table():
+    """FIBER (complex128), DM, DAC, a chirp-z FIBER and x('w') all end up on complex128 plans of the same length and
+    batch and reuse its operator staging and table slots.  Which operator / table is staged is tracked by the C plan
+    (ssfm_plan_set_tag / _get_tag): interleaving the users in every order must give each its oracle result."""
+    from oracle import transmitter_numpy as tx
+    gv(sps=8, R=16e9, N=64)
+    n = 4096
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.03
+    kw = dict(length=4, h=1.0, alpha=0.2, beta_2=-21.7, beta_3=0.1, gamma=1.5)
+    want_f = orc.fiber_c128(a, gv.dt, **kw)
+    want_dm = orc.dm_c128(a, gv.dt, -300.0)[0]
+    bits = (rng.integers(0, 2, 256)).astype(np.uint8)                    # 256 x 8 = 2048 samples -> DAC plan of 4096 points
+    want_dac = tx.dac(bits, 8, gv.fs, pulse_shape="gaussian", Vpp=1.5)
+    odd = a[:2001]                                                       # chirp-z on a 4096-point plan
+    want_odd = orc.fiber_c64(odd, gv.dt, **kw)
+    want_w = np.fft.fft(odd)
+
+    def fiber():
+        assert relmax(oa.FIBER(optical_signal(a), precision="complex128", **kw).signal, want_f) < TOL_C128
+
+    def dm():
+        assert relmax(oa.DM(optical_signal(a), D=-300.0).signal, want_dm) < 1e-12
+
+    def dac():
+        assert relmax(oa.DAC(bits, Vpp=1.5, pulse_shape="gaussian").signal, want_dac) < 1e-12
+
+    def odd_fiber():
+        assert relmax(oa.FIBER(optical_signal(odd), **kw).signal, want_odd) < TOL_100
+
+    def spectrum():
+        assert relmax(optical_signal(odd)("w").signal, want_w) < 1e-12
+
+    users = [fiber, dm, dac, odd_fiber, spectrum]
+    import itertools
+    for order in list(itertools.permutations(range(5)))[::7]:            # 18 of the 120 orders, every user in every position
+        for k in order:
+            users[k]()
+    for u in users:                                                      # and repeated calls hit the cached state
+        u(); u()
+    # the tags themselves: a label survives until the buffer is reused
+    p = _lib.Plan(n, 1, _lib.C128)
+    try:
+        assert p.tag(0) == 0 and p.tag(1) == 0
+        p.set_linear_operator(np.zeros(n, complex)); p.set_tag(0, 17)
+        assert p.tag(0) == 17
+        p.transfer_table(np.ones(n, complex), 0); p.set_tag(1, 5)
+        assert p.tag(0) == 0 and p.tag(1) == 5                           # the upload went through the operator's staging buffer
+        p.set_field(a); p.table_from_field(0)
+        assert p.tag(1) == 0
+        p.set_linear_operator(np.zeros(n, complex)); p.set_tag(0, 9)
+        p.apply_dispersion(gv.dt, 1e-24, want_H=True)
+        assert p.tag(0) == 0
+    finally:
+        p.close()
+
+
+def test_no_host_arithmetic_left_in_the_device_paths():
+    """Transfer counters: the Bluestein kernels, LPF of a complex device signal, AC coupling of a complex pulse and the
+    empty polarisation of an EDFA are all made on the device (round-1 versions went through NumPy)."""
+    gv(sps=16, R=10e9, N=128)
+    rng = np.random.default_rng(5)
+    x = _lib.DeviceArray.from_host((rng.standard_normal(3000) + 1j * rng.standard_normal(3000)) * 0.05, np.complex128)
+    oa.devices._CHIRPS.clear()
+    before = dict(_lib.TRANSFERS)
+    y = oa.FIBER(optical_signal.from_device(x), length=2, h=1.0, beta_2=-20.0, gamma=1.0)          # chirp-z: kernels built on the device
+    assert {k: _lib.TRANSFERS[k] - before[k] for k in before} == {"h2d": 1, "d2h": 0}              # (the operator D~ of the odd length)
+    e = oa.electrical_signal.from_device(x)
+    before = dict(_lib.TRANSFERS)
+    f = oa.LPF(e, BW=5e9)
+    assert _lib.TRANSFERS == before and f._raw("signal").dtype == np.float64
+    from scipy import signal as sg
+    sos = sg.bessel(4, 5e9, "low", fs=gv.fs, norm="mag", output="sos")
+    assert relmax(f.signal, sg.sosfiltfilt(sos, x.to_host().real)) < 1e-11
+    bits = rng.integers(0, 2, 128).astype(np.uint8)
+    before = _lib.TRANSFERS["d2h"]
+    v = oa.DAC(bits, pulse_shape="gaussian", c=0.7, coupling="AC")                                 # complex pulse, AC coupled
+    assert _lib.TRANSFERS["d2h"] == before and v._raw("signal").dtype == np.complex128
+    from oracle import transmitter_numpy as tx
+    assert relmax(v.signal, tx.dac(bits, 16, gv.fs, pulse_shape="gaussian", c=0.7, coupling="AC")) < 1e-12
+    one_pol = optical_signal.from_device(_lib.DeviceArray.from_host(rng.standard_normal(2048) + 0j, np.complex128))
+    np.random.seed(1)
+    before = _lib.TRANSFERS["d2h"]
+    amp = oa.EDFA(one_pol, G=10, NF=5)
+    assert _lib.TRANSFERS["d2h"] == before
+    assert amp.signal.shape == (2, 2048) and not amp.signal[1].any()
+
+
+# ----------------------------------------------------------------------- multi-rank path on real GPUs (RCCL)
+def _run_dist_gpu(tmp_path, world, n_units):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_dist_gpu_worker.py"), str(tmp_path), str(n_units)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)          # fresh child processes: they initialise their own GPUs
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_propagate_channels_over_rccl_matches_single_process(tmp_path, world):
+    """opticomlib_amd.dist.propagate_channels under torch.distributed.run with the nccl (= RCCL) backend: units sharded
+    round-robin, results gathered in GPU memory with one collective, equal BIT FOR BIT to the same calls in this
+    process.  world = 1 exercises the device-side gather code on the single GPU of the test box; world = 2 needs two
+    GPUs (skipped otherwise).  Fixed step (batched plan, uneven unit counts), FIBER + DBP to rank 0 only, adaptive
+    (one by one), device-resident units."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
+    sys_path_worker = os.path.join(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dist_gpu_worker", os.path.join(sys_path_worker, "_dist_gpu_worker.py"))
+    w = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(w)
+    n_units = 5
+    _run_dist_gpu(tmp_path, world, n_units)
+    from opticomlib_amd import dist as od
+    f = w.fields_for(n_units)
+    want_fixed = od.propagate_channels(f, w.DT, **w.FIXED)
+    want_dbp = od.propagate_channels(f, w.DT, dbp=True, **w.FIXED)
+    want_adapt = od.propagate_channels(f[:3], w.DT, **w.ADAPT)
+    assert relmax(want_fixed[0], orc.fiber_c64(f[0], w.DT, **w.FIXED)) < TOL_100        # and the single-process result is the oracle's
+    for rank in range(world):
+        got = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        for k in range(n_units):
+            np.testing.assert_array_equal(got[f"fixed_{k}"], want_fixed[k])
+            np.testing.assert_array_equal(got["fixed_dev"][k], want_fixed[k])
+            if rank == 0:
+                np.testing.assert_array_equal(got[f"dbp_{k}"], want_dbp[k])
+        assert ("dbp_0" in got.files) == (rank == 0)
+        for k in range(3):
+            np.testing.assert_array_equal(got[f"adapt_{k}"], want_adapt[k])

@@ -243,42 +243,8 @@ def test_foreign_signal_objects_are_adopted():
     assert od._adopt(y, "optical_signal")[0].noise is NULL and od._adopt(y, "optical_signal")[0].n_pol == 1
 
 
-# ------------------------------------------------------------------ PRBS (host integer code: needs no GPU)
-def test_prbs_bit_exact_against_golden_and_oracle(golden_dir):
-    """The block-wise generator against vectors captured from the reference, the reference's own literal test
-    vectors (tests/devices_test.py:52-71) and the serial oracle on random orders / seeds / lengths."""
-    import opticomlib_amd as oa
-    from cases import CASES
-    from oracle import prbs_numpy as po
-    from test_oracle_golden import REF_PRBS_20
-    for name, case in CASES.items():
-        if case["func"] != "PRBS":
-            continue
-        g = np.load(os.path.join(golden_dir, name + ".npz"))
-        seq, last = oa.PRBS(return_seed=True, **case["kw"])
-        assert isinstance(seq, oa.binary_sequence) and seq.type is oa.binary_sequence and seq.data.dtype == np.uint8
-        np.testing.assert_array_equal(seq.data, g["out"])
-        assert last == int(g["seed_out"]) and len(seq) == g["out"].size
-    for order, want in REF_PRBS_20.items():
-        assert oa.PRBS(order=order, len=20).data.tolist() == want
-    rng = np.random.default_rng(7)
-    for order in po.TAPS:
-        for _ in range(25):
-            n, seed = int(rng.integers(1, 4000)), int(rng.integers(1, 1 << 40))
-            if seed % (1 << order) == 0:
-                continue
-            a, la = oa.PRBS(order, n, seed, return_seed=True)
-            b, lb = po.prbs(order, n, seed)
-            np.testing.assert_array_equal(a.data, b)
-            assert la == lb
-    # continuing from the returned state reproduces the uninterrupted sequence
-    a, st = oa.PRBS(15, 1000, seed=99, return_seed=True)
-    b = oa.PRBS(15, 500, seed=st)
-    np.testing.assert_array_equal(np.concatenate([a.data, b.data]), oa.PRBS(15, 1500, seed=99).data)
-    assert np.all(oa.PRBS(7, len=2 * 127) == oa.PRBS(7, len=127).data.tolist() * 2)
-
-
-def test_prbs_errors_and_warning():
+# ------------------------------------------------------------------ PRBS: argument checks (the generator is HIP: tests/test_gpu_parity.py)
+def test_prbs_argument_errors_come_before_any_device_work():
     import opticomlib_amd as oa
     with pytest.raises(TypeError, match="must be an integer"):
         oa.PRBS(order=15, len="20")
@@ -286,9 +252,21 @@ def test_prbs_errors_and_warning():
         oa.PRBS(order=8)
     with pytest.raises(ValueError, match="greater than cero"):
         oa.PRBS(order=7, len=0)
-    with pytest.warns(UserWarning, match="changed to 1"):
-        assert oa.PRBS(7, len=10, seed=0).data.tolist() == [1, 0, 0, 0, 0, 0, 1, 1, 0, 0]
-    assert oa.PRBS(7).size == 127
+    if _lib.device_count() == 0:
+        with pytest.raises(oa.SsfmError):                  # no CPU generator behind it
+            oa.PRBS(7)
+
+
+def test_binary_sequence_container():
+    import opticomlib_amd as oa
+    b = oa.binary_sequence("0110 1")
+    assert b.size == 5 and len(b) == 5 and b.ones == 3 and b.zeros == 2 and b.type is oa.binary_sequence
+    assert b.data.dtype == np.uint8 and b[1] == 1 and b[1:3].data.tolist() == [1, 1]
+    assert np.all(b == [0, 1, 1, 0, 1]) and np.asarray(b).tolist() == [0, 1, 1, 0, 1]
+    with pytest.raises(ValueError, match="only 0 and 1"):
+        oa.binary_sequence([0, 2])
+    with pytest.raises(ValueError, match="must be 1D"):
+        oa.binary_sequence([[0, 1]])
 
 
 # ------------------------------------------------------------------ LASER / MZM: argument checks (the arithmetic is HIP: tests/test_gpu_parity.py)
