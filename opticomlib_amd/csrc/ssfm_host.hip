@@ -405,11 +405,12 @@ template <typename T> struct PlanT : PlanBase {
         // inter-pass twiddles W_N^(k1 n2): either the n-entry table in k_time's thread order, or (U16 plans) the two
         // small factor tables the kernel multiplies (ssfm_kernels.hpp SSFM_TWN_COMPUTE)
         if (u16 && SSFM_TWN_COMPUTE) {
-            const long long nA = (long long)(N1 / E) * N2, nB = (long long)E * N2;      // W_N^(j n2), j < N1/E;  W_N^(t n2 N1/E), t < E
+            const long long nA = (long long)(N1 / E) * N2, nB = (long long)E * N2;      // [tile][j][c], j < N1/E;  [tile][t][c], t < E
             HIP_TRY(hipMalloc(&twA, cb * nA));
             HIP_TRY(hipMalloc(&twB, cb * nB));
-            hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, nA, 1ll, (long long)n);
-            hipLaunchKernelGGL(k_make_twpow<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, nB, (long long)(N1 / E), (long long)n);
+            const int C_ = cols_per_tile<T>();
+            hipLaunchKernelGGL(k_make_tw_tiles<T>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, stream, twA, N1 / E, 1ll, N2, C_, (long long)n, (int)u16, N2 / Ef);
+            hipLaunchKernelGGL(k_make_tw_tiles<T>, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, stream, twB, E, (long long)(N1 / E), N2, C_, (long long)n, (int)u16, N2 / Ef);
         } else {
             HIP_TRY(hipMalloc(&twN, cb * n));
             hipLaunchKernelGGL(k_make_twN<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twN, N1, N2, cols_per_tile<T>(), E, (int)u16, N2 / Ef);

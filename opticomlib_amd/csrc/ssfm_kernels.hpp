@@ -164,8 +164,8 @@ template <typename T> struct TimeArgs {
                               // columns and its positions in the row order differ, so BEGIN / END go from one buffer to the other
     T* P;                     // stale |A|^2, tile-major (private to k_time)
     const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]                      (SSFM_TWN_COMPUTE == 0)
-    const cx<T>* twA;         // W_N^m,          m < (N1/E)*N2   W_N^(k1*n2) = twA[j*n2] * twB[t*n2],
-    const cx<T>* twB;         // W_N^(m*N1/E),   m < E*N2        k1 = j + t*N1/E  (SSFM_TWN_COMPUTE == 1)
+    const cx<T>* twA;         // [tile][j][c] = W_N^(j n2),        j < N1/E   W_N^(k1 n2) = twA * twB,  k1 = j + t N1/E,
+    const cx<T>* twB;         // [tile][t][c] = W_N^(t n2 N1/E),   t < E      n2 = column c of the tile  (SSFM_TWN_COMPUTE == 1)
     const cx<T>* tw1;         // W_N1^q
     AdaptState<T>* st;        // nullptr in fixed-step mode
     T* zlog;                  // adaptive mode: z after every step
@@ -476,12 +476,10 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     if constexpr (TWC) {
         // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
         // the tile's E x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
-        for (int e = tid; e < E * C; e += N1 * C / E) {
-            const int ce = e % C;
-            const int ne = U16 ? (int)u16_col_of_pos((long long)tile * C + 2 * (ce & 7) + (ce >> 3), a.Qf) : tile * C + ce;
-            Bs[e] = a.twB[(e / C) * ne];
-        }
-        wA = a.twA[j * ncol];
+        // (both tables are stored tile by tile in the order they are read here: 2 KiB + 2 KiB of contiguous lines per
+        // workgroup; indexed as twB[t n2] / twA[j n2] they were 512 gathers of 8 bytes, 2.4 MB of sectors per launch)
+        for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(long long)tile * (E * C) + e];
+        wA = a.twA[(long long)tile * (Q * C) + ltid];
     } else {
         typedef T w4_t __attribute__((ext_vector_type(4)));
         const w4_t* __restrict__ W4 = reinterpret_cast<const w4_t*>(a.twN) + (long long)tile * (E / 2) * (N1 * C / E) + ltid;
@@ -772,14 +770,17 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 }
 
 // ------------------------------------------------------------------------------ tables
-// tab[m] = W_N^(m*mult) = exp(-2 pi i m mult / N), m < count
-template <typename T> __global__ void k_make_twpow(cx<T>* tab, long long count, long long mult, long long N) {
-    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= count) return;
-    const long long r = (m * mult) % N;
-    double s, c;
-    sincospi(-2.0 * (double)r / (double)N, &s, &c);
-    tab[m] = mk<T>((T)c, (T)s);
+// Factor tables of the inter-pass twiddles, tile by tile: out[(tile * R + r) * C + c] = W_N^(r mult n2(tile, c)), r < R
+// (twA: R = N1/E, mult = 1;  twB: R = E, mult = N1/E)
+template <typename T> __global__ void k_make_tw_tiles(cx<T>* out, int R, long long mult, int N2, int C, long long N, int u16, int Qf) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (long long)R * N2) return;
+    const long long tile = o / ((long long)R * C), r = (o / C) % R, c = o % C;
+    const long long n2 = u16 ? u16_col_of_pos(tile * C + 2 * (c & 7) + (c >> 3), Qf) : tile * C + c;
+    const long long m = (r * mult % N) * n2 % N;
+    double sn, cs;
+    sincospi(-2.0 * (double)m / (double)N, &sn, &cs);
+    out[o] = mk<T>((T)cs, (T)sn);
 }
 // W_N^(k1*n2) at [k1*N2 + n2]
 template <typename T> __global__ void k_make_twN(cx<T>* tab, int N1, int N2, int C, int E, int u16, int Qf) {

@@ -10,7 +10,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/${TAG}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = "k_time_mid" if "k_time" in k and ", 1>" in k else ("k_freq" if "k_freq" in k else None)
+        k = "k_time_mid" if ("k_time<float" in k and (", 1>" in k or ", 1, true>" in k or ", 1, false>" in k)) else ("k_freq" if "k_freq<float" in k else None)
         if k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k, {c: round(sum(v)/len(v)) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
