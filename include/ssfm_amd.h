@@ -116,6 +116,16 @@ int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double
                             int single_step, int64_t max_steps, int64_t* steps_out, double* z_out,
                             void* snapshots);
 
+/* The same run in three calls, so that a z-resolved capture (return_steps, devices.py:1184-1186) reaches the host in
+ * bounded blocks instead of one (max_steps + 1)-field buffer: ssfm_adaptive_begin chooses the first step (capture != 0
+ * announces snapshots); ssfm_adaptive_run takes up to `budget` more steps -- snapshots: NULL, or HOST memory for `budget`
+ * fields, the field after each step this call takes (ask ssfm_get_field for the input beforehand) -- and reports the
+ * steps taken so far and whether z has reached the length; ssfm_adaptive_finish returns the step count and z_out as
+ * ssfm_propagate_adaptive does (z_out: steps + 1 values; size it from ssfm_adaptive_run's count). */
+int ssfm_adaptive_begin(ssfm_plan* plan, double gamma, double length, double phi_max, int single_step, int64_t max_steps, int capture);
+int ssfm_adaptive_run(ssfm_plan* plan, int64_t budget, void* snapshots, int64_t* steps_total, int* done);
+int ssfm_adaptive_finish(ssfm_plan* plan, int64_t* steps_out, double* z_out);
+
 /* out = ifft(fft(field) * H) on every row; H complex, length n, natural FFT order, HOST.
  * (reference DM, devices.py:1027-1029) */
 int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host);

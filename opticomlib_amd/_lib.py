@@ -33,6 +33,9 @@ SYMBOLS = {
     "ssfm_field_device_ptr": (_VP, [_VP]),
     "ssfm_propagate_fixed": (_I, [_VP, _D, _VP, _I64, _VP]),
     "ssfm_propagate_adaptive": (_I, [_VP, _D, _D, _D, _I, _I64, C.POINTER(_I64), C.POINTER(_D), _VP]),
+    "ssfm_adaptive_begin": (_I, [_VP, _D, _D, _D, _I, _I64, _I]),
+    "ssfm_adaptive_run": (_I, [_VP, _I64, _VP, C.POINTER(_I64), C.POINTER(_I)]),
+    "ssfm_adaptive_finish": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
     "ssfm_apply_transfer": (_I, [_VP, _VP]),
     "ssfm_apply_dispersion": (_I, [_VP, _D, _D, _VP]),
     "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
@@ -541,16 +544,31 @@ class Plan:
         return snap
 
     def propagate_adaptive(self, gamma, length, phi_max, single_step, max_steps=1 << 16, snapshots=False):
-        steps = _I64(0)
-        z = np.zeros(max_steps + 1, dtype=np.float64)
-        snap = None
-        if snapshots:
-            snap = host_empty((max_steps + 1, self.batch, self.n), self.cdtype)
-        _check(load().ssfm_propagate_adaptive(self._h, float(gamma), float(length), float(phi_max), int(bool(single_step)),
-                                              int(max_steps), C.byref(steps), z.ctypes.data_as(C.POINTER(_D)),
-                                              _ptr(snap) if snap is not None else None), "ssfm_propagate_adaptive")
+        """Adaptive run; returns ``(steps, z float64 (steps + 1,), snapshots or None)``.  A z-resolved capture is taken in
+        blocks of at most 256 MiB of page-locked memory (``ssfm_adaptive_run``), so its memory follows the steps actually
+        taken, not ``max_steps``."""
+        lib = load()
+        steps, done = _I64(0), _I(0)
+        if not snapshots:
+            _check(lib.ssfm_adaptive_begin(self._h, float(gamma), float(length), float(phi_max), int(bool(single_step)), int(max_steps), 0), "ssfm_adaptive_begin")
+            _check(lib.ssfm_adaptive_run(self._h, int(max_steps), None, C.byref(steps), C.byref(done)), "ssfm_adaptive_run")
+            blocks = None
+        else:
+            blocks = [self.get_field().reshape(1, self.batch, self.n)]                      # the input (devices.py:1150-1152)
+            _check(lib.ssfm_adaptive_begin(self._h, float(gamma), float(length), float(phi_max), int(bool(single_step)), int(max_steps), 1), "ssfm_adaptive_begin")
+            per = max(1, min(64, (256 << 20) // max(1, self.batch * self.n * np.dtype(self.cdtype).itemsize)))
+            while not done.value and steps.value < max_steps:
+                before = steps.value
+                blk = host_empty((per, self.batch, self.n), self.cdtype)
+                _check(lib.ssfm_adaptive_run(self._h, per, _ptr(blk), C.byref(steps), C.byref(done)), "ssfm_adaptive_run")
+                blocks.append(blk[: steps.value - before])
+        z = np.zeros(steps.value + 1, dtype=np.float64)
+        _check(lib.ssfm_adaptive_finish(self._h, C.byref(steps), z.ctypes.data_as(C.POINTER(_D))), "ssfm_adaptive_finish")
         s = steps.value
-        return s, z[: s + 1].copy(), (snap[: s + 1] if snap is not None else None)
+        snap = None
+        if blocks is not None:
+            snap = blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=0)       # a compact copy: nothing of the blocks stays alive
+        return s, z, snap
 
     def apply_transfer(self, H: np.ndarray):
         h = np.ascontiguousarray(H, dtype=self.cdtype)

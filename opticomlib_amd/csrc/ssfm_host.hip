@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -46,12 +47,15 @@ template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = cols_per_tile<T>();
     constexpr bool U16 = u16_layout<T>(N1, C, E);          // the field layout between the kernels (ssfm_kernels.hpp "U16")
+    if constexpr (!U16 && MODE > TM_END) return hipErrorInvalidValue;      // (tile-private time-domain modes: U16 plans only)
+    else {
     constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                          + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((k_time<T, N1, C, E, MODE, U16>), grid, dim3(N1 * C / E), lds, s, a);
     return hipGetLastError();
+    }
 }
 template <typename T, int MODE, int E>
 hipError_t launch_time_e(int N1, int batch, hipStream_t s, const TimeArgs<T>& a) {
@@ -535,7 +539,7 @@ template <typename T> struct PlanT : PlanBase {
 #endif
         (void)lane;
         a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
-        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef;
+        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0;
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
@@ -544,7 +548,7 @@ template <typename T> struct PlanT : PlanBase {
         trace_tag(a, 1, lane);
 #endif
         (void)lane;
-        a.F = Y + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0; a.u16 = u16 ? 1 : 0;
+        a.F = Y + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0; a.u16 = u16 ? 1 : 0; a.step = 0;
         return a;
     }
 
@@ -695,13 +699,24 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
-    int propagate_adaptive(double gamma_d, double length, double phi_max, int single_step, int64_t max_steps,
-                           int64_t* steps_out, double* z_out, void* snapshots) {
+    // ---- adaptive run (reference devices.py:1155-1161, 1172-1196 with h = None), in three parts so that a z-resolved
+    // capture can go to the host in bounded blocks: adaptive_begin (first step size), adaptive_run (up to `budget`
+    // steps; all of them without a capture), adaptive_finish (time-order field, z log).
+    struct AdaptRun {
+        bool active = false;
+        bool tile_private = false;     // U16 plans without capture: the field between END and BEGIN stays in the Y buffer
+        T gamma = 0;
+        T length = 0;
+        int max_steps = 0;
+        int step = 0;                  // index of the next step to launch
+        StepState<T> now = {};         // state after the last launched step (host copy)
+    } ar;
+
+    int adaptive_begin(double gamma_d, double length, double phi_max, int single_step, int64_t max_steps, int capture) {
         if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_adaptive: call ssfm_set_linear_operator first");
         if (max_steps < 1 || max_steps > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_propagate_adaptive: max_steps=%lld", (long long)max_steps);
         if (int rc = use_device()) return rc;
         const T gamma = (T)gamma_d;
-        const int nrows = N1 * batch;
         if (zlog_cap < max_steps + 1) {
             (void)hipFree(zlog); zlog = nullptr; zlog_cap = 0;
             HIP_TRY(hipMalloc(&zlog, sizeof(T) * (max_steps + 1)));
@@ -721,49 +736,106 @@ template <typename T> struct PlanT : PlanBase {
             hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, (const cx<T>*)F, (long long)n * batch, st);
             ++last_launches;
         }
-        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 0, single_step);
+        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 0, single_step, 0);
         ++last_launches;
         HIP_TRY(hipGetLastError());
+        // the first step size comes back at once: it tells how many steps to queue before the first look at the state
+        // (a run of a few dozen steps is then two or three chunks, not five: every look is a 25 us stall)
+        StepState<T> first;
+        HIP_TRY(hipMemcpyAsync(&first, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(first), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));             // (also: hs is a stack variable)
+        ar = AdaptRun();
+        ar.now = first;
+        ar.active = true;
+        ar.gamma = gamma;
+        ar.length = (T)length;
+        ar.max_steps = (int)max_steps;
+        // U16 plans keep the time-domain field between END and the next BEGIN in the Y buffer, in tile-private 16-byte
+        // units (ssfm_kernels.hpp TM_END_Y / TM_BEGIN_Y); a z-resolved capture needs the time-order field after every
+        // step and uses the plain modes
+        ar.tile_private = u16 && !capture;
+        return SSFM_OK;
+    }
+
+    // Up to `budget` more steps.  snapshots != NULL: HOST buffer of `budget` fields, the field after each step taken by
+    // this call (the caller captured the input itself); the run then synchronises after every step.
+    int adaptive_run(int64_t budget, void* snapshots, int64_t* steps_total, int* done) {
+        if (!ar.active) return fail(SSFM_ERR_STATE, "ssfm_adaptive_run: no adaptive run in progress");
+        if (budget < 1) return fail(SSFM_ERR_INVALID, "ssfm_adaptive_run: budget=%lld", (long long)budget);
+        if (int rc = use_device()) return rc;
+        const int nrows = N1 * batch;
         const size_t fb = sizeof(cx<T>) * n * batch;
         char* snap = static_cast<char*>(snapshots);
-        if (snap) if (int rc = copy_field_out(snap, false, false)) return rc;
-        int chunk = snap ? 1 : 16;
-        int prev_steps = 0;
-        for (;;) {
-            for (int i = 0; i < chunk; ++i) {
-                HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
-                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fargs(dperm, 0, st), Ef)));
-                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, 0, 0, st), E)));
+        if (snap && ar.tile_private) return fail(SSFM_ERR_STATE, "ssfm_adaptive_run: the run was not begun with capture");
+        const int first_step = ar.now.steps;
+        auto estimate = [&]() {              // about (L - z) / h steps remain (the step only shrinks towards the clamp at L)
+            const double remain = ar.now.h > (T)0 ? ((double)ar.length - (double)ar.now.z) / (double)ar.now.h : 1.0;
+            const int est = remain > 1e6 ? 128 : (int)(0.75 * remain) + 1;
+            return est < 2 ? 2 : (est > 128 ? 128 : est);
+        };
+        int chunk = snap ? 1 : estimate();
+        while (!ar.now.done && ar.now.steps - first_step < budget) {
+            if ((int64_t)chunk > budget - (ar.now.steps - first_step)) chunk = (int)(budget - (ar.now.steps - first_step));
+            for (int i = 0; i < chunk; ++i, ++ar.step) {
+                TimeArgs<T> tb = targs(ar.gamma, 0, 0, st), te = tb;
+                tb.step = te.step = ar.step;
+                tb.derive = i != 0;         // the first BEGIN of a chunk finds its state in cur[] (k_step_control wrote it)
+                if (ar.tile_private && ar.step > 0) HIP_TRY((launch_time<T, TM_BEGIN_Y>(N1, batch, stream, tb, E)));
+                else HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E)));
+                FreqArgs<T> fa = fargs(dperm, 0, st);
+                fa.step = ar.step;
+                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fa, Ef)));
+                if (ar.tile_private) HIP_TRY((launch_time<T, TM_END_Y>(N1, batch, stream, te, E)));
+                else HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, te, E)));
                 last_launches += 3;
             }
-            HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, stream));
+            // the state after the last launched step, for the host (and for the first BEGIN of the next chunk)
+            hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 1, 0, ar.step);
+            ++last_launches;
+            const int before = ar.now.steps;
+            HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur) + sizeof(StepState<T>) * (ar.step & 1),
+                                   sizeof(ar.now), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (snap && hs.steps == prev_steps + 1)
-                if (int rc = copy_field_out(snap + fb * hs.steps, false, true)) return rc;
-            prev_steps = hs.steps;
-            if (hs.done) break;
-            if (!snap) {
-                // poll less often on long runs, but do not queue far beyond the end: at the current step size
-                // about (L - z) / h steps remain (the step only shrinks towards the clamp at L)
-                if (chunk < 128) chunk *= 2;
-                const double remain = hs.h > (T)0 ? ((double)hs.length - (double)hs.z) / (double)hs.h : 1.0;
-                const int est = remain > 1e6 ? 128 : (int)(0.75 * remain) + 1;
-                if (chunk > est) chunk = est < 2 ? 2 : est;
-            }
+            if (snap && ar.now.steps == before + 1)          // (chunk = 1: the step just launched was really taken)
+                if (int rc = copy_field_out(snap + fb * (size_t)(before - first_step), false, true)) return rc;
+            if (!snap && !ar.now.done) chunk = estimate();       // do not queue far beyond the end
+        }
+        if (steps_total) *steps_total = ar.now.steps;
+        if (done) *done = ar.now.done;
+        return SSFM_OK;
+    }
+
+    int adaptive_finish(int64_t* steps_out, double* z_out) {
+        if (!ar.active) return fail(SSFM_ERR_STATE, "ssfm_adaptive_finish: no adaptive run in progress");
+        if (int rc = use_device()) return rc;
+        ar.active = false;
+        if (ar.tile_private && ar.now.steps > 0) {
+            HIP_TRY((launch_time<T, TM_UNPACK>(N1, batch, stream, targs(ar.gamma, 0, 0, nullptr), E)));      // Y buffer -> time-order field
+            ++last_launches;
         }
         HIP_TRY(hipEventRecord(ev1, stream));
         timed = true;
-        if (steps_out) *steps_out = hs.steps;
+        if (steps_out) *steps_out = ar.now.steps;
         if (z_out) {
-            std::vector<T> zl(hs.steps + 1);
-            HIP_TRY(hipMemcpy(zl.data(), zlog, sizeof(T) * (hs.steps + 1), hipMemcpyDeviceToHost));
-            for (int i = 0; i <= hs.steps; ++i) z_out[i] = (double)zl[i];
+            std::vector<T> zl(ar.now.steps + 1);
+            HIP_TRY(hipMemcpyAsync(zl.data(), zlog, sizeof(T) * (ar.now.steps + 1), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (int i = 0; i <= ar.now.steps; ++i) z_out[i] = (double)zl[i];
         }
         HIP_TRY(hipStreamSynchronize(stream));
-        if (!(hs.z >= hs.length) && hs.steps >= hs.max_steps)
+        if (!(ar.now.z >= ar.length) && ar.now.steps >= ar.max_steps)
             return fail(SSFM_ERR_INVALID, "ssfm_propagate_adaptive: max_steps=%lld reached at z=%g of %g km",
-                        (long long)max_steps, (double)hs.z, (double)hs.length);
+                        (long long)ar.max_steps, (double)ar.now.z, (double)ar.length);
         return SSFM_OK;
+    }
+
+    int propagate_adaptive(double gamma_d, double length, double phi_max, int single_step, int64_t max_steps,
+                           int64_t* steps_out, double* z_out, void* snapshots) {
+        if (int rc = adaptive_begin(gamma_d, length, phi_max, single_step, max_steps, snapshots != nullptr)) return rc;
+        char* snap = static_cast<char*>(snapshots);
+        if (snap) if (int rc = copy_field_out(snap, false, true)) return rc;
+        if (int rc = adaptive_run(max_steps, snap ? snap + sizeof(cx<T>) * n * batch : nullptr, nullptr, nullptr)) return rc;
+        return adaptive_finish(steps_out, z_out);
     }
 
     // out = ifft(fft(x) * H): BEGIN/END with gamma = 0 are pure column transforms
@@ -1012,6 +1084,14 @@ int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double
                             int64_t max_steps, int64_t* steps_out, double* z_out, void* snapshots) {
     WITH_PLAN(plan, P_->propagate_adaptive(gamma, length, phi_max, single_step, max_steps, steps_out, z_out, snapshots));
 }
+
+int ssfm_adaptive_begin(ssfm_plan* plan, double gamma, double length, double phi_max, int single_step, int64_t max_steps, int capture) {
+    WITH_PLAN(plan, P_->adaptive_begin(gamma, length, phi_max, single_step, max_steps, capture));
+}
+int ssfm_adaptive_run(ssfm_plan* plan, int64_t budget, void* snapshots, int64_t* steps_total, int* done) {
+    WITH_PLAN(plan, P_->adaptive_run(budget, snapshots, steps_total, done));
+}
+int ssfm_adaptive_finish(ssfm_plan* plan, int64_t* steps_out, double* z_out) { WITH_PLAN(plan, P_->adaptive_finish(steps_out, z_out)); }
 
 int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host) {
     if (!H_host) return fail(SSFM_ERR_INVALID, "H_host is NULL");

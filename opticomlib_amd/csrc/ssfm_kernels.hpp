@@ -60,29 +60,43 @@ template <bool U16> __host__ __device__ constexpr bool twn_compute() { return SS
 
 namespace ssfm {
 
-enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2 };
+// BEGIN / END: first / last half of MID with the time-order field on one side.  BEGIN_Y / END_Y (U16 plans, adaptive
+// runs): the same, but the time-domain field between END and the next BEGIN stays in the Y buffer in the tile-private
+// 16-byte-unit order (only the same tile reads it back; write-through stores, non-temporal loads) instead of going
+// through time order with 8-byte accesses; UNPACK turns that buffer into the time-order field at the end of the run.
+enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2, TM_BEGIN_Y = 3, TM_END_Y = 4, TM_UNPACK = 5 };
+__host__ __device__ constexpr bool tm_inverse(int m) { return m == TM_MID || m == TM_END || m == TM_END_Y; }     // starts in the half-transformed domain
+__host__ __device__ constexpr bool tm_forward(int m) { return m == TM_BEGIN || m == TM_MID || m == TM_BEGIN_Y; } // ends in it
+__host__ __device__ constexpr bool tm_ends(int m) { return m == TM_END || m == TM_END_Y; }
 
 // Device-resident step control of the adaptive mode (reference devices.py:1155-1161,1193-1196).
-template <typename T> struct AdaptState {
-    T h;            // step about to be / being taken
+//
+// State S_s = (z reached, step h about to be taken, done, steps taken) BEFORE step s lives in cur[s & 1].  END(s)
+// only accumulates max |A|^2: one atomicMax per workgroup on slot (block id mod 64) of slots[s & 1] -- thousands of
+// waves on ONE address serialise (about 13 ns each).  The next BEGIN(s + 1) derives S_(s+1) = f(S_s, max) itself:
+// every wavefront reads the 64 slots and replays devices.py:1173,1193-1196 (the same float operations in every
+// wavefront: the same bits), workgroup 0 also records S_(s+1) in cur[(s + 1) & 1], z in zlog, and clears the slots
+// END(s + 1) will fill.  No ticket chain, no last-arrival logic, no fence: everything a kernel reads was written by an
+// EARLIER kernel of the stream.  (Round 1 let the last workgroup of END run the step control behind a chain of
+// dependent device-scope atomics: 4 us of END's 14.)  k_adapt_finish derives the state after the last launched step
+// for the host; the first BEGIN of the next chunk is told that cur[] already holds its state.
+template <typename T> struct StepState {
     T z;            // position reached
+    T h;            // step about to be taken
+    int done;
+    int steps;      // steps taken so far
+};
+constexpr int kAdaptSlots = 64;
+template <typename T> struct AdaptState {
     T length;
     T phi_max;
     T abs_gamma;
     int adaptive;   // 0: keep h (only clamp), 1: h = phi_max / max(|gamma| |A|^2)
-    int done;
-    int steps;
     int max_steps;
-    unsigned long long maxbits;   // bit pattern of max |A|^2 (non-negative => monotone as integer)
-    unsigned int ticket;          // slots of k_time<END> whose workgroups have all contributed
-    unsigned int pad_;
-    // k_time<END> reduces in two levels: 2048 waves hitting ONE address with atomicMax serialise (about
-    // 13 ns each: the kernel took 38 us instead of 12), so a workgroup reduces through LDS and publishes to
-    // slot (block id mod 64); the last workgroup of a slot raises `ticket`, the last slot runs the step control.
-    unsigned long long slot_max[64];
-    unsigned int slot_ticket[64];
+    int pad_;
+    StepState<T> cur[2];
+    unsigned long long slots[2][kAdaptSlots];      // bit patterns of max |A|^2 (non-negative => monotone as integers)
 };
-constexpr int kAdaptSlots = 64;
 
 // Block id -> (unit, row) so that the `rows` blocks working on the same unit (column tile / spectrum
 // row) share its read-only table through ONE XCD's L2: blocks are dealt round-robin over the 8 XCDs
@@ -175,6 +189,8 @@ template <typename T> struct TimeArgs {
     int N2;
     int rows;                 // rows covered by this launch (grid = N2/C * rows blocks)
     int Qf;                   // threads per row of k_freq (U16 layout: which columns form a tile)
+    int step;                 // adaptive mode: index of the step this launch belongs to (its state is cur[step & 1])
+    int derive;               // adaptive BEGIN: 1 = derive the step's state from the previous step's (see AdaptState)
     SSFM_TRACE_ARGS
 };
 
@@ -367,21 +383,34 @@ template <typename T> __device__ __forceinline__ T bits_float(unsigned long long
 template <> __device__ __forceinline__ float bits_float<float>(unsigned long long b) { return __uint_as_float((unsigned)b); }
 template <> __device__ __forceinline__ double bits_float<double>(unsigned long long b) { return __longlong_as_double((long long)b); }
 
-// Step control, one thread.  phase 0: choose the first step (devices.py:1155-1161);
-// phase 1: account for the step just finished and choose the next (devices.py:1173,1193-1196).
-// account for the step just finished and choose the next one (reference devices.py:1173, 1193-1196)
-template <typename T> __device__ __forceinline__ void step_control_update(AdaptState<T>* st, T* zlog, unsigned long long maxbits) {
-    const T z = st->z + st->h;
-    T h = st->h;
+// S_(s+1) from S_s and the maximum of |A|^2 after step s (reference devices.py:1173, 1193-1196)
+template <typename T> __device__ __forceinline__ StepState<T> step_advance(const AdaptState<T>* st, const StepState<T> prev, unsigned long long maxbits) {
+    if (prev.done) return prev;
+    StepState<T> n;
+    n.z = prev.z + prev.h;
+    T h = prev.h;
     if (st->adaptive) h = st->phi_max / (st->abs_gamma * bits_float<T>(maxbits));
-    const T rem = st->length - z;
-    h = h < rem ? h : rem;
-    st->z = z;
-    st->h = h;
-    st->steps += 1;
-    zlog[st->steps] = z;
-    st->maxbits = 0ull;
-    st->done = !(z < st->length) || st->steps >= st->max_steps;
+    const T rem = st->length - n.z;
+    n.h = h < rem ? h : rem;
+    n.steps = prev.steps + 1;
+    n.done = !(n.z < st->length) || n.steps >= st->max_steps;
+    return n;
+}
+// maximum over the 64 slots, by one wavefront (every lane gets it)
+__device__ __forceinline__ unsigned long long slots_max(const unsigned long long* slots) {
+    unsigned long long mb = slots[threadIdx.x & (kAdaptSlots - 1)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(mb, o);
+        mb = other > mb ? other : mb;
+    }
+    return mb;
+}
+// The state of step `step` as every wavefront of a BEGIN / k_freq / END kernel sees it.  derive: BEGIN of a step whose
+// state is not in cur[] yet.
+template <typename T> __device__ __forceinline__ StepState<T> step_state(const AdaptState<T>* st, int step, bool derive) {
+    if (!derive) return st->cur[step & 1];
+    return step_advance<T>(st, st->cur[(step - 1) & 1], slots_max(st->slots[(step - 1) & 1]));
 }
 
 
@@ -421,13 +450,24 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
+    constexpr bool INV = tm_inverse(MODE), FWD = tm_forward(MODE);
+    static_assert(U16 || MODE <= TM_END, "the tile-private time-domain modes exist for the U16 layout only");
     T hh_prev = a.hh_prev, hh_next = a.hh_next;
-    if (a.st != nullptr) {
-        if (a.st->done) return;
-        hh_prev = hh_next = a.st->h * (T)0.5;
+    const int tid = threadIdx.x;
+    if (a.st != nullptr && MODE != TM_UNPACK) {
+        const StepState<T> S = step_state<T>(a.st, a.step, FWD && a.derive != 0);
+        if (FWD && blockIdx.x == 0 && tid == 0) {
+            // workgroup 0 records the state of this step (BEGIN is the first kernel of a step) and empties the slots its END fills
+            if (a.derive) {
+                a.st->cur[a.step & 1] = S;
+                if (!a.st->cur[(a.step - 1) & 1].done) a.zlog[S.steps] = S.z;
+            }
+        }
+        if (FWD && blockIdx.x == 0 && tid < kAdaptSlots) a.st->slots[a.step & 1][tid] = 0ull;
+        if (S.done) return;
+        hh_prev = hh_next = S.h * (T)0.5;
     }
     SSFM_TRACE_BEGIN(a);
-    const int tid = threadIdx.x;
     // plain: thread = j * C + c.  U16: lane = h * 32 + (j mod 4) * 8 + c8, column c = h * 8 + c8 (see "U16" above)
     const int c = U16 ? (((tid >> 5) & 1) << 3) | (tid & 7) : tid % C;
     const int j = U16 ? ((tid >> 6) << 2) | ((tid >> 3) & 3) : tid / C;
@@ -458,7 +498,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     cx<T> w[E];
     T pold[E];
     LineTw<T, N1, E> tw;
-    if (U16 && MODE != TM_BEGIN) {
+    if (U16 && MODE != TM_BEGIN) {               // half-transformed field, or the tile-private time-domain field: 16-byte units
 #pragma unroll
         for (int g = 0; g < E / 2; ++g) {
             const u4_t q = stream_load<true>(reinterpret_cast<const u4_t*>(&Yb[offy + 2 * g * stride]));
@@ -473,7 +513,9 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     constexpr bool TWC = twn_compute<U16>();
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
     cx<T> wA = mk<T>((T)1, (T)0);
-    if constexpr (TWC) {
+    if constexpr (MODE == TM_UNPACK) {
+        // nothing but the field moves
+    } else if constexpr (TWC) {
         // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
         // the tile's E x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
         // (both tables are stored tile by tile in the order they are read here: 2 KiB + 2 KiB of contiguous lines per
@@ -491,7 +533,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             w[2 * g + 1] = mk<T>(q.z, q.w);
         }
     }
-    if (MODE != TM_BEGIN) {
+    if (INV) {
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
@@ -500,16 +542,27 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         }
     }
     cx<T>* ldsT = Bs + (TWC ? E * C : 0);
-    line_twiddles_issue<T, N1, E>(tw, j, a.tw1, ldsT, tid, N1 * C / E);
-    if (fft_tw_lds_entries(N1, E) > 0 || TWC) __syncthreads();
-    if constexpr (TWC) {
-        w[0] = wA;
+    if constexpr (MODE != TM_UNPACK) {
+        line_twiddles_issue<T, N1, E>(tw, j, a.tw1, ldsT, tid, N1 * C / E);
+        if (fft_tw_lds_entries(N1, E) > 0 || TWC) __syncthreads();
+        if constexpr (TWC) {
+            w[0] = wA;
 #pragma unroll
-        for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
+            for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
+        }
+        line_twiddles_fetch<T, N1, E>(tw, j, ldsT);
     }
-
-    line_twiddles_fetch<T, N1, E>(tw, j, ldsT);
-    if (MODE != TM_BEGIN) {
+    if (MODE == TM_BEGIN_Y || MODE == TM_UNPACK) {
+        // the exchange that undoes END_Y's: every thread gets its own column back
+#pragma unroll
+        for (int g = 0; g < E / 2; ++g) lane32_swap(v[2 * g], v[2 * g + 1]);
+    }
+    if (MODE == TM_UNPACK) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
+        return;
+    }
+    if (INV) {
         if (U16) {
             // lane h = 0 keeps its low half and takes lane + 32's low half; lane h = 1 takes lane - 32's high half
 #pragma unroll
@@ -532,13 +585,13 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     for (int t = 0; t < E; ++t) {
         const T p = v[t].x * v[t].x + v[t].y * v[t].y;
         T ph = (T)0;
-        if (MODE != TM_BEGIN) ph = hh_prev * (a.gamma * pold[t]);
-        if (MODE != TM_END) ph += hh_next * (a.gamma * p);
+        if (INV) ph = hh_prev * (a.gamma * pold[t]);
+        if (FWD) ph += hh_next * (a.gamma * p);
         pnew[t] = p;
         phi[t] = ph;
         pmax = p > pmax ? p : pmax;
     }
-    if (MODE != TM_END && !SSFM_ABL_NO_P) {
+    if (FWD && !SSFM_ABL_NO_P) {
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
@@ -558,61 +611,37 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t].x += phi[t];
     }
-    if (MODE == TM_END) {
-        // (time-order output: plain stores -- it is read by whatever comes after the run, not by the next pass)
+    if (tm_ends(MODE)) {
+        if (MODE == TM_END) {
+            // (time-order output: plain stores -- it is read by whatever comes after the run, not by the next pass)
 #pragma unroll
-        for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
+            for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
+        } else {
+            // tile-private 16-byte units in the Y buffer: only this tile's BEGIN_Y (or UNPACK) reads them back
+#pragma unroll
+            for (int g = 0; g < E / 2; ++g) {
+                lane32_swap(v[2 * g], v[2 * g + 1]);
+                u4_t q;
+                q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
+                stream_store(reinterpret_cast<u4_t*>(&Yb[offy + 2 * g * stride]), q);
+            }
+        }
         if (a.st != nullptr) {
-            // workgroup maximum through LDS, one atomic per workgroup on its slot; the LAST workgroup to arrive
-            // (two-level ticket) then runs the step control, so an adaptive step is 3 launches (BEGIN, k_freq,
-            // END), not 4
+            // max |A|^2 of the workgroup -> its slot; the next BEGIN reads the slots (see AdaptState)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const T other = __shfl_xor(pmax, o);
                 pmax = other > pmax ? other : pmax;
             }
             __shared__ T wave_max[16];
-            __shared__ int last_arrival;
             constexpr int NWAVES = (N1 * C / E + 63) / 64;
-            const unsigned nslots = gridDim.x < (unsigned)kAdaptSlots ? gridDim.x : (unsigned)kAdaptSlots;
             if ((tid & 63) == 0) wave_max[tid >> 6] = pmax;
             __syncthreads();
             if (tid == 0) {
                 T m = wave_max[0];
 #pragma unroll
                 for (int w = 1; w < NWAVES; ++w) m = wave_max[w] > m ? wave_max[w] : m;
-                const unsigned slot = blockIdx.x % kAdaptSlots;
-                const unsigned in_slot = (gridDim.x + kAdaptSlots - 1 - slot) / kAdaptSlots;     // workgroups sharing this slot
-                // No __threadfence() here: a release fence writes back the 32 KiB of field data this workgroup has
-                // just stored (the XCD's dirty L2 lines) -- 512 of them made this kernel 48 us instead of 10.  The
-                // step control only needs the ATOMICS ordered, and an atomic that returns a value has been performed
-                // at the point of coherence: each ticket increment carries a data dependency on the atomic before
-                // it.  The field itself becomes visible at the kernel boundary, as for every other kernel.
-                const unsigned long long old = atomicMax(&a.st->slot_max[slot], float_bits<T>(m));
-                const unsigned dep0 = (unsigned)(old >> 63);                         // always 0: |A|^2 >= 0
-                int last = 0;
-                if (in_slot == 1) {
-                    // small grids (<= 64 workgroups): the slot is this workgroup's own, two atomics fewer in the chain
-                    last = atomicAdd(&a.st->ticket, 1u + dep0) == nslots - 1;
-                } else if (atomicAdd(&a.st->slot_ticket[slot], 1u + dep0) == in_slot - 1) {
-                    const unsigned dep1 = atomicExch(&a.st->slot_ticket[slot], 0u) >> 31;    // reset for the next step; always 0
-                    last = atomicAdd(&a.st->ticket, 1u + dep1) == nslots - 1;
-                }
-                last_arrival = last;
-            }
-            __syncthreads();
-            if (last_arrival && tid < 64) {
-                // the last workgroup of the grid: one wavefront collects (and clears) the slots in parallel
-                unsigned long long mb = (unsigned)tid < nslots ? atomicExch(&a.st->slot_max[tid], 0ull) : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned long long other = __shfl_xor(mb, o);
-                    mb = other > mb ? other : mb;
-                }
-                if (tid == 0) {
-                    atomicExch(&a.st->ticket, 0u);
-                    step_control_update<T>(a.st, a.zlog, mb);
-                }
+                atomicMax(&a.st->slots[a.step & 1][blockIdx.x % kAdaptSlots], float_bits<T>(m));
             }
         }
         SSFM_TRACE_END(a);
@@ -649,8 +678,9 @@ template <typename T> struct FreqArgs {
     cx<T>* F;
     const cx<T>* tab;        // FM_TABLE: exp(D~ h)/N (or H/N) at [k1*N2 + k2];  FM_FLY: D~ at the same place
     const cx<T>* tw2;        // W_N2^q
-    const AdaptState<T>* st; // FM_FLY: step size source when non-null
+    const AdaptState<T>* st; // FM_FLY: step size source when non-null (the state of step `step`)
     T h;                     // FM_FLY with st == nullptr
+    int step;
     T inv_n;
     int N1;
     int rows;                // batch rows covered by this launch
@@ -670,8 +700,9 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 
     T h = a.h;
     if (MODE == FM_FLY && a.st != nullptr) {
-        if (a.st->done) return;
-        h = a.st->h;
+        const StepState<T> S = a.st->cur[a.step & 1];
+        if (S.done) return;
+        h = S.h;
     }
     SSFM_TRACE_BEGIN(a);
     const int tid = threadIdx.x;
@@ -737,9 +768,16 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 #pragma unroll
         for (int t = 0; t < E; ++t) ph[t] = m[t].y * h;
         sincos_all<E>(ph, sn, cs);
+        // Re D~ = -alpha/2 is the same number at every frequency for a fibre (devices.py:1145): then exp(Re h) is ONE
+        // exponential per thread instead of 16 (bit-identical: the same float product, the same function); any other
+        // operator takes the general path
+        bool flat = true;
+#pragma unroll
+        for (int t = 1; t < E; ++t) flat = flat && (m[t].x == m[0].x);
+        const T e0 = exp_acc<T>(m[0].x * h);
 #pragma unroll
         for (int t = 0; t < E; ++t) {
-            const T e = exp_acc<T>(m[t].x * h);
+            const T e = flat ? e0 : exp_acc<T>(m[t].x * h);
             m[t] = mk<T>((e * cs[t]) * a.inv_n, (e * sn[t]) * a.inv_n);
         }
     }
@@ -863,35 +901,36 @@ template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long
     if (threadIdx.x == 0) {
         T m = wave_max[0];
         for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) m = wave_max[w] > m ? wave_max[w] : m;
-        atomicMax(&st->slot_max[blockIdx.x % kAdaptSlots], float_bits<T>(m));
+        atomicMax(&st->slots[1][blockIdx.x % kAdaptSlots], float_bits<T>(m));       // (the slots "before step 0")
     }
 }
 
-// launched with one wavefront: the lanes collect (and clear) k_absmax's slots, lane 0 decides
-template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog, int phase, int single_step) {
+// Launched with one wavefront.  phase 0: the first step from k_absmax's slots (reference devices.py:1155-1161) -> cur[0];
+// phase 1 (k_adapt_finish): the state after the last launched step `step - 1` -> cur[step & 1], for the host and for
+// the first BEGIN of the next chunk.
+template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog, int phase, int single_step, int step) {
     if (phase == 0) {
-        unsigned long long mb = threadIdx.x < (unsigned)kAdaptSlots ? atomicExch(&st->slot_max[threadIdx.x], 0ull) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(mb, o);
-            mb = other > mb ? other : mb;
-        }
+        const unsigned long long mb = slots_max(st->slots[1]);
+        if (threadIdx.x < kAdaptSlots) { st->slots[0][threadIdx.x] = 0ull; st->slots[1][threadIdx.x] = 0ull; }
         if (threadIdx.x != 0) return;
-        st->maxbits = mb;
         T h;
         if (single_step) h = st->length;
-        else h = st->phi_max / (st->abs_gamma * bits_float<T>(st->maxbits));
+        else h = st->phi_max / (st->abs_gamma * bits_float<T>(mb));
         h = h < st->length ? h : st->length;
-        st->h = h;
-        st->z = (T)0;
-        st->steps = 0;
-        st->done = !((T)0 < st->length);
-        st->maxbits = 0ull;
+        StepState<T> S;
+        S.h = h;
+        S.z = (T)0;
+        S.steps = 0;
+        S.done = !((T)0 < st->length);
+        st->cur[0] = S;
+        st->cur[1] = S;
         zlog[0] = (T)0;
         return;
     }
-    if (threadIdx.x != 0 || st->done) return;
-    step_control_update<T>(st, zlog, st->maxbits);
+    const StepState<T> S = step_state<T>(st, step, true);
+    if (threadIdx.x != 0) return;
+    if (!st->cur[(step - 1) & 1].done) zlog[S.steps] = S.z;
+    st->cur[step & 1] = S;
 }
 
 }  // namespace ssfm
