@@ -124,6 +124,16 @@ def _check(rc, what):
         raise SsfmError(f"{what} failed (status {rc}): {msg}")
 
 
+def _check_filter(rc, what):
+    """An input shorter than the padding is the caller's ValueError in SciPy (``sosfiltfilt`` / ``_validate_pad``), and so
+    it is here; everything else is a library failure."""
+    if rc == 1:
+        msg = load().ssfm_last_error().decode(errors="replace")
+        if "padlen" in msg:
+            raise ValueError(msg)
+    _check(rc, what)
+
+
 def device_count() -> int:
     n = _I(0)
     rc = load().ssfm_device_count(C.byref(n))
@@ -150,8 +160,8 @@ def sosfiltfilt(sos: np.ndarray, zi: np.ndarray, x: np.ndarray, device: int = 0)
     n = xs.shape[-1]
     batch = int(xs.size // n) if n else 0
     y = np.empty_like(xs)
-    _check(load().ssfm_sosfiltfilt(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _ptr(xs), _ptr(y), n, batch, int(is_c)),
-           "ssfm_sosfiltfilt")
+    _check_filter(load().ssfm_sosfiltfilt(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _ptr(xs), _ptr(y), n, batch, int(is_c)),
+                  "ssfm_sosfiltfilt")
     return y
 
 
@@ -160,8 +170,8 @@ def sosfiltfilt_device(sos: np.ndarray, zi: np.ndarray, x_ptr: int, y_ptr: int, 
     """The same on DEVICE buffers (raw pointers; float64 or interleaved complex128, ``batch`` rows of ``n``)."""
     sos = np.ascontiguousarray(sos, dtype=np.float64)
     zi = np.ascontiguousarray(zi, dtype=np.float64)
-    _check(load().ssfm_sosfiltfilt_device(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _VP(x_ptr), _VP(y_ptr), int(n), int(batch),
-                                          int(bool(is_complex))), "ssfm_sosfiltfilt_device")
+    _check_filter(load().ssfm_sosfiltfilt_device(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _VP(x_ptr), _VP(y_ptr), int(n), int(batch),
+                                                 int(bool(is_complex))), "ssfm_sosfiltfilt_device")
 
 
 def square_law(signal: np.ndarray, noise, r: float, device: int = 0):

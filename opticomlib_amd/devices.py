@@ -248,19 +248,33 @@ class _ChirpZ:
         self.n, self.batch, self.dev = int(n), int(batch), int(dev)
         M = 1 << max(8, (2 * n - 2).bit_length())
         self.plan = get_plan(M, batch, _lib.C128, dev)
-        want = _tag("chirp", n)
-        if self.plan.tag(1) != want or self.plan.tag(2) != want:
-            # both convolution kernels are generated AND transformed on the device (csrc/chirpz.hip): no host FFT, no upload
-            for slot in (0, 1):
-                self.plan.load_chirp_kernel(n, slot)
-                self.plan.table_from_field(slot)
-                self.plan.set_tag(1 + slot, want)
+        with self.plan.lock:
+            self._ensure_tables()
         key = (dev, n)
         if key not in _CHIRPS:
             _CHIRPS[key] = (_lib.chirp_device(n, False, dev), _lib.chirp_device(n, True, dev))
             while len(_CHIRPS) > 4:
                 _CHIRPS.pop(next(iter(_CHIRPS)))
         self.chirp, self.chirp_conj = _CHIRPS[key]
+
+    def _ensure_tables(self):
+        want = _tag("chirp", self.n)
+        if self.plan.tag(1) != want or self.plan.tag(2) != want:
+            # both convolution kernels are generated AND transformed on the device (csrc/chirpz.hip): no host FFT, no upload
+            for slot in (0, 1):
+                self.plan.load_chirp_kernel(self.n, slot)
+                self.plan.table_from_field(slot)
+                self.plan.set_tag(1 + slot, want)
+
+    # the engine works in the plan's field buffer and table slots: its users hold the plan's lock for their whole sequence
+    def __enter__(self):
+        self.plan.lock.acquire()
+        self._ensure_tables()
+        return self
+
+    def __exit__(self, *exc):
+        self.plan.lock.release()
+        return False
 
     def step(self, A, P, Dt, gamma: float, h: float, maxbits=None):
         """One symmetric split step of size ``h`` on the device array ``A`` (batch, n), in place."""
@@ -314,13 +328,13 @@ def _fourier(obj, domain, shift=False):
     if n < 2 or 2 * n - 1 > (1 << hi):
         raise ValueError(f"the device transform takes 2 ... 2^{hi - 1} samples per row, got {n} (there is no CPU fallback)")
     single = all(np.dtype(a.dtype) in (np.dtype(np.complex64), np.dtype(np.float32)) for a in raws)   # NumPy >= 2 keeps single precision
-    eng = _ChirpZ(n, rows * len(raws), dev)
     buf = _lib.DeviceArray((rows * len(raws), n), np.complex128, dev)
     row_bytes = rows * n * 16
     cp = lambda dst, src, nbytes: _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(dst), _lib._VP(src), nbytes, 2), "ssfm_device_copy")
     for k, a in enumerate(raws):
         cp(buf.ptr + k * row_bytes, _dev_array(a, np.complex128, dev).ptr, row_bytes)
-    res = eng.fourier(buf, inverse)
+    with _ChirpZ(n, rows * len(raws), dev) as eng:
+        res = eng.fourier(buf, inverse)
     outs = []
     s_ = n // 2
     for k in range(len(raws)):
@@ -351,7 +365,14 @@ def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_ma
     n = shape[-1]
     batch = 1 if len(shape) == 1 else shape[0]
     rt = _F32 if prec == _lib.C64 else np.float64
-    eng = _ChirpZ(n, batch, dev)
+    with _ChirpZ(n, batch, dev) as eng:
+        return _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar)
+
+
+def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar):
+    n = shape[-1]
+    batch = 1 if len(shape) == 1 else shape[0]
+    rt = _F32 if prec == _lib.C64 else np.float64
     A = A_dev if A_dev.dtype == np.complex128 else A_dev.astype(np.complex128)
     if A is A_dev:
         A = A.copy()                                            # the caller's array is never modified
@@ -599,13 +620,13 @@ def DM(input: optical_signal, D: float, retH: bool = False, *, device=None):
         phase = 1j * w ** 2 * D / 2                                 # the exponential itself is taken on the device
         Hd = _lib.DeviceArray.from_host(phase, np.complex128, dev)
         nrow = rows * (2 if has_noise else 1)
-        eng = _ChirpZ(n, nrow, dev)
         buf = _lib.DeviceArray((nrow, n), np.complex128, dev)
         for k, a in enumerate([raw_s, raw_n] if has_noise else [raw_s]):
             d = _dev_array(a, np.complex128, dev)
             _lib._check(_lib.load().ssfm_device_copy(dev, _lib._VP(buf.ptr + k * rows * n * 16), _lib._VP(d.ptr), rows * n * 16, 2), "ssfm_device_copy")
-        eng.transfer(buf, Hd, exponent=True)
-        eng.plan.synchronize()
+        with _ChirpZ(n, nrow, dev) as eng:
+            eng.transfer(buf, Hd, exponent=True)
+            eng.plan.synchronize()
         outs = []
         for k in range(2 if has_noise else 1):
             o = _lib.DeviceArray(shape, np.complex128, dev)

@@ -1,4 +1,5 @@
-"""Two host threads driving the library at once (separate plans): results must equal the single-threaded ones."""
+"""Host threads driving the library at once -- on different shapes (separate plans) AND on the same shapes (the same
+cached plan: the device functions hold the plan's lock for their whole sequence): results must equal the single-threaded ones."""
 import sys, threading; sys.path.insert(0, '.')
 import numpy as np
 import opticomlib_amd as oa
@@ -23,7 +24,7 @@ def worker(idx):
                 got[i] = run(cases[i])
     except Exception as e:       # noqa: BLE001
         errs.append(repr(e))
-ts = [threading.Thread(target=worker, args=(idx,)) for idx in ([0, 2], [1, 3])]
+ts = [threading.Thread(target=worker, args=(idx,)) for idx in ([0, 2], [1, 3], [0, 1, 2, 3], [3, 2, 1, 0])]
 [t.start() for t in ts]; [t.join() for t in ts]
 ok = not errs and all(np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]) for g, w in zip(got, want))
 print("threads:", "identical to the single-threaded results" if ok else f"MISMATCH / errors: {errs}")
