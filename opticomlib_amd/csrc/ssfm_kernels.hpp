@@ -37,7 +37,12 @@
 #ifndef SSFM_TWN_COMPUTE
 #define SSFM_TWN_COMPUTE 1
 #endif
-template <bool U16> __host__ __device__ constexpr bool twn_compute() { return SSFM_TWN_COMPUTE != 0 && U16; }
+// SSFM_C128_POLICY: 1 = complex128 plans (16-byte elements as they are) use the same memory policy and in-kernel twiddles
+#ifndef SSFM_C128_POLICY
+#define SSFM_C128_POLICY 0
+#endif
+template <typename T, bool U16> __host__ __device__ constexpr bool stream_policy() { return U16 || (sizeof(T) == 8 && SSFM_C128_POLICY != 0); }
+template <typename T, bool U16> __host__ __device__ constexpr bool twn_compute() { return SSFM_TWN_COMPUTE != 0 && stream_policy<T, U16>(); }
 
 // Launch-level trace for tools/trace_timeline.py (diagnostic builds only: -DSSFM_TRACE=1).  Every
 // workgroup folds its start / end time (s_memrealtime, 100 MHz) into 4 words of its launch's slot.
@@ -360,7 +365,13 @@ __device__ __forceinline__ void stream_store(f32x4* p, f32x4 v) {
 }
 __device__ __forceinline__ void stream_store(f64x4* p, f64x4 v) { *p = v; }
 __device__ __forceinline__ void stream_store(cf32* p, cf32 v) { *p = v; }
-__device__ __forceinline__ void stream_store(cf64* p, cf64 v) { *p = v; }
+__device__ __forceinline__ void stream_store(cf64* p, cf64 v) {
+#if SSFM_C128_POLICY
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
 
 template <int C> struct ColIdx {
     int c;
@@ -508,9 +519,9 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     } else {
         const cx<T>* __restrict__ src = MODE == TM_BEGIN ? Fb : Yb;
 #pragma unroll
-        for (int t = 0; t < E; ++t) v[t] = stream_load<false>(&src[off + t * stride]);
+        for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0 && MODE != TM_BEGIN)>(&src[off + t * stride]);
     }
-    constexpr bool TWC = twn_compute<U16>();
+    constexpr bool TWC = twn_compute<T, U16>();
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
     cx<T> wA = mk<T>((T)1, (T)0);
     if constexpr (MODE == TM_UNPACK) {
@@ -537,7 +548,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
-            if (SSFM_ABL_NO_P) q = (T)1e-3; else q = stream_load<U16>(&Pb[g * PSTR]);
+            if (SSFM_ABL_NO_P) q = (T)1e-3; else q = stream_load<stream_policy<T, U16>()>(&Pb[g * PSTR]);
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     }
@@ -733,7 +744,7 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < E; ++t) v[t] = stream_load<false>(&Frow[j + t * Q]);
+        for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0)>(&Frow[j + t * Q]);
     }
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
