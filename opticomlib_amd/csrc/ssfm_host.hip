@@ -408,7 +408,7 @@ template <typename T> struct PlanT : PlanBase {
         if (u16) HIP_TRY(hipMalloc(&Y, cb * n * batch));
         // inter-pass twiddles W_N^(k1 n2): either the n-entry table in k_time's thread order, or (U16 plans) the two
         // small factor tables the kernel multiplies (ssfm_kernels.hpp SSFM_TWN_COMPUTE)
-        if (SSFM_TWN_COMPUTE && (u16 || (sizeof(T) == 8 && SSFM_C128_POLICY))) {
+        if (SSFM_TWN_COMPUTE && (u16 || (sizeof(T) == 8 && SSFM_C128_TWC))) {
             const long long nA = (long long)(N1 / E) * N2, nB = (long long)E * N2;      // [tile][j][c], j < N1/E;  [tile][t][c], t < E
             HIP_TRY(hipMalloc(&twA, cb * nA));
             HIP_TRY(hipMalloc(&twB, cb * nB));

@@ -42,7 +42,12 @@
 #define SSFM_C128_POLICY 0
 #endif
 template <typename T, bool U16> __host__ __device__ constexpr bool stream_policy() { return U16 || (sizeof(T) == 8 && SSFM_C128_POLICY != 0); }
-template <typename T, bool U16> __host__ __device__ constexpr bool twn_compute() { return SSFM_TWN_COMPUTE != 0 && stream_policy<T, U16>(); }
+// SSFM_C128_TWC: in-kernel inter-pass twiddles for complex128 plans too (C1 43.7 -> 42.8 us per step, and 16 MiB less table
+// memory per 2^20 plan; the write-through / non-temporal policy LOSES 2 % there: profiles/r02_c128_policy_ab.txt)
+#ifndef SSFM_C128_TWC
+#define SSFM_C128_TWC 1
+#endif
+template <typename T, bool U16> __host__ __device__ constexpr bool twn_compute() { return SSFM_TWN_COMPUTE != 0 && (U16 || (sizeof(T) == 8 && SSFM_C128_TWC != 0)); }
 
 // Launch-level trace for tools/trace_timeline.py (diagnostic builds only: -DSSFM_TRACE=1).  Every
 // workgroup folds its start / end time (s_memrealtime, 100 MHz) into 4 words of its launch's slot.
