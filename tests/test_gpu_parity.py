@@ -1765,3 +1765,50 @@ def test_filter_input_shorter_than_the_padding_is_a_value_error():
         oa.LPF(np.ones(10), BW=1e9)
     with pytest.raises(ValueError, match="padlen"):
         oa.BPF(optical_signal(np.ones(12, complex)), BW=1e9)
+
+
+def test_adaptive_capture_goes_to_the_host_in_blocks_and_api_order():
+    """return_steps with the adaptive step: the capture is taken through ssfm_adaptive_begin / _run / _finish in blocks
+    (64 snapshots at this size), so a run of ~200 steps crosses several block boundaries; snapshots, z and the final
+    field equal those of the same run without capture, the memory follows the steps taken (not max_steps), and the three
+    entry points refuse to be called out of order."""
+    gv(**workloads.BENCH_GV)
+    n = 1 << 10
+    a = workloads.qpsk_field(n, seed=11, power_w=20e-3)
+    kw = dict(length=12, phi_max=0.004, **workloads.SMF)
+    z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+    steps = len(z) - 1
+    assert steps > 100 and A_z.shape == (steps + 1, 2, n) and A_z.dtype == np.complex64
+    assert A_z.base is None or A_z.base.nbytes == A_z.nbytes       # a compact array: nothing of max_steps + 1 fields is kept alive
+    np.testing.assert_array_equal(A_z[0], a.astype(np.complex64))
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    assert relmax(A_z[-1], y) < 2e-6                     # capture runs the time-order modes, the plain run the tile-private ones
+    zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+    assert abs(len(zr) - len(z)) <= 1 and relmax(A_z[-1], Ar[-1]) < TOL_1000
+    k = min(len(z), len(zr)) // 2
+    np.testing.assert_allclose(z[:k], zr[:k], rtol=2e-4)
+    assert relmax(A_z[70], Ar[70]) < TOL_100 * 5          # a snapshot beyond the first block boundary
+    p = _lib.Plan(n, 2, _lib.C64)
+    try:
+        lib = _lib.load()
+        import ctypes as C
+        st, dn = C.c_int64(0), C.c_int(0)
+        assert lib.ssfm_adaptive_run(p._h, 4, None, C.byref(st), C.byref(dn)) == 5                      # SSFM_ERR_STATE: no run begun
+        assert lib.ssfm_adaptive_finish(p._h, C.byref(st), None) == 5
+        assert lib.ssfm_adaptive_begin(p._h, 1.3, 12.0, 0.004, 0, 1 << 16, 0) == 5                      # no operator yet
+        p.set_linear_operator(oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13))
+        p.set_field(a)
+        assert lib.ssfm_adaptive_begin(p._h, 1.3, 12.0, 0.004, 0, 1 << 16, 0) == 0
+        blk = _lib.host_empty((4, 2, n), np.complex64)
+        assert lib.ssfm_adaptive_run(p._h, 4, blk.ctypes.data_as(C.c_void_p), C.byref(st), C.byref(dn)) == 5   # capture was not announced
+        assert lib.ssfm_adaptive_run(p._h, 10, None, C.byref(st), C.byref(dn)) == 0 and st.value == 10 and dn.value == 0
+        assert lib.ssfm_adaptive_run(p._h, 1 << 16, None, C.byref(st), C.byref(dn)) == 0 and dn.value == 1 and st.value == steps
+        zz = np.zeros(st.value + 1)
+        assert lib.ssfm_adaptive_finish(p._h, C.byref(st), zz.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        np.testing.assert_array_equal(zz, z)
+        np.testing.assert_array_equal(p.get_field(), y)   # budgeted runs take the same steps as one run
+        with pytest.raises(oa.SsfmError, match="max_steps=5 reached"):
+            p.set_field(a)
+            p.propagate_adaptive(1.3, 12.0, 0.004, False, max_steps=5)
+    finally:
+        p.close()
