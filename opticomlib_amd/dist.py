@@ -273,7 +273,18 @@ def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False
     n = unit_shape[-1]
     fixed = kw.get("h") is not None and not kw.get("return_steps") and not kw.get("show_progress")
     fixed = fixed and _is_fast_size(n, prec)                      # other lengths: one by one (chirp-z)
-    if fixed and len(mine) >= 1:
+    if fixed and len(mine) == 0:
+        # a rank without units (more ranks than units) still takes part in the collective, with nothing to send
+        if ws > 1 and _device_backend():
+            out = gather_device(0, 0, unit_shape, cdt, n_units, dev, to_all=to_all)
+            if out is None:
+                return None
+            if on_device:
+                return out
+            host = out.to_host()
+            return [host[u] for u in range(n_units)]
+        return gather_results([], n_units, to_all=to_all)
+    if fixed:
         _check_size(n, prec)
         rows = len(mine) * (int(np.prod(unit_shape[:-1])) if len(unit_shape) > 1 else 1)
         plan = get_plan(n, rows, prec, dev)
