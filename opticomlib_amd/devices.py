@@ -12,6 +12,7 @@ There is deliberately NO CPU fallback: sizes the HIP path does not cover raise
 from __future__ import annotations
 
 import os
+import threading
 import time
 from collections import OrderedDict
 
@@ -21,6 +22,7 @@ from . import _lib
 from .typing import NULL, binary_sequence, electrical_signal, gv, optical_signal
 
 _F32 = np.float32
+_CACHE_LOCK = threading.RLock()       # guards the module's small caches (plans, operators, grid powers, chirps) against concurrent callers
 _PLANS: "OrderedDict[tuple, _lib.Plan]" = OrderedDict()
 _MAX_PLANS = 12           # a 2^20 x 2 plan holds ~0.1 GB of the 288 GB; a link script cycles through a handful of shapes
 
@@ -34,20 +36,27 @@ def get_plan(n: int, batch: int, precision: int, device=None) -> _lib.Plan:
     """Plans own all device buffers; keep the few most recent ones alive."""
     device = default_device() if device is None else int(device)
     key = (device, int(n), int(batch), int(precision))
-    plan = _PLANS.pop(key, None)
-    if plan is None:
-        plan = _lib.Plan(n, batch, precision, device)
-    _PLANS[key] = plan
-    while len(_PLANS) > _MAX_PLANS:
-        _, old = _PLANS.popitem(last=False)
-        old.close()
+    with _CACHE_LOCK:
+        plan = _PLANS.pop(key, None)
+        if plan is None:
+            plan = _lib.Plan(n, batch, precision, device)
+        _PLANS[key] = plan
+        evicted = []
+        while len(_PLANS) > _MAX_PLANS:
+            evicted.append(_PLANS.popitem(last=False)[1])
+    for old in evicted:
+        with old.lock:                       # (a thread may still be inside a call on it)
+            old.close()
     return plan
 
 
 def release_plans():
-    while _PLANS:
-        _, p = _PLANS.popitem()
-        p.close()
+    with _CACHE_LOCK:
+        plans = list(_PLANS.values())
+        _PLANS.clear()
+    for p in plans:
+        with p.lock:
+            p.close()
 
 
 def _tag(*key) -> int:
@@ -165,15 +174,17 @@ def linear_operator(n, dt, alpha, beta_2, beta_3, precision=_lib.C64):
     simulation calls FIBER / DBP with the same fibre again and again.
     """
     key = (int(n), float(dt), float(alpha), float(beta_2), float(beta_3), int(precision))
-    hit = _OPERATORS.get(key)
-    if hit is not None:
-        _OPERATORS.move_to_end(key)
-        return hit
+    with _CACHE_LOCK:
+        hit = _OPERATORS.get(key)
+        if hit is not None:
+            _OPERATORS.move_to_end(key)
+            return hit
     d = _linear_operator(n, dt, alpha, beta_2, beta_3, precision)
     d.flags.writeable = False
-    _OPERATORS[key] = d
-    while len(_OPERATORS) > _MAX_OPERATORS:
-        _OPERATORS.popitem(last=False)
+    with _CACHE_LOCK:
+        _OPERATORS[key] = d
+        while len(_OPERATORS) > _MAX_OPERATORS:
+            _OPERATORS.popitem(last=False)
     return d
 
 
@@ -185,19 +196,21 @@ def _grid_powers(n, dt, precision):
     NumPy's ``w**3`` (``pow``) costs 38 ms at 2^20 points -- 12x a whole 100-step propagation -- and depends only on
     the sampling grid, so a sweep over fibre parameters pays it once."""
     key = (int(n), float(dt), int(precision))
-    hit = _GRID_POWERS.get(key)
-    if hit is None:
-        w = np.fft.fftfreq(n, dt) * 2 * np.pi * 1e-12        # rad/ps
-        if precision == _lib.C64:
-            w = np.asarray(w, dtype=_F32)
-        hit = (w**2, w**3)
-        for a in hit:
-            a.flags.writeable = False
+    with _CACHE_LOCK:
+        hit = _GRID_POWERS.get(key)
+        if hit is not None:
+            _GRID_POWERS.move_to_end(key)
+            return hit
+    w = np.fft.fftfreq(n, dt) * 2 * np.pi * 1e-12        # rad/ps
+    if precision == _lib.C64:
+        w = np.asarray(w, dtype=_F32)
+    hit = (w**2, w**3)
+    for a in hit:
+        a.flags.writeable = False
+    with _CACHE_LOCK:
         _GRID_POWERS[key] = hit
         while len(_GRID_POWERS) > 2:
             _GRID_POWERS.popitem(last=False)
-    else:
-        _GRID_POWERS.move_to_end(key)
     return hit
 
 
@@ -251,11 +264,12 @@ class _ChirpZ:
         with self.plan.lock:
             self._ensure_tables()
         key = (dev, n)
-        if key not in _CHIRPS:
-            _CHIRPS[key] = (_lib.chirp_device(n, False, dev), _lib.chirp_device(n, True, dev))
-            while len(_CHIRPS) > 4:
-                _CHIRPS.pop(next(iter(_CHIRPS)))
-        self.chirp, self.chirp_conj = _CHIRPS[key]
+        with _CACHE_LOCK:
+            if key not in _CHIRPS:
+                _CHIRPS[key] = (_lib.chirp_device(n, False, dev), _lib.chirp_device(n, True, dev))
+                while len(_CHIRPS) > 4:
+                    _CHIRPS.pop(next(iter(_CHIRPS)))
+            self.chirp, self.chirp_conj = _CHIRPS[key]
 
     def _ensure_tables(self):
         want = _tag("chirp", self.n)
