@@ -128,6 +128,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_SAME_GPU"):             # diagnostics only: every rank on GPU 0 (needs BENCH_DIST_BACKEND=gloo: RCCL wants one GPU per rank)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
