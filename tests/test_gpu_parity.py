@@ -1290,6 +1290,9 @@ def test_c_abi_from_plain_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ABI version 1" in r.stdout and "back-propagated" in r.stdout
+    assert "operator label after set: 0x5eed, after a new operator: 0" in r.stdout          # the plan cleared the label itself
+    assert "adaptive:" in r.stdout and "z_end = 20.000000 km" in r.stdout
+    assert "PRBS-7: 10000001000001100001" in r.stdout                                         # reference tests/devices_test.py:52-71
 
 
 # ----------------------------------------------------------------------- API behaviour on the device
