@@ -57,6 +57,12 @@ struct SosCoefs {
     double b0[kMaxSections], b1[kMaxSections], b2[kMaxSections], a1[kMaxSections], a2[kMaxSections];
 };
 
+// SOS_WT: the 16-byte sample stores go out write-through (sc1), as the propagator's do -- the next kernel's readers sit on
+// other CUs, so a dirty line in this XCD's L2 only adds a flush at the kernel boundary.  2^20 x 2 complex: 90.5 -> 87.5 us,
+// other shapes unchanged; non-temporal loads measured 4 % slower (profiles/r02_sosfilt_policy_ab.txt).
+#ifndef SOS_WT
+#define SOS_WT 1
+#endif
 // One direction of the forward-backward pass.  Rows hold CH interleaved channels.
 struct SosPass {
     const double* src;      // forward: caller's x; backward: y1 (padded forward output, [row][m][CH])
@@ -79,8 +85,16 @@ template <int CH> __device__ __forceinline__ Smp<CH> ld(const double* p, long lo
     return r;
 }
 template <int CH> __device__ __forceinline__ void st(double* p, long long e, const Smp<CH>& s) {
+#if SOS_WT
+    if constexpr (CH == 2) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v q = {s.v[0], s.v[1]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(reinterpret_cast<d2v*>(p + 2 * e)), "v"(q) : "memory");
+    } else p[e] = s.v[0];
+#else
     if constexpr (CH == 2) *reinterpret_cast<double2*>(p + 2 * e) = make_double2(s.v[0], s.v[1]);
     else p[e] = s.v[0];
+#endif
 }
 
 // sample i of the pass input of the row starting at `base`
