@@ -139,6 +139,8 @@ template <typename T> struct PlanT : PlanBase {
     cx<T>* tw2 = nullptr;      // N2
     cx<T>* dnat = nullptr;     // n  (D~ or H, natural order, staging)
     cx<T>* dperm = nullptr;    // n  (D~ transposed order)
+    cx<T>* dperm_fly = nullptr;  // the same for the rows of k_freq<FM_FLY> where they use another number of points per thread (Ef_fly)
+    cx<T>* tw2_fly = nullptr;
     cx<T>* scratch = nullptr;  // batch * n, lazily
     cx<T>* xfer_tab[2] = {nullptr, nullptr};   // resident transfer functions of ssfm_transfer_table (n each, lazily)
     struct Tab { T h; cx<T>* ptr; bool valid; };
@@ -165,6 +167,7 @@ template <typename T> struct PlanT : PlanBase {
     bool u16 = false;          // field layout between the kernels: 16-byte units (ssfm_kernels.hpp "U16")
     int E = 16;                // points per thread of k_time (env SSFM_E = 8 | 16)
     int Ef = 16;               // ... and of k_freq (env SSFM_EF); the two kernels only share the field layout
+    int Ef_fly = 16;           // ... and of k_freq when it forms exp(D~ h) itself (adaptive runs, more step sizes than tables)
     bool stagger = false;      // env SSFM_STAGGER
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
@@ -327,7 +330,7 @@ template <typename T> struct PlanT : PlanBase {
 
     int free_all() {
         if (stream) (void)hipStreamSynchronize(stream);
-        void* bufs[] = {F, Y != F ? Y : nullptr, P, twN, twA, twB, tw1, tw2, dnat, dperm, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
+        void* bufs[] = {F, Y != F ? Y : nullptr, P, twN, twA, twB, tw1, tw2, tw2_fly, dnat, dperm, dperm_fly, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
         for (int g = 1; g < kMaxLanes; ++g) {
@@ -384,6 +387,12 @@ template <typename T> struct PlanT : PlanBase {
         if (std::getenv("SSFM_E")) Ef = E;
         if (const char* e = std::getenv("SSFM_EF")) Ef = std::atoi(e) == 16 ? 16 : 8;
         if (k > 20) E = Ef = 16;        // the large tiles (N1 = 512, N2 = 8192) exist for 16 points per thread only
+        // complex128 rows that form exp(D~ h) in the kernel: 16 points per thread need 256 VGPRs + 164 AGPRs (one wave per SIMD),
+        // 8 need 248 (two): adaptive 2^20 x 2 81.3 -> 74.6 us per step (profiles/r02_adaptive_c128_ef.txt).  The operator table's
+        // order follows the points per thread, so these rows get their own copy of D~ and of the row twiddles.
+        Ef_fly = Ef;
+        if (sizeof(T) == 8 && Ef == 16 && k <= 20 && !std::getenv("SSFM_E") && !std::getenv("SSFM_EF")) Ef_fly = 8;
+        if (const char* e = std::getenv("SSFM_EF_FLY")) Ef_fly = k > 20 ? 16 : (std::atoi(e) == 16 ? 16 : 8);
         if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = (e[0] == 'a' || e[0] == 'A') ? -1 : (std::atoi(e) != 0 ? 1 : 0);
         // two lanes pay off once a launch is long enough to hide the other lane's gap; below ~2^20 points in
@@ -423,6 +432,10 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = make_line_table(&tw2, N2, Ef)) return rc;
         HIP_TRY(hipMalloc(&dnat, cb * n));
         HIP_TRY(hipMalloc(&dperm, cb * n));
+        if (Ef_fly != Ef) {
+            if (int rc = make_line_table(&tw2_fly, N2, Ef_fly)) return rc;
+            HIP_TRY(hipMalloc(&dperm_fly, cb * n));
+        }
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
         HIP_TRY(hipGetLastError());
@@ -508,6 +521,9 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipMemcpyAsync(dnat, host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)dnat, dperm, N1, N2, N2 / Ef, (T)0, inv_n());
+        if (dperm_fly)
+            hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                               (const cx<T>*)dnat, dperm_fly, N1, N2, N2 / Ef_fly, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         // host buffer may be reused by the caller right after return
         HIP_TRY(hipStreamSynchronize(stream));
@@ -552,6 +568,13 @@ template <typename T> struct PlanT : PlanBase {
         return a;
     }
 
+    // k_freq<FM_FLY>: D~ and the row twiddles in the order of ITS points per thread
+    FreqArgs<T> fargs_fly(T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
+        FreqArgs<T> a = fargs(dperm_fly ? dperm_fly : dperm, h, s, row0, lane);
+        if (tw2_fly) a.tw2 = tw2_fly;
+        return a;
+    }
+
     int copy_field_out(void* dst, bool is_device, bool wait) {
         HIP_TRY(hipMemcpyAsync(dst, F, sizeof(cx<T>) * n * batch, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         if (wait) HIP_TRY(hipStreamSynchronize(stream));
@@ -591,7 +614,7 @@ template <typename T> struct PlanT : PlanBase {
                     if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
                 return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0, lane_), Ef);
             }
-            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs(dperm, hs, nullptr, row0, lane_), Ef);
+            return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs_fly(hs, nullptr, row0, lane_), Ef_fly);
         };
         auto freq = [&](T hs) -> hipError_t { return freq_rows(hs, 0, batch, stream); };
         (void)nrows;
@@ -782,9 +805,9 @@ template <typename T> struct PlanT : PlanBase {
                 tb.derive = i != 0;         // the first BEGIN of a chunk finds its state in cur[] (k_step_control wrote it)
                 if (ar.tile_private && ar.step > 0) HIP_TRY((launch_time<T, TM_BEGIN_Y>(N1, batch, stream, tb, E)));
                 else HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E)));
-                FreqArgs<T> fa = fargs(dperm, 0, st);
+                FreqArgs<T> fa = fargs_fly(0, st);
                 fa.step = ar.step;
-                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fa, Ef)));
+                HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fa, Ef_fly)));
                 if (ar.tile_private) HIP_TRY((launch_time<T, TM_END_Y>(N1, batch, stream, te, E)));
                 else HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, te, E)));
                 last_launches += 3;

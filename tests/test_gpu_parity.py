@@ -269,13 +269,33 @@ def test_c128_against_oracle_dual_pol():
     assert relmax(y32, ref) < TOL_100
 
 
-def test_c128_adaptive_against_oracle():
+@pytest.mark.parametrize("log2n, length", [(12, 20), (18, 3), (19, 2)])
+def test_c128_adaptive_against_oracle(log2n, length):
+    """(2^18 and 2^19: complex128 rows that form exp(D~ h) in the kernel run with 8 points per thread and their own copy of
+    the operator, ssfm_host.hip `Ef_fly`; fixed steps with more step sizes than tables take the same rows)"""
     gv(**workloads.BENCH_GV)
-    a = workloads.qpsk_field(1 << 12, seed=12, power_w=10e-3)
-    kw = dict(length=20, phi_max=0.05, **workloads.SMF)
+    a = workloads.qpsk_field(1 << log2n, seed=12, power_w=10e-3)
+    kw = dict(length=length, phi_max=0.05, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal
     ref = orc.fiber_c128(a, gv.dt, **kw)
     assert relmax(y, ref) < 1e-7          # step sizes agree to rounding; splitting error tracks
+    if log2n >= 18:
+        hs = np.linspace(0.05, 0.35, 2 * length * 5 // 2)          # more distinct step sizes than operator tables
+        hs = hs * (length / hs.sum())
+        p = _lib.Plan(a.shape[-1], a.shape[0], _lib.C128)
+        try:
+            p.set_linear_operator(oa.devices.linear_operator(a.shape[-1], gv.dt, workloads.SMF["alpha"], workloads.SMF["beta_2"], workloads.SMF["beta_3"], _lib.C128))
+            p.set_field(a)
+            p.propagate_fixed(workloads.SMF["gamma"], hs)
+            got = p.get_field()
+        finally:
+            p.close()
+        D = orc.linear_operator_c128(a.shape[-1], gv.dt, workloads.SMF["alpha"], workloads.SMF["beta_2"], workloads.SMF["beta_3"])
+        want = np.asarray(a, np.complex128)
+        for h_ in hs:                                               # the loop of oracle/ssfm_numpy.fiber_c128 over a given schedule
+            N_hat = 1j * workloads.SMF["gamma"] * np.abs(want) ** 2
+            want = np.fft.ifft(np.fft.fft(want * np.exp(h_ / 2 * N_hat)) * np.exp(D * h_)) * np.exp(h_ / 2 * N_hat)
+        assert relmax(got, want) < TOL_C128
 
 
 # ----------------------------------------------------------------------- reference's own tests
