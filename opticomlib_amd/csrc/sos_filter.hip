@@ -30,6 +30,7 @@
 // = 48 B against the algorithmic 16 B (read x once, write y once).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -49,8 +50,14 @@ constexpr int kWave = 64;          // lanes per wavefront
 #ifndef SOS_WAVES
 #define SOS_WAVES 4
 #endif
-constexpr int kWaves = SOS_WAVES;  // wavefronts per workgroup (measured, BPF 2^20 x 2 complex: 4 -> 97 us, 2 -> 95 us, 1 -> 131 us per call)
-constexpr int kGroup = kWave * kWaves;   // chunks per group = threads per workgroup
+// Wavefronts per workgroup W (a template parameter of the kernels; chunks per group = threads per workgroup = 64 W).
+// Measured, kernels per call (profiles/r02_sosfilt_shape.txt): 2^20 x 2 complex 87 us with 4, 95 with 2, 88.5 with 3
+// (first version: 1 -> 131 us); 2^20 real 45 / 48-50 / 43; but the short calls of a 2^14 ... 2^16-sample link, which
+// are a latency chain of four small kernels, run 11-12 % faster with 2 (2^16 real 32.3 -> 28.5 us, 2^14 complex 38.1 ->
+// 34.0): `sos_waves()` picks 2 up to kSmallChunks chunks in all, SOS_WAVES above.
+constexpr int kWavesLarge = SOS_WAVES;
+constexpr int kWavesSmall = 2;
+constexpr long long kSmallChunks = 16384;
 constexpr int kMaxSections = 4;    // Bessel orders up to 8
 
 struct SosCoefs {
@@ -189,7 +196,7 @@ template <int K, int CH> __device__ __forceinline__ void mat_acc(const double* M
 // overlapped with its data loads).
 constexpr int kScanSteps = 6;
 template <int K> __device__ __forceinline__ void stage_pow2(const double* __restrict__ pw, double* lds_pw, int tid) {
-    for (int e = tid; e < (kScanSteps + 1) * K * K; e += kGroup) {
+    for (int e = tid; e < (kScanSteps + 1) * K * K; e += (int)blockDim.x) {
         const int k = e / (K * K);
         lds_pw[e] = pw[((long long)1 << k) * K * K + e % (K * K)];
     }
@@ -227,10 +234,11 @@ template <int K, int CH> __device__ __forceinline__ void mat_apply(const double*
 }
 
 // state vector s[CH][K] <-> z[NS][2] per channel
-template <int NS, int CH>
-__global__ __launch_bounds__(kGroup) void k_chunk_scan(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ pw,
+template <int NS, int CH, int W>
+__global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ pw,
                                                        double* __restrict__ E, double* __restrict__ T) {
     constexpr int K = 2 * NS;
+    constexpr int kWaves = W, kGroup = kWave * W;
     __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
     __shared__ double lds_pw[(kScanSteps + 1) * K * K];
     __shared__ double tot[kWaves][CH * K];
@@ -326,12 +334,13 @@ __global__ __launch_bounds__(kGroup) void k_chunk_scan(SosCoefs c, SosPass p, in
     }
 }
 
-template <int NS, int CH>
-__global__ __launch_bounds__(kGroup) void k_apply(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi,
+template <int NS, int CH, int W>
+__global__ __launch_bounds__(kWave * W) void k_apply(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi,
                                                   const double* __restrict__ pw, const double* __restrict__ pwG, const double* __restrict__ pwH,
                                                   const double* __restrict__ E, const double* __restrict__ T,
                                                   double* __restrict__ y1, double* __restrict__ out) {
     constexpr int K = 2 * NS;
+    constexpr int kWaves = W, kGroup = kWave * W;
     __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
     __shared__ double lds_m64[K * K];
     __shared__ double red[kWaves][CH * K];
@@ -507,10 +516,11 @@ template <int K> void matmul(const double* A, const double* B, double* C) {
         }
 }
 
-// tables[level][j] = (M_level)^j, j = 0..64; level 0: M = A^kChunk, level 1: M^256 (one group of 4 x 64
+// tables[level][j] = (M_level)^j, j = 0..64; level 0: M = A^kChunk, level 1: M^(64 W) (one group of W x 64
 // chunks), level 2: M^16384 (64 groups)
-template <int NS> void build_tables(const SosCoefs& c, std::vector<double>& tab) {
+template <int NS, int W> void build_tables(const SosCoefs& c, std::vector<double>& tab) {
     constexpr int K = 2 * NS;
+    constexpr int kWaves = W;
     double M[K * K];
     // column q of A^kChunk = state after kChunk zero-input steps from the unit state e_q
     for (int q = 0; q < K; ++q) {
@@ -545,10 +555,11 @@ template <int NS> void build_tables(const SosCoefs& c, std::vector<double>& tab)
 
 #define WS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SSFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
-template <int NS, int CH>
-int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const double* zi_h, const double* x, double* y,
+template <int NS, int CH, int W>
+int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const double* zi_h, const double* x, double* y,
                long long n, int rows, int edge, bool on_device) {
     constexpr int K = 2 * NS;
+    constexpr int kGroup = kWave * W;
     const long long m = n + 2ll * edge;
     const long long nchunks_ll = (m + kChunk - 1) / kChunk;
     if (nchunks_ll > (1ll << 30)) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_sosfiltfilt: n=%lld too long", n);
@@ -572,9 +583,10 @@ int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const dou
     // tables + zi: rebuilt only when the filter changes
     std::vector<double> key(sos_key, sos_key + 6 * NS);
     key.insert(key.end(), zi_h, zi_h + K);
+    key.push_back((double)W);                              // the group map is (M^64)^W
     if (key != w.table_key) {
         std::vector<double> tab;
-        build_tables<NS>(c, tab);
+        build_tables<NS, W>(c, tab);
         tab.insert(tab.end(), zi_h, zi_h + K);
         WS_TRY(hipMemcpyAsync(w.buf[5], tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, w.stream));
         WS_TRY(hipStreamSynchronize(w.stream));            // `tab` is a local
@@ -601,8 +613,8 @@ int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const dou
     for (int dir = 0; dir < 2; ++dir) {
         p.backward = dir;
         p.src = dir == 0 ? d_x : d_y1;
-        hipLaunchKernelGGL((k_chunk_scan<NS, CH>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_pw, d_E, d_T);
-        hipLaunchKernelGGL((k_apply<NS, CH>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
+        hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_pw, d_E, d_T);
+        hipLaunchKernelGGL((k_apply<NS, CH, W>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
                            (const double*)d_T, d_y1, d_out);
         WS_TRY(hipGetLastError());
     }
@@ -611,6 +623,20 @@ int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const dou
     WS_TRY(hipStreamSynchronize(w.stream));
     WS_TRY(hipEventElapsedTime(&w.last_ms, w.ev0, w.ev1));
     return SSFM_OK;
+}
+
+// the workgroup shape follows the size of the call (see kWavesSmall)
+inline int sos_waves(long long n, int rows, int edge) {
+    const long long chunks = (n + 2ll * edge + kChunk - 1) / kChunk * rows;
+    if (const char* e = std::getenv("SOS_WAVES_FORCE")) { const int v = std::atoi(e); if (v == kWavesSmall || v == kWavesLarge) return v; }
+    return chunks <= kSmallChunks ? kWavesSmall : kWavesLarge;
+}
+template <int NS, int CH>
+int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const double* zi_h, const double* x, double* y,
+               long long n, int rows, int edge, bool on_device) {
+    if (kWavesSmall != kWavesLarge && sos_waves(n, rows, edge) == kWavesSmall)
+        return run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+    return run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
 }
 
 int sosfiltfilt_impl(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,

@@ -493,6 +493,26 @@ def test_sosfiltfilt_lengths_and_orders_against_scipy(order, n):
     assert relmax(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1)) < TOL_FILT
 
 
+@pytest.mark.parametrize("waves", ["2", "4"])
+def test_sosfiltfilt_both_workgroup_shapes(waves, monkeypatch):
+    """The filter kernels exist with 2 and with 4 wavefronts per workgroup and pick by the size of the call
+    (sos_filter.hip `sos_waves`); here both shapes run every size, across their group boundaries (64 W chunks of 12)."""
+    from scipy import signal as sg
+    monkeypatch.setenv("SOS_WAVES_FORCE", waves)
+    for order, n in ((4, 1530), (4, 1537), (4, 3060), (4, 3073), (3, 12 * 128 * 7 + 5), (8, 12 * 256 * 3 - 31), (4, (1 << 18) + 3)):
+        sos = sg.bessel(order, 0.07 if n > 4096 else 0.2, "low", norm="mag", output="sos")
+        zi = sg.sosfilt_zi(sos)
+        rng = np.random.default_rng(n)
+        x = rng.standard_normal(n).cumsum() * 0.05 + rng.standard_normal(n)
+        assert relmax(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x)) < TOL_FILT
+        xc = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n)))
+        assert relmax(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1)) < TOL_FILT
+        # the other shape right after: the tables of the group level are rebuilt for it
+        monkeypatch.setenv("SOS_WAVES_FORCE", "4" if waves == "2" else "2")
+        assert relmax(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x)) < TOL_FILT
+        monkeypatch.setenv("SOS_WAVES_FORCE", waves)
+
+
 def test_sosfiltfilt_on_device_buffers():
     """ssfm_sosfiltfilt_device on the field buffers of complex128 plans: same result as the host entry
     point, out of place and in place (a propagated field is filtered where it lies)."""
