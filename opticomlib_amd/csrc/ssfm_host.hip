@@ -116,6 +116,38 @@ hipError_t launch_freq(int N2, int nrows, hipStream_t s, FreqArgs<T> a, int E) {
     return E == 8 ? launch_freq_e<T, MODE, 8>(N2, nrows, s, a) : launch_freq_e<T, MODE, 16>(N2, nrows, s, a);
 }
 
+// k_small: one workgroup per row, the whole schedule in one launch.  Points per thread: 8 up to 2048 samples and for
+// complex128 (more wavefronts per row; complex128 with 16 would not fit the registers), 16 for complex64 rows of 4096 / 8192.
+#ifndef SSFM_SMALL_E16_MIN
+#define SSFM_SMALL_E16_MIN 4096
+#endif
+template <typename T> constexpr int small_points(int n) { return sizeof(T) == 4 && n >= SSFM_SMALL_E16_MIN ? 16 : 8; }
+template <typename T> constexpr bool small_supported(int n) {
+    return n >= 256 && n <= (sizeof(T) == 4 ? 8192 : 4096) && (n & (n - 1)) == 0;
+}
+static_assert(kSmallTabs == kMaxTables, "k_small takes one table per cached step size");
+template <typename T, int N>
+hipError_t launch_small_n(int rows, hipStream_t s, const SmallArgs<T>& a) {
+    constexpr int E = small_points<T>(N);
+    constexpr size_t lds = (fft_nstages(N, E) > 1 ? (size_t)row_lds_elems(N, E) * sizeof(cx<T>) : 0) + (size_t)fft_tw_lds_entries(N, E) * sizeof(cx<T>);
+    static hipError_t attr = allow_lds(k_small<T, N, E>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_small<T, N, E>), dim3(rows), dim3(N / E), lds, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_small(int n, int rows, hipStream_t s, const SmallArgs<T>& a) {
+    switch (n) {
+        case 256:  return launch_small_n<T, 256>(rows, s, a);
+        case 512:  return launch_small_n<T, 512>(rows, s, a);
+        case 1024: return launch_small_n<T, 1024>(rows, s, a);
+        case 2048: return launch_small_n<T, 2048>(rows, s, a);
+        case 4096: return launch_small_n<T, 4096>(rows, s, a);
+        case 8192: if constexpr (sizeof(T) == 4) return launch_small_n<T, 8192>(rows, s, a); else break;
+    }
+    return hipErrorInvalidValue;
+}
+
 // ----------------------------------------------------------------------------- plan
 struct PlanBase {
     int precision = 0;
@@ -146,6 +178,14 @@ template <typename T> struct PlanT : PlanBase {
     struct Tab { T h; cx<T>* ptr; bool valid; };
     Tab tabs[kMaxTables] = {};
     int tab_rr = 0;
+    // single-launch engine of small plans (ssfm_kernels.hpp k_small): its own row twiddles and operator tables (another order)
+    bool small = false;        // env SSFM_SMALL=0 turns it off
+    cx<T>* tw_small = nullptr;
+    Tab stabs[kMaxTables] = {};
+    int stab_rr = 0;
+    T* d_hs = nullptr;         // the schedule on the device: step sizes, then one table index per step
+    size_t d_hs_cap = 0;
+    std::vector<unsigned char> h_sched;
     AdaptState<T>* st = nullptr;
     T* zlog = nullptr;
     int64_t zlog_cap = 0;
@@ -155,7 +195,7 @@ template <typename T> struct PlanT : PlanBase {
     // labels it (ssfm_plan_set_tag) and asks later whether it is still there (ssfm_plan_get_tag); every entry point
     // that overwrites or reuses a buffer clears its label here, so a stale label cannot survive.  0 = nothing known.
     uint64_t tags[3] = {0, 0, 0};
-    void drop_operator() { have_op = false; tags[0] = 0; for (auto& t : tabs) t.valid = false; }
+    void drop_operator() { have_op = false; tags[0] = 0; for (auto& t : tabs) t.valid = false; for (auto& t : stabs) t.valid = false; }
     bool timed = false;
     int64_t last_launches = 0;
     bool profiling = false;
@@ -333,6 +373,9 @@ template <typename T> struct PlanT : PlanBase {
         void* bufs[] = {F, Y != F ? Y : nullptr, P, twN, twA, twB, tw1, tw2, tw2_fly, dnat, dperm, dperm_fly, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
+        for (auto& t : stabs) (void)hipFree(t.ptr);
+        (void)hipFree(tw_small);
+        (void)hipFree(d_hs);
         for (int g = 1; g < kMaxLanes; ++g) {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
             if (lane_stream[g]) (void)hipStreamDestroy(lane_stream[g]);
@@ -436,6 +479,9 @@ template <typename T> struct PlanT : PlanBase {
             if (int rc = make_line_table(&tw2_fly, N2, Ef_fly)) return rc;
             HIP_TRY(hipMalloc(&dperm_fly, cb * n));
         }
+        small = small_supported<T>((int)n);
+        if (const char* e = std::getenv("SSFM_SMALL")) small = small && std::atoi(e) != 0;
+        if (small) if (int rc = make_line_table(&tw_small, (int)n, small_points<T>((int)n))) return rc;
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
         HIP_TRY(hipGetLastError());
@@ -528,23 +574,44 @@ template <typename T> struct PlanT : PlanBase {
         // host buffer may be reused by the caller right after return
         HIP_TRY(hipStreamSynchronize(stream));
         for (auto& t : tabs) t.valid = false;
+        for (auto& t : stabs) t.valid = false;
         have_op = true;
         tags[0] = 0;
         return SSFM_OK;
     }
 
-    // exp(D~ h)/N in transposed order, cached per distinct h
-    int table_for(T h, const cx<T>** out) {
-        for (auto& t : tabs)
-            if (t.valid && std::memcmp(&t.h, &h, sizeof(T)) == 0) { *out = t.ptr; return SSFM_OK; }
-        Tab& t = tabs[tab_rr];
-        tab_rr = (tab_rr + 1) % kMaxTables;
-        if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
-        hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)dnat, t.ptr, N1, N2, N2 / Ef, h, inv_n());
-        HIP_TRY(hipGetLastError());
-        t.h = h; t.valid = true;
-        *out = t.ptr;
+    // exp(D~ h)/N for every step size of a schedule (at most kMaxTables), cached per distinct h.  `one_line`: the table of the
+    // single-launch engine (N1 = 1: the table index is the frequency index), else the transposed order of k_freq.
+    // A slot that holds a table this schedule needs is never the victim of another of its tables (a round-robin victim could
+    // be: schedules {a,b}, {c,d}, {a,e} on one plan would have run a's steps with e's table).
+    int tables_for(const std::vector<T>& distinct, const cx<T>** out, bool one_line) {
+        Tab* cache = one_line ? stabs : tabs;
+        int& rr = one_line ? stab_rr : tab_rr;
+        bool pinned[kMaxTables] = {};
+        for (size_t i = 0; i < distinct.size(); ++i) {
+            out[i] = nullptr;
+            for (int k = 0; k < kMaxTables; ++k)
+                if (cache[k].valid && std::memcmp(&cache[k].h, &distinct[i], sizeof(T)) == 0) { out[i] = cache[k].ptr; pinned[k] = true; }
+        }
+        for (size_t i = 0; i < distinct.size(); ++i) {
+            if (out[i]) continue;
+            int v = rr;
+            while (pinned[v]) v = (v + 1) % kMaxTables;      // distinct.size() <= kMaxTables: there is one
+            Tab& t = cache[v];
+            rr = (v + 1) % kMaxTables;
+            pinned[v] = true;
+            t.valid = false;
+            if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
+            if (one_line)
+                hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                                   (const cx<T>*)dnat, t.ptr, 1, (int)n, (int)n / small_points<T>((int)n), distinct[i], inv_n());
+            else
+                hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                                   (const cx<T>*)dnat, t.ptr, N1, N2, N2 / Ef, distinct[i], inv_n());
+            HIP_TRY(hipGetLastError());
+            t.h = distinct[i]; t.valid = true;
+            out[i] = t.ptr;
+        }
         return SSFM_OK;
     }
 
@@ -581,6 +648,33 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
+    // the whole schedule in one launch (k_small); `distinct` holds at most kMaxTables step sizes
+    int run_small(T gamma, const T* h, int64_t nsteps, const std::vector<T>& distinct) {
+        SmallArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        if (int rc = tables_for(distinct, a.tab, true)) return rc;
+        const size_t hb = sizeof(T) * (size_t)nsteps, need = hb + (size_t)nsteps;
+        if (d_hs_cap < need) {
+            (void)hipFree(d_hs); d_hs = nullptr; d_hs_cap = 0;
+            HIP_TRY(hipMalloc(&d_hs, need + need / 2));
+            d_hs_cap = need + need / 2;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));             // the staging vector may still feed the previous run's copy
+        h_sched.resize(need);
+        std::memcpy(h_sched.data(), h, hb);
+        for (int64_t s = 0; s < nsteps; ++s) {
+            unsigned char w = 0;
+            for (size_t i = 0; i < distinct.size(); ++i)
+                if (std::memcmp(&distinct[i], &h[s], sizeof(T)) == 0) w = (unsigned char)i;
+            h_sched[hb + (size_t)s] = w;
+        }
+        HIP_TRY(hipMemcpyAsync(d_hs, h_sched.data(), need, hipMemcpyHostToDevice, stream));
+        a.F = F; a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb; a.tw = tw_small; a.gamma = gamma; a.nsteps = (int)nsteps;
+        ++last_launches;
+        HIP_TRY(launch_small<T>((int)n, batch, stream, a));
+        return SSFM_OK;
+    }
+
     int propagate_fixed(double gamma_d, const T* h, int64_t nsteps, void* snapshots) {
         if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_fixed: call ssfm_set_linear_operator first");
         if (int rc = use_device()) return rc;
@@ -602,9 +696,9 @@ template <typename T> struct PlanT : PlanBase {
         }
         const bool use_tables = distinct.size() <= (size_t)kMaxTables;
         std::vector<const cx<T>*> tabptr(distinct.size(), nullptr);
-        if (use_tables)
-            for (size_t i = 0; i < distinct.size(); ++i)
-                if (int rc = table_for(distinct[i], &tabptr[i])) return rc;
+        const bool go_small = small && use_tables && !profiling && snapshots == nullptr && nsteps <= 0x7fffffff;
+        if (use_tables && !go_small)
+            if (int rc = tables_for(distinct, tabptr.data(), false)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
             const int lane_ = rows > 0 ? row0 / rows : 0;
             ++last_launches;
@@ -680,7 +774,9 @@ template <typename T> struct PlanT : PlanBase {
 #if SSFM_TRACE
             if (int rc = trace_begin((int)(2 * nsteps + 1) * nlanes)) return rc;
 #endif
-            if (int rc = run_steps_maybe_graph(enqueue_steps, gamma, h, nsteps, tabptr)) return rc;
+            if (go_small) {
+                if (int rc = run_small(gamma, h, nsteps, distinct)) return rc;
+            } else if (int rc = run_steps_maybe_graph(enqueue_steps, gamma, h, nsteps, tabptr)) return rc;
 #if SSFM_TRACE
             if (int rc = trace_dump()) return rc;
 #endif

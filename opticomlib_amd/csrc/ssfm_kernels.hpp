@@ -832,6 +832,89 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     SSFM_TRACE_END(a);
 }
 
+// ------------------------------------------------------------------------------ k_small
+// A field of up to 8192 samples is ONE line of the row transform: a workgroup keeps a whole row in its registers and runs
+// the complete fixed-step schedule in a single launch -- rotation, N-point FFT, exp(D~ h)/N, inverse FFT, rotation, for every
+// step, with LDS for the exchanges only.  The two-kernel engine spends 2.6 us per kernel on such a plan whatever its size
+// (dependent-launch boundary; profiles/r02_small_graph.txt: eager and hipGraph alike), i.e. 5.2-6 us per step.
+// The arithmetic per step is k_time's and k_freq<FM_TABLE>'s: the second half rotation of a step and the first of the next
+// are one rotation by the sum of the two phases, |A|^2 of the step's start stays in registers (`pold`).
+constexpr int kSmallTabs = 4;
+template <typename T> struct SmallArgs {
+    cx<T>* F;                          // batch rows of N samples, time order, advanced in place
+    const cx<T>* tab[kSmallTabs];      // exp(D~ h)/N per distinct step size, at freq_tab_pos(k, N / E)
+    const T* hs;                       // the schedule: nsteps step sizes [km]
+    const unsigned char* which;        // per step: its table
+    const cx<T>* tw;                   // stage twiddles of the N-point line (make_line_table(N, E))
+    T gamma;
+    int nsteps;
+};
+template <typename T, int N, int E>
+__global__ __launch_bounds__(N / E) void k_small(const SmallArgs<T> a) {
+    constexpr int Q = N / E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+    const int j = threadIdx.x;
+    cx<T>* __restrict__ Frow = a.F + (long long)blockIdx.x * N;
+    using RI = RowIdx<row_pad_shift(E)>;
+    const RI idx{0};
+    cx<T> v[E];
+    cx<T> m[E];
+#pragma unroll
+    for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
+    LineTw<T, N, E> tw;
+    cx<T>* ldsT = lds + (fft_nstages(N, E) > 1 ? row_lds_elems(N, E) : 0);
+    line_twiddles_issue<T, N, E>(tw, j, a.tw, ldsT, j, Q);
+    if (fft_tw_lds_entries(N, E) > 0) __syncthreads();
+    line_twiddles_fetch<T, N, E>(tw, j, ldsT);
+    const T half = (T)0.5;
+    T pold[E];
+    T phi[E];
+    {   // first half step of step 0 (k_time<TM_BEGIN>)
+        const T hh = half * a.hs[0];
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+            T ph = (T)0;
+            ph += hh * (a.gamma * p);
+            pold[t] = p;
+            phi[t] = ph;
+        }
+        rotate_all<E>(v, phi);
+    }
+    typedef T m4_t __attribute__((ext_vector_type(4)));
+    for (int s = 0; s < a.nsteps; ++s) {
+        const T h = a.hs[s];
+        const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(a.tab[a.which[s]]) + j;
+#pragma unroll
+        for (int g = 0; g < E / 2; ++g) {
+            const m4_t q = T4[g * Q];
+            m[2 * g] = mk<T>(q.x, q.y);
+            m[2 * g + 1] = mk<T>(q.z, q.w);
+        }
+        // (exchange parity 1: the LDS buffer was last read by the previous transform, a barrier precedes its rewrite)
+        fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
+        fft_line<T, N, E, +1, 1, RI>(v, lds, 0, j, idx, tw);
+        // k_time<TM_MID> (TM_END after the last step): both half-step phases in one rotation
+        const T hh_prev = half * h;
+        const bool more = s + 1 < a.nsteps;
+        const T hh_next = more ? half * a.hs[s + 1] : (T)0;
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+            T ph = hh_prev * (a.gamma * pold[t]);
+            if (more) ph += hh_next * (a.gamma * p);
+            pold[t] = p;
+            phi[t] = ph;
+        }
+        rotate_all<E>(v, phi);
+    }
+#pragma unroll
+    for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
+}
+
 // ------------------------------------------------------------------------------ tables
 // Factor tables of the inter-pass twiddles, tile by tile: out[(tile * R + r) * C + c] = W_N^(r mult n2(tile, c)), r < R
 // (twA: R = N1/E, mult = 1;  twB: R = E, mult = N1/E)

@@ -493,6 +493,79 @@ def test_sosfiltfilt_lengths_and_orders_against_scipy(order, n):
     assert relmax(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1)) < TOL_FILT
 
 
+@pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
+@pytest.mark.parametrize("log2n", [8, 9, 10, 11, 12, 13])
+def test_single_launch_engine_against_the_two_kernel_engine(log2n, prec, monkeypatch):
+    """Plans of up to 8192 samples run a fixed-step schedule in ONE launch (ssfm_kernels.hpp k_small: a workgroup keeps a row
+    in registers); SSFM_SMALL=0 at plan creation selects the two-kernel engine for the same plan shape.  Same arithmetic per
+    step, another FFT factorisation: agreement at rounding level, and both against the oracle."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    rng = np.random.default_rng(log2n)
+    a = ((rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n))) * 0.05).astype(np.complex64 if prec == _lib.C64 else np.complex128)
+    hs = np.array([0.5] * 7 + [0.25, 0.5, 0.125, 0.5, 0.5, 0.03125], dtype=np.float32 if prec == _lib.C64 else np.float64)   # 4 distinct sizes
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
+    got = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("SSFM_SMALL", small)
+        p = _lib.Plan(n, 3, prec)
+        try:
+            p.set_linear_operator(D)
+            for rep in range(2):                                   # second run: cached tables, reused schedule buffer
+                p.set_field(a)
+                p.propagate_fixed(1.3, hs)
+            got[small] = p.get_field()
+            launches = p.last_propagate_ms()[1]
+        finally:
+            p.close()
+        single = n <= (8192 if prec == _lib.C64 else 4096)
+        assert launches == (1 if small == "1" and single else 1 + 2 * hs.size)
+    tol = 2e-6 if prec == _lib.C64 else 1e-12
+    assert relmax(got["1"], got["0"]) < tol
+    if prec == _lib.C128:
+        Dn = orc.linear_operator_c128(n, gv.dt, 0.2, -21.7, 0.13)
+        want = a.copy()
+        for h_ in hs:
+            N_hat = 1j * 1.3 * np.abs(want) ** 2
+            want = np.fft.ifft(np.fft.fft(want * np.exp(h_ / 2 * N_hat), axis=-1) * np.exp(Dn * h_), axis=-1) * np.exp(h_ / 2 * N_hat)
+        assert relmax(got["1"], want) < TOL_C128
+    else:
+        Dc = orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13)
+        want = a.copy()
+        for h_ in hs:
+            want = orc.ssfm_step_c64(want, Dc, np.float32(1.3), np.float32(h_))
+        assert relmax(got["1"], want) < TOL_100
+
+
+def test_operator_tables_of_one_schedule_do_not_evict_each_other():
+    """The table cache holds four step sizes per plan.  Schedules {a, b}, {c, d}, {a, e} in this order used to hand the third
+    run e's table for a's steps (round-robin victim = a's slot).  Both engines; against a fresh plan, bit for bit."""
+    gv(**workloads.BENCH_GV)
+    for n in (4096, 1 << 15):
+        rng = np.random.default_rng(n)
+        a = ((rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))) * 0.05).astype(np.complex64)
+        D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+        scheds = [np.array(v, np.float32) for v in ([0.5, 0.25, 0.5], [0.125, 0.0625, 0.125], [0.5, 1.0, 0.5, 1.0])]
+        p = _lib.Plan(n, 2, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            for hs in scheds:
+                p.set_field(a)
+                p.propagate_fixed(1.3, hs)
+            got = p.get_field()
+        finally:
+            p.close()
+        q = _lib.Plan(n, 2, _lib.C64)
+        try:
+            q.set_linear_operator(D)
+            q.set_field(a)
+            q.propagate_fixed(1.3, scheds[-1])
+            want = q.get_field()
+        finally:
+            q.close()
+        assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("waves", ["2", "4"])
 def test_sosfiltfilt_both_workgroup_shapes(waves, monkeypatch):
     """The filter kernels exist with 2 and with 4 wavefronts per workgroup and pick by the size of the call
