@@ -148,6 +148,40 @@ hipError_t launch_small(int n, int rows, hipStream_t s, const SmallArgs<T>& a) {
     return hipErrorInvalidValue;
 }
 
+// k_small_adapt: all rows of the plan in ONE workgroup (they share the step size); at most 512 threads, so that a thread
+// may use the whole register file
+template <typename T> constexpr bool small_adapt_supported(int n, int rows) {
+    return small_supported<T>(n) && n <= 4096 && rows >= 1 && rows <= 2 && rows * n / small_points<T>(n) <= 512;     // (8192 x 1: 14.8 us per step, chunked 12.7)
+}
+template <typename T, int N, int ROWS>
+hipError_t launch_small_adapt_nr(hipStream_t s, const SmallAdaptArgs<T>& a) {
+    constexpr int E = small_points<T>(N);
+    if constexpr (ROWS * N / E <= 512) {
+        constexpr size_t lds = (fft_nstages(N, E) > 1 ? (size_t)ROWS * row_lds_elems(N, E) * sizeof(cx<T>) : 0) + (size_t)fft_tw_lds_entries(N, E) * sizeof(cx<T>);
+        static hipError_t attr = allow_lds(k_small_adapt<T, N, E, ROWS>, lds);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL((k_small_adapt<T, N, E, ROWS>), dim3(1), dim3(ROWS * N / E), lds, s, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+template <typename T, int N>
+hipError_t launch_small_adapt_n(int rows, hipStream_t s, const SmallAdaptArgs<T>& a) {
+    return rows == 1 ? launch_small_adapt_nr<T, N, 1>(s, a) : launch_small_adapt_nr<T, N, 2>(s, a);
+}
+template <typename T>
+hipError_t launch_small_adapt(int n, int rows, hipStream_t s, const SmallAdaptArgs<T>& a) {
+    switch (n) {
+        case 256:  return launch_small_adapt_n<T, 256>(rows, s, a);
+        case 512:  return launch_small_adapt_n<T, 512>(rows, s, a);
+        case 1024: return launch_small_adapt_n<T, 1024>(rows, s, a);
+        case 2048: return launch_small_adapt_n<T, 2048>(rows, s, a);
+        case 4096: return launch_small_adapt_n<T, 4096>(rows, s, a);
+    }
+    return hipErrorInvalidValue;
+}
+
 // ----------------------------------------------------------------------------- plan
 struct PlanBase {
     int precision = 0;
@@ -181,6 +215,7 @@ template <typename T> struct PlanT : PlanBase {
     // single-launch engine of small plans (ssfm_kernels.hpp k_small): its own row twiddles and operator tables (another order)
     bool small = false;        // env SSFM_SMALL=0 turns it off
     cx<T>* tw_small = nullptr;
+    cx<T>* dsmall = nullptr;   // D~ in the one-line order (k_small_adapt)
     Tab stabs[kMaxTables] = {};
     int stab_rr = 0;
     T* d_hs = nullptr;         // the schedule on the device: step sizes, then one table index per step
@@ -375,6 +410,7 @@ template <typename T> struct PlanT : PlanBase {
         for (auto& t : tabs) (void)hipFree(t.ptr);
         for (auto& t : stabs) (void)hipFree(t.ptr);
         (void)hipFree(tw_small);
+        (void)hipFree(dsmall);
         (void)hipFree(d_hs);
         for (int g = 1; g < kMaxLanes; ++g) {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
@@ -481,7 +517,10 @@ template <typename T> struct PlanT : PlanBase {
         }
         small = small_supported<T>((int)n);
         if (const char* e = std::getenv("SSFM_SMALL")) small = small && std::atoi(e) != 0;
-        if (small) if (int rc = make_line_table(&tw_small, (int)n, small_points<T>((int)n))) return rc;
+        if (small) {
+            if (int rc = make_line_table(&tw_small, (int)n, small_points<T>((int)n))) return rc;
+            HIP_TRY(hipMalloc(&dsmall, cb * n));
+        }
         HIP_TRY(hipMalloc(&st, sizeof(AdaptState<T>)));
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
         HIP_TRY(hipGetLastError());
@@ -570,6 +609,9 @@ template <typename T> struct PlanT : PlanBase {
         if (dperm_fly)
             hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                                (const cx<T>*)dnat, dperm_fly, N1, N2, N2 / Ef_fly, (T)0, inv_n());
+        if (dsmall)
+            hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                               (const cx<T>*)dnat, dsmall, 1, (int)n, (int)n / small_points<T>((int)n), (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         // host buffer may be reused by the caller right after return
         HIP_TRY(hipStreamSynchronize(stream));
@@ -829,6 +871,9 @@ template <typename T> struct PlanT : PlanBase {
         int max_steps = 0;
         int step = 0;                  // index of the next step to launch
         StepState<T> now = {};         // state after the last launched step (host copy)
+        bool deferred = false;         // small plan without capture: nothing launched yet -- the first adaptive_run decides between
+        int single_step = 0;           // the single-launch kernel (budget covers the run) and the chunked engine
+        T phi_max = 0;
     } ar;
 
     int adaptive_begin(double gamma_d, double length, double phi_max, int single_step, int64_t max_steps, int capture) {
@@ -841,16 +886,29 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipMalloc(&zlog, sizeof(T) * (max_steps + 1)));
             zlog_cap = max_steps + 1;
         }
-        AdaptState<T> hs;
-        std::memset(&hs, 0, sizeof(hs));
-        hs.length = (T)length;
-        hs.phi_max = (T)phi_max;
-        hs.abs_gamma = gamma < 0 ? -gamma : gamma;
-        hs.adaptive = 1;
-        hs.max_steps = (int)max_steps;
         last_launches = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
-        HIP_TRY(hipMemcpyAsync(st, &hs, sizeof(hs), hipMemcpyHostToDevice, stream));
+        if (small && !capture && small_adapt_supported<T>((int)n, batch)) {
+            ar = AdaptRun();
+            ar.active = true; ar.deferred = true;
+            ar.gamma = gamma; ar.length = (T)length; ar.phi_max = (T)phi_max; ar.max_steps = (int)max_steps; ar.single_step = single_step;
+            return SSFM_OK;
+        }
+        return adaptive_begin_chunked(gamma, (T)length, (T)phi_max, single_step, (int)max_steps, capture);
+    }
+    AdaptState<T> adapt_host;          // staging copy of the run's parameters (a member: the copy below is asynchronous)
+    int upload_adapt_state(T gamma, T length, T phi_max, int max_steps) {
+        std::memset(&adapt_host, 0, sizeof(adapt_host));
+        adapt_host.length = length;
+        adapt_host.phi_max = phi_max;
+        adapt_host.abs_gamma = gamma < 0 ? -gamma : gamma;
+        adapt_host.adaptive = 1;
+        adapt_host.max_steps = max_steps;
+        HIP_TRY(hipMemcpyAsync(st, &adapt_host, sizeof(adapt_host), hipMemcpyHostToDevice, stream));
+        return SSFM_OK;
+    }
+    int adaptive_begin_chunked(T gamma, T length, T phi_max, int single_step, int max_steps, int capture) {
+        if (int rc = upload_adapt_state(gamma, length, phi_max, max_steps)) return rc;
         if (!single_step) {
             hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, (const cx<T>*)F, (long long)n * batch, st);
             ++last_launches;
@@ -862,7 +920,7 @@ template <typename T> struct PlanT : PlanBase {
         // (a run of a few dozen steps is then two or three chunks, not five: every look is a 25 us stall)
         StepState<T> first;
         HIP_TRY(hipMemcpyAsync(&first, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(first), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));             // (also: hs is a stack variable)
+        HIP_TRY(hipStreamSynchronize(stream));
         ar = AdaptRun();
         ar.now = first;
         ar.active = true;
@@ -882,6 +940,26 @@ template <typename T> struct PlanT : PlanBase {
         if (!ar.active) return fail(SSFM_ERR_STATE, "ssfm_adaptive_run: no adaptive run in progress");
         if (budget < 1) return fail(SSFM_ERR_INVALID, "ssfm_adaptive_run: budget=%lld", (long long)budget);
         if (int rc = use_device()) return rc;
+        if (ar.deferred) {
+            if (snapshots != nullptr) return fail(SSFM_ERR_STATE, "ssfm_adaptive_run: the run was not begun with capture");
+            const AdaptRun keep = ar;
+            if (budget >= (int64_t)keep.max_steps) {
+                // the whole run in one launch (k_small_adapt); the state and the z log are read once, here
+                if (int rc = upload_adapt_state(keep.gamma, keep.length, keep.phi_max, keep.max_steps)) return rc;
+                SmallAdaptArgs<T> sa;
+                sa.F = F; sa.D = dsmall; sa.tw = tw_small; sa.st = st; sa.zlog = zlog; sa.gamma = keep.gamma; sa.inv_n = inv_n(); sa.single_step = keep.single_step;
+                ++last_launches;
+                HIP_TRY(launch_small_adapt<T>((int)n, batch, stream, sa));
+                HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(ar.now), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                ar.deferred = false;
+                if (steps_total) *steps_total = ar.now.steps;
+                if (done) *done = ar.now.done;
+                return SSFM_OK;
+            }
+            // a budgeted caller: the chunked engine from the start
+            if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
+        }
         const int nrows = N1 * batch;
         const size_t fb = sizeof(cx<T>) * n * batch;
         char* snap = static_cast<char*>(snapshots);
@@ -927,6 +1005,10 @@ template <typename T> struct PlanT : PlanBase {
     int adaptive_finish(int64_t* steps_out, double* z_out) {
         if (!ar.active) return fail(SSFM_ERR_STATE, "ssfm_adaptive_finish: no adaptive run in progress");
         if (int rc = use_device()) return rc;
+        if (ar.deferred) {           // finished before any step was asked for: the chunked engine's begin leaves the same state behind
+            const AdaptRun keep = ar;
+            if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
+        }
         ar.active = false;
         if (ar.tile_private && ar.now.steps > 0) {
             HIP_TRY((launch_time<T, TM_UNPACK>(N1, batch, stream, targs(ar.gamma, 0, 0, nullptr), E)));      // Y buffer -> time-order field

@@ -915,6 +915,146 @@ __global__ __launch_bounds__(N / E) void k_small(const SmallArgs<T> a) {
     for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
 }
 
+// The adaptive run of a small plan (reference devices.py:1155-1161, 1172-1196 with h = None) in ONE launch: ROWS rows (the
+// polarisations of a signal share the step size: the maximum is taken over all of them) in one workgroup, D~ in registers
+// (exp(D~ h) formed per step as k_freq<FM_FLY> does), the step control of step_advance() between the inverse transform and
+// the rotation: |A|^2 is the same before and after a rotation, so the next step size is known before the phases are applied.
+template <typename T> struct SmallAdaptArgs {
+    cx<T>* F;                 // ROWS rows of N samples, time order, advanced in place
+    const cx<T>* D;           // D~ at freq_tab_pos(k, N / E)
+    const cx<T>* tw;
+    AdaptState<T>* st;        // length, phi_max, abs_gamma, adaptive, max_steps in; cur[0] = final state out
+    T* zlog;
+    T gamma;
+    T inv_n;
+    int single_step;
+};
+template <typename T, int N, int E, int ROWS>
+__global__ __launch_bounds__(ROWS * N / E) void k_small_adapt(const SmallAdaptArgs<T> a) {
+    constexpr int Q = N / E;
+    constexpr int NW = (ROWS * Q + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+    __shared__ unsigned long long wave_max[2][NW];
+    const int tid = threadIdx.x;
+    const int j = tid % Q;
+    const int rr = tid / Q;
+    cx<T>* __restrict__ Frow = a.F + (long long)rr * N;
+    using RI = RowIdx<row_pad_shift(E)>;
+    const RI idx{rr * row_lds_elems(N, E)};
+    cx<T> v[E];
+    cx<T> d[E];
+    cx<T> m[E];
+#pragma unroll
+    for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
+    {
+        typedef T m4_t __attribute__((ext_vector_type(4)));
+        const m4_t* __restrict__ D4 = reinterpret_cast<const m4_t*>(a.D) + j;
+#pragma unroll
+        for (int g = 0; g < E / 2; ++g) {
+            const m4_t q = D4[g * Q];
+            d[2 * g] = mk<T>(q.x, q.y);
+            d[2 * g + 1] = mk<T>(q.z, q.w);
+        }
+    }
+    LineTw<T, N, E> tw;
+    cx<T>* ldsT = lds + (fft_nstages(N, E) > 1 ? ROWS * row_lds_elems(N, E) : 0);
+    line_twiddles_issue<T, N, E>(tw, j, a.tw, ldsT, tid, ROWS * Q);
+    if (fft_tw_lds_entries(N, E) > 0) __syncthreads();
+    line_twiddles_fetch<T, N, E>(tw, j, ldsT);
+    bool flat = true;
+#pragma unroll
+    for (int t = 1; t < E; ++t) flat = flat && (d[t].x == d[0].x);
+    // max over the workgroup of a per-thread value (bit patterns of non-negative numbers are monotone)
+    int par = 0;
+    auto wg_max = [&](T x) -> unsigned long long {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const T other = __shfl_xor(x, o);
+            x = other > x ? other : x;
+        }
+        if ((tid & 63) == 0) wave_max[par][tid >> 6] = float_bits<T>(x);
+        __syncthreads();
+        unsigned long long mb = wave_max[par][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mb = wave_max[par][w] > mb ? wave_max[par][w] : mb;
+        par ^= 1;                    // the next reduction writes the other set: no second barrier
+        return mb;
+    };
+    const T half = (T)0.5;
+    T pold[E];
+    T phi[E];
+    StepState<T> S;
+    {   // first step size (k_absmax + k_step_control phase 0) and the first half rotation (k_time<TM_BEGIN>)
+        T pmax = (T)0;
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+            pold[t] = p;
+            pmax = p > pmax ? p : pmax;
+        }
+        const unsigned long long mb = wg_max(pmax);
+        T h;
+        if (a.single_step) h = a.st->length;
+        else h = a.st->phi_max / (a.st->abs_gamma * bits_float<T>(mb));
+        h = h < a.st->length ? h : a.st->length;
+        S.h = h; S.z = (T)0; S.steps = 0; S.done = !((T)0 < a.st->length);
+        if (tid == 0) a.zlog[0] = (T)0;
+        if (!S.done) {
+            const T hh = S.h * half;
+#pragma unroll
+            for (int t = 0; t < E; ++t) {
+                T ph = (T)0;
+                ph += hh * (a.gamma * pold[t]);
+                phi[t] = ph;
+            }
+            rotate_all<E>(v, phi);
+        }
+    }
+    while (!S.done) {
+        const T h = S.h;
+        fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+        {   // exp(D~ h)/N as k_freq<FM_FLY>
+            T ph[E], sn[E], cs[E];
+#pragma unroll
+            for (int t = 0; t < E; ++t) ph[t] = d[t].y * h;
+            sincos_all<E>(ph, sn, cs);
+            const T e0 = exp_acc<T>(d[0].x * h);
+#pragma unroll
+            for (int t = 0; t < E; ++t) {
+                const T e = flat ? e0 : exp_acc<T>(d[t].x * h);
+                m[t] = mk<T>((e * cs[t]) * a.inv_n, (e * sn[t]) * a.inv_n);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
+        fft_line<T, N, E, +1, 1, RI>(v, lds, 0, j, idx, tw);
+        T pnew[E];
+        T pmax = (T)0;
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+            pnew[t] = p;
+            pmax = p > pmax ? p : pmax;
+        }
+        const StepState<T> Sn = step_advance<T>(a.st, S, wg_max(pmax));
+        if (tid == 0) a.zlog[Sn.steps] = Sn.z;
+        const T hh_prev = h * half, hh_next = Sn.h * half;
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            T ph = hh_prev * (a.gamma * pold[t]);
+            if (!Sn.done) ph += hh_next * (a.gamma * pnew[t]);
+            pold[t] = pnew[t];
+            phi[t] = ph;
+        }
+        rotate_all<E>(v, phi);
+        S = Sn;
+    }
+#pragma unroll
+    for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
+    if (tid == 0) a.st->cur[0] = S;
+}
+
 // ------------------------------------------------------------------------------ tables
 // Factor tables of the inter-pass twiddles, tile by tile: out[(tile * R + r) * C + c] = W_N^(r mult n2(tile, c)), r < R
 // (twA: R = N1/E, mult = 1;  twB: R = E, mult = N1/E)
