@@ -691,7 +691,7 @@ template <typename T> struct PlanT : PlanBase {
     }
 
     // the whole schedule in one launch (k_small); `distinct` holds at most kMaxTables step sizes
-    int run_small(T gamma, const T* h, int64_t nsteps, const std::vector<T>& distinct) {
+    int run_small(T gamma, const T* h, int64_t nsteps, const std::vector<T>& distinct, cx<T>* dsnap = nullptr) {
         SmallArgs<T> a;
         std::memset(&a, 0, sizeof(a));
         if (int rc = tables_for(distinct, a.tab, true)) return rc;
@@ -711,7 +711,7 @@ template <typename T> struct PlanT : PlanBase {
             h_sched[hb + (size_t)s] = w;
         }
         HIP_TRY(hipMemcpyAsync(d_hs, h_sched.data(), need, hipMemcpyHostToDevice, stream));
-        a.F = F; a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb; a.tw = tw_small; a.gamma = gamma; a.nsteps = (int)nsteps;
+        a.F = F; a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb; a.tw = tw_small; a.snap = dsnap; a.gamma = gamma; a.nsteps = (int)nsteps;
         ++last_launches;
         HIP_TRY(launch_small<T>((int)n, batch, stream, a));
         return SSFM_OK;
@@ -738,7 +738,8 @@ template <typename T> struct PlanT : PlanBase {
         }
         const bool use_tables = distinct.size() <= (size_t)kMaxTables;
         std::vector<const cx<T>*> tabptr(distinct.size(), nullptr);
-        const bool go_small = small && use_tables && !profiling && snapshots == nullptr && nsteps <= 0x7fffffff;
+        const bool small_sched = small && use_tables && !profiling && nsteps <= 0x7fffffff;
+        const bool go_small = small_sched && snapshots == nullptr;
         if (use_tables && !go_small)
             if (int rc = tables_for(distinct, tabptr.data(), false)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
@@ -833,6 +834,21 @@ template <typename T> struct PlanT : PlanBase {
             int64_t block = (int64_t)std::min<size_t>((size_t)(nsteps + 1), std::max<size_t>(1, std::min<size_t>(free_b / 2, size_t(8) << 30) / fb));
             char* dsnap = nullptr;
             HIP_TRY(hipMalloc(&dsnap, fb * (size_t)block));
+            if (small_sched && block == nsteps + 1) {
+                // a small plan whose whole capture fits the device: the single launch writes every snapshot itself
+                hipError_t e = hipMemcpyAsync(dsnap, F, fb, hipMemcpyDeviceToDevice, stream);             // the input
+                int rc = e == hipSuccess ? run_small(gamma, h, nsteps, distinct, reinterpret_cast<cx<T>*>(dsnap)) : fail(SSFM_ERR_HIP, "snapshot copy failed: %s", hipGetErrorString(e));
+                if (rc == SSFM_OK) {
+                    e = hipMemcpyAsync(snap, dsnap, fb * (size_t)(nsteps + 1), hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                    if (e != hipSuccess) rc = fail(SSFM_ERR_HIP, "snapshot download failed: %s", hipGetErrorString(e));
+                }
+                (void)hipFree(dsnap);
+                if (rc != SSFM_OK) return rc;
+                HIP_TRY(hipEventRecord(ev1, stream));
+                timed = true;
+                return SSFM_OK;
+            }
             auto flush = [&](int64_t first, int64_t count) -> int {
                 hipError_t e = hipMemcpyAsync(snap + fb * first, dsnap, fb * (size_t)count, hipMemcpyDeviceToHost, stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(stream);

@@ -846,6 +846,7 @@ template <typename T> struct SmallArgs {
     const T* hs;                       // the schedule: nsteps step sizes [km]
     const unsigned char* which;        // per step: its table
     const cx<T>* tw;                   // stage twiddles of the N-point line (make_line_table(N, E))
+    cx<T>* snap;                       // z-resolved capture (devices.py:1184-1186): the field after step s at snap + (s + 1) * rows * N, or NULL
     T gamma;
     int nsteps;
 };
@@ -905,11 +906,26 @@ __global__ __launch_bounds__(N / E) void k_small(const SmallArgs<T> a) {
         for (int t = 0; t < E; ++t) {
             const T p = v[t].x * v[t].x + v[t].y * v[t].y;
             T ph = hh_prev * (a.gamma * pold[t]);
-            if (more) ph += hh_next * (a.gamma * p);
+            if (more && a.snap == nullptr) ph += hh_next * (a.gamma * p);
             pold[t] = p;
             phi[t] = ph;
         }
         rotate_all<E>(v, phi);
+        if (a.snap != nullptr) {
+            // a capture needs the field BETWEEN the two half rotations (k_time<TM_END>, then <TM_BEGIN>, as the two-kernel engine does)
+            cx<T>* __restrict__ srow = a.snap + ((long long)(s + 1) * gridDim.x + blockIdx.x) * N;
+#pragma unroll
+            for (int t = 0; t < E; ++t) srow[j + t * Q] = v[t];
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < E; ++t) {
+                    T ph = (T)0;
+                    ph += hh_next * (a.gamma * pold[t]);
+                    phi[t] = ph;
+                }
+                rotate_all<E>(v, phi);
+            }
+        }
     }
 #pragma unroll
     for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];

@@ -584,6 +584,37 @@ def test_single_launch_adaptive_run_against_the_chunked_engine(log2n, rows, prec
         assert relmax(f1, ref) < 1e-7
 
 
+@pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
+def test_single_launch_capture_against_the_two_kernel_engine(prec, monkeypatch):
+    """return_steps on a small plan: the single launch writes the field after every step between its two half rotations
+    (what k_time<END> hands to the capture of the two-kernel engine)."""
+    n = 2048
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=5, power_w=5e-3)
+    hs = np.array([0.5, 0.5, 0.25, 0.5, 0.125, 0.5, 0.5], dtype=np.float32 if prec == _lib.C64 else np.float64)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
+    got = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("SSFM_SMALL", small)
+        p = _lib.Plan(n, 2, prec)
+        try:
+            p.set_linear_operator(D)
+            p.set_field(a)
+            snaps = p.propagate_fixed(1.3, hs, snapshots=True)
+            got[small] = (np.array(snaps), p.get_field(), p.last_propagate_ms()[1])
+        finally:
+            p.close()
+    s1, f1, l1 = got["1"]
+    s0, f0, l0 = got["0"]
+    assert l1 == 1 and l0 > hs.size and s1.shape == (hs.size + 1, 2, n) == s0.shape
+    np.testing.assert_array_equal(s1[0], a.astype(s1.dtype))
+    np.testing.assert_array_equal(s1[-1], f1)
+    tol = 2e-6 if prec == _lib.C64 else 1e-12
+    for k in range(1, hs.size + 1):
+        assert relmax(s1[k], s0[k]) < tol
+    assert relmax(f1, f0) < tol
+
+
 def test_operator_tables_of_one_schedule_do_not_evict_each_other():
     """The table cache holds four step sizes per plan.  Schedules {a, b}, {c, d}, {a, e} in this order used to hand the third
     run e's table for a's steps (round-robin victim = a's slot).  Both engines; against a fresh plan, bit for bit."""

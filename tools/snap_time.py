@@ -4,7 +4,7 @@ import opticomlib_amd as oa
 from opticomlib_amd import workloads
 from opticomlib_amd.typing import gv, optical_signal
 gv(**workloads.BENCH_GV)
-for k, steps in ((14, 400), (16, 200), (20, 20)):
+for k, steps in ((10, 1000), (12, 1000), (14, 400), (16, 200), (20, 20)):
     a = workloads.qpsk_field(1 << k, seed=1)
     x = optical_signal(a)
     kw = dict(length=steps * 0.5, h=0.5, **workloads.SMF)
