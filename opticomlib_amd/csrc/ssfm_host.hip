@@ -47,7 +47,8 @@ template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = cols_per_tile<T>();
     constexpr bool U16 = u16_layout<T>(N1, C, E);          // the field layout between the kernels (ssfm_kernels.hpp "U16")
-    if constexpr (!U16 && MODE > TM_END) return hipErrorInvalidValue;      // (tile-private time-domain modes: U16 plans only)
+    if constexpr (!U16 && MODE > TM_END && MODE != TM_MID_A) return hipErrorInvalidValue;      // (tile-private time-domain modes: U16 plans only)
+    else if constexpr (MODE == TM_MID_A && N1 != 128 && N1 != 256) return hipErrorInvalidValue;   // (the fused adaptive kernel: plans of 2^14 ... 2^18 samples)
     else {
     constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                          + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
@@ -216,6 +217,8 @@ template <typename T> struct PlanT : PlanBase {
     bool small = false;        // env SSFM_SMALL=0 turns it off
     cx<T>* tw_small = nullptr;
     cx<T>* dsmall = nullptr;   // D~ in the one-line order (k_small_adapt)
+    bool fused_ok = true;      // TM_MID_A may be used (env SSFM_ADAPT_FUSED=0, or a grid that once did not run as a whole, clears it)
+    cx<T>* fused_backup = nullptr;   // the input of a fused adaptive run, for the fall-back
     Tab stabs[kMaxTables] = {};
     int stab_rr = 0;
     T* d_hs = nullptr;         // the schedule on the device: step sizes, then one table index per step
@@ -411,6 +414,7 @@ template <typename T> struct PlanT : PlanBase {
         for (auto& t : stabs) (void)hipFree(t.ptr);
         (void)hipFree(tw_small);
         (void)hipFree(dsmall);
+        (void)hipFree(fused_backup);
         (void)hipFree(d_hs);
         for (int g = 1; g < kMaxLanes; ++g) {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
@@ -515,6 +519,7 @@ template <typename T> struct PlanT : PlanBase {
             if (int rc = make_line_table(&tw2_fly, N2, Ef_fly)) return rc;
             HIP_TRY(hipMalloc(&dperm_fly, cb * n));
         }
+        if (const char* e = std::getenv("SSFM_ADAPT_FUSED")) fused_ok = std::atoi(e) != 0;
         small = small_supported<T>((int)n);
         if (const char* e = std::getenv("SSFM_SMALL")) small = small && std::atoi(e) != 0;
         if (small) {
@@ -887,6 +892,7 @@ template <typename T> struct PlanT : PlanBase {
         int max_steps = 0;
         int step = 0;                  // index of the next step to launch
         StepState<T> now = {};         // state after the last launched step (host copy)
+        bool fused = false;            // column kernel of at most 128 workgroups, no capture: END + BEGIN in one launch (TM_MID_A)
         bool deferred = false;         // small plan without capture: nothing launched yet -- the first adaptive_run decides between
         int single_step = 0;           // the single-launch kernel (budget covers the run) and the chunked engine
         T phi_max = 0;
@@ -920,6 +926,8 @@ template <typename T> struct PlanT : PlanBase {
         adapt_host.abs_gamma = gamma < 0 ? -gamma : gamma;
         adapt_host.adaptive = 1;
         adapt_host.max_steps = max_steps;
+        adapt_host.patience = 2000000ll;
+        if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) adapt_host.patience = std::atoll(e);
         HIP_TRY(hipMemcpyAsync(st, &adapt_host, sizeof(adapt_host), hipMemcpyHostToDevice, stream));
         return SSFM_OK;
     }
@@ -946,7 +954,17 @@ template <typename T> struct PlanT : PlanBase {
         // U16 plans keep the time-domain field between END and the next BEGIN in the Y buffer, in tile-private 16-byte
         // units (ssfm_kernels.hpp TM_END_Y / TM_BEGIN_Y); a z-resolved capture needs the time-order field after every
         // step and uses the plain modes
-        ar.tile_private = u16 && !capture;
+        ar.phi_max = phi_max;
+        ar.single_step = single_step;
+        // a column kernel of at most 64 workgroups (measured: a gain up to there, profiles/r02_medium_adaptive.txt) waits for the global maximum inside the launch (TM_MID_A); the input is kept
+        // for the case that the GPU does not run the grid as a whole (then: the three-launch engine, for good)
+        ar.fused = fused_ok && !capture && (N1 == 128 || N1 == 256) && (long long)(N2 / cols_per_tile<T>()) * batch <= 64;
+        if (ar.fused) {
+            const size_t fb = sizeof(cx<T>) * n * batch;
+            if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
+            HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));
+        }
+        ar.tile_private = u16 && !capture && !ar.fused;
         return SSFM_OK;
     }
 
@@ -976,6 +994,12 @@ template <typename T> struct PlanT : PlanBase {
             // a budgeted caller: the chunked engine from the start
             if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
         }
+        if (ar.fused && ar.step == 0 && budget < (int64_t)ar.max_steps) {
+            // a caller that takes the run in pieces may stop between two of them: it gets the engine that leaves a time-order
+            // field after every step
+            ar.fused = false;
+            ar.tile_private = u16;
+        }
         const int nrows = N1 * batch;
         const size_t fb = sizeof(cx<T>) * n * batch;
         char* snap = static_cast<char*>(snapshots);
@@ -993,22 +1017,39 @@ template <typename T> struct PlanT : PlanBase {
                 TimeArgs<T> tb = targs(ar.gamma, 0, 0, st), te = tb;
                 tb.step = te.step = ar.step;
                 tb.derive = i != 0;         // the first BEGIN of a chunk finds its state in cur[] (k_step_control wrote it)
-                if (ar.tile_private && ar.step > 0) HIP_TRY((launch_time<T, TM_BEGIN_Y>(N1, batch, stream, tb, E)));
+                if (ar.fused) {
+                    // BEGIN once; then FREQ + MID_A per step (MID_A(s) leaves the state of step s + 1 in cur[(s + 1) & 1])
+                    if (ar.step == 0) { tb.derive = 0; HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E))); ++last_launches; }
+                } else if (ar.tile_private && ar.step > 0) HIP_TRY((launch_time<T, TM_BEGIN_Y>(N1, batch, stream, tb, E)));
                 else HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E)));
                 FreqArgs<T> fa = fargs_fly(0, st);
                 fa.step = ar.step;
                 HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fa, Ef_fly)));
-                if (ar.tile_private) HIP_TRY((launch_time<T, TM_END_Y>(N1, batch, stream, te, E)));
+                if (ar.fused) HIP_TRY((launch_time<T, TM_MID_A>(N1, batch, stream, te, E)));
+                else if (ar.tile_private) HIP_TRY((launch_time<T, TM_END_Y>(N1, batch, stream, te, E)));
                 else HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, te, E)));
-                last_launches += 3;
+                last_launches += ar.fused ? 2 : 3;
             }
             // the state after the last launched step, for the host (and for the first BEGIN of the next chunk)
-            hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 1, 0, ar.step);
-            ++last_launches;
+            if (!ar.fused) {
+                hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 1, 0, ar.step);
+                ++last_launches;
+            }
             const int before = ar.now.steps;
+            unsigned gave_up = 0;
             HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur) + sizeof(StepState<T>) * (ar.step & 1),
                                    sizeof(ar.now), hipMemcpyDeviceToHost, stream));
+            if (ar.fused) HIP_TRY(hipMemcpyAsync(&gave_up, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(gave_up), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            if (ar.fused && gave_up) {
+                // the grid did not run as a whole (another job holds CUs): the same run again on the three-launch engine
+                const AdaptRun keep = ar;
+                fused_ok = false;
+                HIP_TRY(hipMemcpyAsync(F, fused_backup, fb, hipMemcpyDeviceToDevice, stream));
+                if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
+                chunk = estimate();
+                continue;
+            }
             if (snap && ar.now.steps == before + 1)          // (chunk = 1: the step just launched was really taken)
                 if (int rc = copy_field_out(snap + fb * (size_t)(before - first_step), false, true)) return rc;
             if (!snap && !ar.now.done) chunk = estimate();       // do not queue far beyond the end

@@ -74,9 +74,12 @@ namespace ssfm {
 // runs): the same, but the time-domain field between END and the next BEGIN stays in the Y buffer in the tile-private
 // 16-byte-unit order (only the same tile reads it back; write-through stores, non-temporal loads) instead of going
 // through time order with 8-byte accesses; UNPACK turns that buffer into the time-order field at the end of the run.
-enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2, TM_BEGIN_Y = 3, TM_END_Y = 4, TM_UNPACK = 5 };
-__host__ __device__ constexpr bool tm_inverse(int m) { return m == TM_MID || m == TM_END || m == TM_END_Y; }     // starts in the half-transformed domain
-__host__ __device__ constexpr bool tm_forward(int m) { return m == TM_BEGIN || m == TM_MID || m == TM_BEGIN_Y; } // ends in it
+// TM_MID_A: the MID of an ADAPTIVE run of a plan whose column kernel is at most 128 workgroups (2^14 ... 2^18 samples): END and
+// the next BEGIN in one launch, the workgroups waiting INSIDE the kernel for the global max |A|^2 (a grid barrier over that few
+// workgroups costs 1-2 us, profiles/r02_barrier_probe.txt; the third launch it replaces 3.5 us).
+enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2, TM_BEGIN_Y = 3, TM_END_Y = 4, TM_UNPACK = 5, TM_MID_A = 6 };
+__host__ __device__ constexpr bool tm_inverse(int m) { return m == TM_MID || m == TM_END || m == TM_END_Y || m == TM_MID_A; }     // starts in the half-transformed domain
+__host__ __device__ constexpr bool tm_forward(int m) { return m == TM_BEGIN || m == TM_MID || m == TM_BEGIN_Y || m == TM_MID_A; } // ends in it
 __host__ __device__ constexpr bool tm_ends(int m) { return m == TM_END || m == TM_END_Y; }
 
 // Device-resident step control of the adaptive mode (reference devices.py:1155-1161,1193-1196).
@@ -106,6 +109,9 @@ template <typename T> struct AdaptState {
     int pad_;
     StepState<T> cur[2];
     unsigned long long slots[2][kAdaptSlots];      // bit patterns of max |A|^2 (non-negative => monotone as integers)
+    unsigned arrive[2];     // TM_MID_A: workgroups that have delivered their maximum for the step of this parity
+    unsigned error;         // TM_MID_A: a workgroup gave up waiting (the GPU did not run the whole grid at once): the host falls back
+    long long patience;     // TM_MID_A: ticks of the 100 MHz clock a workgroup waits for the others (20 ms; tests set 0)
 };
 
 // Block id -> (unit, row) so that the `rows` blocks working on the same unit (column tile / spectrum
@@ -475,22 +481,9 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
     constexpr bool INV = tm_inverse(MODE), FWD = tm_forward(MODE);
-    static_assert(U16 || MODE <= TM_END, "the tile-private time-domain modes exist for the U16 layout only");
+    static_assert(U16 || MODE <= TM_END || MODE == TM_MID_A, "the tile-private time-domain modes exist for the U16 layout only");
     T hh_prev = a.hh_prev, hh_next = a.hh_next;
     const int tid = threadIdx.x;
-    if (a.st != nullptr && MODE != TM_UNPACK) {
-        const StepState<T> S = step_state<T>(a.st, a.step, FWD && a.derive != 0);
-        if (FWD && blockIdx.x == 0 && tid == 0) {
-            // workgroup 0 records the state of this step (BEGIN is the first kernel of a step) and empties the slots its END fills
-            if (a.derive) {
-                a.st->cur[a.step & 1] = S;
-                if (!a.st->cur[(a.step - 1) & 1].done) a.zlog[S.steps] = S.z;
-            }
-        }
-        if (FWD && blockIdx.x == 0 && tid < kAdaptSlots) a.st->slots[a.step & 1][tid] = 0ull;
-        if (S.done) return;
-        hh_prev = hh_next = S.h * (T)0.5;
-    }
     SSFM_TRACE_BEGIN(a);
     // plain: thread = j * C + c.  U16: lane = h * 32 + (j mod 4) * 8 + c8, column c = h * 8 + c8 (see "U16" above)
     const int c = U16 ? (((tid >> 5) & 1) << 3) | (tid & 7) : tid % C;
@@ -566,6 +559,31 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     }
+    // The step control state (adaptive runs) is read HERE, after every global load of the tile has been issued: it was written
+    // by the previous launch, so its load is a miss of ~2 us that would otherwise stand in front of the whole kernel.  (A launch
+    // queued beyond the end of the run returns now; its loads went to registers only.)
+    StepState<T> S_this = {};            // TM_MID_A: the state of the step this launch finishes
+    if constexpr (MODE == TM_MID_A) {
+        S_this = a.st->cur[a.step & 1];
+        if (S_this.done) {
+            // a launch queued beyond the end of the run: hand the final state on (the host reads cur[] of the LAST launched step)
+            if (blockIdx.x == 0 && tid == 0) a.st->cur[(a.step + 1) & 1] = S_this;
+            return;
+        }
+        hh_prev = S_this.h * (T)0.5;
+    } else if (a.st != nullptr && MODE != TM_UNPACK) {
+        const StepState<T> S = step_state<T>(a.st, a.step, FWD && a.derive != 0);
+        if (FWD && blockIdx.x == 0 && tid == 0) {
+            // workgroup 0 records the state of this step (BEGIN is the first kernel of a step) and empties the slots its END fills
+            if (a.derive) {
+                a.st->cur[a.step & 1] = S;
+                if (!a.st->cur[(a.step - 1) & 1].done) a.zlog[S.steps] = S.z;
+            }
+        }
+        if (FWD && blockIdx.x == 0 && tid < kAdaptSlots) a.st->slots[a.step & 1][tid] = 0ull;
+        if (S.done) return;
+        hh_prev = hh_next = S.h * (T)0.5;
+    }
     cx<T>* ldsT = Bs + (TWC ? E * C : 0);
     if constexpr (MODE != TM_UNPACK) {
         line_twiddles_issue<T, N1, E>(tw, j, a.tw1, ldsT, tid, N1 * C / E);
@@ -606,6 +624,75 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     T pmax = (T)0;
     T phi[E];
     T pnew[E];
+    bool fwd_active = true;               // TM_MID_A: false when this step ends the run
+    if constexpr (MODE == TM_MID_A) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            pnew[t] = v[t].x * v[t].x + v[t].y * v[t].y;
+            pmax = pnew[t] > pmax ? pnew[t] : pmax;
+        }
+        // ---- the step control, inside the launch: every workgroup delivers its maximum, waits until all have, and replays
+        // step_advance() on the same 64 slots (the same float operations: the same bits in every workgroup)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const T other = __shfl_xor(pmax, o);
+            pmax = other > pmax ? other : pmax;
+        }
+        __shared__ T wave_max_a[16];
+        __shared__ StepState<T> s_next;
+        __shared__ int s_ok;
+        constexpr int NWAVES_A = (N1 * C / E + 63) / 64;
+        if ((tid & 63) == 0) wave_max_a[tid >> 6] = pmax;
+        __syncthreads();
+        if (tid < 64) {
+            const int set = a.step & 1;
+            int good = 0;
+            if (tid == 0) {
+                T m = wave_max_a[0];
+#pragma unroll
+                for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
+                atomicMax(&a.st->slots[set][blockIdx.x % kAdaptSlots], float_bits<T>(m));
+                __hip_atomic_fetch_add(&a.st->arrive[set], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const long long t0 = wall_clock64();                  // 100 MHz
+                for (;;) {
+                    if (__hip_atomic_load(&a.st->arrive[set], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { good = 1; break; }
+                    if (wall_clock64() - t0 > a.st->patience) break;  // (20 ms) the grid is not running as a whole -- give up, never hang
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            good = __shfl(good, 0);
+            unsigned long long mb = 0ull;
+            if (good) {
+                mb = __hip_atomic_load(&a.st->slots[set][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(mb, o);
+                    mb = other > mb ? other : mb;
+                }
+            }
+            if (tid == 0) {
+                s_ok = good;
+                if (good) s_next = step_advance<T>(a.st, S_this, mb);
+                else atomicExch(&a.st->error, 1u);
+            }
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        const StepState<T> Sn = s_next;
+        if (blockIdx.x == 0) {
+            // workgroup 0 records the state of the next step and empties what the next step's launch will fill
+            if (tid == 0) { a.st->cur[(a.step + 1) & 1] = Sn; a.zlog[Sn.steps] = Sn.z; a.st->arrive[(a.step + 1) & 1] = 0u; }
+            if (tid < kAdaptSlots) a.st->slots[(a.step + 1) & 1][tid] = 0ull;
+        }
+        fwd_active = !Sn.done;
+        hh_next = Sn.h * (T)0.5;
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            T ph = hh_prev * (a.gamma * pold[t]);
+            if (fwd_active) ph += hh_next * (a.gamma * pnew[t]);
+            phi[t] = ph;
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < E; ++t) {
         const T p = v[t].x * v[t].x + v[t].y * v[t].y;
@@ -615,6 +702,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         pnew[t] = p;
         phi[t] = ph;
         pmax = p > pmax ? p : pmax;
+    }
     }
     if (FWD && !SSFM_ABL_NO_P) {
 #pragma unroll
@@ -635,6 +723,14 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     else {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t].x += phi[t];
+    }
+    if constexpr (MODE == TM_MID_A) {
+        if (!fwd_active) {
+            // the run ends with this step: time-order field, as k_time<TM_END> leaves it
+#pragma unroll
+            for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
+            return;
+        }
     }
     if (tm_ends(MODE)) {
         if (MODE == TM_END) {
@@ -674,7 +770,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     }
     // exchanges alternate between two LDS buffers; the forward transform continues the count
     constexpr int NX = fft_nstages(N1, E) - 1;      // exchanges of the inverse transform
-    constexpr int XP_FWD = (MODE != TM_MID || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
+    constexpr int XP_FWD = ((MODE != TM_MID && MODE != TM_MID_A) || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
     if (U16) {
 #pragma unroll
@@ -724,11 +820,6 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
     T h = a.h;
-    if (MODE == FM_FLY && a.st != nullptr) {
-        const StepState<T> S = a.st->cur[a.step & 1];
-        if (S.done) return;
-        h = S.h;
-    }
     SSFM_TRACE_BEGIN(a);
     const int tid = threadIdx.x;
     const int j = tid % Q;
@@ -772,6 +863,12 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
             m[2 * g] = mk<T>(q.x, q.y);
             m[2 * g + 1] = mk<T>(q.z, q.w);
         }
+    }
+    if (MODE == FM_FLY && a.st != nullptr) {
+        // (read after the row and the operator have been asked for: the state was written by the previous launch, a ~2 us miss)
+        const StepState<T> S = a.st->cur[a.step & 1];
+        if (S.done) return;
+        h = S.h;
     }
     SSFM_STAMP(1);
 #if SSFM_STAMPS

@@ -615,6 +615,74 @@ def test_single_launch_capture_against_the_two_kernel_engine(prec, monkeypatch):
     assert relmax(f1, f0) < tol
 
 
+@pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
+@pytest.mark.parametrize("log2n, rows", [(14, 1), (14, 2), (15, 2), (16, 2), (17, 1)])
+def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, rows, prec, monkeypatch):
+    """Plans of 2^14 ... 2^18 samples finish a step and begin the next in ONE launch of the column kernel (TM_MID_A: the
+    workgroups wait inside the kernel for the global max |A|^2); SSFM_ADAPT_FUSED=0 at plan creation keeps END and BEGIN apart.
+    Same step rule on the same maxima: identical z logs; the fields differ by the rounding of one merged rotation per step."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=60 + log2n, power_w=10e-3)[:rows]
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SSFM_ADAPT_FUSED", fused)
+        p = _lib.Plan(n, rows, prec)
+        try:
+            p.set_linear_operator(D)
+            for rep in range(2):
+                p.set_field(a)
+                steps, z, _ = p.propagate_adaptive(1.3, 4.0, 0.002, False)
+            res[fused] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
+        finally:
+            p.close()
+    s1, z1, f1, l1 = res["1"]
+    s0, z0, f0, l0 = res["0"]
+    assert s1 > 10 and abs(z1[-1] - 4.0) < 1e-5
+    assert l1 < l0 and l1 <= 2 * s1 + 40 and l0 >= 3 * s0           # two launches per step instead of three
+    assert abs(s1 - s0) <= 1
+    k = min(s1, s0, 12)
+    np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6 if prec == _lib.C64 else 1e-12)
+    assert relmax(f1, f0) < (5 * TOL_100 if prec == _lib.C64 else 1e-9)
+    if log2n <= 15:
+        if prec == _lib.C128:
+            ref = orc.fiber_c128(a if rows > 1 else a[0], gv.dt, 4.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.002)
+            assert relmax(f1, ref) < 1e-7
+        else:
+            ref = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 4.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.002)
+            assert relmax(f1, ref) < TOL_1000
+
+
+def test_fused_adaptive_kernel_gives_up_and_the_run_falls_back(monkeypatch):
+    """A workgroup of the fused kernel never waits longer than its patience for the others (a GPU shared with another job
+    may not run the whole grid at once).  With no patience at all some workgroups give up: the plan restores the input, runs
+    the three-launch engine instead -- bit for bit its result -- and keeps to it."""
+    n = 1 << 15
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=3, power_w=10e-3)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    monkeypatch.setenv("SSFM_ADAPT_FUSED", "0")
+    q = _lib.Plan(n, 2, _lib.C64)
+    try:
+        q.set_linear_operator(D); q.set_field(a)
+        s0, z0, _ = q.propagate_adaptive(1.3, 4.0, 0.002, False)
+        f0 = q.get_field()
+    finally:
+        q.close()
+    monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
+    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
+    p = _lib.Plan(n, 2, _lib.C64)
+    try:
+        p.set_linear_operator(D)
+        for rep in range(2):                       # the second run starts on the three-launch engine
+            p.set_field(a)
+            s1, z1, _ = p.propagate_adaptive(1.3, 4.0, 0.002, False)
+            assert s1 == s0 and np.array_equal(z1, z0) and np.array_equal(p.get_field(), f0)
+    finally:
+        p.close()
+
+
 def test_operator_tables_of_one_schedule_do_not_evict_each_other():
     """The table cache holds four step sizes per plan.  Schedules {a, b}, {c, d}, {a, e} in this order used to hand the third
     run e's table for a's steps (round-robin victim = a's slot).  Both engines; against a fresh plan, bit for bit."""
