@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- SSFM sample*steps/s on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|c2|c3|c4]
 
-One bench "step" = one complete propagation of the workload: configuration C2 of SURVEY.md 8
-(2^20-sample dual-polarisation complex64 field, FIBER(length=125 km, h=0.125 km) = exactly 1000
-SSFM steps; QPSK-like 32 GBd, 16 samples/symbol, 0 dBm/pol; alpha 0.2 dB/km, beta_2 -21.7 ps^2/km,
-beta_3 0.13 ps^3/km, gamma 1.3 /(W km)).  The field is resident in HBM when the timed region
-starts; each timed step restores the input with a device-to-device copy (16 MiB, ~1e-3 of a
-step) so that every step propagates the same physical signal instead of an ever weaker one.
+One bench "step" = one complete pass of the workload over its synthetic input, resident in HBM when the timed region
+starts (each timed step restores the input with a device-to-device copy, ~1e-3 of a step, so that every step propagates
+the same physical signal instead of an ever weaker one).
 
-N > 1: configuration C3 of BASELINE.json -- 8 independent 2^20 x 2 fields (WDM channels, seeds 3000..3007), unit i
-on rank i % N, each rank's 8/N fields batched in ONE plan; the path shards with no data-path collective
-("scaling": "strong": the 8 fields are the whole job).  After the timed region the propagated fields (16 MiB each)
-are gathered to rank 0 in GPU memory over RCCL (opticomlib_amd.dist.gather_device) and that is timed separately
-(`gather_ms`).  `--workload c3` runs the same 8-field job on one GPU (the N = 1 point of that curve).
+  auto / c2   configuration C2 of SURVEY.md 8 on EVERY GPU: a 2^20-sample dual-polarisation complex64 field,
+              FIBER(length=125 km, h=0.125 km) = exactly 1000 SSFM steps; QPSK-like 32 GBd, 16 samples/symbol, 0 dBm/pol;
+              alpha 0.2 dB/km, beta_2 -21.7 ps^2/km, beta_3 0.13 ps^3/km, gamma 1.3 /(W km).  N = 1: seed 2024 (the headline
+              line).  N > 1: one such field per rank, seeds 3000 + rank -- independent WDM channels, "scaling": "weak"; at
+              N = 8 this IS configuration C3 (8 channels, one per GPU).
+  c3          configuration C3 as a fixed job: 8 channels (seeds 3000..3007), unit i on rank i % N, a rank's channels batched in
+              ONE plan ("scaling": "strong").
+  c4          configuration C4: 64 Monte-Carlo PRBS realisations (LFSR seeds 1..64, generated ON the device), FIBER(100 x 1 km)
+              then DBP(100 x 1 km) back to back in GPU memory, unit i on rank i % N, 8 realisations resident at a time.
 
-Prints ONE JSON line on rank 0.
+The path shards over independent fields: NO collective inside the timed region.  With a process group the propagated
+fields are then gathered to rank 0 in GPU memory by ONE RCCL collective on the plans' field buffers
+(opticomlib_amd.dist.gather_device), timed separately as `gather_ms`.
+
+Launching.  `--gpus N` with N > 1 (or `--workload c3|c4` at any N, so that the RCCL gather really runs) and no RANK in the
+environment: this process -- BEFORE it imports torch or touches a GPU -- starts
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>
+as a child, lets the child's rank 0 print the JSON line on the inherited stdout and exits with the child's code.  Under
+torch.distributed.run itself (RANK set) it is one of the ranks.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -28,8 +35,6 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -38,12 +43,46 @@ N_POL = 2
 SSFM_STEPS = 1000
 LENGTH_KM, H_KM = 125.0, 0.125          # exactly 1000 float32 steps
 C3_FIELDS = 8                           # configuration C3: 8 independent WDM channels
+C4_SEEDS = 64                           # configuration C4: 64 PRBS realisations, FIBER + DBP
+C4_LENGTH_KM, C4_H_KM = 100.0, 1.0      # 100 steps each way
+C4_RESIDENT = 8                         # realisations propagated together in one plan
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md chip table (spec)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=48, help="SSFM steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-kernel HIP-event passes")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C1 (complex128) figure reported beside the headline")
+    ap.add_argument("--cpu-manycore", type=int, default=0, help="also time the tidied CPU variant on this many processes (0 = skip)")
+    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4"], default="auto")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """Start the ranks as a fresh child (nothing in THIS process has touched a GPU, torch is not even imported) and
+    hand on its exit code.  The child's rank 0 writes the JSON line to the stdout it inherits."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(a, dt, fibre, sample_steps):
     """The oracle (NumPy restatement of the reference, single thread like the reference) timed on
     a bounded sample of the SAME workload: `sample_steps` SSFM steps of the 2^20 x 2 field."""
+    import numpy as np
     from oracle import ssfm_numpy as orc
     t = time.perf_counter()
     orc.fiber_c64(a, dt, length=LENGTH_KM, h=H_KM, max_steps=sample_steps, **fibre)
@@ -88,6 +127,7 @@ def secondary_c1(a, dt, fibre, device):
 def _manycore_worker(job):
     seed, dt, fibre, steps = job
     os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import numpy as np
     from opticomlib_amd import workloads
     from oracle import ssfm_numpy as orc
     a = workloads.qpsk_field(1 << LOG2N, seed=seed).astype(np.complex64)
@@ -112,17 +152,51 @@ def cpu_baseline_manycore(dt, fibre, procs, sample_steps):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=48, help="SSFM steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-kernel HIP-event pass")
-    ap.add_argument("--cpu-manycore", type=int, default=0, help="also time the tidied CPU variant on this many processes (0 = skip)")
-    ap.add_argument("--workload", choices=["auto", "c2", "c3"], default="auto", help="auto: C2 (one field) on 1 GPU, C3 (8 fields sharded) on more")
-    args = ap.parse_args()
+def committed_profile_figures(kernels, rows_per_launch):
+    """Figures that cannot be taken inside a bench run (rocprofv3 is a separate process; PMC counters need their own
+    passes): read from the newest committed summaries under profiles/ and reported under `from_profiles`, apart from
+    what this run measured."""
+    out = {}
+    for stats_name in ("r03_final_kernel_stats.csv", "r02_final_kernel_stats.csv"):
+        stats = os.path.join(ROOT, "profiles", stats_name)
+        if not os.path.exists(stats):
+            continue
+        try:
+            import csv
+            acc = {}
+            for row in csv.DictReader(open(stats)):
+                for k in kernels:
+                    if k + "<float" in row["Name"]:          # the C2 kernels (the file may also hold C1's complex128 ones)
+                        c, tns = acc.get(k, (0, 0.0))
+                        acc[k] = (c + int(row["Calls"]), tns + float(row["TotalDurationNs"]))
+            out["rocprof_kernel_us"] = {k: tns / c / 1e3 for k, (c, tns) in acc.items() if c}
+            out["rocprof_source"] = f"profiles/{stats_name} (rocprofv3 --kernel-trace --stats of this command: kernel begin->end, no launch gap)"
+        except Exception:
+            pass
+        break
+    for pmc_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
+        if not os.path.exists(pmc):
+            continue
+        try:
+            t = json.load(open(pmc))
+            # (the PMC passes were taken on one-row launches; a launch over more rows moves that many times the field bytes)
+            per_row = {k: t.get(k, {}).get("bytes_per_launch") for k in kernels}
+            out["traffic_per_kernel"] = {k: (v * rows_per_launch if v else None) for k, v in per_row.items()}
+            out["traffic_source"] = f"profiles/{pmc_name} (FETCH_SIZE x 2 + WRITE_SIZE per one-row launch, x rows_per_launch): " + str(t.get("_source"))
+        except Exception:
+            pass
+        break
+    return out
 
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "RANK" not in os.environ and (args.gpus > 1 or args.workload in ("c3", "c4")):
+        sys.exit(self_launch(args, argv))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -131,8 +205,13 @@ def main():
     if os.environ.get("BENCH_SAME_GPU"):             # diagnostics only: every rank on GPU 0 (needs BENCH_DIST_BACKEND=gloo: RCCL wants one GPU per rank)
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} is running with WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` "
+                         f"(it launches its own ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    visible = torch.cuda.device_count()               # (counting devices does not initialise the GPU)
+    if visible < (1 if os.environ.get("BENCH_SAME_GPU") else world):
+        raise SystemExit(f"bench.py --gpus {world} needs {world} GPUs on this node: {visible} visible "
+                         f"(rank {rank}: torch.cuda.device_count() = {visible})")
     distributed = "RANK" in os.environ          # under torch.distributed.run, also with one rank
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")          # diagnostics only: gloo | none
     if backend == "none":
@@ -146,38 +225,89 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from opticomlib_amd import _lib, devices, workloads
+    from opticomlib_amd import dist as od
 
     n = 1 << LOG2N
     fibre = dict(workloads.SMF)
     dt = 1.0 / (workloads.BENCH_GV["sps"] * workloads.BENCH_GV["R"])
-    c3 = args.workload == "c3" or (args.workload == "auto" and world > 1)
-    from opticomlib_amd import dist as od
-    if c3:
-        units = od.shard(C3_FIELDS, rank, world)                  # round-robin: unit i on rank i % world
-        a = np.stack([workloads.qpsk_field(n, seed=3000 + u, n_pol=N_POL) for u in units]) if units else np.zeros((0, N_POL, n))
-    else:
-        units = [0]
-        a = workloads.qpsk_field(n, seed=2024, n_pol=N_POL)[None]                     # C2 seed
-    fields_here = len(units)
-    hs, _ = devices.step_schedule(LENGTH_KM, H_KM, _lib.C64)
-    assert hs.size == SSFM_STEPS
+    workload = "c2" if args.workload == "auto" else args.workload
+    lin = lambda sign, prec=_lib.C64: devices.linear_operator(n, dt, sign * fibre["alpha"], sign * fibre["beta_2"], sign * fibre["beta_3"], prec)  # noqa: E731
 
-    plan = None
-    if fields_here:
-        plan = _lib.Plan(n, N_POL * fields_here, _lib.C64, device=local_rank)
-        plan.set_linear_operator(devices.linear_operator(n, dt, fibre["alpha"], fibre["beta_2"], fibre["beta_3"], _lib.C64))
-        x_dev = torch.from_numpy(np.ascontiguousarray(a.astype(np.complex64))).cuda()       # resident input
+    plans = []
+    a_c2 = None
+    if workload in ("c2", "c3"):
+        if workload == "c3":
+            total_fields, scaling = C3_FIELDS, "strong"
+            units = od.shard(C3_FIELDS, rank, world)                  # round-robin: unit i on rank i % world
+            seeds = [3000 + u for u in units]
+        else:
+            total_fields, scaling = world, "weak"
+            units = [rank]
+            seeds = [2024] if world == 1 else [3000 + rank]           # N = 1: the C2 seed; N > 1: the WDM channels of C3
+        fields_here = len(units)
+        steps_per_field = SSFM_STEPS
+        hs, _ = devices.step_schedule(LENGTH_KM, H_KM, _lib.C64)
+        assert hs.size == SSFM_STEPS
+        plan = None
+        if fields_here:
+            a = np.stack([workloads.qpsk_field(n, seed=s, n_pol=N_POL) for s in seeds])
+            a_c2 = a[0]
+            plan = _lib.Plan(n, N_POL * fields_here, _lib.C64, device=local_rank)
+            plans.append(plan)
+            plan.set_linear_operator(lin(1.0))
+            x_dev = torch.from_numpy(np.ascontiguousarray(a.astype(np.complex64))).cuda()       # resident input
+
+        def one_step():
+            if plan is None:
+                return
+            plan.set_field_device(x_dev.data_ptr())          # D2D restore on the plan's stream
+            plan.propagate_fixed(fibre["gamma"], hs)         # 1 + 2*1000 launches per lane, asynchronous
+
+        result_ptr = (lambda: plan.field_device_ptr if plan is not None else 0)
+        result_owner = plan
+    else:
+        # C4: this rank's realisations are generated in GPU memory from their LFSR seeds before the timed region
+        total_fields, scaling = C4_SEEDS, "strong"
+        units = od.shard(C4_SEEDS, rank, world)
+        fields_here = len(units)
+        steps_per_field = 200
+        hs, _ = devices.step_schedule(C4_LENGTH_KM, C4_H_KM, _lib.C64)
+        assert hs.size == 100
+        per = min(C4_RESIDENT, max(fields_here, 1))
+        assert fields_here % per == 0, "C4: the realisations of a rank must fill whole resident blocks"
+        x_all = _lib.DeviceArray((max(fields_here, 1), N_POL, n), np.complex64, local_rank)
+        y_all = _lib.DeviceArray((max(fields_here, 1), N_POL, n), np.complex64, local_rank)
+        fb = N_POL * n * 8
+        for k, u in enumerate(units):
+            f = workloads.prbs_field_device(n, seed=1 + u, power_w=1e-3, device=local_rank)
+            _lib._check(_lib.load().ssfm_device_copy(local_rank, _lib._VP(x_all.ptr + k * fb), _lib._VP(f.ptr), fb, 2), "ssfm_device_copy")
+        devices.release_plans()                              # (the generator's complex128 plan)
+        plan_f = plan_b = None
+        if fields_here:
+            plan_f = _lib.Plan(n, N_POL * per, _lib.C64, device=local_rank)      # FIBER: its operator stays resident
+            plan_b = _lib.Plan(n, N_POL * per, _lib.C64, device=local_rank)      # DBP = FIBER with every parameter negated (devices.py:1280-1283)
+            plans += [plan_f, plan_b]
+            plan_f.set_linear_operator(lin(1.0))
+            plan_b.set_linear_operator(lin(-1.0))
+        plan = plan_f
+
+        def one_step():
+            for b0 in range(0, fields_here, per):
+                plan_f.set_field_device(x_all.ptr + b0 * fb)
+                plan_f.propagate_fixed(fibre["gamma"], hs)
+                plan_f.synchronize()                                             # plan_b's stream reads plan_f's buffer
+                plan_b.set_field_device(plan_f.field_device_ptr)
+                plan_b.propagate_fixed(-fibre["gamma"], hs)
+                plan_b.get_field_device(y_all.ptr + b0 * fb)
+                plan_b.synchronize()                                             # before plan_f's buffer is overwritten
+
+        result_ptr = (lambda: y_all.ptr)
+        result_owner = y_all
     torch.cuda.synchronize()
 
-    def one_step():
-        if plan is None:
-            return
-        plan.set_field_device(x_dev.data_ptr())          # D2D restore on the plan's stream
-        plan.propagate_fixed(fibre["gamma"], hs)         # 1 + 2*1000 launches per lane, asynchronous
-
     def fence():
-        if plan is not None:
-            plan.synchronize()                           # the plan's own (non-blocking, high-priority) streams
+        for p in plans:
+            p.synchronize()                              # the plans' own (non-blocking, high-priority) streams
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -202,50 +332,57 @@ def main():
         elapsed = float(t.item())
 
     ms_dev, launches = plan.last_propagate_ms() if plan is not None else (0.0, 0)
-    out = plan.get_field().reshape(fields_here, N_POL, n) if plan is not None else np.zeros((0, N_POL, n), np.complex64)
+    if workload == "c4":
+        out = y_all.to_host()[:fields_here]
+    else:
+        out = plan.get_field().reshape(fields_here, N_POL, n) if plan is not None else np.zeros((0, N_POL, n), np.complex64)
     powers = [float(np.mean(np.abs(o.astype(np.complex128)) ** 2)) for o in out]
 
     # the only "exchange" of this path: the gather of the results at the end, in GPU memory (RCCL over xGMI)
     gather_ms = None
+    collectives = None
     checks = powers
-    if c3 and distributed and backend == "nccl":
-        total = C3_FIELDS
-        got = od.gather_device(plan.field_device_ptr if plan is not None else 0, fields_here, (N_POL, n), np.complex64, total, local_rank,
-                               to_all=False, owner=plan)                                      # warm-up: communicator set-up
+    if distributed and backend == "nccl":
+        def gather():
+            return od.gather_device(result_ptr(), fields_here, (N_POL, n), np.complex64, total_fields, local_rank, to_all=False, owner=result_owner)
+        got = gather()                                         # warm-up: communicator set-up
         reps = 3
         fence()
         tg = time.perf_counter()
         for _ in range(reps):
-            got = od.gather_device(plan.field_device_ptr if plan is not None else 0, fields_here, (N_POL, n), np.complex64, total, local_rank,
-                                   to_all=False, owner=plan)
+            got = gather()
         fence()
         gather_ms = (time.perf_counter() - tg) / reps * 1e3
+        collectives = dict(od.COLLECTIVES)
         if rank == 0:
             g = got.to_host()
-            checks = [float(np.mean(np.abs(g[u].astype(np.complex128)) ** 2)) for u in range(total)]
-            mine = od.shard(total, 0, world)
+            checks = [float(np.mean(np.abs(g[u].astype(np.complex128)) ** 2)) for u in range(total_fields)]
+            mine = od.shard(total_fields, 0, world)
             for k, u in enumerate(mine):                                                      # the gathered block holds this rank's own results in place
                 assert np.array_equal(g[u], out[k]), "gathered field differs from the local result"
     elif distributed:
-        dev = "cuda" if backend == "nccl" else "cpu"
-        gl = [torch.zeros(max(1, -(-C3_FIELDS // world)), dtype=torch.float64, device=dev) for _ in range(world)]
+        gl = [torch.zeros(max(1, -(-total_fields // world)), dtype=torch.float64) for _ in range(world)]
         mine_t = torch.zeros_like(gl[0])
         mine_t[: len(powers)] = torch.tensor(powers, dtype=torch.float64)
         dist.all_gather(gl, mine_t)
         checks = [float(v) for t in gl for v in t.tolist()]
 
-    total_fields = C3_FIELDS if c3 else world
-    value = total_fields * n * SSFM_STEPS * args.steps / elapsed                   # whole job: every field of every rank
+    value = total_fields * n * steps_per_field * args.steps / elapsed                   # whole job: every field of every rank
 
     roofline = None
     cpu = None
     cpu_many = None
     other = None
     if rank == 0:
-        lanes = plan.lanes
-        rows_per_launch = N_POL * fields_here // lanes       # a launch covers one lane's rows
-        b_alg_launch = 2 * rows_per_launch * 8 * n           # its rows read once + written once
-        if not args.no_profile_pass:
+        per_gpu_rate = value * fields_here / max(total_fields, 1)
+        roofline = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "step_frac": 2 * N_POL * 8 * per_gpu_rate / (HBM_PEAK_GBS * 1e9),
+                    "step_frac_note": "whole step on this GPU: 32 B per sample*step (dual-pol complex64 field read once + written once) x its sample*steps/s / peak"}
+        if not args.no_profile_pass and workload != "c4" and plan is not None:
+            lanes = plan.lanes
+            rows_per_launch = N_POL * fields_here // lanes       # a launch covers one lane's rows
+            b_alg_launch = 2 * rows_per_launch * 8 * n           # its rows read once + written once
+
             def timed_pass(mode):
                 plan.set_profiling(mode)
                 one_step()
@@ -253,84 +390,39 @@ def main():
                 kt = plan.kernel_times()
                 plan.set_profiling(0)
                 return kt
-            sparse = timed_pass(2)                         # cheap: pooled average launch time
-            dense = timed_pass(1)                          # per-class split (perturbed by its own events)
-            pooled_us = sum(v[1] for v in sparse.values()) / sum(v[0] for v in sparse.values()) * 1e3
-            dense_avg = {k: v[1] / max(v[0], 1) for k, v in dense.items()}
-            # The committed rocprofv3 --kernel-trace --stats summary of this command: kernel begin -> end only, while the
-            # event-based figures additionally contain the dependent-launch gap that follows every kernel on its stream.
-            rocprof_us, rocprof_src = {}, None
-            for stats_name in ("r02_final_kernel_stats.csv", "r01_final_kernel_stats.csv"):
-                stats = os.path.join(ROOT, "profiles", stats_name)
-                if not os.path.exists(stats):
-                    continue
-                try:
-                    import csv
-                    acc = {}
-                    for row in csv.DictReader(open(stats)):
-                        for k in dense_avg:
-                            if k + "<float" in row["Name"]:          # the C2 kernels (the file also holds C1's complex128 ones)
-                                c, tns = acc.get(k, (0, 0.0))
-                                acc[k] = (c + int(row["Calls"]), tns + float(row["TotalDurationNs"]))
-                    rocprof_us = {k: tns / c / 1e3 for k, (c, tns) in acc.items() if c}
-                    rocprof_src = f"profiles/{stats_name} (kernel begin->end, no launch gap)"
-                except Exception:
-                    pass
-                break
-            # Split of the pooled time between the two kernels.  An event after every launch doubles the host's work per
-            # launch; once the kernels are faster than that, the event-to-event intervals only show the host's cadence
-            # (both classes come out equal to four digits) and carry no information: then the split follows the ratio of
-            # the committed rocprofv3 averages, so that `kernel` is the same kernel in both sources.
-            ks = sorted(dense_avg)
-            degenerate = len(ks) == 2 and abs(dense_avg[ks[0]] / max(dense_avg[ks[1]], 1e-12) - 1.0) < 0.01
-            if degenerate and len(rocprof_us) == 2:
-                mean_r = sum(rocprof_us.values()) / 2
-                launch_us = {k: pooled_us * rocprof_us[k] / mean_r for k in ks}
-                split_source = "ratio of the committed rocprofv3 averages (the event-per-launch pass was host-bound: equal intervals)"
-            else:
-                dense_pooled = sum(v[1] for v in dense.values()) / sum(v[0] for v in dense.values())
-                launch_us = {k: pooled_us * dense_avg[k] / dense_pooled for k in dense}
-                split_source = "event after every launch"
-            dom = max(launch_us, key=launch_us.get)
-            avg_us = launch_us[dom]
-            achieved = b_alg_launch / (avg_us * 1e-6) / 1e9
-            roofline = {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            sparse = timed_pass(2)                         # one event per 64 launches: pooled average launch time, no perturbation
+            sampled = timed_pass(3)                        # one bracketed launch of each kernel per 16 launches: per-kernel duration
+            pooled_us = sum(v[1] for v in sparse.values()) / max(sum(v[0] for v in sparse.values()), 1) * 1e3
+            launch_us = {k: (v[1] / v[0] * 1e3 if v[0] else None) for k, v in sampled.items()}
+            ok = all(v is not None for v in launch_us.values())
+            dom = max(launch_us, key=lambda k: launch_us[k] or 0.0) if ok else None
+            avg_us = launch_us[dom] if ok else None
+            achieved = b_alg_launch / (avg_us * 1e-6) / 1e9 if ok else None
+            prof = committed_profile_figures(list(launch_us), rows_per_launch)
+            roofline.update({
+                "kernel": dom, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS if ok else None,
+                "traffic": (prof.get("traffic_per_kernel") or {}).get(dom),
                 "avg_launch_us": avg_us,
                 "launch_us": launch_us,
-                "launch_us_split_source": split_source,
+                "launches_sampled": {k: v[0] for k, v in sampled.items()},
                 "pooled_launch_us": pooled_us,
-                "launch_us_dense_events": {k: v * 1e3 for k, v in dense_avg.items()},
-                "rocprof_kernel_us": rocprof_us or None,
-                "rocprof_avg_us_of_kernel": rocprof_us.get(dom),
-                "rocprof_source": rocprof_src,
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "lanes": lanes, "rows_per_launch": rows_per_launch,
-                "note": "HIP events on the launch's own stream. pooled_launch_us: one event per 64 launches "
-                        "(interval / launches, includes the dependent-launch gap of ~1.5 us that rocprofv3's begin->end "
-                        "durations do not). launch_us: the pooled time split between the two kernels (launch_us_split_source). "
-                        "With lanes > 1 launches of different row groups overlap on the chip; the chip-level figure is step_frac",
-                "step_frac": 2 * N_POL * 8 * (value * fields_here / total_fields) / (HBM_PEAK_GBS * 1e9),
-            }
-            for pmc_name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
-                pmc = os.path.join(ROOT, "profiles", pmc_name)
-                if not os.path.exists(pmc):
-                    continue
-                try:
-                    t = json.load(open(pmc))
-                    # (the PMC passes were taken on one-row launches; a launch over more rows moves that many times the field bytes)
-                    per_row = {k: t.get(k, {}).get("bytes_per_launch") for k in launch_us}
-                    roofline["traffic"] = per_row.get(dom) * rows_per_launch if per_row.get(dom) else None
-                    roofline["traffic_per_kernel"] = {k: (v * rows_per_launch if v else None) for k, v in per_row.items()}
-                    roofline["traffic_source"] = f"profiles/{pmc_name} (per one-row launch, x rows_per_launch): " + str(t.get("_source"))
-                except Exception:
-                    pass
-                break
-        if world == 1 and not c3:
-            other = secondary_c1(a[0], dt, fibre, local_rank)
+                "measured_in_this_run": ["achieved", "frac", "avg_launch_us", "launch_us", "launches_sampled", "pooled_launch_us", "step_frac"],
+                "read_from_profiles": ["traffic", "from_profiles"],
+                "from_profiles": prof,
+                "note": "HIP events on the launch's own stream, two extra passes of the same workload after the timed region. "
+                        "launch_us: one launch of each kernel per 16 is bracketed by two events (event -> kernel -> event: the "
+                        "kernel plus the dependent-launch gap in front of it, ~1.5 us, which rocprofv3's begin->end durations under "
+                        "from_profiles do not contain). pooled_launch_us: one event per 64 launches, interval / launches. With "
+                        "lanes > 1 launches of different row groups overlap on the chip; the chip-level figure is step_frac",
+            })
+        if world == 1 and workload == "c2" and not args.no_secondary:
+            other = secondary_c1(a_c2, dt, fibre, local_rank)
         if world == 1 and args.cpu_steps > 0:
-            cpu = cpu_baseline(a[0], dt, fibre, args.cpu_steps)
+            if a_c2 is None:
+                a_c2 = workloads.qpsk_field(n, seed=2024, n_pol=N_POL)
+            cpu = cpu_baseline(a_c2, dt, fibre, args.cpu_steps)
         if world == 1 and args.cpu_manycore > 0:
             cpu_many = cpu_baseline_manycore(dt, fibre, args.cpu_manycore, max(8, args.cpu_steps // 4))
 
@@ -339,6 +431,15 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
+    names = {
+        "c2": ("C2: 2^20-sample dual-pol optical_signal, FIBER(length=125, h=0.125) = 1000 SSFM steps, complex64" if world == 1 else
+               f"C2 on every GPU: one 2^20-sample dual-pol field per rank (WDM channels, seeds 3000 + rank; at 8 GPUs = configuration C3), "
+               f"FIBER(length=125, h=0.125) = 1000 SSFM steps each, complex64"),
+        "c3": (f"C3: {C3_FIELDS} independent 2^20-sample dual-pol fields (WDM channels, seeds 3000..), FIBER(length=125, h=0.125) = 1000 SSFM steps each, "
+               f"complex64, unit i on rank i % {world}, a rank's fields batched in one plan"),
+        "c4": (f"C4: {C4_SEEDS} Monte-Carlo PRBS realisations (LFSR seeds 1..{C4_SEEDS}, generated on the device), 2^20-sample dual-pol, FIBER(100 x 1 km) + "
+               f"DBP(100 x 1 km) back to back in GPU memory, complex64, unit i on rank i % {world}, {C4_RESIDENT} resident per plan"),
+    }
     print(json.dumps({
         "metric": "SSFM sample*steps/sec, 2^20-sample dual-pol fiber",
         "value": value,
@@ -348,24 +449,23 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if c3 else "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "c64",
         "data": "synthetic",
         "config": {
-            "workload": (f"C3: {C3_FIELDS} independent 2^20-sample dual-pol fields (WDM channels, seeds 3000..), FIBER(length=125, h=0.125) = 1000 SSFM steps each, "
-                         f"complex64, unit i on rank i % {world}, a rank's fields batched in one plan" if c3 else
-                         "C2: 2^20-sample dual-pol optical_signal, FIBER(length=125, h=0.125) = 1000 SSFM steps, complex64"),
-            "n_samples": n, "n_pol": N_POL, "ssfm_steps_per_bench_step": SSFM_STEPS,
+            "workload": names[workload],
+            "n_samples": n, "n_pol": N_POL, "ssfm_steps_per_field": steps_per_field,
             "fields_total": total_fields, "fields_per_gpu": fields_here, "parallelism": f"independent-fields x{world}",
         },
-        **({"gather_ms": gather_ms, "gather_bytes": C3_FIELDS * N_POL * n * 8,
+        **({"gather_ms": gather_ms, "gather_bytes": total_fields * N_POL * n * 8, "collectives_issued": collectives,
             "gather_note": "all propagated fields to rank 0 in GPU memory, one RCCL gather on the plans' field buffers; after the timed region, not in `value`"}
            if gather_ms is not None else {}),
         "device_ms_last_propagate": ms_dev,
         "launches_per_propagate": launches,
-        "us_per_ssfm_step": elapsed / args.steps / SSFM_STEPS * 1e6,
-        "output_power_W_per_rank": checks,
+        "us_per_ssfm_step": elapsed / args.steps / steps_per_field * 1e6 / max(fields_here, 1),
+        "us_per_ssfm_step_note": "wall time of a bench step / SSFM steps per field / fields on this GPU (per field-step)",
+        "output_power_W_per_field": checks,
         "roofline": roofline,
         "cpu_baseline": cpu,
         **({"cpu_baseline_manycore": cpu_many} if cpu_many else {}),

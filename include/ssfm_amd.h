@@ -286,6 +286,9 @@ int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
  *           the marker packets slow a launch-dense run noticeably (~30 % at 11 us per launch)
  *   mode 2  an event after every 64th launch of a stream: negligible overhead; each interval is split
  *           between the two classes by launch count (so both classes report the pooled average)
+ *   mode 3  sampled: after every 14 launches of a stream ONE launch of each class is bracketed by two events
+ *           (3 extra markers per 16 launches, the host stays ahead of the GPU); ssfm_kernel_times then reports
+ *           only those single-launch intervals: launches sampled and their summed duration per class
  * After ssfm_synchronize, ssfm_kernel_times returns per class the number of launches and the summed
  * event-to-event time in ms (a dependent-launch gap is counted with the launch that follows it). */
 int ssfm_set_profiling(ssfm_plan* plan, int mode);

@@ -490,6 +490,10 @@ class Plan:
     def set_tag(self, which: int, tag: int):
         _check(load().ssfm_plan_set_tag(self._h, int(which), C.c_uint64(int(tag) & (2 ** 64 - 1))), "ssfm_plan_set_tag")
 
+    @property
+    def closed(self) -> bool:
+        return self._h is None
+
     def close(self):
         if self._h is not None and _lib is not None:
             _lib.ssfm_plan_destroy(self._h)

@@ -93,7 +93,8 @@ hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
     // forward-only transform writes the plain transposed spectrum for its consumers
     if constexpr (sizeof(T) == 4)
         if (a.u16) return launch_freq_u<T, MODE, N2, E, true>(nrows, s, a);
-    return launch_freq_u<T, MODE, N2, E, false>(nrows, s, a);
+    if constexpr (MODE == FM_PHASE) return hipErrorInvalidValue;      // (phase tables: complex64 plans in the unit layout only)
+    else return launch_freq_u<T, MODE, N2, E, false>(nrows, s, a);
 }
 template <typename T, int MODE, int E>
 hipError_t launch_freq_e(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a) {
@@ -210,8 +211,14 @@ template <typename T> struct PlanT : PlanBase {
     cx<T>* tw2_fly = nullptr;
     cx<T>* scratch = nullptr;  // batch * n, lazily
     cx<T>* xfer_tab[2] = {nullptr, nullptr};   // resident transfer functions of ssfm_transfer_table (n each, lazily)
-    struct Tab { T h; cx<T>* ptr; bool valid; };
+    struct Tab { T h; cx<T>* ptr; bool valid; int kind; };      // kind 0: exp(D~ h)/N as complex numbers; 1: its phases (FM_PHASE)
     Tab tabs[kMaxTables] = {};
+    // Re D~ is the same number at every frequency (a fibre: -alpha/2, reference devices.py:1145): |exp(D~ h)| is a scalar and the
+    // table may hold phases only.  Decided when the operator is set; env SSFM_PHASE_TABLE=0 keeps the complex tables.
+    bool op_flat_re = false;
+    T op_re0 = 0;
+    bool phase_tables = true;
+    bool force_fly = false;    // env SSFM_FORCE_FLY=1 (diagnostic): fixed-step runs form exp(D~ h) in the kernel as adaptive runs do
     int tab_rr = 0;
     // single-launch engine of small plans (ssfm_kernels.hpp k_small): its own row twiddles and operator tables (another order)
     bool small = false;        // env SSFM_SMALL=0 turns it off
@@ -252,16 +259,21 @@ template <typename T> struct PlanT : PlanBase {
     hipEvent_t fork_ev = nullptr;
     // per-lane pools of events (profiling).  mode 1: an event after every launch (per-class times, but
     // the marker packets slow a launch-dense run by ~30 %); mode 2: an event after every 64th launch
-    // (negligible overhead; the interval is split between the classes by launch count).
+    // (negligible overhead; the interval is split between the classes by launch count); mode 3: after every
+    // kSampleStride launches ONE launch of each class is bracketed by two events (3 extra markers per 16 launches: the
+    // host keeps ahead of the GPU) -- kernel_times() then reports those single-launch intervals only.
     struct LaneProf {
         std::vector<hipEvent_t> ev;
         std::vector<int> c0, c1;          // launches of class 0 / 1 between event i-1 and event i
         size_t n = 0;
         int pend0 = 0, pend1 = 0;
+        int sampling = 0;                 // mode 3: launches of the current sample group still to be bracketed
     };
     LaneProf prof[8];
     int prof_mode = 0;
+    int prof_mode_run = 0;            // the mode the recorded events were taken in
     static constexpr int kSparseStride = 64;
+    static constexpr int kSampleStride = 14;
 
     int prof_record(LaneProf& p, int lane) {
         if (p.n == p.ev.size()) {
@@ -281,10 +293,15 @@ template <typename T> struct PlanT : PlanBase {
     int prof_mark(int cls, int lane = 0) {
         if (!profiling) return SSFM_OK;
         LaneProf& p = prof[lane];
-        if (cls < 0) { p.pend0 = p.pend1 = 0; return prof_record(p, lane); }
+        if (cls < 0) { p.pend0 = p.pend1 = 0; p.sampling = 0; prof_mode_run = prof_mode; return prof_record(p, lane); }
         if (cls == 0) ++p.pend0;
         if (cls == 1) ++p.pend1;
         if (cls == 2) return (p.pend0 + p.pend1) ? prof_record(p, lane) : (int)SSFM_OK;
+        if (prof_mode == 3) {
+            if (p.sampling > 0) { --p.sampling; return prof_record(p, lane); }              // this interval holds exactly this launch
+            if (p.pend0 + p.pend1 >= kSampleStride) { p.sampling = 2; return prof_record(p, lane); }
+            return SSFM_OK;
+        }
         if (prof_mode == 1 || p.pend0 + p.pend1 >= kSparseStride) return prof_record(p, lane);
         return SSFM_OK;
     }
@@ -297,6 +314,7 @@ template <typename T> struct PlanT : PlanBase {
             for (size_t i = 1; i < p.n; ++i) {
                 const int tot = p.c0[i] + p.c1[i];
                 if (tot == 0) continue;
+                if (prof_mode_run == 3 && tot != 1) continue;          // sampled mode: the bracketed single launches only
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, p.ev[i - 1], p.ev[i]));
                 counts[0] += p.c0[i];
@@ -520,6 +538,8 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipMalloc(&dperm_fly, cb * n));
         }
         if (const char* e = std::getenv("SSFM_ADAPT_FUSED")) fused_ok = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_PHASE_TABLE")) phase_tables = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_FORCE_FLY")) force_fly = std::atoi(e) != 0;
         small = small_supported<T>((int)n);
         if (const char* e = std::getenv("SSFM_SMALL")) small = small && std::atoi(e) != 0;
         if (small) {
@@ -608,6 +628,13 @@ template <typename T> struct PlanT : PlanBase {
 
     int set_operator(const void* host) {
         if (int rc = use_device()) return rc;
+        {
+            const T* d = static_cast<const T*>(host);             // (re, im) pairs
+            bool flat = true;
+            for (int64_t i = 1; i < n && flat; ++i) flat = std::memcmp(&d[2 * i], &d[0], sizeof(T)) == 0;
+            op_flat_re = flat;
+            op_re0 = d[0];
+        }
         HIP_TRY(hipMemcpyAsync(dnat, host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)dnat, dperm, N1, N2, N2 / Ef, (T)0, inv_n());
@@ -631,14 +658,14 @@ template <typename T> struct PlanT : PlanBase {
     // single-launch engine (N1 = 1: the table index is the frequency index), else the transposed order of k_freq.
     // A slot that holds a table this schedule needs is never the victim of another of its tables (a round-robin victim could
     // be: schedules {a,b}, {c,d}, {a,e} on one plan would have run a's steps with e's table).
-    int tables_for(const std::vector<T>& distinct, const cx<T>** out, bool one_line) {
+    int tables_for(const std::vector<T>& distinct, const cx<T>** out, bool one_line, int kind = 0) {
         Tab* cache = one_line ? stabs : tabs;
         int& rr = one_line ? stab_rr : tab_rr;
         bool pinned[kMaxTables] = {};
         for (size_t i = 0; i < distinct.size(); ++i) {
             out[i] = nullptr;
             for (int k = 0; k < kMaxTables; ++k)
-                if (cache[k].valid && std::memcmp(&cache[k].h, &distinct[i], sizeof(T)) == 0) { out[i] = cache[k].ptr; pinned[k] = true; }
+                if (cache[k].valid && cache[k].kind == kind && std::memcmp(&cache[k].h, &distinct[i], sizeof(T)) == 0) { out[i] = cache[k].ptr; pinned[k] = true; }
         }
         for (size_t i = 0; i < distinct.size(); ++i) {
             if (out[i]) continue;
@@ -649,9 +676,13 @@ template <typename T> struct PlanT : PlanBase {
             pinned[v] = true;
             t.valid = false;
             if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
+            t.kind = kind;
             if (one_line)
                 hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                                    (const cx<T>*)dnat, t.ptr, 1, (int)n, (int)n / small_points<T>((int)n), distinct[i], inv_n());
+            else if (kind == 1)
+                hipLaunchKernelGGL(k_make_phase_table<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                                   (const cx<T>*)dnat, reinterpret_cast<unsigned*>(t.ptr), N1, N2, N2 / Ef, distinct[i]);
             else
                 hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                                    (const cx<T>*)dnat, t.ptr, N1, N2, N2 / Ef, distinct[i], inv_n());
@@ -678,7 +709,7 @@ template <typename T> struct PlanT : PlanBase {
         trace_tag(a, 1, lane);
 #endif
         (void)lane;
-        a.F = Y + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0; a.u16 = u16 ? 1 : 0; a.step = 0;
+        a.F = Y + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0; a.u16 = u16 ? 1 : 0; a.step = 0; a.amp = (T)0;
         return a;
     }
 
@@ -741,12 +772,14 @@ template <typename T> struct PlanT : PlanBase {
             for (T d : distinct) seen = seen || std::memcmp(&d, &h[s], sizeof(T)) == 0;
             if (!seen) distinct.push_back(h[s]);
         }
-        const bool use_tables = distinct.size() <= (size_t)kMaxTables;
+        const bool use_tables = distinct.size() <= (size_t)kMaxTables && !force_fly;
         std::vector<const cx<T>*> tabptr(distinct.size(), nullptr);
         const bool small_sched = small && use_tables && !profiling && nsteps <= 0x7fffffff;
         const bool go_small = small_sched && snapshots == nullptr;
+        // a fibre's operator has one modulus for all frequencies: 4-byte phase tables (ssfm_kernels.hpp FM_PHASE)
+        const bool use_phase = use_tables && phase_tables && sizeof(T) == 4 && u16 && op_flat_re;
         if (use_tables && !go_small)
-            if (int rc = tables_for(distinct, tabptr.data(), false)) return rc;
+            if (int rc = tables_for(distinct, tabptr.data(), false, use_phase ? 1 : 0)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
             const int lane_ = rows > 0 ? row0 / rows : 0;
             ++last_launches;
@@ -754,6 +787,13 @@ template <typename T> struct PlanT : PlanBase {
                 const cx<T>* tp = nullptr;
                 for (size_t i = 0; i < distinct.size(); ++i)
                     if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
+                if (use_phase) {
+                    FreqArgs<T> fa = fargs(tp, hs, nullptr, row0, lane_);
+                    // the modulus as the complex table forms it: e = exp(Re * h) with the product in T, then e * (1/N) (exact: N = 2^k)
+                    const T xr = op_re0 * hs;
+                    fa.amp = (T)std::exp((double)xr) * inv_n();
+                    return launch_freq<T, FM_PHASE>(N2, N1 * rows, st_, fa, Ef);
+                }
                 return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0, lane_), Ef);
             }
             return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs_fly(hs, nullptr, row0, lane_), Ef_fly);

@@ -793,7 +793,10 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 }
 
 // ------------------------------------------------------------------------------ k_freq
-enum FreqMode { FM_TABLE = 0, FM_FLY = 1, FM_FWD_ONLY = 2 };
+// FM_PHASE: the operator table of a FIBRE (|exp(D~ h)| is the same number at every frequency: Re D~ = -alpha/2,
+// devices.py:1145) holds only the PHASE of every entry, as a 32-bit fraction of a turn (4 bytes per frequency instead of
+// 8: the table is 16 of the 96 bytes a dual-pol sample*step moves); the kernel forms amp * (cos, sin) itself.
+enum FreqMode { FM_TABLE = 0, FM_FLY = 1, FM_FWD_ONLY = 2, FM_PHASE = 3 };
 
 template <typename T> struct FreqArgs {
     cx<T>* F;
@@ -801,6 +804,7 @@ template <typename T> struct FreqArgs {
     const cx<T>* tw2;        // W_N2^q
     const AdaptState<T>* st; // FM_FLY: step size source when non-null (the state of step `step`)
     T h;                     // FM_FLY with st == nullptr
+    T amp;                   // FM_PHASE: exp(Re D~ h) / N, the modulus of every table entry
     int step;
     T inv_n;
     int N1;
@@ -812,6 +816,36 @@ template <typename T> struct FreqArgs {
 template <typename T> __device__ __forceinline__ T exp_acc(T x);
 template <> __device__ __forceinline__ float exp_acc<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double exp_acc<double>(double x) { return exp(x); }
+
+// ---- phase tables (FM_PHASE).  Entry = round(frac(phi / 2 pi) * 2^32), phi = the reference's float32 product Im(D~) * h
+// (devices.py:1179) taken to double: resolution 1.5e-9 rad, finer than the float32 ulp of any phase above 0.013 rad.
+// Row k1, element k2 = j + t Q  ->  ((t >> 2) Q + j) 4 + (t & 3): a thread's slots 4g .. 4g+3 are one 16-byte load.
+__host__ __device__ __forceinline__ long long freq_phase_pos(long long k2, int Q) {
+    const long long j = k2 % Q, t = k2 / Q;
+    return ((t >> 2) * Q + j) * 4 + (t & 3);
+}
+// amp * exp(i 2 pi u / 2^32).  The turn fraction needs no range reduction: u << 1 read as a signed number IS the angle
+// modulo pi in [-pi/2, pi/2) (in units of pi / 2^32), and bit 31 of u + 2^30 says whether the half turn taken off was odd
+// (then both components change sign: folded into amp).  cos and sin run as the two halves of ONE packed polynomial in
+// z = x^2 (5 v_pk_fma_f32): leading coefficients 1, -1/2 and 1 exact, the rest least-squares fits on [-pi/2, pi/2]
+// rounded to float32; against the correctly rounded values: rms 4e-8, |c|^2 + |s|^2 - 1 = -1e-8 on average (the
+// tabulated float32 pairs themselves: 0 +- 8e-8).  About 15 instructions per frequency.
+__device__ __forceinline__ cf32 phase32_factor(unsigned u, float amp) {
+    const int r = (int)(u << 1);
+    const unsigned flip = (u + 0x40000000u) & 0x80000000u;
+    const float x = (float)r * 7.3145906e-10f;                   // pi / 2^32
+    const float z = x * x;
+    const cf32 z2 = mk<float>(z, z);
+    cf32 acc = mk<float>(-2.6185691126556776e-07f, -2.39068338458992e-08f);
+    acc = acc * z2 + mk<float>(2.4768854927970096e-05f, 2.7526464236871107e-06f);
+    acc = acc * z2 + mk<float>(-0.0013888560933992267f, -0.00019840890308842063f);
+    acc = acc * z2 + mk<float>(0.041666656732559204f, 0.008333330973982811f);
+    acc = acc * z2 + mk<float>(-0.5f, -0.1666666716337204f);
+    acc = acc * z2 + mk<float>(1.0f, 1.0f);
+    const float as = __uint_as_float(__float_as_uint(amp) ^ flip);
+    return acc * mk<float>(as, as * x);
+}
+__device__ __forceinline__ cf64 phase32_factor(unsigned, double) { return mk<double>(0.0, 0.0); }      // (complex64 plans only)
 
 template <typename T, int N2, int ROWS, int E, int MODE, bool U16 = false>
 __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const FreqArgs<T> a) {
@@ -853,7 +887,16 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     }
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
-    if (MODE != FM_FWD_ONLY) {
+    unsigned pu[E];
+    if (MODE == FM_PHASE) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ P4 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(a.tab) + (long long)k1 * N2) + j;
+#pragma unroll
+        for (int g = 0; g < E / 4; ++g) {
+            const u32x4 q = P4[g * Q];
+            pu[4 * g] = q.x; pu[4 * g + 1] = q.y; pu[4 * g + 2] = q.z; pu[4 * g + 3] = q.w;
+        }
+    } else if (MODE != FM_FWD_ONLY) {
         typedef T m4_t __attribute__((ext_vector_type(4)));
         const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(trow) + j;
 #pragma unroll
@@ -902,6 +945,10 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
             const T e = flat ? e0 : exp_acc<T>(m[t].x * h);
             m[t] = mk<T>((e * cs[t]) * a.inv_n, (e * sn[t]) * a.inv_n);
         }
+    }
+    if (MODE == FM_PHASE) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) m[t] = phase32_factor(pu[t], a.amp);
     }
 #pragma unroll
     for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
@@ -1212,6 +1259,19 @@ __global__ void k_make_freq_table(const cx<T>* __restrict__ src, cx<T>* __restri
         d.y = (e * (T)s) * inv_n;
     }
     out[k1 * N2 + freq_tab_pos(k2, Q)] = d;
+}
+// phase table of exp(D~ h) (FM_PHASE): out[k1*N2 + freq_phase_pos(k2)] = round(frac(Im(src[k1 + N1*k2]) * h / 2 pi) * 2^32),
+// the product in T exactly as the reference forms it (complex64 * float32), the rest in double
+template <typename T>
+__global__ void k_make_phase_table(const cx<T>* __restrict__ src, unsigned* __restrict__ out, int N1, int N2, int Q, T h) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long N = (long long)N1 * N2;
+    if (o >= N) return;
+    const long long k1 = o / N2, k2 = o % N2;
+    const T xi = src[k1 + (long long)N1 * k2].y * h;
+    double turns = (double)xi * 0.15915494309189533577;          // 1 / (2 pi)
+    turns -= floor(turns);
+    out[k1 * N2 + freq_phase_pos(k2, Q)] = (unsigned)(unsigned long long)llrint(turns * 4294967296.0);      // (2^32 wraps to 0)
 }
 // DM transfer function (reference devices.py:1025-1027): H_k = exp(1j * w_k^2 * D / 2), w_k = fftfreq(n, dt)[k] * 2 * pi,
 // every product in float64 in the reference's order.  Writes H/N in the transposed order and, if

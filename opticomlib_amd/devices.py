@@ -33,20 +33,19 @@ def default_device() -> int:
 
 
 def get_plan(n: int, batch: int, precision: int, device=None) -> _lib.Plan:
-    """Plans own all device buffers; keep the few most recent ones alive."""
+    """Plans own all device buffers; keep the few most recent ones alive.
+
+    Eviction only DROPS the cache's reference: the plan's buffers are freed when its last user lets go of it
+    (``Plan.__del__``), never under a thread that was handed the plan a moment ago and has not taken its lock yet."""
     device = default_device() if device is None else int(device)
     key = (device, int(n), int(batch), int(precision))
     with _CACHE_LOCK:
         plan = _PLANS.pop(key, None)
-        if plan is None:
+        if plan is None or plan.closed:
             plan = _lib.Plan(n, batch, precision, device)
         _PLANS[key] = plan
-        evicted = []
         while len(_PLANS) > _MAX_PLANS:
-            evicted.append(_PLANS.popitem(last=False)[1])
-    for old in evicted:
-        with old.lock:                       # (a thread may still be inside a call on it)
-            old.close()
+            _PLANS.popitem(last=False)
     return plan
 
 
@@ -61,8 +60,24 @@ def release_plans():
 
 def _tag(*key) -> int:
     """Non-zero 64-bit label of what a caller stages in a plan (``Plan.set_tag`` / ``Plan.tag``): the plan itself
-    clears the label whenever the buffer is overwritten, so a matching label means the content is still there."""
-    return (hash(key) & (2 ** 64 - 1)) | 1
+    clears the label whenever the buffer is overwritten, so a matching label means the content is still there.
+
+    A digest of the exact values, NOT Python's ``hash``: ``hash(-1.0) == hash(-2.0)`` in CPython, so a hash-labelled
+    plan took ``FIBER(beta_2=-2)`` for the ``FIBER(beta_2=-1)`` it had staged.  Floats enter by their bit patterns
+    (``-0.0`` and ``0.0``, ``1`` and ``1.0`` are different keys: a spurious miss only re-stages)."""
+    import hashlib
+    import struct
+    h = hashlib.blake2b(digest_size=8)
+    for k in key:
+        if isinstance(k, float):
+            h.update(b"f" + struct.pack("<d", k))
+        elif isinstance(k, (int, np.integer)):
+            h.update(b"i" + int(k).to_bytes(16, "little", signed=True))
+        elif isinstance(k, str):
+            h.update(b"s" + k.encode() + b"\0")
+        else:
+            raise TypeError(f"_tag: unsupported key component {type(k).__name__}")
+    return int.from_bytes(h.digest(), "little") | 1
 
 
 def _is_fast_size(n: int, precision: int) -> bool:

@@ -89,11 +89,23 @@ def _real_dtype(dt: np.dtype):
     return (np.dtype(np.float64) if dt == np.complex128 else np.dtype(np.float32)) if dt.kind == "c" else dt
 
 
-def gather_device(local_ptr: int, n_local: int, unit_shape, dtype, n_units: int, device: int, to_all: bool = True, owner=None):
+# how many collectives this process has really issued on device memory (tests assert that the one-rank RCCL run is not a shortcut)
+COLLECTIVES = {"all_gather_into_tensor": 0, "gather": 0}
+
+
+def gather_device(local_ptr: int, n_local: int, unit_shape, dtype, n_units: int, device: int, to_all: bool = True, owner=None,
+                  force_collective: bool = True):
     """Gather per-unit results that lie side by side in the memory of GPU ``device`` (``n_local`` units of
     ``unit_shape`` and ``dtype`` at ``local_ptr``; unit k is unit ``shard(n_units)[k]``) into ONE device array of
     shape ``(n_units,) + unit_shape`` in unit order: ``_lib.DeviceArray`` on every rank (``to_all``) or on rank 0
-    (others get ``None``).  One collective on device memory; nothing crosses PCIe."""
+    (others get ``None``).  One collective on device memory; nothing crosses PCIe.
+
+    The collective runs whenever a device process group exists, ALSO with one rank (``force_collective``; a
+    one-rank RCCL run is how the path is exercised on a one-GPU box).  The receive buffer is the result itself
+    whenever rank-major order is unit order (one rank, or one unit per rank -- configuration C3 on 8 GPUs): RCCL
+    writes the chunks where they belong; otherwise one strided device copy reorders them.  Every rank returns only
+    after the collective has completed on ITS device: the send buffer is usually a plan's field buffer, which the
+    plan's own stream is free to overwrite as soon as the caller lets go of the plan."""
     import torch
     import torch.distributed as dist
     from . import _lib
@@ -111,22 +123,28 @@ def gather_device(local_ptr: int, n_local: int, unit_shape, dtype, n_units: int,
         if n_local:
             send[: n_local * per_unit].copy_(_torch_view(local_ptr, n_local * per_unit, rdt, device, owner))
     need = to_all or rank == 0
-    if ws == 1:
-        got = send
+    collective = _device_backend() and (ws > 1 or force_collective)
+    in_place = need and ws * per_rank == n_units and (ws == 1 or per_rank == 1)     # rank-major order IS unit order
+    out = _lib.DeviceArray((n_units,) + tuple(unit_shape), dtype, device) if need else None
+    dst = _torch_view(out.ptr, n_units * per_unit, rdt, device, out) if need else None
+    got = None
+    if need:
+        got = dst if in_place else torch.empty(ws * per_rank * per_unit, dtype=tdt, device=dev)
+    if not collective:
+        if ws != 1:
+            raise RuntimeError("gather_device needs a device (nccl) process group for more than one rank")
+        dst.copy_(send)                      # no process group (or the collective declined): one rank's units are the result
     elif to_all:
-        got = torch.empty(ws * per_rank * per_unit, dtype=tdt, device=dev)
         dist.all_gather_into_tensor(got, send)
+        COLLECTIVES["all_gather_into_tensor"] += 1
     else:
-        parts = [torch.empty(per_rank * per_unit, dtype=tdt, device=dev) for _ in range(ws)] if rank == 0 else None
-        dist.gather(send, parts, dst=0)
-        got = torch.cat(parts) if rank == 0 else None
-    if not need:
-        return None
-    out = _lib.DeviceArray((n_units,) + tuple(unit_shape), dtype, device)
-    dst = _torch_view(out.ptr, n_units * per_unit, rdt, device, out)
-    # got[r, k] is unit k * ws + r: rank-major -> unit order (a strided device copy)
-    dst.view(n_units, per_unit).copy_(got.view(ws, per_rank, per_unit).transpose(0, 1).reshape(ws * per_rank, per_unit)[:n_units])
-    torch.cuda.synchronize(dev)
+        # rank 0 receives every chunk where it belongs: views of the one receive buffer, no list of temporaries
+        dist.gather(send, list(got.chunk(ws)) if rank == 0 else None, dst=0)
+        COLLECTIVES["gather"] += 1
+    if need and not in_place:
+        # got[r, k] is unit k * ws + r: rank-major -> unit order (one strided device copy)
+        dst.view(n_units, per_unit).copy_(got.view(ws, per_rank, per_unit).transpose(0, 1).reshape(ws * per_rank, per_unit)[:n_units])
+    torch.cuda.synchronize(dev)              # on EVERY rank: the collective has read `send` (a plan's field buffer) when we return
     return out
 
 
@@ -141,7 +159,7 @@ def gather_results(local: Sequence, n_units: int, to_all: bool = True, on_device
     from . import _lib
     rank, ws = world()
     is_dev = len(local) > 0 and all(isinstance(a, _lib.DeviceArray) for a in local)
-    if ws == 1:
+    if ws == 1 and not (is_dev and _device_backend()):       # (a one-rank device group still runs the collective below)
         if on_device or not is_dev:
             return list(local)
         return [a.to_host() for a in local]
@@ -303,8 +321,8 @@ def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False
                     plan.set_linear_operator(linear_operator(n, dt, -kw.get("alpha", 0.0), -kw.get("beta_2", 0.0), -kw.get("beta_3", 0.0), prec))
                     plan.propagate_fixed(-kw.get("gamma", 0.0), hs)
             plan.synchronize()
-            if ws > 1 and _device_backend():
-                # the plan's field buffer IS the send buffer
+            if _device_backend():
+                # the plan's field buffer IS the send buffer (one rank included: the collective still runs)
                 out = gather_device(plan.field_device_ptr, len(mine), unit_shape, cdt, n_units, dev, to_all=to_all, owner=plan)
             else:
                 out = _lib.DeviceArray((len(mine),) + unit_shape, cdt, dev)
@@ -333,7 +351,7 @@ def propagate_channels(fields, dt: float, to_all: bool = True, dbp: bool = False
             if dbp:
                 y = DBP(y, device=dev, **kw)
             local.append(y._raw("signal"))
-    if ws == 1 and on_device:
+    if ws == 1 and on_device and not _device_backend():
         blk = _lib.DeviceArray((n_units,) + unit_shape, cdt, dev)
         nb = int(np.prod(unit_shape)) * cdt.itemsize
         for k, a in enumerate(local):

@@ -46,6 +46,21 @@ def main():
     dev = od.propagate_channels(local, DT, to_all=True, on_device=True, **FIXED)
     assert isinstance(dev, _lib.DeviceArray) and dev.shape == (n_units,) + f.shape[1:]
     res["fixed_dev"] = dev.to_host()
+    # the gather itself on known data: every unit carries its own index; uneven counts (padding + reorder), one unit per
+    # rank (RCCL writes straight into the result), to every rank and to rank 0 only
+    for total in (n_units, ws):
+        mine_t = od.shard(total)
+        blk = np.stack([np.full((2, 64), u + 1j * (u + 0.5), np.complex64) for u in mine_t]) if mine_t else np.zeros((0, 2, 64), np.complex64)
+        d = _lib.DeviceArray.from_host(blk, np.complex64, od_device()) if len(mine_t) else None
+        for to_all in (True, False):
+            g = od.gather_device(d.ptr if d is not None else 0, len(mine_t), (2, 64), np.complex64, total, od_device(), to_all=to_all, owner=d)
+            assert (g is None) == (not to_all and rank != 0)
+            if g is not None:
+                h = g.to_host()
+                assert h.shape == (total, 2, 64)
+                for u in range(total):
+                    assert np.all(h[u] == np.complex64(u + 1j * (u + 0.5))), (total, to_all, u)
+    res["collectives"] = np.array([od.COLLECTIVES["all_gather_into_tensor"], od.COLLECTIVES["gather"]])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     import torch.distributed as dist
     if dist.is_initialized():

@@ -1871,6 +1871,25 @@ def test_full_size_c4_against_the_strided_fixture(golden_dir):
 
 
 # ----------------------------------------------------------------------- what a plan holds is the plan's knowledge
+def test_sweeping_a_parameter_through_minus_one_and_minus_two_restages_the_operator():
+    """hash(-1.0) == hash(-2.0): with hash-derived plan labels the second call of such a sweep silently reused the first
+    call's operator (ADVICE r2).  Every call of the sweep must match the oracle for ITS parameters, also through DBP's
+    negated ones."""
+    gv(sps=8, R=16e9, N=64)
+    n = 4096
+    rng = np.random.default_rng(11)
+    a = ((rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))) * 0.03).astype(np.complex64)
+    x = optical_signal(a)
+    for fn, orc_sign in ((oa.FIBER, 1.0), (oa.DBP, -1.0)):
+        for name in ("beta_2", "beta_3", "alpha"):
+            for val in (-1.0, -2.0, 1.0, 2.0):
+                kw = dict(length=3, h=1.0, alpha=0.2, beta_2=-20.0, beta_3=0.1, gamma=1.5)
+                kw[name] = val
+                okw = {k: (orc_sign * v if k in ("alpha", "beta_2", "beta_3", "gamma") else v) for k, v in kw.items()}
+                want = orc.fiber_c64(a, gv.dt, **okw)
+                assert relmax(fn(x, **kw).signal, want) < TOL_100, (fn.__name__, name, val)
+
+
 def test_interleaved_users_of_one_plan_never_see_a_stale_table():
     """FIBER (complex128), DM, DAC, a chirp-z FIBER and x('w') all end up on complex128 plans of the same length and
     batch and reuse its operator staging and table slots.  Which operator / table is staged is tracked by the C plan
@@ -1979,8 +1998,9 @@ def _run_dist_gpu(tmp_path, world, n_units):
 def test_propagate_channels_over_rccl_matches_single_process(tmp_path, world):
     """opticomlib_amd.dist.propagate_channels under torch.distributed.run with the nccl (= RCCL) backend: units sharded
     round-robin, results gathered in GPU memory with one collective, equal BIT FOR BIT to the same calls in this
-    process.  world = 1 exercises the device-side gather code on the single GPU of the test box; world = 2 needs two
-    GPUs (skipped otherwise).  Fixed step (batched plan, uneven unit counts), FIBER + DBP to rank 0 only, adaptive
+    process.  world = 1 runs the same collectives (all_gather_into_tensor / gather on the zero-copy view of the plan's
+    field buffer -- counted by dist.COLLECTIVES) on the single GPU of the test box; world = 2 needs two GPUs (skipped
+    otherwise).  Fixed step (batched plan, uneven unit counts), FIBER + DBP to rank 0 only, adaptive
     (one by one), device-resident units."""
     import torch
     if torch.cuda.device_count() < world:
@@ -2008,6 +2028,8 @@ def test_propagate_channels_over_rccl_matches_single_process(tmp_path, world):
         assert ("dbp_0" in got.files) == (rank == 0)
         for k in range(3):
             np.testing.assert_array_equal(got[f"adapt_{k}"], want_adapt[k])
+        # the gathers were real RCCL collectives on device memory -- with ONE rank too (no world-size shortcut)
+        assert got["collectives"][0] >= 4 and got["collectives"][1] >= 3, got["collectives"]
 
 
 def test_host_threads_on_the_same_plans():

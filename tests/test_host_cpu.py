@@ -312,3 +312,22 @@ def test_optical_signal_algebra():
     assert x[4:10].signal.shape == (2, 6) and optical_signal(s1[0])[::2].size == 16
     with pytest.raises(ValueError):
         x.power("mW")
+
+
+def test_plan_labels_do_not_collide_like_python_hashes():
+    """hash(-1.0) == hash(-2.0) in CPython: a hash-derived label made FIBER(beta_2=-2) reuse the operator staged for
+    FIBER(beta_2=-1).  The label is a digest of the exact values."""
+    from opticomlib_amd.devices import _tag
+    assert hash(-1.0) == hash(-2.0)                                      # the trap itself
+    seen = set()
+    for a in (0.0, 0.2, -0.2, 1.0, -1.0, 2.0, -2.0):
+        for b2 in (-1.0, -2.0, 1.0, 2.0, -21.7, 0.0):
+            for b3 in (-1.0, -2.0, 0.0, 0.13):
+                t = _tag("fibre", 1.953125e-12, a, b2, b3)
+                assert t & 1 and 0 < t < 2 ** 64
+                seen.add(t)
+    assert len(seen) == 7 * 6 * 4
+    assert _tag("chirp", 3000) == _tag("chirp", 3000) != _tag("chirp", 3001)
+    assert _tag("gauss-shape", 4096, 16) != _tag("gauss-shape", 16, 4096)
+    with pytest.raises(TypeError):
+        _tag("x", [1, 2])
