@@ -294,31 +294,70 @@ template <int E> __device__ __forceinline__ void rotate_all(cf32 (&v)[E], const 
         }
     }
 }
-template <int E> __device__ __forceinline__ void rotate_all(cf64 (&v)[E], const double (&phi)[E]) {
-#pragma unroll
-    for (int t = 0; t < E; ++t) {
-        double s, c;
-        sincos(phi[t], &s, &c);
-        v[t] = cmul(v[t], mk<double>(c, s));
-    }
+// double, |x| <= pi/4: the fdlibm kernels (__kernel_sin / __kernel_cos without the tail argument), < 1 ulp.  The library
+// sincos() carries its argument reduction (Cody-Waite and Payne-Hanek paths, ~60 float64 instructions and a dozen
+// branches per call): 40 % of the float64 instructions of k_time<double>, which is bound by them.
+__device__ __forceinline__ void sincos_tiny(double x, double& s, double& c) {
+    const double z = x * x;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    s = fma(x * z, ps, x);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    c = 1.0 - (hz - z * (z * pc));
 }
-// E sin/cos pairs with ONE path decision per thread (on-the-fly linear operator of the adaptive mode:
-// the dispersion phases reach tens of radians, so the plain Cody-Waite path is the common one)
-template <int E> __device__ __forceinline__ void sincos_all(const float (&phi)[E], float (&sn)[E], float (&cs)[E]) {
-    float amax = 0.0f;
+template <int E> __device__ __forceinline__ void rotate_all(cf64 (&v)[E], const double (&phi)[E]) {
+    double amax = 0.0;
 #pragma unroll
-    for (int t = 0; t < E; ++t) amax = fmaxf(amax, fabsf(phi[t]));
-    if (__builtin_expect(amax <= kSincosSmallMax, 1)) {
+    for (int t = 0; t < E; ++t) amax = fmax(amax, fabs(phi[t]));
+    if (__builtin_expect(amax <= (double)kSincosTinyMax, 1)) {          // (false for NaN: the library path propagates it)
 #pragma unroll
-        for (int t = 0; t < E; ++t) sincos_f32<false>(phi[t], sn[t], cs[t]);
+        for (int t = 0; t < E; ++t) {
+            double s, c;
+            sincos_tiny(phi[t], s, c);
+            v[t] = cmul(v[t], mk<double>(c, s));
+        }
     } else {
 #pragma unroll
-        for (int t = 0; t < E; ++t) sincos_f32<true>(phi[t], sn[t], cs[t]);
+        for (int t = 0; t < E; ++t) {
+            double s, c;
+            sincos(phi[t], &s, &c);
+            v[t] = cmul(v[t], mk<double>(c, s));
+        }
     }
 }
-template <int E> __device__ __forceinline__ void sincos_all(const double (&phi)[E], double (&sn)[E], double (&cs)[E]) {
-#pragma unroll
-    for (int t = 0; t < E; ++t) sincos(phi[t], &sn[t], &cs[t]);
+// amp * (cos x, sin x) for |x| <= pi/2 as ONE packed polynomial in z = x^2: cos and sin are the two halves of the accumulator
+// (5 v_pk_fma_f32); leading coefficients 1, -1/2 and 1 exact, the rest least-squares fits on [-pi/2, pi/2] rounded to
+// float32.  Against the correctly rounded values: rms 4e-8, |c|^2 + |s|^2 - 1 = -1e-8 on average (correctly rounded
+// float32 pairs themselves: 0 +- 8e-8).
+__device__ __forceinline__ cf32 expi_half_turn(float x, float amp) {
+    const float z = x * x;
+    const cf32 z2 = mk<float>(z, z);
+    cf32 acc = mk<float>(-2.6185691126556776e-07f, -2.39068338458992e-08f);
+    acc = acc * z2 + mk<float>(2.4768854927970096e-05f, 2.7526464236871107e-06f);
+    acc = acc * z2 + mk<float>(-0.0013888560933992267f, -0.00019840890308842063f);
+    acc = acc * z2 + mk<float>(0.041666656732559204f, 0.008333330973982811f);
+    acc = acc * z2 + mk<float>(-0.5f, -0.1666666716337204f);
+    acc = acc * z2 + mk<float>(1.0f, 1.0f);
+    return acc * mk<float>(amp, amp * x);
+}
+// amp * exp(i x), |x| <= kSincosSmallMax: Cody-Waite reduction by pi (k = rint(x / pi), three fma terms whose sum is pi to
+// double precision) leaves |r| <= pi/2, an odd k flips the sign of both components (folded into amp) -- no quadrant
+// selects: about 16 instructions instead of 33 per point of the on-the-fly operator.
+__device__ __forceinline__ cf32 expi_f32(float x, float amp) {
+    const float k = rintf(x * 0.3183098861837907f);
+    float r = fmaf(k, -3.14154052734375f, x);
+    r = fmaf(k, -5.2126124501228333e-05f, r);
+    r = fmaf(k, -1.2154188766544394e-10f, r);
+    const unsigned flip = (unsigned)(int)k << 31;
+    return expi_half_turn(r, __uint_as_float(__float_as_uint(amp) ^ flip));
 }
 // scalar form
 template <typename T> __device__ __forceinline__ void sincos_acc(T x, T& s, T& c);
@@ -457,8 +496,13 @@ template <typename T> __host__ __device__ constexpr bool lds_double_buffer() { r
 #define SSFM_MIN_WAVES_256 2
 #endif
 // (a 512-thread workgroup with 16 points per thread needs the full 256 registers: one workgroup per CU)
+// complex128 kernels: waves per SIMD to ask the register allocator for (experiment knob; 1 = no constraint)
+#ifndef SSFM_MIN_WAVES_C128
+#define SSFM_MIN_WAVES_C128 1
+#endif
 __host__ __device__ constexpr int min_waves(int threads, int tsize, int e = 16) {
-    return tsize == 4 && threads >= 256 ? (threads == 256 ? SSFM_MIN_WAVES_256 : (e == 16 ? 2 : threads / 128)) : 1;
+    return tsize == 4 && threads >= 256 ? (threads == 256 ? SSFM_MIN_WAVES_256 : (e == 16 ? 2 : threads / 128))
+                                        : (tsize == 8 && e == 8 ? SSFM_MIN_WAVES_C128 : 1);
 }
 
 // (SSFM_CAP_WAVES: complex64 workgroups of 256 threads are meant to sit two per CU -- a launch of one lane is 256 of
@@ -538,8 +582,12 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         // the tile's E x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
         // (both tables are stored tile by tile in the order they are read here: 2 KiB + 2 KiB of contiguous lines per
         // workgroup; indexed as twB[t n2] / twA[j n2] they were 512 gathers of 8 bytes, 2.4 MB of sectors per launch)
+        if (SSFM_ABL_NO_TWN) {
+            for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = mk<T>((T)1, (T)0);
+        } else {
         for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(long long)tile * (E * C) + e];
         wA = a.twA[(long long)tile * (Q * C) + ltid];
+        }
     } else {
         typedef T w4_t __attribute__((ext_vector_type(4)));
         const w4_t* __restrict__ W4 = reinterpret_cast<const w4_t*>(a.twN) + (long long)tile * (E / 2) * (N1 * C / E) + ltid;
@@ -827,25 +875,46 @@ __host__ __device__ __forceinline__ long long freq_phase_pos(long long k2, int Q
 // amp * exp(i 2 pi u / 2^32).  The turn fraction needs no range reduction: u << 1 read as a signed number IS the angle
 // modulo pi in [-pi/2, pi/2) (in units of pi / 2^32), and bit 31 of u + 2^30 says whether the half turn taken off was odd
 // (then both components change sign: folded into amp).  cos and sin run as the two halves of ONE packed polynomial in
-// z = x^2 (5 v_pk_fma_f32): leading coefficients 1, -1/2 and 1 exact, the rest least-squares fits on [-pi/2, pi/2]
-// rounded to float32; against the correctly rounded values: rms 4e-8, |c|^2 + |s|^2 - 1 = -1e-8 on average (the
-// tabulated float32 pairs themselves: 0 +- 8e-8).  About 15 instructions per frequency.
+// z = x^2 (expi_half_turn above).  About 15 instructions per frequency.
 __device__ __forceinline__ cf32 phase32_factor(unsigned u, float amp) {
     const int r = (int)(u << 1);
     const unsigned flip = (u + 0x40000000u) & 0x80000000u;
     const float x = (float)r * 7.3145906e-10f;                   // pi / 2^32
-    const float z = x * x;
-    const cf32 z2 = mk<float>(z, z);
-    cf32 acc = mk<float>(-2.6185691126556776e-07f, -2.39068338458992e-08f);
-    acc = acc * z2 + mk<float>(2.4768854927970096e-05f, 2.7526464236871107e-06f);
-    acc = acc * z2 + mk<float>(-0.0013888560933992267f, -0.00019840890308842063f);
-    acc = acc * z2 + mk<float>(0.041666656732559204f, 0.008333330973982811f);
-    acc = acc * z2 + mk<float>(-0.5f, -0.1666666716337204f);
-    acc = acc * z2 + mk<float>(1.0f, 1.0f);
-    const float as = __uint_as_float(__float_as_uint(amp) ^ flip);
-    return acc * mk<float>(as, as * x);
+    return expi_half_turn(x, __uint_as_float(__float_as_uint(amp) ^ flip));
 }
 __device__ __forceinline__ cf64 phase32_factor(unsigned, double) { return mk<double>(0.0, 0.0); }      // (complex64 plans only)
+
+// m[t] <- exp(D~_t h) / N with D~_t = m[t] on entry and ph[t] = Im(D~_t) h; `flat`: Re D~ is the same at every t and
+// e0 = exp(Re D~ h).  (e * c) * inv_n == (e * inv_n) * c exactly: N is a power of two.
+template <int E> __device__ __forceinline__ void fly_factors(cf32 (&m)[E], const float (&ph)[E], bool flat, float e0, float h, float inv_n) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < E; ++t) amax = fmaxf(amax, fabsf(ph[t]));
+    if (__builtin_expect(amax <= kSincosSmallMax, 1)) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const float e = flat ? e0 : exp_acc<float>(m[t].x * h);
+            m[t] = expi_f32(ph[t], e * inv_n);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            float sn, cs;
+            sincos_f32<true>(ph[t], sn, cs);
+            const float e = flat ? e0 : exp_acc<float>(m[t].x * h);
+            m[t] = mk<float>((e * cs) * inv_n, (e * sn) * inv_n);
+        }
+    }
+}
+template <int E> __device__ __forceinline__ void fly_factors(cf64 (&m)[E], const double (&ph)[E], bool flat, double e0, double h, double inv_n) {
+#pragma unroll
+    for (int t = 0; t < E; ++t) {
+        double sn, cs;
+        sincos(ph[t], &sn, &cs);
+        const double e = flat ? e0 : exp_acc<double>(m[t].x * h);
+        m[t] = mk<double>((e * cs) * inv_n, (e * sn) * inv_n);
+    }
+}
 
 template <typename T, int N2, int ROWS, int E, int MODE, bool U16 = false>
 __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const FreqArgs<T> a) {
@@ -893,7 +962,8 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
         const u32x4* __restrict__ P4 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(a.tab) + (long long)k1 * N2) + j;
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
-            const u32x4 q = P4[g * Q];
+            u32x4 q;
+            if (SSFM_ABL_NO_TAB) q = 0x12345678u; else q = P4[g * Q];
             pu[4 * g] = q.x; pu[4 * g + 1] = q.y; pu[4 * g + 2] = q.z; pu[4 * g + 3] = q.w;
         }
     } else if (MODE != FM_FWD_ONLY) {
@@ -929,10 +999,9 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     SSFM_STAMP(3);
     if (MODE == FM_FLY) {
         // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
-        T ph[E], sn[E], cs[E];
+        T ph[E];
 #pragma unroll
         for (int t = 0; t < E; ++t) ph[t] = m[t].y * h;
-        sincos_all<E>(ph, sn, cs);
         // Re D~ = -alpha/2 is the same number at every frequency for a fibre (devices.py:1145): then exp(Re h) is ONE
         // exponential per thread instead of 16 (bit-identical: the same float product, the same function); any other
         // operator takes the general path
@@ -940,11 +1009,7 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 #pragma unroll
         for (int t = 1; t < E; ++t) flat = flat && (m[t].x == m[0].x);
         const T e0 = exp_acc<T>(m[0].x * h);
-#pragma unroll
-        for (int t = 0; t < E; ++t) {
-            const T e = flat ? e0 : exp_acc<T>(m[t].x * h);
-            m[t] = mk<T>((e * cs[t]) * a.inv_n, (e * sn[t]) * a.inv_n);
-        }
+        fly_factors<E>(m, ph, flat, e0, h, a.inv_n);
     }
     if (MODE == FM_PHASE) {
 #pragma unroll
@@ -1175,16 +1240,11 @@ __global__ __launch_bounds__(ROWS * N / E) void k_small_adapt(const SmallAdaptAr
         const T h = S.h;
         fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
         {   // exp(D~ h)/N as k_freq<FM_FLY>
-            T ph[E], sn[E], cs[E];
+            T ph[E];
 #pragma unroll
-            for (int t = 0; t < E; ++t) ph[t] = d[t].y * h;
-            sincos_all<E>(ph, sn, cs);
+            for (int t = 0; t < E; ++t) { ph[t] = d[t].y * h; m[t] = d[t]; }
             const T e0 = exp_acc<T>(d[0].x * h);
-#pragma unroll
-            for (int t = 0; t < E; ++t) {
-                const T e = flat ? e0 : exp_acc<T>(d[t].x * h);
-                m[t] = mk<T>((e * cs[t]) * a.inv_n, (e * sn[t]) * a.inv_n);
-            }
+            fly_factors<E>(m, ph, flat, e0, h, a.inv_n);
         }
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);

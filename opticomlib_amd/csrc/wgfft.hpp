@@ -66,6 +66,23 @@ __device__ __forceinline__ cf64 mul_mi(cf64 a) { cf64 r; r.x = a.y; r.y = -a.x; 
 __device__ __forceinline__ cf64 mul_pi(cf64 a) { cf64 r; r.x = -a.y; r.y = a.x; return r; }
 __device__ __forceinline__ cf64 scale2(cf64 a, cf64 s) { return a * s; }
 
+// SSFM_SCALAR_FP32 = 1 (experiment, with -fno-slp-vectorize): plain component-wise float arithmetic instead of the packed forms.
+// Measured issue cost on MI355X (tools/ubench_pk_issue.hip, profiles/r03_ubench_pk_issue.txt): a v_pk_fma_f32 costs a lone wave
+// 9.0 cycles against 12.2 for the two v_fma_f32 it replaces, but with two or more waves per SIMD 6.0 / 5.3 against 4.2 / 3.8.
+#ifndef SSFM_SCALAR_FP32
+#define SSFM_SCALAR_FP32 0
+#endif
+#if SSFM_SCALAR_FP32
+__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { cf32 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { cf32 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+__device__ __forceinline__ cf32 scale2(cf32 a, cf32 s) { cf32 r; r.x = a.x * s.x; r.y = a.y * s.y; return r; }
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { cf32 r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r; }
+__device__ __forceinline__ cf32 cmulc(cf32 a, cf32 b) { cf32 r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r; }
+__device__ __forceinline__ cf32 add_mi(cf32 a, cf32 d) { cf32 r; r.x = a.x + d.y; r.y = a.y - d.x; return r; }
+__device__ __forceinline__ cf32 add_pi(cf32 a, cf32 d) { cf32 r; r.x = a.x - d.y; r.y = a.y + d.x; return r; }
+__device__ __forceinline__ cf32 mul_mi(cf32 a) { cf32 r; r.x = a.y; r.y = -a.x; return r; }
+__device__ __forceinline__ cf32 mul_pi(cf32 a) { cf32 r; r.x = -a.y; r.y = a.x; return r; }
+#else
 // ---- float forms: packed FP32 with modifiers (VOP3P).  op_sel[i] / op_sel_hi[i] pick the half of
 // source i that feeds the low / high result lane; neg_lo / neg_hi negate a source per lane.
 __device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return a + b; }      // v_pk_add_f32
@@ -105,6 +122,8 @@ __device__ __forceinline__ cf32 mul_pi(cf32 a) {                // (-a.y, a.x)
     asm("v_pk_mul_f32 %0, 1.0, %1 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(r) : "v"(a));
     return r;
 }
+
+#endif
 
 // Tables hold forward twiddles exp(-i*theta); DIR < 0 = forward, DIR > 0 = inverse (conjugate).
 template <int DIR, typename C> __device__ __forceinline__ C cmuld(C a, C w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
