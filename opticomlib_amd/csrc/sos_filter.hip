@@ -235,8 +235,8 @@ template <int K, int CH> __device__ __forceinline__ void mat_apply(const double*
 
 // state vector s[CH][K] <-> z[NS][2] per channel
 template <int NS, int CH, int W>
-__global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ pw,
-                                                       double* __restrict__ E, double* __restrict__ T) {
+__global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks, int ngroups, const double* __restrict__ pw,
+                                                       const double* __restrict__ G, double* __restrict__ E, double* __restrict__ T) {
     constexpr int K = 2 * NS;
     constexpr int kWaves = W, kGroup = kWave * W;
     __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
@@ -265,21 +265,33 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosCoefs c, SosPass p,
         const int len = (int)(i0 + kChunk <= p.m ? kChunk : p.m - i0);
         Smp<CH> xs[kChunk];
         load_chunk<CH>(p, base, w0, lane, len, plain, lds_all[wv], xs);
-        double z[CH][NS][2];
+        // The chunk's particular solution -- the state after its samples from a ZERO state -- is linear in the samples:
+        // p_c = sum_t G[:, t] x_t, G[:, t] = the state kChunk - 1 - t steps after a unit sample (built on the host by
+        // running the recurrence on unit samples).  K fma per sample and channel instead of the 9 NS float64 operations
+        // of the recurrence itself, which only the output pass (k_apply) has to run.  A short last chunk ends `len`
+        // samples in: its sample t has the weight of sample kChunk - len + t of a full one.
+        if (len == kChunk) {
 #pragma unroll
-        for (int a = 0; a < CH; ++a)
+            for (int t = 0; t < kChunk; ++t)
 #pragma unroll
-            for (int q = 0; q < NS; ++q) z[a][q][0] = z[a][q][1] = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    const double g = G[k * kChunk + t];
 #pragma unroll
-        for (int t = 0; t < kChunk; ++t)
-            if (t < len) {
+                    for (int a = 0; a < CH; ++a) s[a][k] = fma(g, xs[t].v[a], s[a][k]);
+                }
+        } else {
+            const int off = kChunk - len;
 #pragma unroll
-                for (int a = 0; a < CH; ++a) sos_step<NS>(c, z[a], xs[t].v[a]);
-            }
+            for (int t = 0; t < kChunk; ++t)
+                if (t < len) {
 #pragma unroll
-        for (int a = 0; a < CH; ++a)
+                    for (int k = 0; k < K; ++k) {
+                        const double g = G[k * kChunk + off + t];
 #pragma unroll
-            for (int q = 0; q < NS; ++q) { s[a][2 * q] = z[a][q][0]; s[a][2 * q + 1] = z[a][q][1]; }
+                        for (int a = 0; a < CH; ++a) s[a][k] = fma(g, xs[t].v[a], s[a][k]);
+                    }
+                }
+        }
     }
     __syncthreads();                      // lds_pw staged
     wave_scan<K, CH>(s, lds_pw);
@@ -538,6 +550,22 @@ template <int NS, int W> void build_tables(const SosCoefs& c, std::vector<double
         }
         for (int r = 0; r < K; ++r) M[r * K + q] = z[r / 2][r % 2];
     }
+    // G[k][t]: component k of the state at the end of a chunk whose only non-zero sample is a 1 at position t
+    std::vector<double> G((size_t)K * kChunk, 0.0);
+    for (int t = 0; t < kChunk; ++t) {
+        double z[NS][2];
+        for (int s = 0; s < NS; ++s) z[s][0] = z[s][1] = 0.0;
+        for (int i = t; i < kChunk; ++i) {
+            double x = i == t ? 1.0 : 0.0;
+            for (int s = 0; s < NS; ++s) {
+                const double xn = x;
+                x = c.b0[s] * xn + z[s][0];
+                z[s][0] = c.b1[s] * xn - c.a1[s] * x + z[s][1];
+                z[s][1] = c.b2[s] * xn - c.a2[s] * x;
+            }
+        }
+        for (int k = 0; k < K; ++k) G[(size_t)k * kChunk + t] = z[k / 2][k % 2];
+    }
     tab.assign((size_t)3 * (kWave + 1) * K * K, 0.0);
     for (int level = 0; level < 3; ++level) {
         double* P = tab.data() + (size_t)level * (kWave + 1) * K * K;
@@ -551,6 +579,7 @@ template <int NS, int W> void build_tables(const SosCoefs& c, std::vector<double
             std::memcpy(M, A, sizeof(M));
         }
     }
+    tab.insert(tab.end(), G.begin(), G.end());                 // (behind the three levels of matrix powers)
 }
 
 #define WS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SSFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
@@ -578,7 +607,8 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
     WS_TRY(w.need(1, sizeof(double) * (size_t)m * rows * CH));
     WS_TRY(w.need(2, sizeof(double) * (size_t)ngroups * kGroup * rows * CH * K));
     WS_TRY(w.need(3, sizeof(double) * (size_t)ngroups * rows * CH * K));
-    const size_t tab_doubles = (size_t)3 * (kWave + 1) * K * K;
+    const size_t pow_doubles = (size_t)3 * (kWave + 1) * K * K;
+    const size_t tab_doubles = pow_doubles + (size_t)K * kChunk;          // matrix powers, then G
     WS_TRY(w.need(5, sizeof(double) * (tab_doubles + K)));
     // tables + zi: rebuilt only when the filter changes
     std::vector<double> key(sos_key, sos_key + 6 * NS);
@@ -595,6 +625,7 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
     const double* d_pw = w.buf[5];
     const double* d_pwG = w.buf[5] + (size_t)(kWave + 1) * K * K;
     const double* d_pwH = w.buf[5] + (size_t)2 * (kWave + 1) * K * K;
+    const double* d_G = w.buf[5] + pow_doubles;
     const double* d_zi = w.buf[5] + tab_doubles;
     const double* d_x = x;
     double* d_out = y;
@@ -613,7 +644,7 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
     for (int dir = 0; dir < 2; ++dir) {
         p.backward = dir;
         p.src = dir == 0 ? d_x : d_y1;
-        hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_pw, d_E, d_T);
+        hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, p, nchunks, ngroups, d_pw, d_G, d_E, d_T);
         hipLaunchKernelGGL((k_apply<NS, CH, W>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
                            (const double*)d_T, d_y1, d_out);
         WS_TRY(hipGetLastError());

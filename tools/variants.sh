@@ -9,15 +9,16 @@ OUT=$ROOT/build/var
 SRC="ssfm_host.hip sos_filter.hip frontend.hip device_mem.hip chirpz.hip transmitter.hip prbs.hip"
 mode=$1; shift
 if [ "$mode" = build ]; then
-  # only ssfm_host.hip sees the flags: it is compiled per variant and linked with the product's other objects (build/obj)
+  # one translation unit sees the flags (VSRC, default ssfm_host.hip): it is compiled per variant and linked with the product's other objects (build/obj)
+  VSRC=${VSRC:-ssfm_host.hip}
   mkdir -p $OUT
   make -s -j8 -C $ROOT/opticomlib_amd/csrc > /dev/null || exit 1
-  OTHERS=$(for f in $SRC; do [ $f = ssfm_host.hip ] || echo $ROOT/build/obj/${f%.hip}.o; done)
+  OTHERS=$(for f in $SRC; do [ $f = $VSRC ] || echo $ROOT/build/obj/${f%.hip}.o; done)
   n=0
   for v in "$@"; do
     name=${v%%:*}; flags=$(echo ${v#*:} | tr '@' ' ')
-    ( cd $ROOT/opticomlib_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include $flags -c -o $OUT/host_$name.o ssfm_host.hip 2>$OUT/$name.log \
-      && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/_ssfm_$name.so $OUT/host_$name.o $OTHERS 2>>$OUT/$name.log && rm -f $OUT/host_$name.o && echo built $name || { echo FAILED $name; tail -5 $OUT/$name.log; } ) &
+    ( cd $ROOT/opticomlib_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include $flags -c -o $OUT/obj_$name.o $VSRC 2>$OUT/$name.log \
+      && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/_ssfm_$name.so $OUT/obj_$name.o $OTHERS 2>>$OUT/$name.log && rm -f $OUT/obj_$name.o && echo built $name || { echo FAILED $name; tail -5 $OUT/$name.log; } ) &
     n=$((n+1)); if [ $((n % 6)) = 0 ]; then wait; fi
   done; wait
 else
