@@ -225,6 +225,8 @@ template <typename T> struct PlanT : PlanBase {
     cx<T>* tw_small = nullptr;
     cx<T>* dsmall = nullptr;   // D~ in the one-line order (k_small_adapt)
     bool fused_ok = true;      // TM_MID_A may be used (env SSFM_ADAPT_FUSED=0, or a grid that once did not run as a whole, clears it)
+    bool lanes2_ok = false;    // adaptive runs use two lanes: opt-in (env SSFM_ADAPT_LANES=2) -- measured 43 against 33 us per step of the
+                               // one-stream engine at 2^20 x 2 (profiles/r03_adaptive_two_lanes.txt); a lane that once gave up waiting clears it
     cx<T>* fused_backup = nullptr;   // the input of a fused adaptive run, for the fall-back
     Tab stabs[kMaxTables] = {};
     int stab_rr = 0;
@@ -538,6 +540,7 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipMalloc(&dperm_fly, cb * n));
         }
         if (const char* e = std::getenv("SSFM_ADAPT_FUSED")) fused_ok = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_ADAPT_LANES")) lanes2_ok = std::atoi(e) >= 2;
         if (const char* e = std::getenv("SSFM_PHASE_TABLE")) phase_tables = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_FORCE_FLY")) force_fly = std::atoi(e) != 0;
         small = small_supported<T>((int)n);
@@ -700,7 +703,7 @@ template <typename T> struct PlanT : PlanBase {
 #endif
         (void)lane;
         a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
-        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0;
+        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0; a.lane = 0; a.lanes2 = 0;
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
@@ -933,6 +936,7 @@ template <typename T> struct PlanT : PlanBase {
         int step = 0;                  // index of the next step to launch
         StepState<T> now = {};         // state after the last launched step (host copy)
         bool fused = false;            // column kernel of at most 128 workgroups, no capture: END + BEGIN in one launch (TM_MID_A)
+        bool lanes2 = false;           // two row groups on two streams, joined only through the step control state (see adaptive_run)
         bool deferred = false;         // small plan without capture: nothing launched yet -- the first adaptive_run decides between
         int single_step = 0;           // the single-launch kernel (budget covers the run) and the chunked engine
         T phi_max = 0;
@@ -1005,6 +1009,22 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));
         }
         ar.tile_private = u16 && !capture && !ar.fused;
+        // Two lanes (round 3, opt-in): the rows only share the step size, so each half of them runs its own BEGIN_Y -> k_freq -> END_Y
+        // chain on its own stream, as the fixed-step lanes do; a lane's BEGIN(s + 1) waits INSIDE the kernel for the other lane's
+        // END(s) maxima (AdaptState::arrived) -- no host-side event between the streams inside a chunk (ten host calls per step made
+        // round 2's two-lane attempt host-bound).  Parity-green and SLOWER than one stream (43 vs 33 us per step at 2^20 x 2): meeting
+        // once per step keeps the lanes in step, so the same kernels of both run side by side -- what a two-row launch does anyway --
+        // and six launches per step instead of three reach the host's enqueue rate.  Fixed-step lanes gain because they may drift
+        // half a period apart.  Needs whole slot groups per END launch, at most half the chip's workgroup slots per launch (a waiting
+        // BEGIN must never hold every slot) and the tile-private layout; the input is kept for the case that a lane ever gives up
+        // waiting (then: one lane, for good).
+        ar.lanes2 = lanes2_ok && nlanes == 2 && ar.tile_private && !single_step && batch % 2 == 0
+                    && ((long long)(N2 / cols_per_tile<T>()) * (batch / 2)) % kAdaptSlots == 0 && (long long)(N2 / cols_per_tile<T>()) * (batch / 2) <= 256;
+        if (ar.lanes2) {
+            const size_t fb = sizeof(cx<T>) * n * batch;
+            if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
+            HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));
+        }
         return SSFM_OK;
     }
 
@@ -1040,6 +1060,7 @@ template <typename T> struct PlanT : PlanBase {
             ar.fused = false;
             ar.tile_private = u16;
         }
+        if (ar.lanes2 && ar.step == 0 && budget < (int64_t)ar.max_steps) ar.lanes2 = false;      // (pieces: the one-stream engine)
         const int nrows = N1 * batch;
         const size_t fb = sizeof(cx<T>) * n * batch;
         char* snap = static_cast<char*>(snapshots);
@@ -1053,6 +1074,37 @@ template <typename T> struct PlanT : PlanBase {
         int chunk = snap ? 1 : estimate();
         while (!ar.now.done && ar.now.steps - first_step < budget) {
             if ((int64_t)chunk > budget - (ar.now.steps - first_step)) chunk = (int)(budget - (ar.now.steps - first_step));
+            if (ar.lanes2) {
+                // fork once per chunk; inside it the lanes meet only in device memory
+                const int rows = batch / 2;
+                HIP_TRY(hipEventRecord(fork_ev, stream));
+                HIP_TRY(hipStreamWaitEvent(lane_stream[1], fork_ev, 0));
+                for (int i = 0; i < chunk; ++i, ++ar.step) {
+                    // (kernel by kernel, lane by lane: the host enqueues a launch every few microseconds, and a lane whose kernels
+                    // were all enqueued after the other's would lag it by a whole step's worth of launches)
+                    for (int k = 0; k < 3; ++k)
+                        for (int g = 0; g < 2; ++g) {
+                            TimeArgs<T> tb = targs(ar.gamma, 0, 0, st, g * rows, g);
+                            tb.step = ar.step;
+                            tb.lane = g;
+                            tb.lanes2 = 1;
+                            tb.derive = i != 0;
+                            if (k == 0) {
+                                if (ar.step > 0) HIP_TRY((launch_time<T, TM_BEGIN_Y>(N1, rows, lane_stream[g], tb, E)));
+                                else HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], tb, E)));
+                            } else if (k == 1) {
+                                FreqArgs<T> fa = fargs_fly(0, st, g * rows, g);
+                                fa.step = ar.step;
+                                HIP_TRY((launch_freq<T, FM_FLY>(N2, N1 * rows, lane_stream[g], fa, Ef_fly)));
+                            } else {
+                                HIP_TRY((launch_time<T, TM_END_Y>(N1, rows, lane_stream[g], tb, E)));
+                            }
+                        }
+                    last_launches += 6;
+                }
+                HIP_TRY(hipEventRecord(lane_ev[1], lane_stream[1]));
+                HIP_TRY(hipStreamWaitEvent(stream, lane_ev[1], 0));
+            } else
             for (int i = 0; i < chunk; ++i, ++ar.step) {
                 TimeArgs<T> tb = targs(ar.gamma, 0, 0, st), te = tb;
                 tb.step = te.step = ar.step;
@@ -1079,12 +1131,13 @@ template <typename T> struct PlanT : PlanBase {
             unsigned gave_up = 0;
             HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur) + sizeof(StepState<T>) * (ar.step & 1),
                                    sizeof(ar.now), hipMemcpyDeviceToHost, stream));
-            if (ar.fused) HIP_TRY(hipMemcpyAsync(&gave_up, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(gave_up), hipMemcpyDeviceToHost, stream));
+            if (ar.fused || ar.lanes2) HIP_TRY(hipMemcpyAsync(&gave_up, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(gave_up), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (ar.fused && gave_up) {
-                // the grid did not run as a whole (another job holds CUs): the same run again on the three-launch engine
+            if ((ar.fused || ar.lanes2) && gave_up) {
+                // the grid did not run as a whole (another job holds CUs) / a lane waited in vain for the other: the same run again on
+                // the one-stream three-launch engine
                 const AdaptRun keep = ar;
-                fused_ok = false;
+                if (ar.fused) fused_ok = false; else lanes2_ok = false;
                 HIP_TRY(hipMemcpyAsync(F, fused_backup, fb, hipMemcpyDeviceToDevice, stream));
                 if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
                 chunk = estimate();

@@ -100,6 +100,7 @@ template <typename T> struct StepState {
     int steps;      // steps taken so far
 };
 constexpr int kAdaptSlots = 64;
+constexpr int kAdaptLanes = 2;
 template <typename T> struct AdaptState {
     T length;
     T phi_max;
@@ -108,7 +109,12 @@ template <typename T> struct AdaptState {
     int max_steps;
     int pad_;
     StepState<T> cur[2];
-    unsigned long long slots[2][kAdaptSlots];      // bit patterns of max |A|^2 (non-negative => monotone as integers)
+    unsigned long long slots[kAdaptLanes][2][kAdaptSlots];      // bit patterns of max |A|^2 (non-negative => monotone as integers); [lane][step parity][slot]
+    // two-lane adaptive runs (the polarisations of one field on two streams, ssfm_host.hip adaptive_run): workgroups of END
+    // that have delivered their maximum, per lane and slot, counted over the WHOLE run and never cleared inside it (a
+    // cleared counter could be read before its clearing: the lanes are not in step).  BEGIN(s) of one lane waits until the
+    // OTHER lane's counters show s complete ENDs; its own lane's END(s - 1) is an earlier kernel of its stream.
+    unsigned long long arrived[kAdaptLanes][kAdaptSlots];
     unsigned arrive[2];     // TM_MID_A: workgroups that have delivered their maximum for the step of this parity
     unsigned error;         // TM_MID_A: a workgroup gave up waiting (the GPU did not run the whole grid at once): the host falls back
     long long patience;     // TM_MID_A: ticks of the 100 MHz clock a workgroup waits for the others (20 ms; tests set 0)
@@ -207,6 +213,8 @@ template <typename T> struct TimeArgs {
     int Qf;                   // threads per row of k_freq (U16 layout: which columns form a tile)
     int step;                 // adaptive mode: index of the step this launch belongs to (its state is cur[step & 1])
     int derive;               // adaptive BEGIN: 1 = derive the step's state from the previous step's (see AdaptState)
+    int lane;                 // adaptive: which set of slots this launch's rows deliver their maxima to (0 in single-lane runs)
+    int lanes2;               // adaptive, two lanes: END counts its arrivals, a deriving BEGIN waits for the other lane's (AdaptState::arrived)
     SSFM_TRACE_ARGS
 };
 
@@ -466,8 +474,14 @@ template <typename T> __device__ __forceinline__ StepState<T> step_advance(const
     return n;
 }
 // maximum over the 64 slots, by one wavefront (every lane gets it)
-__device__ __forceinline__ unsigned long long slots_max(const unsigned long long* slots) {
-    unsigned long long mb = slots[threadIdx.x & (kAdaptSlots - 1)];
+// (both lanes' sets: a single-lane run leaves the second lane's at zero.  Agent-scope loads: in a two-lane run the other
+// lane's END may have written its slots -- with memory-side atomics -- after THIS kernel started, so a line of them in this
+// XCD's L2 or this CU's L1 may be two steps old)
+template <typename T> __device__ __forceinline__ unsigned long long slots_max(const AdaptState<T>* st, int parity) {
+    const int i = threadIdx.x & (kAdaptSlots - 1);
+    unsigned long long mb = __hip_atomic_load(&st->slots[0][parity][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long m1 = __hip_atomic_load(&st->slots[1][parity][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mb = m1 > mb ? m1 : mb;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(mb, o);
@@ -479,7 +493,7 @@ __device__ __forceinline__ unsigned long long slots_max(const unsigned long long
 // state is not in cur[] yet.
 template <typename T> __device__ __forceinline__ StepState<T> step_state(const AdaptState<T>* st, int step, bool derive) {
     if (!derive) return st->cur[step & 1];
-    return step_advance<T>(st, st->cur[(step - 1) & 1], slots_max(st->slots[(step - 1) & 1]));
+    return step_advance<T>(st, st->cur[(step - 1) & 1], slots_max<T>(st, (step - 1) & 1));
 }
 
 
@@ -620,6 +634,27 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         }
         hh_prev = S_this.h * (T)0.5;
     } else if (a.st != nullptr && MODE != TM_UNPACK) {
+        if (FWD && a.derive != 0 && a.lanes2 != 0) {
+            // two-lane run: the other lane's END(step - 1) must have delivered all its maxima.  One wavefront polls the other
+            // lane's 64 arrival counters (one load instruction per poll) until each shows `step` complete ENDs; never longer
+            // than the patience of AdaptState (then: error flag, the host repeats the run on one lane).
+            __shared__ int s_lane_ok;
+            if (tid < 64) {
+                const unsigned long long want = (unsigned long long)a.step * (gridDim.x / kAdaptSlots);
+                const unsigned long long* cnt = a.st->arrived[a.lane ^ 1];
+                const long long t0 = wall_clock64();
+                int good = 0;
+                for (;;) {
+                    const unsigned long long got = __hip_atomic_load(&cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(got >= want)) { good = 1; break; }
+                    if (wall_clock64() - t0 > a.st->patience) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (tid == 0) { s_lane_ok = good; if (!good) atomicExch(&a.st->error, 1u); }
+            }
+            __syncthreads();
+            if (!s_lane_ok) return;
+        }
         const StepState<T> S = step_state<T>(a.st, a.step, FWD && a.derive != 0);
         if (FWD && blockIdx.x == 0 && tid == 0) {
             // workgroup 0 records the state of this step (BEGIN is the first kernel of a step) and empties the slots its END fills
@@ -628,7 +663,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
                 if (!a.st->cur[(a.step - 1) & 1].done) a.zlog[S.steps] = S.z;
             }
         }
-        if (FWD && blockIdx.x == 0 && tid < kAdaptSlots) a.st->slots[a.step & 1][tid] = 0ull;
+        if (FWD && blockIdx.x == 0 && tid < kAdaptSlots) a.st->slots[a.lane][a.step & 1][tid] = 0ull;
         if (S.done) return;
         hh_prev = hh_next = S.h * (T)0.5;
     }
@@ -699,7 +734,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
                 T m = wave_max_a[0];
 #pragma unroll
                 for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
-                atomicMax(&a.st->slots[set][blockIdx.x % kAdaptSlots], float_bits<T>(m));
+                atomicMax(&a.st->slots[0][set][blockIdx.x % kAdaptSlots], float_bits<T>(m));
                 __hip_atomic_fetch_add(&a.st->arrive[set], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 const long long t0 = wall_clock64();                  // 100 MHz
                 for (;;) {
@@ -711,7 +746,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             good = __shfl(good, 0);
             unsigned long long mb = 0ull;
             if (good) {
-                mb = __hip_atomic_load(&a.st->slots[set][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mb = __hip_atomic_load(&a.st->slots[0][set][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     const unsigned long long other = __shfl_xor(mb, o);
@@ -730,7 +765,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         if (blockIdx.x == 0) {
             // workgroup 0 records the state of the next step and empties what the next step's launch will fill
             if (tid == 0) { a.st->cur[(a.step + 1) & 1] = Sn; a.zlog[Sn.steps] = Sn.z; a.st->arrive[(a.step + 1) & 1] = 0u; }
-            if (tid < kAdaptSlots) a.st->slots[(a.step + 1) & 1][tid] = 0ull;
+            if (tid < kAdaptSlots) a.st->slots[0][(a.step + 1) & 1][tid] = 0ull;
         }
         fwd_active = !Sn.done;
         hh_next = Sn.h * (T)0.5;
@@ -810,7 +845,8 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
                 T m = wave_max[0];
 #pragma unroll
                 for (int w = 1; w < NWAVES; ++w) m = wave_max[w] > m ? wave_max[w] : m;
-                atomicMax(&a.st->slots[a.step & 1][blockIdx.x % kAdaptSlots], float_bits<T>(m));
+                atomicMax(&a.st->slots[a.lane][a.step & 1][blockIdx.x % kAdaptSlots], float_bits<T>(m));
+                if (a.lanes2) __hip_atomic_fetch_add(&a.st->arrived[a.lane][blockIdx.x % kAdaptSlots], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         SSFM_TRACE_END(a);
@@ -1382,7 +1418,7 @@ template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long
     if (threadIdx.x == 0) {
         T m = wave_max[0];
         for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) m = wave_max[w] > m ? wave_max[w] : m;
-        atomicMax(&st->slots[1][blockIdx.x % kAdaptSlots], float_bits<T>(m));       // (the slots "before step 0")
+        atomicMax(&st->slots[0][1][blockIdx.x % kAdaptSlots], float_bits<T>(m));       // (the slots "before step 0")
     }
 }
 
@@ -1391,8 +1427,9 @@ template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long
 // the first BEGIN of the next chunk.
 template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog, int phase, int single_step, int step) {
     if (phase == 0) {
-        const unsigned long long mb = slots_max(st->slots[1]);
-        if (threadIdx.x < kAdaptSlots) { st->slots[0][threadIdx.x] = 0ull; st->slots[1][threadIdx.x] = 0ull; }
+        const unsigned long long mb = slots_max<T>(st, 1);
+        if (threadIdx.x < kAdaptSlots)
+            for (int l = 0; l < kAdaptLanes; ++l) { st->slots[l][0][threadIdx.x] = 0ull; st->slots[l][1][threadIdx.x] = 0ull; }
         if (threadIdx.x != 0) return;
         T h;
         if (single_step) h = st->length;

@@ -654,6 +654,71 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
             assert relmax(f1, ref) < TOL_1000
 
 
+@pytest.mark.parametrize("log2n", [19, 20])
+def test_two_lane_adaptive_run_against_the_one_stream_engine(log2n, monkeypatch):
+    """An adaptive run of a dual-polarisation field of 2^19 samples or more drives the polarisations on two streams, as the
+    fixed-step runs do; they share nothing but the step size, which a lane's BEGIN derives from BOTH lanes' maxima after waiting
+    inside the kernel for the other lane's END (AdaptState::arrived).  SSFM_ADAPT_LANES=1 at plan creation keeps the one-stream
+    engine.  Same maxima, same rule, the same kernels row by row: identical z logs and fields, bit for bit; against the oracle."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=70 + log2n, power_w=10e-3)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    res = {}
+    for lanes in ("2", "1"):
+        monkeypatch.setenv("SSFM_ADAPT_LANES", lanes)
+        p = _lib.Plan(n, 2, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            for rep in range(2):
+                p.set_field(a)
+                steps, z, _ = p.propagate_adaptive(1.3, 3.0, 0.004, False)
+            res[lanes] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
+        finally:
+            p.close()
+    s2, z2, f2, l2 = res["2"]
+    s1, z1, f1, l1 = res["1"]
+    assert s2 == s1 > 8 and abs(z2[-1] - 3.0) < 1e-5
+    assert l2 >= 6 * s2 and l1 < 3 * s1 + 40           # six launches per step on two streams, three on one
+    np.testing.assert_array_equal(z2, z1)
+    np.testing.assert_array_equal(f2, f1)
+    if log2n == 19:
+        zr, Ar = orc.fiber_c64(a, gv.dt, 3.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.004, return_steps=True)
+        assert abs(len(zr) - 1 - s2) <= 1
+        k = min(len(zr), len(z2), 8)
+        np.testing.assert_allclose(z2[:k], zr[:k], rtol=2e-5)
+        assert relmax(f2, Ar[-1]) < TOL_100
+
+
+def test_two_lane_adaptive_run_without_patience_still_gives_the_one_stream_result(monkeypatch):
+    """A lane never waits longer than its patience for the other one; with none at all a lane that finds the other's maxima
+    missing gives up at once, the plan restores the input and repeats the run on one stream.  Whichever way each run goes,
+    the result is the one-stream result."""
+    n = 1 << 19
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=5, power_w=10e-3)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    monkeypatch.setenv("SSFM_ADAPT_LANES", "1")
+    q = _lib.Plan(n, 2, _lib.C64)
+    try:
+        q.set_linear_operator(D); q.set_field(a)
+        s0, z0, _ = q.propagate_adaptive(1.3, 3.0, 0.004, False)
+        f0 = q.get_field()
+    finally:
+        q.close()
+    monkeypatch.setenv("SSFM_ADAPT_LANES", "2")
+    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
+    p = _lib.Plan(n, 2, _lib.C64)
+    try:
+        p.set_linear_operator(D)
+        for rep in range(3):
+            p.set_field(a)
+            s1, z1, _ = p.propagate_adaptive(1.3, 3.0, 0.004, False)
+            assert s1 == s0 and np.array_equal(z1, z0) and np.array_equal(p.get_field(), f0)
+    finally:
+        p.close()
+
+
 def test_fused_adaptive_kernel_gives_up_and_the_run_falls_back(monkeypatch):
     """A workgroup of the fused kernel never waits longer than its patience for the others (a GPU shared with another job
     may not run the whole grid at once).  With no patience at all some workgroups give up: the plan restores the input, runs
