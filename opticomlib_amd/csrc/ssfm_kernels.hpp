@@ -31,6 +31,12 @@
 #ifndef SSFM_ABL_NO_NL
 #define SSFM_ABL_NO_NL 0
 #endif
+#ifndef SSFM_LATE_TAB
+#define SSFM_LATE_TAB 0
+#endif
+#ifndef SSFM_LATE_P
+#define SSFM_LATE_P 1
+#endif
 // 1: form the inter-pass twiddles in the kernel from two small tables (U16 plans); 0: stream the N-entry table.
 // One complex multiply per point against 8 bytes per point of table traffic: 20.8 vs 21.6 us per step alone, 18.1 vs
 // 20.7 together with the memory policy below (profiles/r02_ab_u16_sc1_twnc.txt)
@@ -613,14 +619,20 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             w[2 * g + 1] = mk<T>(q.z, q.w);
         }
     }
-    if (INV) {
+    // SSFM_LATE_P: |A|^2 of the step's start is only needed after the inverse transform: its loads are issued after the
+    // transform's first stage instead of with the field loads -- a smaller burst at the head of the kernel, which the tail of the
+    // other lane's kernel queues behind (launch timeline: the last workgroup of a launch ends 2-3 us after the first).  Six
+    // interleaved rounds, 2^20 x 2: 16.97 against 17.52 us per step (profiles/r03_ablation_and_knobs.txt)
+    auto load_pold = [&]() {
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
             if (SSFM_ABL_NO_P) q = (T)1e-3; else q = stream_load<stream_policy<T, U16>()>(&Pb[g * PSTR]);
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
-    }
+    };
+    constexpr bool LATE_P = SSFM_LATE_P != 0 && MODE == TM_MID && U16;
+    if (INV && !LATE_P) load_pold();
     // The step control state (adaptive runs) is read HERE, after every global load of the tile has been issued: it was written
     // by the previous launch, so its load is a miss of ~2 us that would otherwise stand in front of the whole kernel.  (A launch
     // queued beyond the end of the run returns now; its loads went to registers only.)
@@ -698,7 +710,8 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         }
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmulc(v[t], w[t]);
-        if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
+        if constexpr (LATE_P) fft_line_hook<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw, load_pold);
+        else if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
     }
     // v = time-domain samples A(n1, n2).  Nonlinear operator (reference devices.py:1175-1181):
     // the second half step of the step being finished uses the |A|^2 of its START (pold), the
@@ -993,7 +1006,9 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
     unsigned pu[E];
-    if (MODE == FM_PHASE) {
+    // SSFM_LATE_TAB (experiment): the phase loads are issued after the first stage of the forward transform instead of with the
+    // field loads -- a smaller burst at the head of the kernel, which the tail of the other lane's kernel queues behind
+    auto load_phases = [&]() {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4* __restrict__ P4 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(a.tab) + (long long)k1 * N2) + j;
 #pragma unroll
@@ -1002,6 +1017,9 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
             if (SSFM_ABL_NO_TAB) q = 0x12345678u; else q = P4[g * Q];
             pu[4 * g] = q.x; pu[4 * g + 1] = q.y; pu[4 * g + 2] = q.z; pu[4 * g + 3] = q.w;
         }
+    };
+    if (MODE == FM_PHASE) {
+        if (!SSFM_LATE_TAB) load_phases();
     } else if (MODE != FM_FWD_ONLY) {
         typedef T m4_t __attribute__((ext_vector_type(4)));
         const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(trow) + j;
@@ -1026,6 +1044,9 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 #endif
     if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
+    if (MODE == FM_PHASE && SSFM_LATE_TAB) {
+        fft_line_hook<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw, load_phases);
+    } else
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll

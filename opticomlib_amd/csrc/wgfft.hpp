@@ -444,4 +444,17 @@ __device__ __forceinline__ void fft_line(cx<T> (&v)[E], cx<T>* lds, const int BU
     if constexpr (M > 3) fft_stage<T, L, E, DIR, 3, XP, IDX>(v, lds, BUF, j, idx, tw);
 }
 
+// The same with a hook between the first stage and the rest: `mid()` runs after the first stage's butterflies and LDS writes
+// (a place to issue loads whose data is only needed after the transform).
+template <typename T, int L, int E, int DIR, int XP, typename IDX, typename F>
+__device__ __forceinline__ void fft_line_hook(cx<T> (&v)[E], cx<T>* lds, const int BUF, const int j, const IDX& idx,
+                                              const LineTw<T, L, E>& tw, F&& mid) {
+    constexpr int M = fft_nstages(L, E);
+    fft_stage<T, L, E, DIR, 0, XP, IDX>(v, lds, BUF, j, idx, tw);
+    mid();
+    if constexpr (M > 1) fft_stage<T, L, E, DIR, 1, XP, IDX>(v, lds, BUF, j, idx, tw);
+    if constexpr (M > 2) fft_stage<T, L, E, DIR, 2, XP, IDX>(v, lds, BUF, j, idx, tw);
+    if constexpr (M > 3) fft_stage<T, L, E, DIR, 3, XP, IDX>(v, lds, BUF, j, idx, tw);
+}
+
 }  // namespace ssfm

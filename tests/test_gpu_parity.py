@@ -506,6 +506,7 @@ def test_single_launch_engine_against_the_two_kernel_engine(log2n, prec, monkeyp
     hs = np.array([0.5] * 7 + [0.25, 0.5, 0.125, 0.5, 0.5, 0.03125], dtype=np.float32 if prec == _lib.C64 else np.float64)   # 4 distinct sizes
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
     got = {}
+    monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)               # (that diagnostic knob takes the tables, and with them this engine, away)
     for small in ("1", "0"):
         monkeypatch.setenv("SSFM_SMALL", small)
         p = _lib.Plan(n, 3, prec)
@@ -594,6 +595,7 @@ def test_single_launch_capture_against_the_two_kernel_engine(prec, monkeypatch):
     hs = np.array([0.5, 0.5, 0.25, 0.5, 0.125, 0.5, 0.5], dtype=np.float32 if prec == _lib.C64 else np.float64)
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
     got = {}
+    monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)
     for small in ("1", "0"):
         monkeypatch.setenv("SSFM_SMALL", small)
         p = _lib.Plan(n, 2, prec)
@@ -626,6 +628,7 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
     a = workloads.qpsk_field(n, seed=60 + log2n, power_w=10e-3)[:rows]
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
     res = {}
+    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)     # (the knob suite runs everything without patience too)
     for fused in ("1", "0"):
         monkeypatch.setenv("SSFM_ADAPT_FUSED", fused)
         p = _lib.Plan(n, rows, prec)
@@ -665,6 +668,8 @@ def test_two_lane_adaptive_run_against_the_one_stream_engine(log2n, monkeypatch)
     a = workloads.qpsk_field(n, seed=70 + log2n, power_w=10e-3)
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
     res = {}
+    monkeypatch.setenv("SSFM_LANES", "2")                              # (whatever the suite runs under)
+    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
     for lanes in ("2", "1"):
         monkeypatch.setenv("SSFM_ADAPT_LANES", lanes)
         p = _lib.Plan(n, 2, _lib.C64)
@@ -706,6 +711,7 @@ def test_two_lane_adaptive_run_without_patience_still_gives_the_one_stream_resul
         f0 = q.get_field()
     finally:
         q.close()
+    monkeypatch.setenv("SSFM_LANES", "2")
     monkeypatch.setenv("SSFM_ADAPT_LANES", "2")
     monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
     p = _lib.Plan(n, 2, _lib.C64)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# The whole GPU parity suite under every documented environment knob, then the randomised stress runs (tests/diag).
+#   bash tools/knob_suite.sh TAG      -> gpurun_out/TAG_knob_suite.txt, gpurun_out/TAG_fuzz.txt
+set -u
+TAG=${1:-knobs}
+mkdir -p gpurun_out
+OUT=gpurun_out/${TAG}_knob_suite.txt
+: > $OUT
+for k in "SSFM_LANES=1" "SSFM_GRAPH=1" "SSFM_GRAPH=auto" "SSFM_E=8" "SSFM_STAGGER=1" "SSFM_SMALL=0" "SSFM_ADAPT_FUSED=0" \
+         "SSFM_FUSED_PATIENCE_TICKS=-1" "SSFM_PHASE_TABLE=0" "SSFM_FORCE_FLY=1" "SSFM_ADAPT_LANES=2"; do
+  echo "== $k" >> $OUT; env $k timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -2 >> $OUT
+done
+cat $OUT
+F=gpurun_out/${TAG}_fuzz.txt
+{ echo "== tests/diag/fuzz_many.py 400 2026"; timeout 1500 python tests/diag/fuzz_many.py 400 2026 2>&1 | tail -8;
+  echo "== tests/diag/fuzz_filters.py"; timeout 600 python tests/diag/fuzz_filters.py 2>&1 | tail -4;
+  echo "== tests/diag/fuzz_misc.py"; timeout 600 python tests/diag/fuzz_misc.py 2>&1 | tail -6; } > $F 2>&1
+cat $F
