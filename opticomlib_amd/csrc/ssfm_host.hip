@@ -259,18 +259,6 @@ template <typename T> struct PlanT : PlanBase {
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
     hipEvent_t fork_ev = nullptr;
-    // chained launches of the fixed-step lanes (ssfm_kernels.hpp ChainArgs): a second stream per lane, the lanes' arrival counters
-    // and the error word in device memory, its pinned host copy, and what a repeat of the run with plain launches needs
-    struct ChainState { unsigned long long done[kMaxLanes][kChainSlots]; unsigned error; unsigned pad_[3]; };
-    hipStream_t lane_stream2[kMaxLanes] = {};
-    hipEvent_t lane_ev2[kMaxLanes] = {};
-    ChainState* chain_st = nullptr;
-    unsigned* chain_err_host = nullptr;
-    bool chain_ok = true;          // env SSFM_CHAIN=0, or a run whose wait once ran out of patience, clears it
-    bool chain_pending = false;    // a chained run is in flight: its error word is looked at by the next call that uses the plan
-    std::vector<T> chain_sched;
-    double chain_gamma = 0;
-    long long chain_patience = 2000000ll;
     // per-lane pools of events (profiling).  mode 1: an event after every launch (per-class times, but
     // the marker packets slow a launch-dense run by ~30 %); mode 2: an event after every 64th launch
     // (negligible overhead; the interval is split between the classes by launch count); mode 3: after every
@@ -452,12 +440,6 @@ template <typename T> struct PlanT : PlanBase {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
             if (lane_stream[g]) (void)hipStreamDestroy(lane_stream[g]);
         }
-        for (int g = 0; g < kMaxLanes; ++g) {
-            if (lane_ev2[g]) (void)hipEventDestroy(lane_ev2[g]);
-            if (lane_stream2[g]) (void)hipStreamDestroy(lane_stream2[g]);
-        }
-        (void)hipFree(chain_st);
-        if (chain_err_host) (void)hipHostFree(chain_err_host);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         for (auto& p : prof) {
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
@@ -529,17 +511,6 @@ template <typename T> struct PlanT : PlanBase {
         for (int g = 1; g < nlanes; ++g) {
             HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, prio_hi));
             HIP_TRY(hipEventCreateWithFlags(&lane_ev[g], hipEventDisableTiming));
-        }
-        if (const char* e = std::getenv("SSFM_CHAIN")) chain_ok = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) chain_patience = std::atoll(e);
-        if (nlanes > 1 && sizeof(T) == 4) {
-            for (int g = 0; g < nlanes; ++g) {
-                HIP_TRY(hipStreamCreateWithPriority(&lane_stream2[g], hipStreamNonBlocking, prio_hi));
-                HIP_TRY(hipEventCreateWithFlags(&lane_ev2[g], hipEventDisableTiming));
-            }
-            HIP_TRY(hipMalloc(&chain_st, sizeof(ChainState)));
-            HIP_TRY(hipHostMalloc(&chain_err_host, sizeof(unsigned)));
-            *chain_err_host = 0u;
         }
         const size_t cb = sizeof(cx<T>);
         HIP_TRY(hipMalloc(&F, cb * n * batch));
@@ -656,25 +627,7 @@ template <typename T> struct PlanT : PlanBase {
     }
 #endif
 
-    int use_device() {
-        HIP_TRY(hipSetDevice(device));
-        return chain_pending ? finish_chain() : (int)SSFM_OK;
-    }
-    // A chained run is asynchronous like every run; whether one of its waits ran out of patience is known once it has
-    // finished.  The next call that uses the plan looks: on an error the input is restored and the run repeated with plain
-    // launches (and the plan keeps to them).
-    int finish_chain() {
-        chain_pending = false;
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (*chain_err_host == 0u) return SSFM_OK;
-        *chain_err_host = 0u;
-        chain_ok = false;
-        HIP_TRY(hipMemcpyAsync(F, fused_backup, sizeof(cx<T>) * n * batch, hipMemcpyDeviceToDevice, stream));
-        const std::vector<T> sched = chain_sched;
-        if (int rc = propagate_fixed(chain_gamma, sched.data(), (int64_t)sched.size(), nullptr)) return rc;
-        HIP_TRY(hipStreamSynchronize(stream));
-        return SSFM_OK;
-    }
+    int use_device() { HIP_TRY(hipSetDevice(device)); return SSFM_OK; }
 
     int set_operator(const void* host) {
         if (int rc = use_device()) return rc;
@@ -751,7 +704,6 @@ template <typename T> struct PlanT : PlanBase {
         (void)lane;
         a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0; a.lane = 0; a.lanes2 = 0;
-        a.chain = ChainArgs{nullptr, 0ull, nullptr, 0ll, 0};
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
@@ -761,7 +713,6 @@ template <typename T> struct PlanT : PlanBase {
 #endif
         (void)lane;
         a.F = Y + (size_t)row0 * n; a.tab = tab; a.tw2 = tw2; a.st = s; a.h = h; a.inv_n = inv_n(); a.N1 = N1; a.rows = 0; a.u16 = u16 ? 1 : 0; a.step = 0; a.amp = (T)0;
-        a.chain = ChainArgs{nullptr, 0ull, nullptr, 0ll, 0};
         return a;
     }
 
@@ -832,7 +783,7 @@ template <typename T> struct PlanT : PlanBase {
         const bool use_phase = use_tables && phase_tables && sizeof(T) == 4 && u16 && op_flat_re;
         if (use_tables && !go_small)
             if (int rc = tables_for(distinct, tabptr.data(), false, use_phase ? 1 : 0)) return rc;
-        auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_, const ChainArgs* ch = nullptr) -> hipError_t {
+        auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
             const int lane_ = rows > 0 ? row0 / rows : 0;
             ++last_launches;
             if (use_tables) {
@@ -841,15 +792,12 @@ template <typename T> struct PlanT : PlanBase {
                     if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
                 if (use_phase) {
                     FreqArgs<T> fa = fargs(tp, hs, nullptr, row0, lane_);
-                    if (ch) fa.chain = *ch;
                     // the modulus as the complex table forms it: e = exp(Re * h) with the product in T, then e * (1/N) (exact: N = 2^k)
                     const T xr = op_re0 * hs;
                     fa.amp = (T)std::exp((double)xr) * inv_n();
                     return launch_freq<T, FM_PHASE>(N2, N1 * rows, st_, fa, Ef);
                 }
-                FreqArgs<T> fa = fargs(tp, hs, nullptr, row0, lane_);
-                if (ch) fa.chain = *ch;
-                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fa, Ef);
+                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st_, fargs(tp, hs, nullptr, row0, lane_), Ef);
             }
             return launch_freq<T, FM_FLY>(N2, N1 * rows, st_, fargs_fly(hs, nullptr, row0, lane_), Ef_fly);
         };
@@ -858,75 +806,7 @@ template <typename T> struct PlanT : PlanBase {
         const T half = (T)0.5;
         for (auto& p : prof) p.n = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
-        // chained launches: see ssfm_kernels.hpp ChainArgs.  Both kernels' grids must fill whole counter slots.
-        const long long grid_t = (long long)(N2 / cols_per_tile<T>()) * (batch / nlanes);
-        const long long grid_f = (long long)N1 * (batch / nlanes) / ::freq_rows(N2, Ef);
-        const bool use_chain = chain_ok && chain_st != nullptr && nlanes > 1 && u16 && use_tables && !profiling && graph_policy == 0
-                               && snapshots == nullptr && !go_small && nsteps >= 4 && grid_t % kChainSlots == 0 && grid_f % kChainSlots == 0;
-        auto enqueue_chained = [&]() -> int {
-            const int rows = batch / nlanes;
-            const size_t fb = sizeof(cx<T>) * n * batch;
-            if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
-            HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));          // for a repeat with plain launches
-            HIP_TRY(hipMemsetAsync(chain_st, 0, sizeof(ChainState), stream));
-            HIP_TRY(hipEventRecord(fork_ev, stream));
-            for (int g = 0; g < nlanes; ++g) {
-                if (g > 0) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
-                HIP_TRY(hipStreamWaitEvent(lane_stream2[g], fork_ev, 0));
-            }
-            unsigned long long expect[kMaxLanes] = {};
-            unsigned long long* done0 = reinterpret_cast<unsigned long long*>(chain_st);
-            unsigned* err = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(chain_st) + offsetof(ChainState, error));
-            auto link = [&](int g, long long grid, bool signal) {
-                ChainArgs c{done0 + (size_t)g * kChainSlots, expect[g], err, chain_patience, signal ? 1 : 0};
-                if (signal) expect[g] += (unsigned long long)(grid / kChainSlots);
-                return c;
-            };
-            auto sub = [&](int g, int64_t i) { return (i & 1) ? lane_stream2[g] : lane_stream[g]; };
-            // kernel 0 of a lane: BEGIN.  Its successor starts behind an EVENT (once per run): both would be dispatchable at the same
-            // moment otherwise, and a waiting successor that took every free workgroup slot would lock its predecessor out.
-            for (int g = 0; g < nlanes; ++g) {
-                ++last_launches;
-                TimeArgs<T> ta = targs(gamma, 0, h[0] * half, nullptr, g * rows, g);
-                ta.chain = link(g, grid_t, true);
-                HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, sub(g, 0), ta, E)));
-                HIP_TRY(hipEventRecord(lane_ev2[g], sub(g, 0)));
-                HIP_TRY(hipStreamWaitEvent(sub(g, 1), lane_ev2[g], 0));
-            }
-            int64_t i = 1;                         // index of the next kernel in a lane's chain
-            for (int64_t s2 = 0; s2 < nsteps; ++s2) {
-                for (int g = 0; g < nlanes; ++g) {
-                    const ChainArgs c = link(g, grid_f, true);
-                    HIP_TRY(freq_rows(h[s2], g * rows, rows, sub(g, i), &c));
-                }
-                ++i;
-                for (int g = 0; g < nlanes; ++g) {
-                    ++last_launches;
-                    if (s2 + 1 < nsteps) {
-                        TimeArgs<T> ta = targs(gamma, h[s2] * half, h[s2 + 1] * half, nullptr, g * rows, g);
-                        ta.chain = link(g, grid_t, true);
-                        HIP_TRY((launch_time<T, TM_MID>(N1, rows, sub(g, i), ta, E)));
-                    } else {
-                        TimeArgs<T> ta = targs(gamma, h[s2] * half, 0, nullptr, g * rows, g);
-                        ta.chain = link(g, grid_t, false);
-                        HIP_TRY((launch_time<T, TM_END>(N1, rows, sub(g, i), ta, E)));
-                    }
-                }
-                ++i;
-            }
-            for (int g = 0; g < nlanes; ++g) {
-                if (g > 0) { HIP_TRY(hipEventRecord(lane_ev[g], lane_stream[g])); HIP_TRY(hipStreamWaitEvent(stream, lane_ev[g], 0)); }
-                HIP_TRY(hipEventRecord(lane_ev2[g], lane_stream2[g]));
-                HIP_TRY(hipStreamWaitEvent(stream, lane_ev2[g], 0));
-            }
-            HIP_TRY(hipMemcpyAsync(chain_err_host, err, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            chain_sched.assign(h, h + nsteps);
-            chain_gamma = gamma_d;
-            chain_pending = true;
-            return SSFM_OK;
-        };
         auto enqueue_steps = [&]() -> int {
-            if (use_chain) return enqueue_chained();
             if (nlanes > 1) {
                 const int rows = batch / nlanes;
                 HIP_TRY(hipEventRecord(fork_ev, stream));

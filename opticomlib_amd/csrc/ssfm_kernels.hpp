@@ -199,57 +199,6 @@ __host__ __device__ __forceinline__ long long time_tw_pos_u16(long long k1, long
     return ((tile * (E / 2) + (t >> 1)) * ((long long)Q1 * 16) + thread) * 2 + (t & 1);
 }
 
-// ---- "chained" launches of a fixed-step lane (round 3).  Consecutive kernels of a lane go to TWO streams in turn, with NO
-// stream dependency between them: kernel i + 1 is dispatched while kernel i still runs, takes the workgroup slots that kernel
-// i's early finishers leave (the last workgroup of a launch ends 2-3 us after the first, profiles/r03_launch_timeline.txt),
-// fetches what does not depend on kernel i (twiddles, operator table) and then waits IN the kernel until every workgroup of
-// kernel i has signalled: the dependent-launch gap (1.3-1.5 us), the dispatch ramp and the table latency disappear from the
-// lane's chain, which is what bounds a step (2 x (kernel + gap)).  Kernel i + 2 follows kernel i on its stream.
-//   producer: field stores are write-through (sc1) already; every wave drains them (s_waitcnt vmcnt(0)), the workgroup meets
-//             at a barrier, ONE lane adds 1 to the lane's counter of slot (block id mod 64) -- counted over the whole run,
-//             never cleared inside it;
-//   consumer: one wavefront polls the 64 counters (one relaxed agent-scope load instruction per poll) until each shows
-//             `expect` arrivals, never longer than `patience` (then: error word, the host repeats the run with plain
-//             launches); the field is then read with sc1 loads only (buffer_load ... sc1: they bypass this CU's L1, which the
-//             kernel's own start could not have invalidated late enough) -- MI355X_MICROARCH.md "Valid forms", all-sc1 row.
-// The first kernel of a run waits for nothing; |A|^2 and the tables come from kernels that finished before this one was
-// dispatched (stream order) and keep their plain / non-temporal loads.
-struct ChainArgs {
-    unsigned long long* done;      // this lane's 64 arrival counters; nullptr: plain launches
-    unsigned long long expect;     // arrivals per counter that complete the previous kernel of the lane (0: nothing to wait for)
-    unsigned* error;
-    long long patience;            // ticks of the 100 MHz clock
-    int signal;                    // this kernel has a successor in the chain
-};
-constexpr int kChainSlots = 64;
-__device__ __forceinline__ bool chain_wait(const ChainArgs& c, int tid) {
-    __shared__ __attribute__((aligned(16))) int s_chain_ok[4];
-    if (tid < 64) {
-        const long long t0 = wall_clock64();
-        int good = 0;
-        for (;;) {
-            const unsigned long long got = __hip_atomic_load(&c.done[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(got >= c.expect)) { good = 1; break; }
-            if (wall_clock64() - t0 > c.patience) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (tid == 0) { s_chain_ok[0] = good; if (!good) atomicExch(c.error, 1u); }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // (no instruction: the loads below stay below)
-    return s_chain_ok[0] != 0;
-}
-__device__ __forceinline__ void chain_signal(const ChainArgs& c, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave: its write-through stores have landed
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(&c.done[blockIdx.x & (kChainSlots - 1)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// 16 bytes at byte offset `off` of the buffer behind `rsrc`, sc1 (agent-scope coherent, compiler-tracked)
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t load16_sc1(__amdgpu_buffer_rsrc_t rsrc, int off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
-}
-
 template <typename T> struct TimeArgs {
     cx<T>* F;                 // field in time order, batch rows of N (read by BEGIN, written by END)
     cx<T>* Y;                 // field in the half-transformed layout between the kernels.  Plain layout: Y == F, a tile
@@ -272,7 +221,6 @@ template <typename T> struct TimeArgs {
     int derive;               // adaptive BEGIN: 1 = derive the step's state from the previous step's (see AdaptState)
     int lane;                 // adaptive: which set of slots this launch's rows deliver their maxima to (0 in single-lane runs)
     int lanes2;               // adaptive, two lanes: END counts its arrivals, a deriving BEGIN waits for the other lane's (AdaptState::arrived)
-    ChainArgs chain;          // fixed-step lanes: chained launches (see ChainArgs)
     SSFM_TRACE_ARGS
 };
 
@@ -632,23 +580,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     cx<T> w[E];
     T pold[E];
     LineTw<T, N1, E> tw;
-    // chained launch that has a predecessor: the field is loaded after the wait below, with sc1 loads
-    const bool chain_on = U16 && sizeof(T) == 4 && (MODE == TM_BEGIN || MODE == TM_MID || MODE == TM_END) && a.chain.done != nullptr;
-    const bool chain_dep = chain_on && MODE != TM_BEGIN && a.chain.expect != 0;
-    auto load_field = [&](bool sc1) {
     if (U16 && MODE != TM_BEGIN) {               // half-transformed field, or the tile-private time-domain field: 16-byte units
-        if constexpr (sizeof(T) == 4) {
-            if (sc1) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Yb, 0, (int)(N * (long long)sizeof(cx<T>)), 0x00020000);
-#pragma unroll
-                for (int g = 0; g < E / 2; ++g) {
-                    const u32x4_t q = load16_sc1(rs, (offy + 2 * g * stride) * (int)sizeof(cx<T>));
-                    v[2 * g] = mk<T>(__uint_as_float(q.x), __uint_as_float(q.y));
-                    v[2 * g + 1] = mk<T>(__uint_as_float(q.z), __uint_as_float(q.w));
-                }
-                return;
-            }
-        }
 #pragma unroll
         for (int g = 0; g < E / 2; ++g) {
             const u4_t q = stream_load<true>(reinterpret_cast<const u4_t*>(&Yb[offy + 2 * g * stride]));
@@ -660,8 +592,6 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0 && MODE != TM_BEGIN)>(&src[off + t * stride]);
     }
-    };
-    if (!chain_dep) load_field(false);
     constexpr bool TWC = twn_compute<T, U16>();
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
     cx<T> wA = mk<T>((T)1, (T)0);
@@ -760,10 +690,6 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
         }
         line_twiddles_fetch<T, N1, E>(tw, j, ldsT);
-    }
-    if (chain_dep) {
-        if (!chain_wait(a.chain, tid)) return;
-        load_field(true);
     }
     if (MODE == TM_BEGIN_Y || MODE == TM_UNPACK) {
         // the exchange that undoes END_Y's: every thread gets its own column back
@@ -961,7 +887,6 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 #pragma unroll
         for (int t = 0; t < E; ++t) stream_store(&Yb[off + t * stride], cmul(v[t], w[t]));
     }
-    if (chain_on && a.chain.signal) chain_signal(a.chain, tid);
 #if SSFM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -981,7 +906,6 @@ template <typename T> struct FreqArgs {
     const AdaptState<T>* st; // FM_FLY: step size source when non-null (the state of step `step`)
     T h;                     // FM_FLY with st == nullptr
     T amp;                   // FM_PHASE: exp(Re D~ h) / N, the modulus of every table entry
-    ChainArgs chain;         // fixed-step lanes: chained launches (see ChainArgs)
     int step;
     T inv_n;
     int N1;
@@ -1071,23 +995,8 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     LineTw<T, N2, E> tw;
     SSFM_STAMP(0);
     typedef T u4_t __attribute__((ext_vector_type(4)));
-    const bool chain_on = U16 && sizeof(T) == 4 && (MODE == FM_TABLE || MODE == FM_PHASE) && a.chain.done != nullptr;
-    const bool chain_dep = chain_on && a.chain.expect != 0;
-    auto load_field = [&](bool sc1) {
     if (U16) {
         // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
-        if constexpr (sizeof(T) == 4) {
-            if (sc1) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Frow, 0, N2 * (int)sizeof(cx<T>), 0x00020000);
-#pragma unroll
-                for (int g = 0; g < E / 2; ++g) {
-                    const u32x4_t q = load16_sc1(rs, (g * Q + j) * 16);
-                    v[2 * g] = mk<T>(__uint_as_float(q.x), __uint_as_float(q.y));
-                    v[2 * g + 1] = mk<T>(__uint_as_float(q.z), __uint_as_float(q.w));
-                }
-                return;
-            }
-        }
 #pragma unroll
         for (int g = 0; g < E / 2; ++g) {
             const u4_t q = stream_load<true>(reinterpret_cast<const u4_t*>(Frow) + g * Q + j);
@@ -1098,8 +1007,6 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0)>(&Frow[j + t * Q]);
     }
-    };
-    if (!chain_dep) load_field(false);
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
     unsigned pu[E];
@@ -1139,10 +1046,6 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SSFM_STAMP(2);
 #endif
-    if (chain_dep) {
-        if (!chain_wait(a.chain, tid)) return;        // (its barrier also covers the LDS copy of the stage twiddles)
-        load_field(true);
-    } else
     if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
     if (MODE == FM_PHASE && SSFM_LATE_TAB) {
@@ -1189,7 +1092,6 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 #pragma unroll
         for (int t = 0; t < E; ++t) stream_store(&Frow[j + t * Q], v[t]);
     }
-    if (chain_on && a.chain.signal) chain_signal(a.chain, tid);
 #if SSFM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -657,74 +657,6 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
             assert relmax(f1, ref) < TOL_1000
 
 
-@pytest.mark.parametrize("log2n, rows", [(20, 2), (19, 2), (20, 4), (21, 2)])
-def test_chained_launches_against_plain_launches(log2n, rows, monkeypatch):
-    """Fixed-step runs on two lanes chain their kernels through device memory (ssfm_kernels.hpp ChainArgs): consecutive
-    kernels of a lane sit on two streams with no stream dependency, the later one waits in the kernel for the earlier one's
-    workgroups and reads the field with sc1 loads.  SSFM_CHAIN=0 at plan creation keeps plain dependent launches.  The same
-    kernels on the same data: bit-identical fields after 60 and after 61 steps (both parities of the chain), repeatedly."""
-    n = 1 << log2n
-    gv(**workloads.BENCH_GV)
-    a = np.concatenate([workloads.qpsk_field(n, seed=80 + k, power_w=4e-3) for k in range(rows // 2)]).astype(np.complex64)
-    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
-    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
-    monkeypatch.setenv("SSFM_LANES", "2")
-    monkeypatch.setenv("SSFM_GRAPH", "0")
-    got = {}
-    for chain in ("1", "0"):
-        monkeypatch.setenv("SSFM_CHAIN", chain)
-        p = _lib.Plan(n, rows, _lib.C64)
-        try:
-            p.set_linear_operator(D)
-            outs = []
-            for nsteps in (60, 61, 60):
-                hs = np.full(nsteps, 0.125, np.float32)
-                hs[-1] = 0.0625                                   # a second table for the last step
-                p.set_field(a)
-                p.propagate_fixed(1.3, hs)
-                outs.append((p.get_field(), p.last_propagate_ms()[1]))
-            got[chain] = outs
-        finally:
-            p.close()
-    for (f1, l1), (f0, l0) in zip(got["1"], got["0"]):
-        assert l1 == l0
-        np.testing.assert_array_equal(f1, f0)
-    np.testing.assert_array_equal(got["1"][0][0], got["1"][2][0])
-    if log2n == 19:
-        A = a.astype(np.complex64)
-        ref = orc.fiber_c64(A.reshape(rows, n)[:2], gv.dt, 60 * 0.125 - 0.0625, 0.2, -21.7, 0.13, 1.3, h=0.125)
-        assert relmax(got["1"][0][0][:2], ref) < TOL_100
-
-
-def test_chained_launches_without_patience_give_the_plain_result(monkeypatch):
-    """A chained kernel never waits longer than its patience; with none at all a kernel that finds its predecessor unfinished gives
-    up at once: the plan restores the input, repeats the run with plain launches and keeps to them.  Either way the result is
-    the plain one."""
-    n = 1 << 20
-    gv(**workloads.BENCH_GV)
-    a = workloads.qpsk_field(n, seed=9, power_w=4e-3).astype(np.complex64)
-    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
-    hs = np.full(40, 0.25, np.float32)
-    monkeypatch.setenv("SSFM_LANES", "2")
-    monkeypatch.setenv("SSFM_CHAIN", "0")
-    q = _lib.Plan(n, 2, _lib.C64)
-    try:
-        q.set_linear_operator(D); q.set_field(a); q.propagate_fixed(1.3, hs)
-        f0 = q.get_field()
-    finally:
-        q.close()
-    monkeypatch.setenv("SSFM_CHAIN", "1")
-    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
-    p = _lib.Plan(n, 2, _lib.C64)
-    try:
-        p.set_linear_operator(D)
-        for rep in range(3):
-            p.set_field(a); p.propagate_fixed(1.3, hs)
-            np.testing.assert_array_equal(p.get_field(), f0)
-    finally:
-        p.close()
-
-
 @pytest.mark.parametrize("log2n", [19, 20])
 def test_two_lane_adaptive_run_against_the_one_stream_engine(log2n, monkeypatch):
     """An adaptive run of a dual-polarisation field of 2^19 samples or more drives the polarisations on two streams, as the
