@@ -241,7 +241,9 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
     constexpr int kWaves = W, kGroup = kWave * W;
     __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
     __shared__ double lds_pw[(kScanSteps + 1) * K * K];
-    __shared__ double tot[kWaves][CH * K];
+    // (the wavefront totals go into each wavefront's OWN staging slice, which it no longer needs after its transposes: with a separate
+    // array three workgroups did not fit a CU's LDS, 3 x 54 400 B > 160 KiB.  Measured: no change in time -- the kernel is not short of
+    // resident workgroups, profiles/r03_sosfilt.txt)
     const int row = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const int ch = g * kGroup + tid;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
         for (int k = 0; k < K; ++k) {
             const double prev = __shfl_up(s[a][k], 1, kWave);
             ex[a][k] = lane ? prev : 0.0;
-            if (lane == kWave - 1) tot[wv][a * K + k] = s[a][k];
+            if (lane == kWave - 1) reinterpret_cast<double*>(lds_all[wv])[a * K + k] = s[a][k];
         }
     __syncthreads();
     // start state of this wavefront if the GROUP started from zero: ws_{w+1} = M^64 ws_w + tot_w
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
 #pragma unroll
         for (int a = 0; a < CH; ++a)
 #pragma unroll
-            for (int k = 0; k < K; ++k) ws[a][k] += tot[w][a * K + k];
+            for (int k = 0; k < K; ++k) ws[a][k] += reinterpret_cast<const double*>(lds_all[w])[a * K + k];
     }
     // e_c = M^lane ws + (wavefront-local exclusive prefix)
 #pragma unroll
@@ -341,13 +343,19 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
 #pragma unroll
             for (int a = 0; a < CH; ++a)
 #pragma unroll
-                for (int k = 0; k < K; ++k) To[a * K + k] = ws[a][k] + tot[kWaves - 1][a * K + k];
+                for (int k = 0; k < K; ++k) To[a * K + k] = ws[a][k] + reinterpret_cast<const double*>(lds_all[kWaves - 1])[a * K + k];
         }
     }
 }
 
+// SOS_APPLY_WAVES = 3 asks the register allocator for three workgroups per CU (230 -> 168 registers, 120 bytes of scratch per lane), so
+// that a 2^20 x 2 call's 683 workgroups would be resident at once instead of 512 + 171: measured SLOWER, 95.9 against 86.5 us of kernels per
+// call (profiles/r03_sosfilt.txt) -- the spills cost more than the second, third-full generation.
+#ifndef SOS_APPLY_WAVES
+#define SOS_APPLY_WAVES 2
+#endif
 template <int NS, int CH, int W>
-__global__ __launch_bounds__(kWave * W) void k_apply(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi,
+__global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <= 2 ? SOS_APPLY_WAVES : 1, 8))) void k_apply(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi,
                                                   const double* __restrict__ pw, const double* __restrict__ pwG, const double* __restrict__ pwH,
                                                   const double* __restrict__ E, const double* __restrict__ T,
                                                   double* __restrict__ y1, double* __restrict__ out) {
