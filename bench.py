@@ -393,8 +393,12 @@ def main():
             sparse = timed_pass(2)                         # one event per 64 launches: pooled average launch time, no perturbation
             sampled = timed_pass(3)                        # one bracketed launch of each kernel per 16 launches: per-kernel duration
             pooled_us = sum(v[1] for v in sparse.values()) / max(sum(v[0] for v in sparse.values()), 1) * 1e3
-            launch_us = {k: (v[1] / v[0] * 1e3 if v[0] else None) for k, v in sampled.items()}
-            ok = all(v is not None for v in launch_us.values())
+            bracketed_us = {k: (v[1] / v[0] * 1e3 if v[0] else None) for k, v in sampled.items()}
+            ok = all(v is not None for v in bracketed_us.values())
+            # The bracketed intervals carry the cost of their own two marker packets (1-2 us each way), the pooled figure does not:
+            # the pooled time per launch is split between the two kernels in the ratio of their bracketed times.
+            mean_b = sum(bracketed_us.values()) / len(bracketed_us) if ok else None
+            launch_us = {k: (pooled_us * bracketed_us[k] / mean_b if ok else None) for k in bracketed_us}
             dom = max(launch_us, key=lambda k: launch_us[k] or 0.0) if ok else None
             avg_us = launch_us[dom] if ok else None
             achieved = b_alg_launch / (avg_us * 1e-6) / 1e9 if ok else None
@@ -405,17 +409,19 @@ def main():
                 "avg_launch_us": avg_us,
                 "launch_us": launch_us,
                 "launches_sampled": {k: v[0] for k, v in sampled.items()},
+                "bracketed_launch_us": bracketed_us,
                 "pooled_launch_us": pooled_us,
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "lanes": lanes, "rows_per_launch": rows_per_launch,
-                "measured_in_this_run": ["achieved", "frac", "avg_launch_us", "launch_us", "launches_sampled", "pooled_launch_us", "step_frac"],
+                "measured_in_this_run": ["achieved", "frac", "avg_launch_us", "launch_us", "launches_sampled", "bracketed_launch_us", "pooled_launch_us", "step_frac"],
                 "read_from_profiles": ["traffic", "from_profiles"],
                 "from_profiles": prof,
                 "note": "HIP events on the launch's own stream, two extra passes of the same workload after the timed region. "
-                        "launch_us: one launch of each kernel per 16 is bracketed by two events (event -> kernel -> event: the "
-                        "kernel plus the dependent-launch gap in front of it, ~1.5 us, which rocprofv3's begin->end durations under "
-                        "from_profiles do not contain). pooled_launch_us: one event per 64 launches, interval / launches. With "
-                        "lanes > 1 launches of different row groups overlap on the chip; the chip-level figure is step_frac",
+                        "pooled_launch_us: one event per 64 launches, interval / launches = average kernel + the dependent-launch gap "
+                        "behind it (~1.4 us, which rocprofv3's begin->end durations under from_profiles do not contain). "
+                        "bracketed_launch_us: one launch of each kernel per 16 between two events of its own (adds the markers' own "
+                        "cost). launch_us = pooled_launch_us split in the ratio of the bracketed times; avg_launch_us = the larger. "
+                        "With lanes > 1 launches of different row groups overlap on the chip; the chip-level figure is step_frac",
             })
         if world == 1 and workload == "c2" and not args.no_secondary:
             other = secondary_c1(a_c2, dt, fibre, local_rank)

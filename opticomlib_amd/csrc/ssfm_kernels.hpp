@@ -35,7 +35,7 @@
 #define SSFM_LATE_TAB 0
 #endif
 #ifndef SSFM_LATE_P
-#define SSFM_LATE_P 1
+#define SSFM_LATE_P 2
 #endif
 // 1: form the inter-pass twiddles in the kernel from two small tables (U16 plans); 0: stream the N-entry table.
 // One complex multiply per point against 8 bytes per point of table traffic: 20.8 vs 21.6 us per step alone, 18.1 vs
@@ -631,7 +631,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     };
-    constexpr bool LATE_P = SSFM_LATE_P != 0 && MODE == TM_MID && U16;
+    constexpr bool LATE_P = SSFM_LATE_P != 0 && U16 && (SSFM_LATE_P == 2 ? INV : MODE == TM_MID);       // (2: every mode that reads |A|^2)
     if (INV && !LATE_P) load_pold();
     // The step control state (adaptive runs) is read HERE, after every global load of the tile has been issued: it was written
     // by the previous launch, so its load is a miss of ~2 us that would otherwise stand in front of the whole kernel.  (A launch

@@ -1,17 +1,34 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, bench (N = 1: C2; one-rank RCCL run of the C3 path), rocprofv3 kernel trace.
-# Outputs under gpurun_out/ (copy what is to be kept into profiles/).
+# One GPU-box visit that produces everything a round commits under profiles/: parity suite, smoke, the bench lines (C2; C3 and C4 through
+# bench.py's own one-rank launch, so that the RCCL gather really runs), rocprofv3 kernel stats of the bench command, PMC traffic,
+# SQ counters, and kernel stats of C1 / an adaptive run / the filters.   bash tools/gpu_round.sh TAG   -> gpurun_out/TAG_*
 set -u
 TAG=${1:-r}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/${TAG}_pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/${TAG}_smoke.log
-python bench.py --steps 5 --warmup 1 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; cut -c1-1500 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --workload c3 --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass > gpurun_out/${TAG}_bench_c3_1rank.json 2> gpurun_out/${TAG}_bench_c3.err; echo "bench c3 (1 rank, nccl) rc=$?"; cut -c1-900 gpurun_out/${TAG}_bench_c3_1rank.json; tail -3 gpurun_out/${TAG}_bench_c3.err
-rm -rf gpurun_out/${TAG}_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass > gpurun_out/${TAG}_prof_bench.json 2> gpurun_out/${TAG}_prof.err; echo "rocprof rc=$?"
-find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12
-find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} gpurun_out/${TAG}_kernel_stats.csv
-# keep only the summaries (the full trace is large)
-find gpurun_out/${TAG}_prof -name "*kernel_trace.csv" -size +2M -delete
+T=gpurun_out/$TAG
+python -m pytest tests -m gpu -q > ${T}_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 ${T}_pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > ${T}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 ${T}_smoke.log
+python bench.py --steps 5 --warmup 1 > ${T}_bench.json 2> ${T}_bench.err; echo "bench rc=$?"; cut -c1-1800 ${T}_bench.json; tail -2 ${T}_bench.err
+python bench.py --workload c3 --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass > ${T}_bench_c3_1rank.json 2> ${T}_bench_c3.err; echo "bench c3 (one rank, nccl) rc=$?"; cut -c1-900 ${T}_bench_c3_1rank.json
+python bench.py --workload c4 --steps 2 --warmup 1 --cpu-steps 0 > ${T}_bench_c4_1rank.json 2> ${T}_bench_c4.err; echo "bench c4 (one rank, nccl) rc=$?"; cut -c1-900 ${T}_bench_c4_1rank.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass --no-secondary > ${T}_bench_c2_torchrun.json 2> ${T}_bench_c2_torchrun.err; echo "bench under torchrun (one rank) rc=$?"; cut -c1-600 ${T}_bench_c2_torchrun.json
+rm -rf ${T}_prof
+rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_prof -- python3 bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass > ${T}_prof_bench.json 2> ${T}_prof.err; echo "rocprof rc=$?"
+find ${T}_prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} ${T}_kernel_stats.csv; head -8 ${T}_kernel_stats.csv
+find ${T}_prof -name "*kernel_trace.csv" -size +2M -delete
+bash tools/gpu_pmc.sh ${TAG}_pmc > ${T}_pmc.log 2>&1; tail -3 ${T}_pmc.log
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  rm -rf ${T}_sq
+  rocprofv3 --pmc $set --output-format csv -d ${T}_sq -- python3 bench.py --steps 1 --warmup 0 --cpu-steps 0 --no-profile-pass --no-secondary > /dev/null 2> ${T}_sq.err
+  python tools/sq_summary.py ${T}_sq "k_freq_c64=k_freq<float" "k_time_mid_c64=k_time<float, 256, 16, 16, 1" > ${T}_sq.txt; cat ${T}_sq.txt
+done
+find ${T}_sq -name "*.csv" -size +1M -delete
+for what in "c1:tools/c1_prof.py" "adaptive:tools/adaptive_prof.py" "sos:tools/sos_prof.py"; do
+  name=${what%%:*}; script=${what#*:}
+  rm -rf ${T}_${name}prof
+  rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_${name}prof -- python3 $script > ${T}_${name}_run.txt 2> ${T}_${name}prof.err
+  find ${T}_${name}prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} ${T}_${name}_kernel_stats.csv; head -5 ${T}_${name}_kernel_stats.csv | cut -c1-200
+  find ${T}_${name}prof -name "*kernel_trace.csv" -size +1M -delete
+done
+python tools/cfg_times.py > ${T}_cfg_times.txt 2>&1; cat ${T}_cfg_times.txt
