@@ -121,7 +121,10 @@ int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double
  * announces snapshots); ssfm_adaptive_run takes up to `budget` more steps -- snapshots: NULL, or HOST memory for `budget`
  * fields, the field after each step this call takes (ask ssfm_get_field for the input beforehand) -- and reports the
  * steps taken so far and whether z has reached the length; ssfm_adaptive_finish returns the step count and z_out as
- * ssfm_propagate_adaptive does (z_out: steps + 1 values; size it from ssfm_adaptive_run's count). */
+ * ssfm_propagate_adaptive does (z_out: steps + 1 values; size it from ssfm_adaptive_run's count).
+ * Between ssfm_adaptive_begin and ssfm_adaptive_finish the plan's field buffer (ssfm_get_field, ssfm_field_device_ptr) is only
+ * defined when the run was begun with capture != 0: without a capture the field of a complex64 plan stays in an internal
+ * tile-private order between steps, and ssfm_adaptive_finish produces the time-order field. */
 int ssfm_adaptive_begin(ssfm_plan* plan, double gamma, double length, double phi_max, int single_step, int64_t max_steps, int capture);
 int ssfm_adaptive_run(ssfm_plan* plan, int64_t budget, void* snapshots, int64_t* steps_total, int* done);
 int ssfm_adaptive_finish(ssfm_plan* plan, int64_t* steps_out, double* z_out);

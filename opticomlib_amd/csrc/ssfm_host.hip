@@ -1055,8 +1055,8 @@ template <typename T> struct PlanT : PlanBase {
             if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
         }
         if (ar.fused && ar.step == 0 && budget < (int64_t)ar.max_steps) {
-            // a caller that takes the run in pieces may stop between two of them: it gets the engine that leaves a time-order
-            // field after every step
+            // a caller that takes the run in pieces gets the chunked engine (the fused kernel's launches are queued a whole run ahead);
+            // the field itself stays in the tile-private order until ssfm_adaptive_finish (include/ssfm_amd.h)
             ar.fused = false;
             ar.tile_private = u16;
         }

@@ -37,6 +37,9 @@
 #ifndef SSFM_LATE_P
 #define SSFM_LATE_P 2
 #endif
+#ifndef SSFM_LATE_P_C128
+#define SSFM_LATE_P_C128 1
+#endif
 // 1: form the inter-pass twiddles in the kernel from two small tables (U16 plans); 0: stream the N-entry table.
 // One complex multiply per point against 8 bytes per point of table traffic: 20.8 vs 21.6 us per step alone, 18.1 vs
 // 20.7 together with the memory policy below (profiles/r02_ab_u16_sc1_twnc.txt)
@@ -631,7 +634,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     };
-    constexpr bool LATE_P = SSFM_LATE_P != 0 && U16 && (SSFM_LATE_P == 2 ? INV : MODE == TM_MID);       // (2: every mode that reads |A|^2)
+    constexpr bool LATE_P = SSFM_LATE_P != 0 && (U16 || (sizeof(T) == 8 && SSFM_LATE_P_C128 != 0)) && (SSFM_LATE_P == 2 ? INV : MODE == TM_MID);       // (2: every mode that reads |A|^2)
     if (INV && !LATE_P) load_pold();
     // The step control state (adaptive runs) is read HERE, after every global load of the tile has been issued: it was written
     // by the previous launch, so its load is a miss of ~2 us that would otherwise stand in front of the whole kernel.  (A launch
@@ -639,6 +642,9 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     StepState<T> S_this = {};            // TM_MID_A: the state of the step this launch finishes
     if constexpr (MODE == TM_MID_A) {
         S_this = a.st->cur[a.step & 1];
+        // (a workgroup of an EARLIER launch gave up waiting: the run is void and the host will repeat it -- the launches still
+        // queued return at once instead of each waiting out its own patience on a field that no longer means anything)
+        if (a.st->error != 0u) return;
         if (S_this.done) {
             // a launch queued beyond the end of the run: hand the final state on (the host reads cur[] of the LAST launched step)
             if (blockIdx.x == 0 && tid == 0) a.st->cur[(a.step + 1) & 1] = S_this;
@@ -668,6 +674,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             __syncthreads();
             if (!s_lane_ok) return;
         }
+        if (a.st->error != 0u) return;                        // (see TM_MID_A above; set by a two-lane run's wait as well)
         const StepState<T> S = step_state<T>(a.st, a.step, FWD && a.derive != 0);
         if (FWD && blockIdx.x == 0 && tid == 0) {
             // workgroup 0 records the state of this step (BEGIN is the first kernel of a step) and empties the slots its END fills
@@ -1038,7 +1045,7 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     if (MODE == FM_FLY && a.st != nullptr) {
         // (read after the row and the operator have been asked for: the state was written by the previous launch, a ~2 us miss)
         const StepState<T> S = a.st->cur[a.step & 1];
-        if (S.done) return;
+        if (S.done || a.st->error != 0u) return;             // (error: see k_time<TM_MID_A>)
         h = S.h;
     }
     SSFM_STAMP(1);
