@@ -174,7 +174,7 @@ def committed_profile_figures(kernels, rows_per_launch):
         except Exception:
             pass
         break
-    for pmc_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for pmc_name in ("r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if not os.path.exists(pmc):
             continue
