@@ -10,7 +10,13 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "ssfm_amd.h"
@@ -184,6 +190,57 @@ hipError_t launch_small_adapt(int n, int rows, hipStream_t s, const SmallAdaptAr
     return hipErrorInvalidValue;
 }
 
+// A host thread that enqueues ONE lane's launches.  The host issues a launch per ~3.1 us, a 2^20 x 2 step is four launches per
+// 17 us: one thread is 72 % busy with it and falls behind as soon as something slows it down -- in a process that has initialised
+// RCCL a launch takes ~4.6 us and the run becomes host-bound (18.3 instead of 17.1 us per step, profiles/r03_host_enqueue.txt).
+// With the lanes on threads of their own each thread issues two launches per step.
+class LaneWorker {
+  public:
+    ~LaneWorker() { stop(); }
+    void start(int device) {
+        if (th_.joinable()) return;
+        th_ = std::thread([this, device] {
+            (void)hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(m_);
+            for (;;) {
+                cv_.wait(lk, [this] { return has_job_ || quit_; });
+                if (quit_) return;
+                std::function<int()> job = std::move(job_);
+                has_job_ = false;
+                lk.unlock();
+                const int rc = job();
+                std::string err = rc != SSFM_OK ? std::string(ssfm::g_err) : std::string();
+                lk.lock();
+                rc_ = rc; err_ = std::move(err); done_ = true;
+                cv_.notify_all();
+            }
+        });
+    }
+    void submit(std::function<int()> job) {
+        std::lock_guard<std::mutex> lk(m_);
+        job_ = std::move(job); has_job_ = true; done_ = false;
+        cv_.notify_all();
+    }
+    int wait() {                      // the job's status; its error text becomes this thread's
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return done_; });
+        if (rc_ != SSFM_OK) std::snprintf(ssfm::g_err, sizeof(ssfm::g_err), "%s", err_.c_str());
+        return rc_;
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(m_); quit_ = true; cv_.notify_all(); }
+        if (th_.joinable()) th_.join();
+    }
+  private:
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    bool has_job_ = false, done_ = false, quit_ = false;
+    int rc_ = SSFM_OK;
+    std::string err_;
+};
+
 // ----------------------------------------------------------------------------- plan
 struct PlanBase {
     int precision = 0;
@@ -244,7 +301,9 @@ template <typename T> struct PlanT : PlanBase {
     uint64_t tags[3] = {0, 0, 0};
     void drop_operator() { have_op = false; tags[0] = 0; for (auto& t : tabs) t.valid = false; for (auto& t : stabs) t.valid = false; }
     bool timed = false;
-    int64_t last_launches = 0;
+    std::atomic<int64_t> last_launches{0};
+    LaneWorker lane_worker[8];        // (lane g > 0: a host thread of its own for its launches; env SSFM_LANE_THREADS=0: all from the caller's thread)
+    bool lane_threads = true;
     bool profiling = false;
     // "lanes": rows are independent (they only share the adaptive step size), so a fixed-step run
     // drives disjoint row groups on separate streams; kernels of different groups overlap, which
@@ -406,7 +465,7 @@ template <typename T> struct PlanT : PlanBase {
                 graph_policy = 0;                       // this runtime cannot: eager from now on
                 return enqueue();
             }
-            g.graph = graph; g.exec = exec; g.launches = last_launches;
+            g.graph = graph; g.exec = exec; g.launches = last_launches.load();
         }
         if (want_graph) {
             last_launches = g.launches;
@@ -427,6 +486,7 @@ template <typename T> struct PlanT : PlanBase {
     T inv_n() const { return (T)1 / (T)n; }
 
     int free_all() {
+        for (auto& w : lane_worker) w.stop();
         if (stream) (void)hipStreamSynchronize(stream);
         void* bufs[] = {F, Y != F ? Y : nullptr, P, twN, twA, twB, tw1, tw2, tw2_fly, dnat, dperm, dperm_fly, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
         for (void* b : bufs) (void)hipFree(b);
@@ -497,6 +557,7 @@ template <typename T> struct PlanT : PlanBase {
         if (sizeof(T) == 8 && Ef == 16 && k <= 20 && !std::getenv("SSFM_E") && !std::getenv("SSFM_EF")) Ef_fly = 8;
         if (const char* e = std::getenv("SSFM_EF_FLY")) Ef_fly = k > 20 ? 16 : (std::atoi(e) == 16 ? 16 : 8);
         if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_LANE_THREADS")) lane_threads = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = (e[0] == 'a' || e[0] == 'A') ? -1 : (std::atoi(e) != 0 ? 1 : 0);
         // two lanes pay off once a launch is long enough to hide the other lane's gap; below ~2^20 points in
         // all a step is launch-bound and the second stream only doubles the launches (2^14 x 2: 8.1 us per
@@ -806,7 +867,36 @@ template <typename T> struct PlanT : PlanBase {
         const T half = (T)0.5;
         for (auto& p : prof) p.n = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
+        // one lane's launches, start to end
+        auto lane_run = [&](int g) -> int {
+            const int rows = batch / nlanes;
+            ++last_launches;
+            HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows, g), E)));
+            for (int64_t s = 0; s < nsteps; ++s) {
+                HIP_TRY(freq_rows(h[s], g * rows, rows, lane_stream[g]));
+                ++last_launches;
+                if (s + 1 < nsteps)
+                    HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows, g), E)));
+                else
+                    HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows, g), E)));
+            }
+            return SSFM_OK;
+        };
         auto enqueue_steps = [&]() -> int {
+            if (nlanes > 1 && lane_threads && !profiling && !stagger && graph_policy == 0 && nsteps >= 16) {
+                // every lane from a host thread of its own (LaneWorker): lane 0 from this one
+                HIP_TRY(hipEventRecord(fork_ev, stream));
+                for (int g = 1; g < nlanes; ++g) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
+                for (int g = 1; g < nlanes; ++g) { lane_worker[g].start(device); lane_worker[g].submit([&lane_run, g] { return lane_run(g); }); }
+                int rc = lane_run(0);
+                for (int g = 1; g < nlanes; ++g) { const int r = lane_worker[g].wait(); if (rc == SSFM_OK) rc = r; }
+                if (rc != SSFM_OK) return rc;
+                for (int g = 1; g < nlanes; ++g) {
+                    HIP_TRY(hipEventRecord(lane_ev[g], lane_stream[g]));
+                    HIP_TRY(hipStreamWaitEvent(stream, lane_ev[g], 0));
+                }
+                return SSFM_OK;
+            }
             if (nlanes > 1) {
                 const int rows = batch / nlanes;
                 HIP_TRY(hipEventRecord(fork_ev, stream));
