@@ -430,6 +430,9 @@ template <typename T> struct PlanT : PlanBase {
         mix(&gamma, sizeof(T)); mix(&nsteps, sizeof(nsteps)); mix(h, sizeof(T) * (size_t)nsteps);
         for (auto tp : tabptr) mix(&tp, sizeof(tp));
         mix(&nlanes, sizeof(nlanes)); mix(&E, sizeof(E)); mix(&Ef, sizeof(Ef));
+        // (kernel ARGUMENTS are frozen in a captured graph: the modulus of a phase table is one -- it follows Re D~, which a new operator
+        // changes while the table keeps its address -- and so is the choice between the two table kinds)
+        mix(&op_re0, sizeof(op_re0)); mix(&op_flat_re, sizeof(op_flat_re)); mix(&phase_tables, sizeof(phase_tables));
         int idx = -1;
         for (size_t i = 0; i < graphs.size(); ++i) if (graphs[i].key == key) idx = (int)i;
         if (idx < 0) {
@@ -449,6 +452,7 @@ template <typename T> struct PlanT : PlanBase {
         // call 1: eager (a single FIBER call never pays for a capture); call 2: capture + replay
         bool want_graph;
         if (graph_policy == 1) want_graph = g.calls >= 2;
+        else if (graph_policy == 2) want_graph = g.calls >= 4;          // (a loop over the same schedule by now: capture pays from about a dozen calls on)
         else if (g.calls <= 2) want_graph = false;
         else if (g.calls == 3) want_graph = true;
         else want_graph = g.exec != nullptr && g.graph_ms >= 0.f && (g.eager_ms < 0.f || g.graph_ms < g.eager_ms);
@@ -567,6 +571,14 @@ template <typename T> struct PlanT : PlanBase {
         nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
         if (nlanes > batch) nlanes = batch;
         while (batch % nlanes) --nlanes;
+        // One-lane plans of the two-kernel engine (2^14 ... 2^19 samples) are bound by the HOST's launch rate as much as by the GPU's
+        // (two launches per 8-12 us step, 3.1 us of host time each): replayed as a hipGraph they run 7.3 instead of 8.1 us per step at
+        // 2^14, 8.9 / 9.5 at 2^16, 11.5 / 11.9 at 2^19 x 1 (profiles/r03_host_enqueue.txt; two-lane plans LOSE under a graph: 20.3 vs 13.3 us at
+        // 2^19 x 2, the replay serialises the lanes).  SSFM_GRAPH=lazy captures a schedule when it comes a fourth time.  NOT the default:
+        // while one host thread captures, another thread's legacy-stream call (hipMemcpy, hipDeviceSynchronize -- the helper entry points
+        // of this library use them) fails with hipErrorStreamCaptureImplicit (tools/thread_check.py found it), so graphs stay opt-in for
+        // single-threaded callers.
+        if (const char* e = std::getenv("SSFM_GRAPH")) if (e[0] == 'l' || e[0] == 'L') graph_policy = 2;
         lane_stream[0] = stream;
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
         for (int g = 1; g < nlanes; ++g) {

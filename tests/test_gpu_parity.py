@@ -754,6 +754,27 @@ def test_fused_adaptive_kernel_gives_up_and_the_run_falls_back(monkeypatch):
         p.close()
 
 
+def test_replayed_graphs_follow_the_operator(monkeypatch):
+    """A schedule that comes again is replayed as a hipGraph (SSFM_GRAPH=1: from the second call; SSFM_GRAPH=lazy: from the fourth).  Kernel arguments are frozen in a graph -- among them the modulus of a phase table, which follows the fibre's loss --
+    so FIBER and DBP (negated loss) with the SAME schedule on the SAME plan must not share a graph: five rounds of FIBER then DBP,
+    each against the oracle."""
+    gv(**workloads.BENCH_GV)
+    n = 1 << 15
+    a = workloads.qpsk_field(n, seed=12, power_w=4e-3).astype(np.complex64)
+    kw = dict(length=8, h=0.5, alpha=0.25, beta_2=-21.7, beta_3=0.13, gamma=1.3)
+    want_f = orc.fiber_c64(a, gv.dt, **kw)
+    want_b = orc.fiber_c64(want_f, gv.dt, length=8, h=0.5, alpha=-0.25, beta_2=21.7, beta_3=-0.13, gamma=-1.3)
+    for graph in ("1", "lazy"):
+        monkeypatch.setenv("SSFM_GRAPH", graph)
+        oa.devices.release_plans()
+        for rep in range(5):
+            y = oa.FIBER(optical_signal(a), **kw)
+            assert relmax(y.signal, want_f) < TOL_100, (graph, rep)
+            z = oa.DBP(y, **kw)
+            assert relmax(z.signal, want_b) < TOL_100, (graph, rep)
+    oa.devices.release_plans()
+
+
 def test_operator_tables_of_one_schedule_do_not_evict_each_other():
     """The table cache holds four step sizes per plan.  Schedules {a, b}, {c, d}, {a, e} in this order used to hand the third
     run e's table for a's steps (round-robin victim = a's slot).  Both engines; against a fresh plan, bit for bit."""
