@@ -105,15 +105,26 @@ template <int CH> __device__ __forceinline__ void st(double* p, long long e, con
 }
 
 // sample i of the pass input of the row starting at `base`
+// Branch-free on purpose: the lanes of a wavefront at a row's edge take different paths here, and loads behind divergent
+// branches cannot be issued together -- the 12 samples of a chunk became 12 to 36 dependent trips to memory, and the two or four
+// edge wavefronts of a launch ran twice as long as all the others: they WERE the kernel's duration (19 us with a bulk that is done
+// after 10, profiles/r03_sosfilt.txt).  Both candidate samples are loaded unconditionally (indices clamped into the row), the
+// odd extension 2 x[end] - x[mirror] (scipy's odd_ext) is formed and one select picks.
 template <int CH> __device__ __forceinline__ Smp<CH> sos_input(const SosPass& p, const double* base, long long i) {
-    if (p.backward) return ld<CH>(base, p.m - 1 - i);                            // reversed forward output
-    if (i >= p.edge && i < p.edge + p.n) return ld<CH>(base, i - p.edge);
-    Smp<CH> a, b;
-    if (i < p.edge) { a = ld<CH>(base, 0); b = ld<CH>(base, p.edge - i); }       // odd extension, left
-    else            { a = ld<CH>(base, p.n - 1); b = ld<CH>(base, p.n - 2 - (i - p.edge - p.n)); }   // right
+    if (p.backward) { const long long k = p.m - 1 - i; return ld<CH>(base, k < 0 ? 0 : k); }     // reversed forward output (wave-uniform branch)
+    const long long j = i - p.edge;                                              // position in the row; outside [0, n): odd extension
+    const bool left = j < 0, right = j >= p.n;
+    long long ia = left ? 0 : (right ? p.n - 1 : j);                             // the row's end sample, or the sample itself
+    long long ib = left ? -j : (right ? 2 * (p.n - 1) - j : j);                  // its mirror image
+    ib = ib < 0 ? 0 : (ib > p.n - 1 ? p.n - 1 : ib);                             // (only lanes beyond the padded length get here clamped)
+    const Smp<CH> a = ld<CH>(base, ia), b = ld<CH>(base, ib);
+    Smp<CH> r;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) a.v[c] = 2.0 * a.v[c] - b.v[c];
-    return a;
+    for (int c = 0; c < CH; ++c) {
+        const double ext = 2.0 * a.v[c] - b.v[c];
+        r.v[c] = (left || right) ? ext : a.v[c];
+    }
+    return r;
 }
 template <int CH> __device__ __forceinline__ const double* pass_row(const SosPass& p, int row) {
     return p.src + (long long)row * (p.backward ? p.m : p.n) * CH;
@@ -173,9 +184,28 @@ template <int CH> __device__ __forceinline__ void load_chunk(const SosPass& p, c
     } else {
         const long long i0 = w0 + (long long)lane * kChunk;
 #pragma unroll
-        for (int t = 0; t < kChunk; ++t)
-            if (t < len) xs[t] = sos_input<CH>(p, base, i0 + t);
+        for (int t = 0; t < kChunk; ++t) xs[t] = sos_input<CH>(p, base, i0 + t);     // (samples beyond `len` are loaded from clamped positions and never used)
+        (void)len;
     }
+}
+
+// The two halves of load_chunk's plain path, for a caller with work in between that should not have to keep 12 samples per channel in
+// registers meanwhile (k_apply's group reduction): coalesced loads -> the wavefront's LDS slice, and later slice -> this lane's chunk.
+template <int CH> __device__ __forceinline__ void chunk_to_lds(const SosPass& p, const double* base, long long w0, int lane, Smp<CH>* lds) {
+    Smp<CH> tmp[kChunk];
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) {
+        const long long i = w0 + t * kWave + lane;
+        tmp[t] = ld<CH>(base, p.backward ? p.m - 1 - i : i - p.edge);
+    }
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) lds[lds_pos(t * kWave + lane)] = tmp[t];
+    wave_lds_sync();
+}
+template <int CH> __device__ __forceinline__ void chunk_from_lds(Smp<CH>* lds, int lane, Smp<CH> (&xs)[kChunk]) {
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) xs[t] = lds[lane * (kChunk + 1) + t];
+    wave_lds_sync();
 }
 
 // y += M x  (M row-major K x K, wave-uniform address)
@@ -190,19 +220,12 @@ template <int K, int CH> __device__ __forceinline__ void mat_acc(const double* M
         }
 }
 
-// The scan's doubling steps use M^1, M^2, M^4 ... M^32, the combination of the wavefronts M^64.  Fetching
-// them step by step from global memory puts dependent cache misses on the critical path of kernels that
-// only live for microseconds, so a workgroup copies the seven matrices to LDS up front (one latency,
-// overlapped with its data loads).
+// The scan's doubling steps use M^1, M^2, M^4 ... M^32, the combination of the wavefronts M^64.  Fetching them step by step from
+// global memory puts dependent cache misses on the critical path of kernels that only live for microseconds, so a workgroup keeps
+// a copy of the seven matrices in LDS (k_chunk_scan: fetched up front by its last wavefront, written after that one's transposes).
 constexpr int kScanSteps = 6;
-template <int K> __device__ __forceinline__ void stage_pow2(const double* __restrict__ pw, double* lds_pw, int tid) {
-    for (int e = tid; e < (kScanSteps + 1) * K * K; e += (int)blockDim.x) {
-        const int k = e / (K * K);
-        lds_pw[e] = pw[((long long)1 << k) * K * K + e % (K * K)];
-    }
-}
 // Inclusive scan over the 64 lanes of a wavefront of the affine maps s -> M s + x_lane (same M in every
-// lane): afterwards x_lane = sum_{i <= lane} M^(lane - i) x_i.  lds_pw = stage_pow2's copy of the powers.
+// lane): afterwards x_lane = sum_{i <= lane} M^(lane - i) x_i.  lds_pw = the workgroup's LDS copy of the powers.
 template <int K, int CH> __device__ __forceinline__ void wave_scan(double (&x)[CH][K], const double* lds_pw) {
     const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
@@ -240,16 +263,27 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
     constexpr int K = 2 * NS;
     constexpr int kWaves = W, kGroup = kWave * W;
     __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
-    __shared__ double lds_pw[(kScanSteps + 1) * K * K];
-    // (the wavefront totals go into each wavefront's OWN staging slice, which it no longer needs after its transposes: with a separate
-    // array three workgroups did not fit a CU's LDS, 3 x 54 400 B > 160 KiB.  Measured: no change in time -- the kernel is not short of
-    // resident workgroups, profiles/r03_sosfilt.txt)
+    // The staging slices are ALL the LDS of the kernel: the wavefront totals go into each wavefront's own slice and the matrix powers
+    // of the scan into the last wavefront's (offset 1 KiB), both written once the owner has finished its transposes.  52 KiB per
+    // workgroup: three fit a CU whatever the allocation granule is (54 272 B did not: a 2^20 x 2 call's 684 workgroups ran as two
+    // generations, and a launch took twice a workgroup's lifetime -- profiles/r03_sosfilt.txt).
+    static_assert((kScanSteps + 1) * K * K * sizeof(double) + 1024 <= sizeof(Smp<CH>) * kLdsElems, "the powers fit the slice");
+    double* const lds_pw = reinterpret_cast<double*>(lds_all[kWaves - 1]) + 128;
     const int row = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const int ch = g * kGroup + tid;
     const long long w0 = ((long long)g * kGroup + wv * kWave) * kChunk;
     const bool plain = wave_is_plain(p, w0);
-    stage_pow2<K>(pw, lds_pw, tid);
+    // (the last wavefront fetches the scan's matrix powers now and writes them to LDS after its transposes)
+    constexpr int kPwEntries = (kScanSteps + 1) * K * K, kPwPerLane = (kPwEntries + kWave - 1) / kWave;
+    double pw_stage[kPwPerLane];
+    if (wv == kWaves - 1) {
+#pragma unroll
+        for (int i = 0; i < kPwPerLane; ++i) {
+            const int e = lane + i * kWave;
+            pw_stage[i] = e < kPwEntries ? pw[((long long)1 << (e / (K * K))) * K * K + e % (K * K)] : 0.0;
+        }
+    }
     // this lane's M^lane, for the offset of its wavefront inside the group (fetched ahead of its use)
     double Ml[K][K];
 #pragma unroll
@@ -293,6 +327,13 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
                         for (int a = 0; a < CH; ++a) s[a][k] = fma(g, xs[t].v[a], s[a][k]);
                     }
                 }
+        }
+    }
+    if (wv == kWaves - 1) {
+#pragma unroll
+        for (int i = 0; i < kPwPerLane; ++i) {
+            const int e = lane + i * kWave;
+            if (e < kPwEntries) lds_pw[e] = pw_stage[i];
         }
     }
     __syncthreads();                      // lds_pw staged
@@ -352,7 +393,7 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
 // that a 2^20 x 2 call's 683 workgroups would be resident at once instead of 512 + 171: measured SLOWER, 95.9 against 86.5 us of kernels per
 // call (profiles/r03_sosfilt.txt) -- the spills cost more than the second, third-full generation.
 #ifndef SOS_APPLY_WAVES
-#define SOS_APPLY_WAVES 2
+#define SOS_APPLY_WAVES 3
 #endif
 template <int NS, int CH, int W>
 __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <= 2 ? SOS_APPLY_WAVES : 1, 8))) void k_apply(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi,
@@ -385,8 +426,19 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
         for (int q = 0; q < K; ++q) { Ml[r][q] = pw[(long long)lane * K * K + r * K + q]; MG[r][q] = pwG[(long long)lane * K * K + r * K + q]; }
     const long long i0 = (long long)ch * kChunk;
     const int len = (int)(i0 + kChunk <= p.m ? kChunk : p.m - i0);
-    Smp<CH> xs[kChunk];
-    if (active) load_chunk<CH>(p, base, w0, lane, len, plain, lds_all[wv], xs);
+    // the samples: a plain wavefront parks them in its LDS slice until the group's start state is known (they would be 48 registers
+    // through the whole reduction: 230 in all, two workgroups per CU, two generations for a 2^20 x 2 call); an edge wavefront keeps them
+    // (an edge wavefront loads lane by lane and parks its samples the same way)
+    if (active) {
+        if (plain) chunk_to_lds<CH>(p, base, w0, lane, lds_all[wv]);
+        else {
+            Smp<CH> xe[kChunk];
+            load_chunk<CH>(p, base, w0, lane, len, false, lds_all[wv], xe);
+#pragma unroll
+            for (int t = 0; t < kChunk; ++t) lds_all[wv][lane * (kChunk + 1) + t] = xe[t];
+            wave_lds_sync();
+        }
+    }
 
     // ---- start state of the group: S_g = sum over distances d = 0..g of (M^256)^d v_d,
     //      v_d = T_{g-1-d} for d < g, v_g = s_0 = zi * x_0.  d = 64 a + lane: lane power, then wavefront power.
@@ -451,6 +503,8 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
             sg[a][k] = t;
         }
     if (!active) return;
+    Smp<CH> xs[kChunk];
+    chunk_from_lds<CH>(lds_all[wv], lane, xs);
     // true start state of the chunk = M^lane (M^64)^wv S_g + e_c
     for (int w = 0; w < wv; ++w) mat_apply<K, CH>(lds_m64, sg);
 #pragma unroll
