@@ -75,6 +75,11 @@ struct SosPass {
     const double* src;      // forward: caller's x; backward: y1 (padded forward output, [row][m][CH])
     long long n;            // original samples per row
     long long m;            // padded length n + 2*edge
+    long long mv;           // length of the sequence the pass runs over: forward m; backward the whole chunk grid, ngroups * group * kChunk >= m:
+                            // the backward sequence is b[i'] = y1[min(mv - 1 - i', m - 1)] -- it STARTS with mv - m copies of y1[m - 1], under which
+                            // the initial state zi * y1[m - 1] (scipy: zi * y[-1]) stays where it is (steady state) -- so that backward chunk c'
+                            // is forward chunk (chunks - 1 - c') sample for sample, and the forward output pass can run the backward chunk pass
+                            // on the outputs it holds in registers
     int edge;
     int backward;
 };
@@ -111,7 +116,11 @@ template <int CH> __device__ __forceinline__ void st(double* p, long long e, con
 // after 10, profiles/r03_sosfilt.txt).  Both candidate samples are loaded unconditionally (indices clamped into the row), the
 // odd extension 2 x[end] - x[mirror] (scipy's odd_ext) is formed and one select picks.
 template <int CH> __device__ __forceinline__ Smp<CH> sos_input(const SosPass& p, const double* base, long long i) {
-    if (p.backward) { const long long k = p.m - 1 - i; return ld<CH>(base, k < 0 ? 0 : k); }     // reversed forward output (wave-uniform branch)
+    if (p.backward) {                                                            // reversed forward output (wave-uniform branch)
+        long long k = p.mv - 1 - i;
+        k = k < 0 ? 0 : (k > p.m - 1 ? p.m - 1 : k);                             // (beyond the end: the virtual copies of y1[m - 1])
+        return ld<CH>(base, k);
+    }
     const long long j = i - p.edge;                                              // position in the row; outside [0, n): odd extension
     const bool left = j < 0, right = j >= p.n;
     long long ia = left ? 0 : (right ? p.n - 1 : j);                             // the row's end sample, or the sample itself
@@ -152,7 +161,7 @@ __device__ __forceinline__ int lds_pos(int r) { return r + r / kChunk; }
 // Is the wavefront's sample range [w0, w0 + 64 * kChunk) of the padded sequence plain memory (no odd extension,
 // no ragged end)?  Wave-uniform.
 __device__ __forceinline__ bool wave_is_plain(const SosPass& p, long long w0) {
-    if (p.backward) return w0 + kWaveSamples <= p.m;
+    if (p.backward) return w0 >= p.mv - p.m;                  // (past the virtual copies; the grid ends with the sequence)
     return w0 >= p.edge && w0 + kWaveSamples <= p.edge + p.n;
 }
 
@@ -173,7 +182,7 @@ template <int CH> __device__ __forceinline__ void load_chunk(const SosPass& p, c
 #pragma unroll
         for (int t = 0; t < kChunk; ++t) {
             const long long i = w0 + t * kWave + lane;
-            tmp[t] = ld<CH>(base, p.backward ? p.m - 1 - i : i - p.edge);
+            tmp[t] = ld<CH>(base, p.backward ? p.mv - 1 - i : i - p.edge);
         }
 #pragma unroll
         for (int t = 0; t < kChunk; ++t) lds[lds_pos(t * kWave + lane)] = tmp[t];
@@ -196,7 +205,7 @@ template <int CH> __device__ __forceinline__ void chunk_to_lds(const SosPass& p,
 #pragma unroll
     for (int t = 0; t < kChunk; ++t) {
         const long long i = w0 + t * kWave + lane;
-        tmp[t] = ld<CH>(base, p.backward ? p.m - 1 - i : i - p.edge);
+        tmp[t] = ld<CH>(base, p.backward ? p.mv - 1 - i : i - p.edge);
     }
 #pragma unroll
     for (int t = 0; t < kChunk; ++t) lds[lds_pos(t * kWave + lane)] = tmp[t];
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(kWave * W) void k_chunk_scan(SosPass p, int nchunks
     if (plain || ch < nchunks) {
         const double* base = pass_row<CH>(p, row);
         const long long i0 = (long long)ch * kChunk;
-        const int len = (int)(i0 + kChunk <= p.m ? kChunk : p.m - i0);
+        const int len = (int)(i0 + kChunk <= p.mv ? kChunk : p.mv - i0);
         Smp<CH> xs[kChunk];
         load_chunk<CH>(p, base, w0, lane, len, plain, lds_all[wv], xs);
         // The chunk's particular solution -- the state after its samples from a ZERO state -- is linear in the samples:
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
 #pragma unroll
         for (int q = 0; q < K; ++q) { Ml[r][q] = pw[(long long)lane * K * K + r * K + q]; MG[r][q] = pwG[(long long)lane * K * K + r * K + q]; }
     const long long i0 = (long long)ch * kChunk;
-    const int len = (int)(i0 + kChunk <= p.m ? kChunk : p.m - i0);
+    const int len = (int)(i0 + kChunk <= p.mv ? kChunk : p.mv - i0);
     // the samples: a plain wavefront parks them in its LDS slice until the group's start state is known (they would be 48 registers
     // through the whole reduction: 230 in all, two workgroups per CU, two generations for a 2^20 x 2 call); an edge wavefront keeps them
     // (an edge wavefront loads lane by lane and parks its samples the same way)
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
             if (!p.backward) st<CH>(dst_f, i, y);
             else {
                 // y = reverse(y2)[edge : m - edge]  ->  out[nn] = y2[m - 1 - (nn + edge)]
-                const long long nn = p.m - 1 - i - p.edge;
+                const long long nn = p.mv - 1 - i - p.edge;
                 if (nn >= 0 && nn < p.n) st<CH>(dst_b, nn, y);
             }
         }
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
             for (int a = 0; a < CH; ++a) y.v[a] = sos_step<NS>(c, z[a], xs[t].v[a]);
             if (!p.backward) st<CH>(dst_f, i0 + t, y);
             else {
-                const long long nn = p.m - 1 - (i0 + t) - p.edge;
+                const long long nn = p.mv - 1 - (i0 + t) - p.edge;
                 if (nn >= 0 && nn < p.n) st<CH>(dst_b, nn, y);
             }
         }
@@ -706,8 +715,10 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
     for (int dir = 0; dir < 2; ++dir) {
         p.backward = dir;
         p.src = dir == 0 ? d_x : d_y1;
-        hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, p, nchunks, ngroups, d_pw, d_G, d_E, d_T);
-        hipLaunchKernelGGL((k_apply<NS, CH, W>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
+        p.mv = dir == 0 ? m : (long long)ngroups * kGroup * kChunk;
+        const int chunks = dir == 0 ? nchunks : ngroups * kGroup;
+        hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, p, chunks, ngroups, d_pw, d_G, d_E, d_T);
+        hipLaunchKernelGGL((k_apply<NS, CH, W>), grid, block, 0, w.stream, c, p, chunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
                            (const double*)d_T, d_y1, d_out);
         WS_TRY(hipGetLastError());
     }
