@@ -70,6 +70,9 @@ struct SosCoefs {
 #ifndef SOS_WT
 #define SOS_WT 1
 #endif
+#ifndef SOS_FUSE
+#define SOS_FUSE 1
+#endif
 // One direction of the forward-backward pass.  Rows hold CH interleaved channels.
 struct SosPass {
     const double* src;      // forward: caller's x; backward: y1 (padded forward output, [row][m][CH])
@@ -251,6 +254,24 @@ template <int K, int CH> __device__ __forceinline__ void wave_scan(double (&x)[C
         mat_acc<K, CH>(lds_pw + k * K * K, up, x);
     }
 }
+// The same scan in the OPPOSITE lane order (lane 63 first): afterwards x_lane = sum_{i >= lane} M^(i - lane) x_i -- the backward pass's
+// chunk order inside the forward pass's wavefront (see SosPass::mv).
+template <int K, int CH> __device__ __forceinline__ void wave_scan_rev(double (&x)[CH][K], const double* lds_pw) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int k = 0; k < kScanSteps; ++k) {
+        const int d = 1 << k;
+        double up[CH][K];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const double o = __shfl_down(x[c][q], d, kWave);
+                up[c][q] = lane + d < kWave ? o : 0.0;
+            }
+        mat_acc<K, CH>(lds_pw + k * K * K, up, x);
+    }
+}
 // x <- M x
 template <int K, int CH> __device__ __forceinline__ void mat_apply(const double* M, double (&x)[CH][K]) {
     double y[CH][K];
@@ -408,12 +429,17 @@ template <int NS, int CH, int W>
 __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <= 2 ? SOS_APPLY_WAVES : 1, 8))) void k_apply(SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi,
                                                   const double* __restrict__ pw, const double* __restrict__ pwG, const double* __restrict__ pwH,
                                                   const double* __restrict__ E, const double* __restrict__ T,
-                                                  double* __restrict__ y1, double* __restrict__ out) {
+                                                  double* __restrict__ y1, double* __restrict__ out,
+                                                  const double* __restrict__ G, double* __restrict__ E2, double* __restrict__ T2) {
+    // E2 != nullptr (forward pass): the kernel also runs the BACKWARD pass's chunk pass on the outputs it holds -- backward chunk c' is
+    // this thread's chunk read the other way round (SosPass::mv) -- and leaves its E / T in E2 / T2: no second k_chunk_scan launch, no
+    // second read of y1
     constexpr int K = 2 * NS;
     constexpr int kWaves = W, kGroup = kWave * W;
     __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
     __shared__ double lds_m64[K * K];
     __shared__ double red[kWaves][CH * K];
+    __shared__ __attribute__((aligned(16))) double c_lds[2];
     const int row = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const int ch = g * kGroup + tid;
@@ -511,7 +537,11 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
             for (int w = 1; w < kWaves; ++w) t += red[w][a * K + k];
             sg[a][k] = t;
         }
-    if (!active) return;
+    const bool fuse = E2 != nullptr;
+    if (!active && !fuse) return;
+    Smp<CH> ys[kChunk];                    // this chunk's outputs (kept for the fused chunk pass)
+    Smp<CH>* lds = lds_all[wv];
+    if (active) {
     Smp<CH> xs[kChunk];
     chunk_from_lds<CH>(lds_all[wv], lane, xs);
     // true start state of the chunk = M^lane (M^64)^wv S_g + e_c
@@ -528,17 +558,15 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
     for (int a = 0; a < CH; ++a)
 #pragma unroll
         for (int q = 0; q < NS; ++q) { z[a][q][0] = s[a][2 * q]; z[a][q][1] = s[a][2 * q + 1]; }
-    Smp<CH>* lds = lds_all[wv];
     double* const dst_f = y1 + (long long)row * p.m * CH;
     double* const dst_b = out + (long long)row * p.n * CH;
     if (plain) {
         // outputs back through LDS, then coalesced stores
 #pragma unroll
         for (int t = 0; t < kChunk; ++t) {
-            Smp<CH> y;
 #pragma unroll
-            for (int a = 0; a < CH; ++a) y.v[a] = sos_step<NS>(c, z[a], xs[t].v[a]);
-            lds[lane * (kChunk + 1) + t] = y;
+            for (int a = 0; a < CH; ++a) ys[t].v[a] = sos_step<NS>(c, z[a], xs[t].v[a]);
+            lds[lane * (kChunk + 1) + t] = ys[t];
         }
         wave_lds_sync();
 #pragma unroll
@@ -547,25 +575,124 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
             const long long i = w0 + t * kWave + lane;
             if (!p.backward) st<CH>(dst_f, i, y);
             else {
-                // y = reverse(y2)[edge : m - edge]  ->  out[nn] = y2[m - 1 - (nn + edge)]
+                // y = reverse(y2)[edge : m - edge]  ->  out[nn] = y2 at forward position nn + edge
                 const long long nn = p.mv - 1 - i - p.edge;
                 if (nn >= 0 && nn < p.n) st<CH>(dst_b, nn, y);
             }
         }
-        return;
+        wave_lds_sync();
+    } else {
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+            if (t < len) {
+#pragma unroll
+                for (int a = 0; a < CH; ++a) ys[t].v[a] = sos_step<NS>(c, z[a], xs[t].v[a]);
+                if (!p.backward) st<CH>(dst_f, i0 + t, ys[t]);
+                else {
+                    const long long nn = p.mv - 1 - (i0 + t) - p.edge;
+                    if (nn >= 0 && nn < p.n) st<CH>(dst_b, nn, ys[t]);
+                }
+            }
     }
+    }
+    if (!fuse) return;
+
+    // ---- the backward pass's chunk pass (k_chunk_scan's work) on the outputs of this chunk, read from its end to its start.
+    // Positions at and beyond m hold y1[m - 1] (SosPass::mv): the thread that produced it shares it; all such chunks are in the last group.
+    const long long last = p.m - 1;
+    if (g == ngroups - 1) {
+        if ((long long)ch * kChunk <= last && last < (long long)ch * kChunk + kChunk) {
+            Smp<CH> cv = ys[0];
+#pragma unroll
+            for (int t = 1; t < kChunk; ++t) if (i0 + t == last) cv = ys[t];
+#pragma unroll
+            for (int a = 0; a < CH; ++a) c_lds[a] = cv.v[a];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+            if (i0 + t > last) {
+#pragma unroll
+                for (int a = 0; a < CH; ++a) ys[t].v[a] = c_lds[a];
+            }
+    }
+    // the scan's matrix powers: the last wavefront copies them into its slice (free now), offset 1 KiB
+    constexpr int kPwEntries = (kScanSteps + 1) * K * K;
+    double* const lds_pw = reinterpret_cast<double*>(lds_all[kWaves - 1]) + 128;
+    if (wv == kWaves - 1)
+        for (int e = lane; e < kPwEntries; e += kWave) lds_pw[e] = pw[((long long)1 << (e / (K * K))) * K * K + e % (K * K)];
+    // this lane's power for the offset of its wavefront inside the group: its backward position in the wavefront is 63 - lane
+    double Mb[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) Mb[r][q] = pw[(long long)(kWave - 1 - lane) * K * K + r * K + q];
+    double sb[CH][K];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) sb[a][k] = 0.0;
 #pragma unroll
     for (int t = 0; t < kChunk; ++t)
-        if (t < len) {
-            Smp<CH> y;
 #pragma unroll
-            for (int a = 0; a < CH; ++a) y.v[a] = sos_step<NS>(c, z[a], xs[t].v[a]);
-            if (!p.backward) st<CH>(dst_f, i0 + t, y);
-            else {
-                const long long nn = p.mv - 1 - (i0 + t) - p.edge;
-                if (nn >= 0 && nn < p.n) st<CH>(dst_b, nn, y);
-            }
+        for (int k = 0; k < K; ++k) {
+            const double gk = G[k * kChunk + t];
+#pragma unroll
+            for (int a = 0; a < CH; ++a) sb[a][k] = fma(gk, ys[kChunk - 1 - t].v[a], sb[a][k]);
         }
+    __syncthreads();                      // lds_pw staged
+    wave_scan_rev<K, CH>(sb, lds_pw);
+    double exb[CH][K];
+    double* const totb = reinterpret_cast<double*>(lds_all[wv]);          // (the wavefront's total, in its own slice)
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double prev = __shfl_down(sb[a][k], 1, kWave);
+            exb[a][k] = lane != kWave - 1 ? prev : 0.0;
+            if (lane == 0) totb[a * K + k] = sb[a][k];
+        }
+    __syncthreads();
+    // backward order of the wavefronts: the last one comes first
+    double wsb[CH][K];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) wsb[a][k] = 0.0;
+    for (int b = 0; b < kWaves - 1 - wv; ++b) {
+        mat_apply<K, CH>(lds_m64, wsb);
+        const double* tb = reinterpret_cast<const double*>(lds_all[kWaves - 1 - b]);
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) wsb[a][k] += tb[a * K + k];
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a) exb[a][r] += Mb[r][q] * wsb[a][q];
+        }
+    // backward chunk index of this thread: (chunks in the grid) - 1 - ch; backward group: ngroups - 1 - g
+    const long long chb = (long long)ngroups * kGroup - 1 - ch;
+    double* Eb = E2 + ((long long)row * ngroups * kGroup + chb) * (CH * K);
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) Eb[a * K + k] = exb[a][k];
+    if (wv == 0) {
+        // group total = state after the last wavefront in backward order (this one)
+        mat_apply<K, CH>(lds_m64, wsb);
+        if (lane == 0) {
+            double* Tb = T2 + ((long long)row * ngroups + (ngroups - 1 - g)) * (CH * K);
+            const double* tb = reinterpret_cast<const double*>(lds_all[0]);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) Tb[a * K + k] = wsb[a][k] + tb[a * K + k];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -575,7 +702,7 @@ struct Workspace {
     std::mutex mu;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // x staging, y1, E, T, (unused), tables
+    double* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // x staging, y1, E, T (both passes), E of the backward pass, tables
     size_t cap[6] = {0, 0, 0, 0, 0, 0};
     std::vector<double> table_key;       // sos coefficients the device tables were built for
     float last_ms = 0.f;
@@ -677,7 +804,8 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
     if (!on_device) WS_TRY(w.need(0, xbytes));
     WS_TRY(w.need(1, sizeof(double) * (size_t)m * rows * CH));
     WS_TRY(w.need(2, sizeof(double) * (size_t)ngroups * kGroup * rows * CH * K));
-    WS_TRY(w.need(3, sizeof(double) * (size_t)ngroups * rows * CH * K));
+    WS_TRY(w.need(3, sizeof(double) * (size_t)ngroups * rows * CH * K * 2));           // T of the forward and of the backward pass
+    WS_TRY(w.need(4, sizeof(double) * (size_t)ngroups * kGroup * rows * CH * K));       // E of the backward pass (written by the forward output kernel)
     const size_t pow_doubles = (size_t)3 * (kWave + 1) * K * K;
     const size_t tab_doubles = pow_doubles + (size_t)K * kChunk;          // matrix powers, then G
     WS_TRY(w.need(5, sizeof(double) * (tab_doubles + K)));
@@ -712,16 +840,18 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
     SosPass p;
     p.n = n; p.m = m; p.edge = edge;
     const dim3 grid((unsigned)(ngroups * rows)), block(kGroup);
-    for (int dir = 0; dir < 2; ++dir) {
-        p.backward = dir;
-        p.src = dir == 0 ? d_x : d_y1;
-        p.mv = dir == 0 ? m : (long long)ngroups * kGroup * kChunk;
-        const int chunks = dir == 0 ? nchunks : ngroups * kGroup;
-        hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, p, chunks, ngroups, d_pw, d_G, d_E, d_T);
-        hipLaunchKernelGGL((k_apply<NS, CH, W>), grid, block, 0, w.stream, c, p, chunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
-                           (const double*)d_T, d_y1, d_out);
-        WS_TRY(hipGetLastError());
-    }
+    // Three launches per call: chunk pass (forward), output pass (forward) + chunk pass (backward) in one kernel, output pass (backward).
+    // SOS_FUSE=0 (build knob) keeps the backward chunk pass a launch of its own.
+    double *d_E2 = w.buf[4], *d_T2 = w.buf[3] + (size_t)ngroups * rows * CH * K;
+    p.backward = 0; p.src = d_x; p.mv = m;
+    hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, p, nchunks, ngroups, d_pw, d_G, d_E, d_T);
+    hipLaunchKernelGGL((k_apply<NS, CH, W>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E,
+                       (const double*)d_T, d_y1, d_out, d_G, SOS_FUSE ? d_E2 : nullptr, SOS_FUSE ? d_T2 : nullptr);
+    p.backward = 1; p.src = d_y1; p.mv = (long long)ngroups * kGroup * kChunk;
+    if (!SOS_FUSE) hipLaunchKernelGGL((k_chunk_scan<NS, CH, W>), grid, block, 0, w.stream, p, ngroups * kGroup, ngroups, d_pw, d_G, d_E2, d_T2);
+    hipLaunchKernelGGL((k_apply<NS, CH, W>), grid, block, 0, w.stream, c, p, ngroups * kGroup, ngroups, d_zi, d_pw, d_pwG, d_pwH, (const double*)d_E2,
+                       (const double*)d_T2, d_y1, d_out, d_G, (double*)nullptr, (double*)nullptr);
+    WS_TRY(hipGetLastError());
     WS_TRY(hipEventRecord(w.ev1, w.stream));
     if (!on_device) WS_TRY(hipMemcpyAsync(y, w.buf[0], xbytes, hipMemcpyDeviceToHost, w.stream));
     WS_TRY(hipStreamSynchronize(w.stream));
