@@ -30,6 +30,8 @@
 // = 48 B against the algorithmic 16 B (read x once, write y once).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -155,6 +157,21 @@ __device__ __forceinline__ double sos_step(const SosCoefs& c, double (&z)[NS][2]
     return x;
 }
 
+// The same step with fused multiply-adds (5 operations per section instead of 9; each product is no longer rounded on its own, so the
+// result differs from SciPy's loop in the last bits -- as the chunk start states do anyway).  The one-launch kernel, whose workgroups
+// all compute at the same time, is bound by its float64 instruction count.
+template <int NS>
+__device__ __forceinline__ double sos_step_fma(const SosCoefs& c, double (&z)[NS][2], double x) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double xn = x;
+        x = fma(c.b0[s], xn, z[s][0]);
+        z[s][0] = fma(c.b1[s], xn, fma(-c.a1[s], x, z[s][1]));
+        z[s][1] = fma(c.b2[s], xn, -c.a2[s] * x);
+    }
+    return x;
+}
+
 // LDS staging of a wavefront's 64 x kChunk samples: element r = chunk * kChunk + t lives at r + r / kChunk
 // (one pad element per chunk: a lane's ds_read/ds_write of "its" sample t is bank-conflict free).
 constexpr int kWaveSamples = kWave * kChunk;
@@ -214,18 +231,35 @@ template <int CH> __device__ __forceinline__ void chunk_to_lds(const SosPass& p,
     for (int t = 0; t < kChunk; ++t) lds[lds_pos(t * kWave + lane)] = tmp[t];
     wave_lds_sync();
 }
+// The same for a wavefront at a row's edge or end: sample by sample through sos_input (two coalesced loads and a select each) instead of
+// lane by lane -- in the one-launch kernel every workgroup waits for the totals of the row's first group.
+template <int CH> __device__ __forceinline__ void chunk_to_lds_edge(const SosPass& p, const double* base, long long w0, int lane, Smp<CH>* lds) {
+    Smp<CH> tmp[kChunk];
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) {
+        long long i = w0 + t * kWave + lane;
+        i = i < p.mv ? i : p.mv - 1;                              // (beyond the sequence: never used)
+        tmp[t] = sos_input<CH>(p, base, i);
+    }
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) lds[lds_pos(t * kWave + lane)] = tmp[t];
+    wave_lds_sync();
+}
 template <int CH> __device__ __forceinline__ void chunk_from_lds(Smp<CH>* lds, int lane, Smp<CH> (&xs)[kChunk]) {
 #pragma unroll
     for (int t = 0; t < kChunk; ++t) xs[t] = lds[lane * (kChunk + 1) + t];
     wave_lds_sync();
 }
 
-// y += M x  (M row-major K x K, wave-uniform address)
+// y += M x  (M row-major K x K, wave-uniform address).  Every map of this file is a power of the cascade's one-chunk map, and in a
+// cascade a section never sees the ones after it: the maps are block lower triangular (2 x 2 blocks, exact zeros above -- the host
+// builds them by running the recurrence on unit states), so those products are skipped: 12 of 16 for two sections, 40 of 64 for four.
 template <int K, int CH> __device__ __forceinline__ void mat_acc(const double* M, const double (&x)[CH][K], double (&y)[CH][K]) {
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
         for (int q = 0; q < K; ++q) {
+            if (q / 2 > r / 2) continue;
             const double mrq = M[r * K + q];
 #pragma unroll
             for (int c = 0; c < CH; ++c) y[c][r] += mrq * x[c][q];
@@ -695,6 +729,566 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
     }
 }
 
+// ------------------------------------------------------------------------------------------ one launch
+// The whole forward-backward filter in ONE launch, for calls whose workgroups are all resident at once (host: `one_launch_capacity`).
+// A workgroup keeps its 256 chunks in registers / LDS from the first load to the last store and meets the others twice, through
+// the group totals in HBM: forward it needs the totals of every EARLIER group of its row, backward those of every LATER one.  Each
+// total goes out with a flag (= the call's epoch; the flags are never reset); a reader polls the flags of the totals it needs with
+// agent-scope loads.  x is read once, the result written once -- 16 B per real sample, the algorithmic minimum, against 51 of the
+// three-launch form (no y1, no chunk states in HBM at all).
+// With every workgroup in the same phase at the same time nothing hides a trip to memory, and while the samples stream in or out
+// such a trip takes microseconds: between the sample loads and the sample stores the kernel touches global memory only for the
+// totals -- the scan's matrix powers live in LDS for the whole launch (in the pad elements of the staging slices, which the sample
+// traffic never touches), the per-lane powers are asked for ahead of the waits.
+// A workgroup that waits longer than `patience` (another process's grid sharing the GPU could keep part of this one out) raises
+// `*status` and leaves; the host then repeats the call with the three-launch form (x is never written).
+struct SosLink {
+    double* T;            // [2][gridDim.x][CH * K]: forward totals (+ the start state's image in group 0's), then backward
+    unsigned* flag;       // [2][gridDim.x]
+    int* status;          // host-visible
+    unsigned epoch;
+    long long patience;   // ticks of the 100 MHz clock
+    long long* tl;        // SOS_TIMELINE builds: [gridDim.x][16] clock readings of a workgroup's phases (dev aid), else unused
+};
+#ifndef SOS_TIMELINE
+#define SOS_TIMELINE 0
+#endif
+#if SOS_TIMELINE
+#define SOS_MARK(i) do { if (threadIdx.x == 0 && L.tl) L.tl[(long long)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define SOS_MARK(i) do { } while (0)
+#endif
+constexpr int kLookIter = 3;      // a workgroup looks back over at most kLookIter x (its threads) groups: the one-launch form's limit on groups per row
+
+// No fences in the hand-over: an agent-scope release / acquire is a write-back / invalidate of the XCD's whole L2 on gfx950
+// (buffer_wbl2 / buffer_inv sc1), and with 684 workgroups doing both twice a 2^20 x 2 call took 141 us, its workgroups 12 to 55 us
+// from "samples loaded" to "total published" (profiles/r03_sosfilt.txt).  Instead the totals are written through (sc1 stores), the
+// writer waits for their acknowledgement before it raises the flag, and readers fetch them with sc1 loads, which go past the caches.
+typedef double sos_d2v __attribute__((ext_vector_type(2)));
+
+// Doubles `e` of the workgroup's LDS-resident table (scan powers M^1 .. M^32, M^64, then the wavefronts' carries and totals): pad
+// element number e / CH of the staging slices (slice-major), component e % CH.  Compile-time `e` -> an immediate offset.
+template <int CH> struct PadTable {
+    Smp<CH>* slices;       // lds_all[0]
+    __device__ __forceinline__ double& operator[](int e) const {
+        const int pad = e / CH;
+        return slices[(pad / kWave) * kLdsElems + (pad % kWave) * (kChunk + 1) + kChunk].v[e % CH];
+    }
+};
+template <int K, int CH, class Tab> __device__ __forceinline__ void mat_acc_t(const Tab& M, int base, const double (&x)[CH][K], double (&y)[CH][K]) {
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            if (q / 2 > r / 2) continue;
+            const double mrq = M[base + r * K + q];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) y[c][r] += mrq * x[c][q];
+        }
+}
+template <int K, int CH, class Tab> __device__ __forceinline__ void mat_apply_t(const Tab& M, int base, double (&x)[CH][K]) {
+    double y[CH][K];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[c][k] = 0.0;
+    mat_acc_t<K, CH>(M, base, x, y);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[c][k] = y[c][k];
+}
+// wave_scan / wave_scan_rev with the powers in a PadTable
+template <int K, int CH, bool REV, class Tab> __device__ __forceinline__ void wave_scan_t(double (&x)[CH][K], const Tab& pwt) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int k = 0; k < kScanSteps; ++k) {
+        const int d = 1 << k;
+        double up[CH][K];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int q = 0; q < K; ++q) up[c][q] = REV ? __shfl_down(x[c][q], d, kWave) : __shfl_up(x[c][q], d, kWave);
+        if (REV ? lane + d < kWave : lane >= d) mat_acc_t<K, CH>(pwt, k * K * K, up, x);       // (the others have no partner: one branch instead of 2 N selects)
+    }
+}
+
+// acc = start state of group number `g` of its pass = sum_{d < g} (M^group)^d T'_{g-1-d}; T'_j = the published totals of the row
+// (`Tb`, `Fb`: the row's totals and flags in the pass's own group order).  Waits for each of them: all flags first, then all totals
+// in one round of loads.
+template <int K, int CH, int W>
+__device__ __forceinline__ void group_start(const SosLink& L, const double* Tb, const unsigned* Fb, int g, const double* __restrict__ pwG,
+                                            const double* __restrict__ pwH, double (&acc)[CH][K], int* s_fail) {
+    constexpr int kGroup = kWave * W, N = CH * K;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    double MG[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) MG[r][q] = pwG[(long long)lane * K * K + r * K + q];
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[a][k] = 0.0;
+    const long long t0 = wall_clock64();
+#pragma unroll
+    for (int it = 0; it < kLookIter; ++it) {
+        const int d = it * kGroup + tid;
+        if (d < g) {
+            while (__hip_atomic_load(Fb + (g - 1 - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != L.epoch) {
+                if (wall_clock64() - t0 > L.patience) { *s_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
+    // the totals: 16-byte sc1 buffer loads (compiler-tracked; the flat-address form of an sc1 load only exists as inline assembly, whose
+    // result registers the compiler would be free to copy or spill before the data is there)
+    typedef unsigned int sos_u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Tb), 0, g * N * (int)sizeof(double), 0x00020000);
+    sos_d2v q[kLookIter][N / 2];
+#pragma unroll
+    for (int it = 0; it < kLookIter; ++it) {
+        const int d = it * kGroup + tid;
+        const int off = d < g ? (g - 1 - d) * N * (int)sizeof(double) : 0;
+        if (it * kGroup < g) {                       // (uniform)
+#pragma unroll
+            for (int i = 0; i < N / 2; ++i) {
+                const sos_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16 * i, 0, 16 /* sc1 */);
+                q[it][i] = __builtin_bit_cast(sos_d2v, raw);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kLookIter; ++it) {
+        const bool have = it * kGroup + tid < g;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) q[it][i] = have ? q[it][i] : sos_d2v{0.0, 0.0};
+    }
+    // per lane: (M^group)^(64 (it W + wv)) (M^group)^lane T' for each round, summed; ONE reduction over the wavefront at the end
+#pragma unroll
+    for (int it = 0; it < kLookIter; ++it) {
+        if (it * kGroup >= g) break;                 // (uniform)
+        double u[CH][K], vv[CH][K];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int qq = 0; qq < K; ++qq) {
+                const int e = a * K + qq;
+                vv[a][qq] = e % 2 ? q[it][e / 2].y : q[it][e / 2].x;
+                u[a][qq] = 0.0;
+            }
+        mat_acc<K, CH>(&MG[0][0], vv, u);
+        if (it * kGroup + wv * kWave < g) mat_acc<K, CH>(pwH + (long long)(it * W + wv) * K * K, u, acc);      // wave-uniform, scalar loads
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[a][k] += __shfl_xor(acc[a][k], o, kWave);
+}
+
+template <int NS, int CH, int W>
+__global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <= 2 ? SOS_APPLY_WAVES : 1, 8))) void k_filtfilt(
+    SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi, const double* __restrict__ pw,
+    const double* __restrict__ pwG, const double* __restrict__ pwH, const double* __restrict__ G, double* __restrict__ out, SosLink L) {
+    constexpr int K = 2 * NS, N = CH * K;
+    constexpr int kWaves = W, kGroup = kWave * W;
+    constexpr int kPwEntries = (kScanSteps + 1) * K * K;       // M^1, M^2 .. M^32, M^64
+    constexpr int kM64 = kScanSteps * K * K, kCarry = kPwEntries, kTot = kCarry + kWaves * N, kG = kTot + kWaves * N, kTabSize = kG + K * kChunk;
+    constexpr bool kPads = kTabSize <= kWave * kWaves * CH;       // the table fits the slices' pad elements
+    __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
+    __shared__ double red[kWaves][N];
+    __shared__ __attribute__((aligned(16))) double c_lds[2];
+    __shared__ __attribute__((aligned(16))) int s_fail[4];
+    __shared__ __attribute__((aligned(16))) double v0_lds[N];            // the pass's start state zi * (first sample), in the group that holds it
+    __shared__ __attribute__((aligned(16))) double tab_lds[kPads ? 2 : kTabSize];
+    struct FlatTable { double* t; __device__ __forceinline__ double& operator[](int e) const { return t[e]; } };
+    const PadTable<CH> padt{&lds_all[0][0]};
+    const FlatTable flatt{tab_lds};
+    const auto tabv = [&](int e) -> double& { if constexpr (kPads) return padt[e]; else return flatt[e]; };
+    struct TabRef { decltype(tabv) f; __device__ __forceinline__ double& operator[](int e) const { return f(e); } };
+    const TabRef tab{tabv};
+    const int row = blockIdx.x / ngroups, g = blockIdx.x % ngroups, gb = ngroups - 1 - g;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int ch = g * kGroup + tid;
+    const long long w0 = ((long long)g * kGroup + wv * kWave) * kChunk;
+    const bool plain = wave_is_plain(p, w0);
+    const bool active = plain || ch < nchunks;
+    const double* base = pass_row<CH>(p, row);
+    const long long i0 = (long long)ch * kChunk;
+    const int len = (int)(i0 + kChunk <= p.mv ? kChunk : p.mv - i0);
+    Smp<CH>* const lds = lds_all[wv];
+    double* const Tf = L.T + (long long)row * ngroups * N;
+    double* const Tbk = L.T + ((long long)gridDim.x + (long long)row * ngroups) * N;
+    unsigned* const Ff = L.flag + (long long)row * ngroups;
+    unsigned* const Fbk = L.flag + (long long)gridDim.x + (long long)row * ngroups;
+    if (tid == 0) s_fail[0] = 0;
+    SOS_MARK(0);
+    // the scan's powers -> the LDS table (the pads are nobody else's: no barrier needed before the samples use the slices)
+    for (int e0 = tid; e0 < kPwEntries + K * kChunk; e0 += kGroup) {
+        const bool is_g = e0 >= kPwEntries;
+        const int e = is_g ? kG + (e0 - kPwEntries) : e0;
+        const double val = is_g ? G[e0 - kPwEntries] : pw[((long long)1 << (e0 / (K * K))) * K * K + e0 % (K * K)];
+        if constexpr (kPads) {
+            const int pad = e / CH;
+            lds_all[0][(pad / kWave) * kLdsElems + (pad % kWave) * (kChunk + 1) + kChunk].v[e % CH] = val;
+        } else tab_lds[e] = val;
+    }
+    // the image of the pass's start state zi * x_0 under one group map goes out with group 0's total; group 0 itself starts from it
+    if (g == 0 && tid == 0) {
+        const Smp<CH> u0 = sos_input<CH>(p, base, 0);
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) v0_lds[a * K + k] = zi[k] * u0.v[a];
+    }
+
+    // ---- forward chunk pass (k_chunk_scan's work; the chunk states stay in registers)
+    Smp<CH> xs[kChunk];
+    double ex[CH][K];                     // the chunk's start state if its WAVEFRONT started from zero
+    {
+        double s[CH][K];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) s[a][k] = 0.0;
+        if (plain || g * kGroup + wv * kWave < nchunks) {          // (the whole wavefront moves its 768 samples, whichever lanes hold chunks)
+            if (plain) chunk_to_lds<CH>(p, base, w0, lane, lds);
+            else chunk_to_lds_edge<CH>(p, base, w0, lane, lds);
+            chunk_from_lds<CH>(lds, lane, xs);
+        }
+        SOS_MARK(1);
+        __syncthreads();                      // table, s_fail, v0 staged
+        if (active) {
+            if (len == kChunk) {
+#pragma unroll
+                for (int t = 0; t < kChunk; ++t)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const double gk = tab[kG + k * kChunk + t];
+#pragma unroll
+                        for (int a = 0; a < CH; ++a) s[a][k] = fma(gk, xs[t].v[a], s[a][k]);
+                    }
+            } else {
+                const int off = kChunk - len;
+#pragma unroll
+                for (int t = 0; t < kChunk; ++t)
+                    if (t < len) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const double gk = tab[kG + k * kChunk + off + t];
+#pragma unroll
+                            for (int a = 0; a < CH; ++a) s[a][k] = fma(gk, xs[t].v[a], s[a][k]);
+                        }
+                    }
+            }
+        }
+        SOS_MARK(2);
+        wave_scan_t<K, CH, false>(s, tab);
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double prev = __shfl_up(s[a][k], 1, kWave);
+                ex[a][k] = lane ? prev : 0.0;
+                if (lane == kWave - 1) tab[kTot + wv * N + a * K + k] = s[a][k];
+            }
+        __syncthreads();
+        SOS_MARK(3);
+        // start state of this wavefront if the GROUP started from zero: ws_{w+1} = M^64 ws_w + tot_w.  Kept in the table (wave-uniform).
+        double ws[CH][K];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) ws[a][k] = 0.0;
+        for (int w = 0; w < wv; ++w) {
+            mat_apply_t<K, CH>(tab, kM64, ws);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) ws[a][k] += tab[kTot + w * N + a * K + k];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) tab[kCarry + wv * N + a * K + k] = ws[a][k];
+        }
+        if (wv == kWaves - 1 && g + 1 < ngroups) {
+            mat_apply_t<K, CH>(tab, kM64, ws);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) ws[a][k] += tab[kTot + (kWaves - 1) * N + a * K + k];
+            if (g == 0) {
+                double v0[CH][K];
+#pragma unroll
+                for (int a = 0; a < CH; ++a)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) v0[a][k] = v0_lds[a * K + k];
+                mat_acc<K, CH>(pwG + K * K, v0, ws);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int a = 0; a < CH; ++a)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) __hip_atomic_store(Tf + (long long)g * N + a * K + k, ws[a][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    SOS_MARK(4);
+    // the samples wait in the wavefront's slice while the group's start state is formed
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) lds[lane * (kChunk + 1) + t] = xs[t];
+        wave_lds_sync();
+    }
+    // (the flag follows the total once that is acknowledged: by now it mostly is)
+    if (wv == kWaves - 1 && g + 1 < ngroups) {
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        if (lane == 0) __hip_atomic_store(Ff + g, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    SOS_MARK(5);
+    double sg[CH][K];
+    {
+        double acc[CH][K];
+        group_start<K, CH, W>(L, Tf, Ff, g, pwG, pwH, acc, s_fail);
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) red[wv][a * K + k] = acc[a][k];
+        }
+    }
+    // this lane's M^lane, for the offset of its chunk inside the wavefront
+    double Ml[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) Ml[r][q] = pw[(long long)lane * K * K + r * K + q];
+    __syncthreads();
+    if (s_fail[0]) {
+        if (tid == 0) __hip_atomic_store(L.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double t = red[0][a * K + k];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) t += red[w][a * K + k];
+            sg[a][k] = g == 0 ? v0_lds[a * K + k] : t;
+        }
+    SOS_MARK(6);
+    // ---- forward output pass: the chunk from its true start state M^lane ((M^64)^wv S_g + ws) + ex; the outputs replace the samples
+    for (int w = 0; w < wv; ++w) mat_apply_t<K, CH>(tab, kM64, sg);
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) sg[a][k] += tab[kCarry + wv * N + a * K + k];
+    if (active) {
+        chunk_from_lds<CH>(lds, lane, xs);
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+#pragma unroll
+                for (int a = 0; a < CH; ++a) ex[a][r] += Ml[r][q] * sg[a][q];
+            }
+        double z[CH][NS][2];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { z[a][q][0] = ex[a][2 * q]; z[a][q][1] = ex[a][2 * q + 1]; }
+        if (len == kChunk) {
+#pragma unroll
+            for (int t = 0; t < kChunk; ++t)
+#pragma unroll
+                for (int a = 0; a < CH; ++a) xs[t].v[a] = sos_step_fma<NS>(c, z[a], xs[t].v[a]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < kChunk; ++t)
+                if (t < len) {
+#pragma unroll
+                    for (int a = 0; a < CH; ++a) xs[t].v[a] = sos_step_fma<NS>(c, z[a], xs[t].v[a]);
+                }
+        }
+    }
+    SOS_MARK(7);
+    // ---- backward chunk pass on the outputs, read from the chunk's end to its start (SosPass::mv).  Positions at and beyond m hold
+    // y1[m - 1]: the thread that produced it shares it; all such chunks are in the last group.
+    const long long last = p.m - 1;
+    if (gb == 0) {
+        if (i0 <= last && last < i0 + kChunk) {
+            Smp<CH> cv = xs[0];
+#pragma unroll
+            for (int t = 1; t < kChunk; ++t) if (i0 + t == last) cv = xs[t];
+#pragma unroll
+            for (int a = 0; a < CH; ++a) c_lds[a] = cv.v[a];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+            if (i0 + t > last) {
+#pragma unroll
+                for (int a = 0; a < CH; ++a) xs[t].v[a] = c_lds[a];
+            }
+        if (tid == 0) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) v0_lds[a * K + k] = zi[k] * c_lds[a];
+        }
+    }
+    double exb[CH][K];
+    {
+        double sb[CH][K];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) sb[a][k] = 0.0;
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double gk = tab[kG + k * kChunk + t];
+#pragma unroll
+                for (int a = 0; a < CH; ++a) sb[a][k] = fma(gk, xs[kChunk - 1 - t].v[a], sb[a][k]);
+            }
+        wave_scan_t<K, CH, true>(sb, tab);
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double prev = __shfl_down(sb[a][k], 1, kWave);
+                exb[a][k] = lane != kWave - 1 ? prev : 0.0;
+                if (lane == 0) tab[kTot + wv * N + a * K + k] = sb[a][k];
+            }
+        __syncthreads();                      // (also: v0_lds of the backward pass staged, every wavefront past its use of the forward carries)
+        SOS_MARK(8);
+        // backward order of the wavefronts: the last one comes first
+        double wsb[CH][K];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int k = 0; k < K; ++k) wsb[a][k] = 0.0;
+        for (int b = 0; b < kWaves - 1 - wv; ++b) {
+            mat_apply_t<K, CH>(tab, kM64, wsb);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) wsb[a][k] += tab[kTot + (kWaves - 1 - b) * N + a * K + k];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) tab[kCarry + wv * N + a * K + k] = wsb[a][k];
+        }
+        if (wv == 0 && gb + 1 < ngroups) {
+            mat_apply_t<K, CH>(tab, kM64, wsb);
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) wsb[a][k] += tab[kTot + a * K + k];
+            if (gb == 0) {
+                double v0[CH][K];
+#pragma unroll
+                for (int a = 0; a < CH; ++a)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) v0[a][k] = v0_lds[a * K + k];
+                mat_acc<K, CH>(pwG + K * K, v0, wsb);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int a = 0; a < CH; ++a)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) __hip_atomic_store(Tbk + (long long)gb * N + a * K + k, wsb[a][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) lds[lane * (kChunk + 1) + t] = xs[t];
+    wave_lds_sync();
+    if (wv == 0 && gb + 1 < ngroups) {
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        if (lane == 0) __hip_atomic_store(Fbk + gb, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    SOS_MARK(9);
+    double sgb[CH][K];
+    {
+        double acc[CH][K];
+        group_start<K, CH, W>(L, Tbk, Fbk, gb, pwG, pwH, acc, s_fail);
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a)
+#pragma unroll
+                for (int k = 0; k < K; ++k) red[wv][a * K + k] = acc[a][k];
+        }
+    }
+    // this lane's power for the offset of its chunk inside the wavefront: its backward position there is 63 - lane
+    double Mb[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) Mb[r][q] = pw[(long long)(kWave - 1 - lane) * K * K + r * K + q];
+    __syncthreads();
+    if (s_fail[0]) {
+        if (tid == 0) __hip_atomic_store(L.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double t = red[0][a * K + k];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) t += red[w][a * K + k];
+            sgb[a][k] = gb == 0 ? v0_lds[a * K + k] : t;
+        }
+    SOS_MARK(10);
+    // ---- backward output pass: the chunk from its end, start state M^(63 - lane) ((M^64)^(W - 1 - wv) S_gb + wsb) + exb
+    for (int w = 0; w < kWaves - 1 - wv; ++w) mat_apply_t<K, CH>(tab, kM64, sgb);
+#pragma unroll
+    for (int a = 0; a < CH; ++a)
+#pragma unroll
+        for (int k = 0; k < K; ++k) sgb[a][k] += tab[kCarry + wv * N + a * K + k];
+    chunk_from_lds<CH>(lds, lane, xs);
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a) exb[a][r] += Mb[r][q] * sgb[a][q];
+        }
+    {
+        double z[CH][NS][2];
+#pragma unroll
+        for (int a = 0; a < CH; ++a)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { z[a][q][0] = exb[a][2 * q]; z[a][q][1] = exb[a][2 * q + 1]; }
+#pragma unroll
+        for (int t = kChunk - 1; t >= 0; --t) {
+#pragma unroll
+            for (int a = 0; a < CH; ++a) xs[t].v[a] = sos_step_fma<NS>(c, z[a], xs[t].v[a]);
+            lds[lane * (kChunk + 1) + t] = xs[t];
+        }
+    }
+    wave_lds_sync();
+    SOS_MARK(11);
+    // the result sits where the sample was: padded position k -> out[k - edge]
+    double* const dst = out + (long long)row * p.n * CH;
+#pragma unroll
+    for (int t = 0; t < kChunk; ++t) {
+        const Smp<CH> y = lds[lds_pos(t * kWave + lane)];
+        const long long nn = w0 + t * kWave + lane - p.edge;
+        if (nn >= 0 && nn < p.n) st<CH>(dst, nn, y);
+    }
+    SOS_MARK(12);
+}
+
 // ---------------------------------------------------------------------------------------------- host
 // Scratch memory of the filter, one set per device, grown on demand and kept (a hipMalloc/hipFree pair
 // per call cost more than the kernels).  Calls on one device are serialised by `mu`.
@@ -706,6 +1300,14 @@ struct Workspace {
     size_t cap[6] = {0, 0, 0, 0, 0, 0};
     std::vector<double> table_key;       // sos coefficients the device tables were built for
     float last_ms = 0.f;
+    // one-launch form (k_filtfilt): group totals + their flags, the call counter the flags are compared with, the host-visible give-up word
+    double* link_T = nullptr;
+    unsigned* link_flag = nullptr;
+    size_t link_T_cap = 0, link_flag_cap = 0;
+    unsigned epoch = 0;
+    int* status = nullptr;
+    int give_ups = 0;                    // calls that fell back to three launches after waiting in vain; the form is dropped after kMaxGiveUps
+    int last_launches = 0;
     hipError_t need(int i, size_t bytes) {
         if (bytes <= cap[i]) return hipSuccess;
         if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
@@ -782,6 +1384,38 @@ template <int NS, int W> void build_tables(const SosCoefs& c, std::vector<double
 
 #define WS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SSFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+// ---- the one-launch form's conditions
+constexpr int kMaxGiveUps = 3;
+// SSFM_SOS_ONE_LAUNCH=0: always three launches (read per call)
+inline bool one_launch_enabled() {
+    const char* e = std::getenv("SSFM_SOS_ONE_LAUNCH");
+    return !(e && std::atoi(e) == 0);
+}
+// how long a workgroup waits for a total before it gives the call up, in 10 ns ticks (SSFM_SOS_PATIENCE_US, default 2 ms)
+inline long long one_launch_patience() {
+    if (const char* e = std::getenv("SSFM_SOS_PATIENCE_US")) { const long long v = std::atoll(e); if (v > 0) return v * 100; }
+    return 200000;
+}
+// Workgroups of k_filtfilt the device holds at once.  The runtime's occupancy answer is cut to what the LDS allows with the 512-byte
+// allocation granule and the 161 280 usable bytes measured on gfx950 (three workgroups of 53 760 B fit a CU, three of 54 272 B do not:
+// profiles/r03_sosfilt.txt) -- a grid that waits for workgroups that cannot start would only end by its patience.
+template <int NS, int CH, int W> long long one_launch_capacity() {
+    static long long cap = -1;                                  // (calls are serialised by Workspace::mu)
+    if (cap >= 0) return cap;
+    int per_cu = 0, cus = 0, dev = 0;
+    hipFuncAttributes fa;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_filtfilt<NS, CH, W>, kWave * W, 0) != hipSuccess ||
+        hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_filtfilt<NS, CH, W>)) != hipSuccess) {
+        (void)hipGetLastError();
+        return cap = 0;
+    }
+    const long long lds = ((long long)fa.sharedSizeBytes + 511) / 512 * 512;
+    const long long by_lds = lds > 0 ? 161280 / lds : per_cu;
+    if (const char* e = std::getenv("SSFM_SOS_ONE_LAUNCH_CAP")) return cap = std::atoll(e);      // (tests: force the three-launch form by size)
+    return cap = (long long)cus * (per_cu < by_lds ? per_cu : by_lds);
+}
+
 template <int NS, int CH, int W>
 int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const double* zi_h, const double* x, double* y,
                long long n, int rows, int edge, bool on_device) {
@@ -833,13 +1467,93 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
         d_x = w.buf[0];
         d_out = w.buf[0];          // the backward pass writes the trimmed result over the staged input
     }
-    double *d_y1 = w.buf[1], *d_E = w.buf[2], *d_T = w.buf[3];
-    WS_TRY(hipEventRecord(w.ev0, w.stream));
-    // One stream: splitting the rows over two streams (as the propagator does) was measured SLOWER here
-    // (145 vs 121 us for 2 x 2^20 complex) -- every kernel is a short latency chain, not a bandwidth phase.
     SosPass p;
     p.n = n; p.m = m; p.edge = edge;
     const dim3 grid((unsigned)(ngroups * rows)), block(kGroup);
+    // ---- one launch, when the whole grid is resident at once.  The result never lands on the input (a call that gives up is repeated
+    // from it): an in-place call's goes to the scratch buffer first and is copied over the input afterwards.
+    const bool overlap = on_device && !(reinterpret_cast<const char*>(y) + xbytes <= reinterpret_cast<const char*>(x) ||
+                                        reinterpret_cast<const char*>(x) + xbytes <= reinterpret_cast<const char*>(y));
+    if (one_launch_enabled() && w.give_ups < kMaxGiveUps && ngroups <= kLookIter * kGroup &&
+        (long long)grid.x <= one_launch_capacity<NS, CH, W>()) {
+        const size_t tdoubles = (size_t)2 * grid.x * CH * K;
+        if (tdoubles > w.link_T_cap) {
+            if (w.link_T) (void)hipFree(w.link_T);
+            w.link_T = nullptr; w.link_T_cap = 0;
+            WS_TRY(hipMalloc(&w.link_T, sizeof(double) * tdoubles));
+            w.link_T_cap = tdoubles;
+        }
+        if ((size_t)2 * grid.x > w.link_flag_cap) {
+            if (w.link_flag) (void)hipFree(w.link_flag);
+            w.link_flag = nullptr; w.link_flag_cap = 0;
+            WS_TRY(hipMalloc(&w.link_flag, sizeof(unsigned) * 2 * grid.x));
+            WS_TRY(hipMemsetAsync(w.link_flag, 0, sizeof(unsigned) * 2 * grid.x, w.stream));
+            w.link_flag_cap = (size_t)2 * grid.x;
+            w.epoch = 0;
+        }
+        if (!w.status) WS_TRY(hipHostMalloc(&w.status, 64, hipHostMallocMapped));
+        if (++w.epoch == 0) {                                  // (the counter wrapped: old flags could match again)
+            WS_TRY(hipMemsetAsync(w.link_flag, 0, sizeof(unsigned) * w.link_flag_cap, w.stream));
+            w.epoch = 1;
+        }
+        *w.status = 0;
+        SosLink L;
+        L.T = w.link_T; L.flag = w.link_flag; L.status = w.status; L.epoch = w.epoch; L.patience = one_launch_patience();
+        L.tl = nullptr;
+#if SOS_TIMELINE
+        static long long* d_tl = nullptr; static size_t tl_cap = 0;
+        if (std::getenv("SOS_TIMELINE_DUMP")) {
+            if (tl_cap < grid.x) { if (d_tl) (void)hipFree(d_tl); WS_TRY(hipMalloc(&d_tl, sizeof(long long) * 16 * grid.x)); tl_cap = grid.x; }
+            L.tl = d_tl;
+        }
+#endif
+        double* const d_res = (!on_device || overlap) ? w.buf[1] : y;
+        p.backward = 0; p.src = d_x; p.mv = m;
+        WS_TRY(hipEventRecord(w.ev0, w.stream));
+        hipLaunchKernelGGL((k_filtfilt<NS, CH, W>), grid, block, 0, w.stream, c, p, nchunks, ngroups, d_zi, d_pw, d_pwG, d_pwH, d_G, d_res, L);
+        WS_TRY(hipGetLastError());
+        WS_TRY(hipEventRecord(w.ev1, w.stream));
+        if (!on_device) WS_TRY(hipMemcpyAsync(y, d_res, xbytes, hipMemcpyDeviceToHost, w.stream));
+        WS_TRY(hipStreamSynchronize(w.stream));
+        if (*w.status == 0 && on_device && overlap) {
+            WS_TRY(hipMemcpyAsync(y, d_res, xbytes, hipMemcpyDeviceToDevice, w.stream));
+            WS_TRY(hipStreamSynchronize(w.stream));
+        }
+#if SOS_TIMELINE
+        if (L.tl) {
+            // per phase: when the first, the median and the last workgroup got there, in us after the first workgroup's start; then a few workgroups' own lines
+            std::vector<long long> h((size_t)16 * grid.x);
+            WS_TRY(hipMemcpy(h.data(), L.tl, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+            long long t0 = h[0];
+            for (unsigned b = 0; b < grid.x; ++b) t0 = h[(size_t)b * 16] < t0 ? h[(size_t)b * 16] : t0;
+            static const char* names[13] = {"start", "loaded", "chunk sums", "scanned", "total stored", "flag raised", "forward start state", "forward outputs",
+                                            "backward scanned", "backward flag raised", "backward start state", "backward outputs", "end"};
+            constexpr int kMarks = 13;
+            for (int i = 0; i < kMarks; ++i) {
+                std::vector<double> v;
+                for (unsigned b = 0; b < grid.x; ++b) v.push_back((h[(size_t)b * 16 + i] - t0) * 0.01);
+                std::sort(v.begin(), v.end());
+                std::fprintf(stderr, "%2d %-22s first %6.2f  median %6.2f  last %6.2f us\n", i, names[i], v.front(), v[v.size() / 2], v.back());
+            }
+            for (unsigned b = 0; b < grid.x; b += grid.x / 6 ? grid.x / 6 : 1) {
+                std::fprintf(stderr, "  workgroup %4u:", b);
+                for (int i = 0; i < kMarks; ++i) std::fprintf(stderr, " %6.2f", (h[(size_t)b * 16 + i] - t0) * 0.01);
+                std::fprintf(stderr, "\n");
+            }
+        }
+#endif
+        if (*w.status == 0) {
+            WS_TRY(hipEventElapsedTime(&w.last_ms, w.ev0, w.ev1));
+            w.last_launches = 1;
+            return SSFM_OK;
+        }
+        ++w.give_ups;                                          // part of the grid never ran beside the rest: three launches from the untouched input
+    }
+    double *d_y1 = w.buf[1], *d_E = w.buf[2], *d_T = w.buf[3];
+    w.last_launches = 3;
+    WS_TRY(hipEventRecord(w.ev0, w.stream));
+    // One stream: splitting the rows over two streams (as the propagator does) was measured SLOWER here
+    // (145 vs 121 us for 2 x 2^20 complex) -- every kernel is a short latency chain, not a bandwidth phase.
     // Three launches per call: chunk pass (forward), output pass (forward) + chunk pass (backward) in one kernel, output pass (backward).
     // SOS_FUSE=0 (build knob) keeps the backward chunk pass a launch of its own.
     double *d_E2 = w.buf[4], *d_T2 = w.buf[3] + (size_t)ngroups * rows * CH * K;
