@@ -151,9 +151,16 @@ int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sect
  * field can be filtered where it was propagated.  sos and zi stay HOST arrays.  Synchronous. */
 int ssfm_sosfiltfilt_device(int device, const double* sos, const double* zi, int n_sections, const void* x_dev, void* y_dev,
                             int64_t n, int batch, int is_complex);
-/* Device time [ms] of the six kernels of the last ssfm_sosfiltfilt* call on `device` (HIP events on the
+/* Device time [ms] of the kernels of the last ssfm_sosfiltfilt* call on `device` (HIP events on the
  * filter's stream, transfers excluded). */
 int ssfm_sosfiltfilt_last_ms(int device, float* ms);
+/* Kernel launches of the last ssfm_sosfiltfilt* call on `device`: 1 when the whole forward-backward pass ran as one
+ * launch (every workgroup of the call resident at once: up to about 2.3 M real or complex samples in all on an
+ * MI355X, at most 512 groups of 3072 samples per row), 3 otherwise (longer calls; SSFM_SOS_ONE_LAUNCH=0; a call
+ * whose workgroups did not all get to run side by side within SSFM_SOS_PATIENCE_US -- default 2000 -- is
+ * repeated in this form, and after three such calls in a row the next 1000 calls skip the one-launch form).  The two
+ * forms agree to rounding (the one-launch form uses fused multiply-adds), not bit for bit. */
+int ssfm_sosfiltfilt_last_launches(int device, int* launches);
 
 /* Square-law detection of the reference's PD (devices.py:1512-1515): i_ph = r * (x * x.conj()).real summed
  * over the polarisations, signal and noise kept apart as the reference's signal algebra does

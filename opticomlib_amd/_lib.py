@@ -41,6 +41,7 @@ SYMBOLS = {
     "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
     "ssfm_sosfiltfilt_device": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
     "ssfm_sosfiltfilt_last_ms": (_I, [_I, C.POINTER(C.c_float)]),
+    "ssfm_sosfiltfilt_last_launches": (_I, [_I, C.POINTER(C.c_int)]),
     "ssfm_square_law": (_I, [_I, _VP, _VP, _I, _I64, _D, _D, _VP, _VP]),
     "ssfm_square_law_device": (_I, [_I, _VP, _VP, _I, _I64, _D, _D, _VP, _VP]),
     "ssfm_device_alloc": (_I, [_I, C.c_size_t, C.POINTER(_VP)]),
@@ -197,6 +198,13 @@ def sosfiltfilt_last_ms(device: int = 0) -> float:
     ms = C.c_float()
     _check(load().ssfm_sosfiltfilt_last_ms(int(device), C.byref(ms)), "ssfm_sosfiltfilt_last_ms")
     return float(ms.value)
+
+
+def sosfiltfilt_last_launches(device: int = 0) -> int:
+    """Kernel launches of the last filter call on ``device``: 1 (one-launch form) or 3."""
+    k = C.c_int()
+    _check(load().ssfm_sosfiltfilt_last_launches(int(device), C.byref(k)), "ssfm_sosfiltfilt_last_launches")
+    return int(k.value)
 
 
 # ----------------------------------------------------------------------------- device-resident arrays

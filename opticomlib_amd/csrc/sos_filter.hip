@@ -237,9 +237,13 @@ template <int CH> __device__ __forceinline__ void chunk_to_lds_edge(const SosPas
     Smp<CH> tmp[kChunk];
 #pragma unroll
     for (int t = 0; t < kChunk; ++t) {
-        long long i = w0 + t * kWave + lane;
-        i = i < p.mv ? i : p.mv - 1;                              // (beyond the sequence: never used)
-        tmp[t] = sos_input<CH>(p, base, i);
+        const long long b = w0 + t * kWave;                          // (wave-uniform: most of the 12 instructions of an edge wavefront are plain)
+        if (b >= p.edge && b + kWave <= p.edge + p.n) tmp[t] = ld<CH>(base, b + lane - p.edge);
+        else {
+            long long i = b + lane;
+            i = i < p.mv ? i : p.mv - 1;                          // (beyond the sequence: never used)
+            tmp[t] = sos_input<CH>(p, base, i);
+        }
     }
 #pragma unroll
     for (int t = 0; t < kChunk; ++t) lds[lds_pos(t * kWave + lane)] = tmp[t];
@@ -758,7 +762,7 @@ struct SosLink {
 #else
 #define SOS_MARK(i) do { } while (0)
 #endif
-constexpr int kLookIter = 3;      // a workgroup looks back over at most kLookIter x (its threads) groups: the one-launch form's limit on groups per row
+constexpr int kLookIter = 2;      // a workgroup looks back over at most kLookIter x (its threads) groups: the one-launch form's limit on groups per row
 
 // No fences in the hand-over: an agent-scope release / acquire is a write-back / invalidate of the XCD's whole L2 on gfx950
 // (buffer_wbl2 / buffer_inv sc1), and with 684 workgroups doing both twice a 2^20 x 2 call took 141 us, its workgroups 12 to 55 us
@@ -1097,6 +1101,7 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
 #pragma unroll
                 for (int a = 0; a < CH; ++a) ex[a][r] += Ml[r][q] * sg[a][q];
             }
+        SOS_MARK(13);
         double z[CH][NS][2];
 #pragma unroll
         for (int a = 0; a < CH; ++a)
@@ -1306,7 +1311,8 @@ struct Workspace {
     size_t link_T_cap = 0, link_flag_cap = 0;
     unsigned epoch = 0;
     int* status = nullptr;
-    int give_ups = 0;                    // calls that fell back to three launches after waiting in vain; the form is dropped after kMaxGiveUps
+    int give_ups = 0;                    // calls IN A ROW that fell back to three launches after waiting in vain; from kMaxGiveUps on the form rests
+    int rested = 0;                      // ... for kRestCalls calls, then gets another try
     int last_launches = 0;
     hipError_t need(int i, size_t bytes) {
         if (bytes <= cap[i]) return hipSuccess;
@@ -1385,7 +1391,7 @@ template <int NS, int W> void build_tables(const SosCoefs& c, std::vector<double
 #define WS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SSFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 // ---- the one-launch form's conditions
-constexpr int kMaxGiveUps = 3;
+constexpr int kMaxGiveUps = 3, kRestCalls = 1000;
 // SSFM_SOS_ONE_LAUNCH=0: always three launches (read per call)
 inline bool one_launch_enabled() {
     const char* e = std::getenv("SSFM_SOS_ONE_LAUNCH");
@@ -1474,6 +1480,7 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
     // from it): an in-place call's goes to the scratch buffer first and is copied over the input afterwards.
     const bool overlap = on_device && !(reinterpret_cast<const char*>(y) + xbytes <= reinterpret_cast<const char*>(x) ||
                                         reinterpret_cast<const char*>(x) + xbytes <= reinterpret_cast<const char*>(y));
+    if (w.give_ups >= kMaxGiveUps && ++w.rested >= kRestCalls) { w.give_ups = kMaxGiveUps - 1; w.rested = 0; }
     if (one_launch_enabled() && w.give_ups < kMaxGiveUps && ngroups <= kLookIter * kGroup &&
         (long long)grid.x <= one_launch_capacity<NS, CH, W>()) {
         const size_t tdoubles = (size_t)2 * grid.x * CH * K;
@@ -1526,9 +1533,9 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
             WS_TRY(hipMemcpy(h.data(), L.tl, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
             long long t0 = h[0];
             for (unsigned b = 0; b < grid.x; ++b) t0 = h[(size_t)b * 16] < t0 ? h[(size_t)b * 16] : t0;
-            static const char* names[13] = {"start", "loaded", "chunk sums", "scanned", "total stored", "flag raised", "forward start state", "forward outputs",
-                                            "backward scanned", "backward flag raised", "backward start state", "backward outputs", "end"};
-            constexpr int kMarks = 13;
+            static const char* names[14] = {"start", "loaded", "chunk sums", "scanned", "total stored", "flag raised", "forward start state", "forward outputs",
+                                            "backward scanned", "backward flag raised", "backward start state", "backward outputs", "end", "(forward chunk state)"};
+            constexpr int kMarks = 14;
             for (int i = 0; i < kMarks; ++i) {
                 std::vector<double> v;
                 for (unsigned b = 0; b < grid.x; ++b) v.push_back((h[(size_t)b * 16 + i] - t0) * 0.01);
@@ -1545,6 +1552,7 @@ int run_filter_w(Workspace& w, const SosCoefs& c, const double* sos_key, const d
         if (*w.status == 0) {
             WS_TRY(hipEventElapsedTime(&w.last_ms, w.ev0, w.ev1));
             w.last_launches = 1;
+            w.give_ups = 0;
             return SSFM_OK;
         }
         ++w.give_ups;                                          // part of the grid never ran beside the rest: three launches from the untouched input
@@ -1636,6 +1644,14 @@ extern "C" int ssfm_sosfiltfilt(int device, const double* sos, const double* zi,
 extern "C" int ssfm_sosfiltfilt_device(int device, const double* sos, const double* zi, int n_sections, const void* x_dev, void* y_dev,
                                        int64_t n, int batch, int is_complex) {
     return sosfiltfilt_impl(device, sos, zi, n_sections, x_dev, y_dev, n, batch, is_complex, true);
+}
+
+extern "C" int ssfm_sosfiltfilt_last_launches(int device, int* launches) {
+    if (!launches) return fail(SSFM_ERR_INVALID, "launches is NULL");
+    if (device < 0 || device >= kMaxDevices) return fail(SSFM_ERR_NO_DEVICE, "ssfm_sosfiltfilt_last_launches: device %d", device);
+    std::lock_guard<std::mutex> lock(g_ws[device].mu);
+    *launches = g_ws[device].last_launches;
+    return SSFM_OK;
 }
 
 extern "C" int ssfm_sosfiltfilt_last_ms(int device, float* ms) {

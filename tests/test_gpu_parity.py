@@ -856,6 +856,59 @@ def test_sosfiltfilt_on_device_buffers():
         q.close()
 
 
+@pytest.mark.parametrize("order,n,rows,cplx", [(4, 1 << 16, 2, True), (2, 5000, 1, False), (8, 70001, 2, True), (5, 300000, 1, False),
+                                               (4, 1 << 20, 2, True), (3, 777, 3, True)])
+def test_sosfiltfilt_in_one_launch_and_in_three(order, n, rows, cplx, monkeypatch):
+    """Both forms of the filter against SciPy and against each other: the one-launch kernel (every workgroup of the call
+    resident, group totals handed over through flags in HBM) and the three-launch form that longer calls, or a call that
+    could not get its whole grid running, use."""
+    from scipy import signal as sg
+    sos = sg.bessel(order, 0.06, "low", norm="mag", output="sos")
+    zi = sg.sosfilt_zi(sos)
+    rng = np.random.default_rng(n + order)
+    x = rng.standard_normal((rows, n)).cumsum(axis=-1) * 0.02 + rng.standard_normal((rows, n))
+    if cplx:
+        x = x + 1j * rng.standard_normal((rows, n))
+    want = sg.sosfiltfilt(sos, x, axis=-1)
+    monkeypatch.delenv("SSFM_SOS_ONE_LAUNCH", raising=False)
+    one = _lib.sosfiltfilt(sos, zi, x)
+    launches_default = _lib.sosfiltfilt_last_launches()
+    monkeypatch.setenv("SSFM_SOS_ONE_LAUNCH", "0")
+    three = _lib.sosfiltfilt(sos, zi, x)
+    assert _lib.sosfiltfilt_last_launches() == 3
+    assert relmax(one, want) < TOL_FILT and relmax(three, want) < TOL_FILT
+    assert relmax(one, three) < 1e-13
+    if order <= 4:
+        assert launches_default == 1                                   # (orders 5 to 8 fit one workgroup per CU: the longest calls fall back)
+
+
+def test_sosfiltfilt_one_launch_gives_up_cleanly(monkeypatch):
+    """A grid that cannot make progress as a whole (here: forced, a wait of 0.01 us) hands the call to the three-launch
+    form: same result, input untouched."""
+    from scipy import signal as sg
+    sos = sg.bessel(4, 0.1, "low", norm="mag", output="sos")
+    zi = sg.sosfilt_zi(sos)
+    rng = np.random.default_rng(11)
+    n = 1 << 17
+    x = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
+    want = sg.sosfiltfilt(sos, x, axis=-1)
+    p, q = _lib.Plan(n, 2, _lib.C128), _lib.Plan(n, 2, _lib.C128)
+    try:
+        p.set_field(x)
+        p.synchronize()
+        monkeypatch.setenv("SSFM_SOS_PATIENCE_US", "1")
+        _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, q.field_device_ptr, n, 2, True)
+        # (a 1 us wait may or may not be enough on an idle GPU: either form is acceptable, the result is not)
+        assert _lib.sosfiltfilt_last_launches() in (1, 3)
+        assert relmax(q.get_field(), want) < TOL_FILT
+        assert np.array_equal(p.get_field(), x)
+        _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, p.field_device_ptr, n, 2, True)      # in place
+        assert relmax(p.get_field(), want) < TOL_FILT
+    finally:
+        p.close()
+        q.close()
+
+
 def test_narrow_filters_warn_and_stay_within_the_documented_bound():
     from scipy import signal as sg
     gv(sps=16, R=10e9)
