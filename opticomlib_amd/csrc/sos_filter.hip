@@ -762,6 +762,9 @@ struct SosLink {
 #else
 #define SOS_MARK(i) do { } while (0)
 #endif
+#ifndef SOS_AHEAD_LARGE
+#define SOS_AHEAD_LARGE 0
+#endif
 constexpr int kLookIter = 2;      // a workgroup looks back over at most kLookIter x (its threads) groups: the one-launch form's limit on groups per row
 
 // No fences in the hand-over: an agent-scope release / acquire is a write-back / invalidate of the XCD's whole L2 on gfx950
@@ -853,7 +856,7 @@ __device__ __forceinline__ void group_start(const SosLink& L, const double* Tb, 
 #pragma unroll
     for (int it = 0; it < kLookIter; ++it) {
         const int d = it * kGroup + tid;
-        const int off = d < g ? (g - 1 - d) * N * (int)sizeof(double) : 0;
+        const int off = d < g ? (g - 1 - d) * N * (int)sizeof(double) : 0x7ffffff0;        // (beyond the descriptor's range: the load returns zeros)
         if (it * kGroup < g) {                       // (uniform)
 #pragma unroll
             for (int i = 0; i < N / 2; ++i) {
@@ -861,12 +864,6 @@ __device__ __forceinline__ void group_start(const SosLink& L, const double* Tb, 
                 q[it][i] = __builtin_bit_cast(sos_d2v, raw);
             }
         }
-    }
-#pragma unroll
-    for (int it = 0; it < kLookIter; ++it) {
-        const bool have = it * kGroup + tid < g;
-#pragma unroll
-        for (int i = 0; i < N / 2; ++i) q[it][i] = have ? q[it][i] : sos_d2v{0.0, 0.0};
     }
     // per lane: (M^group)^(64 (it W + wv)) (M^group)^lane T' for each round, summed; ONE reduction over the wavefront at the end
 #pragma unroll
@@ -893,7 +890,7 @@ __device__ __forceinline__ void group_start(const SosLink& L, const double* Tb, 
 }
 
 template <int NS, int CH, int W>
-__global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <= 2 ? SOS_APPLY_WAVES : 1, 8))) void k_filtfilt(
+__global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <= 2 && W != kWavesSmall ? SOS_APPLY_WAVES : 1, 8))) void k_filtfilt(
     SosCoefs c, SosPass p, int nchunks, int ngroups, const double* __restrict__ zi, const double* __restrict__ pw,
     const double* __restrict__ pwG, const double* __restrict__ pwH, const double* __restrict__ G, double* __restrict__ out, SosLink L) {
     constexpr int K = 2 * NS, N = CH * K;
@@ -901,6 +898,7 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
     constexpr int kPwEntries = (kScanSteps + 1) * K * K;       // M^1, M^2 .. M^32, M^64
     constexpr int kM64 = kScanSteps * K * K, kCarry = kPwEntries, kTot = kCarry + kWaves * N, kG = kTot + kWaves * N, kTabSize = kG + K * kChunk;
     constexpr bool kPads = kTabSize <= kWave * kWaves * CH;       // the table fits the slices' pad elements
+    constexpr bool kAhead = W == kWavesSmall || SOS_AHEAD_LARGE;
     __shared__ Smp<CH> lds_all[kWaves][kLdsElems];
     __shared__ double red[kWaves][N];
     __shared__ __attribute__((aligned(16))) double c_lds[2];
@@ -1054,6 +1052,15 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
         if (lane == 0) __hip_atomic_store(Ff + g, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     SOS_MARK(5);
+    // this lane's M^lane, for the offset of its chunk inside the wavefront: asked for ahead of the wait where the registers allow it
+    // (the two-wavefront shape of short calls, which are pure latency chains), behind it otherwise (three workgroups per CU: 168 registers)
+    double Ml[K][K];
+    if constexpr (kAhead) {
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int q = 0; q < K; ++q) Ml[r][q] = pw[(long long)lane * K * K + r * K + q];
+    }
     double sg[CH][K];
     {
         double acc[CH][K];
@@ -1065,12 +1072,12 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
                 for (int k = 0; k < K; ++k) red[wv][a * K + k] = acc[a][k];
         }
     }
-    // this lane's M^lane, for the offset of its chunk inside the wavefront
-    double Ml[K][K];
+    if constexpr (!kAhead) {
 #pragma unroll
-    for (int r = 0; r < K; ++r)
+        for (int r = 0; r < K; ++r)
 #pragma unroll
-        for (int q = 0; q < K; ++q) Ml[r][q] = pw[(long long)lane * K * K + r * K + q];
+            for (int q = 0; q < K; ++q) Ml[r][q] = pw[(long long)lane * K * K + r * K + q];
+    }
     __syncthreads();
     if (s_fail[0]) {
         if (tid == 0) __hip_atomic_store(L.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1222,6 +1229,14 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
         if (lane == 0) __hip_atomic_store(Fbk + gb, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     SOS_MARK(9);
+    // this lane's power for the offset of its chunk inside the wavefront: its backward position there is 63 - lane
+    double Mb[K][K];
+    if constexpr (kAhead) {
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int q = 0; q < K; ++q) Mb[r][q] = pw[(long long)(kWave - 1 - lane) * K * K + r * K + q];
+    }
     double sgb[CH][K];
     {
         double acc[CH][K];
@@ -1233,12 +1248,12 @@ __global__ __launch_bounds__(kWave * W) __attribute__((amdgpu_waves_per_eu(NS <=
                 for (int k = 0; k < K; ++k) red[wv][a * K + k] = acc[a][k];
         }
     }
-    // this lane's power for the offset of its chunk inside the wavefront: its backward position there is 63 - lane
-    double Mb[K][K];
+    if constexpr (!kAhead) {
 #pragma unroll
-    for (int r = 0; r < K; ++r)
+        for (int r = 0; r < K; ++r)
 #pragma unroll
-        for (int q = 0; q < K; ++q) Mb[r][q] = pw[(long long)(kWave - 1 - lane) * K * K + r * K + q];
+            for (int q = 0; q < K; ++q) Mb[r][q] = pw[(long long)(kWave - 1 - lane) * K * K + r * K + q];
+    }
     __syncthreads();
     if (s_fail[0]) {
         if (tid == 0) __hip_atomic_store(L.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
