@@ -1,5 +1,5 @@
 """Zero-phase filter kernels for a handful of shapes, device-resident, back to back (tuning aid for SOS_CHUNK / SOS_WAVES)."""
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from opticomlib_amd import _lib
 from scipy import signal as sg

@@ -1,6 +1,6 @@
 """Phase timeline of the one-launch filter kernel (dev aid; needs a -DSOS_TIMELINE=1 build of sos_filter.hip):
     VSRC=sos_filter.hip tools/variants.sh build tl:-DSOS_TIMELINE=1;  SSFM_LIB=build/var/_ssfm_tl.so [LOG2N=20 ROWS=2 CPLX=1] python tools/sos_timeline.py"""
-import os, sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from opticomlib_amd import _lib
 from scipy import signal as sg
