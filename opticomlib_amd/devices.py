@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import os
 import threading
+import functools
 import time
 from collections import OrderedDict
 
@@ -702,12 +703,22 @@ def _warn_narrow(cutoff_hz, fs, what):
                       f"scipy.signal.sosfiltfilt by about {5e-20 * (fs / cutoff_hz) ** 3:.1e} (relative)", RuntimeWarning, stacklevel=3)
 
 
-def _bessel_sos(n, cutoff_hz, fs):
-    """Filter DESIGN (O(order) host work, identical call to the reference's): Bessel low-pass as
-    second-order sections, magnitude-normalised, plus the steady-state initial conditions."""
+@functools.lru_cache(maxsize=64)
+def _bessel_design(n, cutoff_hz, fs):
     from scipy import signal as sg
     sos = sg.bessel(N=n, Wn=cutoff_hz, btype="low", fs=fs, output="sos", norm="mag")
-    return sos, sg.sosfilt_zi(sos)
+    zi = sg.sosfilt_zi(sos)
+    sos.setflags(write=False)
+    zi.setflags(write=False)
+    return sos, zi
+
+
+def _bessel_sos(n, cutoff_hz, fs):
+    """Filter DESIGN (O(order) host work, identical call to the reference's): Bessel low-pass as
+    second-order sections, magnitude-normalised, plus the steady-state initial conditions.  SciPy
+    needs a millisecond for it -- 20 to 50 times the filter kernels of a call -- so the (read-only)
+    result of the last 64 distinct (order, cutoff, fs) is kept."""
+    return _bessel_design(int(n) if isinstance(n, (int, np.integer)) else n, float(cutoff_hz), float(fs))
 
 
 def LPF(input, BW: float, n: int = 4, fs: float = None, retH: bool = False, *, device=None):
