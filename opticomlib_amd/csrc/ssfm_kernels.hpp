@@ -34,6 +34,9 @@
 #ifndef SSFM_LATE_TAB
 #define SSFM_LATE_TAB 0
 #endif
+#ifndef SSFM_RELAXED_BARRIER
+#define SSFM_RELAXED_BARRIER 1
+#endif
 #ifndef SSFM_LATE_P
 #define SSFM_LATE_P 2
 #endif
@@ -759,10 +762,18 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 #pragma unroll
                 for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
                 atomicMax(&a.st->slots[0][set][blockIdx.x % kAdaptSlots], float_bits<T>(m));
+#if SSFM_RELAXED_BARRIER
+                // Only atomics cross this barrier (the slots, read back with agent-scope loads below), so no fence is needed -- an agent-scope
+                // release / acquire writes back / invalidates the XCD's whole L2 on gfx950 -- just the order: the maximum is acknowledged
+                // before the arrival is counted.
+                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                __hip_atomic_fetch_add(&a.st->arrive[set], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                 __hip_atomic_fetch_add(&a.st->arrive[set], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                 const long long t0 = wall_clock64();                  // 100 MHz
                 for (;;) {
-                    if (__hip_atomic_load(&a.st->arrive[set], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { good = 1; break; }
+                    if (__hip_atomic_load(&a.st->arrive[set], SSFM_RELAXED_BARRIER ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { good = 1; break; }
                     if (wall_clock64() - t0 > a.st->patience) break;  // (20 ms) the grid is not running as a whole -- give up, never hang
                     __builtin_amdgcn_s_sleep(1);
                 }
