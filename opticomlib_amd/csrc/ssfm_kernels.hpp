@@ -881,7 +881,15 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 #pragma unroll
                 for (int w = 1; w < NWAVES; ++w) m = wave_max[w] > m ? wave_max[w] : m;
                 atomicMax(&a.st->slots[a.lane][a.step & 1][blockIdx.x % kAdaptSlots], float_bits<T>(m));
-                if (a.lanes2) __hip_atomic_fetch_add(&a.st->arrived[a.lane][blockIdx.x % kAdaptSlots], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.lanes2) {
+#if SSFM_RELAXED_BARRIER && SSFM_STORE_MODE == 1 && SSFM_P_WT == 1
+                    // (the field and |A|^2 stores of this workgroup are write-through and were waited for at the barrier above; see TM_MID_A)
+                    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][blockIdx.x % kAdaptSlots], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][blockIdx.x % kAdaptSlots], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                }
             }
         }
         SSFM_TRACE_END(a);
