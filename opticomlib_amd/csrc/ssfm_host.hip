@@ -22,6 +22,7 @@
 #include "ssfm_amd.h"
 #include "ssfm_common.hpp"
 #include "ssfm_kernels.hpp"
+#include "ssfm_medium.hpp"
 
 using namespace ssfm;
 
@@ -281,6 +282,16 @@ template <typename T> struct PlanT : PlanBase {
     bool small = false;        // env SSFM_SMALL=0 turns it off
     cx<T>* tw_small = nullptr;
     cx<T>* dsmall = nullptr;   // D~ in the one-line order (k_small_adapt)
+    // single-launch engine of medium plans (ssfm_kernels.hpp k_medium): its barrier counters and error word in device memory, a pinned
+    // host copy of the error word, and what a repeat of the run on the two-kernel engine needs
+    bool medium_ok = true;     // env SSFM_MEDIUM=0, or a run whose barrier once ran out of patience, clears it
+    unsigned long long* medium_st = nullptr;       // kBarShards counters, then the error word
+    unsigned* medium_err_host = nullptr;
+    bool medium_pending = false;
+    int medium_xcc = -1, medium_xccs = 8;          // the XCD this plan's single-launch runs use, of so many
+    std::vector<T> medium_sched;
+    double medium_gamma = 0;
+    long long medium_patience = 2000000ll;
     bool fused_ok = true;      // TM_MID_A may be used (env SSFM_ADAPT_FUSED=0, or a grid that once did not run as a whole, clears it)
     bool lanes2_ok = false;    // adaptive runs use two lanes: opt-in (env SSFM_ADAPT_LANES=2) -- measured 43 against 33 us per step of the
                                // one-stream engine at 2^20 x 2 (profiles/r03_adaptive_two_lanes.txt); a lane that once gave up waiting clears it
@@ -499,6 +510,8 @@ template <typename T> struct PlanT : PlanBase {
         (void)hipFree(tw_small);
         (void)hipFree(dsmall);
         (void)hipFree(fused_backup);
+        (void)hipFree(medium_st);
+        if (medium_err_host) (void)hipHostFree(medium_err_host);
         (void)hipFree(d_hs);
         for (int g = 1; g < kMaxLanes; ++g) {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
@@ -613,6 +626,8 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipMalloc(&dperm_fly, cb * n));
         }
         if (const char* e = std::getenv("SSFM_ADAPT_FUSED")) fused_ok = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_MEDIUM")) medium_ok = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) medium_patience = std::atoll(e);
         if (const char* e = std::getenv("SSFM_ADAPT_LANES")) lanes2_ok = std::atoi(e) >= 2;
         if (const char* e = std::getenv("SSFM_PHASE_TABLE")) phase_tables = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_FORCE_FLY")) force_fly = std::atoi(e) != 0;
@@ -700,7 +715,83 @@ template <typename T> struct PlanT : PlanBase {
     }
 #endif
 
-    int use_device() { HIP_TRY(hipSetDevice(device)); return SSFM_OK; }
+    int use_device() {
+        HIP_TRY(hipSetDevice(device));
+        return medium_pending ? finish_medium() : (int)SSFM_OK;
+    }
+    // A single-launch run of a medium plan is asynchronous like every run; whether one of its barriers ran out of patience is known
+    // once it has finished.  The next call that uses the plan looks: on an error the input is restored and the run repeated on the
+    // two-kernel engine (and the plan keeps to it).
+    int finish_medium() {
+        medium_pending = false;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (*medium_err_host == 0u) return SSFM_OK;
+        *medium_err_host = 0u;
+        medium_ok = false;
+        HIP_TRY(hipMemcpyAsync(F, fused_backup, sizeof(cx<T>) * n * batch, hipMemcpyDeviceToDevice, stream));
+        const std::vector<T> sched = medium_sched;
+        if (int rc = propagate_fixed(medium_gamma, sched.data(), (int64_t)sched.size(), nullptr)) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SSFM_OK;
+    }
+    // the whole schedule in one launch (k_medium); `distinct` holds at most kMaxTables step sizes
+    int run_medium(T gamma, double gamma_d, const T* h, int64_t nsteps, const std::vector<T>& distinct, bool phase) {
+        if constexpr (sizeof(T) != 4) { (void)gamma; (void)gamma_d; (void)h; (void)nsteps; (void)distinct; (void)phase; return fail(SSFM_ERR_STATE, "the medium engine is complex64 only"); }
+        else {
+        MediumArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        if (int rc = tables_for(distinct, a.tab, false, phase ? 1 : 0)) return rc;
+        for (size_t i = 0; i < distinct.size(); ++i) { const T xr = op_re0 * distinct[i]; a.amp[i] = (T)std::exp((double)xr) * inv_n(); }
+        const size_t hb = sizeof(T) * (size_t)nsteps, need = hb + (size_t)nsteps;
+        if (d_hs_cap < need) {
+            (void)hipFree(d_hs); d_hs = nullptr; d_hs_cap = 0;
+            HIP_TRY(hipMalloc(&d_hs, need + need / 2));
+            d_hs_cap = need + need / 2;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));             // the staging vector may still feed the previous run's copy
+        h_sched.resize(need);
+        std::memcpy(h_sched.data(), h, hb);
+        for (int64_t s = 0; s < nsteps; ++s) {
+            unsigned char w = 0;
+            for (size_t i = 0; i < distinct.size(); ++i)
+                if (std::memcmp(&distinct[i], &h[s], sizeof(T)) == 0) w = (unsigned char)i;
+            h_sched[hb + (size_t)s] = w;
+        }
+        HIP_TRY(hipMemcpyAsync(d_hs, h_sched.data(), need, hipMemcpyHostToDevice, stream));
+        const size_t fb = sizeof(cx<T>) * n * batch;
+        if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
+        HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));          // for a repeat on the two-kernel engine
+        if (!medium_st) {
+            HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * (kBarShards + 2)));
+            HIP_TRY(hipHostMalloc(&medium_err_host, sizeof(unsigned)));
+            *medium_err_host = 0u;
+        }
+        HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + 2), stream));
+        a.F = F; a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.tw2 = tw2;
+        a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb;
+        a.bar = medium_st; a.error = reinterpret_cast<unsigned*>(medium_st + kBarShards); a.patience = medium_patience;
+        if (medium_xcc < 0) {
+            // the XCDs a launch is dealt to, and this plan's among them
+            static std::atomic<int> next_plan{0};
+            const unsigned mask = xcc_mask(device);
+            if (mask == 0u) return fail(SSFM_ERR_HIP, "the XCD probe launch failed");
+            medium_xccs = __builtin_popcount(mask);
+            int k = next_plan.fetch_add(1) % medium_xccs;
+            for (int b = 0; b < 32; ++b)
+                if ((mask >> b) & 1u) { if (k == 0) { medium_xcc = b; break; } --k; }
+        }
+        a.xcc = (unsigned)medium_xcc;
+        a.nblk = (unsigned)((N2 / cols_per_tile<T>()) * batch);
+        a.gamma = gamma; a.inv_n = inv_n(); a.nsteps = (int)nsteps; a.rows = batch; a.Qf = N2 / Ef;
+        ++last_launches;
+        HIP_TRY(launch_medium(N1, N2, phase, (int)a.nblk, medium_xccs, stream, a));
+        HIP_TRY(hipMemcpyAsync(medium_err_host, a.error, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        medium_sched.assign(h, h + nsteps);
+        medium_gamma = gamma_d;
+        medium_pending = true;
+        return SSFM_OK;
+        }
+    }
 
     int set_operator(const void* host) {
         if (int rc = use_device()) return rc;
@@ -854,7 +945,12 @@ template <typename T> struct PlanT : PlanBase {
         const bool go_small = small_sched && snapshots == nullptr;
         // a fibre's operator has one modulus for all frequencies: 4-byte phase tables (ssfm_kernels.hpp FM_PHASE)
         const bool use_phase = use_tables && phase_tables && sizeof(T) == 4 && u16 && op_flat_re;
-        if (use_tables && !go_small)
+        // plans of 2^14 ... 2^17 samples in the unit layout: the whole schedule in one launch (ssfm_kernels.hpp k_medium)
+        const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+        const bool go_medium = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !go_small && !profiling
+                               && snapshots == nullptr && graph_policy == 0 && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
+                               && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || n * batch <= (1ll << 16)) && (use_phase || !phase_tables || !op_flat_re);
+        if (use_tables && !go_small && !go_medium)
             if (int rc = tables_for(distinct, tabptr.data(), false, use_phase ? 1 : 0)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
             const int lane_ = rows > 0 ? row0 / rows : 0;
@@ -969,6 +1065,8 @@ template <typename T> struct PlanT : PlanBase {
 #endif
             if (go_small) {
                 if (int rc = run_small(gamma, h, nsteps, distinct)) return rc;
+            } else if (go_medium) {
+                if (int rc = run_medium(gamma, gamma_d, h, nsteps, distinct, use_phase)) return rc;
             } else if (int rc = run_steps_maybe_graph(enqueue_steps, gamma, h, nsteps, tabptr)) return rc;
 #if SSFM_TRACE
             if (int rc = trace_dump()) return rc;

@@ -543,8 +543,41 @@ __host__ __device__ constexpr int min_waves(int threads, int tsize, int e = 16) 
 #else
 #define SSFM_KERNEL_BOUNDS(threads, tsize, e) __launch_bounds__(threads, min_waves(threads, tsize, e))
 #endif
-template <typename T, int N1, int C, int E, int MODE, bool U16 = false>
-__global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeArgs<T> a) {
+// 16 bytes at byte offset `off` of the buffer behind `rsrc`, sc1: agent-scope coherent (served past this CU's L1) and tracked by the
+// compiler's wait counters -- how a workgroup reads what ANOTHER workgroup of the same launch has stored (k_medium)
+// SSFM_MEDIUM_LOCAL (default): k_medium's workgroups all sit on ONE XCD and meet in that XCD's L2 -- plain stores (the CU's L1 writes
+// through), loads with sc0 nt (they miss the L1 and are answered by the L2), barrier counters as L2 atomics: a store + barrier + load
+// round costs 1.1-1.3 us for 16-32 workgroups against 2.1-2.8 us across the XCDs, which meet in memory (tools/xcd_barrier_probe.hip,
+// profiles/r03_xcd_barrier.txt; sc0 alone or an L1 invalidate + plain load return STALE data).  0: sc1 stores / sc1 loads / agent-scope atomics.
+#ifndef SSFM_MEDIUM_LOCAL
+#define SSFM_MEDIUM_LOCAL 1
+#endif
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t load16_sc1(__amdgpu_buffer_rsrc_t rsrc, int off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SSFM_MEDIUM_LOCAL ? 3 /* sc0 nt */ : 16 /* sc1 */);
+}
+// a field store of a pass: write-through to memory, except inside k_medium on one XCD (see above)
+template <bool PK, typename P, typename V> __device__ __forceinline__ void pass_store(P* p, V v) {
+    if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) *p = v;
+    else stream_store(p, v);
+}
+// an atomic add executed in this XCD's L2, returning the old value
+__device__ __forceinline__ unsigned long long l2_add_u64(unsigned long long* p, unsigned long long v) {
+    unsigned long long old;
+    asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
+    return old;
+}
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
+}
+
+// The body of k_time for workgroup `bid` of `nblk`.  PK: called from the persistent kernel of the medium plans (k_medium), where
+// the field between the passes was stored by other workgroups of the SAME launch: it is read with sc1 loads (the stores are
+// write-through already), MI355X_MICROARCH.md "Valid forms".
+template <typename T, int N1, int C, int E, int MODE, bool U16, bool PK = false>
+__device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned bid, const unsigned nblk) {
     constexpr int Q = N1 / E;                      // threads per column
     static_assert(!U16 || (sizeof(T) == 4 && C == 16 && Q % 4 == 0 && E % 2 == 0), "U16 layout: complex64, 16 columns, whole waves of 4 j");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -561,7 +594,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     const int ltid = U16 ? j * C + c : tid;       // thread index the tables are laid out by
     const long long N = (long long)N1 * a.N2;
     int tile, brow;
-    xcd_unit_row(blockIdx.x, a.N2 / C, a.rows, tile, brow);
+    xcd_unit_row(bid, a.N2 / C, a.rows, tile, brow);
     if (U16) tile = u16_tile_of_unit(tile, a.N2 / C);
     // natural (time-order) column of this thread: the tile's columns are contiguous in the row ORDER of the layout
     const int ncol = U16 ? (int)u16_col_of_pos((long long)tile * C + 2 * (c & 7) + (c >> 3), a.Qf) : tile * C + c;
@@ -587,11 +620,21 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
     T pold[E];
     LineTw<T, N1, E> tw;
     if (U16 && MODE != TM_BEGIN) {               // half-transformed field, or the tile-private time-domain field: 16-byte units
+        if constexpr (PK && sizeof(T) == 4) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Yb, 0, (int)(N * (long long)sizeof(cx<T>)), 0x00020000);
+#pragma unroll
+            for (int g = 0; g < E / 2; ++g) {
+                const u32x4_t q = load16_sc1(rs, (offy + 2 * g * stride) * (int)sizeof(cx<T>));
+                v[2 * g] = mk<T>(__uint_as_float(q.x), __uint_as_float(q.y));
+                v[2 * g + 1] = mk<T>(__uint_as_float(q.z), __uint_as_float(q.w));
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < E / 2; ++g) {
             const u4_t q = stream_load<true>(reinterpret_cast<const u4_t*>(&Yb[offy + 2 * g * stride]));
             v[2 * g] = mk<T>(q.x, q.y);
             v[2 * g + 1] = mk<T>(q.z, q.w);
+        }
         }
     } else {
         const cx<T>* __restrict__ src = MODE == TM_BEGIN ? Fb : Yb;
@@ -650,7 +693,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         if (a.st->error != 0u) return;
         if (S_this.done) {
             // a launch queued beyond the end of the run: hand the final state on (the host reads cur[] of the LAST launched step)
-            if (blockIdx.x == 0 && tid == 0) a.st->cur[(a.step + 1) & 1] = S_this;
+            if (bid == 0 && tid == 0) a.st->cur[(a.step + 1) & 1] = S_this;
             return;
         }
         hh_prev = S_this.h * (T)0.5;
@@ -662,7 +705,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             __shared__ __attribute__((aligned(16))) int s_lane_ok_[4];     // (16 bytes: statics precede the dynamic LDS region, whose base must stay 16-byte aligned)
             int& s_lane_ok = s_lane_ok_[0];
             if (tid < 64) {
-                const unsigned long long want = (unsigned long long)a.step * (gridDim.x / kAdaptSlots);
+                const unsigned long long want = (unsigned long long)a.step * (nblk / kAdaptSlots);
                 const unsigned long long* cnt = a.st->arrived[a.lane ^ 1];
                 const long long t0 = wall_clock64();
                 int good = 0;
@@ -679,14 +722,14 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         }
         if (a.st->error != 0u) return;                        // (see TM_MID_A above; set by a two-lane run's wait as well)
         const StepState<T> S = step_state<T>(a.st, a.step, FWD && a.derive != 0);
-        if (FWD && blockIdx.x == 0 && tid == 0) {
+        if (FWD && bid == 0 && tid == 0) {
             // workgroup 0 records the state of this step (BEGIN is the first kernel of a step) and empties the slots its END fills
             if (a.derive) {
                 a.st->cur[a.step & 1] = S;
                 if (!a.st->cur[(a.step - 1) & 1].done) a.zlog[S.steps] = S.z;
             }
         }
-        if (FWD && blockIdx.x == 0 && tid < kAdaptSlots) a.st->slots[a.lane][a.step & 1][tid] = 0ull;
+        if (FWD && bid == 0 && tid < kAdaptSlots) a.st->slots[a.lane][a.step & 1][tid] = 0ull;
         if (S.done) return;
         hh_prev = hh_next = S.h * (T)0.5;
     }
@@ -761,7 +804,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
                 T m = wave_max_a[0];
 #pragma unroll
                 for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
-                atomicMax(&a.st->slots[0][set][blockIdx.x % kAdaptSlots], float_bits<T>(m));
+                atomicMax(&a.st->slots[0][set][bid % kAdaptSlots], float_bits<T>(m));
 #if SSFM_RELAXED_BARRIER
                 // Only atomics cross this barrier (the slots, read back with agent-scope loads below), so no fence is needed -- an agent-scope
                 // release / acquire writes back / invalidates the XCD's whole L2 on gfx950 -- just the order: the maximum is acknowledged
@@ -773,7 +816,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
 #endif
                 const long long t0 = wall_clock64();                  // 100 MHz
                 for (;;) {
-                    if (__hip_atomic_load(&a.st->arrive[set], SSFM_RELAXED_BARRIER ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { good = 1; break; }
+                    if (__hip_atomic_load(&a.st->arrive[set], SSFM_RELAXED_BARRIER ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= nblk) { good = 1; break; }
                     if (wall_clock64() - t0 > a.st->patience) break;  // (20 ms) the grid is not running as a whole -- give up, never hang
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -797,7 +840,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
         __syncthreads();
         if (!s_ok) return;
         const StepState<T> Sn = s_next;
-        if (blockIdx.x == 0) {
+        if (bid == 0) {
             // workgroup 0 records the state of the next step and empties what the next step's launch will fill
             if (tid == 0) { a.st->cur[(a.step + 1) & 1] = Sn; a.zlog[Sn.steps] = Sn.z; a.st->arrive[(a.step + 1) & 1] = 0u; }
             if (tid < kAdaptSlots) a.st->slots[0][(a.step + 1) & 1][tid] = 0ull;
@@ -862,7 +905,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
                 lane32_swap(v[2 * g], v[2 * g + 1]);
                 u4_t q;
                 q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
-                stream_store(reinterpret_cast<u4_t*>(&Yb[offy + 2 * g * stride]), q);
+                pass_store<PK>(reinterpret_cast<u4_t*>(&Yb[offy + 2 * g * stride]), q);
             }
         }
         if (a.st != nullptr) {
@@ -880,14 +923,14 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
                 T m = wave_max[0];
 #pragma unroll
                 for (int w = 1; w < NWAVES; ++w) m = wave_max[w] > m ? wave_max[w] : m;
-                atomicMax(&a.st->slots[a.lane][a.step & 1][blockIdx.x % kAdaptSlots], float_bits<T>(m));
+                atomicMax(&a.st->slots[a.lane][a.step & 1][bid % kAdaptSlots], float_bits<T>(m));
                 if (a.lanes2) {
 #if SSFM_RELAXED_BARRIER && SSFM_STORE_MODE == 1 && SSFM_P_WT == 1
                     // (the field and |A|^2 stores of this workgroup are write-through and were waited for at the barrier above; see TM_MID_A)
                     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][blockIdx.x % kAdaptSlots], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][bid % kAdaptSlots], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][blockIdx.x % kAdaptSlots], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][bid % kAdaptSlots], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #endif
                 }
             }
@@ -907,16 +950,21 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeAr
             lane32_swap(v[2 * g], v[2 * g + 1]);           // (the exchange is its own inverse)
             u4_t q;
             q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
-            stream_store(reinterpret_cast<u4_t*>(&Yb[offy + 2 * g * stride]), q);
+            pass_store<PK>(reinterpret_cast<u4_t*>(&Yb[offy + 2 * g * stride]), q);
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < E; ++t) stream_store(&Yb[off + t * stride], cmul(v[t], w[t]));
+        for (int t = 0; t < E; ++t) pass_store<PK>(&Yb[off + t * stride], cmul(v[t], w[t]));
     }
 #if SSFM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     SSFM_TRACE_END(a);
+}
+
+template <typename T, int N1, int C, int E, int MODE, bool U16 = false>
+__global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeArgs<T> a) {
+    time_body<T, N1, C, E, MODE, U16, false>(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------ k_freq
@@ -995,8 +1043,9 @@ template <int E> __device__ __forceinline__ void fly_factors(cf64 (&m)[E], const
     }
 }
 
-template <typename T, int N2, int ROWS, int E, int MODE, bool U16 = false>
-__global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const FreqArgs<T> a) {
+// The body of k_freq for workgroup `bid` (PK: see time_body)
+template <typename T, int N2, int ROWS, int E, int MODE, bool U16, bool PK = false>
+__device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned bid) {
     constexpr int Q = N2 / E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -1008,7 +1057,7 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     const int rr = tid / Q;
     // block -> (group of ROWS consecutive k1, batch row); batch rows of one k1 group share an XCD
     int kgrp, brow;
-    xcd_unit_row(blockIdx.x, a.N1 / ROWS, a.rows, kgrp, brow);
+    xcd_unit_row(bid, a.N1 / ROWS, a.rows, kgrp, brow);
     const int k1 = kgrp * ROWS + rr;
     const long long row = (long long)brow * a.N1 + k1;
     cx<T>* __restrict__ Frow = a.F + row * N2;
@@ -1023,11 +1072,21 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     typedef T u4_t __attribute__((ext_vector_type(4)));
     if (U16) {
         // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
+        if constexpr (PK && sizeof(T) == 4) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Frow, 0, N2 * (int)sizeof(cx<T>), 0x00020000);
+#pragma unroll
+            for (int g = 0; g < E / 2; ++g) {
+                const u32x4_t q = load16_sc1(rs, (g * Q + j) * 16);
+                v[2 * g] = mk<T>(__uint_as_float(q.x), __uint_as_float(q.y));
+                v[2 * g + 1] = mk<T>(__uint_as_float(q.z), __uint_as_float(q.w));
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < E / 2; ++g) {
             const u4_t q = stream_load<true>(reinterpret_cast<const u4_t*>(Frow) + g * Q + j);
             v[2 * g] = mk<T>(q.x, q.y);
             v[2 * g + 1] = mk<T>(q.z, q.w);
+        }
         }
     } else {
 #pragma unroll
@@ -1080,7 +1139,7 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
-        for (int t = 0; t < E; ++t) stream_store(&Frow[j + t * Q], v[t]);
+        for (int t = 0; t < E; ++t) pass_store<PK>(&Frow[j + t * Q], v[t]);
         return;
     }
     SSFM_STAMP(3);
@@ -1112,11 +1171,11 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
         for (int g = 0; g < E / 2; ++g) {
             u4_t q;
             q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
-            stream_store(reinterpret_cast<u4_t*>(Frow) + g * Q + j, q);
+            pass_store<PK>(reinterpret_cast<u4_t*>(Frow) + g * Q + j, q);
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < E; ++t) stream_store(&Frow[j + t * Q], v[t]);
+        for (int t = 0; t < E; ++t) pass_store<PK>(&Frow[j + t * Q], v[t]);
     }
 #if SSFM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1128,6 +1187,126 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
     SSFM_TRACE_END(a);
 }
 
+template <typename T, int N2, int ROWS, int E, int MODE, bool U16 = false>
+__global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const FreqArgs<T> a) {
+    freq_body<T, N2, ROWS, E, MODE, U16, false>(a, blockIdx.x);
+}
+
+constexpr int kSmallTabs = 4;          // operator tables per schedule of the single-launch engines (k_medium, k_small)
+// ------------------------------------------------------------------------------ k_medium
+// Plans of 2^14 ... 2^17 samples (the reference's example and test sizes): a field is a few dozen column tiles / row groups, a
+// step of the two-kernel engine is two launches of 2.6 us each whatever the size (dependent-launch boundary), i.e. 7-10 us.
+// Here ONE launch runs the whole fixed-step schedule: workgroup b owns column tile b in the time passes and row group b in the
+// frequency passes (both counts are equal by construction: ROWS = N1 * 16 / N2 rows per group), and between two passes all
+// workgroups meet at a barrier in device memory -- at most 64 of them, 0.5-1.4 us (profiles/r02_barrier_probe.txt), less than the
+// launch it replaces.  The passes are the bodies of k_time / k_freq; what changes is how the field travels between them:
+// written with write-through (sc1) stores as ever, read with sc1 loads (PK = true), because reader and writer now belong to
+// the same launch (MI355X_MICROARCH.md "Valid forms": sc1 stores, every storing wave drained, one arrival per workgroup, a
+// relaxed poll, then sc1 loads only).  |A|^2 stays private to a workgroup (its tile) and keeps its loads: the same CU wrote it.
+// A workgroup never waits longer than `patience` (the grid is far below the chip's capacity, but the chip may be shared):
+// then the error word is set and the host repeats the run with the two-kernel engine.
+template <typename T> struct MediumArgs {
+    cx<T>* F;                          // time-order field, in and out
+    cx<T>* Y;                          // the field between the passes
+    T* P;
+    const cx<T>* twA;
+    const cx<T>* twB;
+    const cx<T>* tw1;
+    const cx<T>* tw2;
+    const cx<T>* tab[kSmallTabs];      // per distinct step size: exp(D~ h)/N (FM_TABLE) or its phases (FM_PHASE), k_freq's order
+    T amp[kSmallTabs];                 // FM_PHASE: the modulus
+    const T* hs;                       // the schedule: nsteps step sizes [km]
+    const unsigned char* which;        // per step: its table
+    unsigned long long* bar;           // 8 arrival counters, the error word, the ticket counter: zeroed before the launch
+    unsigned xcc;                      // the XCD the launch's workgroups meet on (plans take turns, so that concurrent plans do not share one)
+    unsigned nblk;                     // workgroups that do the work (the launch has that many per XCD)
+    unsigned* error;
+    long long patience;                // ticks of the 100 MHz clock
+    T gamma;
+    T inv_n;
+    int nsteps;
+    int rows;                          // batch rows
+    int Qf;
+};
+constexpr int kBarShards = 8;
+// every workgroup of the launch has passed here `epoch` times once each counter shows epoch * nblk / 8 arrivals
+__device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned* error, long long patience, unsigned long long& epoch,
+                                               const unsigned bid, const unsigned nblk, const int tid) {
+    __shared__ __attribute__((aligned(16))) int s_bar_ok[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every wave: its write-through stores have landed
+    __syncthreads();
+    ++epoch;
+    if (tid < 64) {
+#if SSFM_MEDIUM_LOCAL
+        if (tid == 0) l2_add_u64(&bar[bid & (kBarShards - 1)], 1ull);
+#else
+        if (tid == 0) __hip_atomic_fetch_add(&bar[bid & (kBarShards - 1)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        const unsigned long long want = epoch * (nblk / kBarShards);
+        const long long t0 = wall_clock64();
+        int good = 0;
+        for (;;) {
+#if SSFM_MEDIUM_LOCAL
+            unsigned long long got = want;
+            if (tid < kBarShards) got = l2_add_u64(&bar[tid], 0ull);
+#else
+            const unsigned long long got = tid < kBarShards ? __hip_atomic_load(&bar[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+#endif
+            if (__all(got >= want)) { good = 1; break; }
+            if (wall_clock64() - t0 > patience) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (tid == 0) { s_bar_ok[0] = good; if (!good) atomicExch(error, 1u); }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // (no instruction: the loads of the next pass stay below)
+    return s_bar_ok[0] != 0;
+}
+template <typename T, int N1, int N2, int E, int FMODE>
+__global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
+    constexpr int C = 16, ROWS = N1 * C / N2;
+    static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
+    const int tid = threadIdx.x;
+#if SSFM_MEDIUM_LOCAL
+    // launched with 8 x nblk workgroups, dealt round robin to the XCDs: the ones on XCD a.xcc take the tiles in the order they arrive
+    // (the others leave); should fewer than nblk arrive there, the first barrier runs out of patience and the host repeats the run
+    // on the two-kernel engine
+    if (xcc_id() != a.xcc) return;
+    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
+    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + 1, 1ull);
+    __syncthreads();
+    const unsigned bid = s_bid[0], nblk = a.nblk;
+    if (bid >= nblk) return;
+#else
+    const unsigned bid = blockIdx.x, nblk = gridDim.x;
+#endif
+    unsigned long long epoch = 0;
+    TimeArgs<T> ta;
+    ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = nullptr;
+    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
+    FreqArgs<T> fa;
+    fa.F = a.Y; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = a.inv_n; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0;
+    const T half = (T)0.5;
+    ta.hh_prev = (T)0; ta.hh_next = a.hs[0] * half;
+    time_body<T, N1, C, E, TM_BEGIN, true, true>(ta, bid, nblk);
+    if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+    for (int s = 0; s < a.nsteps; ++s) {
+        const int w = a.which[s];
+        fa.tab = a.tab[w]; fa.amp = a.amp[w]; fa.h = a.hs[s];
+        freq_body<T, N2, ROWS, E, FMODE, true, true>(fa, bid);
+        if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+        ta.hh_prev = a.hs[s] * half;
+        if (s + 1 < a.nsteps) {
+            ta.hh_next = a.hs[s + 1] * half;
+            time_body<T, N1, C, E, TM_MID, true, true>(ta, bid, nblk);
+            if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+        } else {
+            ta.hh_next = (T)0;
+            time_body<T, N1, C, E, TM_END, true, true>(ta, bid, nblk);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ k_small
 // A field of up to 8192 samples is ONE line of the row transform: a workgroup keeps a whole row in its registers and runs
 // the complete fixed-step schedule in a single launch -- rotation, N-point FFT, exp(D~ h)/N, inverse FFT, rotation, for every
@@ -1135,7 +1314,6 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const Fre
 // (dependent-launch boundary; profiles/r02_small_graph.txt: eager and hipGraph alike), i.e. 5.2-6 us per step.
 // The arithmetic per step is k_time's and k_freq<FM_TABLE>'s: the second half rotation of a step and the first of the next
 // are one rotation by the sum of the two phases, |A|^2 of the step's start stays in registers (`pold`).
-constexpr int kSmallTabs = 4;
 template <typename T> struct SmallArgs {
     cx<T>* F;                          // batch rows of N samples, time order, advanced in place
     const cx<T>* tab[kSmallTabs];      // exp(D~ h)/N per distinct step size, at freq_tab_pos(k, N / E)

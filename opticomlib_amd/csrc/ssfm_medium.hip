@@ -1,0 +1,64 @@
+// ssfm_medium.hip -- the single-launch fixed-step engine of plans of 2^14 ... 2^17 samples (ssfm_kernels.hpp k_medium), in a
+// translation unit of its own (its four shapes x two operator-table kinds are a minute of compile time).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+
+#include "ssfm_kernels.hpp"
+#include "ssfm_medium.hpp"
+
+namespace ssfm {
+namespace {
+template <int N1, int N2, int FMODE>
+hipError_t launch_shape(int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {
+    using T = float;
+    constexpr int E = 8, C = 16, ROWS = N1 * C / N2;
+    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+                           + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
+    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+                           + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
+    constexpr size_t lds = lds_t > lds_f ? lds_t : lds_f;
+    static hipError_t attr = lds <= 48 * 1024 ? hipSuccess
+        : hipFuncSetAttribute(reinterpret_cast<const void*>(k_medium<T, N1, N2, E, FMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_medium<T, N1, N2, E, FMODE>), dim3(SSFM_MEDIUM_LOCAL ? xccs * nblk : nblk), dim3(N1 * C / E), lds, s, a);
+    return hipGetLastError();
+}
+template <int FMODE> hipError_t launch_mode(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {
+    if (N1 == 128 && N2 == 128) return launch_shape<128, 128, FMODE>(nblk, xccs, s, a);
+    if (N1 == 128 && N2 == 256) return launch_shape<128, 256, FMODE>(nblk, xccs, s, a);
+    if (N1 == 256 && N2 == 256) return launch_shape<256, 256, FMODE>(nblk, xccs, s, a);
+    if (N1 == 256 && N2 == 512) return launch_shape<256, 512, FMODE>(nblk, xccs, s, a);
+    return hipErrorInvalidValue;
+}
+}  // namespace
+
+bool medium_shape(int N1, int N2) { return (N1 == 128 && (N2 == 128 || N2 == 256)) || (N1 == 256 && (N2 == 256 || N2 == 512)); }
+
+hipError_t launch_medium(int N1, int N2, bool phase_tables, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {
+    return phase_tables ? launch_mode<FM_PHASE>(N1, N2, nblk, xccs, s, a) : launch_mode<FM_TABLE>(N1, N2, nblk, xccs, s, a);
+}
+
+namespace {
+__global__ void k_xcc_probe(unsigned* mask) {
+    if (threadIdx.x == 0) atomicOr(mask, 1u << xcc_id());
+}
+}  // namespace
+unsigned xcc_mask(int device) {
+    static std::mutex mu;
+    static unsigned cache[64] = {0};
+    if (device < 0 || device >= 64) return 0u;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache[device]) return cache[device];
+    int cur = 0;
+    unsigned* d = nullptr;
+    unsigned h = 0u;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device || hipMalloc(&d, sizeof(unsigned)) != hipSuccess) return 0u;
+    if (hipMemset(d, 0, sizeof(unsigned)) == hipSuccess) {
+        hipLaunchKernelGGL(k_xcc_probe, dim3(256), dim3(64), 0, 0, d);
+        if (hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) h = 0u;
+    }
+    (void)hipFree(d);
+    return cache[device] = h;
+}
+}  // namespace ssfm

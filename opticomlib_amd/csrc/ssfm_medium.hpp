@@ -1,0 +1,13 @@
+// ssfm_medium.hpp -- launcher of the single-launch engine of medium plans (ssfm_medium.hip)
+#pragma once
+#include "ssfm_kernels.hpp"
+
+namespace ssfm {
+bool medium_shape(int N1, int N2);
+// complex64 plans in the 16-byte-unit layout, 8 points per thread, nblk = (N2 / 16) * rows workgroups (a multiple of 8, at most 64)
+// (launched with `xccs` x nblk workgroups when the engine keeps to one XCD, see SSFM_MEDIUM_LOCAL)
+hipError_t launch_medium(int N1, int N2, bool phase_tables, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a);
+// The XCC ids (HW_REG_XCC_ID) the workgroups of a launch on `device` are dealt to, as a bit mask: 0xff on an MI355X in SPX mode, 1 when
+// every XCD is a device of its own.  Found once per device by a probe launch (synchronous); 0 on error.
+unsigned xcc_mask(int device);
+}  // namespace ssfm

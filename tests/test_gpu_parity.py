@@ -617,6 +617,74 @@ def test_single_launch_capture_against_the_two_kernel_engine(prec, monkeypatch):
     assert relmax(f1, f0) < tol
 
 
+@pytest.mark.parametrize("log2n, rows", [(14, 1), (14, 2), (15, 1), (15, 2), (16, 1), (16, 2), (17, 1), (17, 2), (16, 4)])
+def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, monkeypatch):
+    """complex64 plans of up to 2^16 samples in all (2^14 x 1..4, 2^15 x 1..2, 2^16 x 1) run a fixed-step schedule in ONE launch
+    (ssfm_kernels.hpp k_medium: the passes of the two-kernel engine separated by barriers, all workgroups on one XCD and meeting in its L2);
+    SSFM_MEDIUM=0 at plan creation, or a larger plan, keeps the two-kernel engine.  The same passes on the same data: bit-identical
+    fields, repeatedly (a stale read of another workgroup's data would show here); and against the oracle."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    rng = np.random.default_rng(100 + log2n)
+    a = ((rng.standard_normal((rows, n)) + 1j * rng.standard_normal((rows, n))) * 0.05).astype(np.complex64)
+    hs = np.array([0.5] * 30 + [0.25, 0.5, 0.125, 0.5, 0.5, 0.03125], dtype=np.float32)      # 4 distinct sizes
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
+    monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)
+    monkeypatch.delenv("SSFM_E", raising=False)
+    monkeypatch.setenv("SSFM_GRAPH", "0")
+    got = {}
+    for med in ("1", "0"):
+        monkeypatch.setenv("SSFM_MEDIUM", med)
+        p = _lib.Plan(n, rows, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            outs = []
+            for rep in range(3):
+                p.set_field(a)
+                p.propagate_fixed(1.3, hs if rep != 1 else hs[:7])
+                outs.append((p.get_field(), p.last_propagate_ms()[1]))
+            got[med] = outs
+        finally:
+            p.close()
+    for (f1, l1), (f0, l0) in zip(got["1"], got["0"]):
+        assert l0 > 10 and (l1 == 1 if n * rows <= (1 << 16) else l1 == l0)
+        np.testing.assert_array_equal(f1, f0)
+    np.testing.assert_array_equal(got["1"][0][0], got["1"][2][0])
+    if log2n <= 15:
+        A = a.copy()
+        for h_ in hs:
+            A = orc.ssfm_step_c64(A, orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13), np.float32(1.3), h_)
+        assert relmax(got["1"][0][0], A) < TOL_100
+
+
+def test_medium_single_launch_engine_without_patience_falls_back(monkeypatch):
+    """A workgroup of k_medium never waits longer than its patience at a barrier; with none at all some give up: the plan restores the
+    input, repeats the run on the two-kernel engine -- bit for bit its result -- and keeps to it."""
+    n = 1 << 15
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=3, power_w=5e-3).astype(np.complex64)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    hs = np.full(25, 0.2, np.float32)
+    monkeypatch.setenv("SSFM_MEDIUM", "0")
+    q = _lib.Plan(n, 2, _lib.C64)
+    try:
+        q.set_linear_operator(D); q.set_field(a); q.propagate_fixed(1.3, hs)
+        f0 = q.get_field()
+    finally:
+        q.close()
+    monkeypatch.setenv("SSFM_MEDIUM", "1")
+    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
+    p = _lib.Plan(n, 2, _lib.C64)
+    try:
+        p.set_linear_operator(D)
+        for rep in range(3):
+            p.set_field(a); p.propagate_fixed(1.3, hs)
+            np.testing.assert_array_equal(p.get_field(), f0)
+    finally:
+        p.close()
+
+
 @pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
 @pytest.mark.parametrize("log2n, rows", [(14, 1), (14, 2), (15, 2), (16, 2), (17, 1)])
 def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, rows, prec, monkeypatch):

@@ -6,7 +6,7 @@
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/build/var
-SRC="ssfm_host.hip sos_filter.hip frontend.hip device_mem.hip chirpz.hip transmitter.hip prbs.hip"
+SRC="ssfm_host.hip ssfm_medium.hip sos_filter.hip frontend.hip device_mem.hip chirpz.hip transmitter.hip prbs.hip"
 mode=$1; shift
 if [ "$mode" = build ]; then
   # one translation unit sees the flags (VSRC, default ssfm_host.hip): it is compiled per variant and linked with the product's other objects (build/obj)
