@@ -2251,6 +2251,8 @@ def test_host_threads_on_the_same_plans():
     (tools/thread_check.py; ctypes releases the GIL during the calls)."""
     import subprocess
     import sys
+    if os.environ.get("SSFM_GRAPH", "0") not in ("", "0"):
+        pytest.skip("hipGraph capture (opt-in) is not safe beside host threads that use the legacy stream: INTEGRATION.md, DESIGN.md section 4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_check.py")], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr[-2000:]
