@@ -658,6 +658,50 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
         assert relmax(got["1"][0][0], A) < TOL_100
 
 
+def test_medium_single_launch_engine_on_several_plans_at_once(monkeypatch):
+    """Plans take turns on the XCDs, so that single-launch runs of different plans -- here four host threads, each with its own plan,
+    twenty runs each, all in flight together -- do not wait for each other's workgroups; every result equals the two-kernel engine's."""
+    import threading
+    n = 1 << 14
+    gv(**workloads.BENCH_GV)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    hs = np.full(40, 0.25, np.float32)
+    fields = [workloads.qpsk_field(n, seed=40 + k, power_w=5e-3).astype(np.complex64) for k in range(4)]
+    monkeypatch.setenv("SSFM_GRAPH", "0")
+    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
+    monkeypatch.setenv("SSFM_MEDIUM", "0")
+    want = []
+    for a in fields:
+        q = _lib.Plan(n, 2, _lib.C64)
+        try:
+            q.set_linear_operator(D); q.set_field(a); q.propagate_fixed(1.3, hs)
+            want.append(q.get_field())
+        finally:
+            q.close()
+    monkeypatch.setenv("SSFM_MEDIUM", "1")
+    plans = [_lib.Plan(n, 2, _lib.C64) for _ in fields]
+    errors = []
+    def work(k):
+        try:
+            plans[k].set_linear_operator(D)
+            for rep in range(20):
+                plans[k].set_field(fields[k]); plans[k].propagate_fixed(1.3, hs)
+                got = plans[k].get_field()
+                if not np.array_equal(got, want[k]):
+                    errors.append((k, rep, "mismatch"))
+            if os.environ.get("SSFM_MEDIUM_EXPECT", "1") == "1" and plans[k].last_propagate_ms()[1] != 1:
+                errors.append((k, "launches", plans[k].last_propagate_ms()[1]))
+        except Exception as e:                                            # noqa: BLE001
+            errors.append((k, repr(e)))
+    try:
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+    finally:
+        for p in plans: p.close()
+    assert not errors, errors
+
+
 def test_medium_single_launch_engine_without_patience_falls_back(monkeypatch):
     """A workgroup of k_medium never waits longer than its patience at a barrier; with none at all some give up: the plan restores the
     input, repeats the run on the two-kernel engine -- bit for bit its result -- and keeps to it."""
