@@ -1202,7 +1202,17 @@ template <typename T> struct PlanT : PlanBase {
         ar.single_step = single_step;
         // a column kernel of at most 64 workgroups (measured: a gain up to there, profiles/r02_medium_adaptive.txt) waits for the global maximum inside the launch (TM_MID_A); the input is kept
         // for the case that the GPU does not run the grid as a whole (then: the three-launch engine, for good)
-        ar.fused = fused_ok && !capture && (N1 == 128 || N1 == 256) && (long long)(N2 / cols_per_tile<T>()) * batch <= 64;
+        // Larger complex64 grids (up to 512 workgroups = two per CU: 2^20 x 2) take the same kernel with a hand-over that has no counter to
+        // serialise on (AdaptState::wgmax): the column pass is then ONE launch per step instead of two -- 64 MiB of field traffic per step
+        // instead of 96.  SSFM_ADAPT_FUSED_MAX caps the workgroups (64: round 2's rule).
+        const long long col_blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+        long long fused_max = sizeof(T) == 4 ? kAdaptWords : kAdaptSlots;
+        if (const char* e = std::getenv("SSFM_ADAPT_FUSED_MAX")) fused_max = std::atoll(e) < fused_max ? std::atoll(e) : fused_max;
+        int cus = 0;
+        if (col_blocks > kAdaptSlots && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || col_blocks > 2ll * cus || col_blocks % 64 != 0))
+            fused_max = kAdaptSlots;                              // (the whole grid must be resident at once: two workgroups per CU)
+        if (lanes2_ok) fused_max = fused_max < kAdaptSlots ? fused_max : kAdaptSlots;      // (the opt-in two-lane form keeps its sizes)
+        ar.fused = fused_ok && !capture && (N1 == 128 || N1 == 256) && col_blocks <= (fused_max > kAdaptSlots ? fused_max : kAdaptSlots);
         if (ar.fused) {
             const size_t fb = sizeof(cx<T>) * n * batch;
             if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));

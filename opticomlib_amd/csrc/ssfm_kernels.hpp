@@ -113,6 +113,7 @@ template <typename T> struct StepState {
 };
 constexpr int kAdaptSlots = 64;
 constexpr int kAdaptLanes = 2;
+constexpr int kAdaptWords = 512;       // workgroups of the largest fused adaptive column kernel (2^20 x 2: 256 tiles x 2 rows)
 template <typename T> struct AdaptState {
     T length;
     T phi_max;
@@ -127,6 +128,10 @@ template <typename T> struct AdaptState {
     // cleared counter could be read before its clearing: the lanes are not in step).  BEGIN(s) of one lane waits until the
     // OTHER lane's counters show s complete ENDs; its own lane's END(s - 1) is an earlier kernel of its stream.
     unsigned long long arrived[kAdaptLanes][kAdaptSlots];
+    // TM_MID_A with more than kAdaptSlots workgroups (complex64): one word per workgroup and step parity, (step + 1) << 32 | bits of its
+    // maximum -- flag and value in ONE 8-byte store, no atomics, no counter that 512 workgroups would serialise on (a counter barrier
+    // over 512 workgroups costs 7-9 us, profiles/r02_barrier_probe.txt; this hand-over about 2).  Zeroed by the host before a run.
+    unsigned long long wgmax[2][kAdaptWords];
     unsigned arrive[2];     // TM_MID_A: workgroups that have delivered their maximum for the step of this parity
     unsigned error;         // TM_MID_A: a workgroup gave up waiting (the GPU did not run the whole grid at once): the host falls back
     long long patience;     // TM_MID_A: ticks of the 100 MHz clock a workgroup waits for the others (20 ms; tests set 0)
@@ -797,6 +802,57 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         constexpr int NWAVES_A = (N1 * C / E + 63) / 64;
         if ((tid & 63) == 0) wave_max_a[tid >> 6] = pmax;
         __syncthreads();
+        if (sizeof(T) == 4 && nblk > (unsigned)kAdaptSlots) {
+            // ---- large grids: every workgroup publishes ONE word, a wavefront of every workgroup reads them all
+            if (tid < 64) {
+                const int set = a.step & 1;
+                const unsigned long long epoch = (unsigned long long)(unsigned)(a.step + 1) << 32;
+                if (tid == 0) {
+                    T m = wave_max_a[0];
+#pragma unroll
+                    for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
+                    __hip_atomic_store(&a.st->wgmax[set][bid], epoch | (float_bits<T>(m) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const unsigned long long* words = a.st->wgmax[set];
+                const long long t0 = wall_clock64();
+                int good = 0;
+                unsigned long long mb = 0ull;
+                // a lane asks again only for the words it has not seen complete (512 workgroups x 512 words per round would be 2 MiB of
+                // 8-byte uncached reads per round: the first form of this loop made the hand-over 6 us long)
+                unsigned pending = 0u;
+#pragma unroll
+                for (int i = 0; i < kAdaptWords / 64; ++i)
+                    if ((unsigned)tid + 64u * (unsigned)i < nblk) pending |= 1u << i;
+                for (;;) {
+#pragma unroll
+                    for (int i = 0; i < kAdaptWords / 64; ++i) {
+                        if (pending & (1u << i)) {
+                            const unsigned long long wd = __hip_atomic_load(&words[(unsigned)tid + 64u * (unsigned)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((wd >> 32) == (epoch >> 32)) {
+                                pending &= ~(1u << i);
+                                const unsigned long long vb = wd & 0xffffffffull;
+                                mb = vb > mb ? vb : mb;
+                            }
+                        }
+                    }
+                    if (__all(pending == 0u)) { good = 1; break; }
+                    if (wall_clock64() - t0 > a.st->patience) break;              // the grid is not running as a whole -- give up, never hang
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                if (good) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned long long other = __shfl_xor(mb, o);
+                        mb = other > mb ? other : mb;
+                    }
+                }
+                if (tid == 0) {
+                    s_ok = good;
+                    if (good) s_next = step_advance<T>(a.st, S_this, mb);
+                    else atomicExch(&a.st->error, 1u);
+                }
+            }
+        } else
         if (tid < 64) {
             const int set = a.step & 1;
             int good = 0;

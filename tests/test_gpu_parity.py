@@ -769,6 +769,40 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
             assert relmax(f1, ref) < TOL_1000
 
 
+@pytest.mark.parametrize("log2n, rows", [(18, 2), (19, 1), (19, 2), (20, 2)])
+def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch):
+    """complex64 plans whose column kernel has up to 512 workgroups (2^20 x 2: two per CU, all resident) run the same fused kernel:
+    every workgroup publishes (step, max |A|^2) as one 8-byte word and reads everybody's (AdaptState::wgmax) -- two launches per step
+    instead of three.  SSFM_ADAPT_FUSED_MAX=64 keeps round 2's limit.  Same step rule on the same maxima: the z logs agree."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=70 + log2n, power_w=10e-3)[:rows]
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
+    monkeypatch.delenv("SSFM_ADAPT_LANES", raising=False)
+    monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
+    res = {}
+    for cap in ("512", "64"):
+        monkeypatch.setenv("SSFM_ADAPT_FUSED_MAX", cap)
+        p = _lib.Plan(n, rows, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            for rep in range(2):
+                p.set_field(a)
+                steps, z, _ = p.propagate_adaptive(1.3, 6.0, 0.004, False)
+            res[cap] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
+        finally:
+            p.close()
+    s1, z1, f1, l1 = res["512"]
+    s0, z0, f0, l0 = res["64"]
+    assert s1 > 10 and abs(z1[-1] - 6.0) < 1e-5
+    assert l1 < l0 and l1 <= 2 * s1 + 40 and l0 >= 3 * s0
+    assert abs(s1 - s0) <= 1
+    k = min(s1, s0, 12)
+    np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6)
+    assert relmax(f1, f0) < 5 * TOL_100
+
+
 @pytest.mark.parametrize("log2n", [19, 20])
 def test_two_lane_adaptive_run_against_the_one_stream_engine(log2n, monkeypatch):
     """An adaptive run of a dual-polarisation field of 2^19 samples or more drives the polarisations on two streams, as the
@@ -782,6 +816,7 @@ def test_two_lane_adaptive_run_against_the_one_stream_engine(log2n, monkeypatch)
     res = {}
     monkeypatch.setenv("SSFM_LANES", "2")                              # (whatever the suite runs under)
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
+    monkeypatch.setenv("SSFM_ADAPT_FUSED_MAX", "64")                   # (the one-stream reference: three launches per step)
     for lanes in ("2", "1"):
         monkeypatch.setenv("SSFM_ADAPT_LANES", lanes)
         p = _lib.Plan(n, 2, _lib.C64)
@@ -816,6 +851,7 @@ def test_two_lane_adaptive_run_without_patience_still_gives_the_one_stream_resul
     a = workloads.qpsk_field(n, seed=5, power_w=10e-3)
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
     monkeypatch.setenv("SSFM_ADAPT_LANES", "1")
+    monkeypatch.setenv("SSFM_ADAPT_FUSED_MAX", "64")                   # (one stream = three launches per step here)
     q = _lib.Plan(n, 2, _lib.C64)
     try:
         q.set_linear_operator(D); q.set_field(a)
