@@ -34,6 +34,9 @@
 #ifndef SSFM_LATE_TAB
 #define SSFM_LATE_TAB 0
 #endif
+#ifndef SSFM_WORD_BARRIER_ALL
+#define SSFM_WORD_BARRIER_ALL 1
+#endif
 #ifndef SSFM_RELAXED_BARRIER
 #define SSFM_RELAXED_BARRIER 1
 #endif
@@ -802,7 +805,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         constexpr int NWAVES_A = (N1 * C / E + 63) / 64;
         if ((tid & 63) == 0) wave_max_a[tid >> 6] = pmax;
         __syncthreads();
-        if (sizeof(T) == 4 && nblk > (unsigned)kAdaptSlots) {
+        if (sizeof(T) == 4 && (SSFM_WORD_BARRIER_ALL || nblk > (unsigned)kAdaptSlots)) {
             // ---- large grids: every workgroup publishes ONE word, a wavefront of every workgroup reads them all
             if (tid < 64) {
                 const int set = a.step & 1;
