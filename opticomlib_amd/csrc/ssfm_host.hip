@@ -285,9 +285,10 @@ template <typename T> struct PlanT : PlanBase {
     // single-launch engine of medium plans (ssfm_kernels.hpp k_medium): its barrier counters and error word in device memory, a pinned
     // host copy of the error word, and what a repeat of the run on the two-kernel engine needs
     bool medium_ok = true;     // env SSFM_MEDIUM=0, or a run whose barrier once ran out of patience, clears it
-    unsigned long long* medium_st = nullptr;       // kBarShards counters, then the error word
+    unsigned long long* medium_st = nullptr;       // kBarShards counters, kBarWords flag words, the error word, the ticket counter
     unsigned* medium_err_host = nullptr;
     bool medium_pending = false;
+    long long medium_max_samples = 1ll << 17;      // samples in all (rows x n) up to which the one-XCD engine is used (measured: a gain up to there; env SSFM_MEDIUM_MAX_LOG2)
     int medium_xcc = -1, medium_xccs = 8;          // the XCD this plan's single-launch runs use, of so many
     std::vector<T> medium_sched;
     double medium_gamma = 0;
@@ -627,6 +628,7 @@ template <typename T> struct PlanT : PlanBase {
         }
         if (const char* e = std::getenv("SSFM_ADAPT_FUSED")) fused_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_MEDIUM")) medium_ok = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_MEDIUM_MAX_LOG2")) medium_max_samples = 1ll << std::atoi(e);
         if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) medium_patience = std::atoll(e);
         if (const char* e = std::getenv("SSFM_ADAPT_LANES")) lanes2_ok = std::atoi(e) >= 2;
         if (const char* e = std::getenv("SSFM_PHASE_TABLE")) phase_tables = std::atoi(e) != 0;
@@ -762,14 +764,14 @@ template <typename T> struct PlanT : PlanBase {
         if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
         HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));          // for a repeat on the two-kernel engine
         if (!medium_st) {
-            HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * (kBarShards + 2)));
+            HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * (kBarShards + kBarWords + 2)));
             HIP_TRY(hipHostMalloc(&medium_err_host, sizeof(unsigned)));
             *medium_err_host = 0u;
         }
-        HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + 2), stream));
+        HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + kBarWords + 2), stream));
         a.F = F; a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.tw2 = tw2;
         a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb;
-        a.bar = medium_st; a.error = reinterpret_cast<unsigned*>(medium_st + kBarShards); a.patience = medium_patience;
+        a.bar = medium_st; a.error = reinterpret_cast<unsigned*>(medium_st + kBarShards + kBarWords); a.patience = medium_patience;
         if (medium_xcc < 0) {
             // the XCDs a launch is dealt to, and this plan's among them
             static std::atomic<int> next_plan{0};
@@ -949,7 +951,7 @@ template <typename T> struct PlanT : PlanBase {
         const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
         const bool go_medium = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !go_small && !profiling
                                && snapshots == nullptr && graph_policy == 0 && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
-                               && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || n * batch <= (1ll << 16)) && (use_phase || !phase_tables || !op_flat_re);
+                               && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || n * batch <= medium_max_samples) && (use_phase || !phase_tables || !op_flat_re);
         if (use_tables && !go_small && !go_medium)
             if (int rc = tables_for(distinct, tabptr.data(), false, use_phase ? 1 : 0)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {

@@ -1288,6 +1288,18 @@ template <typename T> struct MediumArgs {
     int Qf;
 };
 constexpr int kBarShards = 8;
+#ifndef SSFM_MEDIUM_WORDS
+#define SSFM_MEDIUM_WORDS 1
+#endif
+constexpr int kBarWords = 64;          // one-XCD form: a flag word per workgroup (no atomics), behind the shards; then the error word and the ticket counter
+__device__ __forceinline__ unsigned long long ld_l2_u64(const unsigned long long* p) {         // misses the CU's L1, answered by the XCD's L2
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st_l2_u64(unsigned long long* p, unsigned long long v) {       // a plain store: written through the L1 into the XCD's L2
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
 // every workgroup of the launch has passed here `epoch` times once each counter shows epoch * nblk / 8 arrivals
 __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned* error, long long patience, unsigned long long& epoch,
                                                const unsigned bid, const unsigned nblk, const int tid) {
@@ -1297,7 +1309,12 @@ __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned
     ++epoch;
     if (tid < 64) {
 #if SSFM_MEDIUM_LOCAL
+        // every workgroup raises its own word to the epoch; a wavefront of every workgroup reads them all (one per lane)
+#if SSFM_MEDIUM_WORDS
+        if (tid == 0) st_l2_u64(&bar[kBarShards + bid], epoch);
+#else
         if (tid == 0) l2_add_u64(&bar[bid & (kBarShards - 1)], 1ull);
+#endif
 #else
         if (tid == 0) __hip_atomic_fetch_add(&bar[bid & (kBarShards - 1)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -1307,7 +1324,11 @@ __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned
         for (;;) {
 #if SSFM_MEDIUM_LOCAL
             unsigned long long got = want;
+#if SSFM_MEDIUM_WORDS
+            if ((unsigned)tid < nblk) got = ld_l2_u64(&bar[kBarShards + tid]) >= epoch ? want : 0ull;
+#else
             if (tid < kBarShards) got = l2_add_u64(&bar[tid], 0ull);
+#endif
 #else
             const unsigned long long got = tid < kBarShards ? __hip_atomic_load(&bar[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
 #endif
@@ -1332,7 +1353,7 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
     // on the two-kernel engine
     if (xcc_id() != a.xcc) return;
     __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
-    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + 1, 1ull);
+    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
     __syncthreads();
     const unsigned bid = s_bid[0], nblk = a.nblk;
     if (bid >= nblk) return;

@@ -619,7 +619,7 @@ def test_single_launch_capture_against_the_two_kernel_engine(prec, monkeypatch):
 
 @pytest.mark.parametrize("log2n, rows", [(14, 1), (14, 2), (15, 1), (15, 2), (16, 1), (16, 2), (17, 1), (17, 2), (16, 4)])
 def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, monkeypatch):
-    """complex64 plans of up to 2^16 samples in all (2^14 x 1..4, 2^15 x 1..2, 2^16 x 1) run a fixed-step schedule in ONE launch
+    """complex64 plans of up to 2^17 samples in all (2^14 x 1..4, 2^15 x 1..4, 2^16 x 1..2, 2^17 x 1) run a fixed-step schedule in ONE launch
     (ssfm_kernels.hpp k_medium: the passes of the two-kernel engine separated by barriers, all workgroups on one XCD and meeting in its L2);
     SSFM_MEDIUM=0 at plan creation, or a larger plan, keeps the two-kernel engine.  The same passes on the same data: bit-identical
     fields, repeatedly (a stale read of another workgroup's data would show here); and against the oracle."""
@@ -648,7 +648,7 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
         finally:
             p.close()
     for (f1, l1), (f0, l0) in zip(got["1"], got["0"]):
-        assert l0 > 10 and (l1 == 1 if n * rows <= (1 << 16) else l1 == l0)
+        assert l0 > 10 and (l1 == 1 if n * rows <= (1 << 17) else l1 == l0)
         np.testing.assert_array_equal(f1, f0)
     np.testing.assert_array_equal(got["1"][0][0], got["1"][2][0])
     if log2n <= 15:
