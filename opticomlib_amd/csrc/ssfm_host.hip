@@ -288,6 +288,7 @@ template <typename T> struct PlanT : PlanBase {
     unsigned long long* medium_st = nullptr;       // kBarShards counters, kBarWords flag words, the error word, the ticket counter
     unsigned* medium_err_host = nullptr;
     bool medium_pending = false;
+    bool medium_adapt_ok = true;   // env SSFM_MEDIUM_ADAPT=0, or a run whose workgroups once did not all get to run, clears it
     long long medium_max_samples = 1ll << 17;      // samples in all (rows x n) up to which the one-XCD engine is used (measured: a gain up to there; env SSFM_MEDIUM_MAX_LOG2)
     int medium_xcc = -1, medium_xccs = 8;          // the XCD this plan's single-launch runs use, of so many
     std::vector<T> medium_sched;
@@ -629,6 +630,7 @@ template <typename T> struct PlanT : PlanBase {
         if (const char* e = std::getenv("SSFM_ADAPT_FUSED")) fused_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_MEDIUM")) medium_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_MEDIUM_MAX_LOG2")) medium_max_samples = 1ll << std::atoi(e);
+        if (const char* e = std::getenv("SSFM_MEDIUM_ADAPT")) medium_adapt_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) medium_patience = std::atoll(e);
         if (const char* e = std::getenv("SSFM_ADAPT_LANES")) lanes2_ok = std::atoi(e) >= 2;
         if (const char* e = std::getenv("SSFM_PHASE_TABLE")) phase_tables = std::atoi(e) != 0;
@@ -870,6 +872,7 @@ template <typename T> struct PlanT : PlanBase {
         (void)lane;
         a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0; a.lane = 0; a.lanes2 = 0;
+        a.s_in = nullptr; a.s_out = nullptr;
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
@@ -1139,6 +1142,7 @@ template <typename T> struct PlanT : PlanBase {
         StepState<T> now = {};         // state after the last launched step (host copy)
         bool fused = false;            // column kernel of at most 128 workgroups, no capture: END + BEGIN in one launch (TM_MID_A)
         bool lanes2 = false;           // two row groups on two streams, joined only through the step control state (see adaptive_run)
+        bool medium = false;           // (deferred) a medium plan: the single-launch kernel is k_medium_adapt (one XCD)
         bool deferred = false;         // small plan without capture: nothing launched yet -- the first adaptive_run decides between
         int single_step = 0;           // the single-launch kernel (budget covers the run) and the chunked engine
         T phi_max = 0;
@@ -1161,6 +1165,16 @@ template <typename T> struct PlanT : PlanBase {
             ar.active = true; ar.deferred = true;
             ar.gamma = gamma; ar.length = (T)length; ar.phi_max = (T)phi_max; ar.max_steps = (int)max_steps; ar.single_step = single_step;
             return SSFM_OK;
+        }
+        if constexpr (sizeof(T) == 4) {
+            const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+            if (SSFM_MEDIUM_LOCAL && medium_ok && medium_adapt_ok && fused_ok && !capture && !single_step && u16 && E == 8 && Ef == 8 && Ef_fly == 8 && medium_shape(N1, N2)
+                && twA != nullptr && blocks % kBarShards == 0 && blocks <= kBarWords && n * batch <= medium_max_samples) {
+                ar = AdaptRun();
+                ar.active = true; ar.deferred = true; ar.medium = true;
+                ar.gamma = gamma; ar.length = (T)length; ar.phi_max = (T)phi_max; ar.max_steps = (int)max_steps; ar.single_step = single_step;
+                return SSFM_OK;
+            }
         }
         return adaptive_begin_chunked(gamma, (T)length, (T)phi_max, single_step, (int)max_steps, capture);
     }
@@ -1249,6 +1263,56 @@ template <typename T> struct PlanT : PlanBase {
         if (ar.deferred) {
             if (snapshots != nullptr) return fail(SSFM_ERR_STATE, "ssfm_adaptive_run: the run was not begun with capture");
             const AdaptRun keep = ar;
+            if (keep.medium && budget >= (int64_t)keep.max_steps) {
+                if constexpr (sizeof(T) == 4) {
+                    // the whole run in one launch on one XCD (k_medium_adapt); the input is kept for the case that its workgroups do not all get to run
+                    const size_t fb = sizeof(cx<T>) * n * batch;
+                    if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
+                    HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));
+                    if (int rc = upload_adapt_state(keep.gamma, keep.length, keep.phi_max, keep.max_steps)) return rc;
+                    hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, (const cx<T>*)F, (long long)n * batch, st);
+                    hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 0, 0, 0);
+                    last_launches += 2;
+                    if (!medium_st) {
+                        HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * (kBarShards + kBarWords + 2)));
+                        HIP_TRY(hipHostMalloc(&medium_err_host, sizeof(unsigned)));
+                        *medium_err_host = 0u;
+                    }
+                    HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + kBarWords + 2), stream));
+                    if (medium_xcc < 0) {
+                        static std::atomic<int> next_plan_a{0};
+                        const unsigned mask = xcc_mask(device);
+                        if (mask == 0u) return fail(SSFM_ERR_HIP, "the XCD probe launch failed");
+                        medium_xccs = __builtin_popcount(mask);
+                        int k = next_plan_a.fetch_add(1) % medium_xccs;
+                        for (int b = 0; b < 32; ++b)
+                            if ((mask >> b) & 1u) { if (k == 0) { medium_xcc = b; break; } --k; }
+                    }
+                    MediumAdaptArgs<T> ma;
+                    ma.F = F; ma.Y = Y; ma.P = P; ma.twA = twA; ma.twB = twB; ma.tw1 = tw1; ma.tw2 = tw2; ma.D = dperm; ma.st = st; ma.zlog = zlog;
+                    ma.bar = medium_st; ma.error = reinterpret_cast<unsigned*>(medium_st + kBarShards + kBarWords); ma.patience = medium_patience;
+                    ma.xcc = (unsigned)medium_xcc; ma.nblk = (unsigned)((N2 / cols_per_tile<T>()) * batch);
+                    ma.gamma = keep.gamma; ma.inv_n = inv_n(); ma.rows = batch; ma.Qf = N2 / Ef;
+                    ++last_launches;
+                    HIP_TRY(launch_medium_adapt(N1, N2, (int)ma.nblk, medium_xccs, stream, ma));
+                    unsigned gave_up = 0, gave_up2 = 0;
+                    HIP_TRY(hipMemcpyAsync(&gave_up, ma.error, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(&gave_up2, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(ar.now), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    if (!gave_up && !gave_up2) {
+                        ar.deferred = false;
+                        if (steps_total) *steps_total = ar.now.steps;
+                        if (done) *done = ar.now.done;
+                        return SSFM_OK;
+                    }
+                    // part of the grid never ran beside the rest: the same run on the chunked engine, which this plan then keeps to
+                    medium_adapt_ok = false;
+                    HIP_TRY(hipMemcpyAsync(F, fused_backup, fb, hipMemcpyDeviceToDevice, stream));
+                }
+            } else if (keep.medium) {
+                // (a caller that takes the run in pieces: the chunked engine)
+            } else
             if (budget >= (int64_t)keep.max_steps) {
                 // the whole run in one launch (k_small_adapt); the state and the z log are read once, here
                 if (int rc = upload_adapt_state(keep.gamma, keep.length, keep.phi_max, keep.max_steps)) return rc;

@@ -235,6 +235,8 @@ template <typename T> struct TimeArgs {
     int derive;               // adaptive BEGIN: 1 = derive the step's state from the previous step's (see AdaptState)
     int lane;                 // adaptive: which set of slots this launch's rows deliver their maxima to (0 in single-lane runs)
     int lanes2;               // adaptive, two lanes: END counts its arrivals, a deriving BEGIN waits for the other lane's (AdaptState::arrived)
+    const StepState<T>* s_in; // k_medium_adapt (PK): TM_MID_A takes the state of the step it finishes from here (LDS) instead of st->cur[],
+    StepState<T>* s_out;      // ... and leaves the next step's here (untouched if the hand-over ran out of patience)
     SSFM_TRACE_ARGS
 };
 
@@ -575,6 +577,14 @@ __device__ __forceinline__ unsigned long long l2_add_u64(unsigned long long* p, 
     asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
     return old;
 }
+__device__ __forceinline__ unsigned long long ld_l2_u64(const unsigned long long* p) {         // misses the CU's L1, answered by the XCD's L2
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st_l2_u64(unsigned long long* p, unsigned long long v) {       // a plain store: written through the L1 into the XCD's L2
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ unsigned xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -694,7 +704,10 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     // by the previous launch, so its load is a miss of ~2 us that would otherwise stand in front of the whole kernel.  (A launch
     // queued beyond the end of the run returns now; its loads went to registers only.)
     StepState<T> S_this = {};            // TM_MID_A: the state of the step this launch finishes
-    if constexpr (MODE == TM_MID_A) {
+    if constexpr (MODE == TM_MID_A && PK) {
+        S_this = *a.s_in;
+        hh_prev = S_this.h * (T)0.5;
+    } else if constexpr (MODE == TM_MID_A) {
         S_this = a.st->cur[a.step & 1];
         // (a workgroup of an EARLIER launch gave up waiting: the run is void and the host will repeat it -- the launches still
         // queued return at once instead of each waiting out its own patience on a field that no longer means anything)
@@ -814,7 +827,8 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                     T m = wave_max_a[0];
 #pragma unroll
                     for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
-                    __hip_atomic_store(&a.st->wgmax[set][bid], epoch | (float_bits<T>(m) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) st_l2_u64(&a.st->wgmax[set][bid], epoch | (float_bits<T>(m) & 0xffffffffull));
+                    else __hip_atomic_store(&a.st->wgmax[set][bid], epoch | (float_bits<T>(m) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const unsigned long long* words = a.st->wgmax[set];
                 const long long t0 = wall_clock64();
@@ -830,7 +844,9 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
 #pragma unroll
                     for (int i = 0; i < kAdaptWords / 64; ++i) {
                         if (pending & (1u << i)) {
-                            const unsigned long long wd = __hip_atomic_load(&words[(unsigned)tid + 64u * (unsigned)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            unsigned long long wd;
+                            if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) wd = ld_l2_u64(&words[(unsigned)tid + 64u * (unsigned)i]);
+                            else wd = __hip_atomic_load(&words[(unsigned)tid + 64u * (unsigned)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((wd >> 32) == (epoch >> 32)) {
                                 pending &= ~(1u << i);
                                 const unsigned long long vb = wd & 0xffffffffull;
@@ -899,6 +915,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         __syncthreads();
         if (!s_ok) return;
         const StepState<T> Sn = s_next;
+        if constexpr (PK) { if (tid == 0) *a.s_out = Sn; }
         if (bid == 0) {
             // workgroup 0 records the state of the next step and empties what the next step's launch will fill
             if (tid == 0) { a.st->cur[(a.step + 1) & 1] = Sn; a.zlog[Sn.steps] = Sn.z; a.st->arrive[(a.step + 1) & 1] = 0u; }
@@ -1292,14 +1309,7 @@ constexpr int kBarShards = 8;
 #define SSFM_MEDIUM_WORDS 1
 #endif
 constexpr int kBarWords = 64;          // one-XCD form: a flag word per workgroup (no atomics), behind the shards; then the error word and the ticket counter
-__device__ __forceinline__ unsigned long long ld_l2_u64(const unsigned long long* p) {         // misses the CU's L1, answered by the XCD's L2
-    unsigned long long v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc0 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void st_l2_u64(unsigned long long* p, unsigned long long v) {       // a plain store: written through the L1 into the XCD's L2
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
+
 // every workgroup of the launch has passed here `epoch` times once each counter shows epoch * nblk / 8 arrivals
 __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned* error, long long patience, unsigned long long& epoch,
                                                const unsigned bid, const unsigned nblk, const int tid) {
@@ -1385,6 +1395,78 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
             time_body<T, N1, C, E, TM_END, true, true>(ta, bid, nblk);
         }
     }
+}
+
+// ------------------------------------------------------------------------------ k_medium_adapt
+// The ADAPTIVE run of a medium plan in one launch on one XCD: k_medium's passes with the step size found on the way.  Every workgroup
+// keeps the step control state itself (the same arithmetic on the same maxima: the same bits everywhere, as in TM_MID_A); the maxima
+// travel as one word per workgroup through the XCD's L2 (AdaptState::wgmax); workgroup 0 writes the z log and, at the end, the state
+// the host reads.  The first step's size is in st->cur[0] (k_absmax + k_step_control ran before the launch).
+template <typename T> struct MediumAdaptArgs {
+    cx<T>* F;
+    cx<T>* Y;
+    T* P;
+    const cx<T>* twA;
+    const cx<T>* twB;
+    const cx<T>* tw1;
+    const cx<T>* tw2;
+    const cx<T>* D;                    // D~ in k_freq<FM_FLY>'s order
+    AdaptState<T>* st;
+    T* zlog;
+    unsigned long long* bar;           // as MediumArgs::bar
+    unsigned xcc, nblk;
+    unsigned* error;
+    long long patience;
+    T gamma;
+    T inv_n;
+    int rows;
+    int Qf;
+};
+template <typename T, int N1, int N2, int E>
+__global__ __launch_bounds__(N1 * 16 / E) void k_medium_adapt(const MediumAdaptArgs<T> a) {
+    constexpr int C = 16, ROWS = N1 * C / N2;
+    static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
+    const int tid = threadIdx.x;
+#if SSFM_MEDIUM_LOCAL
+    if (xcc_id() != a.xcc) return;
+    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
+    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
+    __syncthreads();
+    const unsigned bid = s_bid[0], nblk = a.nblk;
+    if (bid >= nblk) return;
+#else
+    const unsigned bid = blockIdx.x, nblk = gridDim.x;
+#endif
+    __shared__ __attribute__((aligned(16))) StepState<T> s_state[2];       // [0] the step being taken, [1] where TM_MID_A leaves the next one
+    unsigned long long epoch = 0;
+    StepState<T> S = a.st->cur[0];
+    if (S.done) return;
+    TimeArgs<T> ta;
+    ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = a.zlog;
+    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
+    ta.s_in = &s_state[0]; ta.s_out = &s_state[1];
+    FreqArgs<T> fa;
+    fa.F = a.Y; fa.tab = a.D; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = a.inv_n; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0; fa.amp = (T)0;
+    const T half = (T)0.5;
+    ta.hh_prev = (T)0; ta.hh_next = S.h * half;
+    time_body<T, N1, C, E, TM_BEGIN, true, true>(ta, bid, nblk);
+    if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+    ta.st = a.st;
+    for (int step = 0;; ++step) {
+        fa.h = S.h;
+        freq_body<T, N2, ROWS, E, FM_FLY, true, true>(fa, bid);
+        if (tid == 0) { s_state[0] = S; s_state[1].steps = -0x7fffffff; }
+        if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;       // (its barriers also publish s_state to the workgroup)
+        ta.step = step;
+        time_body<T, N1, C, E, TM_MID_A, true, true>(ta, bid, nblk);
+        __syncthreads();
+        const StepState<T> Sn = s_state[1];
+        if (Sn.steps == -0x7fffffff) return;                   // the hand-over of the maxima ran out of patience (error word set)
+        S = Sn;
+        if (S.done) break;
+        if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+    }
+    if (bid == 0 && tid == 0) a.st->cur[0] = S;                // (the host reads cur[0])
 }
 
 // ------------------------------------------------------------------------------ k_small

@@ -769,6 +769,49 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
             assert relmax(f1, ref) < TOL_1000
 
 
+@pytest.mark.parametrize("log2n, rows", [(14, 1), (14, 2), (14, 4), (15, 2), (16, 1), (16, 2), (17, 1)])
+def test_medium_adaptive_run_in_one_launch(log2n, rows, monkeypatch):
+    """complex64 plans of up to 2^17 samples in all take a whole ADAPTIVE run in one launch on one XCD (k_medium_adapt: k_medium's
+    passes, the step size found on the way; every workgroup keeps the step control state itself).  SSFM_MEDIUM_ADAPT=0 keeps two
+    launches per step.  Same step rule on the same maxima: the same number of steps, z logs equal, fields equal to rounding; twice in
+    a row (the flag words are epochs: a stale one would show); against the oracle at the small sizes."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    rng = np.random.default_rng(300 + log2n + rows)
+    a = (workloads.qpsk_field(n, seed=80 + log2n, power_w=10e-3)[:1] * np.ones((rows, 1))).astype(np.complex64)
+    a = (a * (1 + 0.1 * rng.standard_normal((rows, 1)))).astype(np.complex64)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
+    monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
+    monkeypatch.setenv("SSFM_MEDIUM", "1")
+    res = {}
+    for one in ("1", "0"):
+        monkeypatch.setenv("SSFM_MEDIUM_ADAPT", one)
+        p = _lib.Plan(n, rows, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            outs = []
+            for rep in range(2):
+                p.set_field(a)
+                steps, z, _ = p.propagate_adaptive(1.3, 5.0, 0.003, False)
+                outs.append((steps, z, p.get_field(), p.last_propagate_ms()[1]))
+            res[one] = outs
+        finally:
+            p.close()
+    (s1, z1, f1, l1), (s1b, z1b, f1b, _) = res["1"]
+    s0, z0, f0, l0 = res["0"][0]
+    assert s1 > 10 and abs(z1[-1] - 5.0) < 1e-5
+    assert l1 <= 3 and l0 >= 2 * s0                                   # |A|^2 maximum, first step size, the run itself
+    assert s1 == s1b and np.array_equal(z1, z1b) and np.array_equal(f1, f1b)
+    assert abs(s1 - s0) <= 1
+    k = min(s1, s0, 12)
+    np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6)
+    assert relmax(f1, f0) < 5 * TOL_100
+    if log2n <= 14 and rows <= 2:
+        ref = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 5.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.003)
+        assert relmax(f1, ref) < TOL_1000
+
+
 @pytest.mark.parametrize("log2n, rows", [(18, 2), (19, 1), (19, 2), (20, 2)])
 def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch):
     """complex64 plans whose column kernel has up to 512 workgroups (2^20 x 2: two per CU, all resident) run the same fused kernel:
