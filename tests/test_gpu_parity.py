@@ -669,6 +669,8 @@ def test_medium_single_launch_engine_on_several_plans_at_once(monkeypatch):
     fields = [workloads.qpsk_field(n, seed=40 + k, power_w=5e-3).astype(np.complex64) for k in range(4)]
     monkeypatch.setenv("SSFM_GRAPH", "0")
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
+    monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)
+    monkeypatch.delenv("SSFM_E", raising=False)
     monkeypatch.setenv("SSFM_MEDIUM", "0")
     want = []
     for a in fields:
