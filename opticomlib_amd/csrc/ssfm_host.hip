@@ -288,6 +288,8 @@ template <typename T> struct PlanT : PlanBase {
     unsigned long long* medium_st = nullptr;       // kBarShards counters, kBarWords flag words, the error word, the ticket counter
     unsigned* medium_err_host = nullptr;
     bool medium_pending = false;
+    bool fused_lanes_ok = false;   // env SSFM_ADAPT_FUSED_LANES=1: the large fused adaptive form on two streams (measured: 28.9-29.7 against 29.6-31.1 us per step at
+                                   // 2^20 x 2 -- the lanes meet in every MID_A, so little overlaps -- for four launches per step instead of two: opt-in)
     bool medium_adapt_ok = true;   // env SSFM_MEDIUM_ADAPT=0, or a run whose workgroups once did not all get to run, clears it
     long long medium_max_samples = 1ll << 17;      // samples in all (rows x n) up to which the one-XCD engine is used (measured: a gain up to there; env SSFM_MEDIUM_MAX_LOG2)
     int medium_xcc = -1, medium_xccs = 8;          // the XCD this plan's single-launch runs use, of so many
@@ -631,6 +633,7 @@ template <typename T> struct PlanT : PlanBase {
         if (const char* e = std::getenv("SSFM_MEDIUM")) medium_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_MEDIUM_MAX_LOG2")) medium_max_samples = 1ll << std::atoi(e);
         if (const char* e = std::getenv("SSFM_MEDIUM_ADAPT")) medium_adapt_ok = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_ADAPT_FUSED_LANES")) fused_lanes_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) medium_patience = std::atoll(e);
         if (const char* e = std::getenv("SSFM_ADAPT_LANES")) lanes2_ok = std::atoi(e) >= 2;
         if (const char* e = std::getenv("SSFM_PHASE_TABLE")) phase_tables = std::atoi(e) != 0;
@@ -1142,6 +1145,7 @@ template <typename T> struct PlanT : PlanBase {
         StepState<T> now = {};         // state after the last launched step (host copy)
         bool fused = false;            // column kernel of at most 128 workgroups, no capture: END + BEGIN in one launch (TM_MID_A)
         bool lanes2 = false;           // two row groups on two streams, joined only through the step control state (see adaptive_run)
+        bool fused_lanes = false;      // fused, and the two polarisations on a stream each: FLY + MID_A per lane and step, the lanes meet in MID_A's hand-over
         bool medium = false;           // (deferred) a medium plan: the single-launch kernel is k_medium_adapt (one XCD)
         bool deferred = false;         // small plan without capture: nothing launched yet -- the first adaptive_run decides between
         int single_step = 0;           // the single-launch kernel (budget covers the run) and the chunked engine
@@ -1234,6 +1238,9 @@ template <typename T> struct PlanT : PlanBase {
             if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
             HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));
         }
+        // the large fused form on two lanes: a lane's launches are FLY and MID_A over its rows; MID_A waits for the words of BOTH lanes, so the
+        // lanes stay within a step of each other (SSFM_ADAPT_FUSED_LANES=1: opt-in, see fused_lanes_ok)
+        ar.fused_lanes = ar.fused && fused_lanes_ok && sizeof(T) == 4 && nlanes == 2 && batch == 2 && col_blocks > kAdaptSlots && (col_blocks / 2) % 64 == 0;
         ar.tile_private = u16 && !capture && !ar.fused;
         // Two lanes (round 3, opt-in): the rows only share the step size, so each half of them runs its own BEGIN_Y -> k_freq -> END_Y
         // chain on its own stream, as the fixed-step lanes do; a lane's BEGIN(s + 1) waits INSIDE the kernel for the other lane's
@@ -1350,6 +1357,29 @@ template <typename T> struct PlanT : PlanBase {
         int chunk = snap ? 1 : estimate();
         while (!ar.now.done && ar.now.steps - first_step < budget) {
             if ((int64_t)chunk > budget - (ar.now.steps - first_step)) chunk = (int)(budget - (ar.now.steps - first_step));
+            if (ar.fused && ar.fused_lanes) {
+                const int rows = batch / 2;
+                HIP_TRY(hipEventRecord(fork_ev, stream));
+                HIP_TRY(hipStreamWaitEvent(lane_stream[1], fork_ev, 0));
+                for (int i = 0; i < chunk; ++i, ++ar.step) {
+                    for (int k = (ar.step == 0 ? 0 : 1); k < 3; ++k)
+                        for (int g = 0; g < 2; ++g) {
+                            if (k == 1) {
+                                FreqArgs<T> fa = fargs_fly(0, st, g * rows, g);
+                                fa.step = ar.step;
+                                HIP_TRY((launch_freq<T, FM_FLY>(N2, N1 * rows, lane_stream[g], fa, Ef_fly)));
+                            } else {
+                                TimeArgs<T> tb = targs(ar.gamma, 0, 0, st, g * rows, g);
+                                tb.step = ar.step; tb.lane = g; tb.lanes2 = 1; tb.derive = 0;
+                                if (k == 0) HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], tb, E)));
+                                else HIP_TRY((launch_time<T, TM_MID_A>(N1, rows, lane_stream[g], tb, E)));
+                            }
+                            ++last_launches;
+                        }
+                }
+                HIP_TRY(hipEventRecord(lane_ev[1], lane_stream[1]));
+                HIP_TRY(hipStreamWaitEvent(stream, lane_ev[1], 0));
+            } else
             if (ar.lanes2) {
                 // fork once per chunk; inside it the lanes meet only in device memory
                 const int rows = batch / 2;

@@ -823,12 +823,14 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             if (tid < 64) {
                 const int set = a.step & 1;
                 const unsigned long long epoch = (unsigned long long)(unsigned)(a.step + 1) << 32;
+                // (two lanes, one launch each: the words of both; this launch's are the lane's share)
+                const unsigned total = a.lanes2 ? 2u * nblk : nblk, mine = (a.lanes2 ? (unsigned)a.lane * nblk : 0u) + bid;
                 if (tid == 0) {
                     T m = wave_max_a[0];
 #pragma unroll
                     for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
-                    if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) st_l2_u64(&a.st->wgmax[set][bid], epoch | (float_bits<T>(m) & 0xffffffffull));
-                    else __hip_atomic_store(&a.st->wgmax[set][bid], epoch | (float_bits<T>(m) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) st_l2_u64(&a.st->wgmax[set][mine], epoch | (float_bits<T>(m) & 0xffffffffull));
+                    else __hip_atomic_store(&a.st->wgmax[set][mine], epoch | (float_bits<T>(m) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const unsigned long long* words = a.st->wgmax[set];
                 const long long t0 = wall_clock64();
@@ -839,7 +841,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 unsigned pending = 0u;
 #pragma unroll
                 for (int i = 0; i < kAdaptWords / 64; ++i)
-                    if ((unsigned)tid + 64u * (unsigned)i < nblk) pending |= 1u << i;
+                    if ((unsigned)tid + 64u * (unsigned)i < total) pending |= 1u << i;
                 for (;;) {
 #pragma unroll
                     for (int i = 0; i < kAdaptWords / 64; ++i) {

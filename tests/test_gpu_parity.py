@@ -825,6 +825,7 @@ def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch):
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
     monkeypatch.delenv("SSFM_ADAPT_LANES", raising=False)
+    monkeypatch.delenv("SSFM_ADAPT_FUSED_LANES", raising=False)
     monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
     res = {}
     for cap in ("512", "64"):
@@ -846,6 +847,38 @@ def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch):
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6)
     assert relmax(f1, f0) < 5 * TOL_100
+
+
+@pytest.mark.parametrize("log2n", [19, 20])
+def test_fused_adaptive_kernel_on_two_lanes(log2n, monkeypatch):
+    """SSFM_ADAPT_FUSED_LANES=1 (opt-in): the fused form with a stream per polarisation; MID_A of a lane reads the words of both lanes.
+    The same kernels on the same rows, the same maxima: z logs and fields identical to the one-stream fused run, bit for bit."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=90 + log2n, power_w=10e-3)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    monkeypatch.setenv("SSFM_LANES", "2")
+    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
+    monkeypatch.delenv("SSFM_ADAPT_LANES", raising=False)
+    monkeypatch.delenv("SSFM_ADAPT_FUSED_MAX", raising=False)
+    monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
+    res = {}
+    for lanes in ("1", "0"):
+        monkeypatch.setenv("SSFM_ADAPT_FUSED_LANES", lanes)
+        p = _lib.Plan(n, 2, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            for rep in range(2):
+                p.set_field(a)
+                steps, z, _ = p.propagate_adaptive(1.3, 3.0, 0.004, False)
+            res[lanes] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
+        finally:
+            p.close()
+    s2, z2, f2, l2 = res["1"]
+    s1, z1, f1, l1 = res["0"]
+    assert s2 == s1 > 8 and l2 >= 4 * s2 and l1 < 2 * s1 + 40
+    np.testing.assert_array_equal(z2, z1)
+    np.testing.assert_array_equal(f2, f1)
 
 
 @pytest.mark.parametrize("log2n", [19, 20])
