@@ -950,14 +950,16 @@ template <typename T> struct PlanT : PlanBase {
         const bool use_tables = distinct.size() <= (size_t)kMaxTables && !force_fly;
         std::vector<const cx<T>*> tabptr(distinct.size(), nullptr);
         const bool small_sched = small && use_tables && !profiling && nsteps <= 0x7fffffff;
-        const bool go_small = small_sched && snapshots == nullptr;
         // a fibre's operator has one modulus for all frequencies: 4-byte phase tables (ssfm_kernels.hpp FM_PHASE)
         const bool use_phase = use_tables && phase_tables && sizeof(T) == 4 && u16 && op_flat_re;
-        // plans of 2^14 ... 2^17 samples in the unit layout: the whole schedule in one launch (ssfm_kernels.hpp k_medium)
+        // plans of 2^12 ... 2^17 samples in the unit layout: the whole schedule in one launch on one XCD (ssfm_kernels.hpp k_medium).  Measured against the
+        // one-workgroup-per-row kernel of the small plans (k_small): 5.4 against 6.4 us per step at 8192 samples, 5.6 against 3.5 at 4096 -- so from 8192 on
         const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
-        const bool go_medium = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !go_small && !profiling
+        const bool med_elig = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !profiling
                                && snapshots == nullptr && graph_policy == 0 && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
                                && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || n * batch <= medium_max_samples) && (use_phase || !phase_tables || !op_flat_re);
+        const bool go_small = small_sched && snapshots == nullptr && !(med_elig && SSFM_MEDIUM_LOCAL && n >= 8192);
+        const bool go_medium = med_elig && !go_small;
         if (use_tables && !go_small && !go_medium)
             if (int rc = tables_for(distinct, tabptr.data(), false, use_phase ? 1 : 0)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
@@ -1164,21 +1166,24 @@ template <typename T> struct PlanT : PlanBase {
         }
         last_launches = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
-        if (small && !capture && small_adapt_supported<T>((int)n, batch)) {
+        // (4096 x 2: the one-XCD engine, 8.1 us per step, before the one-workgroup kernel that holds both rows, 10.4)
+        bool med_adapt = false;
+        if constexpr (sizeof(T) == 4) {
+            const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+            med_adapt = SSFM_MEDIUM_LOCAL && medium_ok && medium_adapt_ok && fused_ok && !capture && !single_step && u16 && E == 8 && Ef == 8 && Ef_fly == 8 && medium_shape(N1, N2)
+                        && twA != nullptr && blocks % kBarShards == 0 && blocks <= kBarWords && n * batch <= medium_max_samples;
+        }
+        if (small && !capture && small_adapt_supported<T>((int)n, batch) && !(med_adapt && n == 4096 && batch == 2)) {
             ar = AdaptRun();
             ar.active = true; ar.deferred = true;
             ar.gamma = gamma; ar.length = (T)length; ar.phi_max = (T)phi_max; ar.max_steps = (int)max_steps; ar.single_step = single_step;
             return SSFM_OK;
         }
-        if constexpr (sizeof(T) == 4) {
-            const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
-            if (SSFM_MEDIUM_LOCAL && medium_ok && medium_adapt_ok && fused_ok && !capture && !single_step && u16 && E == 8 && Ef == 8 && Ef_fly == 8 && medium_shape(N1, N2)
-                && twA != nullptr && blocks % kBarShards == 0 && blocks <= kBarWords && n * batch <= medium_max_samples) {
-                ar = AdaptRun();
-                ar.active = true; ar.deferred = true; ar.medium = true;
-                ar.gamma = gamma; ar.length = (T)length; ar.phi_max = (T)phi_max; ar.max_steps = (int)max_steps; ar.single_step = single_step;
-                return SSFM_OK;
-            }
+        if (med_adapt) {
+            ar = AdaptRun();
+            ar.active = true; ar.deferred = true; ar.medium = true;
+            ar.gamma = gamma; ar.length = (T)length; ar.phi_max = (T)phi_max; ar.max_steps = (int)max_steps; ar.single_step = single_step;
+            return SSFM_OK;
         }
         return adaptive_begin_chunked(gamma, (T)length, (T)phi_max, single_step, (int)max_steps, capture);
     }

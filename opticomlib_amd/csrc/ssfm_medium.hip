@@ -25,6 +25,8 @@ hipError_t launch_shape(int nblk, int xccs, hipStream_t s, const MediumArgs<floa
     return hipGetLastError();
 }
 template <int FMODE> hipError_t launch_mode(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {
+    if (N1 == 64 && N2 == 64) return launch_shape<64, 64, FMODE>(nblk, xccs, s, a);
+    if (N1 == 64 && N2 == 128) return launch_shape<64, 128, FMODE>(nblk, xccs, s, a);
     if (N1 == 128 && N2 == 128) return launch_shape<128, 128, FMODE>(nblk, xccs, s, a);
     if (N1 == 128 && N2 == 256) return launch_shape<128, 256, FMODE>(nblk, xccs, s, a);
     if (N1 == 256 && N2 == 256) return launch_shape<256, 256, FMODE>(nblk, xccs, s, a);
@@ -51,6 +53,8 @@ hipError_t launch_adapt_shape(int nblk, int xccs, hipStream_t s, const MediumAda
 }
 }  // namespace
 hipError_t launch_medium_adapt(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumAdaptArgs<float>& a) {
+    if (N1 == 64 && N2 == 64) return launch_adapt_shape<64, 64>(nblk, xccs, s, a);
+    if (N1 == 64 && N2 == 128) return launch_adapt_shape<64, 128>(nblk, xccs, s, a);
     if (N1 == 128 && N2 == 128) return launch_adapt_shape<128, 128>(nblk, xccs, s, a);
     if (N1 == 128 && N2 == 256) return launch_adapt_shape<128, 256>(nblk, xccs, s, a);
     if (N1 == 256 && N2 == 256) return launch_adapt_shape<256, 256>(nblk, xccs, s, a);
@@ -58,7 +62,7 @@ hipError_t launch_medium_adapt(int N1, int N2, int nblk, int xccs, hipStream_t s
     return hipErrorInvalidValue;
 }
 
-bool medium_shape(int N1, int N2) { return (N1 == 128 && (N2 == 128 || N2 == 256)) || (N1 == 256 && (N2 == 256 || N2 == 512)); }
+bool medium_shape(int N1, int N2) { return (N1 == 64 && (N2 == 64 || N2 == 128)) || (N1 == 128 && (N2 == 128 || N2 == 256)) || (N1 == 256 && (N2 == 256 || N2 == 512)); }
 
 hipError_t launch_medium(int N1, int N2, bool phase_tables, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {
     return phase_tables ? launch_mode<FM_PHASE>(N1, N2, nblk, xccs, s, a) : launch_mode<FM_TABLE>(N1, N2, nblk, xccs, s, a);

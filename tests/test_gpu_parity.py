@@ -507,6 +507,7 @@ def test_single_launch_engine_against_the_two_kernel_engine(log2n, prec, monkeyp
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
     got = {}
     monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)               # (that diagnostic knob takes the tables, and with them this engine, away)
+    monkeypatch.setenv("SSFM_MEDIUM", "0")                            # (8192 samples: k_small against the two-kernel engine, not the one-XCD engine)
     for small in ("1", "0"):
         monkeypatch.setenv("SSFM_SMALL", small)
         p = _lib.Plan(n, 3, prec)
@@ -550,6 +551,7 @@ def test_single_launch_adaptive_run_against_the_chunked_engine(log2n, rows, prec
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, prec)
     single = rows * n // (16 if (prec == _lib.C64 and n >= 4096) else 8) <= 512 and n <= 4096
     res = {}
+    monkeypatch.setenv("SSFM_MEDIUM_ADAPT", "0")                      # (4096 x 2 and 8192: this test is about k_small_adapt and the chunked engine)
     for small in ("1", "0"):
         monkeypatch.setenv("SSFM_SMALL", small)
         p = _lib.Plan(n, rows, prec)
@@ -656,6 +658,43 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
         for h_ in hs:
             A = orc.ssfm_step_c64(A, orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13), np.float32(1.3), h_)
         assert relmax(got["1"][0][0], A) < TOL_100
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4])
+def test_plans_of_8192_samples_take_the_one_xcd_engine(rows, monkeypatch):
+    """At 8192 samples the one-XCD engine (k_medium, 64 x 128 shape) is faster than the one-workgroup-per-row kernel of the small plans
+    (5.4 against 6.4 us per step) and is the default: one launch, bit-identical to the two-kernel engine (SSFM_SMALL=0 SSFM_MEDIUM=0),
+    within the oracle's tolerance, and close to the small-plan kernel's result (SSFM_MEDIUM=0)."""
+    n = 8192
+    gv(**workloads.BENCH_GV)
+    rng = np.random.default_rng(813 + rows)
+    a = ((rng.standard_normal((rows, n)) + 1j * rng.standard_normal((rows, n))) * 0.05).astype(np.complex64)
+    hs = np.array([0.5] * 20 + [0.25, 0.5, 0.125], dtype=np.float32)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    for k in ("SSFM_FUSED_PATIENCE_TICKS", "SSFM_FORCE_FLY", "SSFM_E"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SSFM_GRAPH", "0")
+    got = {}
+    for name, env in (("default", {"SSFM_MEDIUM": "1", "SSFM_SMALL": "1"}), ("small", {"SSFM_MEDIUM": "0", "SSFM_SMALL": "1"}),
+                      ("two-kernel", {"SSFM_MEDIUM": "0", "SSFM_SMALL": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = _lib.Plan(n, rows, _lib.C64)
+        try:
+            p.set_linear_operator(D)
+            p.set_field(a)
+            p.propagate_fixed(1.3, hs)
+            got[name] = (p.get_field(), p.last_propagate_ms()[1])
+        finally:
+            p.close()
+    assert got["default"][1] == 1 and got["small"][1] == 1 and got["two-kernel"][1] > 10
+    np.testing.assert_array_equal(got["default"][0], got["two-kernel"][0])
+    assert relmax(got["default"][0], got["small"][0]) < TOL_100
+    if rows <= 2:
+        A = a.copy()
+        for h_ in hs:
+            A = orc.ssfm_step_c64(A, orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13), np.float32(1.3), h_)
+        assert relmax(got["default"][0], A) < TOL_100
 
 
 def test_medium_single_launch_engine_on_several_plans_at_once(monkeypatch):
@@ -771,7 +810,7 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
             assert relmax(f1, ref) < TOL_1000
 
 
-@pytest.mark.parametrize("log2n, rows", [(14, 1), (14, 2), (14, 4), (15, 2), (16, 1), (16, 2), (17, 1)])
+@pytest.mark.parametrize("log2n, rows", [(12, 2), (13, 1), (13, 2), (14, 1), (14, 2), (14, 4), (15, 2), (16, 1), (16, 2), (17, 1)])
 def test_medium_adaptive_run_in_one_launch(log2n, rows, monkeypatch):
     """complex64 plans of up to 2^17 samples in all take a whole ADAPTIVE run in one launch on one XCD (k_medium_adapt: k_medium's
     passes, the step size found on the way; every workgroup keeps the step control state itself).  SSFM_MEDIUM_ADAPT=0 keeps two
@@ -786,6 +825,7 @@ def test_medium_adaptive_run_in_one_launch(log2n, rows, monkeypatch):
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
     monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
     monkeypatch.setenv("SSFM_MEDIUM", "1")
+    monkeypatch.setenv("SSFM_SMALL", "0" if log2n == 12 else "1")          # (4096 x 2: the reference run is the launch-per-pass engine, not k_small_adapt)
     res = {}
     for one in ("1", "0"):
         monkeypatch.setenv("SSFM_MEDIUM_ADAPT", one)
