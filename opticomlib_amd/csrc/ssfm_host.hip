@@ -741,6 +741,18 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipStreamSynchronize(stream));
         return SSFM_OK;
     }
+    // the XCDs a launch's workgroups are dealt to (probe launch, once per device), and this plan's among them: plans take turns
+    int pick_xcc() {
+        if (medium_xcc >= 0) return SSFM_OK;
+        static std::atomic<int> next_plan{0};
+        const unsigned mask = xcc_mask(device);
+        if (mask == 0u) return fail(SSFM_ERR_HIP, "the XCD probe launch failed");
+        medium_xccs = __builtin_popcount(mask);
+        int k = next_plan.fetch_add(1) % medium_xccs;
+        for (int b = 0; b < 32; ++b)
+            if ((mask >> b) & 1u) { if (k == 0) { medium_xcc = b; break; } --k; }
+        return SSFM_OK;
+    }
     // the whole schedule in one launch (k_medium); `distinct` holds at most kMaxTables step sizes
     int run_medium(T gamma, double gamma_d, const T* h, int64_t nsteps, const std::vector<T>& distinct, bool phase) {
         if constexpr (sizeof(T) != 4) { (void)gamma; (void)gamma_d; (void)h; (void)nsteps; (void)distinct; (void)phase; return fail(SSFM_ERR_STATE, "the medium engine is complex64 only"); }
@@ -777,16 +789,7 @@ template <typename T> struct PlanT : PlanBase {
         a.F = F; a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.tw2 = tw2;
         a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb;
         a.bar = medium_st; a.error = reinterpret_cast<unsigned*>(medium_st + kBarShards + kBarWords); a.patience = medium_patience;
-        if (medium_xcc < 0) {
-            // the XCDs a launch is dealt to, and this plan's among them
-            static std::atomic<int> next_plan{0};
-            const unsigned mask = xcc_mask(device);
-            if (mask == 0u) return fail(SSFM_ERR_HIP, "the XCD probe launch failed");
-            medium_xccs = __builtin_popcount(mask);
-            int k = next_plan.fetch_add(1) % medium_xccs;
-            for (int b = 0; b < 32; ++b)
-                if ((mask >> b) & 1u) { if (k == 0) { medium_xcc = b; break; } --k; }
-        }
+        if (int rc = pick_xcc()) return rc;
         a.xcc = (unsigned)medium_xcc;
         a.nblk = (unsigned)((N2 / cols_per_tile<T>()) * batch);
         a.gamma = gamma; a.inv_n = inv_n(); a.nsteps = (int)nsteps; a.rows = batch; a.Qf = N2 / Ef;
@@ -1291,15 +1294,7 @@ template <typename T> struct PlanT : PlanBase {
                         *medium_err_host = 0u;
                     }
                     HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + kBarWords + 2), stream));
-                    if (medium_xcc < 0) {
-                        static std::atomic<int> next_plan_a{0};
-                        const unsigned mask = xcc_mask(device);
-                        if (mask == 0u) return fail(SSFM_ERR_HIP, "the XCD probe launch failed");
-                        medium_xccs = __builtin_popcount(mask);
-                        int k = next_plan_a.fetch_add(1) % medium_xccs;
-                        for (int b = 0; b < 32; ++b)
-                            if ((mask >> b) & 1u) { if (k == 0) { medium_xcc = b; break; } --k; }
-                    }
+                    if (int rc = pick_xcc()) return rc;
                     MediumAdaptArgs<T> ma;
                     ma.F = F; ma.Y = Y; ma.P = P; ma.twA = twA; ma.twB = twB; ma.tw1 = tw1; ma.tw2 = tw2; ma.D = dperm; ma.st = st; ma.zlog = zlog;
                     ma.bar = medium_st; ma.error = reinterpret_cast<unsigned*>(medium_st + kBarShards + kBarWords); ma.patience = medium_patience;
