@@ -1076,7 +1076,9 @@ def test_sosfiltfilt_both_workgroup_shapes(waves, monkeypatch):
     (sos_filter.hip `sos_waves`); here both shapes run every size, across their group boundaries (64 W chunks of 12)."""
     from scipy import signal as sg
     monkeypatch.setenv("SOS_WAVES_FORCE", waves)
-    for order, n in ((4, 1530), (4, 1537), (4, 3060), (4, 3073), (3, 12 * 128 * 7 + 5), (8, 12 * 256 * 3 - 31), (4, (1 << 18) + 3)):
+    # (... and of 18: with four wavefronts a call that fits the one-launch form takes the long chunk; 18 * 64 = 1152 per wavefront, 4608 per group)
+    for order, n in ((4, 1530), (4, 1537), (4, 3060), (4, 3073), (3, 12 * 128 * 7 + 5), (8, 12 * 256 * 3 - 31), (4, (1 << 18) + 3),
+                     (4, 4608 - 30), (4, 4608 - 29), (4, 2 * 4608 - 30 - 18), (2, 1152 * 3 - 18), (5, 18 * 256 * 5 + 1), (4, 18 * 64 * 9 - 30 + 17)):
         sos = sg.bessel(order, 0.07 if n > 4096 else 0.2, "low", norm="mag", output="sos")
         zi = sg.sosfilt_zi(sos)
         rng = np.random.default_rng(n)
