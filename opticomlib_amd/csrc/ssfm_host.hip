@@ -878,7 +878,7 @@ template <typename T> struct PlanT : PlanBase {
         (void)lane;
         a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0; a.lane = 0; a.lanes2 = 0;
-        a.s_in = nullptr; a.s_out = nullptr;
+        a.s_in = nullptr; a.s_out = nullptr; a.pkeep = nullptr;
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {

@@ -237,6 +237,8 @@ template <typename T> struct TimeArgs {
     int lanes2;               // adaptive, two lanes: END counts its arrivals, a deriving BEGIN waits for the other lane's (AdaptState::arrived)
     const StepState<T>* s_in; // k_medium_adapt (PK): TM_MID_A takes the state of the step it finishes from here (LDS) instead of st->cur[],
     StepState<T>* s_out;      // ... and leaves the next step's here (untouched if the hand-over ran out of patience)
+    T* pkeep;                 // PK: the thread's E values of |A|^2 stay in registers from one column pass to the next (the same workgroup has the tile
+                              // every time) instead of going through the P buffer
     SSFM_TRACE_ARGS
 };
 
@@ -562,6 +564,9 @@ __host__ __device__ constexpr int min_waves(int threads, int tsize, int e = 16) 
 #ifndef SSFM_MEDIUM_LOCAL
 #define SSFM_MEDIUM_LOCAL 1
 #endif
+#ifndef SSFM_MEDIUM_PKEEP
+#define SSFM_MEDIUM_PKEEP 1
+#endif
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4_t load16_sc1(__amdgpu_buffer_rsrc_t rsrc, int off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SSFM_MEDIUM_LOCAL ? 3 /* sc0 nt */ : 16 /* sc1 */);
@@ -691,6 +696,11 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     // other lane's kernel queues behind (launch timeline: the last workgroup of a launch ends 2-3 us after the first).  Six
     // interleaved rounds, 2^20 x 2: 16.97 against 17.52 us per step (profiles/r03_ablation_and_knobs.txt)
     auto load_pold = [&]() {
+        if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
+#pragma unroll
+            for (int t = 0; t < E; ++t) pold[t] = a.pkeep[t];
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
             p4_t q;
@@ -943,6 +953,12 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         pmax = p > pmax ? p : pmax;
     }
     }
+    if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
+        if (FWD) {
+#pragma unroll
+            for (int t = 0; t < E; ++t) a.pkeep[t] = pnew[t];
+        }
+    } else
     if (FWD && !SSFM_ABL_NO_P) {
 #pragma unroll
         for (int g = 0; g < E / 4; ++g) {
@@ -1373,9 +1389,11 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
     const unsigned bid = blockIdx.x, nblk = gridDim.x;
 #endif
     unsigned long long epoch = 0;
+    T pk[E];
     TimeArgs<T> ta;
     ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = nullptr;
     ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
+    ta.s_in = nullptr; ta.s_out = nullptr; ta.pkeep = pk;
     FreqArgs<T> fa;
     fa.F = a.Y; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = a.inv_n; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0;
     const T half = (T)0.5;
@@ -1446,7 +1464,8 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium_adapt(const MediumAdaptA
     TimeArgs<T> ta;
     ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = a.zlog;
     ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
-    ta.s_in = &s_state[0]; ta.s_out = &s_state[1];
+    T pk[E];
+    ta.s_in = &s_state[0]; ta.s_out = &s_state[1]; ta.pkeep = pk;
     FreqArgs<T> fa;
     fa.F = a.Y; fa.tab = a.D; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = a.inv_n; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0; fa.amp = (T)0;
     const T half = (T)0.5;
