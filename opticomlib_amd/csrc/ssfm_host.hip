@@ -286,10 +286,13 @@ template <typename T> struct PlanT : PlanBase {
     // host copy of the error word, and what a repeat of the run on the two-kernel engine needs
     bool medium_ok = true;     // env SSFM_MEDIUM=0, or a run whose barrier once ran out of patience, clears it
     unsigned long long* medium_st = nullptr;       // kBarShards counters, kBarWords flag words, the error word, the ticket counter
-    unsigned* medium_err_host = nullptr;
+    unsigned* medium_err_host = nullptr;        // two words: a dual-polarisation plan of long rows runs its rows as two launches (run_medium)
+    hipStream_t medium_stream2 = nullptr;       // ... the second one here, on another XCD
+    hipEvent_t medium_ev2 = nullptr;
     bool medium_pending = false;
     bool fused_lanes_ok = false;   // env SSFM_ADAPT_FUSED_LANES=1: the large fused adaptive form on two streams (measured: 28.9-29.7 against 29.6-31.1 us per step at
                                    // 2^20 x 2 -- the lanes meet in every MID_A, so little overlaps -- for four launches per step instead of two: opt-in)
+    bool medium_split_ok = true;   // env SSFM_MEDIUM_SPLIT=0: a dual-polarisation plan's rows stay in one launch
     bool medium_adapt_ok = true;   // env SSFM_MEDIUM_ADAPT=0, or a run whose workgroups once did not all get to run, clears it
     long long medium_max_samples = 1ll << 17;      // samples in all (rows x n) up to which the one-XCD engine is used (measured: a gain up to there; env SSFM_MEDIUM_MAX_LOG2)
     int medium_xcc = -1, medium_xccs = 8;          // the XCD this plan's single-launch runs use, of so many
@@ -516,6 +519,8 @@ template <typename T> struct PlanT : PlanBase {
         (void)hipFree(fused_backup);
         (void)hipFree(medium_st);
         if (medium_err_host) (void)hipHostFree(medium_err_host);
+        if (medium_ev2) (void)hipEventDestroy(medium_ev2);
+        if (medium_stream2) (void)hipStreamDestroy(medium_stream2);
         (void)hipFree(d_hs);
         for (int g = 1; g < kMaxLanes; ++g) {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
@@ -633,6 +638,7 @@ template <typename T> struct PlanT : PlanBase {
         if (const char* e = std::getenv("SSFM_MEDIUM")) medium_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_MEDIUM_MAX_LOG2")) medium_max_samples = 1ll << std::atoi(e);
         if (const char* e = std::getenv("SSFM_MEDIUM_ADAPT")) medium_adapt_ok = std::atoi(e) != 0;
+        if (const char* e = std::getenv("SSFM_MEDIUM_SPLIT")) medium_split_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_ADAPT_FUSED_LANES")) fused_lanes_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) medium_patience = std::atoll(e);
         if (const char* e = std::getenv("SSFM_ADAPT_LANES")) lanes2_ok = std::atoi(e) >= 2;
@@ -732,8 +738,8 @@ template <typename T> struct PlanT : PlanBase {
     int finish_medium() {
         medium_pending = false;
         HIP_TRY(hipStreamSynchronize(stream));
-        if (*medium_err_host == 0u) return SSFM_OK;
-        *medium_err_host = 0u;
+        if (medium_err_host[0] == 0u && medium_err_host[1] == 0u) return SSFM_OK;
+        medium_err_host[0] = medium_err_host[1] = 0u;
         medium_ok = false;
         HIP_TRY(hipMemcpyAsync(F, fused_backup, sizeof(cx<T>) * n * batch, hipMemcpyDeviceToDevice, stream));
         const std::vector<T> sched = medium_sched;
@@ -753,6 +759,8 @@ template <typename T> struct PlanT : PlanBase {
             if ((mask >> b) & 1u) { if (k == 0) { medium_xcc = b; break; } --k; }
         return SSFM_OK;
     }
+    // fixed-step runs of a dual-polarisation plan of long rows: one launch per row (see run_medium)
+    bool medium_rows_split() const { return SSFM_MEDIUM_LOCAL && medium_split_ok && batch == 2 && n >= (1ll << 16); }
     // the whole schedule in one launch (k_medium); `distinct` holds at most kMaxTables step sizes
     int run_medium(T gamma, double gamma_d, const T* h, int64_t nsteps, const std::vector<T>& distinct, bool phase) {
         if constexpr (sizeof(T) != 4) { (void)gamma; (void)gamma_d; (void)h; (void)nsteps; (void)distinct; (void)phase; return fail(SSFM_ERR_STATE, "the medium engine is complex64 only"); }
@@ -781,21 +789,50 @@ template <typename T> struct PlanT : PlanBase {
         if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
         HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));          // for a repeat on the two-kernel engine
         if (!medium_st) {
-            HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * (kBarShards + kBarWords + 2)));
-            HIP_TRY(hipHostMalloc(&medium_err_host, sizeof(unsigned)));
-            *medium_err_host = 0u;
+            HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * 2 * (kBarShards + kBarWords + 2)));
+            HIP_TRY(hipHostMalloc(&medium_err_host, 2 * sizeof(unsigned)));
+            medium_err_host[0] = medium_err_host[1] = 0u;
         }
-        HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + kBarWords + 2), stream));
+        constexpr size_t kSet = kBarShards + kBarWords + 2;
+        HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * 2 * kSet, stream));
         a.F = F; a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.tw2 = tw2;
         a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb;
         a.bar = medium_st; a.error = reinterpret_cast<unsigned*>(medium_st + kBarShards + kBarWords); a.patience = medium_patience;
         if (int rc = pick_xcc()) return rc;
         a.xcc = (unsigned)medium_xcc;
-        a.nblk = (unsigned)((N2 / cols_per_tile<T>()) * batch);
-        a.gamma = gamma; a.inv_n = inv_n(); a.nsteps = (int)nsteps; a.rows = batch; a.Qf = N2 / Ef;
+        a.gamma = gamma; a.inv_n = inv_n(); a.nsteps = (int)nsteps; a.Qf = N2 / Ef;
+        // The rows of a fixed-step run share nothing: a dual-polarisation plan of long rows (2^16 samples and more) runs them as TWO launches, each
+        // on an XCD and a stream of its own (2^16 x 2: 8.3 against 9.25 us per step in one launch; 2^17 x 2 only fits this way)
+        const bool two = medium_rows_split();
+        a.rows = two ? 1 : batch;
+        a.nblk = (unsigned)((N2 / cols_per_tile<T>()) * a.rows);
+        if (two) {
+            if (!medium_stream2) {
+                HIP_TRY(hipStreamCreateWithFlags(&medium_stream2, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&medium_ev2, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(fork_ev, stream));                  // (behind the uploads and the backup copy, ahead of the first launch)
+            HIP_TRY(hipStreamWaitEvent(medium_stream2, fork_ev, 0));
+        }
         ++last_launches;
         HIP_TRY(launch_medium(N1, N2, phase, (int)a.nblk, medium_xccs, stream, a));
         HIP_TRY(hipMemcpyAsync(medium_err_host, a.error, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        medium_err_host[1] = 0u;
+        if (two) {
+            MediumArgs<T> b = a;
+            b.F = F + n; b.Y = Y + n; b.P = P + n;
+            b.bar = medium_st + kSet; b.error = reinterpret_cast<unsigned*>(medium_st + kSet + kBarShards + kBarWords);
+            // the next XCD of the device's set
+            const unsigned mask = xcc_mask(device);
+            unsigned nx = (unsigned)medium_xcc;
+            do { nx = (nx + 1u) & 31u; } while (!((mask >> nx) & 1u));
+            b.xcc = medium_xccs > 1 ? nx : (unsigned)medium_xcc;
+            ++last_launches;
+            HIP_TRY(launch_medium(N1, N2, phase, (int)b.nblk, medium_xccs, medium_stream2, b));
+            HIP_TRY(hipMemcpyAsync(medium_err_host + 1, b.error, sizeof(unsigned), hipMemcpyDeviceToHost, medium_stream2));
+            HIP_TRY(hipEventRecord(medium_ev2, medium_stream2));
+            HIP_TRY(hipStreamWaitEvent(stream, medium_ev2, 0));
+        }
         medium_sched.assign(h, h + nsteps);
         medium_gamma = gamma_d;
         medium_pending = true;
@@ -957,10 +994,11 @@ template <typename T> struct PlanT : PlanBase {
         const bool use_phase = use_tables && phase_tables && sizeof(T) == 4 && u16 && op_flat_re;
         // plans of 2^12 ... 2^17 samples in the unit layout: the whole schedule in one launch on one XCD (ssfm_kernels.hpp k_medium).  Measured against the
         // one-workgroup-per-row kernel of the small plans (k_small): 5.4 against 6.4 us per step at 8192 samples, 5.6 against 3.5 at 4096 -- so from 8192 on
-        const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+        const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * (medium_rows_split() ? 1 : batch);
+        const long long med_samples = medium_rows_split() ? n : n * batch;
         const bool med_elig = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !profiling
                                && snapshots == nullptr && graph_policy == 0 && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
-                               && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || n * batch <= medium_max_samples) && (use_phase || !phase_tables || !op_flat_re);
+                               && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || med_samples <= medium_max_samples) && (use_phase || !phase_tables || !op_flat_re);
         const bool go_small = small_sched && snapshots == nullptr && !(med_elig && SSFM_MEDIUM_LOCAL && n >= 8192);
         const bool go_medium = med_elig && !go_small;
         if (use_tables && !go_small && !go_medium)
@@ -1289,9 +1327,9 @@ template <typename T> struct PlanT : PlanBase {
                     hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 0, 0, 0);
                     last_launches += 2;
                     if (!medium_st) {
-                        HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * (kBarShards + kBarWords + 2)));
-                        HIP_TRY(hipHostMalloc(&medium_err_host, sizeof(unsigned)));
-                        *medium_err_host = 0u;
+                        HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * 2 * (kBarShards + kBarWords + 2)));
+                        HIP_TRY(hipHostMalloc(&medium_err_host, 2 * sizeof(unsigned)));
+                        medium_err_host[0] = medium_err_host[1] = 0u;
                     }
                     HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + kBarWords + 2), stream));
                     if (int rc = pick_xcc()) return rc;
