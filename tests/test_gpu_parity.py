@@ -634,6 +634,7 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
     monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)
     monkeypatch.delenv("SSFM_E", raising=False)
+    monkeypatch.delenv("SSFM_MEDIUM_SPLIT", raising=False)
     monkeypatch.setenv("SSFM_GRAPH", "0")
     got = {}
     for med in ("1", "0"):
