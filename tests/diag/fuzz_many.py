@@ -15,8 +15,8 @@ gv(**workloads.BENCH_GV)
 worst = []
 bad = 0
 for i in range(count):
-    pow2 = rng.integers(0, 3) > 0
-    n = 1 << int(rng.integers(8, 15)) if pow2 else int(rng.integers(2, 20000))
+    pow2 = rng.integers(0, 3) > 0 or os.environ.get("FUZZ_POW2_ONLY") == "1"
+    n = 1 << int(rng.integers(int(os.environ.get("FUZZ_MINLOG2", "8")), int(os.environ.get("FUZZ_MAXLOG2", "14")) + 1)) if pow2 else int(rng.integers(2, 20000))
     npol = int(rng.integers(1, 3))
     sign = -1.0 if rng.integers(0, 4) == 0 else 1.0
     fib = dict(alpha=sign * float(rng.uniform(0, 0.5)), beta_2=sign * float(rng.uniform(-30, 30)),
