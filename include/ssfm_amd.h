@@ -278,6 +278,15 @@ int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, vo
 int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode);
 int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh,
                     void* maxbits_dev);
+/* A whole FIBER / DBP run on a field of ANY length through the three kernels above and ssfm_apply_table, driven from C (the per-kernel entry
+ * points cost a host call each, and an adaptive run driven from the host waits for every step's maximum): A (batch x n complex128, DEVICE) is
+ * advanced in place, P is scratch (batch x n float64, DEVICE), chirp / Dt as for ssfm_chirp_pre / _mid; slots 0 and 1 of the plan hold the
+ * chirp kernels.  hs != NULL: fixed step, `nsteps` step sizes (HOST).  hs == NULL: the adaptive rule of devices.py:1172-1196,
+ * h = phi_max / (|gamma| max|A|^2) clamped to the rest of `length`, evaluated on the device in float32 (f32 != 0: the reference's arithmetic
+ * in complex64 mode) or float64; z_out (HOST, max_steps + 1 doubles, nullable) receives z after every step, *steps_out the steps taken.
+ * Synchronous. */
+int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, void* P, const void* chirp, const void* Dt, int64_t n, double gamma,
+                         const double* hs, int64_t nsteps, double length, double phi_max, int f32, int64_t max_steps, double* z_out, int64_t* steps_out);
 
 /* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);

@@ -71,6 +71,7 @@ SYMBOLS = {
     "ssfm_chirp_pre": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D]),
     "ssfm_chirp_mid": (_I, [_VP, _I64, _I, _VP, _I64, _D, _I]),
     "ssfm_chirp_post": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D, _VP]),
+    "ssfm_chirp_propagate": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
@@ -652,6 +653,22 @@ class Plan:
     def chirp_post(self, A: "DeviceArray", P, chirp: "DeviceArray", gamma: float, hh: float, maxbits=None):
         _check(load().ssfm_chirp_post(self._h, self.n, self.batch, _VP(A.ptr), None if P is None else _VP(P.ptr), _VP(chirp.ptr), A.shape[-1],
                                       float(gamma), float(hh), None if maxbits is None else _VP(maxbits.ptr)), "ssfm_chirp_post")
+
+    def chirp_propagate(self, A: "DeviceArray", P: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, hs=None, *, length: float = 0.0,
+                        phi_max: float = 0.0, f32: bool = True, max_steps: int = 1 << 20):
+        """A whole chirp-z run from C (ssfm_chirp_propagate).  ``hs``: float64 host array of step sizes (fixed step) or None (adaptive);
+        returns (steps, z) with z = positions after every step (adaptive) or None (fixed)."""
+        steps = _I64(0)
+        if hs is not None:
+            hs = np.ascontiguousarray(hs, dtype=np.float64)
+            _check(load().ssfm_chirp_propagate(self._h, self.n, self.batch, _VP(A.ptr), _VP(P.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma),
+                                               hs.ctypes.data_as(C.POINTER(_D)), hs.size, 0.0, 0.0, 1 if f32 else 0, 1, None, C.byref(steps)), "ssfm_chirp_propagate")
+            return int(steps.value), None
+        z = np.zeros(int(max_steps) + 1, dtype=np.float64)
+        _check(load().ssfm_chirp_propagate(self._h, self.n, self.batch, _VP(A.ptr), _VP(P.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma),
+                                           None, 0, float(length), float(phi_max), 1 if f32 else 0, int(max_steps), z.ctypes.data_as(C.POINTER(_D)), C.byref(steps)),
+               "ssfm_chirp_propagate")
+        return int(steps.value), z[: int(steps.value) + 1]
 
     def debug_fft(self) -> np.ndarray:
         out = host_empty((self.batch, self.n), self.cdtype)

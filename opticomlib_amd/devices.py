@@ -414,6 +414,29 @@ def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, g
     L = rt(length)
     zs, snaps = [rt(0)], ([A.copy()] if return_steps else None)
     steps = 0
+    if not return_steps and bar is None and os.environ.get("SSFM_CHIRP_LOOP", "c") != "python":
+        # the whole run from C (ssfm_chirp_propagate): no host call per kernel, the adaptive step rule on the device
+        if h is None:
+            b2, b3 = rt(beta_2), rt(beta_3)
+            if bool((b2 == 0 and b3 == 0) or rt(gamma) == 0):                  # one step of the whole length (reference devices.py:1163-1170)
+                eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(L)]))
+                zs = [rt(0), L]
+            else:
+                if not float(L) > 0:
+                    return A, zs, snaps
+                max_steps, z0 = 1 << 17, rt(0)
+                while True:                                   # (one call unless a run needs more than 131072 steps: then it goes on from where it is)
+                    steps, z = eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, None, length=float(rt(L - z0)), phi_max=float(rt(phi_max)),
+                                                        f32=(prec == _lib.C64), max_steps=max_steps)
+                    zs += [rt(z0 + rt(v)) for v in z[1:]]
+                    if steps < max_steps or not (zs[-1] < L):
+                        break
+                    z0 = zs[-1]
+        else:
+            hs, z_all = step_schedule(length, h, prec)
+            eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.asarray(hs, dtype=np.float64))
+            zs = list(z_all)
+        return A, zs, snaps
     if h is None:
         b2, b3 = rt(beta_2), rt(beta_3)
         single = bool((b2 == 0 and b3 == 0) or rt(gamma) == 0)
