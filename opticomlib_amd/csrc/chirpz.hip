@@ -17,6 +17,9 @@
 // (batch x N, natural order) and the plan's field buffer (batch x M); nothing synchronises with the host.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ssfm_amd.h"
@@ -223,10 +226,14 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     };
     if (hs) {
         if (nsteps < 0) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: nsteps=%lld", (long long)nsteps);
+        const auto t0 = std::chrono::steady_clock::now();
         for (int64_t s = 0; s < nsteps; ++s)
             if (int rc = step(hs[s], nullptr, nullptr)) return rc;
         HIP_TRY(hipGetLastError());
+        const auto t1 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(t.stream));
+        if (std::getenv("SSFM_CHIRP_DEBUG")) std::fprintf(stderr, "chirp fixed: %lld steps, enqueue %.1f us per step, total %.1f us per step\n", (long long)nsteps,
+            std::chrono::duration<double, std::micro>(t1 - t0).count() / nsteps, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nsteps);
         if (steps_out) *steps_out = nsteps;
         return SSFM_OK;
     }
