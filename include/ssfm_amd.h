@@ -254,6 +254,10 @@ int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, si
  * `plan_n` / `batch` are the plan's own length and batch; all asynchronous on the plan's stream. */
 int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot);
 int ssfm_apply_table(ssfm_plan* plan, int slot);
+/* x <- ifft(fft(ifft(fft(x) * H0) * mul) * H1) on the plan's field: ssfm_apply_table(plan, 0), a pointwise product with the time-domain table `mul`
+ * (plan length entries, DEVICE, the plan's precision, the same for every row), ssfm_apply_table(plan, 1) -- with the middle (inverse pass, product,
+ * forward pass) in one launch: five launches instead of seven.  Plans in the plain layout (complex128).  Asynchronous. */
+int ssfm_apply_tables_mul(ssfm_plan* plan, const void* mul_dev);
 /* The chirp c_m = exp(-i pi m^2 / n) of that identity, generated on the device with its phase reduced exactly in
  * integers: ssfm_device_chirp writes c (conj = 0) or conj(c) (1), n complex128, into DEVICE memory (synchronous);
  * ssfm_load_chirp_kernel writes the convolution kernel v[m] = v[plan_n - m] = conj(c_m) (which = 0, forward transform) or

@@ -63,6 +63,7 @@ SYMBOLS = {
     "ssfm_device_mem_info": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ssfm_transfer_table": (_I, [_VP, _VP, _I]),
     "ssfm_apply_table": (_I, [_VP, _I]),
+    "ssfm_apply_tables_mul": (_I, [_VP, _VP]),
     "ssfm_load_padded": (_I, [_VP, _I64, _VP, _I, _I64]),
     "ssfm_load_symbols": (_I, [_VP, _I64, _VP, _I64, _I]),
     "ssfm_laser": (_I, [_I, _VP, _I64, _D, _VP, _VP, _I, _D, _D, _D]),

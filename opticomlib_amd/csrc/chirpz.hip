@@ -166,6 +166,21 @@ extern "C" int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void*
 
 // ------------------------------------------------------------------------------- a whole run from C
 namespace {
+// tab[m] = exp(D~[m] h) for m < n, 0 up to M: what k_chirp_mid multiplies with, as a table for the fused middle pass (ssfm_apply_tables_mul)
+__global__ __launch_bounds__(256) void k_chirp_mktab(const double2* __restrict__ D, double2* __restrict__ tab, long long n, long long M, double h, const ChirpCtl* __restrict__ ctl) {
+    if (ctl) { if (ctl->done) return; h = ctl->h; }
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
+        double2 e = make_double2(0.0, 0.0);
+        if (m < n) {
+            const double2 d = D[m];
+            double sn, cs;
+            sincos(d.y * h, &sn, &cs);
+            const double g = exp(d.x * h);
+            e = make_double2(g * cs, g * sn);
+        }
+        tab[m] = e;
+    }
+}
 // max |A|^2 of the input (the first step size)
 __global__ __launch_bounds__(256) void k_chirp_absmax(const double2* __restrict__ A, long long total, ChirpCtl* __restrict__ ctl) {
     double pmax = 0.0;
@@ -215,11 +230,32 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     if (!A || !P || !chirp || !Dt) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: NULL argument");
     const unsigned gM = blocks_for(t.M * batch), gN = blocks_for((long long)n * batch);
     const double scale = 1.0 / (double)n;
+    // The middle of a step -- inverse pass of the first convolution, product with exp(D~ h), forward pass of the second -- as ONE column launch
+    // (ssfm_apply_tables_mul) with the factors from a table: seven launches per fixed step instead of nine (the table of a repeated step size is
+    // kept), nine instead of ten per adaptive step.  SSFM_CHIRP_FUSED=0: the three-launch middle.
+    const char* fe = std::getenv("SSFM_CHIRP_FUSED");
+    bool fused_mid = !(fe && std::atoi(fe) == 0);
+    double2* mtab = nullptr;
+    double mtab_h = 0.0;
+    bool mtab_set = false;
+    struct Free { double2*& p; ~Free() { if (p) (void)hipFree(p); } } free_mtab{mtab};
+    if (fused_mid) HIP_TRY(hipMalloc(&mtab, sizeof(double2) * (size_t)t.M));
     auto step = [&](double h, const ChirpCtl* ctl, unsigned long long* mb) -> int {
         hipLaunchKernelGGL(k_chirp_pre, dim3(gM), dim3(256), 0, t.stream, (const double2*)A, (double*)P, (const double2*)chirp, t.F, (long long)n, t.M, batch, gamma, 0.5 * h, ctl);
+        if (fused_mid) {
+            if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
+                hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
+                mtab_h = h; mtab_set = true;
+            }
+            const int rc = ssfm_apply_tables_mul(plan, mtab);
+            if (rc == SSFM_ERR_UNSUPPORTED) fused_mid = false;          // (a plan in the 16-byte-unit layout: nothing was launched; the three-launch middle from here on)
+            else if (rc) return rc;
+        }
+        if (!fused_mid) {
         if (int rc = ssfm_apply_table(plan, 0)) return rc;
         hipLaunchKernelGGL(k_chirp_mid, dim3(gM), dim3(256), 0, t.stream, (const double2*)Dt, t.F, (long long)n, t.M, batch, h, 0, ctl);
         if (int rc = ssfm_apply_table(plan, 1)) return rc;
+        }
         hipLaunchKernelGGL(k_chirp_post, dim3(gN), dim3(256), 0, t.stream, (double2*)A, (const double*)P, (const double2*)chirp, (const double2*)t.F, (long long)n, t.M, batch,
                            gamma, 0.5 * h, scale, mb, ctl);
         return SSFM_OK;

@@ -915,7 +915,7 @@ template <typename T> struct PlanT : PlanBase {
         (void)lane;
         a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
         a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0; a.lane = 0; a.lanes2 = 0;
-        a.s_in = nullptr; a.s_out = nullptr; a.pkeep = nullptr;
+        a.s_in = nullptr; a.s_out = nullptr; a.pkeep = nullptr; a.mul = nullptr;
         return a;
     }
     FreqArgs<T> fargs(const cx<T>* tab, T h, const AdaptState<T>* s, int row0 = 0, int lane = 0) {
@@ -1599,6 +1599,24 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipStreamSynchronize(stream));                  // H_host may be released by the caller
         return SSFM_OK;
     }
+    // x <- ifft(fft(ifft(fft(x) * H0) * mul) * H1) with the tables of slots 0 and 1 and a time-domain table `mul` (n entries per row, DEVICE, the plan's
+    // precision): the two applications of apply_table around a pointwise product, the middle of it -- inverse pass, product, forward pass -- in ONE column
+    // launch (k_time<TM_MID> with TimeArgs::mul).  Five launches instead of seven.  Plain layout only (complex128 plans; complex64 plans of the plain layout).
+    int apply_tables_mul(const void* mul_dev) {
+        if (!xfer_tab[0] || !xfer_tab[1]) return fail(SSFM_ERR_STATE, "ssfm_apply_tables_mul: slots 0 and 1 must hold tables");
+        if (u16) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_apply_tables_mul: not for plans in the 16-byte-unit layout");
+        if (!mul_dev) return fail(SSFM_ERR_INVALID, "ssfm_apply_tables_mul: NULL table");
+        if (int rc = use_device()) return rc;
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[0], 0, nullptr), Ef)));
+        TimeArgs<T> tm = targs(0, 0, 0, nullptr);
+        tm.mul = static_cast<const cx<T>*>(mul_dev);
+        HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, tm, E)));
+        HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[1], 0, nullptr), Ef)));
+        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        last_launches += 5;
+        return SSFM_OK;
+    }
     // slot <- fft(field): the field itself becomes a resident transfer function (row 0; the field is consumed)
     int table_from_field(int slot) {
         if (slot < 0 || slot > 1) return fail(SSFM_ERR_INVALID, "ssfm_table_from_field: slot %d", slot);
@@ -1808,6 +1826,7 @@ int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot) {
     WITH_PLAN(plan, P_->transfer_table(H_host, slot));
 }
 int ssfm_apply_table(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->apply_table(slot)); }
+int ssfm_apply_tables_mul(ssfm_plan* plan, const void* mul_dev) { WITH_PLAN(plan, P_->apply_tables_mul(mul_dev)); }
 int ssfm_table_from_field(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->table_from_field(slot)); }
 int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }
 

@@ -237,6 +237,9 @@ template <typename T> struct TimeArgs {
     int lanes2;               // adaptive, two lanes: END counts its arrivals, a deriving BEGIN waits for the other lane's (AdaptState::arrived)
     const StepState<T>* s_in; // k_medium_adapt (PK): TM_MID_A takes the state of the step it finishes from here (LDS) instead of st->cur[],
     StepState<T>* s_out;      // ... and leaves the next step's here (untouched if the hand-over ran out of patience)
+    const cx<T>* mul;         // TM_MID of the plain layout: the time-domain samples are multiplied by mul[position in the row] between the inverse and the
+                              // forward pass (chirp-z: exp(D~ h) between Bluestein's two convolutions -- one column launch instead of END, a
+                              // pointwise kernel and BEGIN); nullptr otherwise
     T* pkeep;                 // PK: the thread's E values of |A|^2 stay in registers from one column pass to the next (the same workgroup has the tile
                               // every time) instead of going through the P buffer
     SSFM_TRACE_ARGS
@@ -979,6 +982,12 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t].x += phi[t];
     }
+    if constexpr (MODE == TM_MID && !U16) {
+        if (a.mul != nullptr) {
+#pragma unroll
+            for (int t = 0; t < E; ++t) v[t] = cmul(v[t], a.mul[off + t * stride]);
+        }
+    }
     if constexpr (MODE == TM_MID_A) {
         if (!fwd_active) {
             // the run ends with this step: time-order field, as k_time<TM_END> leaves it
@@ -1393,7 +1402,7 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
     TimeArgs<T> ta;
     ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = nullptr;
     ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
-    ta.s_in = nullptr; ta.s_out = nullptr; ta.pkeep = pk;
+    ta.s_in = nullptr; ta.s_out = nullptr; ta.pkeep = pk; ta.mul = nullptr;
     FreqArgs<T> fa;
     fa.F = a.Y; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = a.inv_n; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0;
     const T half = (T)0.5;
@@ -1465,7 +1474,7 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium_adapt(const MediumAdaptA
     ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = a.zlog;
     ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
     T pk[E];
-    ta.s_in = &s_state[0]; ta.s_out = &s_state[1]; ta.pkeep = pk;
+    ta.s_in = &s_state[0]; ta.s_out = &s_state[1]; ta.pkeep = pk; ta.mul = nullptr;
     FreqArgs<T> fa;
     fa.F = a.Y; fa.tab = a.D; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = a.inv_n; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0; fa.amp = (T)0;
     const T half = (T)0.5;
