@@ -258,6 +258,29 @@ int ssfm_apply_table(ssfm_plan* plan, int slot);
  * (plan length entries, DEVICE, the plan's precision, the same for every row), ssfm_apply_table(plan, 1) -- with the middle (inverse pass, product,
  * forward pass) in one launch: five launches instead of seven.  Plans in the plain layout (complex128).  Asynchronous. */
 int ssfm_apply_tables_mul(ssfm_plan* plan, const void* mul_dev);
+/* One whole chirp-z step in FIVE launches: ssfm_apply_tables_mul with ssfm_chirp_pre folded into its first column launch and ssfm_chirp_post into
+ * its last (the caller's field A, `n` complex128 per row, is read and written directly; the plan's field buffer is not touched).
+ *   A <- [ifft_n(fft_n(A exp(i gamma |A|^2 hh)) * D)] exp(i gamma |A|^2 hh)   with D = the time-domain table `mul_dev` between the two convolutions
+ * P (n float64 per row) receives |A|^2 of the step's start.  h_dev (nullable, DEVICE double): hh = *h_dev / 2 instead of `hh`;  done_dev (nullable,
+ * DEVICE int): the first and the last launch do nothing when it is set;  maxbits_dev (nullable, DEVICE 8 bytes): atomic maximum of the bit pattern
+ * of |A|^2 after the step.  complex128 plans (SSFM_ERR_UNSUPPORTED otherwise, nothing launched).  Asynchronous on the plan's stream. */
+typedef struct ssfm_chirp_io {
+    void* A;
+    void* P;
+    const void* chirp;
+    int64_t n;
+    double gamma, hh;
+    const void* h_dev;
+    const void* done_dev;
+    void* maxbits_dev;
+} ssfm_chirp_io;
+int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* io);
+/* A whole FIXED-step run of a field of n <= plan length / 2 samples per row (DEVICE, complex128, natural order, advanced in place) in ONE launch: a
+ * workgroup per row keeps the row in registers and does the four line transforms of every step itself (k_small_chirp, csrc/ssfm_kernels.hpp).
+ * chirp (n complex128, DEVICE) as ssfm_device_chirp writes it, Dt = D~ (n complex128, DEVICE, natural frequency order), hs: nsteps step sizes [km]
+ * (HOST).  Complex128 plans of 256 ... 4096 samples (SSFM_ERR_UNSUPPORTED otherwise, nothing launched).  Asynchronous on the plan's stream after
+ * the schedule has been copied. */
+int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
 /* The chirp c_m = exp(-i pi m^2 / n) of that identity, generated on the device with its phase reduced exactly in
  * integers: ssfm_device_chirp writes c (conj = 0) or conj(c) (1), n complex128, into DEVICE memory (synchronous);
  * ssfm_load_chirp_kernel writes the convolution kernel v[m] = v[plan_n - m] = conj(c_m) (which = 0, forward transform) or

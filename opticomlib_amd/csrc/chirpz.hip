@@ -240,7 +240,23 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     bool mtab_set = false;
     struct Free { double2*& p; ~Free() { if (p) (void)hipFree(p); } } free_mtab{mtab};
     if (fused_mid) HIP_TRY(hipMalloc(&mtab, sizeof(double2) * (size_t)t.M));
+    // ... and the step's two ends -- the chirp products, the half nonlinear steps, the zero padding, the maximum -- inside the first and the last of
+    // those column launches (ssfm_chirp_step): five launches per fixed step, seven per adaptive step.  SSFM_CHIRP_ENDS=0: the separate kernels.
+    const char* ee = std::getenv("SSFM_CHIRP_ENDS");
+    bool fused_ends = fused_mid && !(ee && std::atoi(ee) == 0);
     auto step = [&](double h, const ChirpCtl* ctl, unsigned long long* mb) -> int {
+        if (fused_ends) {
+            if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
+                hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
+                mtab_h = h; mtab_set = true;
+            }
+            ssfm_chirp_io io;
+            io.A = A; io.P = P; io.chirp = chirp; io.n = n; io.gamma = gamma; io.hh = 0.5 * h;
+            io.h_dev = ctl ? &ctl->h : nullptr; io.done_dev = ctl ? &ctl->done : nullptr; io.maxbits_dev = mb;
+            const int rc = ssfm_chirp_step(plan, mtab, &io);
+            if (rc != SSFM_ERR_UNSUPPORTED) return rc;
+            fused_ends = false;                                         // (nothing was launched: the separate kernels from here on)
+        }
         hipLaunchKernelGGL(k_chirp_pre, dim3(gM), dim3(256), 0, t.stream, (const double2*)A, (double*)P, (const double2*)chirp, t.F, (long long)n, t.M, batch, gamma, 0.5 * h, ctl);
         if (fused_mid) {
             if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
@@ -262,6 +278,17 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     };
     if (hs) {
         if (nsteps < 0) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: nsteps=%lld", (long long)nsteps);
+        // plans of up to 4096 samples (n <= 2048): the whole schedule in one launch, a workgroup per row (k_small_chirp).  SSFM_CHIRP_SMALL=0: off.
+        const char* se = std::getenv("SSFM_CHIRP_SMALL");
+        if (nsteps > 0 && t.M <= 4096 && !(se && std::atoi(se) == 0)) {
+            const int rc = ssfm_chirp_small(plan, A, chirp, Dt, n, gamma, hs, nsteps);
+            if (rc == SSFM_OK) {
+                HIP_TRY(hipStreamSynchronize(t.stream));
+                if (steps_out) *steps_out = nsteps;
+                return SSFM_OK;
+            }
+            if (rc != SSFM_ERR_UNSUPPORTED) return rc;
+        }
         const auto t0 = std::chrono::steady_clock::now();
         for (int64_t s = 0; s < nsteps; ++s)
             if (int rc = step(hs[s], nullptr, nullptr)) return rc;

@@ -157,6 +157,31 @@ hipError_t launch_small(int n, int rows, hipStream_t s, const SmallArgs<T>& a) {
     return hipErrorInvalidValue;
 }
 
+// k_small_chirp: lengths that are not powers of two on one line of the plan's length (complex128), the whole schedule in one launch
+template <typename T, int N>
+hipError_t launch_small_chirp_n(int rows, hipStream_t s, const SmallChirpArgs<T>& a) {
+    constexpr int E = small_points<T>(N);
+    constexpr size_t lds = (fft_nstages(N, E) > 1 ? (size_t)row_lds_elems(N, E) * sizeof(cx<T>) : 0) + (size_t)fft_tw_lds_entries(N, E) * sizeof(cx<T>) + (size_t)N * sizeof(cx<T>);
+    static_assert(lds <= 160 * 1024, "k_small_chirp: the line, its twiddles and H must fit the LDS");
+    static hipError_t attr = allow_lds(k_small_chirp<T, N, E>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_small_chirp<T, N, E>), dim3(rows), dim3(N / E), lds, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_small_chirp(int n, int rows, hipStream_t s, const SmallChirpArgs<T>& a) {
+    if constexpr (sizeof(T) == 8) {
+        switch (n) {
+            case 256:  return launch_small_chirp_n<T, 256>(rows, s, a);
+            case 512:  return launch_small_chirp_n<T, 512>(rows, s, a);
+            case 1024: return launch_small_chirp_n<T, 1024>(rows, s, a);
+            case 2048: return launch_small_chirp_n<T, 2048>(rows, s, a);
+            case 4096: return launch_small_chirp_n<T, 4096>(rows, s, a);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 // k_small_adapt: all rows of the plan in ONE workgroup (they share the step size); at most 512 threads, so that a thread
 // may use the whole register file
 template <typename T> constexpr bool small_adapt_supported(int n, int rows) {
@@ -1602,19 +1627,54 @@ template <typename T> struct PlanT : PlanBase {
     // x <- ifft(fft(ifft(fft(x) * H0) * mul) * H1) with the tables of slots 0 and 1 and a time-domain table `mul` (n entries per row, DEVICE, the plan's
     // precision): the two applications of apply_table around a pointwise product, the middle of it -- inverse pass, product, forward pass -- in ONE column
     // launch (k_time<TM_MID> with TimeArgs::mul).  Five launches instead of seven.  Plain layout only (complex128 plans; complex64 plans of the plain layout).
-    int apply_tables_mul(const void* mul_dev) {
+    // `io` (nullable; complex128 plans): a chirp-z step's two ends folded into the first and the last launch (ChirpIO, ssfm_kernels.hpp) -- the caller's
+    // field in, the caller's field out, the plan's own field buffer untouched.
+    int apply_tables_mul(const void* mul_dev, const ssfm_chirp_io* io = nullptr) {
         if (!xfer_tab[0] || !xfer_tab[1]) return fail(SSFM_ERR_STATE, "ssfm_apply_tables_mul: slots 0 and 1 must hold tables");
         if (u16) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_apply_tables_mul: not for plans in the 16-byte-unit layout");
         if (!mul_dev) return fail(SSFM_ERR_INVALID, "ssfm_apply_tables_mul: NULL table");
+        TimeArgs<T> tb = targs(0, 0, 0, nullptr);
+        if (io) {
+            if (sizeof(T) != 8) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_step: complex128 plans only");
+            if (!io->A || !io->P || !io->chirp || io->n < 2 || 2 * io->n - 1 > n) return fail(SSFM_ERR_INVALID, "ssfm_chirp_step: bad field description");
+            tb.cz.chirp = static_cast<const cx<T>*>(io->chirp); tb.cz.A = static_cast<cx<T>*>(io->A); tb.cz.P = static_cast<T*>(io->P); tb.cz.n = io->n;
+            tb.cz.gamma = (T)io->gamma; tb.cz.hh = (T)io->hh; tb.cz.scale = (T)(1.0 / (double)io->n);
+            tb.cz.h = static_cast<const double*>(io->h_dev); tb.cz.done = static_cast<const int*>(io->done_dev);
+            tb.cz.maxbits = static_cast<unsigned long long*>(io->maxbits_dev);
+        }
         if (int rc = use_device()) return rc;
-        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E)));
         HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[0], 0, nullptr), Ef)));
         TimeArgs<T> tm = targs(0, 0, 0, nullptr);
         tm.mul = static_cast<const cx<T>*>(mul_dev);
         HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, tm, E)));
         HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[1], 0, nullptr), Ef)));
-        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, tb, E)));
         last_launches += 5;
+        return SSFM_OK;
+    }
+    // A fixed-step chirp-z run of a field of nn <= n / 2 samples per row in ONE launch (k_small_chirp); SSFM_ERR_UNSUPPORTED (nothing launched) when the
+    // plan is not a complex128 plan of the one-workgroup-per-row engine.
+    int chirp_small(void* A, const void* chirp, const void* Dt, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
+        if (sizeof(T) != 8 || !small || !tw_small) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small: a complex128 plan of 256 ... 4096 samples is needed");
+        if (!A || !chirp || !Dt || !hs || nn < 2 || 2 * nn - 1 > n || nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_chirp_small: bad arguments");
+        for (int64_t s = 0; s < nsteps; ++s)
+            if (!(hs[s] > 0) || !std::isfinite(hs[s])) return fail(SSFM_ERR_INVALID, "ssfm_chirp_small: step %lld is %g km (must be finite and > 0)", (long long)s, hs[s]);
+        if (int rc = use_device()) return rc;
+        const size_t need = sizeof(double) * (size_t)nsteps;
+        if (d_hs_cap < need) {
+            (void)hipFree(d_hs); d_hs = nullptr; d_hs_cap = 0;
+            HIP_TRY(hipMalloc(&d_hs, need + need / 2));
+            d_hs_cap = need + need / 2;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpyAsync(d_hs, hs, need, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));             // (hs is the caller's)
+        SmallChirpArgs<T> a;
+        a.A = static_cast<cx<T>*>(A); a.chirp = static_cast<const cx<T>*>(chirp); a.Dt = static_cast<const cx<T>*>(Dt); a.hs = reinterpret_cast<const double*>(d_hs);
+        a.tw = tw_small; a.gamma = (T)gamma; a.n = (int)nn; a.nsteps = (int)nsteps;
+        last_launches = 1;
+        HIP_TRY(launch_small_chirp<T>((int)n, batch, stream, a));
         return SSFM_OK;
     }
     // slot <- fft(field): the field itself becomes a resident transfer function (row 0; the field is consumed)
@@ -1827,6 +1887,13 @@ int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot) {
 }
 int ssfm_apply_table(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->apply_table(slot)); }
 int ssfm_apply_tables_mul(ssfm_plan* plan, const void* mul_dev) { WITH_PLAN(plan, P_->apply_tables_mul(mul_dev)); }
+int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
+    WITH_PLAN(plan, P_->chirp_small(A, chirp, Dt, n, gamma, hs, nsteps));
+}
+int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* io) {
+    if (!io) return fail(SSFM_ERR_INVALID, "ssfm_chirp_step: NULL field description");
+    WITH_PLAN(plan, P_->apply_tables_mul(mul_dev, io));
+}
 int ssfm_table_from_field(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->table_from_field(slot)); }
 int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }
 

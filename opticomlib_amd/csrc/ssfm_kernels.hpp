@@ -213,6 +213,23 @@ __host__ __device__ __forceinline__ long long time_tw_pos_u16(long long k1, long
     return ((tile * (E / 2) + (t >> 1)) * ((long long)Q1 * 16) + thread) * 2 + (t & 1);
 }
 
+// A chirp-z step's two ends folded into the column passes of the plain layout (csrc/chirpz.hip has the algebra; chirp == nullptr: off).
+//   TM_BEGIN reads the caller's field A (n samples per row, natural order) instead of the plan's: |A|^2 -> P, half a nonlinear step, times the chirp c,
+//            zeros from n up to the plan's length -- what k_chirp_pre wrote into the plan's field for BEGIN to read back;
+//   TM_END   writes A instead of the plan's field: times conj(c) * scale, the other half nonlinear step with the P of BEGIN, and the maximum of
+//            |A|^2 into *maxbits (nullable) -- what k_chirp_post did from the field END had stored.
+// Steps driven from the device (ssfm_chirp_propagate, adaptive): the step size comes from *h, and a set *done turns the pass into a no-op.
+template <typename T> struct ChirpIO {
+    const cx<T>* chirp;
+    cx<T>* A;
+    T* P;
+    long long n;
+    T gamma, hh, scale;
+    const double* h;
+    const int* done;
+    unsigned long long* maxbits;
+};
+
 template <typename T> struct TimeArgs {
     cx<T>* F;                 // field in time order, batch rows of N (read by BEGIN, written by END)
     cx<T>* Y;                 // field in the half-transformed layout between the kernels.  Plain layout: Y == F, a tile
@@ -242,6 +259,7 @@ template <typename T> struct TimeArgs {
                               // pointwise kernel and BEGIN); nullptr otherwise
     T* pkeep;                 // PK: the thread's E values of |A|^2 stay in registers from one column pass to the next (the same workgroup has the tile
                               // every time) instead of going through the P buffer
+    ChirpIO<T> cz = {};       // chirp-z steps (plain layout, TM_BEGIN / TM_END): see ChirpIO
     SSFM_TRACE_ARGS
 };
 
@@ -664,8 +682,36 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         }
     } else {
         const cx<T>* __restrict__ src = MODE == TM_BEGIN ? Fb : Yb;
+        bool loaded = false;
+        if constexpr (MODE == TM_BEGIN && !U16 && sizeof(T) == 8) {
+            if (a.cz.chirp != nullptr) {
+                if (a.cz.done != nullptr && *a.cz.done) return;
+                const T hh = a.cz.h != nullptr ? (T)(0.5 * *a.cz.h) : a.cz.hh;
+                const cx<T>* __restrict__ Ab = a.cz.A + (long long)brow * a.cz.n;
+                T* __restrict__ Pn = a.cz.P + (long long)brow * a.cz.n;
+#pragma unroll
+                for (int t = 0; t < E; ++t) {
+                    const int m = off + t * stride;
+                    v[t] = mk<T>((T)0, (T)0);
+                    if (m < a.cz.n) {
+                        cx<T> x = Ab[m];
+                        const T p = x.x * x.x + x.y * x.y;
+                        Pn[m] = p;
+                        if (a.cz.gamma != (T)0) {
+                            T sn, cs;
+                            sincos(a.cz.gamma * p * hh, &sn, &cs);
+                            x = mk<T>(x.x * cs - x.y * sn, x.x * sn + x.y * cs);
+                        }
+                        v[t] = cmul(x, a.cz.chirp[m]);
+                    }
+                }
+                loaded = true;
+            }
+        }
+        if (!loaded) {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0 && MODE != TM_BEGIN)>(&src[off + t * stride]);
+        }
     }
     constexpr bool TWC = twn_compute<T, U16>();
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
@@ -998,6 +1044,39 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     }
     if (tm_ends(MODE)) {
         if (MODE == TM_END) {
+            if constexpr (MODE == TM_END && !U16 && sizeof(T) == 8) {
+                if (a.cz.chirp != nullptr) {
+                    if (a.cz.done != nullptr && *a.cz.done) return;
+                    const T hh = a.cz.h != nullptr ? (T)(0.5 * *a.cz.h) : a.cz.hh;
+                    cx<T>* __restrict__ Ab = a.cz.A + (long long)brow * a.cz.n;
+                    const T* __restrict__ Pn = a.cz.P + (long long)brow * a.cz.n;
+                    T pmx = (T)0;
+#pragma unroll
+                    for (int t = 0; t < E; ++t) {
+                        const int m = off + t * stride;
+                        if (m < a.cz.n) {
+                            const cx<T> w = a.cz.chirp[m];
+                            cx<T> x = mk<T>((v[t].x * w.x + v[t].y * w.y) * a.cz.scale, (v[t].y * w.x - v[t].x * w.y) * a.cz.scale);     // z conj(c) / n
+                            if (a.cz.gamma != (T)0) {
+                                T sn, cs;
+                                sincos(a.cz.gamma * Pn[m] * hh, &sn, &cs);
+                                x = mk<T>(x.x * cs - x.y * sn, x.x * sn + x.y * cs);
+                            }
+                            Ab[m] = x;
+                            const T p = x.x * x.x + x.y * x.y;
+                            pmx = p > pmx ? p : pmx;
+                        }
+                    }
+                    if (a.cz.maxbits != nullptr) {
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const T other = __shfl_xor(pmx, o);
+                            pmx = other > pmx ? other : pmx;
+                        }
+                        if ((threadIdx.x & 63) == 0 && pmx > (T)0) atomicMax(a.cz.maxbits, (unsigned long long)__double_as_longlong((double)pmx));
+                    }
+                    return;
+                }
+            }
             // (time-order output: plain stores -- it is read by whatever comes after the run, not by the next pass)
 #pragma unroll
             for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
@@ -1595,6 +1674,136 @@ __global__ __launch_bounds__(N / E) void k_small(const SmallArgs<T> a) {
     }
 #pragma unroll
     for (int t = 0; t < E; ++t) Frow[j + t * Q] = v[t];
+}
+
+// ------------------------------------------------------------------------------ k_small_chirp
+// A field of ANY length n <= 2048 (the reference's own generators: a PRBS-7 word at 16 samples per bit is 2032 samples) through the chirp-z identity
+// on ONE line of N >= 2 n - 1 points, the whole fixed-step schedule in a single launch (csrc/chirpz.hip has the algebra; the launch-per-pass form
+// takes 5 launches, 22 us, per step).  Thread j keeps the samples m = j + t Q of its row; per step
+//     v = A exp(i phi) c            (c_m = exp(-i pi m^2 / n); zero from n up to N)
+//     v = ifft_N(fft_N(v) H)        H = fft_N(conj(c), wrapped around the line) / N: the forward n-point transform, up to a factor c_k
+//     v = v exp(D~ h)               (zero from n up)
+//     v = ifft_N(fft_N(v) conj(H))  the inverse one: its kernel is the conjugate of a sequence that is symmetric on the line, so is its transform
+//     A = v conj(c) / n, rotated by the step's second half phase and the next step's first in one rotation (as k_small does).
+// H is computed here (one transform per launch) in the order the line transform leaves its output, so no table in any order is needed; exp(D~ h) is
+// formed in registers whenever the step size changes (normally twice per run).
+template <typename T> struct SmallChirpArgs {
+    cx<T>* A;                 // rows of n samples, natural order, advanced in place
+    const cx<T>* chirp;       // c, n entries
+    const cx<T>* Dt;          // D~, n entries, natural frequency order
+    const double* hs;         // the schedule: nsteps step sizes [km]
+    const cx<T>* tw;          // stage twiddles of the N-point line
+    T gamma;
+    int n;
+    int nsteps;
+};
+template <typename T, int N, int E>
+__global__ __launch_bounds__(N / E) void k_small_chirp(const SmallChirpArgs<T> a) {
+    constexpr int Q = N / E;
+    constexpr int EH = E / 2;              // n <= N / 2: the samples m = j + t Q with t >= E / 2 are the zero padding, whatever the thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+    const int j = threadIdx.x;
+    const int n = a.n;
+    cx<T>* __restrict__ Arow = a.A + (long long)blockIdx.x * n;
+    using RI = RowIdx<row_pad_shift(E)>;
+    const RI idx{0};
+    cx<T> v[E];
+    LineTw<T, N, E> tw;
+    cx<T>* ldsT = lds + (fft_nstages(N, E) > 1 ? row_lds_elems(N, E) : 0);
+    cx<T>* ldsH = ldsT + fft_tw_lds_entries(N, E);          // H, N entries, as this thread's E values of the line transform's output: [t Q + j]
+    line_twiddles_issue<T, N, E>(tw, j, a.tw, ldsT, j, Q);
+    if (fft_tw_lds_entries(N, E) > 0) __syncthreads();
+    line_twiddles_fetch<T, N, E>(tw, j, ldsT);
+    const cx<T> zero = mk<T>((T)0, (T)0);
+#pragma unroll
+    for (int t = 0; t < E; ++t) {
+        const int m = j + t * Q, d = m < N - m ? m : N - m;
+        v[t] = zero;
+        if (d < n) { const cx<T> c = a.chirp[d]; v[t] = mk<T>(c.x, -c.y); }
+    }
+    fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+    const T inv_line = (T)1 / (T)N, inv_n = (T)1 / (T)n;
+#pragma unroll
+    for (int t = 0; t < E; ++t) ldsH[t * Q + j] = mk<T>(v[t].x * inv_line, v[t].y * inv_line);       // (read back by this thread only)
+    cx<T> cw[EH], ex[EH];
+#pragma unroll
+    for (int t = 0; t < EH; ++t) {
+        const int m = j + t * Q;
+        v[t] = zero; cw[t] = zero; ex[t] = zero;
+        if (m < n) { v[t] = Arow[m]; cw[t] = a.chirp[m]; }
+    }
+    const T half = (T)0.5;
+    T pold[EH];
+    T phi[EH];
+    cx<T> vh[EH];
+    {
+        const T hh = half * (T)a.hs[0];
+#pragma unroll
+        for (int t = 0; t < EH; ++t) {
+            const T p = v[t].x * v[t].x + v[t].y * v[t].y;
+            T ph = (T)0;
+            ph += hh * (a.gamma * p);
+            pold[t] = p;
+            phi[t] = ph;
+            vh[t] = v[t];
+        }
+        rotate_all<EH>(vh, phi);
+#pragma unroll
+        for (int t = 0; t < EH; ++t) v[t] = vh[t];
+    }
+    double hprev = 0.0;
+    for (int s = 0; s < a.nsteps; ++s) {
+        const double hd = a.hs[s];
+        if (s == 0 || hd != hprev) {
+#pragma unroll
+            for (int t = 0; t < EH; ++t) {
+                const int m = j + t * Q;
+                if (m < n) {
+                    const cx<T> d = a.Dt[m];
+                    T sn, cs;
+                    sincos(d.y * (T)hd, &sn, &cs);
+                    const T g = exp(d.x * (T)hd);
+                    ex[t] = mk<T>(g * cs, g * sn);
+                }
+            }
+            hprev = hd;
+        }
+        const T h = (T)hd;
+#pragma unroll
+        for (int t = 0; t < EH; ++t) { v[t] = cmul(v[t], cw[t]); v[t + EH] = zero; }
+        fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = cmul(v[t], ldsH[t * Q + j]);
+        fft_line<T, N, E, +1, 1, RI>(v, lds, 0, j, idx, tw);
+#pragma unroll
+        for (int t = 0; t < EH; ++t) { v[t] = cmul(v[t], ex[t]); v[t + EH] = zero; }
+        fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = cmulc(v[t], ldsH[t * Q + j]);
+        fft_line<T, N, E, +1, 1, RI>(v, lds, 0, j, idx, tw);
+        const T hh_prev = half * h;
+        const bool more = s + 1 < a.nsteps;
+        const T hh_next = more ? half * (T)a.hs[s + 1] : (T)0;
+#pragma unroll
+        for (int t = 0; t < EH; ++t) {
+            const cx<T> y = cmulc(v[t], cw[t]);
+            vh[t] = mk<T>(y.x * inv_n, y.y * inv_n);
+            const T p = vh[t].x * vh[t].x + vh[t].y * vh[t].y;
+            T ph = hh_prev * (a.gamma * pold[t]);
+            if (more) ph += hh_next * (a.gamma * p);
+            pold[t] = p;
+            phi[t] = ph;
+        }
+        rotate_all<EH>(vh, phi);
+#pragma unroll
+        for (int t = 0; t < EH; ++t) v[t] = vh[t];
+    }
+#pragma unroll
+    for (int t = 0; t < EH; ++t) {
+        const int m = j + t * Q;
+        if (m < n) Arow[m] = v[t];
+    }
 }
 
 // The adaptive run of a small plan (reference devices.py:1155-1161, 1172-1196 with h = None) in ONE launch: ROWS rows (the

@@ -201,25 +201,31 @@ def test_any_length_adaptive_complex128_and_dm(n):
     np.testing.assert_allclose(H, np.fft.fftshift(orc.dm_transfer(n, gv.dt, -150.0)), rtol=0, atol=1e-15)
 
 
-@pytest.mark.parametrize("n", [2032, 3000, 8176])
+@pytest.mark.parametrize("n", [100, 500, 1016, 2032, 3000, 8176])
 def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
     """Lengths that are not powers of two: the whole run queued from C (ssfm_chirp_propagate; adaptive: the step rule evaluated on the device in
     the caller's float32 arithmetic) against the loop that calls one entry point per kernel from Python and waits for every step's maximum
     (SSFM_CHIRP_LOOP=python).  With the three-launch middle (SSFM_CHIRP_FUSED=0) the two are the same kernels with the same arguments: bit for bit,
-    and the same z log; with the fused middle pass (default) the product with exp(D~ h) is rounded in another place: 1e-12."""
+    and the same z log; with the fused middle pass (SSFM_CHIRP_ENDS=0) the product with exp(D~ h) is rounded in another place, and with the step's two
+    ends inside the column launches as well (default, five launches per step) so are the chirp products: 1e-12.  Up to 2048 samples a fixed-step run is
+    one launch (k_small_chirp; SSFM_CHIRP_SMALL=0 turns it off), with the two half rotations between steps merged into one: 1e-12 as well."""
     gv(**workloads.BENCH_GV)
     a = workloads.qpsk_field(1 << 14, seed=n, power_w=8e-3)[:, :n]
     x = optical_signal(a)
     for kw in (dict(length=6.0, h=0.37, **workloads.SMF), dict(length=8.0, phi_max=0.004, **workloads.SMF)):
         res = {}
-        for name, env in (("python", {"SSFM_CHIRP_LOOP": "python"}), ("c3", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "0"}), ("c", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "1"})):
+        for name, env in (("python", {"SSFM_CHIRP_LOOP": "python"}), ("c3", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "0", "SSFM_CHIRP_SMALL": "0"}),
+                          ("c7", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "1", "SSFM_CHIRP_ENDS": "0", "SSFM_CHIRP_SMALL": "0"}),
+                          ("c5", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "1", "SSFM_CHIRP_ENDS": "1", "SSFM_CHIRP_SMALL": "0"}),
+                          ("c", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "1", "SSFM_CHIRP_ENDS": "1", "SSFM_CHIRP_SMALL": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             y = oa.FIBER(x, **kw).signal
             z, _ = oa.FIBER(x, return_steps=True, **kw) if name == "python" else (None, None)
             res[name] = (y, z)
         np.testing.assert_array_equal(res["c3"][0], res["python"][0])
-        assert relmax(res["c"][0], res["python"][0]) < 1e-12 * (1 if "h" in kw else 1e4)     # (adaptive: a last-bit difference in a maximum moves a step size)
+        for name in ("c7", "c5", "c"):      # (c5: the step's ends inside the column passes; c: n <= 2048, fixed step: the whole run in one launch)
+            assert relmax(res[name][0], res["python"][0]) < 1e-12 * (1 if "h" in kw else 1e4), name     # (adaptive: a last-bit difference in a maximum moves a step size)
         assert len(res["python"][1]) > 10
 
 
