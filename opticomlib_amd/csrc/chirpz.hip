@@ -301,6 +301,13 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
         return SSFM_OK;
     }
     if (max_steps < 1 || max_steps > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: max_steps=%lld", (long long)max_steps);
+    {   // plans of up to 4096 samples: the whole adaptive run in one launch (k_small_chirp_adapt)
+        const char* se = std::getenv("SSFM_CHIRP_SMALL");
+        if (t.M <= 4096 && gamma != 0.0 && !(se && std::atoi(se) == 0)) {
+            const int rc = ssfm_chirp_small_adapt(plan, A, chirp, Dt, n, gamma, length, phi_max, f32, max_steps, z_out, steps_out);
+            if (rc != SSFM_ERR_UNSUPPORTED) return rc;
+        }
+    }
     ChirpCtl* ctl = nullptr;
     double* zlog = nullptr;
     HIP_TRY(hipMalloc(&ctl, sizeof(ChirpCtl)));

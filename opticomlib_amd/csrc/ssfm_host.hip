@@ -182,6 +182,30 @@ hipError_t launch_small_chirp(int n, int rows, hipStream_t s, const SmallChirpAr
     return hipErrorInvalidValue;
 }
 
+template <typename T, int N>
+hipError_t launch_small_chirp_adapt_n(int rows, hipStream_t s, const SmallChirpAdaptArgs<T>& a) {
+    constexpr int E = small_points<T>(N);
+    constexpr size_t lds = (fft_nstages(N, E) > 1 ? (size_t)row_lds_elems(N, E) * sizeof(cx<T>) : 0) + (size_t)fft_tw_lds_entries(N, E) * sizeof(cx<T>) + (size_t)N * sizeof(cx<T>);
+    static_assert(lds + 256 <= 160 * 1024, "k_small_chirp_adapt: the line, its twiddles and H must fit the LDS");
+    static hipError_t attr = allow_lds(k_small_chirp_adapt<T, N, E>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_small_chirp_adapt<T, N, E>), dim3(rows), dim3(N / E), lds, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_small_chirp_adapt(int n, int rows, hipStream_t s, const SmallChirpAdaptArgs<T>& a) {
+    if constexpr (sizeof(T) == 8) {
+        switch (n) {
+            case 256:  return launch_small_chirp_adapt_n<T, 256>(rows, s, a);
+            case 512:  return launch_small_chirp_adapt_n<T, 512>(rows, s, a);
+            case 1024: return launch_small_chirp_adapt_n<T, 1024>(rows, s, a);
+            case 2048: return launch_small_chirp_adapt_n<T, 2048>(rows, s, a);
+            case 4096: return launch_small_chirp_adapt_n<T, 4096>(rows, s, a);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 // k_small_adapt: all rows of the plan in ONE workgroup (they share the step size); at most 512 threads, so that a thread
 // may use the whole register file
 template <typename T> constexpr bool small_adapt_supported(int n, int rows) {
@@ -1677,6 +1701,40 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(launch_small_chirp<T>((int)n, batch, stream, a));
         return SSFM_OK;
     }
+    // ... and the adaptive run (k_small_chirp_adapt): the rows' workgroups exchange their maxima through memory every step, so all of them must be
+    // resident at once (at most kChirpAdaptRows rows).  Synchronous: the z log and the step count come back.
+    static constexpr int kChirpAdaptRows = 16;
+    int chirp_small_adapt(void* A, const void* chirp, const void* Dt, int64_t nn, double gamma, double length, double phi_max, int f32, int64_t max_steps,
+                          double* z_out, int64_t* steps_out) {
+        if (sizeof(T) != 8 || !small || !tw_small || batch > kChirpAdaptRows)
+            return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small_adapt: a complex128 plan of 256 ... 4096 samples and at most %d rows is needed", kChirpAdaptRows);
+        if (!A || !chirp || !Dt || nn < 2 || 2 * nn - 1 > n || max_steps < 1 || max_steps > 0x7ffffff0 || !(length > 0) || !(phi_max > 0) || gamma == 0.0)
+            return fail(SSFM_ERR_INVALID, "ssfm_chirp_small_adapt: bad arguments");
+        if (int rc = use_device()) return rc;
+        const size_t words = 2 * (size_t)batch * 2, need = sizeof(double) * (size_t)(max_steps + 1) + 8 * words + 16;
+        if (d_hs_cap < need) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(d_hs); d_hs = nullptr; d_hs_cap = 0;
+            HIP_TRY(hipMalloc(&d_hs, need + need / 2));
+            d_hs_cap = need + need / 2;
+        }
+        unsigned char* base = reinterpret_cast<unsigned char*>(d_hs);
+        SmallChirpAdaptArgs<T> a;
+        a.A = static_cast<cx<T>*>(A); a.chirp = static_cast<const cx<T>*>(chirp); a.Dt = static_cast<const cx<T>*>(Dt); a.tw = tw_small;
+        a.xw = reinterpret_cast<unsigned long long*>(base); a.out = reinterpret_cast<int*>(base + 8 * words); a.zlog = reinterpret_cast<double*>(base + 8 * words + 16);
+        a.phi_max = phi_max; a.abs_gamma = gamma < 0 ? -gamma : gamma; a.length = length; a.patience = medium_patience > 0 ? medium_patience : 20000000ll;
+        a.gamma = (T)gamma; a.n = (int)nn; a.max_steps = (int)max_steps; a.f32 = f32;
+        HIP_TRY(hipMemsetAsync(base, 0, 8 * words + 16, stream));
+        last_launches = 1;
+        HIP_TRY(launch_small_chirp_adapt<T>((int)n, batch, stream, a));
+        int out[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(out, a.out, sizeof(out), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (out[1]) return fail(SSFM_ERR_HIP, "ssfm_chirp_small_adapt: the rows' workgroups did not meet within the patience (the field is unchanged unless a row had finished)");
+        if (z_out) HIP_TRY(hipMemcpy(z_out, a.zlog, sizeof(double) * (size_t)(out[0] + 1), hipMemcpyDeviceToHost));
+        if (steps_out) *steps_out = out[0];
+        return SSFM_OK;
+    }
     // slot <- fft(field): the field itself becomes a resident transfer function (row 0; the field is consumed)
     int table_from_field(int slot) {
         if (slot < 0 || slot > 1) return fail(SSFM_ERR_INVALID, "ssfm_table_from_field: slot %d", slot);
@@ -1889,6 +1947,10 @@ int ssfm_apply_table(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->apply_tabl
 int ssfm_apply_tables_mul(ssfm_plan* plan, const void* mul_dev) { WITH_PLAN(plan, P_->apply_tables_mul(mul_dev)); }
 int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
     WITH_PLAN(plan, P_->chirp_small(A, chirp, Dt, n, gamma, hs, nsteps));
+}
+int ssfm_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int f32,
+                           int64_t max_steps, double* z_out, int64_t* steps_out) {
+    WITH_PLAN(plan, P_->chirp_small_adapt(A, chirp, Dt, n, gamma, length, phi_max, f32, max_steps, z_out, steps_out));
 }
 int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* io) {
     if (!io) return fail(SSFM_ERR_INVALID, "ssfm_chirp_step: NULL field description");

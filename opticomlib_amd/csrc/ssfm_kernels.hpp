@@ -1806,6 +1806,208 @@ __global__ __launch_bounds__(N / E) void k_small_chirp(const SmallChirpArgs<T> a
     }
 }
 
+// The ADAPTIVE run (h = phi_max / (|gamma| max |A|^2), the reference's default: devices.py:1155-1161, 1172-1196 with h = None) of such a field in one
+// launch.  The rows of a signal share the step size, and a row needs a whole workgroup's registers, so the workgroups exchange their maxima every
+// step: each stores its own as two 8-byte words (tag << 32 | half of the double's bit pattern; tag = exchange number, the slots alternate) and
+// reads the others' -- relaxed agent-scope accesses and nothing else, the tag inside the word is the ordering.  |A|^2 is the same before and after a
+// rotation, so the next step size is known before the phases are applied: one rotation per step here too.  The step rule is ssfm_chirp_propagate's
+// (chirpz.hip k_chirp_control), evaluated by every workgroup from the same maximum in the caller's arithmetic (RT = float in complex64 mode).
+template <typename T> struct SmallChirpAdaptArgs {
+    cx<T>* A;
+    const cx<T>* chirp;
+    const cx<T>* Dt;
+    const cx<T>* tw;
+    unsigned long long* xw;   // [2][rows][2] exchange words, zeroed before the launch
+    double* zlog;             // z after every step, max_steps + 1 entries
+    int* out;                 // [0] steps taken, [1] != 0: an exchange ran out of patience (nothing was stored)
+    double phi_max, abs_gamma, length;
+    long long patience;       // 100 MHz ticks
+    T gamma;
+    int n;
+    int max_steps;
+    int f32;
+};
+template <typename RT>
+__device__ __forceinline__ void chirp_step_rule(double amax, double phi_max, double abs_gamma, double L, double z, double& h, double& znext) {
+    const RT zz = (RT)z;
+    RT hh = (RT)phi_max / ((RT)abs_gamma * (RT)amax);
+    const RT left = (RT)((RT)L - zz);
+    hh = hh < left ? hh : left;
+    h = (double)hh;
+    znext = (double)(RT)(zz + hh);
+}
+template <typename T, int N, int E>
+__global__ __launch_bounds__(N / E) void k_small_chirp_adapt(const SmallChirpAdaptArgs<T> a) {
+    constexpr int Q = N / E;
+    constexpr int EH = E / 2;
+    constexpr int NW = Q / 64 > 0 ? Q / 64 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double s_red[NW + 1];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
+    const int j = threadIdx.x;
+    const int n = a.n;
+    const int rows = gridDim.x, row = blockIdx.x;
+    cx<T>* __restrict__ Arow = a.A + (long long)row * n;
+    using RI = RowIdx<row_pad_shift(E)>;
+    const RI idx{0};
+    cx<T> v[E];
+    LineTw<T, N, E> tw;
+    cx<T>* ldsT = lds + (fft_nstages(N, E) > 1 ? row_lds_elems(N, E) : 0);
+    cx<T>* ldsH = ldsT + fft_tw_lds_entries(N, E);
+    line_twiddles_issue<T, N, E>(tw, j, a.tw, ldsT, j, Q);
+    if (fft_tw_lds_entries(N, E) > 0) __syncthreads();
+    line_twiddles_fetch<T, N, E>(tw, j, ldsT);
+    const cx<T> zero = mk<T>((T)0, (T)0);
+#pragma unroll
+    for (int t = 0; t < E; ++t) {
+        const int m = j + t * Q, d = m < N - m ? m : N - m;
+        v[t] = zero;
+        if (d < n) { const cx<T> c = a.chirp[d]; v[t] = mk<T>(c.x, -c.y); }
+    }
+    fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+    const T inv_line = (T)1 / (T)N, inv_n = (T)1 / (T)n;
+#pragma unroll
+    for (int t = 0; t < E; ++t) ldsH[t * Q + j] = mk<T>(v[t].x * inv_line, v[t].y * inv_line);
+    cx<T> cw[EH], ex[EH], vh[EH];
+    T pold[EH], phi[EH];
+#pragma unroll
+    for (int t = 0; t < EH; ++t) {
+        const int m = j + t * Q;
+        vh[t] = zero; cw[t] = zero; ex[t] = zero;
+        if (m < n) { vh[t] = Arow[m]; cw[t] = a.chirp[m]; }
+    }
+    // the maximum of |A|^2 over all rows: exchange number `tag` (1, 2, ...).  false: out of patience
+    auto all_rows_max = [&](double mine, unsigned tag, double& out) -> bool {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(mine, o);
+            mine = other > mine ? other : mine;
+        }
+        if ((j & 63) == 0) s_red[j >> 6] = mine;
+        __syncthreads();
+        if (j == 0) {
+            double m = s_red[0];
+            for (int w = 1; w < NW; ++w) m = s_red[w] > m ? s_red[w] : m;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(m), tg = (unsigned long long)tag << 32;
+            unsigned long long* slot = a.xw + ((long long)(tag & 1) * rows + row) * 2;
+            __hip_atomic_store(&slot[0], tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&slot[1], tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = wall_clock64();
+            bool ok = true;
+            for (int r = 0; r < rows && ok; ++r) {
+                if (r == row) continue;
+                const unsigned long long* src = a.xw + ((long long)(tag & 1) * rows + r) * 2;
+                unsigned long long w0, w1;
+                for (;;) {
+                    w0 = __hip_atomic_load(&src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w1 = __hip_atomic_load(&src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((w0 >> 32) == tag && (w1 >> 32) == tag) break;
+                    if (wall_clock64() - t0 > a.patience) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (ok) {
+                    const double other = __longlong_as_double((long long)((w0 << 32) | (w1 & 0xffffffffull)));
+                    m = other > m ? other : m;
+                }
+            }
+            s_red[NW] = ok ? m : -1.0;
+        }
+        __syncthreads();
+        out = s_red[NW];
+        __syncthreads();                 // (s_red is rewritten by the next exchange)
+        return out >= 0.0;
+    };
+    auto fail_out = [&]() { if (j == 0) a.out[1] = 1; };
+    double pm = 0.0;
+#pragma unroll
+    for (int t = 0; t < EH; ++t) {
+        const T p = vh[t].x * vh[t].x + vh[t].y * vh[t].y;
+        pold[t] = p;
+        pm = (double)p > pm ? (double)p : pm;
+    }
+    unsigned tag = 1;
+    double amax;
+    if (!all_rows_max(pm, tag, amax)) { fail_out(); return; }
+    double z = 0.0, h, znext;
+    int steps = 0;
+    if (a.f32) chirp_step_rule<float>(amax, a.phi_max, a.abs_gamma, a.length, z, h, znext);
+    else chirp_step_rule<double>(amax, a.phi_max, a.abs_gamma, a.length, z, h, znext);
+    if (row == 0 && j == 0) a.zlog[0] = 0.0;
+    const T half = (T)0.5;
+    {
+        const T hh = half * (T)h;
+#pragma unroll
+        for (int t = 0; t < EH; ++t) {
+            T ph = (T)0;
+            ph += hh * (a.gamma * pold[t]);
+            phi[t] = ph;
+        }
+        rotate_all<EH>(vh, phi);
+    }
+    for (;;) {
+#pragma unroll
+        for (int t = 0; t < EH; ++t) {
+            const int m = j + t * Q;
+            if (m < n) {
+                const cx<T> d = a.Dt[m];
+                T sn, cs;
+                sincos(d.y * (T)h, &sn, &cs);
+                const T g = exp(d.x * (T)h);
+                ex[t] = mk<T>(g * cs, g * sn);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < EH; ++t) { v[t] = cmul(vh[t], cw[t]); v[t + EH] = zero; }
+        fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = cmul(v[t], ldsH[t * Q + j]);
+        fft_line<T, N, E, +1, 1, RI>(v, lds, 0, j, idx, tw);
+#pragma unroll
+        for (int t = 0; t < EH; ++t) { v[t] = cmul(v[t], ex[t]); v[t + EH] = zero; }
+        fft_line<T, N, E, -1, 1, RI>(v, lds, 0, j, idx, tw);
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = cmulc(v[t], ldsH[t * Q + j]);
+        fft_line<T, N, E, +1, 1, RI>(v, lds, 0, j, idx, tw);
+        T pnew[EH];
+        pm = 0.0;
+#pragma unroll
+        for (int t = 0; t < EH; ++t) {
+            const cx<T> y = cmulc(v[t], cw[t]);
+            vh[t] = mk<T>(y.x * inv_n, y.y * inv_n);
+            pnew[t] = vh[t].x * vh[t].x + vh[t].y * vh[t].y;
+            pm = (double)pnew[t] > pm ? (double)pnew[t] : pm;
+        }
+        ++tag;
+        if (!all_rows_max(pm, tag, amax)) { fail_out(); return; }
+        // (k_chirp_control: the step just taken is logged, then the run ends or the next size follows from the maximum)
+        z = znext;
+        ++steps;
+        if (row == 0 && j == 0) a.zlog[steps] = z;
+        const bool done = a.f32 ? (!((float)z < (float)a.length) || steps >= a.max_steps) : (!(z < a.length) || steps >= a.max_steps);
+        double hn = 0.0;
+        if (!done) {
+            if (a.f32) chirp_step_rule<float>(amax, a.phi_max, a.abs_gamma, a.length, z, hn, znext);
+            else chirp_step_rule<double>(amax, a.phi_max, a.abs_gamma, a.length, z, hn, znext);
+        }
+        const T hh_prev = half * (T)h, hh_next = half * (T)hn;
+#pragma unroll
+        for (int t = 0; t < EH; ++t) {
+            T ph = hh_prev * (a.gamma * pold[t]);
+            if (!done) ph += hh_next * (a.gamma * pnew[t]);
+            pold[t] = pnew[t];
+            phi[t] = ph;
+        }
+        rotate_all<EH>(vh, phi);
+        if (done) break;
+        h = hn;
+    }
+#pragma unroll
+    for (int t = 0; t < EH; ++t) {
+        const int m = j + t * Q;
+        if (m < n) Arow[m] = vh[t];
+    }
+    if (row == 0 && j == 0) a.out[0] = steps;
+}
+
 // The adaptive run of a small plan (reference devices.py:1155-1161, 1172-1196 with h = None) in ONE launch: ROWS rows (the
 // polarisations of a signal share the step size: the maximum is taken over all of them) in one workgroup, D~ in registers
 // (exp(D~ h) formed per step as k_freq<FM_FLY> does), the step control of step_advance() between the inverse transform and
