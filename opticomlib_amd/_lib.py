@@ -72,6 +72,9 @@ SYMBOLS = {
     "ssfm_chirp_pre": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D]),
     "ssfm_chirp_mid": (_I, [_VP, _I64, _I, _VP, _I64, _D, _I]),
     "ssfm_chirp_post": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D, _VP]),
+    "ssfm_chirp_step": (_I, [_VP, _VP, _VP]),                       # (plan, mul_dev, const ssfm_chirp_io*)
+    "ssfm_chirp_small": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
+    "ssfm_chirp_small_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_chirp_propagate": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
