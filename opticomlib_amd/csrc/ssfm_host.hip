@@ -158,9 +158,17 @@ hipError_t launch_small(int n, int rows, hipStream_t s, const SmallArgs<T>& a) {
 }
 
 // k_small_chirp: lengths that are not powers of two on one line of the plan's length (complex128), the whole schedule in one launch
+// Points per thread: as k_small.  With 8 points on 512 threads the kernels of the 4096-point line spill (320 bytes of scratch per lane: a workgroup
+// of 512 threads has 256 registers per thread); with 16 points on 256 threads (-DSSFM_CHIRP_E16=1) they do not (256 + 120 accumulation registers),
+// but four wavefronts per workgroup hide less: fixed step 12.6 us per step at n = 2032 either way, adaptive 23.3 against 16.7 (eight exp(D~ h) per
+// thread and step instead of four).  So 8.
+#ifndef SSFM_CHIRP_E16
+#define SSFM_CHIRP_E16 0
+#endif
+template <typename T> constexpr int chirp_points(int n) { return n == 4096 && SSFM_CHIRP_E16 ? 16 : small_points<T>(n); }
 template <typename T, int N>
 hipError_t launch_small_chirp_n(int rows, hipStream_t s, const SmallChirpArgs<T>& a) {
-    constexpr int E = small_points<T>(N);
+    constexpr int E = chirp_points<T>(N);
     constexpr size_t lds = (fft_nstages(N, E) > 1 ? (size_t)row_lds_elems(N, E) * sizeof(cx<T>) : 0) + (size_t)fft_tw_lds_entries(N, E) * sizeof(cx<T>) + (size_t)N * sizeof(cx<T>);
     static_assert(lds <= 160 * 1024, "k_small_chirp: the line, its twiddles and H must fit the LDS");
     static hipError_t attr = allow_lds(k_small_chirp<T, N, E>, lds);
@@ -184,7 +192,7 @@ hipError_t launch_small_chirp(int n, int rows, hipStream_t s, const SmallChirpAr
 
 template <typename T, int N>
 hipError_t launch_small_chirp_adapt_n(int rows, hipStream_t s, const SmallChirpAdaptArgs<T>& a) {
-    constexpr int E = small_points<T>(N);
+    constexpr int E = chirp_points<T>(N);
     constexpr size_t lds = (fft_nstages(N, E) > 1 ? (size_t)row_lds_elems(N, E) * sizeof(cx<T>) : 0) + (size_t)fft_tw_lds_entries(N, E) * sizeof(cx<T>) + (size_t)N * sizeof(cx<T>);
     static_assert(lds + 256 <= 160 * 1024, "k_small_chirp_adapt: the line, its twiddles and H must fit the LDS");
     static hipError_t attr = allow_lds(k_small_chirp_adapt<T, N, E>, lds);
@@ -330,6 +338,7 @@ template <typename T> struct PlanT : PlanBase {
     // single-launch engine of small plans (ssfm_kernels.hpp k_small): its own row twiddles and operator tables (another order)
     bool small = false;        // env SSFM_SMALL=0 turns it off
     cx<T>* tw_small = nullptr;
+    cx<T>* tw_chirp = nullptr; // stage twiddles of the line for the chirp-z kernels where they take other points per thread than k_small (made on first use)
     cx<T>* dsmall = nullptr;   // D~ in the one-line order (k_small_adapt)
     // single-launch engine of medium plans (ssfm_kernels.hpp k_medium): its barrier counters and error word in device memory, a pinned
     // host copy of the error word, and what a repeat of the run on the two-kernel engine needs
@@ -564,6 +573,7 @@ template <typename T> struct PlanT : PlanBase {
         for (auto& t : tabs) (void)hipFree(t.ptr);
         for (auto& t : stabs) (void)hipFree(t.ptr);
         (void)hipFree(tw_small);
+        (void)hipFree(tw_chirp);
         (void)hipFree(dsmall);
         (void)hipFree(fused_backup);
         (void)hipFree(medium_st);
@@ -1696,13 +1706,22 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipStreamSynchronize(stream));             // (hs is the caller's)
         SmallChirpArgs<T> a;
         a.A = static_cast<cx<T>*>(A); a.chirp = static_cast<const cx<T>*>(chirp); a.Dt = static_cast<const cx<T>*>(Dt); a.hs = reinterpret_cast<const double*>(d_hs);
-        a.tw = tw_small; a.gamma = (T)gamma; a.n = (int)nn; a.nsteps = (int)nsteps;
+        if (int rc = chirp_line_table(&a.tw)) return rc;
+        a.gamma = (T)gamma; a.n = (int)nn; a.nsteps = (int)nsteps;
         last_launches = 1;
         HIP_TRY(launch_small_chirp<T>((int)n, batch, stream, a));
         return SSFM_OK;
     }
     // ... and the adaptive run (k_small_chirp_adapt): the rows' workgroups exchange their maxima through memory every step, so all of them must be
     // resident at once (at most kChirpAdaptRows rows).  Synchronous: the z log and the step count come back.
+    int chirp_line_table(const cx<T>** tw) {
+        *tw = tw_small;
+        if (chirp_points<T>((int)n) == small_points<T>((int)n)) return SSFM_OK;
+        if (!tw_chirp)
+            if (int rc = make_line_table(&tw_chirp, (int)n, chirp_points<T>((int)n))) return rc;
+        *tw = tw_chirp;
+        return SSFM_OK;
+    }
     static constexpr int kChirpAdaptRows = 16;
     int chirp_small_adapt(void* A, const void* chirp, const void* Dt, int64_t nn, double gamma, double length, double phi_max, int f32, int64_t max_steps,
                           double* z_out, int64_t* steps_out) {
@@ -1720,7 +1739,8 @@ template <typename T> struct PlanT : PlanBase {
         }
         unsigned char* base = reinterpret_cast<unsigned char*>(d_hs);
         SmallChirpAdaptArgs<T> a;
-        a.A = static_cast<cx<T>*>(A); a.chirp = static_cast<const cx<T>*>(chirp); a.Dt = static_cast<const cx<T>*>(Dt); a.tw = tw_small;
+        a.A = static_cast<cx<T>*>(A); a.chirp = static_cast<const cx<T>*>(chirp); a.Dt = static_cast<const cx<T>*>(Dt);
+        if (int rc = chirp_line_table(&a.tw)) return rc;
         a.xw = reinterpret_cast<unsigned long long*>(base); a.out = reinterpret_cast<int*>(base + 8 * words); a.zlog = reinterpret_cast<double*>(base + 8 * words + 16);
         a.phi_max = phi_max; a.abs_gamma = gamma < 0 ? -gamma : gamma; a.length = length; a.patience = medium_patience > 0 ? medium_patience : 20000000ll;
         a.gamma = (T)gamma; a.n = (int)nn; a.max_steps = (int)max_steps; a.f32 = f32;

@@ -227,6 +227,12 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
         for name in ("c7", "c5", "c"):      # (c5: the step's ends inside the column passes; c: n <= 2048, fixed step: the whole run in one launch)
             assert relmax(res[name][0], res["python"][0]) < 1e-12 * (1 if "h" in kw else 1e4), name     # (adaptive: a last-bit difference in a maximum moves a step size)
         assert len(res["python"][1]) > 10
+    # one polarisation (a single row: the one-launch adaptive engine has nobody to exchange maxima with)
+    x1, kw = optical_signal(a[0]), dict(length=8.0, phi_max=0.004, **workloads.SMF)
+    monkeypatch.setenv("SSFM_CHIRP_LOOP", "python")
+    ref = oa.FIBER(x1, **kw).signal
+    monkeypatch.setenv("SSFM_CHIRP_LOOP", "c")
+    assert relmax(oa.FIBER(x1, **kw).signal, ref) < 1e-8
 
 
 def test_lengths_beyond_the_range_are_rejected():
