@@ -283,7 +283,9 @@ int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* i
 int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
 /* ... and the ADAPTIVE run (h = phi_max / (|gamma| max |A|^2) over all rows, clamped to what is left of `length`; the rule of ssfm_chirp_propagate, in
  * float32 arithmetic when f32 != 0) in one launch: the rows' workgroups exchange their maxima through memory every step (k_small_chirp_adapt).  At
- * most 16 rows.  z_out (HOST, nullable, max_steps + 1 entries) receives z after every step, *steps_out the steps taken.  Synchronous. */
+ * most 16 rows.  z_out (HOST, nullable, max_steps + 1 entries) receives z after every step, *steps_out the steps taken.  Synchronous.
+ * SSFM_ERR_UNSUPPORTED with the field untouched: no such plan, or the rows' workgroups did not meet within the patience (SSFM_FUSED_PATIENCE_TICKS; a
+ * device too busy to keep them resident together) -- ssfm_chirp_propagate then queues the run step by step. */
 int ssfm_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int f32,
                            int64_t max_steps, double* z_out, int64_t* steps_out);
 /* The chirp c_m = exp(-i pi m^2 / n) of that identity, generated on the device with its phase reduced exactly in

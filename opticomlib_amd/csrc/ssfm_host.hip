@@ -1742,15 +1742,17 @@ template <typename T> struct PlanT : PlanBase {
         a.A = static_cast<cx<T>*>(A); a.chirp = static_cast<const cx<T>*>(chirp); a.Dt = static_cast<const cx<T>*>(Dt);
         if (int rc = chirp_line_table(&a.tw)) return rc;
         a.xw = reinterpret_cast<unsigned long long*>(base); a.out = reinterpret_cast<int*>(base + 8 * words); a.zlog = reinterpret_cast<double*>(base + 8 * words + 16);
-        a.phi_max = phi_max; a.abs_gamma = gamma < 0 ? -gamma : gamma; a.length = length; a.patience = medium_patience > 0 ? medium_patience : 20000000ll;
+        a.phi_max = phi_max; a.abs_gamma = gamma < 0 ? -gamma : gamma; a.length = length; a.patience = medium_patience;
         a.gamma = (T)gamma; a.n = (int)nn; a.max_steps = (int)max_steps; a.f32 = f32;
         HIP_TRY(hipMemsetAsync(base, 0, 8 * words + 16, stream));
         last_launches = 1;
         HIP_TRY(launch_small_chirp_adapt<T>((int)n, batch, stream, a));
-        int out[2] = {0, 0};
+        int out[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(out, a.out, sizeof(out), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (out[1]) return fail(SSFM_ERR_HIP, "ssfm_chirp_small_adapt: the rows' workgroups did not meet within the patience (the field is unchanged unless a row had finished)");
+        if (out[1] && out[2] == 0)          // (a busy device: not all rows' workgroups were resident together.  Nothing was stored: the caller's other path can run)
+            return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small_adapt: the rows' workgroups did not meet within the patience; the field is unchanged");
+        if (out[1]) return fail(SSFM_ERR_HIP, "ssfm_chirp_small_adapt: the rows' workgroups did not meet within the patience after %d of %d rows had finished", out[2], batch);
         if (z_out) HIP_TRY(hipMemcpy(z_out, a.zlog, sizeof(double) * (size_t)(out[0] + 1), hipMemcpyDeviceToHost));
         if (steps_out) *steps_out = out[0];
         return SSFM_OK;

@@ -1819,7 +1819,7 @@ template <typename T> struct SmallChirpAdaptArgs {
     const cx<T>* tw;
     unsigned long long* xw;   // [2][rows][2] exchange words, zeroed before the launch
     double* zlog;             // z after every step, max_steps + 1 entries
-    int* out;                 // [0] steps taken, [1] != 0: an exchange ran out of patience (nothing was stored)
+    int* out;                 // [0] steps taken, [1] != 0: an exchange ran out of patience, [2] rows that stored their result (0 with [1] set: A is untouched)
     double phi_max, abs_gamma, length;
     long long patience;       // 100 MHz ticks
     T gamma;
@@ -2005,6 +2005,7 @@ __global__ __launch_bounds__(N / E) void k_small_chirp_adapt(const SmallChirpAda
         const int m = j + t * Q;
         if (m < n) Arow[m] = vh[t];
     }
+    if (j == 0) atomicAdd(&a.out[2], 1);
     if (row == 0 && j == 0) a.out[0] = steps;
 }
 

@@ -235,6 +235,24 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
     assert relmax(oa.FIBER(x1, **kw).signal, ref) < 1e-8
 
 
+def test_one_launch_adaptive_run_of_any_length_gives_up_cleanly(monkeypatch):
+    """With no patience for the other row's maximum the one-launch adaptive engine of n <= 2048 stores nothing and the run is queued step by step."""
+    gv(**workloads.BENCH_GV)
+    x = optical_signal(workloads.qpsk_field(1 << 11, seed=5, power_w=8e-3)[:, :2032])
+    kw = dict(length=8.0, phi_max=0.004, **workloads.SMF)
+    monkeypatch.setenv("SSFM_CHIRP_SMALL", "0")
+    ref = oa.FIBER(x, **kw).signal
+    monkeypatch.setenv("SSFM_CHIRP_SMALL", "1")
+    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
+    try:
+        oa.devices.release_plans()              # (the knob is read when a plan is made)
+        y = oa.FIBER(x, **kw).signal
+    finally:
+        monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS")
+        oa.devices.release_plans()
+    np.testing.assert_array_equal(y, ref)
+
+
 def test_lengths_beyond_the_range_are_rejected():
     gv(sps=16, R=10e9)
     with pytest.raises(ValueError, match="samples per polarisation"):
