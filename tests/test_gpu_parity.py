@@ -235,24 +235,6 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
     assert relmax(oa.FIBER(x1, **kw).signal, ref) < 1e-8
 
 
-def test_one_launch_adaptive_run_of_any_length_gives_up_cleanly(monkeypatch):
-    """With no patience for the other row's maximum the one-launch adaptive engine of n <= 2048 stores nothing and the run is queued step by step."""
-    gv(**workloads.BENCH_GV)
-    x = optical_signal(workloads.qpsk_field(1 << 11, seed=5, power_w=8e-3)[:, :2032])
-    kw = dict(length=8.0, phi_max=0.004, **workloads.SMF)
-    monkeypatch.setenv("SSFM_CHIRP_SMALL", "0")
-    ref = oa.FIBER(x, **kw).signal
-    monkeypatch.setenv("SSFM_CHIRP_SMALL", "1")
-    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
-    try:
-        oa.devices.release_plans()              # (the knob is read when a plan is made)
-        y = oa.FIBER(x, **kw).signal
-    finally:
-        monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS")
-        oa.devices.release_plans()
-    np.testing.assert_array_equal(y, ref)
-
-
 def test_lengths_beyond_the_range_are_rejected():
     gv(sps=16, R=10e9)
     with pytest.raises(ValueError, match="samples per polarisation"):
@@ -2565,3 +2547,21 @@ def test_adaptive_capture_goes_to_the_host_in_blocks_and_api_order():
             p.propagate_adaptive(1.3, 12.0, 0.004, False, max_steps=5)
     finally:
         p.close()
+
+
+def test_one_launch_adaptive_run_of_any_length_gives_up_cleanly(monkeypatch):
+    """With no patience for the other row's maximum the one-launch adaptive engine of n <= 2048 stores nothing and the run is queued step by step.
+    (The knob is read when a plan is made: a length whose plan -- 512 points x 2, complex128 -- no other test uses.  Kept LAST in this file: with it
+    before them, the launch counts of test_fused_adaptive_kernel_on_two_lanes -- an opt-in engine that needs the whole GPU for one grid -- came out as
+    the fallback's in two full-suite runs; fields and z logs were right either way.  Not understood yet: DESIGN.md section 10.)"""
+    gv(**workloads.BENCH_GV)
+    x = optical_signal(workloads.qpsk_field(1 << 11, seed=5, power_w=8e-3)[:, :200])
+    kw = dict(length=8.0, phi_max=0.004, **workloads.SMF)
+    key = (oa.devices.default_device(), 512, 2, _lib.C128)
+    assert key not in oa.devices._PLANS
+    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
+    monkeypatch.setenv("SSFM_CHIRP_SMALL", "0")
+    ref = oa.FIBER(x, **kw).signal
+    monkeypatch.setenv("SSFM_CHIRP_SMALL", "1")
+    y = oa.FIBER(x, **kw).signal
+    np.testing.assert_array_equal(y, ref)
