@@ -720,10 +720,10 @@ template <typename T> struct PlanT : PlanBase {
     // in double on the host and rounded once
     int make_line_table(cx<T>** out, int L, int E) {
         const int M = fft_nstages(L, E);
-        const int total = fft_tw_entries(L, E);
+        const int total = fft_tw_entries(L, E, (int)sizeof(T));
         std::vector<cx<T>> tab((size_t)(total > 0 ? total : 1));
         for (int S = 1; S < M; ++S) {
-            const int R = fft_radix(L, S, E), NB = E / R, KU = fft_tw_ku(L, S, E), off = fft_tw_offset(L, S, E);
+            const int R = fft_radix(L, S, E), NB = E / R, KU = fft_tw_ku(L, S, E), off = fft_tw_offset(L, S, E, (int)sizeof(T));
             for (int i = 0; i < NB; ++i)
                 for (int u = 1; u < R; ++u)
                     for (int ku = 0; ku < KU; ++ku) {
@@ -734,7 +734,7 @@ template <typename T> struct PlanT : PlanBase {
                         if (4 * q == L) { w.x = (T)0; w.y = (T)-1; }
                         if (2 * q == L) { w.x = (T)-1; w.y = (T)0; }
                         if (4 * q == 3 * L) { w.x = (T)0; w.y = (T)1; }
-                        tab[(size_t)off + (size_t)(i * (R - 1) + (u - 1)) * KU + ku] = w;
+                        tab[(size_t)off + (size_t)fft_tw_index(L, S, E, (int)sizeof(T), i * (R - 1) + (u - 1), ku)] = w;
                     }
         }
         HIP_TRY(hipMalloc(out, sizeof(cx<T>) * tab.size()));
@@ -744,34 +744,35 @@ template <typename T> struct PlanT : PlanBase {
 
 #if SSFM_TRACE
     unsigned long long* trace_buf = nullptr;
-    int trace_cap = 0, trace_next = 0;
+    int trace_cap = 0; std::atomic<int> trace_next{0};
     std::vector<int> trace_kind;        // per slot: kind*16 + lane
     int trace_begin(int launches) {
         if (!std::getenv("SSFM_TRACE_FILE")) return SSFM_OK;
         if (trace_cap < launches) {
             (void)hipFree(trace_buf);
-            HIP_TRY(hipMalloc(&trace_buf, sizeof(unsigned long long) * 512 * launches));
+            HIP_TRY(hipMalloc(&trace_buf, sizeof(unsigned long long) * 1024 * launches));
             trace_cap = launches;
         }
-        HIP_TRY(hipMemset(trace_buf, 0, sizeof(unsigned long long) * 512 * launches));
+        HIP_TRY(hipMemset(trace_buf, 0, sizeof(unsigned long long) * 1024 * launches));
         trace_next = 0;
         trace_kind.assign(launches, 0);
         return SSFM_OK;
     }
     template <typename A> void trace_tag(A& a, int kind, int lane) {
         a.trace = nullptr; a.trace_slot = 0;
-        if (trace_buf && trace_next < trace_cap) { a.trace = trace_buf; a.trace_slot = trace_next; trace_kind[trace_next] = kind * 16 + lane; ++trace_next; }
+        if (trace_buf) { const int slot = trace_next.fetch_add(1); if (slot < trace_cap) { a.trace = trace_buf; a.trace_slot = slot; trace_kind[slot] = kind * 16 + lane; } }     // (the lanes' host threads tag concurrently)
     }
     int trace_dump() {
         const char* path = std::getenv("SSFM_TRACE_FILE");
         if (!path || !trace_buf) return SSFM_OK;
         HIP_TRY(hipStreamSynchronize(stream));
-        std::vector<unsigned long long> raw(512 * (size_t)trace_next), h(4 * (size_t)trace_next);
+        const int nt = std::min((int)trace_next, trace_cap);
+        std::vector<unsigned long long> raw(1024 * (size_t)nt), h(4 * (size_t)nt);
         HIP_TRY(hipMemcpy(raw.data(), trace_buf, sizeof(unsigned long long) * raw.size(), hipMemcpyDeviceToHost));
-        for (int i = 0; i < trace_next; ++i) {
+        for (int i = 0; i < nt; ++i) {
             unsigned long long fs = ~0ull, ls = 0, fe = ~0ull, le = 0;
             for (int b = 0; b < 256; ++b) {
-                const unsigned long long s0 = raw[((size_t)i * 256 + b) * 2], e0 = raw[((size_t)i * 256 + b) * 2 + 1];
+                const unsigned long long s0 = raw[((size_t)i * 256 + b) * 4], e0 = raw[((size_t)i * 256 + b) * 4 + 1];
                 if (s0 == 0) continue;
                 fs = s0 < fs ? s0 : fs; ls = s0 > ls ? s0 : ls; fe = e0 < fe ? e0 : fe; le = e0 > le ? e0 : le;
             }
@@ -780,9 +781,23 @@ template <typename T> struct PlanT : PlanBase {
         FILE* f = std::fopen(path, "w");
         if (!f) return SSFM_OK;
         std::fprintf(f, "slot,kind,lane,first_start,last_start,first_end,last_end\n");
-        for (int i = 0; i < trace_next; ++i)
+        for (int i = 0; i < nt; ++i)
             std::fprintf(f, "%d,%d,%d,%llu,%llu,%llu,%llu\n", i, trace_kind[i] / 16, trace_kind[i] % 16, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
         std::fclose(f);
+        // SSFM_TRACE_RAW=path: every workgroup of launches [first, first + count) of the run (SSFM_TRACE_RAW_FIRST, default the middle; 16 launches)
+        if (const char* rp = std::getenv("SSFM_TRACE_RAW")) {
+            if (FILE* g = std::fopen(rp, "w")) {
+                int first = nt / 2;
+                if (const char* e = std::getenv("SSFM_TRACE_RAW_FIRST")) first = std::atoi(e);
+                std::fprintf(g, "slot,kind,lane,block,start,end,xcc,hw_id\n");
+                for (int i = first; i < first + 16 && i < nt; ++i)
+                    for (int b = 0; b < 256; ++b) {
+                        const unsigned long long* w = &raw[((size_t)i * 256 + b) * 4];
+                        std::fprintf(g, "%d,%d,%d,%d,%llu,%llu,%llu,%llu\n", i, trace_kind[i] / 16, trace_kind[i] % 16, b, w[0], w[1], w[2] >> 32, w[2] & 0xffffffffull);
+                    }
+                std::fclose(g);
+            }
+        }
         return SSFM_OK;
     }
 #endif

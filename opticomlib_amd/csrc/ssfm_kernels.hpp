@@ -71,12 +71,18 @@ template <typename T, bool U16> __host__ __device__ constexpr bool twn_compute()
 #endif
 #if SSFM_TRACE
 #define SSFM_TRACE_ARGS unsigned long long* trace; int trace_slot;
+// four words per workgroup: start, end, where it ran (XCC id << 32 | HW_ID: CU, SE, SIMD of the stamping wave), spare
 #define SSFM_TRACE_BEGIN(a)                                                                     \
-    if ((a).trace && threadIdx.x == 0)                                                          \
-        (a).trace[((long long)(a).trace_slot * 256 + (blockIdx.x & 255)) * 2 + 0] = __builtin_amdgcn_s_memrealtime();
+    if ((a).trace && threadIdx.x == 0) {                                                        \
+        unsigned hw_, xc_;                                                                      \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc_));                      \
+        (a).trace[((long long)(a).trace_slot * 256 + (blockIdx.x & 255)) * 4 + 0] = __builtin_amdgcn_s_memrealtime(); \
+        (a).trace[((long long)(a).trace_slot * 256 + (blockIdx.x & 255)) * 4 + 2] = ((unsigned long long)xc_ << 32) | hw_; \
+    }
 #define SSFM_TRACE_END(a)                                                                       \
     if ((a).trace && threadIdx.x == 0)                                                          \
-        (a).trace[((long long)(a).trace_slot * 256 + (blockIdx.x & 255)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+        (a).trace[((long long)(a).trace_slot * 256 + (blockIdx.x & 255)) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #else
 #define SSFM_TRACE_ARGS
 #define SSFM_TRACE_BEGIN(a)
@@ -318,13 +324,30 @@ template <bool BIG> __device__ __forceinline__ void sincos_f32(float x, float& s
     sincos_reduced(r, q, s, c);
     if (BIG && !(fabsf(x) < __builtin_inff())) s = c = __builtin_nanf("");
 }
+// |x| <= 2^-5 (the phase of a split step that resolves the nonlinearity: phi_max is 0.01 ... 0.05 rad by default, a fixed-step run of
+// the headline configuration turns 4e-4 rad per half step): cos x = 1 - z/2 + z^2/24 (truncation z^3/720 < 2e-12), sin x = x (1 - z/6)
+// (relative truncation z^2/120 < 8e-9, an eighth of the float32 half-ulp) with z = x^2 -- both halves of ONE packed fma, then one fma
+// and one product: 4 instructions per point instead of 11 (k_time spends 2/3 of a SIMD's issue slots when both lanes run, so instructions
+// are time: profiles/r04_c2_micro.txt)
+#ifndef SSFM_SINCOS_MICRO
+#define SSFM_SINCOS_MICRO 1
+#endif
+constexpr float kSincosMicroMax = 0.03125f;
+__device__ __forceinline__ cf32 expi_micro(float x) {
+    const float z = x * x;
+    const cf32 acc = mk<float>(4.16666679084300994873e-2f, -1.66666671633720397949e-1f) * mk<float>(z, z) + mk<float>(-0.5f, 1.0f);
+    return mk<float>(fmaf(acc.x, z, 1.0f), acc.y * x);
+}
 // rotate E values by their phases
 template <int E> __device__ __forceinline__ void rotate_all(cf32 (&v)[E], const float (&phi)[E]) {
     float amax = 0.0f;
 #pragma unroll
     for (int t = 0; t < E; ++t) amax = fmaxf(amax, fabsf(phi[t]));
     const bool big = !(amax <= kSincosSmallMax);           // also true for NaN
-    if (__builtin_expect(amax <= kSincosTinyMax, 1)) {
+    if (SSFM_SINCOS_MICRO != 0 && __builtin_expect(amax <= kSincosMicroMax, 1)) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) v[t] = cmul(v[t], expi_micro(phi[t]));
+    } else if (__builtin_expect(amax <= kSincosTinyMax, 1)) {
 #pragma unroll
         for (int t = 0; t < E; ++t) {
             float s, c;
@@ -447,6 +470,15 @@ template <> __device__ __forceinline__ void sincos_acc<double>(double x, double&
 #ifndef SSFM_NT_LOADS
 #define SSFM_NT_LOADS 1
 #endif
+// SSFM_P16: the stale |A|^2 of the large complex64 plans (16 points per thread, unit layout) crosses the launch boundary as 16-bit fixed
+// point relative to the THREAD's own maximum: 2 x 16 bytes + one 4-byte scale per thread instead of 4 x 16 bytes -- 9 instead of 16 of the 91
+// bytes a dual-polarisation sample*step moves.  |A|^2 only ever enters the phase h/2 gamma |A|^2 (devices.py:1175,1181), so what counts is the
+// ABSOLUTE error of that phase: at most 2^-17 of the thread's largest phase (7.6e-6 of <= 0.05 rad; the float32 product itself carries 6e-8
+// relative).  The buffer is private to a tile (the same thread reads back what it wrote), so the scale needs no agreement between threads.
+#ifndef SSFM_P16
+#define SSFM_P16 1
+#endif
+template <typename T, bool U16, int E> __host__ __device__ constexpr bool p16_layout() { return SSFM_P16 != 0 && U16 && sizeof(T) == 4 && E == 16; }
 template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V* p) {
     if constexpr (NT && SSFM_NT_LOADS != 0) return __builtin_nontemporal_load(p);
     else return *p;
@@ -650,6 +682,10 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     typedef T p4_t __attribute__((ext_vector_type(4)));
     p4_t* __restrict__ Pb = reinterpret_cast<p4_t*>(a.P + (long long)brow * N + (long long)tile * (N1 * C)) + tid;
     constexpr int PSTR = N1 * C / E;      // threads per tile
+    // P16: the tile's 16 KiB hold 2 x 16 bytes of 16-bit values per thread (8 KiB), then one float scale per thread
+    constexpr bool P16 = p16_layout<T, U16, E>() && !PK;
+    u32x4_t* __restrict__ Pq = reinterpret_cast<u32x4_t*>(a.P + (long long)brow * N + (long long)tile * (N1 * C)) + tid;
+    float* __restrict__ Ps = reinterpret_cast<float*>(a.P + (long long)brow * N + (long long)tile * (N1 * C)) + (N1 * C / 2) + tid;
     const int off = j * a.N2 + ncol;             // time-order side: element (n1 = j + Q t, n2 = ncol)
     const int stride = Q * a.N2;
     // half-transformed side, U16: the 16-byte unit of row j + Q (2g + h) at columns (c8, h = 0 | 1) of the tile
@@ -748,6 +784,21 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
 #pragma unroll
             for (int t = 0; t < E; ++t) pold[t] = a.pkeep[t];
+            return;
+        }
+        if constexpr (P16) {
+            // 2^23 + q is the float whose low mantissa bits are q: (2^23 + q) sc - 2^23 sc = q sc, one byte permute and one fma per value
+            const float sc = stream_load<true>(Ps) * (1.0f / 65535.0f), off23 = -8388608.0f * sc;
+#pragma unroll
+            for (int g = 0; g < E / 8; ++g) {
+                const u32x4_t q = stream_load<true>(&Pq[g * PSTR]);
+                const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pold[8 * g + 2 * i] = fmaf(__uint_as_float(__builtin_amdgcn_perm(0x4B000000u, w[i], 0x07060100u)), sc, off23);
+                    pold[8 * g + 2 * i + 1] = fmaf(__uint_as_float(__builtin_amdgcn_perm(0x4B000000u, w[i], 0x07060302u)), sc, off23);
+                }
+            }
             return;
         }
 #pragma unroll
@@ -1006,6 +1057,27 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         if (FWD) {
 #pragma unroll
             for (int t = 0; t < E; ++t) a.pkeep[t] = pnew[t];
+        }
+    } else
+    if constexpr (P16) {
+        if (FWD) {
+            float m = pnew[0];
+#pragma unroll
+            for (int t = 1; t < E; ++t) m = fmaxf(m, pnew[t]);
+            const float inv = m > 0.0f ? __builtin_amdgcn_rcpf(m) : 0.0f;          // (v_cvt_pknorm clamps to [0, 1]: the 1-ulp reciprocal cannot overflow)
+            *Ps = m;                                                               // 256 bytes per wave; a plain store (a 4-byte write-through store is 6x the time per byte)
+#pragma unroll
+            for (int g = 0; g < E / 8; ++g) {
+                u32x4_t q;
+                unsigned w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto h2 = __builtin_amdgcn_cvt_pknorm_u16(pnew[8 * g + 2 * i] * inv, pnew[8 * g + 2 * i + 1] * inv);
+                    w[i] = __builtin_bit_cast(unsigned, h2);
+                }
+                q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(&Pq[g * PSTR]), "v"(q) : "memory");
+            }
         }
     } else
     if (FWD && !SSFM_ABL_NO_P) {

@@ -23,6 +23,9 @@
 #ifndef SSFM_STAMPS
 #define SSFM_STAMPS 0
 #endif
+#ifndef SSFM_ABL_LOCALX
+#define SSFM_ABL_LOCALX 0
+#endif
 #if SSFM_STAMPS
 extern __device__ unsigned long long* g_stamp_buf;
 #define SSFM_STAMP(i)                                                                         \
@@ -295,12 +298,31 @@ template <typename T, int L, int E> struct LineTw<T, L, E, true> {
 // per-thread copies were a quarter of a workgroup's whole load traffic.
 __host__ __device__ constexpr int fft_tw_slots_of(int L, int S, int E) { return (E / fft_radix(L, S, E)) * (fft_radix(L, S, E) - 1); }
 __host__ __device__ constexpr int fft_tw_ku(int L, int S, int E) { return fft_ls(L, S, E) < L / E ? fft_ls(L, S, E) : L / E; }
-__host__ __device__ constexpr int fft_tw_offset(int L, int S, int E) {       // first entry of stage S (S >= 1)
-    return S <= 1 ? 0 : fft_tw_offset(L, S - 1, E) + fft_tw_slots_of(L, S - 1, E) * fft_tw_ku(L, S - 1, E);
-}
-__host__ __device__ constexpr int fft_tw_entries(int L, int E) { return fft_tw_offset(L, fft_nstages(L, E), E); }
 // a stage whose table is small is staged through LDS (shared by the workgroup's lines too)
 __host__ __device__ constexpr bool fft_tw_via_lds(int L, int S, int E) { return fft_tw_slots_of(L, S, E) * fft_tw_ku(L, S, E) <= 512; }
+// SSFM_TW_PAIR: a complex64 stage that every thread reads straight from the global table (the last stage of a 4096-point row: 15 factors
+// per thread) stores the factors of slots 2p and 2p+1 side by side: 8 loads of 16 bytes per lane instead of 15 of 8 -- a vector-memory
+// instruction costs a wave the same issue time whether a lane moves 8 or 16 bytes (tools/ubench_load_issue.hip), and these loads stand
+// at the head of k_freq behind the field's.  ts = sizeof of the real type.
+#ifndef SSFM_TW_PAIR
+#define SSFM_TW_PAIR 1
+#endif
+__host__ __device__ constexpr bool fft_tw_paired(int L, int S, int E, int ts) {
+    return SSFM_TW_PAIR != 0 && ts == 4 && SSFM_TW_LAZY_C64 == 0 && !fft_tw_via_lds(L, S, E);
+}
+// table entries of stage S (always an even number, so that every stage starts on a 16-byte boundary)
+__host__ __device__ constexpr int fft_tw_stage_entries(int L, int S, int E, int ts) {
+    return fft_tw_paired(L, S, E, ts) ? ((fft_tw_slots_of(L, S, E) + 1) / 2) * 2 * fft_tw_ku(L, S, E)
+                                      : ((fft_tw_slots_of(L, S, E) * fft_tw_ku(L, S, E) + 1) / 2) * 2;
+}
+__host__ __device__ constexpr int fft_tw_offset(int L, int S, int E, int ts) {       // first entry of stage S (S >= 1)
+    return S <= 1 ? 0 : fft_tw_offset(L, S - 1, E, ts) + fft_tw_stage_entries(L, S - 1, E, ts);
+}
+__host__ __device__ constexpr int fft_tw_entries(int L, int E, int ts) { return fft_tw_offset(L, fft_nstages(L, E), E, ts); }
+// position of (slot, thread class ku) inside stage S
+__host__ __device__ constexpr int fft_tw_index(int L, int S, int E, int ts, int slot, int ku) {
+    return fft_tw_paired(L, S, E, ts) ? ((slot >> 1) * fft_tw_ku(L, S, E) + ku) * 2 + (slot & 1) : slot * fft_tw_ku(L, S, E) + ku;
+}
 __host__ __device__ constexpr int fft_tw_lds_offset(int L, int S, int E) {   // position of stage S in the LDS copy
     return S <= 1 ? 0 : fft_tw_lds_offset(L, S - 1, E) + (fft_tw_via_lds(L, S - 1, E) ? fft_tw_slots_of(L, S - 1, E) * fft_tw_ku(L, S - 1, E) : 0);
 }
@@ -317,8 +339,17 @@ __device__ __forceinline__ void tw_stage_issue(LineTw<T, L, E>& tw, const int j,
                                                const int tid, const int nthreads) {
     constexpr int SLOTS = fft_tw_slots_of(L, S, E);
     constexpr int KU = fft_tw_ku(L, S, E);
-    constexpr int OFF = fft_tw_offset(L, S, E);
-    if constexpr (fft_tw_via_lds(L, S, E)) {
+    constexpr int OFF = fft_tw_offset(L, S, E, (int)sizeof(T));
+    if constexpr (fft_tw_paired(L, S, E, (int)sizeof(T))) {
+        typedef T w4_t __attribute__((ext_vector_type(4)));
+        const w4_t* __restrict__ p4 = reinterpret_cast<const w4_t*>(tab + OFF) + (j & (KU - 1));
+#pragma unroll
+        for (int pr = 0; pr < (SLOTS + 1) / 2; ++pr) {
+            const w4_t q = p4[pr * KU];
+            tw.w[S - 1][2 * pr] = mk<T>(q.x, q.y);
+            if (2 * pr + 1 < SLOTS) tw.w[S - 1][2 * pr + 1] = mk<T>(q.z, q.w);
+        }
+    } else if constexpr (fft_tw_via_lds(L, S, E)) {
         constexpr int LOFF = fft_tw_lds_offset(L, S, E);
         for (int e = tid; e < SLOTS * KU; e += nthreads) ldsT[LOFF + e] = tab[OFF + e];
     } else if constexpr (tw_lazy<T, E, L>()) {
@@ -419,7 +450,14 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
 #endif
     if constexpr (S < M - 1) {
         cx<T>* dst = lds + ((XP + S) & 1) * BUF;
-        if (BUF == 0 && (S > 0 || XP != 0)) __syncthreads();   // single buffer: its readers must be done
+#if SSFM_ABL_LOCALX
+        // timing-only ablation (results WRONG): what the 4096-point row transforms would save if the second exchange of the forward and the
+        // first of the inverse transform needed no workgroup barrier (bit 0), or no exchange took any (bit 1)
+        constexpr bool no_bar = ((SSFM_ABL_LOCALX & 1) && L == 4096 && ((DIR < 0 && S == 1) || (DIR > 0 && S == 0))) || ((SSFM_ABL_LOCALX & 2) && L == 4096);
+#else
+        constexpr bool no_bar = false;
+#endif
+        if (!no_bar && BUF == 0 && (S > 0 || XP != 0)) __syncthreads();   // single buffer: its readers must be done
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int jb = j + i * Q;
@@ -428,7 +466,7 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
 #pragma unroll
             for (int u = 0; u < R; ++u) dst[idx(base + u * LS)] = v[i + u * NB];
         }
-        __syncthreads();
+        if (!no_bar) __syncthreads();
     }
 }
 
