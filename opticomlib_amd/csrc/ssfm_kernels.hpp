@@ -43,6 +43,11 @@
 #ifndef SSFM_LATE_P
 #define SSFM_LATE_P 2
 #endif
+// SSFM_HEAD_ORDER 1: the small tables a workgroup stages through LDS (stage twiddles, the inter-pass twiddle factors) are asked for BEFORE the
+// field loads and committed to LDS while the field is on its way (wgfft.hpp line_twiddles_prefetch); 0: in the order of round 3
+#ifndef SSFM_HEAD_ORDER
+#define SSFM_HEAD_ORDER 1
+#endif
 #ifndef SSFM_LATE_P_C128
 #define SSFM_LATE_P_C128 1
 #endif
@@ -151,7 +156,10 @@ template <typename T> struct AdaptState {
 // (id % 8 labels the group, MI355X_MICROARCH.md), so the rows of a unit take consecutive slots of one
 // group.  Pure speed: any mapping that is a bijection is correct.
 __device__ __forceinline__ void xcd_unit_row(unsigned id, int units, int rows, int& unit, int& row) {
-    if ((units & 7) == 0) {
+    if (rows == 1) {                       // (a lane's launch: no division at the head of the kernel)
+        unit = (int)id;
+        row = 0;
+    } else if ((units & 7) == 0) {
         const unsigned xcd = id & 7, slot = id >> 3;
         unit = (int)((slot / rows) * 8 + xcd);
         row = (int)(slot % rows);
@@ -699,6 +707,25 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     cx<T> w[E];
     T pold[E];
     LineTw<T, N1, E> tw;
+    constexpr bool TWC = twn_compute<T, U16>();
+    constexpr int NT = N1 * C / E;
+    constexpr bool HEAD = SSFM_HEAD_ORDER != 0 && MODE != TM_UNPACK;
+    constexpr int NBS = (E * C + NT - 1) / NT;     // loads per thread of the tile's E x C inter-pass factors
+    TwStaged<T, N1, E, NT> tws;
+    cx<T> bs_pre[NBS];
+    cx<T> wA = mk<T>((T)1, (T)0);
+    if constexpr (HEAD) {
+        // the small tables first (they come back first): the tile's inter-pass factors and the LDS-staged stage twiddles
+        line_twiddles_prefetch<T, N1, E, NT>(tws, a.tw1, tid);
+        if constexpr (TWC) {
+#pragma unroll
+            for (int i = 0; i < NBS; ++i) {
+                const int e = tid + i * NT;
+                bs_pre[i] = (SSFM_ABL_NO_TWN || e >= E * C) ? mk<T>((T)1, (T)0) : a.twB[(long long)tile * (E * C) + e];
+            }
+            if (!SSFM_ABL_NO_TWN) wA = a.twA[(long long)tile * (Q * C) + ltid];
+        }
+    }
     if (U16 && MODE != TM_BEGIN) {               // half-transformed field, or the tile-private time-domain field: 16-byte units
         if constexpr (PK && sizeof(T) == 4) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Yb, 0, (int)(N * (long long)sizeof(cx<T>)), 0x00020000);
@@ -749,11 +776,15 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0 && MODE != TM_BEGIN)>(&src[off + t * stride]);
         }
     }
-    constexpr bool TWC = twn_compute<T, U16>();
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
-    cx<T> wA = mk<T>((T)1, (T)0);
     if constexpr (MODE == TM_UNPACK) {
         // nothing but the field moves
+    } else if constexpr (TWC && HEAD) {
+#pragma unroll
+        for (int i = 0; i < NBS; ++i) {
+            const int e = tid + i * NT;
+            if (e < E * C) Bs[e] = bs_pre[i];
+        }
     } else if constexpr (TWC) {
         // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
         // the tile's E x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
@@ -866,6 +897,10 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     }
     cx<T>* ldsT = Bs + (TWC ? E * C : 0);
     if constexpr (MODE != TM_UNPACK) {
+        if constexpr (HEAD) {
+            line_twiddles_issue_regs<T, N1, E>(tw, j, a.tw1);
+            line_twiddles_commit<T, N1, E, NT>(tws, ldsT, tid);
+        } else
         line_twiddles_issue<T, N1, E>(tw, j, a.tw1, ldsT, tid, N1 * C / E);
         if (fft_tw_lds_entries(N1, E) > 0 || TWC) __syncthreads();
         if constexpr (TWC) {
@@ -1324,6 +1359,9 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     LineTw<T, N2, E> tw;
     SSFM_STAMP(0);
     typedef T u4_t __attribute__((ext_vector_type(4)));
+    constexpr bool HEAD = SSFM_HEAD_ORDER != 0;
+    TwStaged<T, N2, E, ROWS * N2 / E> tws;
+    if constexpr (HEAD) line_twiddles_prefetch<T, N2, E, ROWS * N2 / E>(tws, a.tw2, tid);
     if (U16) {
         // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
         if constexpr (PK && sizeof(T) == 4) {
@@ -1347,7 +1385,8 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0)>(&Frow[j + t * Q]);
     }
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
-    line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
+    if constexpr (HEAD) line_twiddles_issue_regs<T, N2, E>(tw, j, a.tw2);
+    else line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
     unsigned pu[E];
     // SSFM_LATE_TAB (experiment): the phase loads are issued after the first stage of the forward transform instead of with the
     // field loads -- a smaller burst at the head of the kernel, which the tail of the other lane's kernel queues behind
@@ -1385,6 +1424,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SSFM_STAMP(2);
 #endif
+    if constexpr (HEAD) line_twiddles_commit<T, N2, E, ROWS * N2 / E>(tws, ldsT, tid);
     if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
     if (MODE == FM_PHASE && SSFM_LATE_TAB) {

@@ -392,6 +392,65 @@ __device__ __forceinline__ void line_twiddles_issue(LineTw<T, L, E>& tw, const i
     if constexpr (M > 2) tw_stage_issue<T, L, E, 2>(tw, j, tab, ldsT, tid, nthreads);
     if constexpr (M > 3) tw_stage_issue<T, L, E, 3>(tw, j, tab, ldsT, tid, nthreads);
 }
+// The same in three parts, for kernels whose head is a latency chain (k_time, k_freq): the SMALL stages' table entries are asked for
+// FIRST -- before the field loads -- and go to LDS later, while the field is still on its way.  (Vector-memory results return in issue
+// order: staged behind the field loads, as line_twiddles_issue does it, the LDS copy waits for the whole field to land, and the barrier and
+// every load issued after it start a second round trip behind the first: 0.3-0.5 us per kernel, profiles/r04_c2_micro.txt.)
+__host__ __device__ constexpr int fft_tw_prefetch_count(int L, int E, int NT, int S = 1) {
+    return S >= fft_nstages(L, E) ? 0
+         : (fft_tw_via_lds(L, S, E) ? (fft_tw_slots_of(L, S, E) * fft_tw_ku(L, S, E) + NT - 1) / NT : 0) + fft_tw_prefetch_count(L, E, NT, S + 1);
+}
+template <typename T, int L, int E, int NT> struct TwStaged {
+    static constexpr int PF = fft_tw_prefetch_count(L, E, NT);
+    cx<T> r[PF > 0 ? PF : 1];
+};
+template <typename T, int L, int E, int NT, int S>
+__device__ __forceinline__ void tw_stage_prefetch(TwStaged<T, L, E, NT>& p, int& k, const cx<T>* __restrict__ tab, const int tid) {
+    if constexpr (fft_tw_via_lds(L, S, E)) {
+        constexpr int NS = fft_tw_slots_of(L, S, E) * fft_tw_ku(L, S, E), OFF = fft_tw_offset(L, S, E, (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i * NT < NS; ++i) {
+            const int e = tid + i * NT;
+            p.r[k++] = e < NS ? tab[OFF + e] : mk<T>((T)0, (T)0);
+        }
+    }
+}
+template <typename T, int L, int E, int NT, int S>
+__device__ __forceinline__ void tw_stage_commit(const TwStaged<T, L, E, NT>& p, int& k, cx<T>* ldsT, const int tid) {
+    if constexpr (fft_tw_via_lds(L, S, E)) {
+        constexpr int NS = fft_tw_slots_of(L, S, E) * fft_tw_ku(L, S, E), LOFF = fft_tw_lds_offset(L, S, E);
+#pragma unroll
+        for (int i = 0; i * NT < NS; ++i) {
+            const int e = tid + i * NT;
+            if (e < NS) ldsT[LOFF + e] = p.r[k];
+            ++k;
+        }
+    }
+}
+template <typename T, int L, int E, int NT>
+__device__ __forceinline__ void line_twiddles_prefetch(TwStaged<T, L, E, NT>& p, const cx<T>* __restrict__ tab, const int tid) {
+    constexpr int M = fft_nstages(L, E);
+    int k = 0;
+    if constexpr (M > 1) tw_stage_prefetch<T, L, E, NT, 1>(p, k, tab, tid);
+    if constexpr (M > 2) tw_stage_prefetch<T, L, E, NT, 2>(p, k, tab, tid);
+    if constexpr (M > 3) tw_stage_prefetch<T, L, E, NT, 3>(p, k, tab, tid);
+}
+template <typename T, int L, int E, int NT>
+__device__ __forceinline__ void line_twiddles_commit(const TwStaged<T, L, E, NT>& p, cx<T>* ldsT, const int tid) {
+    constexpr int M = fft_nstages(L, E);
+    int k = 0;
+    if constexpr (M > 1) tw_stage_commit<T, L, E, NT, 1>(p, k, ldsT, tid);
+    if constexpr (M > 2) tw_stage_commit<T, L, E, NT, 2>(p, k, ldsT, tid);
+    if constexpr (M > 3) tw_stage_commit<T, L, E, NT, 3>(p, k, ldsT, tid);
+}
+// the stages that every thread reads for itself (registers, or the lazy pointers)
+template <typename T, int L, int E>
+__device__ __forceinline__ void line_twiddles_issue_regs(LineTw<T, L, E>& tw, const int j, const cx<T>* __restrict__ tab) {
+    constexpr int M = fft_nstages(L, E);
+    if constexpr (M > 1 && !fft_tw_via_lds(L, 1, E)) tw_stage_issue<T, L, E, 1>(tw, j, tab, nullptr, 0, 1);
+    if constexpr (M > 2 && !fft_tw_via_lds(L, 2, E)) tw_stage_issue<T, L, E, 2>(tw, j, tab, nullptr, 0, 1);
+    if constexpr (M > 3 && !fft_tw_via_lds(L, 3, E)) tw_stage_issue<T, L, E, 3>(tw, j, tab, nullptr, 0, 1);
+}
 // Phase 2 (after the barrier): LDS -> registers
 template <typename T, int L, int E>
 __device__ __forceinline__ void line_twiddles_fetch(LineTw<T, L, E>& tw, const int j, const cx<T>* ldsT) {
