@@ -48,6 +48,12 @@
 #ifndef SSFM_HEAD_ORDER
 #define SSFM_HEAD_ORDER 1
 #endif
+#ifndef SSFM_EARLY_PHASE
+#define SSFM_EARLY_PHASE 1
+#endif
+#ifndef SSFM_KERNARG_UPFRONT
+#define SSFM_KERNARG_UPFRONT 1
+#endif
 #ifndef SSFM_LATE_P_C128
 #define SSFM_LATE_P_C128 1
 #endif
@@ -672,6 +678,13 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     T hh_prev = a.hh_prev, hh_next = a.hh_next;
     const int tid = threadIdx.x;
     SSFM_TRACE_BEGIN(a);
+#if SSFM_KERNARG_UPFRONT
+    if constexpr (!PK) {
+        // every kernel argument the head of the kernel needs, asked for in ONE scalar-load clause at the entry: left to itself the compiler fetches
+        // Y and P in a later block, behind a second wait (a scalar-cache miss of its own) that stands in front of the field loads
+        asm volatile("" : : "s"(a.Y), "s"(a.P), "s"(a.F), "s"(a.twA), "s"(a.twB), "s"(a.tw1), "s"(a.N2), "s"(a.rows), "s"(a.st));
+    }
+#endif
     // plain: thread = j * C + c.  U16: lane = h * 32 + (j mod 4) * 8 + c8, column c = h * 8 + c8 (see "U16" above)
     const int c = U16 ? (((tid >> 5) & 1) << 3) | (tid & 7) : tid % C;
     const int j = U16 ? ((tid >> 6) << 2) | ((tid >> 3) & 3) : tid / C;
@@ -1360,8 +1373,25 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     SSFM_STAMP(0);
     typedef T u4_t __attribute__((ext_vector_type(4)));
     constexpr bool HEAD = SSFM_HEAD_ORDER != 0;
+    // SSFM_EARLY_PHASE: the phase loads go out BEFORE the field loads (results return in issue order) and amp * exp(i phase) is formed while the
+    // field is on its way -- 200 instructions per thread off the workgroup's critical path (the head of a kernel is a wait of 1-2 us)
+    constexpr bool EARLY_PHASE = HEAD && SSFM_EARLY_PHASE != 0 && MODE == FM_PHASE && !SSFM_LATE_TAB;
     TwStaged<T, N2, E, ROWS * N2 / E> tws;
     if constexpr (HEAD) line_twiddles_prefetch<T, N2, E, ROWS * N2 / E>(tws, a.tw2, tid);
+    unsigned pu[E];
+    // SSFM_LATE_TAB (experiment): the phase loads are issued after the first stage of the forward transform instead of with the
+    // field loads -- a smaller burst at the head of the kernel, which the tail of the other lane's kernel queues behind
+    auto load_phases = [&]() {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ P4 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(a.tab) + (long long)k1 * N2) + j;
+#pragma unroll
+        for (int g = 0; g < E / 4; ++g) {
+            u32x4 q;
+            if (SSFM_ABL_NO_TAB) q = 0x12345678u; else q = P4[g * Q];
+            pu[4 * g] = q.x; pu[4 * g + 1] = q.y; pu[4 * g + 2] = q.z; pu[4 * g + 3] = q.w;
+        }
+    };
+    if constexpr (EARLY_PHASE) load_phases();
     if (U16) {
         // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
         if constexpr (PK && sizeof(T) == 4) {
@@ -1387,21 +1417,8 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
     if constexpr (HEAD) line_twiddles_issue_regs<T, N2, E>(tw, j, a.tw2);
     else line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
-    unsigned pu[E];
-    // SSFM_LATE_TAB (experiment): the phase loads are issued after the first stage of the forward transform instead of with the
-    // field loads -- a smaller burst at the head of the kernel, which the tail of the other lane's kernel queues behind
-    auto load_phases = [&]() {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4* __restrict__ P4 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(a.tab) + (long long)k1 * N2) + j;
-#pragma unroll
-        for (int g = 0; g < E / 4; ++g) {
-            u32x4 q;
-            if (SSFM_ABL_NO_TAB) q = 0x12345678u; else q = P4[g * Q];
-            pu[4 * g] = q.x; pu[4 * g + 1] = q.y; pu[4 * g + 2] = q.z; pu[4 * g + 3] = q.w;
-        }
-    };
     if (MODE == FM_PHASE) {
-        if (!SSFM_LATE_TAB) load_phases();
+        if (!SSFM_LATE_TAB && !EARLY_PHASE) load_phases();
     } else if (MODE != FM_FWD_ONLY) {
         typedef T m4_t __attribute__((ext_vector_type(4)));
         const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(trow) + j;
@@ -1425,6 +1442,11 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     SSFM_STAMP(2);
 #endif
     if constexpr (HEAD) line_twiddles_commit<T, N2, E, ROWS * N2 / E>(tws, ldsT, tid);
+    if constexpr (EARLY_PHASE) {
+#pragma unroll
+        for (int t = 0; t < E; ++t) m[t] = phase32_factor(pu[t], a.amp);
+        __builtin_amdgcn_sched_barrier(0);          // (keeps the factors ahead of the wait for the field)
+    }
     if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
     if (MODE == FM_PHASE && SSFM_LATE_TAB) {
@@ -1451,7 +1473,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         const T e0 = exp_acc<T>(m[0].x * h);
         fly_factors<E>(m, ph, flat, e0, h, a.inv_n);
     }
-    if (MODE == FM_PHASE) {
+    if (MODE == FM_PHASE && !EARLY_PHASE) {
 #pragma unroll
         for (int t = 0; t < E; ++t) m[t] = phase32_factor(pu[t], a.amp);
     }
