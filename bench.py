@@ -24,8 +24,16 @@ fields are then gathered to rank 0 in GPU memory by ONE RCCL collective on the p
 Launching.  `--gpus N` with N > 1 (or `--workload c3|c4` at any N, so that the RCCL gather really runs) and no RANK in the
 environment: this process -- BEFORE it imports torch or touches a GPU -- starts
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>
-as a child, lets the child's rank 0 print the JSON line on the inherited stdout and exits with the child's code.  Under
-torch.distributed.run itself (RANK set) it is one of the ranks.  Prints ONE JSON line on rank 0.
+as a child, passes on the ONE JSON line of the child's rank 0 and exits with the child's code.  Under torch.distributed.run itself
+(RANK set) it is one of the ranks.  Prints ONE JSON line on rank 0.
+
+stdout carries the JSON line and nothing else: every rank points file descriptor 1 at stderr before any library is loaded (RCCL prints a
+five-line version banner and gloo its connection report on the C-level stdout) and keeps a private duplicate of the real stdout for the
+line; a self-launching parent also filters its child's stdout down to the last JSON line.
+
+CPU placement: before anything touches a GPU every rank pins itself (os.sched_setaffinity) to the cores of its GPU's NUMA node
+(/sys/class/drm/card*/device/numa_node -> /sys/devices/system/node/nodeK/cpulist), split between the ranks that share the node; the set is
+reported as `cpu_affinity`.  A two-lane run is sensitive to the host's enqueue rate.  BENCH_NO_PIN=1 leaves the affinity alone.
 """
 from __future__ import annotations
 
@@ -62,6 +70,118 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    """fd 1 -> stderr for everything that is not the JSON line (C libraries included); returns nothing, remembers the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is not None:
+        return
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(os.dup(2), "w", buffering=1)          # Python-level prints of imported modules follow
+
+
+def emit_json_line(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while line:
+        line = line[os.write(fd, line):]
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes():
+    """NUMA node of every GPU in HIP's enumeration order, -1 where the kernel does not say.  HIP numbers the GPUs in the order of the KFD
+    topology nodes (/sys/class/kfd/kfd/topology/nodes/N/properties: simd_count > 0, PCI domain + location_id); without that directory:
+    PCI address order of the amdgpu DRM cards."""
+    import glob
+    nodes = []
+    kfd = []
+    for pth in glob.glob("/sys/class/kfd/kfd/topology/nodes/[0-9]*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(pth).read().splitlines() if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            addr = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+            kfd.append((int(os.path.basename(os.path.dirname(pth))), addr))
+        except (OSError, ValueError, KeyError):
+            continue
+    if kfd:
+        for _, addr in sorted(kfd):
+            try:
+                nodes.append(int(open(f"/sys/bus/pci/devices/{addr}/numa_node").read().strip()))
+            except (OSError, ValueError):
+                nodes.append(-1)
+        return nodes
+    cards = []
+    for dev in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        if os.path.basename(os.path.dirname(dev)).count("-"):
+            continue                                             # connectors (card0-DP-1)
+        try:
+            if "amdgpu" not in os.path.realpath(os.path.join(dev, "driver")):
+                continue
+            cards.append((os.path.basename(os.path.realpath(dev)), dev))
+        except OSError:
+            continue
+    for _, dev in sorted(cards):
+        try:
+            nodes.append(int(open(os.path.join(dev, "numa_node")).read().strip()))
+        except (OSError, ValueError):
+            nodes.append(-1)
+    return nodes
+
+
+def plan_affinity(local_rank, world, nodes, node_cpus, allowed):
+    """The CPU set of rank `local_rank`: the allowed cores of its GPU's NUMA node, dealt evenly to the ranks whose GPUs share that node
+    (rank r takes every k-th core from its position among them).  None = leave the affinity alone (unknown topology, or too few cores)."""
+    if local_rank >= len(nodes) or nodes[local_rank] < 0:
+        return None
+    node = nodes[local_rank]
+    cores = sorted(node_cpus.get(node, set()) & allowed)
+    sharers = [r for r in range(min(world, len(nodes))) if nodes[r] == node]
+    if local_rank not in sharers or len(cores) < 2 * len(sharers):
+        return None
+    k = sharers.index(local_rank)
+    per = len(cores) // len(sharers)
+    return set(cores[k * per:(k + 1) * per])
+
+
+def pin_to_gpu_node(local_rank, world):
+    """Pin this process before it initialises a GPU; returns a short description for the JSON line."""
+    if os.environ.get("BENCH_NO_PIN"):
+        return "unchanged (BENCH_NO_PIN)"
+    try:
+        allowed = os.sched_getaffinity(0)
+        nodes = gpu_numa_nodes()
+        import glob
+        node_cpus = {}
+        for nd in glob.glob("/sys/devices/system/node/node[0-9]*"):
+            try:
+                node_cpus[int(os.path.basename(nd)[4:])] = _parse_cpulist(open(os.path.join(nd, "cpulist")).read())
+            except (OSError, ValueError):
+                pass
+        want = plan_affinity(local_rank, world, nodes, node_cpus, allowed)
+        if not want:
+            return f"unchanged ({len(allowed)} cores; GPU NUMA nodes {nodes or 'unknown'})"
+        os.sched_setaffinity(0, want)
+        lo, hi = min(want), max(want)
+        return f"{len(want)} cores {lo}-{hi} of NUMA node {nodes[local_rank]} (GPU {local_rank})"
+    except Exception as e:                                        # never fail a bench run over placement
+        return f"unchanged ({type(e).__name__}: {e})"
+
+
 def self_launch(args, argv):
     """Start the ranks as a fresh child (nothing in THIS process has touched a GPU, torch is not even imported) and
     hand on its exit code.  The child's rank 0 writes the JSON line to the stdout it inherits."""
@@ -76,7 +196,23 @@ def self_launch(args, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     sys.stdout.flush()
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks keep their stdout clean themselves (guard_stdout); should anything still reach it, only the last JSON line is passed on
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in proc.stdout.decode(errors="replace").splitlines():
+        t = raw.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        if t:
+            print(raw, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode
 
 
 def cpu_baseline(a, dt, fibre, sample_steps):
@@ -196,12 +332,15 @@ def main():
     if "RANK" not in os.environ and (args.gpus > 1 or args.workload in ("c3", "c4")):
         sys.exit(self_launch(args, argv))
 
+    guard_stdout()                                    # before any library can print on it
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu_affinity = pin_to_gpu_node(0 if os.environ.get("BENCH_SAME_GPU") else local_rank, int(os.environ.get("WORLD_SIZE", "1")))
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("BENCH_SAME_GPU"):             # diagnostics only: every rank on GPU 0 (needs BENCH_DIST_BACKEND=gloo: RCCL wants one GPU per rank)
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -446,7 +585,7 @@ def main():
         "c4": (f"C4: {C4_SEEDS} Monte-Carlo PRBS realisations (LFSR seeds 1..{C4_SEEDS}, generated on the device), 2^20-sample dual-pol, FIBER(100 x 1 km) + "
                f"DBP(100 x 1 km) back to back in GPU memory, complex64, unit i on rank i % {world}, {C4_RESIDENT} resident per plan"),
     }
-    print(json.dumps({
+    emit_json_line({
         "metric": "SSFM sample*steps/sec, 2^20-sample dual-pol fiber",
         "value": value,
         "unit": "sample*steps/s",
@@ -476,7 +615,8 @@ def main():
         "cpu_baseline": cpu,
         **({"cpu_baseline_manycore": cpu_many} if cpu_many else {}),
         **({"secondary": other} if other else {}),
-    }))
+        "cpu_affinity": cpu_affinity,
+    })
 
 
 if __name__ == "__main__":

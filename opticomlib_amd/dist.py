@@ -93,6 +93,31 @@ def _real_dtype(dt: np.dtype):
 COLLECTIVES = {"all_gather_into_tensor": 0, "gather": 0}
 
 
+# ---- the arithmetic of gather_device, on plain torch tensors (any device): what tests/test_dist_cpu.py runs for world sizes no box has offered yet
+def gather_layout(n_units: int, ws: int):
+    """(units per rank incl. padding, whether the collective's rank-major receive buffer IS the result in unit order)."""
+    per_rank = -(-n_units // ws)                                                    # ceil: ranks with fewer units pad
+    in_place = ws * per_rank == n_units and (ws == 1 or per_rank == 1)
+    return per_rank, in_place
+
+
+def pad_send(local, n_local: int, per_rank: int, per_unit: int):
+    """A rank's send buffer: its ``n_local`` units as they lie (no copy when the rank owns ``per_rank`` of them), zero padded otherwise."""
+    import torch
+    if n_local == per_rank:
+        return local
+    send = torch.zeros(per_rank * per_unit, dtype=local.dtype, device=local.device)
+    if n_local:
+        send[: n_local * per_unit].copy_(local[: n_local * per_unit])
+    return send
+
+
+def rank_major_to_unit_order(got, dst, ws: int, per_rank: int, per_unit: int, n_units: int):
+    """``got[r, k]`` is unit ``k * ws + r`` (unit i lives on rank i % ws): one strided copy into unit order, the padding dropped."""
+    dst.view(n_units, per_unit).copy_(got.view(ws, per_rank, per_unit).transpose(0, 1).reshape(ws * per_rank, per_unit)[:n_units])
+    return dst
+
+
 def gather_device(local_ptr: int, n_local: int, unit_shape, dtype, n_units: int, device: int, to_all: bool = True, owner=None,
                   force_collective: bool = True):
     """Gather per-unit results that lie side by side in the memory of GPU ``device`` (``n_local`` units of
@@ -113,18 +138,16 @@ def gather_device(local_ptr: int, n_local: int, unit_shape, dtype, n_units: int,
     dtype = np.dtype(dtype)
     rdt = _real_dtype(dtype)
     per_unit = int(np.prod(unit_shape)) * (2 if dtype.kind == "c" else 1)          # real numbers per unit
-    per_rank = -(-n_units // ws)                                                    # ceil: ranks with fewer units pad
+    per_rank, unit_order = gather_layout(n_units, ws)
     dev = torch.device("cuda", device)
     tdt = torch.float64 if rdt == np.float64 else torch.float32
-    if n_local == per_rank:
-        send = _torch_view(local_ptr, per_rank * per_unit, rdt, device, owner)      # as it lies
+    if n_local:
+        send = pad_send(_torch_view(local_ptr, n_local * per_unit, rdt, device, owner), n_local, per_rank, per_unit)      # as it lies when n_local == per_rank
     else:
         send = torch.zeros(per_rank * per_unit, dtype=tdt, device=dev)
-        if n_local:
-            send[: n_local * per_unit].copy_(_torch_view(local_ptr, n_local * per_unit, rdt, device, owner))
     need = to_all or rank == 0
     collective = _device_backend() and (ws > 1 or force_collective)
-    in_place = need and ws * per_rank == n_units and (ws == 1 or per_rank == 1)     # rank-major order IS unit order
+    in_place = need and unit_order                                                  # rank-major order IS unit order
     out = _lib.DeviceArray((n_units,) + tuple(unit_shape), dtype, device) if need else None
     dst = _torch_view(out.ptr, n_units * per_unit, rdt, device, out) if need else None
     got = None
@@ -142,8 +165,7 @@ def gather_device(local_ptr: int, n_local: int, unit_shape, dtype, n_units: int,
         dist.gather(send, list(got.chunk(ws)) if rank == 0 else None, dst=0)
         COLLECTIVES["gather"] += 1
     if need and not in_place:
-        # got[r, k] is unit k * ws + r: rank-major -> unit order (one strided device copy)
-        dst.view(n_units, per_unit).copy_(got.view(ws, per_rank, per_unit).transpose(0, 1).reshape(ws * per_rank, per_unit)[:n_units])
+        rank_major_to_unit_order(got, dst, ws, per_rank, per_unit, n_units)       # (one strided device copy)
     torch.cuda.synchronize(dev)              # on EVERY rank: the collective has read `send` (a plan's field buffer) when we return
     return out
 

@@ -49,3 +49,91 @@ def test_two_rank_gloo_matches_serial(tmp_path, n_units):
         assert len(got.files) == n_units
         for u in range(n_units):
             np.testing.assert_array_equal(got[f"arr_{u}"], want[u])
+
+
+@pytest.mark.parametrize("ws", [1, 2, 3, 8])
+@pytest.mark.parametrize("n_units", [5, 8, 64, 1])
+def test_gather_device_arithmetic_against_a_numpy_model(ws, n_units):
+    """The padding and the rank-major -> unit-order copy of dist.gather_device (the one piece of multi-rank logic that a one-GPU box
+    never executes with more than one rank), run on CPU tensors for every rank of a simulated world against a plain NumPy model."""
+    import torch
+    per_unit = 6
+    per_rank, unit_order = od.gather_layout(n_units, ws)
+    assert per_rank == -(-n_units // ws) and per_rank * ws >= n_units
+    units = np.arange(n_units * per_unit, dtype=np.float32).reshape(n_units, per_unit) + 0.5          # unit u = row u
+    chunks = []
+    for r in range(ws):
+        mine = od.shard(n_units, r, ws)
+        local = torch.from_numpy(units[mine].reshape(-1).copy()) if mine else torch.zeros(0, dtype=torch.float32)
+        send = od.pad_send(local, len(mine), per_rank, per_unit) if mine else torch.zeros(per_rank * per_unit, dtype=torch.float32)
+        assert send.numel() == per_rank * per_unit
+        if len(mine) == per_rank:
+            assert send.data_ptr() == local.data_ptr()          # as it lies: the plan's field buffer is the send buffer
+        else:
+            assert torch.all(send[len(mine) * per_unit:] == 0)
+        chunks.append(send)
+    got = torch.cat(chunks)                                     # what all_gather_into_tensor / gather leave on the receiving rank
+    if unit_order:
+        # the collective may write straight into the result
+        np.testing.assert_array_equal(got.numpy().reshape(-1, per_unit)[:n_units], units)
+        assert ws == 1 or per_rank == 1
+    dst = torch.full((n_units * per_unit,), -1.0)
+    od.rank_major_to_unit_order(got, dst, ws, per_rank, per_unit, n_units)
+    np.testing.assert_array_equal(dst.numpy().reshape(n_units, per_unit), units)
+    # the NumPy model of the same: unit k * ws + r sits at [r, k]
+    model = np.full((n_units, per_unit), -1.0, np.float32)
+    g = got.numpy().reshape(ws, per_rank, per_unit)
+    for r in range(ws):
+        for k in range(per_rank):
+            if k * ws + r < n_units:
+                model[k * ws + r] = g[r, k]
+    np.testing.assert_array_equal(model, units)
+
+
+def test_bench_cpu_placement_plan():
+    """bench.py's rank -> CPU set rule (pure arithmetic; the sysfs reads are best effort)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    node_cpus = {0: set(range(0, 64)) | set(range(128, 192)), 1: set(range(64, 128)) | set(range(192, 256))}
+    sets = [bench.plan_affinity(r, 8, nodes, node_cpus, set(range(256))) for r in range(8)]
+    assert all(len(s) == 32 for s in sets)
+    for r in range(8):
+        assert sets[r] <= node_cpus[nodes[r]]
+        for q in range(r):
+            assert not (sets[r] & sets[q])
+    # fewer ranks than GPUs: only the ranks that exist share a node's cores
+    assert len(bench.plan_affinity(0, 2, nodes, node_cpus, set(range(256)))) == 64
+    assert len(bench.plan_affinity(0, 1, nodes, node_cpus, set(range(256)))) == 128
+    # a container that allows 8 cores, unknown topology, too few cores: leave the affinity alone
+    assert bench.plan_affinity(0, 1, [], node_cpus, set(range(8))) is None
+    assert bench.plan_affinity(0, 1, [-1], node_cpus, set(range(8))) is None
+    assert bench.plan_affinity(0, 8, nodes, node_cpus, {0}) is None
+    assert isinstance(bench.pin_to_gpu_node(0, 1), str)
+
+
+def test_bench_self_launch_passes_only_the_json_line(tmp_path, monkeypatch):
+    """A child that prints a banner before and after its JSON line (as RCCL / gloo do on the C-level stdout): the parent's stdout is the line."""
+    sys.path.insert(0, ROOT)
+    fake = tmp_path / "torch" / "distributed"
+    fake.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (fake / "__init__.py").write_text("")
+    (fake / "run.py").write_text("import sys\nprint('RCCL version : 2.26.6')\nprint('{\"metric\": \"m\", \"value\": 1.5}')\nprint('[Gloo] Rank 0 is connected')\nsys.exit(3)\n")
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.self_launch(bench.parse_args(['--gpus', '2']), ['--gpus', '2']))") % (str(tmp_path), ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, PYTHONPATH=str(tmp_path)))
+    assert r.returncode == 3
+    assert r.stdout == '{"metric": "m", "value": 1.5}\n'
+    assert "RCCL version" in r.stderr and "Gloo" in r.stderr
+
+
+def test_bench_ranks_keep_stdout_for_the_json_line():
+    """guard_stdout(): whatever a library writes to file descriptor 1 afterwards (RCCL's banner is a C-level printf) lands on stderr."""
+    code = ("import sys, os; sys.path.insert(0, %r); import bench; bench.guard_stdout(); os.write(1, b'RCCL version : x\\n'); "
+            "print('python-level chatter'); bench.emit_json_line({'value': 2})") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"value": 2}\n'
+    assert "RCCL version" in r.stderr and "chatter" in r.stderr
