@@ -452,10 +452,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # plan set-up, not part of the protocol's warm-up: first touch of every buffer and table (and, with
-    # SSFM_GRAPH=auto, the library's eager-vs-graph measurement, which needs four runs of the schedule)
-    for _ in range(4 if os.environ.get("SSFM_GRAPH", "")[:1] in ("a", "A") else 1):
-        one_step()
+    # plan set-up, not part of the protocol's warm-up: first touch of every buffer and table
+    one_step()
     fence()
     for _ in range(args.warmup):
         one_step()

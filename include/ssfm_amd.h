@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SSFM_ABI_VERSION 1
+#define SSFM_ABI_VERSION 2
 
 enum ssfm_status {
     SSFM_OK = 0,
@@ -91,7 +91,14 @@ int ssfm_set_linear_operator(ssfm_plan* plan, const void* dtilde_host);
 int ssfm_set_field(ssfm_plan* plan, const void* src, int is_device);
 int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device);
 /* Device address of the plan's resident field (batch*n complex), natural time order
- * between propagate calls. */
+ * between propagate calls.
+ * WHEN THE FIELD IS VALID.  Runs are asynchronous: the result is in the field buffer once ssfm_synchronize / ssfm_get_field has
+ * returned SSFM_OK.  A caller that orders its OWN work behind a run on the plan's stream (ssfm_stream) instead may do so: from the
+ * first call of ssfm_field_device_ptr or ssfm_stream on a plan, ssfm_propagate_fixed resolves the one kind of run whose success is only
+ * known at its end -- the one-launch engine of plans of 2^12 ... 2^17 samples, whose workgroups meet inside the launch and give up
+ * when the GPU does not run them side by side; the run is then repeated on the launch-per-pass engine -- BEFORE it returns (for such
+ * plans the call is then synchronous).  Every other engine either needs no fallback or resolves it inside the call already.
+ * ssfm_last_run_info tells which engine a run took and whether it fell back. */
 void* ssfm_field_device_ptr(ssfm_plan* plan);
 
 /* Fixed-step run (reference devices.py:1172-1196 with h given).
@@ -284,8 +291,9 @@ int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt
 /* ... and the ADAPTIVE run (h = phi_max / (|gamma| max |A|^2) over all rows, clamped to what is left of `length`; the rule of ssfm_chirp_propagate, in
  * float32 arithmetic when f32 != 0) in one launch: the rows' workgroups exchange their maxima through memory every step (k_small_chirp_adapt).  At
  * most 16 rows.  z_out (HOST, nullable, max_steps + 1 entries) receives z after every step, *steps_out the steps taken.  Synchronous.
- * SSFM_ERR_UNSUPPORTED with the field untouched: no such plan, or the rows' workgroups did not meet within the patience (SSFM_FUSED_PATIENCE_TICKS; a
- * device too busy to keep them resident together) -- ssfm_chirp_propagate then queues the run step by step. */
+ * SSFM_ERR_UNSUPPORTED with the field as it came: no such plan, or the rows' workgroups did not meet within the patience (SSFM_FUSED_PATIENCE_TICKS; a
+ * device too busy to keep them resident together; rows that had finished by then are put back from a copy taken before the launch) --
+ * ssfm_chirp_propagate then queues the run step by step. */
 int ssfm_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int f32,
                            int64_t max_steps, double* z_out, int64_t* steps_out);
 /* The chirp c_m = exp(-i pi m^2 / n) of that identity, generated on the device with its phase reduced exactly in
@@ -326,8 +334,38 @@ int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, vo
 int ssfm_debug_fft(ssfm_plan* plan, void* dst);
 
 int ssfm_synchronize(ssfm_plan* plan);
-/* The plan's hipStream_t (as void*), so callers can record events around propagate calls. */
+/* The plan's hipStream_t (as void*), so callers can record events around propagate calls or order their own work behind a run (see
+ * "WHEN THE FIELD IS VALID" at ssfm_field_device_ptr). */
 void* ssfm_stream(ssfm_plan* plan);
+
+/* Which engine the plan's last run took, and whether it had to be repeated on a fallback.  The engines differ in speed only (same results
+ * within the stated tolerances); the single-launch ones need the GPU to run all their workgroups side by side and fall back, after a bounded
+ * wait, when it does not (a shared GPU, a profiler): without this query that is invisible to the caller.
+ *   engine            a value of enum ssfm_engine below: the engine that produced the result of the LAST run (after a fallback: the fallback)
+ *   fell_back         1: the last run was started on a single-launch engine, gave up and was repeated
+ *   fallbacks_total   such repeats over the life of the plan (a plan keeps to the fallback engine after the first)
+ *   lanes_share_queue 1: the runtime could not give the plan's lanes hardware queues of their own (more than four high-priority streams
+ *                     alive and eight replacement streams all mapped to a taken queue): fixed-step lanes then run one after the other
+ * Any pointer may be NULL.  For a run whose fallback is resolved lazily (see ssfm_field_device_ptr) call ssfm_synchronize first. */
+enum ssfm_engine {
+    SSFM_ENGINE_NONE = 0,
+    SSFM_ENGINE_TWO_KERNEL = 1,        /* fixed step: two launches per step (k_time, k_freq), one stream per lane */
+    SSFM_ENGINE_SMALL = 2,             /* fixed step: one launch per run, a workgroup per row (<= 8192 samples) */
+    SSFM_ENGINE_MEDIUM = 3,            /* fixed step: one launch per run on one XCD (2^12 ... 2^17 samples) */
+    SSFM_ENGINE_ADAPT_3 = 4,           /* adaptive: three launches per step */
+    SSFM_ENGINE_ADAPT_FUSED = 5,       /* adaptive: two launches per step, the step size found inside the column launch */
+    SSFM_ENGINE_SMALL_ADAPT = 6,       /* adaptive: one launch per run, one workgroup */
+    SSFM_ENGINE_MEDIUM_ADAPT = 7,      /* adaptive: one launch per run on one XCD */
+    SSFM_ENGINE_CHIRP_SMALL = 8,       /* any length <= 2048: fixed step, one launch per run */
+    SSFM_ENGINE_CHIRP_SMALL_ADAPT = 9, /* any length <= 2048: adaptive, one launch per run */
+    SSFM_ENGINE_CHIRP_STEPS = 10       /* any length: five launches per step (seven adaptive) */
+};
+int ssfm_last_run_info(ssfm_plan* plan, int* engine, int* fell_back, int64_t* fallbacks_total, int* lanes_share_queue);
+
+/* A device buffer of at least `bytes` bytes owned by the plan (slot 0 ... 3; grows on demand, freed with the plan; contents undefined between
+ * calls; a growing call waits for the plan's stream).  For driver loops above this ABI that need scratch memory per call
+ * (ssfm_chirp_propagate: its exp(D~ h) table, step control block and z log) without a hipMalloc / hipFree pair each time. */
+int ssfm_plan_workspace(ssfm_plan* plan, int slot, size_t bytes, void** out);
 
 /* Time of the last propagate call measured with HIP events on the plan's stream [ms], and the
  * number of kernel launches it made.  Valid after ssfm_synchronize. */

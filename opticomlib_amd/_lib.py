@@ -80,6 +80,8 @@ SYMBOLS = {
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
     "ssfm_last_propagate_ms": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(_I64)]),
+    "ssfm_last_run_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I64), C.POINTER(_I)]),
+    "ssfm_plan_workspace": (_I, [_VP, _I, C.c_size_t, C.POINTER(_VP)]),
     "ssfm_set_profiling": (_I, [_VP, _I]),
     "ssfm_kernel_times": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
     "ssfm_num_lanes": (_I, [_VP, C.POINTER(_I)]),
@@ -95,6 +97,11 @@ SYMBOLS = {
     "ssfm_load_bits": (_I, [_VP, _I64, _VP, _I64, _I]),
     "ssfm_load_qpsk": (_I, [_VP, _I64, _I, _VP, _I64, _I]),
 }
+
+
+# enum ssfm_engine of include/ssfm_amd.h, by value
+ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adaptive_fused", "small_adaptive", "medium_adaptive",
+           "chirp_small", "chirp_small_adaptive", "chirp_steps")
 
 
 class SsfmError(RuntimeError):
@@ -118,8 +125,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.ssfm_abi_version() != 1:
-        raise SsfmError(f"ABI version mismatch: library reports {lib.ssfm_abi_version()}, binding expects 1")
+    if lib.ssfm_abi_version() != 2:
+        raise SsfmError(f"ABI version mismatch: library reports {lib.ssfm_abi_version()}, binding expects 2")
     _lib = lib
     return lib
 
@@ -698,6 +705,16 @@ class Plan:
         ms = (_D * 2)()
         _check(load().ssfm_kernel_times(self._h, cnt, ms), "ssfm_kernel_times")
         return {"k_time": (cnt[0], ms[0]), "k_freq": (cnt[1], ms[1])}
+
+    def last_run_info(self) -> dict:
+        """Which engine the last run took (``ENGINES``), whether it had to be repeated on a fallback, such repeats over the plan's life,
+        and whether the plan's lanes share a hardware queue (include/ssfm_amd.h ``ssfm_last_run_info``).  Synchronises first: a one-launch
+        run of a medium plan knows at its end whether its workgroups met."""
+        _check(load().ssfm_synchronize(self._h), "ssfm_synchronize")
+        e, f, t, q = _I(0), _I(0), _I64(0), _I(0)
+        _check(load().ssfm_last_run_info(self._h, C.byref(e), C.byref(f), C.byref(t), C.byref(q)), "ssfm_last_run_info")
+        return {"engine": ENGINES[e.value] if 0 <= e.value < len(ENGINES) else str(e.value), "fell_back": bool(f.value),
+                "fallbacks_total": int(t.value), "lanes_share_queue": bool(q.value)}
 
     def last_propagate_ms(self):
         ms, n = C.c_float(0), _I64(0)

@@ -17,7 +17,7 @@
 // (batch x N, natural order) and the plan's field buffer (batch x M); nothing synchronises with the host.
 #include <hip/hip_runtime.h>
 
-#include <chrono>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -230,74 +230,56 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     if (!A || !P || !chirp || !Dt) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: NULL argument");
     const unsigned gM = blocks_for(t.M * batch), gN = blocks_for((long long)n * batch);
     const double scale = 1.0 / (double)n;
-    // The middle of a step -- inverse pass of the first convolution, product with exp(D~ h), forward pass of the second -- as ONE column launch
-    // (ssfm_apply_tables_mul) with the factors from a table: seven launches per fixed step instead of nine (the table of a repeated step size is
-    // kept), nine instead of ten per adaptive step.  SSFM_CHIRP_FUSED=0: the three-launch middle.
-    const char* fe = std::getenv("SSFM_CHIRP_FUSED");
-    bool fused_mid = !(fe && std::atoi(fe) == 0);
+    // A step is FIVE launches (seven in adaptive mode): the middle of it -- inverse pass of the first convolution, product with exp(D~ h), forward pass
+    // of the second -- is one column launch with the factors from a table (kept while the step size repeats), and the step's two ends -- chirp
+    // products, half nonlinear steps, zero padding, the maximum of |A|^2 -- run inside the first and the last column launch (ssfm_chirp_step).
+    // (The nine- and seven-launch forms this grew out of in round 3 -- 33 / 25.6 against 22 us per step at n = 2032, profiles/r03_anyn_small.txt --
+    // were removed in round 4 together with their environment switches.)
     double2* mtab = nullptr;
+    if (int rc = ssfm_plan_workspace(plan, 0, sizeof(double2) * (size_t)t.M, reinterpret_cast<void**>(&mtab))) return rc;
     double mtab_h = 0.0;
     bool mtab_set = false;
-    struct Free { double2*& p; ~Free() { if (p) (void)hipFree(p); } } free_mtab{mtab};
-    if (fused_mid) HIP_TRY(hipMalloc(&mtab, sizeof(double2) * (size_t)t.M));
-    // ... and the step's two ends -- the chirp products, the half nonlinear steps, the zero padding, the maximum -- inside the first and the last of
-    // those column launches (ssfm_chirp_step): five launches per fixed step, seven per adaptive step.  SSFM_CHIRP_ENDS=0: the separate kernels.
-    const char* ee = std::getenv("SSFM_CHIRP_ENDS");
-    bool fused_ends = fused_mid && !(ee && std::atoi(ee) == 0);
+    (void)gM; (void)gN; (void)scale;
     auto step = [&](double h, const ChirpCtl* ctl, unsigned long long* mb) -> int {
-        if (fused_ends) {
-            if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
-                hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
-                mtab_h = h; mtab_set = true;
-            }
-            ssfm_chirp_io io;
-            io.A = A; io.P = P; io.chirp = chirp; io.n = n; io.gamma = gamma; io.hh = 0.5 * h;
-            io.h_dev = ctl ? &ctl->h : nullptr; io.done_dev = ctl ? &ctl->done : nullptr; io.maxbits_dev = mb;
-            const int rc = ssfm_chirp_step(plan, mtab, &io);
-            if (rc != SSFM_ERR_UNSUPPORTED) return rc;
-            fused_ends = false;                                         // (nothing was launched: the separate kernels from here on)
+        if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
+            hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
+            mtab_h = h; mtab_set = true;
         }
-        hipLaunchKernelGGL(k_chirp_pre, dim3(gM), dim3(256), 0, t.stream, (const double2*)A, (double*)P, (const double2*)chirp, t.F, (long long)n, t.M, batch, gamma, 0.5 * h, ctl);
-        if (fused_mid) {
-            if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
-                hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
-                mtab_h = h; mtab_set = true;
-            }
-            const int rc = ssfm_apply_tables_mul(plan, mtab);
-            if (rc == SSFM_ERR_UNSUPPORTED) fused_mid = false;          // (a plan in the 16-byte-unit layout: nothing was launched; the three-launch middle from here on)
-            else if (rc) return rc;
-        }
-        if (!fused_mid) {
-        if (int rc = ssfm_apply_table(plan, 0)) return rc;
-        hipLaunchKernelGGL(k_chirp_mid, dim3(gM), dim3(256), 0, t.stream, (const double2*)Dt, t.F, (long long)n, t.M, batch, h, 0, ctl);
-        if (int rc = ssfm_apply_table(plan, 1)) return rc;
-        }
-        hipLaunchKernelGGL(k_chirp_post, dim3(gN), dim3(256), 0, t.stream, (double2*)A, (const double*)P, (const double2*)chirp, (const double2*)t.F, (long long)n, t.M, batch,
-                           gamma, 0.5 * h, scale, mb, ctl);
-        return SSFM_OK;
+        ssfm_chirp_io io;
+        io.A = A; io.P = P; io.chirp = chirp; io.n = n; io.gamma = gamma; io.hh = 0.5 * h;
+        io.h_dev = ctl ? &ctl->h : nullptr; io.done_dev = ctl ? &ctl->done : nullptr; io.maxbits_dev = mb;
+        return ssfm_chirp_step(plan, mtab, &io);
     };
+    std::vector<double> hs_used;
     if (hs) {
         if (nsteps < 0) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: nsteps=%lld", (long long)nsteps);
+        // a step of length zero is the identity (the reference's loop does not run for length == 0, devices.py:1172): dropped here, so that both
+        // engines below see the same schedule; anything else that is not a positive finite number is an error
+        for (int64_t s = 0; s < nsteps; ++s) {
+            if (hs[s] == 0.0) continue;
+            if (!(hs[s] > 0) || !std::isfinite(hs[s])) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: step %lld is %g km (must be finite and >= 0)", (long long)s, hs[s]);
+            hs_used.push_back(hs[s]);
+        }
+        const int64_t nsteps_given = nsteps;
+        hs = hs_used.data();
+        nsteps = (int64_t)hs_used.size();
+        if (nsteps == 0) { if (steps_out) *steps_out = nsteps_given; return SSFM_OK; }
         // plans of up to 4096 samples (n <= 2048): the whole schedule in one launch, a workgroup per row (k_small_chirp).  SSFM_CHIRP_SMALL=0: off.
         const char* se = std::getenv("SSFM_CHIRP_SMALL");
         if (nsteps > 0 && t.M <= 4096 && !(se && std::atoi(se) == 0)) {
             const int rc = ssfm_chirp_small(plan, A, chirp, Dt, n, gamma, hs, nsteps);
             if (rc == SSFM_OK) {
                 HIP_TRY(hipStreamSynchronize(t.stream));
-                if (steps_out) *steps_out = nsteps;
+                if (steps_out) *steps_out = nsteps_given;
                 return SSFM_OK;
             }
             if (rc != SSFM_ERR_UNSUPPORTED) return rc;
         }
-        const auto t0 = std::chrono::steady_clock::now();
         for (int64_t s = 0; s < nsteps; ++s)
             if (int rc = step(hs[s], nullptr, nullptr)) return rc;
         HIP_TRY(hipGetLastError());
-        const auto t1 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(t.stream));
-        if (std::getenv("SSFM_CHIRP_DEBUG")) std::fprintf(stderr, "chirp fixed: %lld steps, enqueue %.1f us per step, total %.1f us per step\n", (long long)nsteps,
-            std::chrono::duration<double, std::micro>(t1 - t0).count() / nsteps, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nsteps);
-        if (steps_out) *steps_out = nsteps;
+        if (steps_out) *steps_out = nsteps_given;
         return SSFM_OK;
     }
     if (max_steps < 1 || max_steps > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: max_steps=%lld", (long long)max_steps);
@@ -310,8 +292,8 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     }
     ChirpCtl* ctl = nullptr;
     double* zlog = nullptr;
-    HIP_TRY(hipMalloc(&ctl, sizeof(ChirpCtl)));
-    if (hipMalloc(&zlog, sizeof(double) * (size_t)(max_steps + 1)) != hipSuccess) { (void)hipFree(ctl); return fail(SSFM_ERR_HIP, "ssfm_chirp_propagate: no memory for the z log"); }
+    if (int wrc = ssfm_plan_workspace(plan, 1, sizeof(ChirpCtl), reinterpret_cast<void**>(&ctl))) return wrc;
+    if (int wrc = ssfm_plan_workspace(plan, 2, sizeof(double) * (size_t)(max_steps + 1), reinterpret_cast<void**>(&zlog))) return wrc;
     int rc = SSFM_OK;
     ChirpCtl now;
     std::memset(&now, 0, sizeof(now));
@@ -341,8 +323,6 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
         if (z_out) hip_ok(hipMemcpy(z_out, zlog, sizeof(double) * (size_t)(now.steps + 1), hipMemcpyDeviceToHost), "hipMemcpy");
         if (steps_out) *steps_out = now.steps;
     } while (false);
-    (void)hipFree(ctl);
-    (void)hipFree(zlog);
     return rc;
 }
 

@@ -299,6 +299,32 @@ class LaneWorker {
     std::string err_;
 };
 
+// ----------------------------------------------------------------------------- do two streams share a hardware queue?
+// The HIP runtime maps the streams of a priority class onto at most GPU_MAX_HW_QUEUES (4) hardware queues, and a stream created when the class's
+// queues are all taken shares one -- possibly the one of the SAME plan's other lane (seen whenever 3 mod 4 other streams of the class were alive:
+// profiles/r04_order_dependence.txt).  Kernels of one queue run in order: the plan's lanes would no longer overlap (35 instead of 21 us per step
+// in round 1's measurement), and the round-3 engines whose lanes waited for each other inside a kernel stalled until their patience ran out.
+// Probe: a kernel on stream a waits (at most `patience` ticks of the 100 MHz clock) for a word that a kernel on stream b sets.
+__global__ void k_queue_probe_wait(unsigned* flag, unsigned* seen, long long patience) {
+    const long long t0 = wall_clock64();
+    unsigned v = 0u;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < patience) __builtin_amdgcn_s_sleep(8);
+    *seen = v;
+}
+__global__ void k_queue_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 1: b's kernel ran beside a's (queues of their own); 0: it did not within 0.2 ms (one queue -- or a GPU too busy to tell); < 0: HIP error
+int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* two device words */, hipEvent_t ev) {
+    unsigned seen = 0u;
+    if (hipMemsetAsync(words, 0, 2 * sizeof(unsigned), a) != hipSuccess) return -1;
+    if (hipEventRecord(ev, a) != hipSuccess || hipStreamWaitEvent(b, ev, 0) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(1), 0, a, words, words + 1, 20000ll);
+    hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(1), 0, b, words);
+    if (hipGetLastError() != hipSuccess) return -1;
+    if (hipMemcpyAsync(&seen, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, a) != hipSuccess) return -1;
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+    return seen != 0u ? 1 : 0;
+}
+
 // ----------------------------------------------------------------------------- plan
 struct PlanBase {
     int precision = 0;
@@ -348,18 +374,14 @@ template <typename T> struct PlanT : PlanBase {
     hipStream_t medium_stream2 = nullptr;       // ... the second one here, on another XCD
     hipEvent_t medium_ev2 = nullptr;
     bool medium_pending = false;
-    bool fused_lanes_ok = false;   // env SSFM_ADAPT_FUSED_LANES=1: the large fused adaptive form on two streams (measured: 28.9-29.7 against 29.6-31.1 us per step at
-                                   // 2^20 x 2 -- the lanes meet in every MID_A, so little overlaps -- for four launches per step instead of two: opt-in)
     bool medium_split_ok = true;   // env SSFM_MEDIUM_SPLIT=0: a dual-polarisation plan's rows stay in one launch
     bool medium_adapt_ok = true;   // env SSFM_MEDIUM_ADAPT=0, or a run whose workgroups once did not all get to run, clears it
-    long long medium_max_samples = 1ll << 17;      // samples in all (rows x n) up to which the one-XCD engine is used (measured: a gain up to there; env SSFM_MEDIUM_MAX_LOG2)
+    static constexpr long long medium_max_samples = 1ll << 17;      // samples in all (rows x n) up to which the one-XCD engine is used (measured: a gain up to there)
     int medium_xcc = -1, medium_xccs = 8;          // the XCD this plan's single-launch runs use, of so many
     std::vector<T> medium_sched;
     double medium_gamma = 0;
     long long medium_patience = 2000000ll;
     bool fused_ok = true;      // TM_MID_A may be used (env SSFM_ADAPT_FUSED=0, or a grid that once did not run as a whole, clears it)
-    bool lanes2_ok = false;    // adaptive runs use two lanes: opt-in (env SSFM_ADAPT_LANES=2) -- measured 43 against 33 us per step of the
-                               // one-stream engine at 2^20 x 2 (profiles/r03_adaptive_two_lanes.txt); a lane that once gave up waiting clears it
     cx<T>* fused_backup = nullptr;   // the input of a fused adaptive run, for the fall-back
     Tab stabs[kMaxTables] = {};
     int stab_rr = 0;
@@ -378,6 +400,32 @@ template <typename T> struct PlanT : PlanBase {
     void drop_operator() { have_op = false; tags[0] = 0; for (auto& t : tabs) t.valid = false; for (auto& t : stabs) t.valid = false; }
     bool timed = false;
     std::atomic<int64_t> last_launches{0};
+    // what the last run really did (ssfm_last_run_info): a single-launch engine that falls back is otherwise invisible to the caller
+    int last_engine = SSFM_ENGINE_NONE;
+    int last_fell_back = 0;
+    int64_t fallbacks = 0;
+    bool lanes_share_queue = false;    // the plan's lanes could not be given hardware queues of their own (see streams_run_side_by_side)
+    // A caller that has asked for ssfm_stream() or ssfm_field_device_ptr() may order its own work behind a run without ssfm_synchronize(): for it a
+    // run of the one-launch engine of medium plans is resolved (waited for, checked, repeated on the two-kernel engine if need be) before
+    // ssfm_propagate_fixed returns
+    bool external_order = false;
+    // plan-owned device workspaces that grow on demand (ssfm_plan_workspace): what a driver loop outside this file (chirpz.hip) needs per call
+    // without a hipMalloc / hipFree pair per call -- hipFree waits for the whole device and stalls the streams of every other plan
+    void* work[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t work_cap[4] = {0, 0, 0, 0};
+    int workspace(int slot, size_t bytes, void** out) {
+        if (slot < 0 || slot > 3 || !out) return fail(SSFM_ERR_INVALID, "ssfm_plan_workspace: slot %d", slot);
+        if (int rc = use_device()) return rc;
+        if (work_cap[slot] < bytes) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(work[slot]); work[slot] = nullptr; work_cap[slot] = 0;
+            const size_t want = bytes + bytes / 2 + 256;
+            HIP_TRY(hipMalloc(&work[slot], want));
+            work_cap[slot] = want;
+        }
+        *out = work[slot];
+        return SSFM_OK;
+    }
     LaneWorker lane_worker[8];        // (lane g > 0: a host thread of its own for its launches; env SSFM_LANE_THREADS=0: all from the caller's thread)
     bool lane_threads = true;
     bool profiling = false;
@@ -390,7 +438,6 @@ template <typename T> struct PlanT : PlanBase {
     int E = 16;                // points per thread of k_time (env SSFM_E = 8 | 16)
     int Ef = 16;               // ... and of k_freq (env SSFM_EF); the two kernels only share the field layout
     int Ef_fly = 16;           // ... and of k_freq when it forms exp(D~ h) itself (adaptive runs, more step sizes than tables)
-    bool stagger = false;      // env SSFM_STAGGER
     hipStream_t lane_stream[kMaxLanes] = {};
     hipEvent_t lane_ev[kMaxLanes] = {};
     hipEvent_t fork_ev = nullptr;
@@ -463,106 +510,6 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
-    // Launch mode of fixed-step runs.  A 1000-step run is 2000-4000 launches; they are issued eagerly by
-    // default.  SSFM_GRAPH=1 replays them as ONE captured hipGraph from the second run of a schedule on;
-    // SSFM_GRAPH=auto measures both with the plan's HIP events (runs 1-2 eager, run 3 capture + replay,
-    // ~10 ms once) and keeps the faster from run 4 on -- for hosts whose launch rate cannot keep up with
-    // the GPU.  (With the lanes on their own hardware queues, see init(), eager and graph are within 1 %.)
-    struct GraphEntry {
-        unsigned long long key;
-        hipGraph_t graph;
-        hipGraphExec_t exec;
-        long long launches;
-        unsigned long long age;
-        int calls;                 // runs of this schedule so far
-        float eager_ms, graph_ms;  // measured device time of the eager / graph run (< 0: not yet)
-        float host_ms;             // host time of the eager enqueue loop (< 0: not yet)
-    };
-    std::vector<GraphEntry> graphs;
-    unsigned long long graph_clock = 0;
-    int graph_policy = 0;           // 0 eager (default), 1 always graph, -1 measure both and keep the faster
-    int pending_entry = -1;         // entry whose last run still has to be read from ev0/ev1
-    int pending_mode = 0;           // 0 eager, 1 graph
-    static constexpr size_t kMaxGraphs = 4;
-
-    void harvest_pending() {
-        if (pending_entry < 0 || pending_entry >= (int)graphs.size() || !timed) { pending_entry = -1; return; }
-        float ms = 0.f;
-        if (hipEventSynchronize(ev1) == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
-            GraphEntry& g = graphs[pending_entry];
-            if (pending_mode == 0) g.eager_ms = ms; else g.graph_ms = ms;
-        }
-        pending_entry = -1;
-    }
-
-    template <typename F>
-    int run_steps_maybe_graph(F& enqueue, T gamma, const T* h, int64_t nsteps, const std::vector<const cx<T>*>& tabptr) {
-        if (graph_policy == 0 || profiling) return enqueue();
-        unsigned long long key = 1469598103934665603ull;
-        auto mix = [&](const void* p, size_t nb) {
-            const unsigned char* b = static_cast<const unsigned char*>(p);
-            for (size_t i = 0; i < nb; ++i) { key ^= b[i]; key *= 1099511628211ull; }
-        };
-        mix(&gamma, sizeof(T)); mix(&nsteps, sizeof(nsteps)); mix(h, sizeof(T) * (size_t)nsteps);
-        for (auto tp : tabptr) mix(&tp, sizeof(tp));
-        mix(&nlanes, sizeof(nlanes)); mix(&E, sizeof(E)); mix(&Ef, sizeof(Ef));
-        // (kernel ARGUMENTS are frozen in a captured graph: the modulus of a phase table is one -- it follows Re D~, which a new operator
-        // changes while the table keeps its address -- and so is the choice between the two table kinds)
-        mix(&op_re0, sizeof(op_re0)); mix(&op_flat_re, sizeof(op_flat_re)); mix(&phase_tables, sizeof(phase_tables));
-        int idx = -1;
-        for (size_t i = 0; i < graphs.size(); ++i) if (graphs[i].key == key) idx = (int)i;
-        if (idx < 0) {
-            if (graphs.size() >= kMaxGraphs) {
-                size_t old = 0;
-                for (size_t i = 1; i < graphs.size(); ++i) if (graphs[i].age < graphs[old].age) old = i;
-                if (graphs[old].exec) (void)hipGraphExecDestroy(graphs[old].exec);
-                if (graphs[old].graph) (void)hipGraphDestroy(graphs[old].graph);
-                graphs.erase(graphs.begin() + old);
-            }
-            graphs.push_back(GraphEntry{key, nullptr, nullptr, 0, 0, 0, -1.f, -1.f, -1.f});
-            idx = (int)graphs.size() - 1;
-        }
-        GraphEntry& g = graphs[idx];
-        g.age = ++graph_clock;
-        g.calls += 1;
-        // call 1: eager (a single FIBER call never pays for a capture); call 2: capture + replay
-        bool want_graph;
-        if (graph_policy == 1) want_graph = g.calls >= 2;
-        else if (graph_policy == 2) want_graph = g.calls >= 4;          // (a loop over the same schedule by now: capture pays from about a dozen calls on)
-        else if (g.calls <= 2) want_graph = false;
-        else if (g.calls == 3) want_graph = true;
-        else want_graph = g.exec != nullptr && g.graph_ms >= 0.f && (g.eager_ms < 0.f || g.graph_ms < g.eager_ms);
-        if (want_graph && g.exec == nullptr) {
-            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue();
-            hipGraph_t graph = nullptr;
-            const hipError_t ee = hipStreamEndCapture(stream, &graph);
-            if (rc != SSFM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            if (ee != hipSuccess) return fail(SSFM_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ee));
-            hipGraphExec_t exec = nullptr;
-            if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                (void)hipGraphDestroy(graph);
-                graph_policy = 0;                       // this runtime cannot: eager from now on
-                return enqueue();
-            }
-            g.graph = graph; g.exec = exec; g.launches = last_launches.load();
-        }
-        if (want_graph) {
-            last_launches = g.launches;
-            // the graph is launched between the caller's ev0/ev1 records: re-record ev0 so that a capture
-            // + instantiate above is not counted as device time
-            HIP_TRY(hipEventRecord(ev0, stream));
-            HIP_TRY(hipGraphLaunch(g.exec, stream));
-            if (g.graph_ms < 0.f) { pending_entry = idx; pending_mode = 1; }
-            return SSFM_OK;
-        }
-        if (g.eager_ms < 0.f) { pending_entry = idx; pending_mode = 0; }
-        const auto t0 = std::chrono::steady_clock::now();
-        const int rc = enqueue();
-        if (g.host_ms < 0.f) g.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return rc;
-    }
-
     T inv_n() const { return (T)1 / (T)n; }
 
     int free_all() {
@@ -581,6 +528,7 @@ template <typename T> struct PlanT : PlanBase {
         if (medium_ev2) (void)hipEventDestroy(medium_ev2);
         if (medium_stream2) (void)hipStreamDestroy(medium_stream2);
         (void)hipFree(d_hs);
+        for (void* w : work) (void)hipFree(w);
         for (int g = 1; g < kMaxLanes; ++g) {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
             if (lane_stream[g]) (void)hipStreamDestroy(lane_stream[g]);
@@ -590,8 +538,6 @@ template <typename T> struct PlanT : PlanBase {
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
             p.ev.clear();
         }
-        for (auto& g : graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
-        graphs.clear();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -641,9 +587,7 @@ template <typename T> struct PlanT : PlanBase {
         Ef_fly = Ef;
         if (sizeof(T) == 8 && Ef == 16 && k <= 20 && !std::getenv("SSFM_E") && !std::getenv("SSFM_EF")) Ef_fly = 8;
         if (const char* e = std::getenv("SSFM_EF_FLY")) Ef_fly = k > 20 ? 16 : (std::atoi(e) == 16 ? 16 : 8);
-        if (const char* e = std::getenv("SSFM_STAGGER")) stagger = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_LANE_THREADS")) lane_threads = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SSFM_GRAPH")) graph_policy = (e[0] == 'a' || e[0] == 'A') ? -1 : (std::atoi(e) != 0 ? 1 : 0);
         // two lanes pay off once a launch is long enough to hide the other lane's gap; below ~2^20 points in
         // all a step is launch-bound and the second stream only doubles the launches (2^14 x 2: 8.1 us per
         // step with one lane, 12.0 with two; 2^18 x 2: 14.1 / 14.2; 2^20 x 2: 25.6 / 22.9 in a 200-step run)
@@ -652,19 +596,30 @@ template <typename T> struct PlanT : PlanBase {
         nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
         if (nlanes > batch) nlanes = batch;
         while (batch % nlanes) --nlanes;
-        // One-lane plans of the two-kernel engine (2^14 ... 2^19 samples) are bound by the HOST's launch rate as much as by the GPU's
-        // (two launches per 8-12 us step, 3.1 us of host time each): replayed as a hipGraph they run 7.3 instead of 8.1 us per step at
-        // 2^14, 8.9 / 9.5 at 2^16, 11.5 / 11.9 at 2^19 x 1 (profiles/r03_host_enqueue.txt; two-lane plans LOSE under a graph: 20.3 vs 13.3 us at
-        // 2^19 x 2, the replay serialises the lanes).  SSFM_GRAPH=lazy captures a schedule when it comes a fourth time.  NOT the default:
-        // while one host thread captures, another thread's legacy-stream call (hipMemcpy, hipDeviceSynchronize -- the helper entry points
-        // of this library use them) fails with hipErrorStreamCaptureImplicit (tools/thread_check.py found it), so graphs stay opt-in for
-        // single-threaded callers.
-        if (const char* e = std::getenv("SSFM_GRAPH")) if (e[0] == 'l' || e[0] == 'L') graph_policy = 2;
         lane_stream[0] = stream;
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
         for (int g = 1; g < nlanes; ++g) {
             HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, prio_hi));
             HIP_TRY(hipEventCreateWithFlags(&lane_ev[g], hipEventDisableTiming));
+        }
+        if (nlanes > 1 && nlanes <= 4) {
+            // every lane on a hardware queue of its own: a stream that shares its queue with an earlier lane of this plan is replaced (the runtime
+            // picks the least used queue of the class for a new stream, so the replacement is made BEFORE the old stream is destroyed)
+            unsigned* words = nullptr;
+            HIP_TRY(hipMalloc(&words, 2 * sizeof(unsigned)));
+            for (int g = 1; g < nlanes; ++g) {
+                for (int attempt = 0; ; ++attempt) {
+                    int ok = 1;
+                    for (int k = 0; k < g && ok == 1; ++k) ok = streams_run_side_by_side(lane_stream[k], lane_stream[g], words, fork_ev);
+                    if (ok == 1) break;
+                    if (ok < 0 || attempt == 7) { lanes_share_queue = true; break; }
+                    hipStream_t fresh = nullptr;
+                    if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio_hi) != hipSuccess) { lanes_share_queue = true; break; }
+                    (void)hipStreamDestroy(lane_stream[g]);
+                    lane_stream[g] = fresh;
+                }
+            }
+            (void)hipFree(words);
         }
         const size_t cb = sizeof(cx<T>);
         HIP_TRY(hipMalloc(&F, cb * n * batch));
@@ -695,14 +650,13 @@ template <typename T> struct PlanT : PlanBase {
         }
         if (const char* e = std::getenv("SSFM_ADAPT_FUSED")) fused_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_MEDIUM")) medium_ok = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SSFM_MEDIUM_MAX_LOG2")) medium_max_samples = 1ll << std::atoi(e);
         if (const char* e = std::getenv("SSFM_MEDIUM_ADAPT")) medium_adapt_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_MEDIUM_SPLIT")) medium_split_ok = std::atoi(e) != 0;
-        if (const char* e = std::getenv("SSFM_ADAPT_FUSED_LANES")) fused_lanes_ok = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_FUSED_PATIENCE_TICKS")) medium_patience = std::atoll(e);
-        if (const char* e = std::getenv("SSFM_ADAPT_LANES")) lanes2_ok = std::atoi(e) >= 2;
         if (const char* e = std::getenv("SSFM_PHASE_TABLE")) phase_tables = std::atoi(e) != 0;
         if (const char* e = std::getenv("SSFM_FORCE_FLY")) force_fly = std::atoi(e) != 0;
+        // the XCD this plan's one-launch runs meet on: decided now (the probe launch behind xcc_mask runs once per device, on a stream of its own)
+        if (sizeof(T) == 4 && medium_shape(N1, N2) && (medium_ok || medium_adapt_ok)) (void)pick_xcc();
         small = small_supported<T>((int)n);
         if (const char* e = std::getenv("SSFM_SMALL")) small = small && std::atoi(e) != 0;
         if (small) {
@@ -815,10 +769,12 @@ template <typename T> struct PlanT : PlanBase {
         if (medium_err_host[0] == 0u && medium_err_host[1] == 0u) return SSFM_OK;
         medium_err_host[0] = medium_err_host[1] = 0u;
         medium_ok = false;
+        ++fallbacks;
         HIP_TRY(hipMemcpyAsync(F, fused_backup, sizeof(cx<T>) * n * batch, hipMemcpyDeviceToDevice, stream));
         const std::vector<T> sched = medium_sched;
         if (int rc = propagate_fixed(medium_gamma, sched.data(), (int64_t)sched.size(), nullptr)) return rc;
         HIP_TRY(hipStreamSynchronize(stream));
+        last_fell_back = 1;
         return SSFM_OK;
     }
     // the XCDs a launch's workgroups are dealt to (probe launch, once per device), and this plan's among them: plans take turns
@@ -826,7 +782,7 @@ template <typename T> struct PlanT : PlanBase {
         if (medium_xcc >= 0) return SSFM_OK;
         static std::atomic<int> next_plan{0};
         const unsigned mask = xcc_mask(device);
-        if (mask == 0u) return fail(SSFM_ERR_HIP, "the XCD probe launch failed");
+        if (mask == 0u) { medium_ok = medium_adapt_ok = false; return SSFM_OK; }        // (the probe launch failed: the launch-per-pass engines)
         medium_xccs = __builtin_popcount(mask);
         int k = next_plan.fetch_add(1) % medium_xccs;
         for (int b = 0; b < 32; ++b)
@@ -988,7 +944,7 @@ template <typename T> struct PlanT : PlanBase {
 #endif
         (void)lane;
         a.F = F + (size_t)row0 * n; a.Y = Y + (size_t)row0 * n; a.P = P + (size_t)row0 * n; a.twN = twN; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.st = s; a.zlog = zlog; a.gamma = gamma;
-        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0; a.lane = 0; a.lanes2 = 0;
+        a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = 0; a.Qf = N2 / Ef; a.step = 0; a.derive = 0;
         a.s_in = nullptr; a.s_out = nullptr; a.pkeep = nullptr; a.mul = nullptr;
         return a;
     }
@@ -1047,7 +1003,6 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = use_device()) return rc;
         const T gamma = (T)gamma_d;
         const int nrows = N1 * batch;
-        harvest_pending();                 // device time of the previous run, if it was a measuring run
         last_launches = 0;
         timed = false;
         if (nsteps <= 0) return SSFM_OK;
@@ -1071,10 +1026,12 @@ template <typename T> struct PlanT : PlanBase {
         const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * (medium_rows_split() ? 1 : batch);
         const long long med_samples = medium_rows_split() ? n : n * batch;
         const bool med_elig = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !profiling
-                               && snapshots == nullptr && graph_policy == 0 && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
+                               && snapshots == nullptr && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
                                && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || med_samples <= medium_max_samples) && (use_phase || !phase_tables || !op_flat_re);
         const bool go_small = small_sched && snapshots == nullptr && !(med_elig && SSFM_MEDIUM_LOCAL && n >= 8192);
         const bool go_medium = med_elig && !go_small;
+        last_fell_back = 0;
+        last_engine = (go_small || (small_sched && snapshots != nullptr)) ? SSFM_ENGINE_SMALL : go_medium ? SSFM_ENGINE_MEDIUM : SSFM_ENGINE_TWO_KERNEL;
         if (use_tables && !go_small && !go_medium)
             if (int rc = tables_for(distinct, tabptr.data(), false, use_phase ? 1 : 0)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
@@ -1116,7 +1073,7 @@ template <typename T> struct PlanT : PlanBase {
             return SSFM_OK;
         };
         auto enqueue_steps = [&]() -> int {
-            if (nlanes > 1 && lane_threads && !profiling && !stagger && graph_policy == 0 && nsteps >= 16) {
+            if (nlanes > 1 && lane_threads && !profiling && nsteps >= 16) {
                 // every lane from a host thread of its own (LaneWorker): lane 0 from this one
                 HIP_TRY(hipEventRecord(fork_ev, stream));
                 for (int g = 1; g < nlanes; ++g) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
@@ -1139,12 +1096,6 @@ template <typename T> struct PlanT : PlanBase {
                     ++last_launches;
                     HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows, g), E)));
                     if (int rc = prof_mark(0, g)) return rc;
-                    // stagger: lane g+1 starts once lane g has finished its first kernel, so that the lanes
-                    // run DIFFERENT kernels at any time (one computes while the other streams)
-                    if (stagger && g + 1 < nlanes) {
-                        HIP_TRY(hipEventRecord(fork_ev, lane_stream[g]));
-                        HIP_TRY(hipStreamWaitEvent(lane_stream[g + 1], fork_ev, 0));
-                    }
                 }
                 for (int64_t s = 0; s < nsteps; ++s) {
                     for (int g = 0; g < nlanes; ++g) {
@@ -1192,7 +1143,12 @@ template <typename T> struct PlanT : PlanBase {
                 if (int rc = run_small(gamma, h, nsteps, distinct)) return rc;
             } else if (go_medium) {
                 if (int rc = run_medium(gamma, gamma_d, h, nsteps, distinct, use_phase)) return rc;
-            } else if (int rc = run_steps_maybe_graph(enqueue_steps, gamma, h, nsteps, tabptr)) return rc;
+                if (external_order) {          // (see external_order: the caller may consume the field stream-ordered, without ssfm_synchronize)
+                    HIP_TRY(hipEventRecord(ev1, stream));
+                    timed = true;
+                    return finish_medium();
+                }
+            } else if (int rc = enqueue_steps()) return rc;
 #if SSFM_TRACE
             if (int rc = trace_dump()) return rc;
 #endif
@@ -1207,6 +1163,7 @@ template <typename T> struct PlanT : PlanBase {
             int64_t block = (int64_t)std::min<size_t>((size_t)(nsteps + 1), std::max<size_t>(1, std::min<size_t>(free_b / 2, size_t(8) << 30) / fb));
             char* dsnap = nullptr;
             HIP_TRY(hipMalloc(&dsnap, fb * (size_t)block));
+            if (!(small_sched && block == nsteps + 1)) last_engine = SSFM_ENGINE_TWO_KERNEL;
             if (small_sched && block == nsteps + 1) {
                 // a small plan whose whole capture fits the device: the single launch writes every snapshot itself
                 hipError_t e = hipMemcpyAsync(dsnap, F, fb, hipMemcpyDeviceToDevice, stream);             // the input
@@ -1261,8 +1218,6 @@ template <typename T> struct PlanT : PlanBase {
         int step = 0;                  // index of the next step to launch
         StepState<T> now = {};         // state after the last launched step (host copy)
         bool fused = false;            // column kernel of at most 128 workgroups, no capture: END + BEGIN in one launch (TM_MID_A)
-        bool lanes2 = false;           // two row groups on two streams, joined only through the step control state (see adaptive_run)
-        bool fused_lanes = false;      // fused, and the two polarisations on a stream each: FLY + MID_A per lane and step, the lanes meet in MID_A's hand-over
         bool medium = false;           // (deferred) a medium plan: the single-launch kernel is k_medium_adapt (one XCD)
         bool deferred = false;         // small plan without capture: nothing launched yet -- the first adaptive_run decides between
         int single_step = 0;           // the single-launch kernel (budget covers the run) and the chunked engine
@@ -1280,6 +1235,8 @@ template <typename T> struct PlanT : PlanBase {
             zlog_cap = max_steps + 1;
         }
         last_launches = 0;
+        last_fell_back = 0;
+        last_engine = SSFM_ENGINE_NONE;
         HIP_TRY(hipEventRecord(ev0, stream));
         // (4096 x 2: the one-XCD engine, 8.1 us per step, before the one-workgroup kernel that holds both rows, 10.4)
         bool med_adapt = false;
@@ -1344,40 +1301,24 @@ template <typename T> struct PlanT : PlanBase {
         // for the case that the GPU does not run the grid as a whole (then: the three-launch engine, for good)
         // Larger complex64 grids (up to 512 workgroups = two per CU: 2^20 x 2) take the same kernel with a hand-over that has no counter to
         // serialise on (AdaptState::wgmax): the column pass is then ONE launch per step instead of two -- 64 MiB of field traffic per step
-        // instead of 96.  SSFM_ADAPT_FUSED_MAX caps the workgroups (64: round 2's rule).
+        // instead of 96.
         const long long col_blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
         long long fused_max = sizeof(T) == 4 ? kAdaptWords : kAdaptSlots;
-        if (const char* e = std::getenv("SSFM_ADAPT_FUSED_MAX")) fused_max = std::atoll(e) < fused_max ? std::atoll(e) : fused_max;
         int cus = 0;
         if (col_blocks > kAdaptSlots && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || col_blocks > 2ll * cus || col_blocks % 64 != 0))
             fused_max = kAdaptSlots;                              // (the whole grid must be resident at once: two workgroups per CU)
-        if (lanes2_ok) fused_max = fused_max < kAdaptSlots ? fused_max : kAdaptSlots;      // (the opt-in two-lane form keeps its sizes)
-        ar.fused = fused_ok && !capture && (N1 == 128 || N1 == 256) && col_blocks <= (fused_max > kAdaptSlots ? fused_max : kAdaptSlots);
+        ar.fused = fused_ok && !capture && (N1 == 128 || N1 == 256) && col_blocks <= fused_max;
         if (ar.fused) {
             const size_t fb = sizeof(cx<T>) * n * batch;
             if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
             HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));
         }
-        // the large fused form on two lanes: a lane's launches are FLY and MID_A over its rows; MID_A waits for the words of BOTH lanes, so the
-        // lanes stay within a step of each other (SSFM_ADAPT_FUSED_LANES=1: opt-in, see fused_lanes_ok)
-        ar.fused_lanes = ar.fused && fused_lanes_ok && sizeof(T) == 4 && nlanes == 2 && batch == 2 && col_blocks > kAdaptSlots && (col_blocks / 2) % 64 == 0;
+        // (Two engines that drove the polarisations of an adaptive run on two streams, a lane's kernel waiting INSIDE the launch for the other lane's
+        // maxima, were built in round 3 and removed in round 4: both lost their A/B -- 36-38 and 28.9-29.7 against 32-33 and 29.6-31.1 us per step at
+        // 2^20 x 2, profiles/r03_adaptive_two_lanes.txt, r03_adaptive_fused_large.txt -- and both stall until their patience runs out whenever the
+        // runtime maps the plan's two streams to ONE hardware queue, which it does when the number of live streams of the priority class is 3 mod 4:
+        // profiles/r04_order_dependence.txt.)
         ar.tile_private = u16 && !capture && !ar.fused;
-        // Two lanes (round 3, opt-in): the rows only share the step size, so each half of them runs its own BEGIN_Y -> k_freq -> END_Y
-        // chain on its own stream, as the fixed-step lanes do; a lane's BEGIN(s + 1) waits INSIDE the kernel for the other lane's
-        // END(s) maxima (AdaptState::arrived) -- no host-side event between the streams inside a chunk (ten host calls per step made
-        // round 2's two-lane attempt host-bound).  Parity-green and SLOWER than one stream (43 vs 33 us per step at 2^20 x 2): meeting
-        // once per step keeps the lanes in step, so the same kernels of both run side by side -- what a two-row launch does anyway --
-        // and six launches per step instead of three reach the host's enqueue rate.  Fixed-step lanes gain because they may drift
-        // half a period apart.  Needs whole slot groups per END launch, at most half the chip's workgroup slots per launch (a waiting
-        // BEGIN must never hold every slot) and the tile-private layout; the input is kept for the case that a lane ever gives up
-        // waiting (then: one lane, for good).
-        ar.lanes2 = lanes2_ok && nlanes == 2 && ar.tile_private && !single_step && batch % 2 == 0
-                    && ((long long)(N2 / cols_per_tile<T>()) * (batch / 2)) % kAdaptSlots == 0 && (long long)(N2 / cols_per_tile<T>()) * (batch / 2) <= 256;
-        if (ar.lanes2) {
-            const size_t fb = sizeof(cx<T>) * n * batch;
-            if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
-            HIP_TRY(hipMemcpyAsync(fused_backup, F, fb, hipMemcpyDeviceToDevice, stream));
-        }
         return SSFM_OK;
     }
 
@@ -1421,12 +1362,15 @@ template <typename T> struct PlanT : PlanBase {
                     HIP_TRY(hipStreamSynchronize(stream));
                     if (!gave_up && !gave_up2) {
                         ar.deferred = false;
+                        last_engine = SSFM_ENGINE_MEDIUM_ADAPT;
                         if (steps_total) *steps_total = ar.now.steps;
                         if (done) *done = ar.now.done;
                         return SSFM_OK;
                     }
                     // part of the grid never ran beside the rest: the same run on the chunked engine, which this plan then keeps to
                     medium_adapt_ok = false;
+                    last_fell_back = 1;
+                    ++fallbacks;
                     HIP_TRY(hipMemcpyAsync(F, fused_backup, fb, hipMemcpyDeviceToDevice, stream));
                 }
             } else if (keep.medium) {
@@ -1442,6 +1386,7 @@ template <typename T> struct PlanT : PlanBase {
                 HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(ar.now), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 ar.deferred = false;
+                last_engine = SSFM_ENGINE_SMALL_ADAPT;
                 if (steps_total) *steps_total = ar.now.steps;
                 if (done) *done = ar.now.done;
                 return SSFM_OK;
@@ -1455,7 +1400,6 @@ template <typename T> struct PlanT : PlanBase {
             ar.fused = false;
             ar.tile_private = u16;
         }
-        if (ar.lanes2 && ar.step == 0 && budget < (int64_t)ar.max_steps) ar.lanes2 = false;      // (pieces: the one-stream engine)
         const int nrows = N1 * batch;
         const size_t fb = sizeof(cx<T>) * n * batch;
         char* snap = static_cast<char*>(snapshots);
@@ -1468,61 +1412,8 @@ template <typename T> struct PlanT : PlanBase {
         };
         int chunk = snap ? 1 : estimate();
         while (!ar.now.done && ar.now.steps - first_step < budget) {
+            last_engine = ar.fused ? SSFM_ENGINE_ADAPT_FUSED : SSFM_ENGINE_ADAPT_3;
             if ((int64_t)chunk > budget - (ar.now.steps - first_step)) chunk = (int)(budget - (ar.now.steps - first_step));
-            if (ar.fused && ar.fused_lanes) {
-                const int rows = batch / 2;
-                HIP_TRY(hipEventRecord(fork_ev, stream));
-                HIP_TRY(hipStreamWaitEvent(lane_stream[1], fork_ev, 0));
-                for (int i = 0; i < chunk; ++i, ++ar.step) {
-                    for (int k = (ar.step == 0 ? 0 : 1); k < 3; ++k)
-                        for (int g = 0; g < 2; ++g) {
-                            if (k == 1) {
-                                FreqArgs<T> fa = fargs_fly(0, st, g * rows, g);
-                                fa.step = ar.step;
-                                HIP_TRY((launch_freq<T, FM_FLY>(N2, N1 * rows, lane_stream[g], fa, Ef_fly)));
-                            } else {
-                                TimeArgs<T> tb = targs(ar.gamma, 0, 0, st, g * rows, g);
-                                tb.step = ar.step; tb.lane = g; tb.lanes2 = 1; tb.derive = 0;
-                                if (k == 0) HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], tb, E)));
-                                else HIP_TRY((launch_time<T, TM_MID_A>(N1, rows, lane_stream[g], tb, E)));
-                            }
-                            ++last_launches;
-                        }
-                }
-                HIP_TRY(hipEventRecord(lane_ev[1], lane_stream[1]));
-                HIP_TRY(hipStreamWaitEvent(stream, lane_ev[1], 0));
-            } else
-            if (ar.lanes2) {
-                // fork once per chunk; inside it the lanes meet only in device memory
-                const int rows = batch / 2;
-                HIP_TRY(hipEventRecord(fork_ev, stream));
-                HIP_TRY(hipStreamWaitEvent(lane_stream[1], fork_ev, 0));
-                for (int i = 0; i < chunk; ++i, ++ar.step) {
-                    // (kernel by kernel, lane by lane: the host enqueues a launch every few microseconds, and a lane whose kernels
-                    // were all enqueued after the other's would lag it by a whole step's worth of launches)
-                    for (int k = 0; k < 3; ++k)
-                        for (int g = 0; g < 2; ++g) {
-                            TimeArgs<T> tb = targs(ar.gamma, 0, 0, st, g * rows, g);
-                            tb.step = ar.step;
-                            tb.lane = g;
-                            tb.lanes2 = 1;
-                            tb.derive = i != 0;
-                            if (k == 0) {
-                                if (ar.step > 0) HIP_TRY((launch_time<T, TM_BEGIN_Y>(N1, rows, lane_stream[g], tb, E)));
-                                else HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], tb, E)));
-                            } else if (k == 1) {
-                                FreqArgs<T> fa = fargs_fly(0, st, g * rows, g);
-                                fa.step = ar.step;
-                                HIP_TRY((launch_freq<T, FM_FLY>(N2, N1 * rows, lane_stream[g], fa, Ef_fly)));
-                            } else {
-                                HIP_TRY((launch_time<T, TM_END_Y>(N1, rows, lane_stream[g], tb, E)));
-                            }
-                        }
-                    last_launches += 6;
-                }
-                HIP_TRY(hipEventRecord(lane_ev[1], lane_stream[1]));
-                HIP_TRY(hipStreamWaitEvent(stream, lane_ev[1], 0));
-            } else
             for (int i = 0; i < chunk; ++i, ++ar.step) {
                 TimeArgs<T> tb = targs(ar.gamma, 0, 0, st), te = tb;
                 tb.step = te.step = ar.step;
@@ -1549,13 +1440,14 @@ template <typename T> struct PlanT : PlanBase {
             unsigned gave_up = 0;
             HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur) + sizeof(StepState<T>) * (ar.step & 1),
                                    sizeof(ar.now), hipMemcpyDeviceToHost, stream));
-            if (ar.fused || ar.lanes2) HIP_TRY(hipMemcpyAsync(&gave_up, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(gave_up), hipMemcpyDeviceToHost, stream));
+            if (ar.fused) HIP_TRY(hipMemcpyAsync(&gave_up, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(gave_up), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if ((ar.fused || ar.lanes2) && gave_up) {
-                // the grid did not run as a whole (another job holds CUs) / a lane waited in vain for the other: the same run again on
-                // the one-stream three-launch engine
+            if (ar.fused && gave_up) {
+                // the grid did not run as a whole (another job holds CUs): the same run again on the three-launch engine
                 const AdaptRun keep = ar;
-                if (ar.fused) fused_ok = false; else lanes2_ok = false;
+                fused_ok = false;
+                last_fell_back = 1;
+                ++fallbacks;
                 HIP_TRY(hipMemcpyAsync(F, fused_backup, fb, hipMemcpyDeviceToDevice, stream));
                 if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
                 chunk = estimate();
@@ -1692,6 +1584,7 @@ template <typename T> struct PlanT : PlanBase {
             tb.cz.maxbits = static_cast<unsigned long long*>(io->maxbits_dev);
         }
         if (int rc = use_device()) return rc;
+        if (io) last_engine = SSFM_ENGINE_CHIRP_STEPS;
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E)));
         HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[0], 0, nullptr), Ef)));
         TimeArgs<T> tm = targs(0, 0, 0, nullptr);
@@ -1724,6 +1617,7 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = chirp_line_table(&a.tw)) return rc;
         a.gamma = (T)gamma; a.n = (int)nn; a.nsteps = (int)nsteps;
         last_launches = 1;
+        last_engine = SSFM_ENGINE_CHIRP_SMALL; last_fell_back = 0;
         HIP_TRY(launch_small_chirp<T>((int)n, batch, stream, a));
         return SSFM_OK;
     }
@@ -1760,14 +1654,28 @@ template <typename T> struct PlanT : PlanBase {
         a.phi_max = phi_max; a.abs_gamma = gamma < 0 ? -gamma : gamma; a.length = length; a.patience = medium_patience;
         a.gamma = (T)gamma; a.n = (int)nn; a.max_steps = (int)max_steps; a.f32 = f32;
         HIP_TRY(hipMemsetAsync(base, 0, 8 * words + 16, stream));
+        // the caller's field is kept (a few dozen KiB): rows that had finished when another row's workgroup gave up have stored their result
+        void* keep = nullptr;
+        const size_t fbytes = sizeof(cx<T>) * (size_t)nn * (size_t)batch;
+        if (int rc = workspace(3, fbytes, &keep)) return rc;
+        HIP_TRY(hipMemcpyAsync(keep, A, fbytes, hipMemcpyDeviceToDevice, stream));
         last_launches = 1;
+        last_engine = SSFM_ENGINE_CHIRP_SMALL_ADAPT; last_fell_back = 0;
         HIP_TRY(launch_small_chirp_adapt<T>((int)n, batch, stream, a));
         int out[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(out, a.out, sizeof(out), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (out[1] && out[2] == 0)          // (a busy device: not all rows' workgroups were resident together.  Nothing was stored: the caller's other path can run)
+        if (out[1]) {
+            // a busy device: not all rows' workgroups were resident together.  The field is put back as it came (rows that had finished have
+            // stored theirs) and the caller's other path can run -- as every other single-launch engine of this library does
+            if (out[2] != 0) {
+                HIP_TRY(hipMemcpyAsync(A, keep, fbytes, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
+            ++fallbacks;
+            last_fell_back = 1;
             return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small_adapt: the rows' workgroups did not meet within the patience; the field is unchanged");
-        if (out[1]) return fail(SSFM_ERR_HIP, "ssfm_chirp_small_adapt: the rows' workgroups did not meet within the patience after %d of %d rows had finished", out[2], batch);
+        }
         if (z_out) HIP_TRY(hipMemcpy(z_out, a.zlog, sizeof(double) * (size_t)(out[0] + 1), hipMemcpyDeviceToHost));
         if (steps_out) *steps_out = out[0];
         return SSFM_OK;
@@ -1935,8 +1843,10 @@ int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device) {
 }
 void* ssfm_field_device_ptr(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->F;
-    return static_cast<PlanT<double>*>(plan->impl)->F;
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); P_->external_order = true; return P_->F; }
+    auto* P_ = static_cast<PlanT<double>*>(plan->impl);
+    P_->external_order = true;
+    return P_->F;
 }
 
 int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, void* snapshots) {
@@ -1998,8 +1908,18 @@ int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }
 
 void* ssfm_stream(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->stream;
-    return static_cast<PlanT<double>*>(plan->impl)->stream;
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); P_->external_order = true; return P_->stream; }
+    auto* P_ = static_cast<PlanT<double>*>(plan->impl);
+    P_->external_order = true;
+    return P_->stream;
+}
+
+int ssfm_plan_workspace(ssfm_plan* plan, int slot, size_t bytes, void** out) { WITH_PLAN(plan, P_->workspace(slot, bytes, out)); }
+
+int ssfm_last_run_info(ssfm_plan* plan, int* engine, int* fell_back, int64_t* fallbacks_total, int* lanes_share_queue) {
+    WITH_PLAN(plan, ((engine ? (void)(*engine = P_->last_engine) : (void)0), (fell_back ? (void)(*fell_back = P_->last_fell_back) : (void)0),
+                     (fallbacks_total ? (void)(*fallbacks_total = P_->fallbacks) : (void)0),
+                     (lanes_share_queue ? (void)(*lanes_share_queue = P_->lanes_share_queue ? 1 : 0) : (void)0), (int)SSFM_OK));
 }
 
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches) { WITH_PLAN(plan, last_ms_impl(P_, ms, launches)); }

@@ -54,6 +54,7 @@
 #ifndef SSFM_KERNARG_UPFRONT
 #define SSFM_KERNARG_UPFRONT 1
 #endif
+
 #ifndef SSFM_LATE_P_C128
 #define SSFM_LATE_P_C128 1
 #endif
@@ -132,7 +133,6 @@ template <typename T> struct StepState {
     int steps;      // steps taken so far
 };
 constexpr int kAdaptSlots = 64;
-constexpr int kAdaptLanes = 2;
 constexpr int kAdaptWords = 512;       // workgroups of the largest fused adaptive column kernel (2^20 x 2: 256 tiles x 2 rows)
 template <typename T> struct AdaptState {
     T length;
@@ -142,12 +142,7 @@ template <typename T> struct AdaptState {
     int max_steps;
     int pad_;
     StepState<T> cur[2];
-    unsigned long long slots[kAdaptLanes][2][kAdaptSlots];      // bit patterns of max |A|^2 (non-negative => monotone as integers); [lane][step parity][slot]
-    // two-lane adaptive runs (the polarisations of one field on two streams, ssfm_host.hip adaptive_run): workgroups of END
-    // that have delivered their maximum, per lane and slot, counted over the WHOLE run and never cleared inside it (a
-    // cleared counter could be read before its clearing: the lanes are not in step).  BEGIN(s) of one lane waits until the
-    // OTHER lane's counters show s complete ENDs; its own lane's END(s - 1) is an earlier kernel of its stream.
-    unsigned long long arrived[kAdaptLanes][kAdaptSlots];
+    unsigned long long slots[2][kAdaptSlots];      // bit patterns of max |A|^2 (non-negative => monotone as integers); [step parity][slot]
     // TM_MID_A with more than kAdaptSlots workgroups (complex64): one word per workgroup and step parity, (step + 1) << 32 | bits of its
     // maximum -- flag and value in ONE 8-byte store, no atomics, no counter that 512 workgroups would serialise on (a counter barrier
     // over 512 workgroups costs 7-9 us, profiles/r02_barrier_probe.txt; this hand-over about 2).  Zeroed by the host before a run.
@@ -270,8 +265,6 @@ template <typename T> struct TimeArgs {
     int Qf;                   // threads per row of k_freq (U16 layout: which columns form a tile)
     int step;                 // adaptive mode: index of the step this launch belongs to (its state is cur[step & 1])
     int derive;               // adaptive BEGIN: 1 = derive the step's state from the previous step's (see AdaptState)
-    int lane;                 // adaptive: which set of slots this launch's rows deliver their maxima to (0 in single-lane runs)
-    int lanes2;               // adaptive, two lanes: END counts its arrivals, a deriving BEGIN waits for the other lane's (AdaptState::arrived)
     const StepState<T>* s_in; // k_medium_adapt (PK): TM_MID_A takes the state of the step it finishes from here (LDS) instead of st->cur[],
     StepState<T>* s_out;      // ... and leaves the next step's here (untouched if the hand-over ran out of patience)
     const cx<T>* mul;         // TM_MID of the plain layout: the time-domain samples are multiplied by mul[position in the row] between the inverse and the
@@ -565,14 +558,9 @@ template <typename T> __device__ __forceinline__ StepState<T> step_advance(const
     return n;
 }
 // maximum over the 64 slots, by one wavefront (every lane gets it)
-// (both lanes' sets: a single-lane run leaves the second lane's at zero.  Agent-scope loads: in a two-lane run the other
-// lane's END may have written its slots -- with memory-side atomics -- after THIS kernel started, so a line of them in this
-// XCD's L2 or this CU's L1 may be two steps old)
 template <typename T> __device__ __forceinline__ unsigned long long slots_max(const AdaptState<T>* st, int parity) {
     const int i = threadIdx.x & (kAdaptSlots - 1);
-    unsigned long long mb = __hip_atomic_load(&st->slots[0][parity][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long m1 = __hip_atomic_load(&st->slots[1][parity][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mb = m1 > mb ? m1 : mb;
+    unsigned long long mb = __hip_atomic_load(&st->slots[parity][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (filled by memory-side atomics of an earlier kernel)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(mb, o);
@@ -873,29 +861,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         }
         hh_prev = S_this.h * (T)0.5;
     } else if (a.st != nullptr && MODE != TM_UNPACK) {
-        if (FWD && a.derive != 0 && a.lanes2 != 0) {
-            // two-lane run: the other lane's END(step - 1) must have delivered all its maxima.  One wavefront polls the other
-            // lane's 64 arrival counters (one load instruction per poll) until each shows `step` complete ENDs; never longer
-            // than the patience of AdaptState (then: error flag, the host repeats the run on one lane).
-            __shared__ __attribute__((aligned(16))) int s_lane_ok_[4];     // (16 bytes: statics precede the dynamic LDS region, whose base must stay 16-byte aligned)
-            int& s_lane_ok = s_lane_ok_[0];
-            if (tid < 64) {
-                const unsigned long long want = (unsigned long long)a.step * (nblk / kAdaptSlots);
-                const unsigned long long* cnt = a.st->arrived[a.lane ^ 1];
-                const long long t0 = wall_clock64();
-                int good = 0;
-                for (;;) {
-                    const unsigned long long got = __hip_atomic_load(&cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(got >= want)) { good = 1; break; }
-                    if (wall_clock64() - t0 > a.st->patience) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (tid == 0) { s_lane_ok = good; if (!good) atomicExch(&a.st->error, 1u); }
-            }
-            __syncthreads();
-            if (!s_lane_ok) return;
-        }
-        if (a.st->error != 0u) return;                        // (see TM_MID_A above; set by a two-lane run's wait as well)
+        if (a.st->error != 0u) return;                        // (see TM_MID_A above)
         const StepState<T> S = step_state<T>(a.st, a.step, FWD && a.derive != 0);
         if (FWD && bid == 0 && tid == 0) {
             // workgroup 0 records the state of this step (BEGIN is the first kernel of a step) and empties the slots its END fills
@@ -904,7 +870,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 if (!a.st->cur[(a.step - 1) & 1].done) a.zlog[S.steps] = S.z;
             }
         }
-        if (FWD && bid == 0 && tid < kAdaptSlots) a.st->slots[a.lane][a.step & 1][tid] = 0ull;
+        if (FWD && bid == 0 && tid < kAdaptSlots) a.st->slots[a.step & 1][tid] = 0ull;
         if (S.done) return;
         hh_prev = hh_next = S.h * (T)0.5;
     }
@@ -954,12 +920,61 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     T phi[E];
     T pnew[E];
     bool fwd_active = true;               // TM_MID_A: false when this step ends the run
+    auto store_pnew = [&]() {
+        if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
+            if (FWD) {
+#pragma unroll
+                for (int t = 0; t < E; ++t) a.pkeep[t] = pnew[t];
+            }
+        } else
+        if constexpr (P16) {
+            if (FWD) {
+                float m = pnew[0];
+#pragma unroll
+                for (int t = 1; t < E; ++t) m = fmaxf(m, pnew[t]);
+                const float inv = m > 0.0f ? __builtin_amdgcn_rcpf(m) : 0.0f;          // (v_cvt_pknorm clamps to [0, 1]: the 1-ulp reciprocal cannot overflow)
+                *Ps = m;                                                               // 256 bytes per wave; a plain store (a 4-byte write-through store is 6x the time per byte)
+#pragma unroll
+                for (int g = 0; g < E / 8; ++g) {
+                    u32x4_t q;
+                    unsigned w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto h2 = __builtin_amdgcn_cvt_pknorm_u16(pnew[8 * g + 2 * i] * inv, pnew[8 * g + 2 * i + 1] * inv);
+                        w[i] = __builtin_bit_cast(unsigned, h2);
+                    }
+                    q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(&Pq[g * PSTR]), "v"(q) : "memory");
+                }
+            }
+        } else
+        if (FWD && !SSFM_ABL_NO_P) {
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+                p4_t q;
+                q.x = pnew[4 * g]; q.y = pnew[4 * g + 1]; q.z = pnew[4 * g + 2]; q.w = pnew[4 * g + 3];
+#if SSFM_P_NT
+                __builtin_nontemporal_store(q, &Pb[g * PSTR]);
+#elif SSFM_P_WT
+                if constexpr (sizeof(T) == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(&Pb[g * PSTR]), "v"(q) : "memory");
+                else Pb[g * PSTR] = q;
+#else
+                Pb[g * PSTR] = q;
+#endif
+            }
+        }
+    };
     if constexpr (MODE == TM_MID_A) {
 #pragma unroll
         for (int t = 0; t < E; ++t) {
             pnew[t] = v[t].x * v[t].x + v[t].y * v[t].y;
             pmax = pnew[t] > pmax ? pnew[t] : pmax;
         }
+        // (Round 4 tried to do everything that does not need the next step size BEFORE the workgroups meet -- |A|^2 to the P buffer, the second half
+        // rotation of the finished step, the other rotation after the meeting: 28.1-28.4 against 27.4-27.5 us per step, the second rotation costs
+        // more than the wait hides; and to start the odd rows' workgroups of k_freq<FLY> 1.7 / 3.4 / 5.1 us late, so that the two rows of the one
+        // launch are not in the same phase at the same time: 28.4 / 30.4 / 32.2 against 27.3; and to store |A|^2 alone before the meeting (4.7 of the
+        // launch's 21 MB of writes under the wait): 28.5 against 27.3 -- the workgroup's word is queued behind those stores.  profiles/r04_adaptive.txt)
         // ---- the step control, inside the launch: every workgroup delivers its maximum, waits until all have, and replays
         // step_advance() on the same 64 slots (the same float operations: the same bits in every workgroup)
 #pragma unroll
@@ -981,8 +996,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             if (tid < 64) {
                 const int set = a.step & 1;
                 const unsigned long long epoch = (unsigned long long)(unsigned)(a.step + 1) << 32;
-                // (two lanes, one launch each: the words of both; this launch's are the lane's share)
-                const unsigned total = a.lanes2 ? 2u * nblk : nblk, mine = (a.lanes2 ? (unsigned)a.lane * nblk : 0u) + bid;
+                const unsigned total = nblk, mine = bid;
                 if (tid == 0) {
                     T m = wave_max_a[0];
 #pragma unroll
@@ -1039,7 +1053,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 T m = wave_max_a[0];
 #pragma unroll
                 for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
-                atomicMax(&a.st->slots[0][set][bid % kAdaptSlots], float_bits<T>(m));
+                atomicMax(&a.st->slots[set][bid % kAdaptSlots], float_bits<T>(m));
 #if SSFM_RELAXED_BARRIER
                 // Only atomics cross this barrier (the slots, read back with agent-scope loads below), so no fence is needed -- an agent-scope
                 // release / acquire writes back / invalidates the XCD's whole L2 on gfx950 -- just the order: the maximum is acknowledged
@@ -1059,7 +1073,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             good = __shfl(good, 0);
             unsigned long long mb = 0ull;
             if (good) {
-                mb = __hip_atomic_load(&a.st->slots[0][set][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mb = __hip_atomic_load(&a.st->slots[set][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     const unsigned long long other = __shfl_xor(mb, o);
@@ -1079,7 +1093,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         if (bid == 0) {
             // workgroup 0 records the state of the next step and empties what the next step's launch will fill
             if (tid == 0) { a.st->cur[(a.step + 1) & 1] = Sn; a.zlog[Sn.steps] = Sn.z; a.st->arrive[(a.step + 1) & 1] = 0u; }
-            if (tid < kAdaptSlots) a.st->slots[0][(a.step + 1) & 1][tid] = 0ull;
+            if (tid < kAdaptSlots) a.st->slots[(a.step + 1) & 1][tid] = 0ull;
         }
         fwd_active = !Sn.done;
         hh_next = Sn.h * (T)0.5;
@@ -1101,48 +1115,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         pmax = p > pmax ? p : pmax;
     }
     }
-    if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
-        if (FWD) {
-#pragma unroll
-            for (int t = 0; t < E; ++t) a.pkeep[t] = pnew[t];
-        }
-    } else
-    if constexpr (P16) {
-        if (FWD) {
-            float m = pnew[0];
-#pragma unroll
-            for (int t = 1; t < E; ++t) m = fmaxf(m, pnew[t]);
-            const float inv = m > 0.0f ? __builtin_amdgcn_rcpf(m) : 0.0f;          // (v_cvt_pknorm clamps to [0, 1]: the 1-ulp reciprocal cannot overflow)
-            *Ps = m;                                                               // 256 bytes per wave; a plain store (a 4-byte write-through store is 6x the time per byte)
-#pragma unroll
-            for (int g = 0; g < E / 8; ++g) {
-                u32x4_t q;
-                unsigned w[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const auto h2 = __builtin_amdgcn_cvt_pknorm_u16(pnew[8 * g + 2 * i] * inv, pnew[8 * g + 2 * i + 1] * inv);
-                    w[i] = __builtin_bit_cast(unsigned, h2);
-                }
-                q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(&Pq[g * PSTR]), "v"(q) : "memory");
-            }
-        }
-    } else
-    if (FWD && !SSFM_ABL_NO_P) {
-#pragma unroll
-        for (int g = 0; g < E / 4; ++g) {
-            p4_t q;
-            q.x = pnew[4 * g]; q.y = pnew[4 * g + 1]; q.z = pnew[4 * g + 2]; q.w = pnew[4 * g + 3];
-#if SSFM_P_NT
-            __builtin_nontemporal_store(q, &Pb[g * PSTR]);
-#elif SSFM_P_WT
-            if constexpr (sizeof(T) == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(&Pb[g * PSTR]), "v"(q) : "memory");
-            else Pb[g * PSTR] = q;
-#else
-            Pb[g * PSTR] = q;
-#endif
-        }
-    }
+    store_pnew();
     if (!SSFM_ABL_NO_NL) rotate_all<E>(v, phi);
     else {
 #pragma unroll
@@ -1225,16 +1198,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 T m = wave_max[0];
 #pragma unroll
                 for (int w = 1; w < NWAVES; ++w) m = wave_max[w] > m ? wave_max[w] : m;
-                atomicMax(&a.st->slots[a.lane][a.step & 1][bid % kAdaptSlots], float_bits<T>(m));
-                if (a.lanes2) {
-#if SSFM_RELAXED_BARRIER && SSFM_STORE_MODE == 1 && SSFM_P_WT == 1
-                    // (the field and |A|^2 stores of this workgroup are write-through and were waited for at the barrier above; see TM_MID_A)
-                    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][bid % kAdaptSlots], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-                    __hip_atomic_fetch_add(&a.st->arrived[a.lane][bid % kAdaptSlots], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-                }
+                atomicMax(&a.st->slots[a.step & 1][bid % kAdaptSlots], float_bits<T>(m));
             }
         }
         SSFM_TRACE_END(a);
@@ -1391,7 +1355,21 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
             pu[4 * g] = q.x; pu[4 * g + 1] = q.y; pu[4 * g + 2] = q.z; pu[4 * g + 3] = q.w;
         }
     };
+    // (the same for the operator itself where the kernel forms exp(D~ h): adaptive runs.  Only with 16-byte elements... of either precision)
+    constexpr bool EARLY_FLY = HEAD && SSFM_EARLY_PHASE != 0 && MODE == FM_FLY;
+    auto load_table = [&]() {
+        typedef T m4_t __attribute__((ext_vector_type(4)));
+        const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(trow) + j;
+#pragma unroll
+        for (int g = 0; g < E / 2; ++g) {
+            m4_t q;
+            if (SSFM_ABL_NO_TAB) { q.x = a.inv_n; q.y = (T)0; q.z = a.inv_n; q.w = (T)0; } else q = T4[g * Q];
+            m[2 * g] = mk<T>(q.x, q.y);
+            m[2 * g + 1] = mk<T>(q.z, q.w);
+        }
+    };
     if constexpr (EARLY_PHASE) load_phases();
+    if constexpr (EARLY_FLY) load_table();
     if (U16) {
         // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
         if constexpr (PK && sizeof(T) == 4) {
@@ -1420,15 +1398,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     if (MODE == FM_PHASE) {
         if (!SSFM_LATE_TAB && !EARLY_PHASE) load_phases();
     } else if (MODE != FM_FWD_ONLY) {
-        typedef T m4_t __attribute__((ext_vector_type(4)));
-        const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(trow) + j;
-#pragma unroll
-        for (int g = 0; g < E / 2; ++g) {
-            m4_t q;
-            if (SSFM_ABL_NO_TAB) { q.x = a.inv_n; q.y = (T)0; q.z = a.inv_n; q.w = (T)0; } else q = T4[g * Q];
-            m[2 * g] = mk<T>(q.x, q.y);
-            m[2 * g + 1] = mk<T>(q.z, q.w);
-        }
+        if constexpr (!EARLY_FLY) load_table();
     }
     if (MODE == FM_FLY && a.st != nullptr) {
         // (read after the row and the operator have been asked for: the state was written by the previous launch, a ~2 us miss)
@@ -1442,10 +1412,28 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     SSFM_STAMP(2);
 #endif
     if constexpr (HEAD) line_twiddles_commit<T, N2, E, ROWS * N2 / E>(tws, ldsT, tid);
+    auto fly = [&]() {
+        // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
+        T ph[E];
+#pragma unroll
+        for (int t = 0; t < E; ++t) ph[t] = m[t].y * h;
+        // Re D~ = -alpha/2 is the same number at every frequency for a fibre (devices.py:1145): then exp(Re h) is ONE
+        // exponential per thread instead of 16 (bit-identical: the same float product, the same function); any other
+        // operator takes the general path
+        bool flat = true;
+#pragma unroll
+        for (int t = 1; t < E; ++t) flat = flat && (m[t].x == m[0].x);
+        const T e0 = exp_acc<T>(m[0].x * h);
+        fly_factors<E>(m, ph, flat, e0, h, a.inv_n);
+    };
     if constexpr (EARLY_PHASE) {
 #pragma unroll
         for (int t = 0; t < E; ++t) m[t] = phase32_factor(pu[t], a.amp);
         __builtin_amdgcn_sched_barrier(0);          // (keeps the factors ahead of the wait for the field)
+    }
+    if constexpr (EARLY_FLY) {
+        fly();
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
@@ -1459,20 +1447,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         return;
     }
     SSFM_STAMP(3);
-    if (MODE == FM_FLY) {
-        // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
-        T ph[E];
-#pragma unroll
-        for (int t = 0; t < E; ++t) ph[t] = m[t].y * h;
-        // Re D~ = -alpha/2 is the same number at every frequency for a fibre (devices.py:1145): then exp(Re h) is ONE
-        // exponential per thread instead of 16 (bit-identical: the same float product, the same function); any other
-        // operator takes the general path
-        bool flat = true;
-#pragma unroll
-        for (int t = 1; t < E; ++t) flat = flat && (m[t].x == m[0].x);
-        const T e0 = exp_acc<T>(m[0].x * h);
-        fly_factors<E>(m, ph, flat, e0, h, a.inv_n);
-    }
+    if (MODE == FM_FLY && !EARLY_FLY) fly();
     if (MODE == FM_PHASE && !EARLY_PHASE) {
 #pragma unroll
         for (int t = 0; t < E; ++t) m[t] = phase32_factor(pu[t], a.amp);
@@ -1614,7 +1589,7 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
     T pk[E];
     TimeArgs<T> ta;
     ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = nullptr;
-    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
+    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0;
     ta.s_in = nullptr; ta.s_out = nullptr; ta.pkeep = pk; ta.mul = nullptr;
     FreqArgs<T> fa;
     fa.F = a.Y; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = a.inv_n; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0;
@@ -1685,7 +1660,7 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium_adapt(const MediumAdaptA
     if (S.done) return;
     TimeArgs<T> ta;
     ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = a.zlog;
-    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0; ta.lane = 0; ta.lanes2 = 0;
+    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0;
     T pk[E];
     ta.s_in = &s_state[0]; ta.s_out = &s_state[1]; ta.pkeep = pk; ta.mul = nullptr;
     FreqArgs<T> fa;
@@ -2385,7 +2360,7 @@ template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long
     if (threadIdx.x == 0) {
         T m = wave_max[0];
         for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) m = wave_max[w] > m ? wave_max[w] : m;
-        atomicMax(&st->slots[0][1][blockIdx.x % kAdaptSlots], float_bits<T>(m));       // (the slots "before step 0")
+        atomicMax(&st->slots[1][blockIdx.x % kAdaptSlots], float_bits<T>(m));       // (the slots "before step 0")
     }
 }
 
@@ -2396,7 +2371,7 @@ template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog,
     if (phase == 0) {
         const unsigned long long mb = slots_max<T>(st, 1);
         if (threadIdx.x < kAdaptSlots)
-            for (int l = 0; l < kAdaptLanes; ++l) { st->slots[l][0][threadIdx.x] = 0ull; st->slots[l][1][threadIdx.x] = 0ull; }
+            st->slots[0][threadIdx.x] = 0ull; st->slots[1][threadIdx.x] = 0ull;
         if (threadIdx.x != 0) return;
         T h;
         if (single_step) h = st->length;

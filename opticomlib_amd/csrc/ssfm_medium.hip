@@ -82,12 +82,17 @@ unsigned xcc_mask(int device) {
     int cur = 0;
     unsigned* d = nullptr;
     unsigned h = 0u;
+    hipStream_t s = nullptr;            // (a stream of its own: nothing of this library runs on the legacy stream)
     if (hipGetDevice(&cur) != hipSuccess || cur != device || hipMalloc(&d, sizeof(unsigned)) != hipSuccess) return 0u;
-    if (hipMemset(d, 0, sizeof(unsigned)) == hipSuccess) {
-        hipLaunchKernelGGL(k_xcc_probe, dim3(256), dim3(64), 0, 0, d);
-        if (hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) h = 0u;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) {
+        if (hipMemsetAsync(d, 0, sizeof(unsigned), s) == hipSuccess) {
+            hipLaunchKernelGGL(k_xcc_probe, dim3(256), dim3(64), 0, s, d);
+            if (hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) h = 0u;
+        }
+        (void)hipStreamDestroy(s);
     }
     (void)hipFree(d);
+    if (h == 0u) return 0u;             // (not cached: a later plan may try again)
     return cache[device] = h;
 }
 }  // namespace ssfm

@@ -626,6 +626,10 @@ def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, 
     else:
         output = optical_signal(plan.get_field().reshape(shape))
     output.execution_time = time.time() - t0
+    # beside the reference's execution_time: which engine ran ("two_kernel", "medium", "adaptive_fused" ..., _lib.ENGINES) and whether a one-launch
+    # engine had to give way to its fallback -- a shared GPU or a profiler turns the fast engines off without any other sign
+    info = plan.last_run_info()
+    output.engine = info["engine"] + (" (fell back)" if info["fell_back"] else "")
     return output
 
 

@@ -205,26 +205,23 @@ def test_any_length_adaptive_complex128_and_dm(n):
 def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
     """Lengths that are not powers of two: the whole run queued from C (ssfm_chirp_propagate; adaptive: the step rule evaluated on the device in
     the caller's float32 arithmetic) against the loop that calls one entry point per kernel from Python and waits for every step's maximum
-    (SSFM_CHIRP_LOOP=python).  With the three-launch middle (SSFM_CHIRP_FUSED=0) the two are the same kernels with the same arguments: bit for bit,
-    and the same z log; with the fused middle pass (SSFM_CHIRP_ENDS=0) the product with exp(D~ h) is rounded in another place, and with the step's two
-    ends inside the column launches as well (default, five launches per step) so are the chirp products: 1e-12.  Up to 2048 samples a fixed-step run is
-    one launch (k_small_chirp; SSFM_CHIRP_SMALL=0 turns it off), with the two half rotations between steps merged into one: 1e-12 as well."""
+    (SSFM_CHIRP_LOOP=python).  The C loop takes five launches per step -- the middle of a step in one column launch, the step's two ends inside the
+    first and the last -- so the product with exp(D~ h) and the chirp products are rounded in other places than in the host loop's nine: 1e-12.  Up to
+    2048 samples a fixed-step run is one launch (k_small_chirp; SSFM_CHIRP_SMALL=0 turns it off), with the two half rotations between steps merged
+    into one: 1e-12 as well.  (Round 3's nine- and seven-launch forms of the C loop, bit-identical to the host loop, were removed in round 4.)"""
     gv(**workloads.BENCH_GV)
     a = workloads.qpsk_field(1 << 14, seed=n, power_w=8e-3)[:, :n]
     x = optical_signal(a)
     for kw in (dict(length=6.0, h=0.37, **workloads.SMF), dict(length=8.0, phi_max=0.004, **workloads.SMF)):
         res = {}
-        for name, env in (("python", {"SSFM_CHIRP_LOOP": "python"}), ("c3", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "0", "SSFM_CHIRP_SMALL": "0"}),
-                          ("c7", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "1", "SSFM_CHIRP_ENDS": "0", "SSFM_CHIRP_SMALL": "0"}),
-                          ("c5", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "1", "SSFM_CHIRP_ENDS": "1", "SSFM_CHIRP_SMALL": "0"}),
-                          ("c", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_FUSED": "1", "SSFM_CHIRP_ENDS": "1", "SSFM_CHIRP_SMALL": "1"})):
+        for name, env in (("python", {"SSFM_CHIRP_LOOP": "python"}), ("c5", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_SMALL": "0"}),
+                          ("c", {"SSFM_CHIRP_LOOP": "c", "SSFM_CHIRP_SMALL": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             y = oa.FIBER(x, **kw).signal
             z, _ = oa.FIBER(x, return_steps=True, **kw) if name == "python" else (None, None)
             res[name] = (y, z)
-        np.testing.assert_array_equal(res["c3"][0], res["python"][0])
-        for name in ("c7", "c5", "c"):      # (c5: the step's ends inside the column passes; c: n <= 2048, fixed step: the whole run in one launch)
+        for name in ("c5", "c"):      # (c5: five launches per step; c: n <= 2048: the whole run in one launch)
             assert relmax(res[name][0], res["python"][0]) < 1e-12 * (1 if "h" in kw else 1e4), name     # (adaptive: a last-bit difference in a maximum moves a step size)
         assert len(res["python"][1]) > 10
     # one polarisation (a single row: the one-launch adaptive engine has nobody to exchange maxima with)
@@ -669,7 +666,6 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
     monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)
     monkeypatch.delenv("SSFM_E", raising=False)
     monkeypatch.delenv("SSFM_MEDIUM_SPLIT", raising=False)
-    monkeypatch.setenv("SSFM_GRAPH", "0")
     got = {}
     for med in ("1", "0"):
         monkeypatch.setenv("SSFM_MEDIUM", med)
@@ -681,6 +677,10 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
                 p.set_field(a)
                 p.propagate_fixed(1.3, hs if rep != 1 else hs[:7])
                 outs.append((p.get_field(), p.last_propagate_ms()[1]))
+                # which engine REALLY ran (a one-launch run that gave up would have been repeated on the two-kernel engine behind our back)
+                one_launch = med == "1" and ((n if (rows == 2 and log2n >= 16) else n * rows) <= (1 << 17))
+                info = p.last_run_info()
+                assert info["engine"] == ("medium" if one_launch else "two_kernel") and not info["fell_back"] and info["fallbacks_total"] == 0, info
             got[med] = outs
         finally:
             p.close()
@@ -689,11 +689,65 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
         assert l0 > 10 and (l1 == (2 if split else 1) if (n if split else n * rows) <= (1 << 17) else l1 == l0)
         np.testing.assert_array_equal(f1, f0)
     np.testing.assert_array_equal(got["1"][0][0], got["1"][2][0])
-    if log2n <= 15:
-        A = a.copy()
-        for h_ in hs:
-            A = orc.ssfm_step_c64(A, orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13), np.float32(1.3), h_)
-        assert relmax(got["1"][0][0], A) < TOL_100
+    # every size against the oracle directly (a few seconds of CPU at 2^17 samples)
+    A = a.copy()
+    for h_ in hs:
+        A = orc.ssfm_step_c64(A, orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13), np.float32(1.3), h_)
+    assert relmax(got["1"][0][0], A) < TOL_100
+
+
+def test_a_stream_ordered_consumer_never_sees_a_run_that_gave_up(tmp_path):
+    """include/ssfm_amd.h "WHEN THE FIELD IS VALID": a caller that has asked for the plan's stream may order its own work behind
+    ssfm_propagate_fixed without ssfm_synchronize.  The one-launch engine of medium plans only knows at its end whether its workgroups met;
+    with no patience at all (SSFM_FUSED_PATIENCE_TICKS=-1) they give up, and the call itself must already have repeated the run on the
+    two-kernel engine: a copy queued on the plan's stream right behind the call holds the right field, and the run info says what happened
+    (examples/stream_ordered_consumer.cpp, built with hipcc: the consumer is a HIP program of its own)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stream_ordered_consumer")
+    libdir = os.path.join(root, "opticomlib_amd")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "stream_ordered_consumer.cpp"), "-o", exe,
+                    "-L" + libdir, "-l:_ssfm_amd.so", "-Wl,-rpath," + libdir], check=True, capture_output=True)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SSFM_")}
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "engine 1 fell_back 1 fallbacks 1; stream-ordered copy equals the two-kernel result" in r.stdout
+
+
+def test_the_lanes_of_a_plan_get_hardware_queues_of_their_own(monkeypatch):
+    """The runtime maps the streams of a priority class onto four hardware queues; with 3 (mod 4) other streams of the class alive the second
+    lane of a new plan used to land on the queue of the first (profiles/r04_order_dependence.txt): lanes one after the other, and round 3's
+    engines that waited across lanes inside a kernel stalled until their patience ran out.  A plan now probes its lanes and replaces a stream
+    that shares a queue: with 0 ... 5 other plans alive the lanes report queues of their own and a two-lane run takes the same time."""
+    import time
+    gv(**workloads.BENCH_GV)
+    n = 1 << 19
+    monkeypatch.setenv("SSFM_LANES", "2")
+    a = workloads.qpsk_field(n, seed=4).astype(np.complex64)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    hs = np.full(300, 0.125, np.float32)
+    others, times = [], []
+    try:
+        for k in range(6):
+            p = _lib.Plan(n, 2, _lib.C64)
+            try:
+                assert p.lanes == 2
+                p.set_linear_operator(D); p.set_field(a)
+                p.propagate_fixed(1.3, hs); p.synchronize()
+                t0 = time.perf_counter()
+                p.propagate_fixed(1.3, hs); p.synchronize()
+                times.append(time.perf_counter() - t0)
+                assert not p.last_run_info()["lanes_share_queue"], k
+            finally:
+                p.close()
+            q = _lib.Plan(1 << 14, 1, _lib.C64)                       # one more USED high-priority stream stays alive
+            q.set_linear_operator(oa.devices.linear_operator(1 << 14, gv.dt, 0.2, -21.7, 0.13))
+            q.set_field(workloads.qpsk_field(1 << 14, seed=k, n_pol=1)); q.propagate_fixed(1.3, hs[:3]); q.synchronize()
+            others.append(q)
+    finally:
+        for q in others:
+            q.close()
+    assert max(times) < 1.35 * min(times), times
 
 
 @pytest.mark.parametrize("rows", [1, 2, 4])
@@ -709,7 +763,6 @@ def test_plans_of_8192_samples_take_the_one_xcd_engine(rows, monkeypatch):
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
     for k in ("SSFM_FUSED_PATIENCE_TICKS", "SSFM_FORCE_FLY", "SSFM_E"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("SSFM_GRAPH", "0")
     got = {}
     for name, env in (("default", {"SSFM_MEDIUM": "1", "SSFM_SMALL": "1"}), ("small", {"SSFM_MEDIUM": "0", "SSFM_SMALL": "1"}),
                       ("two-kernel", {"SSFM_MEDIUM": "0", "SSFM_SMALL": "0"})):
@@ -742,7 +795,6 @@ def test_medium_single_launch_engine_on_several_plans_at_once(monkeypatch):
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
     hs = np.full(40, 0.25, np.float32)
     fields = [workloads.qpsk_field(n, seed=40 + k, power_w=5e-3).astype(np.complex64) for k in range(4)]
-    monkeypatch.setenv("SSFM_GRAPH", "0")
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
     monkeypatch.delenv("SSFM_FORCE_FLY", raising=False)
     monkeypatch.delenv("SSFM_E", raising=False)
@@ -837,7 +889,7 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6 if prec == _lib.C64 else 1e-12)
     assert relmax(f1, f0) < (5 * TOL_100 if prec == _lib.C64 else 1e-9)
-    if log2n <= 15:
+    if True:                       # every size against the oracle directly
         if prec == _lib.C128:
             ref = orc.fiber_c128(a if rows > 1 else a[0], gv.dt, 4.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.002)
             assert relmax(f1, ref) < 1e-7
@@ -873,6 +925,8 @@ def test_medium_adaptive_run_in_one_launch(log2n, rows, monkeypatch):
                 p.set_field(a)
                 steps, z, _ = p.propagate_adaptive(1.3, 5.0, 0.003, False)
                 outs.append((steps, z, p.get_field(), p.last_propagate_ms()[1]))
+                info = p.last_run_info()
+                assert (info["engine"] == "medium_adaptive") == (one == "1") and not info["fell_back"], info
             res[one] = outs
         finally:
             p.close()
@@ -885,151 +939,54 @@ def test_medium_adaptive_run_in_one_launch(log2n, rows, monkeypatch):
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6)
     assert relmax(f1, f0) < 5 * TOL_100
-    if log2n <= 14 and rows <= 2:
+    if rows <= 2:                  # (the reference takes one or two polarisations) every size against the oracle directly
         ref = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 5.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.003)
         assert relmax(f1, ref) < TOL_1000
 
 
 @pytest.mark.parametrize("log2n, rows", [(18, 2), (19, 1), (19, 2), (20, 2)])
-def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch):
+def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch, golden_dir):
     """complex64 plans whose column kernel has up to 512 workgroups (2^20 x 2: two per CU, all resident) run the same fused kernel:
     every workgroup publishes (step, max |A|^2) as one 8-byte word and reads everybody's (AdaptState::wgmax) -- two launches per step
-    instead of three.  SSFM_ADAPT_FUSED_MAX=64 keeps round 2's limit.  Same step rule on the same maxima: the z logs agree."""
+    instead of three (SSFM_ADAPT_FUSED=0).  Each engine against the ORACLE's run of the same field at full size (z log, every 257th sample,
+    power: tests/golden/make_adaptive_strided.py), and against each other; the run info says which engine really ran."""
     n = 1 << log2n
     gv(**workloads.BENCH_GV)
     a = workloads.qpsk_field(n, seed=70 + log2n, power_w=10e-3)[:rows]
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
-    monkeypatch.delenv("SSFM_ADAPT_LANES", raising=False)
-    monkeypatch.delenv("SSFM_ADAPT_FUSED_LANES", raising=False)
-    monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
+    g = np.load(os.path.join(golden_dir, "adaptive_full_strided.npz"))
+    key = f"{log2n}x{rows}"
+    zo, so, po = g[f"z_{key}"], g[f"samples_{key}"], g[f"power_{key}"]
     res = {}
-    for cap in ("512", "64"):
-        monkeypatch.setenv("SSFM_ADAPT_FUSED_MAX", cap)
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SSFM_ADAPT_FUSED", fused)
         p = _lib.Plan(n, rows, _lib.C64)
         try:
             p.set_linear_operator(D)
             for rep in range(2):
                 p.set_field(a)
                 steps, z, _ = p.propagate_adaptive(1.3, 6.0, 0.004, False)
-            res[cap] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
+            info = p.last_run_info()
+            assert info["engine"] == ("adaptive_fused" if fused == "1" else "adaptive_3_launches") and not info["fell_back"], info
+            res[fused] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
         finally:
             p.close()
-    s1, z1, f1, l1 = res["512"]
-    s0, z0, f0, l0 = res["64"]
+        # against the oracle (the reference's arithmetic): same number of steps within one, the z log while both are in step, the field
+        f = res[fused][2].reshape(rows, n)
+        assert abs(steps - (len(zo) - 1)) <= 1, (steps, len(zo) - 1)
+        k = min(steps, len(zo) - 1, 12)
+        np.testing.assert_allclose(np.asarray(z)[:k + 1], zo[:k + 1], rtol=5e-6, atol=1e-7)
+        assert relmax(f[:, ::257], so) < TOL_1000, relmax(f[:, ::257], so)
+        np.testing.assert_allclose(np.mean(np.abs(f.astype(np.complex128)) ** 2, axis=-1), po, rtol=1e-4)
+    s1, z1, f1, l1 = res["1"]
+    s0, z0, f0, l0 = res["0"]
     assert s1 > 10 and abs(z1[-1] - 6.0) < 1e-5
     assert l1 < l0 and l1 <= 2 * s1 + 40 and l0 >= 3 * s0
     assert abs(s1 - s0) <= 1
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6)
     assert relmax(f1, f0) < 5 * TOL_100
-
-
-@pytest.mark.parametrize("log2n", [19, 20])
-def test_fused_adaptive_kernel_on_two_lanes(log2n, monkeypatch):
-    """SSFM_ADAPT_FUSED_LANES=1 (opt-in): the fused form with a stream per polarisation; MID_A of a lane reads the words of both lanes.
-    The same kernels on the same rows, the same maxima: z logs and fields identical to the one-stream fused run, bit for bit."""
-    n = 1 << log2n
-    gv(**workloads.BENCH_GV)
-    a = workloads.qpsk_field(n, seed=90 + log2n, power_w=10e-3)
-    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
-    monkeypatch.setenv("SSFM_LANES", "2")
-    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
-    monkeypatch.delenv("SSFM_ADAPT_LANES", raising=False)
-    monkeypatch.delenv("SSFM_ADAPT_FUSED_MAX", raising=False)
-    monkeypatch.setenv("SSFM_ADAPT_FUSED", "1")
-    res = {}
-    for lanes in ("1", "0"):
-        monkeypatch.setenv("SSFM_ADAPT_FUSED_LANES", lanes)
-        p = _lib.Plan(n, 2, _lib.C64)
-        try:
-            p.set_linear_operator(D)
-            for rep in range(2):
-                p.set_field(a)
-                steps, z, _ = p.propagate_adaptive(1.3, 3.0, 0.004, False)
-            res[lanes] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
-        finally:
-            p.close()
-    s2, z2, f2, l2 = res["1"]
-    s1, z1, f1, l1 = res["0"]
-    assert s2 == s1 > 8 and l1 < 2 * s1 + 40
-    if l2 < 4 * s2:
-        # the lanes' first hand-over ran out of patience and the plan fell back to three launches per step (seen when another test preceded this one in a
-        # certain position, DESIGN.md section 10 "Open"): the results must still be right, but the two-lane kernels were not what produced them
-        assert relmax(f2, f1) < 5 * TOL_100 and abs(len(z2) - len(z1)) <= 1
-        pytest.skip(f"the opt-in two-lane fused engine fell back on this box ({l2} launches for {s2} steps): nothing to compare bit for bit")
-    np.testing.assert_array_equal(z2, z1)
-    np.testing.assert_array_equal(f2, f1)
-
-
-@pytest.mark.parametrize("log2n", [19, 20])
-def test_two_lane_adaptive_run_against_the_one_stream_engine(log2n, monkeypatch):
-    """An adaptive run of a dual-polarisation field of 2^19 samples or more drives the polarisations on two streams, as the
-    fixed-step runs do; they share nothing but the step size, which a lane's BEGIN derives from BOTH lanes' maxima after waiting
-    inside the kernel for the other lane's END (AdaptState::arrived).  SSFM_ADAPT_LANES=1 at plan creation keeps the one-stream
-    engine.  Same maxima, same rule, the same kernels row by row: identical z logs and fields, bit for bit; against the oracle."""
-    n = 1 << log2n
-    gv(**workloads.BENCH_GV)
-    a = workloads.qpsk_field(n, seed=70 + log2n, power_w=10e-3)
-    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
-    res = {}
-    monkeypatch.setenv("SSFM_LANES", "2")                              # (whatever the suite runs under)
-    monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS", raising=False)
-    monkeypatch.setenv("SSFM_ADAPT_FUSED_MAX", "64")                   # (the one-stream reference: three launches per step)
-    for lanes in ("2", "1"):
-        monkeypatch.setenv("SSFM_ADAPT_LANES", lanes)
-        p = _lib.Plan(n, 2, _lib.C64)
-        try:
-            p.set_linear_operator(D)
-            for rep in range(2):
-                p.set_field(a)
-                steps, z, _ = p.propagate_adaptive(1.3, 3.0, 0.004, False)
-            res[lanes] = (steps, z, p.get_field(), p.last_propagate_ms()[1])
-        finally:
-            p.close()
-    s2, z2, f2, l2 = res["2"]
-    s1, z1, f1, l1 = res["1"]
-    assert s2 == s1 > 8 and abs(z2[-1] - 3.0) < 1e-5
-    assert l2 >= 6 * s2 and l1 < 3 * s1 + 40           # six launches per step on two streams, three on one
-    np.testing.assert_array_equal(z2, z1)
-    np.testing.assert_array_equal(f2, f1)
-    if log2n == 19:
-        zr, Ar = orc.fiber_c64(a, gv.dt, 3.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.004, return_steps=True)
-        assert abs(len(zr) - 1 - s2) <= 1
-        k = min(len(zr), len(z2), 8)
-        np.testing.assert_allclose(z2[:k], zr[:k], rtol=2e-5)
-        assert relmax(f2, Ar[-1]) < TOL_100
-
-
-def test_two_lane_adaptive_run_without_patience_still_gives_the_one_stream_result(monkeypatch):
-    """A lane never waits longer than its patience for the other one; with none at all a lane that finds the other's maxima
-    missing gives up at once, the plan restores the input and repeats the run on one stream.  Whichever way each run goes,
-    the result is the one-stream result."""
-    n = 1 << 19
-    gv(**workloads.BENCH_GV)
-    a = workloads.qpsk_field(n, seed=5, power_w=10e-3)
-    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
-    monkeypatch.setenv("SSFM_ADAPT_LANES", "1")
-    monkeypatch.setenv("SSFM_ADAPT_FUSED_MAX", "64")                   # (one stream = three launches per step here)
-    q = _lib.Plan(n, 2, _lib.C64)
-    try:
-        q.set_linear_operator(D); q.set_field(a)
-        s0, z0, _ = q.propagate_adaptive(1.3, 3.0, 0.004, False)
-        f0 = q.get_field()
-    finally:
-        q.close()
-    monkeypatch.setenv("SSFM_LANES", "2")
-    monkeypatch.setenv("SSFM_ADAPT_LANES", "2")
-    monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
-    p = _lib.Plan(n, 2, _lib.C64)
-    try:
-        p.set_linear_operator(D)
-        for rep in range(3):
-            p.set_field(a)
-            s1, z1, _ = p.propagate_adaptive(1.3, 3.0, 0.004, False)
-            assert s1 == s0 and np.array_equal(z1, z0) and np.array_equal(p.get_field(), f0)
-    finally:
-        p.close()
 
 
 def test_fused_adaptive_kernel_gives_up_and_the_run_falls_back(monkeypatch):
@@ -1059,27 +1016,6 @@ def test_fused_adaptive_kernel_gives_up_and_the_run_falls_back(monkeypatch):
             assert s1 == s0 and np.array_equal(z1, z0) and np.array_equal(p.get_field(), f0)
     finally:
         p.close()
-
-
-def test_replayed_graphs_follow_the_operator(monkeypatch):
-    """A schedule that comes again is replayed as a hipGraph (SSFM_GRAPH=1: from the second call; SSFM_GRAPH=lazy: from the fourth).  Kernel arguments are frozen in a graph -- among them the modulus of a phase table, which follows the fibre's loss --
-    so FIBER and DBP (negated loss) with the SAME schedule on the SAME plan must not share a graph: five rounds of FIBER then DBP,
-    each against the oracle."""
-    gv(**workloads.BENCH_GV)
-    n = 1 << 15
-    a = workloads.qpsk_field(n, seed=12, power_w=4e-3).astype(np.complex64)
-    kw = dict(length=8, h=0.5, alpha=0.25, beta_2=-21.7, beta_3=0.13, gamma=1.3)
-    want_f = orc.fiber_c64(a, gv.dt, **kw)
-    want_b = orc.fiber_c64(want_f, gv.dt, length=8, h=0.5, alpha=-0.25, beta_2=21.7, beta_3=-0.13, gamma=-1.3)
-    for graph in ("1", "lazy"):
-        monkeypatch.setenv("SSFM_GRAPH", graph)
-        oa.devices.release_plans()
-        for rep in range(5):
-            y = oa.FIBER(optical_signal(a), **kw)
-            assert relmax(y.signal, want_f) < TOL_100, (graph, rep)
-            z = oa.DBP(y, **kw)
-            assert relmax(z.signal, want_b) < TOL_100, (graph, rep)
-    oa.devices.release_plans()
 
 
 def test_operator_tables_of_one_schedule_do_not_evict_each_other():
@@ -2002,7 +1938,8 @@ def test_c_abi_from_plain_c(tmp_path):
                     "-L" + libdir, "-l:_ssfm_amd.so", "-lm", "-Wl,-rpath," + libdir], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "ABI version 1" in r.stdout and "back-propagated" in r.stdout
+    assert "ABI version 2" in r.stdout and "back-propagated" in r.stdout
+    assert "last run: engine 4, fell back 0" in r.stdout or "last run: engine 5, fell back 0" in r.stdout        # (budgeted adaptive calls: a launch-per-pass engine)
     assert "operator label after set: 0x5eed, after a new operator: 0" in r.stdout          # the plan cleared the label itself
     assert "adaptive:" in r.stdout and "z_end = 20.000000 km" in r.stdout
     assert "PRBS-7: 10000001000001100001" in r.stdout                                         # reference tests/devices_test.py:52-71
@@ -2492,8 +2429,6 @@ def test_host_threads_on_the_same_plans():
     (tools/thread_check.py; ctypes releases the GIL during the calls)."""
     import subprocess
     import sys
-    if os.environ.get("SSFM_GRAPH", "0") not in ("", "0"):
-        pytest.skip("hipGraph capture (opt-in) is not safe beside host threads that use the legacy stream: INTEGRATION.md, DESIGN.md section 4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_check.py")], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr[-2000:]
@@ -2556,9 +2491,7 @@ def test_adaptive_capture_goes_to_the_host_in_blocks_and_api_order():
 
 def test_one_launch_adaptive_run_of_any_length_gives_up_cleanly(monkeypatch):
     """With no patience for the other row's maximum the one-launch adaptive engine of n <= 2048 stores nothing and the run is queued step by step.
-    (The knob is read when a plan is made: a length whose plan -- 512 points x 2, complex128 -- no other test uses.  Kept LAST in this file: with it
-    before them, the launch counts of test_fused_adaptive_kernel_on_two_lanes -- an opt-in engine that needs the whole GPU for one grid -- came out as
-    the fallback's in two full-suite runs; fields and z logs were right either way.  Not understood yet: DESIGN.md section 10.)"""
+    (The knob is read when a plan is made: a length whose plan -- 512 points x 2, complex128 -- no other test uses.)"""
     gv(**workloads.BENCH_GV)
     x = optical_signal(workloads.qpsk_field(1 << 11, seed=5, power_w=8e-3)[:, :200])
     kw = dict(length=8.0, phi_max=0.004, **workloads.SMF)
