@@ -293,7 +293,7 @@ def committed_profile_figures(kernels, rows_per_launch):
     passes): read from the newest committed summaries under profiles/ and reported under `from_profiles`, apart from
     what this run measured."""
     out = {}
-    for stats_name in ("r03_final_kernel_stats.csv", "r02_final_kernel_stats.csv"):
+    for stats_name in ("r04_final_kernel_stats.csv", "r03_final_kernel_stats.csv", "r02_final_kernel_stats.csv"):
         stats = os.path.join(ROOT, "profiles", stats_name)
         if not os.path.exists(stats):
             continue
@@ -310,7 +310,7 @@ def committed_profile_figures(kernels, rows_per_launch):
         except Exception:
             pass
         break
-    for pmc_name in ("r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for pmc_name in ("r04_final_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if not os.path.exists(pmc):
             continue
@@ -469,6 +469,7 @@ def main():
         elapsed = float(t.item())
 
     ms_dev, launches = plan.last_propagate_ms() if plan is not None else (0.0, 0)
+    run_info = plan.last_run_info() if plan is not None else None          # which engine ran, whether it fell back, whether the lanes share a queue
     if workload == "c4":
         out = y_all.to_host()[:fields_here]
     else:
@@ -527,38 +528,48 @@ def main():
                 kt = plan.kernel_times()
                 plan.set_profiling(0)
                 return kt
-            sparse = timed_pass(2)                         # one event per 64 launches: pooled average launch time, no perturbation
-            sampled = timed_pass(3)                        # one bracketed launch of each kernel per 16 launches: per-kernel duration
+            # (1) The launch duration that prices the roofline comes from the TIMED REGION itself, not from an extra pass: the plan brackets every
+            # propagate call with two HIP events on its own stream (ssfm_last_propagate_ms); a lane is a strictly serial chain of launches, so
+            # device time / launches per lane = the average launch PERIOD on that stream = kernel + the dependent-launch gap behind it.
+            launches_per_lane = launches / max(lanes, 1)
+            period_us = ms_dev * 1e3 / max(launches_per_lane, 1)
+            # (2) Two extra passes after the timed region only tell the two kernels apart: one launch of each per 16 bracketed by two events of its
+            # own (the brackets add the markers' own cost, so only the RATIO is used), and one event per 64 launches as a cross-check of (1).
+            sparse = timed_pass(2)
+            sampled = timed_pass(3)
             pooled_us = sum(v[1] for v in sparse.values()) / max(sum(v[0] for v in sparse.values()), 1) * 1e3
             bracketed_us = {k: (v[1] / v[0] * 1e3 if v[0] else None) for k, v in sampled.items()}
             ok = all(v is not None for v in bracketed_us.values())
-            # The bracketed intervals carry the cost of their own two marker packets (1-2 us each way), the pooled figure does not:
-            # the pooled time per launch is split between the two kernels in the ratio of their bracketed times.
             mean_b = sum(bracketed_us.values()) / len(bracketed_us) if ok else None
-            launch_us = {k: (pooled_us * bracketed_us[k] / mean_b if ok else None) for k in bracketed_us}
-            dom = max(launch_us, key=lambda k: launch_us[k] or 0.0) if ok else None
-            avg_us = launch_us[dom] if ok else None
-            achieved = b_alg_launch / (avg_us * 1e-6) / 1e9 if ok else None
+            launch_us = {k: (period_us * bracketed_us[k] / mean_b if ok else period_us) for k in bracketed_us}
+            dom = max(launch_us, key=lambda k: launch_us[k] or 0.0)
+            avg_us = launch_us[dom]
+            achieved = b_alg_launch / (avg_us * 1e-6) / 1e9
+            gap_us = 1.35                                  # dependent-launch gap on a stream (profiles/r04_c2_stamps_and_trace.txt: 1.2-1.4 us; MI355X_MICROARCH.md "boundary")
             prof = committed_profile_figures(list(launch_us), rows_per_launch)
             roofline.update({
-                "kernel": dom, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS if ok else None,
+                "kernel": dom, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (prof.get("traffic_per_kernel") or {}).get(dom),
                 "avg_launch_us": avg_us,
                 "launch_us": launch_us,
+                "launch_period_us": period_us,
+                "kernel_us_without_gap": {k: v - gap_us for k, v in launch_us.items()},
+                "assumed_gap_us": gap_us,
                 "launches_sampled": {k: v[0] for k, v in sampled.items()},
                 "bracketed_launch_us": bracketed_us,
                 "pooled_launch_us": pooled_us,
                 "algorithmic_bytes_per_launch": b_alg_launch,
                 "lanes": lanes, "rows_per_launch": rows_per_launch,
-                "measured_in_this_run": ["achieved", "frac", "avg_launch_us", "launch_us", "launches_sampled", "bracketed_launch_us", "pooled_launch_us", "step_frac"],
+                "measured_in_this_run": ["achieved", "frac", "avg_launch_us", "launch_us", "launch_period_us", "launches_sampled", "bracketed_launch_us",
+                                         "pooled_launch_us", "step_frac"],
                 "read_from_profiles": ["traffic", "from_profiles"],
                 "from_profiles": prof,
-                "note": "HIP events on the launch's own stream, two extra passes of the same workload after the timed region. "
-                        "pooled_launch_us: one event per 64 launches, interval / launches = average kernel + the dependent-launch gap "
-                        "behind it (~1.4 us, which rocprofv3's begin->end durations under from_profiles do not contain). "
-                        "bracketed_launch_us: one launch of each kernel per 16 between two events of its own (adds the markers' own "
-                        "cost). launch_us = pooled_launch_us split in the ratio of the bracketed times; avg_launch_us = the larger. "
-                        "With lanes > 1 launches of different row groups overlap on the chip; the chip-level figure is step_frac",
+                "note": "avg_launch_us = the dominant kernel's average launch period on its stream in the TIMED region: HIP events of the plan around the "
+                        "propagate call (device_ms_last_propagate) / launches per lane, split between k_time and k_freq in the ratio of their bracketed "
+                        "times (second extra pass).  A period = kernel + the dependent-launch gap behind it, so `achieved` is a lower bound of the kernel's "
+                        "own rate (kernel_us_without_gap subtracts the stated gap).  With lanes > 1 each lane is such a chain and the chains run side by "
+                        "side: frac equals step_frac when both kernels take the same time.  rocprofv3's begin->end averages (from_profiles) are taken "
+                        "under the profiler, which slows the run by a few per cent",
             })
         if world == 1 and workload == "c2" and not args.no_secondary:
             other = secondary_c1(a_c2, dt, fibre, local_rank)
@@ -606,6 +617,7 @@ def main():
            if gather_ms is not None else {}),
         "device_ms_last_propagate": ms_dev,
         "launches_per_propagate": launches,
+        "engine": run_info,
         "us_per_ssfm_step": elapsed / args.steps / steps_per_field * 1e6 / max(fields_here, 1),
         "us_per_ssfm_step_note": "wall time of a bench step / SSFM steps per field / fields on this GPU (per field-step)",
         "output_power_W_per_field": checks,

@@ -13,6 +13,17 @@ python bench.py --steps 5 --warmup 1 > ${T}_bench.json 2> ${T}_bench.err; echo "
 python bench.py --workload c3 --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass > ${T}_bench_c3_1rank.json 2> ${T}_bench_c3.err; echo "bench c3 (one rank, nccl) rc=$?"; cut -c1-900 ${T}_bench_c3_1rank.json
 python bench.py --workload c4 --steps 2 --warmup 1 --cpu-steps 0 > ${T}_bench_c4_1rank.json 2> ${T}_bench_c4.err; echo "bench c4 (one rank, nccl) rc=$?"; cut -c1-900 ${T}_bench_c4_1rank.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass --no-secondary > ${T}_bench_c2_torchrun.json 2> ${T}_bench_c2_torchrun.err; echo "bench under torchrun (one rank) rc=$?"; cut -c1-600 ${T}_bench_c2_torchrun.json
+# several ranks on the ONE GPU of this box (diagnostics: BENCH_SAME_GPU + gloo; RCCL wants a GPU per rank): the N > 1 code path of bench.py end to end, and that
+# stdout is the JSON line alone
+for spec in "2:c2" "2:c4" "4:c4"; do
+  N=${spec%%:*}; W=${spec#*:}
+  BENCH_SAME_GPU=1 BENCH_DIST_BACKEND=gloo python bench.py --gpus $N --workload $W --steps 1 --warmup 1 --cpu-steps 0 --no-profile-pass --no-secondary > ${T}_bench_${N}ranks_same_gpu_gloo_$W.json 2> ${T}_bench_${N}ranks_$W.err
+  echo "bench --gpus $N --workload $W on one GPU (gloo) rc=$? lines=$(wc -l < ${T}_bench_${N}ranks_same_gpu_gloo_$W.json)"; python -c "import json,sys; d=json.load(open('${T}_bench_${N}ranks_same_gpu_gloo_$W.json')); print(d['n_gpus'], d['value'], d['cpu_affinity'])"
+done
+# where the time of a workgroup goes (in-kernel clock stamps of k_freq alone / with two rows), the lanes' launch timeline and the per-workgroup view (trace build)
+{ echo "== k_freq phases, in-kernel clock stamps (tools/stamp_harness.hip), one row per launch"; ./build/stamp_harness 1; echo "== two rows per launch"; ./build/stamp_harness 2;
+  echo "== launch timeline of the two lanes (tools/trace_timeline.py, -DSSFM_TRACE=1 build)"; SSFM_LIB=build/var/_ssfm_trace.so python tools/trace_timeline.py 2>&1 | tail -14;
+  echo "== per-workgroup view of eight consecutive launches (tools/trace_wg.py)"; SSFM_LIB=build/var/_ssfm_trace.so python tools/trace_wg.py 2>&1 | tail -56; } > ${T}_c2_stamps_and_trace.txt 2>&1; tail -3 ${T}_c2_stamps_and_trace.txt
 rm -rf ${T}_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_prof -- python3 bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass > ${T}_prof_bench.json 2> ${T}_prof.err; echo "rocprof rc=$?"
 find ${T}_prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} ${T}_kernel_stats.csv; head -8 ${T}_kernel_stats.csv
