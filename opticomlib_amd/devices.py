@@ -864,8 +864,10 @@ def PD(input: optical_signal, BW: float, r: float = 1.0, T: float = 300.0, R_loa
     'shot-only', 'ase-thermal', 'ase-shot', 'thermal-shot'; case-insensitive).
 
     ``rng`` (extension): ``"numpy"`` draws the Gaussian currents from NumPy's global generator with the
-    reference's calls in the reference's order (seed-for-seed identical output); ``"device"`` uses the library's
-    Philox generator on the GPU (same statistics, the whole detector stays on the device, ~50x faster at 2^20).
+    reference's calls in the reference's order (seed-for-seed identical output: the default, because it is the
+    reference's result sample for sample); ``"device"`` uses the library's Philox generator on the GPU -- same
+    statistics, the whole detector stays on the device: 1.7 ms instead of 22 ms for ``PD('all')`` at 2^20 x 2
+    (15x; measured, profiles/r04_final_cfg_times.txt).  Use it wherever the realisation need not be the reference's.
     """
     from numbers import Real
     from scipy.constants import e, k as kB
@@ -930,7 +932,12 @@ def EDFA(input: optical_signal, G: float, NF: float, BW: float = None, *, device
     """Erbium-doped fibre amplifier, simplest model (reference ``devices.py:829-942``): field gain
     ``sqrt(G)``, ASE of power ``NF h f0 (G - 1) fs`` split over two polarisations x two quadratures
     added to ``.noise``, then an optical ``BPF`` of bandwidth ``BW`` if given.  Output is always
-    dual-polarisation (a single-polarisation input gets an empty y signal, but ASE in both)."""
+    dual-polarisation (a single-polarisation input gets an empty y signal, but ASE in both).
+
+    ``rng`` as in :func:`PD`: ``"numpy"`` (default) draws the ASE field from NumPy's global generator exactly as the
+    reference does (seed-for-seed identical), ``"device"`` from the library's Philox generator on the GPU: 1.5 ms
+    instead of 54 ms at 2^20 x 2 (35x; profiles/r04_final_cfg_times.txt) -- the four 2^20-sample host draws are
+    all of the cost."""
     from scipy.constants import h
     t0 = time.time()
     input, grid, back = _adopt(input, "optical_signal")
