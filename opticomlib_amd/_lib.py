@@ -672,6 +672,8 @@ class Plan:
         steps = _I64(0)
         if hs is not None:
             hs = np.ascontiguousarray(hs, dtype=np.float64)
+            if hs.size == 0:                       # (length 0: the reference's loop does not run, devices.py:1172)
+                return 0, None
             _check(load().ssfm_chirp_propagate(self._h, self.n, self.batch, _VP(A.ptr), _VP(P.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma),
                                                hs.ctypes.data_as(C.POINTER(_D)), hs.size, 0.0, 0.0, 1 if f32 else 0, 1, None, C.byref(steps)), "ssfm_chirp_propagate")
             return int(steps.value), None

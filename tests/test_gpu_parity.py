@@ -232,6 +232,17 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
     assert relmax(oa.FIBER(x1, **kw).signal, ref) < 1e-8
 
 
+def test_any_length_with_nothing_to_propagate_is_the_identity():
+    """length = 0 (the reference's loop does not run, devices.py:1172): the chirp-z path hands the input back -- fixed step (an empty schedule),
+    the single full-length step of a dispersion-free fibre ([L] = [0]: round 3 returned SSFM_ERR_INVALID from the one-launch kernel) and adaptive."""
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(1 << 10, seed=3, power_w=2e-3)[:, :777]
+    x = optical_signal(a)
+    for kw in (dict(length=0.0, h=0.5, **workloads.SMF), dict(length=0.0, gamma=1.3), dict(length=0.0, phi_max=0.01, **workloads.SMF)):
+        y = oa.FIBER(x, **kw).signal
+        np.testing.assert_array_equal(y, a.astype(np.complex64))
+
+
 def test_lengths_beyond_the_range_are_rejected():
     gv(sps=16, R=10e9)
     with pytest.raises(ValueError, match="samples per polarisation"):
@@ -1936,7 +1947,8 @@ def test_c_abi_from_plain_c(tmp_path):
     libdir = os.path.join(root, "opticomlib_amd")
     subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"), "-o", exe,
                     "-L" + libdir, "-l:_ssfm_amd.so", "-lm", "-Wl,-rpath," + libdir], check=True)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SSFM_")}          # (the knob suite's settings are not the demo's business)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ABI version 2" in r.stdout and "back-propagated" in r.stdout
     assert "last run: engine 4, fell back 0" in r.stdout or "last run: engine 5, fell back 0" in r.stdout        # (budgeted adaptive calls: a launch-per-pass engine)
