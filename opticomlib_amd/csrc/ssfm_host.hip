@@ -61,7 +61,7 @@ hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
                          + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_time<T, N1, C, E, MODE, U16>), grid, dim3(N1 * C / E), lds, s, a);
+    hipLaunchKernelGGL((k_time<T, N1, C, E, MODE, U16>), grid, dim3(N1 * C / E), lds, s, SSFM_TIME_KERNEL_ARGS(a));
     return hipGetLastError();
     }
 }
@@ -91,7 +91,7 @@ hipError_t launch_freq_u(int nrows, hipStream_t s, const FreqArgs<T>& a) {
                          + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_freq<T, N2, ROWS, E, MODE, U16>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, a);
+    hipLaunchKernelGGL((k_freq<T, N2, ROWS, E, MODE, U16>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, SSFM_FREQ_KERNEL_ARGS(a));
     return hipGetLastError();
 }
 template <typename T, int MODE, int N2, int E>

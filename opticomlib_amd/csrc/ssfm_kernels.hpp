@@ -52,7 +52,7 @@
 #define SSFM_EARLY_PHASE 1
 #endif
 #ifndef SSFM_KERNARG_UPFRONT
-#define SSFM_KERNARG_UPFRONT 1
+#define SSFM_KERNARG_UPFRONT 0          // (superseded by the kernel-argument preload of k_time / k_freq: the leading scalars are in SGPRs when the wave starts)
 #endif
 
 #ifndef SSFM_LATE_P_C128
@@ -1228,10 +1228,47 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     SSFM_TRACE_END(a);
 }
 
+// Kernel arguments.  A struct passed by value lives in the kernarg segment and is fetched by scalar loads at the head of the kernel: a miss of
+// its own (the segment was written by the host for this very launch) in front of everything else.  gfx950 can PRELOAD the first 16 dwords of
+// the segment into SGPRs while the wave is launched (-mllvm -amdgpu-kernarg-preload-count=16; .amdhsa_user_sgpr_kernarg_preload_length) -- for
+// scalar and pointer arguments, not for aggregates, 14 dwords at most (16 user SGPRs less the segment pointer).  So the two kernels of a step take
+// what their heads need as leading scalars and the rest -- the fields of the other modes -- as a trailing struct that is fetched where it is used.  (k_medium and the
+// single-launch engines call time_body / freq_body themselves and keep their structs.)
+template <typename T> struct TimeArgsCold {
+    cx<T>* F;
+    const cx<T>* twN;
+    AdaptState<T>* st;
+    T* zlog;
+    int step, derive;
+    const StepState<T>* s_in;
+    StepState<T>* s_out;
+    const cx<T>* mul;
+    T* pkeep;
+    ChirpIO<T> cz;
+    SSFM_TRACE_ARGS
+};
+template <typename T> __host__ __device__ inline TimeArgsCold<T> time_args_cold(const TimeArgs<T>& a) {
+    TimeArgsCold<T> c;
+    c.F = a.F; c.twN = a.twN; c.st = a.st; c.zlog = a.zlog; c.step = a.step; c.derive = a.derive; c.s_in = a.s_in; c.s_out = a.s_out; c.mul = a.mul; c.pkeep = a.pkeep; c.cz = a.cz;
+#if SSFM_TRACE
+    c.trace = a.trace; c.trace_slot = a.trace_slot;
+#endif
+    return c;
+}
 template <typename T, int N1, int C, int E, int MODE, bool U16 = false>
-__global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(const TimeArgs<T> a) {
+__global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(cx<T>* Y, T* P, const cx<T>* twA, const cx<T>* twB, const cx<T>* tw1, int N2, int rows, int Qf,
+                                                                     T gamma, T hh_prev, T hh_next, const TimeArgsCold<T> c) {
+    // (14 dwords are preloaded: the five pointers, N2, rows, Qf and gamma -- what stands in front of the first load; the two half steps follow by scalar load)
+    TimeArgs<T> a;
+    a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.gamma = gamma; a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = rows; a.Qf = Qf;
+    a.F = c.F; a.twN = c.twN; a.st = c.st; a.zlog = c.zlog; a.step = c.step; a.derive = c.derive; a.s_in = c.s_in; a.s_out = c.s_out; a.mul = c.mul; a.pkeep = c.pkeep; a.cz = c.cz;
+#if SSFM_TRACE
+    a.trace = c.trace; a.trace_slot = c.trace_slot;
+#endif
     time_body<T, N1, C, E, MODE, U16, false>(a, blockIdx.x, gridDim.x);
 }
+// host side: the launch of k_time from a TimeArgs
+#define SSFM_TIME_KERNEL_ARGS(a) (a).Y, (a).P, (a).twA, (a).twB, (a).tw1, (a).N2, (a).rows, (a).Qf, (a).gamma, (a).hh_prev, (a).hh_next, ssfm::time_args_cold(a)
 
 // ------------------------------------------------------------------------------ k_freq
 // FM_PHASE: the operator table of a FIBRE (|exp(D~ h)| is the same number at every frequency: Re D~ = -alpha/2,
@@ -1479,9 +1516,24 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
 }
 
 template <typename T, int N2, int ROWS, int E, int MODE, bool U16 = false>
-__global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(const FreqArgs<T> a) {
+__global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(cx<T>* F, const cx<T>* tab, const cx<T>* tw2, const AdaptState<T>* st, T h, T amp, T inv_n, int step, int N1,
+                                                                     int rows, int u16
+#if SSFM_TRACE
+                                                                     , unsigned long long* trace, int trace_slot
+#endif
+                                                                     ) {
+    FreqArgs<T> a;           // (see k_time: every argument of this kernel is a leading scalar, 14 dwords in complex64)
+    a.F = F; a.tab = tab; a.tw2 = tw2; a.st = st; a.h = h; a.amp = amp; a.inv_n = inv_n; a.step = step; a.N1 = N1; a.rows = rows; a.u16 = u16;
+#if SSFM_TRACE
+    a.trace = trace; a.trace_slot = trace_slot;
+#endif
     freq_body<T, N2, ROWS, E, MODE, U16, false>(a, blockIdx.x);
 }
+#if SSFM_TRACE
+#define SSFM_FREQ_KERNEL_ARGS(a) (a).F, (a).tab, (a).tw2, (a).st, (a).h, (a).amp, (a).inv_n, (a).step, (a).N1, (a).rows, (a).u16, (a).trace, (a).trace_slot
+#else
+#define SSFM_FREQ_KERNEL_ARGS(a) (a).F, (a).tab, (a).tw2, (a).st, (a).h, (a).amp, (a).inv_n, (a).step, (a).N1, (a).rows, (a).u16
+#endif
 
 constexpr int kSmallTabs = 4;          // operator tables per schedule of the single-launch engines (k_medium, k_small)
 // ------------------------------------------------------------------------------ k_medium

@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &st, sizeof(st));
     FreqArgs<float> a; a.F = F; a.tab = tab; a.tw2 = tw2; a.st = nullptr; a.h = 0.1f; a.inv_n = 1.f / N; a.N1 = N1; a.rows = rows;
     const size_t lds = ((size_t)row_lds_elems(N2, 16) + fft_tw_lds_entries(N2, 16)) * sizeof(cf32);
-    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((k_freq<float, 4096, 1, 16, FM_TABLE>), dim3(256 * rows), dim3(256), lds, 0, a);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((k_freq<float, 4096, 1, 16, FM_TABLE>), dim3(256 * rows), dim3(256), lds, 0, SSFM_FREQ_KERNEL_ARGS(a));
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(16 * 256 * rows);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);

@@ -17,7 +17,7 @@ if [ "$mode" = build ]; then
   n=0
   for v in "$@"; do
     name=${v%%:*}; flags=$(echo ${v#*:} | tr '@' ' ')
-    ( cd $ROOT/opticomlib_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include $flags -c -o $OUT/obj_$name.o $VSRC 2>$OUT/$name.log \
+    ( cd $ROOT/opticomlib_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -mllvm -amdgpu-kernarg-preload-count=${PRELOAD:-16} $flags -c -o $OUT/obj_$name.o $VSRC 2>$OUT/$name.log \
       && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/_ssfm_$name.so $OUT/obj_$name.o $OTHERS 2>>$OUT/$name.log && rm -f $OUT/obj_$name.o && echo built $name || { echo FAILED $name; tail -5 $OUT/$name.log; } ) &
     n=$((n+1)); if [ $((n % 6)) = 0 ]; then wait; fi
   done; wait
