@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 T=gpurun_out/$TAG
 V=build/var
-PROBE="python tools/adaptive_prof.py" bash tools/ab.sh ${TAG} 3 "product:" "p_store_after_the_meeting:SSFM_LIB=$V/_ssfm_nopearly.so" "three_launches:SSFM_ADAPT_FUSED=0"
+PROBE="python tools/adaptive_prof.py" bash tools/ab.sh ${TAG} 3 "product:" "three_launches:SSFM_ADAPT_FUSED=0"
 rm -rf ${T}_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_prof -- python3 tools/adaptive_prof.py > ${T}_run.txt 2> ${T}_prof.err
 find ${T}_prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} ${T}_kernel_stats.csv; head -6 ${T}_kernel_stats.csv | cut -c1-220

@@ -1,4 +1,4 @@
-// Diagnostic: per-phase cycle stamps of k_freq<float,4096,1,16,TABLE> (one row per launch, like a lane).
+// Diagnostic: per-phase cycle stamps of the product's row kernel k_freq<float,4096,1,16,FM_PHASE,U16> (one row per launch, like a lane; zero tables).
 #define SSFM_STAMPS 1
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -16,9 +16,9 @@ int main(int argc, char** argv) {
     hipMalloc(&st, 8 * 16 * 256 * rows);
     hipMemset(F, 0, sizeof(cf32) * N * rows); hipMemset(tab, 0, sizeof(cf32) * N); hipMemset(tw2, 0, sizeof(cf32) * 65536);
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &st, sizeof(st));
-    FreqArgs<float> a; a.F = F; a.tab = tab; a.tw2 = tw2; a.st = nullptr; a.h = 0.1f; a.inv_n = 1.f / N; a.N1 = N1; a.rows = rows;
+    FreqArgs<float> a; a.F = F; a.tab = tab; a.tw2 = tw2; a.st = nullptr; a.h = 0.1f; a.amp = 1.f / N; a.step = 0; a.inv_n = 1.f / N; a.N1 = N1; a.rows = rows; a.u16 = 1;
     const size_t lds = ((size_t)row_lds_elems(N2, 16) + fft_tw_lds_entries(N2, 16)) * sizeof(cf32);
-    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((k_freq<float, 4096, 1, 16, FM_TABLE>), dim3(256 * rows), dim3(256), lds, 0, SSFM_FREQ_KERNEL_ARGS(a));
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((k_freq<float, 4096, 1, 16, FM_PHASE, true>), dim3(256 * rows), dim3(256), lds, 0, SSFM_FREQ_KERNEL_ARGS(a));
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(16 * 256 * rows);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
