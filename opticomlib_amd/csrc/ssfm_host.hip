@@ -100,7 +100,7 @@ hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
     // forward-only transform writes the plain transposed spectrum for its consumers
     if constexpr (sizeof(T) == 4)
         if (a.u16) return launch_freq_u<T, MODE, N2, E, true>(nrows, s, a);
-    if constexpr (MODE == FM_PHASE) return hipErrorInvalidValue;      // (phase tables: complex64 plans in the unit layout only)
+    if constexpr (MODE == FM_PHASE && sizeof(T) == 4) return hipErrorInvalidValue;      // (complex64 phase tables: plans in the unit layout only)
     else return launch_freq_u<T, MODE, N2, E, false>(nrows, s, a);
 }
 template <typename T, int MODE, int E>
@@ -1020,7 +1020,9 @@ template <typename T> struct PlanT : PlanBase {
         std::vector<const cx<T>*> tabptr(distinct.size(), nullptr);
         const bool small_sched = small && use_tables && !profiling && nsteps <= 0x7fffffff;
         // a fibre's operator has one modulus for all frequencies: 4-byte phase tables (ssfm_kernels.hpp FM_PHASE)
-        const bool use_phase = use_tables && phase_tables && sizeof(T) == 4 && u16 && op_flat_re;
+        // (complex128: float64 turn fractions, 8 instead of 16 bytes per frequency -- measured -2.5 % at 2^20 x 2 (39.5 against 40.5 us per step) and
+        // +5 % at 2^16 x 2, where nothing hides the float64 sincos: from 2^20 samples in all)
+        const bool use_phase = use_tables && phase_tables && op_flat_re && (sizeof(T) == 8 ? n * batch >= (1ll << 20) : u16);
         // plans of 2^12 ... 2^17 samples in the unit layout: the whole schedule in one launch on one XCD (ssfm_kernels.hpp k_medium).  Measured against the
         // one-workgroup-per-row kernel of the small plans (k_small): 5.4 against 6.4 us per step at 8192 samples, 5.6 against 3.5 at 4096 -- so from 8192 on
         const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * (medium_rows_split() ? 1 : batch);

@@ -1313,6 +1313,21 @@ __device__ __forceinline__ cf32 phase32_factor(unsigned u, float amp) {
     return expi_half_turn(x, __uint_as_float(__float_as_uint(amp) ^ flip));
 }
 __device__ __forceinline__ cf64 phase32_factor(unsigned, double) { return mk<double>(0.0, 0.0); }      // (complex64 plans only)
+// complex128 plans (round 4): the phase as a float64 fraction of a turn in [-0.5, 0.5] -- 8 bytes per frequency instead of the 16 of the complex
+// table, which is a third of what k_freq<double> moves (51 MB per launch, DESIGN.md section 5: C1 is bound by traffic).  amp * exp(2 pi i x):
+// k = rint(4 x) quarter turns come off exactly (x - k / 4 has no rounding), the rest |theta| <= pi / 4 goes through the fdlibm kernels (< 1 ulp),
+// the quarter turns are a swap / sign of the two components.  About 30 float64 instructions per frequency, formed under the field loads.
+__device__ __forceinline__ cf64 phase64_factor(double x, double amp) {
+    const double k = rint(4.0 * x);
+    const double theta = fma(k, -0.25, x) * 6.283185307179586476925;
+    double s, c;
+    sincos_tiny(theta, s, c);
+    const int q = (int)k & 3;
+    const double cr = (q & 1) ? -s : c, sr = (q & 1) ? c : s;          // one quarter turn: (c, s) -> (-s, c)
+    const double sg = (q & 2) ? -amp : amp;                            // two: both signs
+    return mk<double>(sg * cr, sg * sr);
+}
+__device__ __forceinline__ cf32 phase64_factor(double, float) { return mk<float>(0.0f, 0.0f); }        // (complex128 plans only)
 
 // m[t] <- exp(D~_t h) / N with D~_t = m[t] on entry and ph[t] = Im(D~_t) h; `flat`: Re D~ is the same at every t and
 // e0 = exp(Re D~ h).  (e * c) * inv_n == (e * inv_n) * c exactly: N is a power of two.
@@ -1382,7 +1397,17 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     unsigned pu[E];
     // SSFM_LATE_TAB (experiment): the phase loads are issued after the first stage of the forward transform instead of with the
     // field loads -- a smaller burst at the head of the kernel, which the tail of the other lane's kernel queues behind
+    double pt[sizeof(T) == 8 ? E : 1];          // complex128: the phases as float64 turn fractions, slots 2g and 2g+1 side by side (freq_tab_pos)
     auto load_phases = [&]() {
+        if constexpr (sizeof(T) == 8) {
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            const d2_t* __restrict__ P2 = reinterpret_cast<const d2_t*>(reinterpret_cast<const double*>(a.tab) + (long long)k1 * N2) + j;
+#pragma unroll
+            for (int g = 0; g < E / 2; ++g) {
+                const d2_t q = P2[g * Q];
+                pt[2 * g] = q.x; pt[2 * g + 1] = q.y;
+            }
+        } else {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4* __restrict__ P4 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned*>(a.tab) + (long long)k1 * N2) + j;
 #pragma unroll
@@ -1390,6 +1415,14 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
             u32x4 q;
             if (SSFM_ABL_NO_TAB) q = 0x12345678u; else q = P4[g * Q];
             pu[4 * g] = q.x; pu[4 * g + 1] = q.y; pu[4 * g + 2] = q.z; pu[4 * g + 3] = q.w;
+        }
+        }
+    };
+    auto phase_factors = [&]() {
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            if constexpr (sizeof(T) == 8) m[t] = phase64_factor(pt[t], a.amp);
+            else m[t] = phase32_factor(pu[t], a.amp);
         }
     };
     // (the same for the operator itself where the kernel forms exp(D~ h): adaptive runs.  Only with 16-byte elements... of either precision)
@@ -1464,8 +1497,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         fly_factors<E>(m, ph, flat, e0, h, a.inv_n);
     };
     if constexpr (EARLY_PHASE) {
-#pragma unroll
-        for (int t = 0; t < E; ++t) m[t] = phase32_factor(pu[t], a.amp);
+        phase_factors();
         __builtin_amdgcn_sched_barrier(0);          // (keeps the factors ahead of the wait for the field)
     }
     if constexpr (EARLY_FLY) {
@@ -1485,10 +1517,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     }
     SSFM_STAMP(3);
     if (MODE == FM_FLY && !EARLY_FLY) fly();
-    if (MODE == FM_PHASE && !EARLY_PHASE) {
-#pragma unroll
-        for (int t = 0; t < E; ++t) m[t] = phase32_factor(pu[t], a.amp);
-    }
+    if (MODE == FM_PHASE && !EARLY_PHASE) phase_factors();
 #pragma unroll
     for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
     SSFM_STAMP(4);
@@ -2359,6 +2388,16 @@ __global__ void k_make_phase_table(const cx<T>* __restrict__ src, unsigned* __re
     if (o >= N) return;
     const long long k1 = o / N2, k2 = o % N2;
     const T xi = src[k1 + (long long)N1 * k2].y * h;
+    if constexpr (sizeof(T) == 8) {
+        // complex128 plans: the float64 fraction of a turn in [-0.5, 0.5], slots 2g / 2g+1 of a thread side by side (freq_tab_pos).  1 / (2 pi) as
+        // a double-double, so that the fraction carries no more than its own final rounding
+        const double c1 = 0.15915494309189535, c2 = -9.839338337591243e-18;
+        const double hi = xi * c1;
+        const double lo = fma(xi, c1, -hi) + xi * c2;
+        const double f = hi - rint(hi);
+        reinterpret_cast<double*>(out)[k1 * N2 + freq_tab_pos(k2, Q)] = f + lo;
+        return;
+    }
     double turns = (double)xi * 0.15915494309189533577;          // 1 / (2 pi)
     turns -= floor(turns);
     out[k1 * N2 + freq_phase_pos(k2, Q)] = (unsigned)(unsigned long long)llrint(turns * 4294967296.0);      // (2^32 wraps to 0)

@@ -14,3 +14,6 @@ template __global__ void ssfm::k_freq<float, 4096, 1, 16, FM_FLY, true>(FARGS(fl
 template __global__ void ssfm::k_time<double, 256, 8, 8, TM_MID, false>(TARGS(double));
 template __global__ void ssfm::k_freq<double, 4096, 1, 16, FM_TABLE, false>(FARGS(double));
 #endif
+#ifdef HOT_C128
+template __global__ void ssfm::k_freq<double, 4096, 1, 16, FM_PHASE, false>(FARGS(double));
+#endif
