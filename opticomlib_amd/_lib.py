@@ -683,6 +683,31 @@ class Plan:
                "ssfm_chirp_propagate")
         return int(steps.value), z[: int(steps.value) + 1]
 
+    def chirp_small(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, hs) -> bool:
+        """A fixed-step chirp-z run of ``A`` (batch, n <= plan length / 2; the PLAN's precision) in one launch (ssfm_chirp_small).  False: this plan has no
+        such engine (nothing was launched)."""
+        hs = np.ascontiguousarray(hs, dtype=np.float64)
+        hs = hs[hs != 0.0]                      # (a step of length zero is the identity)
+        if hs.size == 0:
+            return True
+        rc = load().ssfm_chirp_small(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), hs.ctypes.data_as(C.POINTER(_D)), hs.size)
+        if rc == 2:
+            return False
+        _check(rc, "ssfm_chirp_small")
+        return True
+
+    def chirp_small_adapt(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, length: float, phi_max: float, f32: bool, max_steps: int):
+        """The adaptive run in one launch (ssfm_chirp_small_adapt).  Returns (steps, z) or None when the plan has no such engine or its rows' workgroups did not
+        meet (the field is then as it came)."""
+        z = np.zeros(int(max_steps) + 1, dtype=np.float64)
+        steps = _I64(0)
+        rc = load().ssfm_chirp_small_adapt(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), float(length), float(phi_max), 1 if f32 else 0,
+                                           int(max_steps), z.ctypes.data_as(C.POINTER(_D)), C.byref(steps))
+        if rc == 2:
+            return None
+        _check(rc, "ssfm_chirp_small_adapt")
+        return int(steps.value), z[: int(steps.value) + 1]
+
     def debug_fft(self) -> np.ndarray:
         out = host_empty((self.batch, self.n), self.cdtype)
         _check(load().ssfm_debug_fft(self._h, _ptr(out)), "ssfm_debug_fft")

@@ -178,14 +178,12 @@ hipError_t launch_small_chirp_n(int rows, hipStream_t s, const SmallChirpArgs<T>
 }
 template <typename T>
 hipError_t launch_small_chirp(int n, int rows, hipStream_t s, const SmallChirpArgs<T>& a) {
-    if constexpr (sizeof(T) == 8) {
-        switch (n) {
-            case 256:  return launch_small_chirp_n<T, 256>(rows, s, a);
-            case 512:  return launch_small_chirp_n<T, 512>(rows, s, a);
-            case 1024: return launch_small_chirp_n<T, 1024>(rows, s, a);
-            case 2048: return launch_small_chirp_n<T, 2048>(rows, s, a);
-            case 4096: return launch_small_chirp_n<T, 4096>(rows, s, a);
-        }
+    switch (n) {
+        case 256:  return launch_small_chirp_n<T, 256>(rows, s, a);
+        case 512:  return launch_small_chirp_n<T, 512>(rows, s, a);
+        case 1024: return launch_small_chirp_n<T, 1024>(rows, s, a);
+        case 2048: return launch_small_chirp_n<T, 2048>(rows, s, a);
+        case 4096: return launch_small_chirp_n<T, 4096>(rows, s, a);
     }
     return hipErrorInvalidValue;
 }
@@ -202,14 +200,12 @@ hipError_t launch_small_chirp_adapt_n(int rows, hipStream_t s, const SmallChirpA
 }
 template <typename T>
 hipError_t launch_small_chirp_adapt(int n, int rows, hipStream_t s, const SmallChirpAdaptArgs<T>& a) {
-    if constexpr (sizeof(T) == 8) {
-        switch (n) {
-            case 256:  return launch_small_chirp_adapt_n<T, 256>(rows, s, a);
-            case 512:  return launch_small_chirp_adapt_n<T, 512>(rows, s, a);
-            case 1024: return launch_small_chirp_adapt_n<T, 1024>(rows, s, a);
-            case 2048: return launch_small_chirp_adapt_n<T, 2048>(rows, s, a);
-            case 4096: return launch_small_chirp_adapt_n<T, 4096>(rows, s, a);
-        }
+    switch (n) {
+        case 256:  return launch_small_chirp_adapt_n<T, 256>(rows, s, a);
+        case 512:  return launch_small_chirp_adapt_n<T, 512>(rows, s, a);
+        case 1024: return launch_small_chirp_adapt_n<T, 1024>(rows, s, a);
+        case 2048: return launch_small_chirp_adapt_n<T, 2048>(rows, s, a);
+        case 4096: return launch_small_chirp_adapt_n<T, 4096>(rows, s, a);
     }
     return hipErrorInvalidValue;
 }
@@ -1600,7 +1596,7 @@ template <typename T> struct PlanT : PlanBase {
     // A fixed-step chirp-z run of a field of nn <= n / 2 samples per row in ONE launch (k_small_chirp); SSFM_ERR_UNSUPPORTED (nothing launched) when the
     // plan is not a complex128 plan of the one-workgroup-per-row engine.
     int chirp_small(void* A, const void* chirp, const void* Dt, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
-        if (sizeof(T) != 8 || !small || !tw_small) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small: a complex128 plan of 256 ... 4096 samples is needed");
+        if (!small || !tw_small || n > 4096) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small: a plan of 256 ... 4096 samples is needed");
         if (!A || !chirp || !Dt || !hs || nn < 2 || 2 * nn - 1 > n || nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_chirp_small: bad arguments");
         for (int64_t s = 0; s < nsteps; ++s)
             if (!(hs[s] > 0) || !std::isfinite(hs[s])) return fail(SSFM_ERR_INVALID, "ssfm_chirp_small: step %lld is %g km (must be finite and > 0)", (long long)s, hs[s]);
@@ -1636,8 +1632,8 @@ template <typename T> struct PlanT : PlanBase {
     static constexpr int kChirpAdaptRows = 16;
     int chirp_small_adapt(void* A, const void* chirp, const void* Dt, int64_t nn, double gamma, double length, double phi_max, int f32, int64_t max_steps,
                           double* z_out, int64_t* steps_out) {
-        if (sizeof(T) != 8 || !small || !tw_small || batch > kChirpAdaptRows)
-            return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small_adapt: a complex128 plan of 256 ... 4096 samples and at most %d rows is needed", kChirpAdaptRows);
+        if (!small || !tw_small || n > 4096 || batch > kChirpAdaptRows)
+            return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small_adapt: a plan of 256 ... 4096 samples and at most %d rows is needed", kChirpAdaptRows);
         if (!A || !chirp || !Dt || nn < 2 || 2 * nn - 1 > n || max_steps < 1 || max_steps > 0x7ffffff0 || !(length > 0) || !(phi_max > 0) || gamma == 0.0)
             return fail(SSFM_ERR_INVALID, "ssfm_chirp_small_adapt: bad arguments");
         if (int rc = use_device()) return rc;

@@ -1952,8 +1952,8 @@ __global__ __launch_bounds__(N / E) void k_small_chirp(const SmallChirpArgs<T> a
                 if (m < n) {
                     const cx<T> d = a.Dt[m];
                     T sn, cs;
-                    sincos(d.y * (T)hd, &sn, &cs);
-                    const T g = exp(d.x * (T)hd);
+                    sincos_acc<T>(d.y * (T)hd, sn, cs);
+                    const T g = exp_acc<T>(d.x * (T)hd);
                     ex[t] = mk<T>(g * cs, g * sn);
                 }
             }
@@ -2140,8 +2140,8 @@ __global__ __launch_bounds__(N / E) void k_small_chirp_adapt(const SmallChirpAda
             if (m < n) {
                 const cx<T> d = a.Dt[m];
                 T sn, cs;
-                sincos(d.y * (T)h, &sn, &cs);
-                const T g = exp(d.x * (T)h);
+                sincos_acc<T>(d.y * (T)h, sn, cs);
+                const T g = exp_acc<T>(d.x * (T)h);
                 ex[t] = mk<T>(g * cs, g * sn);
             }
         }

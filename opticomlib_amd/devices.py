@@ -395,8 +395,72 @@ def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_ma
     n = shape[-1]
     batch = 1 if len(shape) == 1 else shape[0]
     rt = _F32 if prec == _lib.C64 else np.float64
+    if prec == _lib.C64 and n <= 2048 and not return_steps and bar is None and os.environ.get("SSFM_CHIRP_LOOP", "c") != "python" \
+            and os.environ.get("SSFM_CHIRP_SMALL", "1") != "0" and batch <= 16:
+        got = _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev)
+        if got is not None:
+            return got
     with _ChirpZ(n, batch, dev) as eng:
         return _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar)
+
+
+_CHIRPS32: "OrderedDict[tuple, object]" = OrderedDict()
+
+
+def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev):
+    """``precision="complex64"`` at up to 2048 samples that are not a power of two: the whole run in ONE launch on a complex64 line of M >= 2n - 1 <= 4096 points
+    (k_small_chirp / k_small_chirp_adapt instantiated for float; round 4).  The reference itself transforms such a length in single precision (pocketfft's Bluestein,
+    devices.py:1178-1180), so this is its arithmetic class: 2e-6 ... 7e-6 from the float64 solution after 100 steps (profiles/r04_chirpz_c64_error.txt) where the
+    complex128 line of the general path sits at 1e-13 -- and a step takes half the time (one CU does the four line transforms of a step; float64 was its bound).
+    ``precision="complex128"`` keeps the complex128 line.  None: the plan has no such engine, or its rows' workgroups did not meet: the general path runs."""
+    n = shape[-1]
+    batch = 1 if len(shape) == 1 else shape[0]
+    M = 1 << max(8, (2 * n - 2).bit_length())
+    plan = get_plan(M, batch, _lib.C64, dev)
+    L = _F32(length)
+    if not float(L) > 0:
+        A = A_dev if A_dev.dtype == np.complex64 else A_dev.astype(np.complex64)
+        return (A.copy() if A is A_dev else A), [_F32(0)], None
+    with plan.lock:
+        key = (dev, n)
+        with _CACHE_LOCK:
+            if key not in _CHIRPS32:
+                _CHIRPS32[key] = _lib.chirp_device(n, False, dev).astype(np.complex64)
+                while len(_CHIRPS32) > 4:
+                    _CHIRPS32.pop(next(iter(_CHIRPS32)))
+            chirp = _CHIRPS32[key]
+        A = A_dev.astype(np.complex64) if A_dev.dtype != np.complex64 else A_dev.copy()          # the caller's array is never modified
+        A.shape = (batch, n)
+        Dt = _lib.DeviceArray.from_host(np.asarray(linear_operator(n, dt, alpha, beta_2, beta_3, _lib.C64), dtype=np.complex64), np.complex64, dev)
+        g = float(_F32(gamma))
+        if h is None:
+            b2, b3 = _F32(beta_2), _F32(beta_3)
+            if bool((b2 == 0 and b3 == 0) or _F32(gamma) == 0):                  # one step of the whole length (reference devices.py:1163-1170)
+                if not plan.chirp_small(A, chirp, Dt, g, np.array([float(L)])):
+                    return None
+                zs = [_F32(0), L]
+            else:
+                zs, z0, max_steps = [_F32(0)], _F32(0), 1 << 17
+                while True:
+                    got = plan.chirp_small_adapt(A, chirp, Dt, g, float(_F32(L - z0)), float(_F32(phi_max)), True, max_steps)
+                    if got is None:
+                        return None if z0 == 0 else _raise_chirp_midway()
+                    steps, z = got
+                    zs += [_F32(z0 + _F32(v)) for v in z[1:]]
+                    if steps < max_steps or not (zs[-1] < L):
+                        break
+                    z0 = zs[-1]
+        else:
+            hs, z_all = step_schedule(length, h, _lib.C64)
+            if not plan.chirp_small(A, chirp, Dt, g, np.asarray(hs, dtype=np.float64)):
+                return None
+            zs = list(z_all)
+        plan.synchronize()
+        return A, zs, None
+
+
+def _raise_chirp_midway():
+    raise _lib.SsfmError("the one-launch chirp-z engine lost its workgroups in the middle of a run of more than 131072 steps")
 
 
 def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar):

@@ -222,14 +222,27 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
             z, _ = oa.FIBER(x, return_steps=True, **kw) if name == "python" else (None, None)
             res[name] = (y, z)
         for name in ("c5", "c"):      # (c5: five launches per step; c: n <= 2048: the whole run in one launch)
-            assert relmax(res[name][0], res["python"][0]) < 1e-12 * (1 if "h" in kw else 1e4), name     # (adaptive: a last-bit difference in a maximum moves a step size)
+            tol = 1e-12 * (1 if "h" in kw else 1e4)                 # (adaptive: a last-bit difference in a maximum moves a step size)
+            if name == "c" and n <= 2048:
+                tol = TOL_100      # (round 4: a complex64 caller's run of up to 2048 samples is ONE launch on a complex64 line -- the reference's own arithmetic class)
+            assert relmax(res[name][0], res["python"][0]) < tol, name
         assert len(res["python"][1]) > 10
+        if n <= 2048:
+            # the complex128 line in one launch (precision="complex128") against the complex128 host loop: 1e-12 as before
+            monkeypatch.setenv("SSFM_CHIRP_LOOP", "python")
+            r128 = oa.FIBER(x, precision="complex128", **kw).signal
+            monkeypatch.setenv("SSFM_CHIRP_LOOP", "c"); monkeypatch.setenv("SSFM_CHIRP_SMALL", "1")
+            y128 = oa.FIBER(x, precision="complex128", **kw).signal
+            assert y128.dtype == np.complex128 and relmax(y128, r128) < 1e-12 * (1 if "h" in kw else 1e4)
+            # ... and the complex64 line against the oracle (the reference's complex64 run of the same field)
+            y64 = oa.FIBER(x, **kw).signal
+            assert y64.dtype == np.complex64 and relmax(y64, orc.fiber_c64(a, gv.dt, **kw)) < TOL_100
     # one polarisation (a single row: the one-launch adaptive engine has nobody to exchange maxima with)
     x1, kw = optical_signal(a[0]), dict(length=8.0, phi_max=0.004, **workloads.SMF)
     monkeypatch.setenv("SSFM_CHIRP_LOOP", "python")
     ref = oa.FIBER(x1, **kw).signal
     monkeypatch.setenv("SSFM_CHIRP_LOOP", "c")
-    assert relmax(oa.FIBER(x1, **kw).signal, ref) < 1e-8
+    assert relmax(oa.FIBER(x1, **kw).signal, ref) < (TOL_100 if n <= 2048 else 1e-8)          # (n <= 2048: the complex64 line, see above)
 
 
 def test_any_length_with_nothing_to_propagate_is_the_identity():
