@@ -271,7 +271,8 @@ _CHIRPS: "OrderedDict[tuple, tuple]" = OrderedDict()      # (device, n) -> (c, c
 class _ChirpZ:
     """Split-step / single-transfer engine for fields of ANY length n on a power-of-two complex128 plan of
     M >= 2n - 1 points (Bluestein; algebra in csrc/chirpz.hip).  The field lives in a device array in natural
-    order; all arithmetic is complex128 whatever the caller's precision."""
+    order; all arithmetic of THIS engine is complex128 whatever the caller's precision (complex64 callers of up to 2048 samples take
+    ``_fiber_chirpz_small_c64`` instead)."""
 
     def __init__(self, n: int, batch: int, dev: int):
         self.n, self.batch, self.dev = int(n), int(batch), int(dev)
@@ -603,7 +604,7 @@ def FIBER(input: optical_signal,
             A = np.ascontiguousarray(A, dtype=plan_dtype)
 
     if not _is_fast_size(n, prec):
-        # any other length: chirp-z path (complex128 arithmetic on a power-of-two plan of >= 2n - 1 points)
+        # any other length: chirp-z path on a power-of-two plan of >= 2n - 1 points (complex128 arithmetic; complex64 for complex64 callers of up to 2048 samples)
         bar = None
         if show_progress:
             try:
