@@ -288,6 +288,11 @@ int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* i
  * (HOST).  Complex128 plans of 256 ... 4096 samples (SSFM_ERR_UNSUPPORTED otherwise, nothing launched).  Asynchronous on the plan's stream after
  * the schedule has been copied. */
 int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
+/* The same on a complex64 plan of 2^13 ... 2^17 points whose rows fit the one-XCD engine (2^17 points in all rows, at most 64 workgroups): lengths
+ * 2048 < n <= plan length / 2 in ONE launch on one XCD -- four passes per step, the chirps of neighbouring steps cancel (k_medium_chirp) -- between two
+ * pointwise launches.  A, chirp, Dt: complex64, DEVICE.  At most four distinct step sizes.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: no such
+ * plan or schedule, or the launch's workgroups did not meet within the patience (the engine is then off for this plan). */
+int ssfm_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
 /* ... and the ADAPTIVE run (h = phi_max / (|gamma| max |A|^2) over all rows, clamped to what is left of `length`; the rule of ssfm_chirp_propagate, in
  * float32 arithmetic when f32 != 0) in one launch: the rows' workgroups exchange their maxima through memory every step (k_small_chirp_adapt).  At
  * most 16 rows.  z_out (HOST, nullable, max_steps + 1 entries) receives z after every step, *steps_out the steps taken.  Synchronous.
@@ -358,7 +363,8 @@ enum ssfm_engine {
     SSFM_ENGINE_MEDIUM_ADAPT = 7,      /* adaptive: one launch per run on one XCD */
     SSFM_ENGINE_CHIRP_SMALL = 8,       /* any length <= 2048: fixed step, one launch per run */
     SSFM_ENGINE_CHIRP_SMALL_ADAPT = 9, /* any length <= 2048: adaptive, one launch per run */
-    SSFM_ENGINE_CHIRP_STEPS = 10       /* any length: five launches per step (seven adaptive) */
+    SSFM_ENGINE_CHIRP_STEPS = 10,      /* any length: five launches per step (seven adaptive) */
+    SSFM_ENGINE_CHIRP_MEDIUM = 11      /* any length, 2048 < n <= 65536, complex64: fixed step, one launch per run on one XCD */
 };
 int ssfm_last_run_info(ssfm_plan* plan, int* engine, int* fell_back, int64_t* fallbacks_total, int* lanes_share_queue);
 

@@ -74,6 +74,7 @@ SYMBOLS = {
     "ssfm_chirp_post": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D, _VP]),
     "ssfm_chirp_step": (_I, [_VP, _VP, _VP]),                       # (plan, mul_dev, const ssfm_chirp_io*)
     "ssfm_chirp_small": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
+    "ssfm_chirp_medium": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
     "ssfm_chirp_small_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_chirp_propagate": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
@@ -101,7 +102,7 @@ SYMBOLS = {
 
 # enum ssfm_engine of include/ssfm_amd.h, by value
 ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adaptive_fused", "small_adaptive", "medium_adaptive",
-           "chirp_small", "chirp_small_adaptive", "chirp_steps")
+           "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium")
 
 
 class SsfmError(RuntimeError):
@@ -694,6 +695,20 @@ class Plan:
         if rc == 2:
             return False
         _check(rc, "ssfm_chirp_small")
+        return True
+
+    def chirp_medium(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, hs) -> bool:
+        """A fixed-step chirp-z run of ``A`` (batch, 2048 < n <= plan length / 2; complex64) in one launch on one XCD between two pointwise ones
+        (ssfm_chirp_medium; synchronous).  False: this plan has no such engine, the schedule has more than four step sizes, or the launch's workgroups did not
+        meet -- ``A`` is then as it was."""
+        hs = np.ascontiguousarray(hs, dtype=np.float64)
+        hs = hs[hs != 0.0]                      # (a step of length zero is the identity)
+        if hs.size == 0:
+            return True
+        rc = load().ssfm_chirp_medium(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), hs.ctypes.data_as(C.POINTER(_D)), hs.size)
+        if rc == 2:
+            return False
+        _check(rc, "ssfm_chirp_medium")
         return True
 
     def chirp_small_adapt(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, length: float, phi_max: float, f32: bool, max_steps: int):

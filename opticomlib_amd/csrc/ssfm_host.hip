@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -155,6 +156,58 @@ hipError_t launch_small(int n, int rows, hipStream_t s, const SmallArgs<T>& a) {
         case 8192: if constexpr (sizeof(T) == 4) return launch_small_n<T, 8192>(rows, s, a); else break;
     }
     return hipErrorInvalidValue;
+}
+
+// ---- kernels around k_medium_chirp (chirp_medium below): a complex64 line, the chirp's phase reduced exactly in integers as in chirpz.hip
+template <typename T> __device__ __forceinline__ cx<T> cm_chirp_value(long long m, long long n, int conj) {
+    const long long r = (m * m) % (2 * n);
+    double sn, cs;
+    sincospi(-(double)r / (double)n, &sn, &cs);
+    return mk<T>((T)cs, (T)(conj ? -sn : sn));
+}
+// row 0 of the field <- the convolution kernel of Bluestein's identity wrapped around the line: conj(c_m) (which = 0) or c_m (1) at m and M - m, m < n
+template <typename T> __global__ __launch_bounds__(256) void k_cm_kernel_line(cx<T>* __restrict__ F, long long n, long long M, int which) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i < n ? i : (M - i < n ? M - i : -1);
+        F[i] = m < 0 ? mk<T>((T)0, (T)0) : cm_chirp_value<T>(m, n, which == 0);
+    }
+}
+// out[m] = exp(D~_m h) / n below n, zero above: the products in T as the reference forms them (complex64 * float32, devices.py:1179), the
+// transcendental functions in double and rounded once (as k_make_freq_table)
+template <typename T> __global__ __launch_bounds__(256) void k_cm_mul_table(const cx<T>* __restrict__ Dt, cx<T>* __restrict__ out, long long n, long long M, T h, T inv) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+        cx<T> d = mk<T>((T)0, (T)0);
+        if (i < n) {
+            const cx<T> x = Dt[i];
+            const T xr = x.x * h, xi = x.y * h;
+            const T e = (T)exp((double)xr);
+            double sn, cs;
+            sincos((double)xi, &sn, &cs);
+            d = mk<T>((e * (T)cs) * inv, (e * (T)sn) * inv);
+        }
+        out[i] = d;
+    }
+}
+__global__ __launch_bounds__(256) void k_cm_narrow(const cx<double>* __restrict__ src, cx<float>* __restrict__ dst, long long M, int conj) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = mk<float>((float)src[i].x, (float)(conj ? -src[i].y : src[i].y));
+}
+template <typename T> __global__ __launch_bounds__(256) void k_cm_pre(const cx<T>* __restrict__ A, const cx<T>* __restrict__ chirp, cx<T>* __restrict__ F, long long n, long long M, int batch) {
+    const long long total = M * batch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / M, m = i - r * M;
+        F[i] = m < n ? cmul(A[r * n + m], chirp[m]) : mk<T>((T)0, (T)0);
+    }
+}
+// A <- line conj(c); nothing when the run's workgroups did not meet (*error != 0): the caller's field is then as it was
+template <typename T> __global__ __launch_bounds__(256) void k_cm_post(cx<T>* __restrict__ A, const cx<T>* __restrict__ chirp, const cx<T>* __restrict__ F, long long n, long long M, int batch,
+                                                                      const unsigned* __restrict__ error) {
+    if (*error != 0u) return;
+    const long long total = n * batch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / n, m = i - r * n;
+        A[i] = cmulc(F[r * M + m], chirp[m]);
+    }
 }
 
 // k_small_chirp: lengths that are not powers of two on one line of the plan's length (complex128), the whole schedule in one launch
@@ -1678,21 +1731,143 @@ template <typename T> struct PlanT : PlanBase {
         if (steps_out) *steps_out = out[0];
         return SSFM_OK;
     }
+    // A fixed-step chirp-z run of nn samples per row (2 nn - 1 <= n) on the line of a MEDIUM complex64 plan (2^13 ... 2^17 points) in one launch on one XCD
+    // (k_medium_chirp) between two pointwise launches.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: not such a plan, more than kMaxTables step
+    // sizes, or the launch's workgroups did not meet within the patience (the engine is then off for this plan).
+    int chirp_medium(void* A_, const void* chirp_, const void* Dt_, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
+        if constexpr (sizeof(T) != 4) { (void)A_; (void)chirp_; (void)Dt_; (void)nn; (void)gamma; (void)hs; (void)nsteps; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
+        else {
+        const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+        if (!SSFM_MEDIUM_LOCAL || !medium_ok || !u16 || E != 8 || Ef != 8 || !medium_shape(N1, N2) || n < 8192 || blocks % kBarShards != 0 || blocks > 64
+            || n * batch > medium_max_samples || medium_xcc < 0)
+            return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: a complex64 plan of 2^13 ... 2^17 points (2^17 in all rows) with the one-XCD engine is needed");
+        if (!A_ || !chirp_ || !Dt_ || !hs || nn < 2 || 2 * nn - 1 > n || nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: bad arguments");
+        std::vector<T> hf((size_t)nsteps), distinct;
+        for (int64_t s = 0; s < nsteps; ++s) {
+            if (!(hs[s] > 0) || !std::isfinite(hs[s])) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: step %lld is %g km (must be finite and > 0)", (long long)s, hs[s]);
+            hf[(size_t)s] = (T)hs[s];
+            bool seen = false;
+            for (const T d : distinct) seen = seen || std::memcmp(&d, &hf[(size_t)s], sizeof(T)) == 0;
+            if (!seen) distinct.push_back(hf[(size_t)s]);
+            if (distinct.size() > (size_t)kMaxTables) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: more than %d distinct step sizes", kMaxTables);
+        }
+        if (int rc = use_device()) return rc;
+        cx<T>* A = static_cast<cx<T>*>(A_);
+        const cx<T>* chirp = static_cast<const cx<T>*>(chirp_);
+        const cx<T>* Dt = static_cast<const cx<T>*>(Dt_);
+        const unsigned gM = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+        last_launches = 0;
+        // the two convolutions' transfer functions, generated and transformed on the device once per length (the slots' tags say what they hold)
+        const uint64_t want = 0xC412000000000000ull ^ (uint64_t)nn;
+        if (!xfer_tab[0] || !xfer_tab[1] || tags[1] != want || tags[2] != want) {
+            // ... in DOUBLE on a complex128 plan of the line's length that lives for this block, rounded once: an error of the tables is the same at every
+            // step and adds up over a run (tables from the complex64 transform itself: 1.6e-5 ... 2.6e-5 from the reference result after 100 steps, the
+            // tolerance is 2e-5; rounded from double: what the data's own rounding leaves).  The kernel of the inverse transform is the conjugate of
+            // the forward one's, and both are symmetric on the line: H1 = conj(H0).
+            tags[1] = tags[2] = 0;
+            for (int slot = 0; slot < 2; ++slot)
+                if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
+            if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
+            std::unique_ptr<PlanT<double>> wide(new (std::nothrow) PlanT<double>());
+            if (!wide) return fail(SSFM_ERR_INVALID, "out of host memory");
+            wide->precision = SSFM_C128;
+            if (int rc = wide->init(device, n, 1)) return rc;
+            hipLaunchKernelGGL(k_cm_kernel_line<double>, dim3(gM), dim3(256), 0, wide->stream, wide->F, (long long)nn, (long long)n, 0);
+            if (int rc = wide->field_spectrum()) return rc;
+            HIP_TRY(hipStreamSynchronize(wide->stream));
+            for (int slot = 0; slot < 2; ++slot) {
+                hipLaunchKernelGGL(k_cm_narrow, dim3(gM), dim3(256), 0, stream, (const cx<double>*)wide->scratch, scratch, (long long)n, slot);
+                hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                                   (const cx<T>*)scratch, xfer_tab[slot], N1, N2, N2 / Ef, (T)0, inv_n());
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipSetDevice(device));
+            last_launches += 8;
+            tags[1] = tags[2] = want;
+        }
+        cx<T>* mulbase = nullptr;
+        if (int rc = workspace(0, sizeof(cx<T>) * (size_t)n * distinct.size(), reinterpret_cast<void**>(&mulbase))) return rc;
+        MediumChirpArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        for (size_t i = 0; i < distinct.size(); ++i) {
+            hipLaunchKernelGGL(k_cm_mul_table<T>, dim3(gM), dim3(256), 0, stream, Dt, mulbase + i * (size_t)n, (long long)nn, (long long)n, distinct[i], (T)(1.0 / (double)nn));
+            a.mul[i] = mulbase + i * (size_t)n;
+            ++last_launches;
+        }
+        const size_t hb = sizeof(T) * (size_t)nsteps, need = hb + (size_t)nsteps;
+        if (d_hs_cap < need) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(d_hs); d_hs = nullptr; d_hs_cap = 0;
+            HIP_TRY(hipMalloc(&d_hs, need + need / 2));
+            d_hs_cap = need + need / 2;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));             // the staging vector may still feed the previous run's copy
+        h_sched.resize(need);
+        std::memcpy(h_sched.data(), hf.data(), hb);
+        for (int64_t s = 0; s < nsteps; ++s) {
+            unsigned char w = 0;
+            for (size_t i = 0; i < distinct.size(); ++i)
+                if (std::memcmp(&distinct[i], &hf[(size_t)s], sizeof(T)) == 0) w = (unsigned char)i;
+            h_sched[hb + (size_t)s] = w;
+        }
+        HIP_TRY(hipMemcpyAsync(d_hs, h_sched.data(), need, hipMemcpyHostToDevice, stream));
+        if (!medium_st) {
+            HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * 2 * (kBarShards + kBarWords + 2)));
+            HIP_TRY(hipHostMalloc(&medium_err_host, 2 * sizeof(unsigned)));
+            medium_err_host[0] = medium_err_host[1] = 0u;
+        }
+        constexpr size_t kSet = kBarShards + kBarWords + 2;
+        HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * 2 * kSet, stream));
+        a.F = F; a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.tw2 = tw2;
+        a.H[0] = xfer_tab[0]; a.H[1] = xfer_tab[1];
+        a.hs = d_hs; a.which = reinterpret_cast<const unsigned char*>(d_hs) + hb;
+        a.bar = medium_st; a.error = reinterpret_cast<unsigned*>(medium_st + kBarShards + kBarWords); a.patience = medium_patience;
+        a.xcc = (unsigned)medium_xcc;
+        a.gamma = (T)gamma; a.n = (int)nn; a.nsteps = (int)nsteps; a.rows = batch; a.Qf = N2 / Ef;
+        a.nblk = (unsigned)blocks;
+        const unsigned gA = (unsigned)std::min<long long>((n * batch + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_cm_pre<T>, dim3(gA), dim3(256), 0, stream, (const cx<T>*)A, chirp, F, (long long)nn, (long long)n, batch);
+        HIP_TRY(launch_medium_chirp(N1, N2, (int)a.nblk, medium_xccs, stream, a));
+        hipLaunchKernelGGL(k_cm_post<T>, dim3(gA), dim3(256), 0, stream, A, chirp, (const cx<T>*)F, (long long)nn, (long long)n, batch, (const unsigned*)a.error);
+        HIP_TRY(hipGetLastError());
+        last_launches += 3;
+        HIP_TRY(hipMemcpyAsync(medium_err_host, a.error, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        last_engine = SSFM_ENGINE_CHIRP_MEDIUM;
+        last_fell_back = 0;
+        if (medium_err_host[0] != 0u) {
+            medium_err_host[0] = 0u;
+            medium_ok = false;
+            ++fallbacks;
+            last_fell_back = 1;
+            return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: the launch's workgroups did not meet within the patience; the field is unchanged");
+        }
+        return SSFM_OK;
+        }
+    }
     // slot <- fft(field): the field itself becomes a resident transfer function (row 0; the field is consumed)
     int table_from_field(int slot) {
         if (slot < 0 || slot > 1) return fail(SSFM_ERR_INVALID, "ssfm_table_from_field: slot %d", slot);
         if (int rc = use_device()) return rc;
         if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
-        if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
         tags[1 + slot] = 0;
+        if (int rc = field_spectrum()) return rc;
+        hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const cx<T>*)scratch, xfer_tab[slot], N1, N2, N2 / Ef, (T)0, inv_n());
+        HIP_TRY(hipGetLastError());
+        ++last_launches;
+        return SSFM_OK;
+    }
+    // scratch <- fft(field) of every row, natural frequency order (the field is consumed)
+    int field_spectrum() {
+        if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
         HIP_TRY((launch_freq<T, FM_FWD_ONLY>(N2, N1 * batch, stream, fargs(dperm, 0, nullptr), Ef)));
         const long long total = (long long)n * batch;
         hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)Y, scratch, N1, N2, batch);
-        hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const cx<T>*)scratch, xfer_tab[slot], N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
-        last_launches += 4;
+        last_launches += 3;
         return SSFM_OK;
     }
     int apply_table(int slot) {
@@ -1900,6 +2075,9 @@ int ssfm_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const vo
 int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* io) {
     if (!io) return fail(SSFM_ERR_INVALID, "ssfm_chirp_step: NULL field description");
     WITH_PLAN(plan, P_->apply_tables_mul(mul_dev, io));
+}
+int ssfm_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
+    WITH_PLAN(plan, P_->chirp_medium(A, chirp, Dt, n, gamma, hs, nsteps));
 }
 int ssfm_table_from_field(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->table_from_field(slot)); }
 int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }

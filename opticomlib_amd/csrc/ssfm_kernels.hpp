@@ -110,9 +110,11 @@ namespace ssfm {
 // TM_MID_A: the MID of an ADAPTIVE run of a plan whose column kernel is at most 128 workgroups (2^14 ... 2^18 samples): END and
 // the next BEGIN in one launch, the workgroups waiting INSIDE the kernel for the global max |A|^2 (a grid barrier over that few
 // workgroups costs 1-2 us, profiles/r02_barrier_probe.txt; the third launch it replaces 3.5 us).
-enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2, TM_BEGIN_Y = 3, TM_END_Y = 4, TM_UNPACK = 5, TM_MID_A = 6 };
-__host__ __device__ constexpr bool tm_inverse(int m) { return m == TM_MID || m == TM_END || m == TM_END_Y || m == TM_MID_A; }     // starts in the half-transformed domain
-__host__ __device__ constexpr bool tm_forward(int m) { return m == TM_BEGIN || m == TM_MID || m == TM_BEGIN_Y || m == TM_MID_A; } // ends in it
+// (TM_MID_L, k_medium_chirp only: the column pass BETWEEN the two convolutions of a chirp-z step -- inverse transform, product with a table in the
+// time order, forward transform; no nonlinear operator, the |A|^2 the thread keeps is left alone)
+enum TimeMode { TM_BEGIN = 0, TM_MID = 1, TM_END = 2, TM_BEGIN_Y = 3, TM_END_Y = 4, TM_UNPACK = 5, TM_MID_A = 6, TM_MID_L = 7 };
+__host__ __device__ constexpr bool tm_inverse(int m) { return m == TM_MID || m == TM_END || m == TM_END_Y || m == TM_MID_A || m == TM_MID_L; }     // starts in the half-transformed domain
+__host__ __device__ constexpr bool tm_forward(int m) { return m == TM_BEGIN || m == TM_MID || m == TM_BEGIN_Y || m == TM_MID_A || m == TM_MID_L; } // ends in it
 __host__ __device__ constexpr bool tm_ends(int m) { return m == TM_END || m == TM_END_Y; }
 
 // Device-resident step control of the adaptive mode (reference devices.py:1155-1161,1193-1196).
@@ -272,6 +274,7 @@ template <typename T> struct TimeArgs {
                               // pointwise kernel and BEGIN); nullptr otherwise
     T* pkeep;                 // PK: the thread's E values of |A|^2 stay in registers from one column pass to the next (the same workgroup has the tile
                               // every time) instead of going through the P buffer
+    int keep = 0;             // PK, TM_MID: > 0 = the samples from this position of the row on are set to zero behind the rotation (chirp-z: the line's padding)
     ChirpIO<T> cz = {};       // chirp-z steps (plain layout, TM_BEGIN / TM_END): see ChirpIO
     SSFM_TRACE_ARGS
 };
@@ -663,6 +666,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
 
     constexpr bool INV = tm_inverse(MODE), FWD = tm_forward(MODE);
     static_assert(U16 || MODE <= TM_END || MODE == TM_MID_A, "the tile-private time-domain modes exist for the U16 layout only");
+    static_assert(MODE != TM_MID_L || PK, "TM_MID_L is a pass of the one-launch engines");
     T hh_prev = a.hh_prev, hh_next = a.hh_next;
     const int tid = threadIdx.x;
     SSFM_TRACE_BEGIN(a);
@@ -813,6 +817,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     // other lane's kernel queues behind (launch timeline: the last workgroup of a launch ends 2-3 us after the first).  Six
     // interleaved rounds, 2^20 x 2: 16.97 against 17.52 us per step (profiles/r03_ablation_and_knobs.txt)
     auto load_pold = [&]() {
+        if constexpr (MODE == TM_MID_L) return;
         if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
 #pragma unroll
             for (int t = 0; t < E; ++t) pold[t] = a.pkeep[t];
@@ -1103,7 +1108,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             if (fwd_active) ph += hh_next * (a.gamma * pnew[t]);
             phi[t] = ph;
         }
-    } else {
+    } else if constexpr (MODE != TM_MID_L) {
 #pragma unroll
     for (int t = 0; t < E; ++t) {
         const T p = v[t].x * v[t].x + v[t].y * v[t].y;
@@ -1115,16 +1120,25 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         pmax = p > pmax ? p : pmax;
     }
     }
+    if constexpr (MODE != TM_MID_L) {
     store_pnew();
     if (!SSFM_ABL_NO_NL) rotate_all<E>(v, phi);
     else {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t].x += phi[t];
     }
-    if constexpr (MODE == TM_MID && !U16) {
+    }
+    if constexpr ((MODE == TM_MID && !U16) || MODE == TM_MID_L) {
         if (a.mul != nullptr) {
 #pragma unroll
             for (int t = 0; t < E; ++t) v[t] = cmul(v[t], a.mul[off + t * stride]);
+        }
+    }
+    if constexpr (MODE == TM_MID && PK) {
+        if (a.keep > 0) {
+#pragma unroll
+            for (int t = 0; t < E; ++t)
+                if (off + t * stride >= a.keep) v[t] = mk<T>((T)0, (T)0);
         }
     }
     if constexpr (MODE == TM_MID_A) {
@@ -1206,7 +1220,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     }
     // exchanges alternate between two LDS buffers; the forward transform continues the count
     constexpr int NX = fft_nstages(N1, E) - 1;      // exchanges of the inverse transform
-    constexpr int XP_FWD = ((MODE != TM_MID && MODE != TM_MID_A) || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
+    constexpr int XP_FWD = ((MODE != TM_MID && MODE != TM_MID_A && MODE != TM_MID_L) || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
     if (U16) {
 #pragma unroll
@@ -1683,6 +1697,90 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
         fa.tab = a.tab[w]; fa.amp = a.amp[w]; fa.h = a.hs[s];
         freq_body<T, N2, ROWS, E, FMODE, true, true>(fa, bid);
         if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+        ta.hh_prev = a.hs[s] * half;
+        if (s + 1 < a.nsteps) {
+            ta.hh_next = a.hs[s + 1] * half;
+            time_body<T, N1, C, E, TM_MID, true, true>(ta, bid, nblk);
+            if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+        } else {
+            ta.hh_next = (T)0;
+            time_body<T, N1, C, E, TM_END, true, true>(ta, bid, nblk);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ k_medium_chirp
+// A fixed-step run of a field of ANY length n, 2048 < n <= N / 2, through the chirp-z identity on a line of N = 2^13 ... 2^17 points in one launch on
+// one XCD (csrc/chirpz.hip has the algebra; the launch-per-pass form takes five launches, 21-33 us, per step).  The chirps on either side of a step
+// cancel against the next step's (c conj(c) = 1 and a rotation commutes with them), so only the run's two ends carry them -- two pointwise launches
+// around this one (ssfm_host.hip chirp_medium); in here the line holds v = A c, zero from n up, and a step is four passes:
+//     row pass     fft . H0 . ifft        H0 = fft_N(conj(c) wrapped) / N: the n-point forward transform up to a factor c_k
+//     column pass  TM_MID_L               ifft, times exp(D~ h) / n (zero from n up: `mul`), fft
+//     row pass     fft . H1 . ifft        H1 = fft_N(c wrapped) / N: the inverse one
+//     column pass  TM_MID / TM_END        ifft, the second half rotation of this step and the first of the next in one, zero from n up, fft
+template <typename T> struct MediumChirpArgs {
+    cx<T>* F;                          // BEGIN reads A c (padded) here, END leaves the line here
+    cx<T>* Y;
+    T* P;
+    const cx<T>* twA;
+    const cx<T>* twB;
+    const cx<T>* tw1;
+    const cx<T>* tw2;
+    const cx<T>* H[2];                 // the two convolutions' transfer functions, k_freq<FM_TABLE>'s order
+    const cx<T>* mul[kSmallTabs];      // per distinct step size: exp(D~ h) / n at the positions below n, zero above (time order of the line)
+    const T* hs;
+    const unsigned char* which;
+    unsigned long long* bar;           // as MediumArgs::bar
+    unsigned xcc, nblk;
+    unsigned* error;
+    long long patience;
+    T gamma;
+    int n;                             // samples of the field
+    int nsteps;
+    int rows;
+    int Qf;
+};
+template <typename T, int N1, int N2, int E>
+__global__ __launch_bounds__(N1 * 16 / E) void k_medium_chirp(const MediumChirpArgs<T> a) {
+    constexpr int C = 16, ROWS = N1 * C / N2;
+    static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
+    const int tid = threadIdx.x;
+#if SSFM_MEDIUM_LOCAL
+    if (xcc_id() != a.xcc) return;
+    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
+    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
+    __syncthreads();
+    const unsigned bid = s_bid[0], nblk = a.nblk;
+    if (bid >= nblk) return;
+#else
+    const unsigned bid = blockIdx.x, nblk = gridDim.x;
+#endif
+    unsigned long long epoch = 0;
+    T pk[E];
+    TimeArgs<T> ta;
+    ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = nullptr;
+    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0;
+    ta.s_in = nullptr; ta.s_out = nullptr; ta.pkeep = pk; ta.mul = nullptr; ta.keep = a.n;
+    TimeArgs<T> tl = ta;
+    tl.gamma = (T)0; tl.hh_prev = tl.hh_next = (T)0; tl.keep = 0;
+    FreqArgs<T> fa;
+    fa.F = a.Y; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = (T)0; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0; fa.h = (T)0; fa.amp = (T)0;
+    const T half = (T)0.5;
+    ta.hh_prev = (T)0; ta.hh_next = a.hs[0] * half;
+    time_body<T, N1, C, E, TM_BEGIN, true, true>(ta, bid, nblk);
+    if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+    for (int s = 0; s < a.nsteps; ++s) {
+        tl.mul = a.mul[a.which[s]];
+#pragma unroll 1
+        for (int half_step = 0; half_step < 2; ++half_step) {
+            fa.tab = a.H[half_step];
+            freq_body<T, N2, ROWS, E, FM_TABLE, true, true>(fa, bid);
+            if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+            if (half_step == 0) {
+                time_body<T, N1, C, E, TM_MID_L, true, true>(tl, bid, nblk);
+                if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+            }
+        }
         ta.hh_prev = a.hs[s] * half;
         if (s + 1 < a.nsteps) {
             ta.hh_next = a.hs[s + 1] * half;

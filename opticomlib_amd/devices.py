@@ -401,6 +401,11 @@ def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_ma
         got = _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev)
         if got is not None:
             return got
+    if prec == _lib.C64 and 2048 < n <= 65536 and not return_steps and bar is None and os.environ.get("SSFM_CHIRP_LOOP", "c") != "python" \
+            and os.environ.get("SSFM_MEDIUM", "1") != "0":
+        got = _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, h, dev)
+        if got is not None:
+            return got
     with _ChirpZ(n, batch, dev) as eng:
         return _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar)
 
@@ -457,6 +462,44 @@ def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gam
                 return None
             zs = list(z_all)
         plan.synchronize()
+        return A, zs, None
+
+
+def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, h, dev):
+    """``precision="complex64"``, FIXED steps, 2048 < n <= 65536 samples that are not a power of two: the whole run in one launch on one XCD on a complex64 line
+    of M >= 2n - 1 points, 2^13 ... 2^17 (k_medium_chirp: four passes per step instead of five launches; round 4).  The arithmetic class of
+    ``_fiber_chirpz_small_c64``.  None: an adaptive run, a plan whose rows do not fit the one-XCD engine (2^17 points in all), more than four step sizes, or
+    a launch whose workgroups did not meet: the general path runs."""
+    n = shape[-1]
+    batch = 1 if len(shape) == 1 else shape[0]
+    M = 1 << (2 * n - 2).bit_length()
+    L = _F32(length)
+    if M * batch > (1 << 17) or not float(L) > 0:
+        return None
+    if h is None:
+        b2, b3 = _F32(beta_2), _F32(beta_3)
+        if not bool((b2 == 0 and b3 == 0) or _F32(gamma) == 0):
+            return None
+        hs, zs = np.array([float(L)]), [_F32(0), L]                             # one step of the whole length (reference devices.py:1163-1170)
+    else:
+        hs, z_all = step_schedule(length, h, _lib.C64)
+        hs, zs = np.asarray(hs, dtype=np.float64), list(z_all)
+    if len(set(hs.tolist())) > 4:
+        return None
+    plan = get_plan(M, batch, _lib.C64, dev)
+    with plan.lock:
+        key = (dev, n)
+        with _CACHE_LOCK:
+            if key not in _CHIRPS32:
+                _CHIRPS32[key] = _lib.chirp_device(n, False, dev).astype(np.complex64)
+                while len(_CHIRPS32) > 4:
+                    _CHIRPS32.pop(next(iter(_CHIRPS32)))
+            chirp = _CHIRPS32[key]
+        A = A_dev.astype(np.complex64) if A_dev.dtype != np.complex64 else A_dev.copy()          # the caller's array is never modified
+        A.shape = (batch, n)
+        Dt = _lib.DeviceArray.from_host(np.asarray(linear_operator(n, dt, alpha, beta_2, beta_3, _lib.C64), dtype=np.complex64), np.complex64, dev)
+        if not plan.chirp_medium(A, chirp, Dt, float(_F32(gamma)), hs):
+            return None
         return A, zs, None
 
 
