@@ -293,6 +293,10 @@ int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt
  * pointwise launches.  A, chirp, Dt: complex64, DEVICE.  At most four distinct step sizes.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: no such
  * plan or schedule, or the launch's workgroups did not meet within the patience (the engine is then off for this plan). */
 int ssfm_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
+/* ... and its ADAPTIVE run (the rule of ssfm_chirp_small_adapt in float32 arithmetic; k_medium_chirp_adapt): z_out (HOST, nullable, max_steps + 1 entries)
+ * receives z after every step, *steps_out the steps taken.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was, as above. */
+int ssfm_chirp_medium_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int64_t max_steps,
+                            double* z_out, int64_t* steps_out);
 /* ... and the ADAPTIVE run (h = phi_max / (|gamma| max |A|^2) over all rows, clamped to what is left of `length`; the rule of ssfm_chirp_propagate, in
  * float32 arithmetic when f32 != 0) in one launch: the rows' workgroups exchange their maxima through memory every step (k_small_chirp_adapt).  At
  * most 16 rows.  z_out (HOST, nullable, max_steps + 1 entries) receives z after every step, *steps_out the steps taken.  Synchronous.
@@ -364,7 +368,8 @@ enum ssfm_engine {
     SSFM_ENGINE_CHIRP_SMALL = 8,       /* any length <= 2048: fixed step, one launch per run */
     SSFM_ENGINE_CHIRP_SMALL_ADAPT = 9, /* any length <= 2048: adaptive, one launch per run */
     SSFM_ENGINE_CHIRP_STEPS = 10,      /* any length: five launches per step (seven adaptive) */
-    SSFM_ENGINE_CHIRP_MEDIUM = 11      /* any length, 2048 < n <= 65536, complex64: fixed step, one launch per run on one XCD */
+    SSFM_ENGINE_CHIRP_MEDIUM = 11,     /* any length, 2048 < n <= 65536, complex64: fixed step, one launch per run on one XCD */
+    SSFM_ENGINE_CHIRP_MEDIUM_ADAPT = 12 /* ... adaptive */
 };
 int ssfm_last_run_info(ssfm_plan* plan, int* engine, int* fell_back, int64_t* fallbacks_total, int* lanes_share_queue);
 

@@ -75,6 +75,7 @@ SYMBOLS = {
     "ssfm_chirp_step": (_I, [_VP, _VP, _VP]),                       # (plan, mul_dev, const ssfm_chirp_io*)
     "ssfm_chirp_small": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
     "ssfm_chirp_medium": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
+    "ssfm_chirp_medium_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_chirp_small_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_chirp_propagate": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_debug_fft": (_I, [_VP, _VP]),
@@ -102,7 +103,7 @@ SYMBOLS = {
 
 # enum ssfm_engine of include/ssfm_amd.h, by value
 ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adaptive_fused", "small_adaptive", "medium_adaptive",
-           "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium")
+           "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium", "chirp_medium_adaptive")
 
 
 class SsfmError(RuntimeError):
@@ -710,6 +711,17 @@ class Plan:
             return False
         _check(rc, "ssfm_chirp_medium")
         return True
+
+    def chirp_medium_adapt(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, length: float, phi_max: float, max_steps: int):
+        """The adaptive run of ``chirp_medium`` (ssfm_chirp_medium_adapt).  Returns (steps, z) or None (``A`` as it was)."""
+        z = np.zeros(int(max_steps) + 1, np.float64)
+        steps = _I64(0)
+        rc = load().ssfm_chirp_medium_adapt(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), float(length), float(phi_max),
+                                            int(max_steps), z.ctypes.data_as(C.POINTER(_D)), C.byref(steps))
+        if rc == 2:
+            return None
+        _check(rc, "ssfm_chirp_medium_adapt")
+        return int(steps.value), z[: int(steps.value) + 1]
 
     def chirp_small_adapt(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, length: float, phi_max: float, f32: bool, max_steps: int):
         """The adaptive run in one launch (ssfm_chirp_small_adapt).  Returns (steps, z) or None when the plan has no such engine or its rows' workgroups did not

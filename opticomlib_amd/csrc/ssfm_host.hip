@@ -1734,29 +1734,16 @@ template <typename T> struct PlanT : PlanBase {
     // A fixed-step chirp-z run of nn samples per row (2 nn - 1 <= n) on the line of a MEDIUM complex64 plan (2^13 ... 2^17 points) in one launch on one XCD
     // (k_medium_chirp) between two pointwise launches.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: not such a plan, more than kMaxTables step
     // sizes, or the launch's workgroups did not meet within the patience (the engine is then off for this plan).
-    int chirp_medium(void* A_, const void* chirp_, const void* Dt_, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
-        if constexpr (sizeof(T) != 4) { (void)A_; (void)chirp_; (void)Dt_; (void)nn; (void)gamma; (void)hs; (void)nsteps; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
+    int chirp_medium_tables(int64_t nn) {
+        if constexpr (sizeof(T) != 4) { (void)nn; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
         else {
         const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
         if (!SSFM_MEDIUM_LOCAL || !medium_ok || !u16 || E != 8 || Ef != 8 || !medium_shape(N1, N2) || n < 8192 || blocks % kBarShards != 0 || blocks > 64
             || n * batch > medium_max_samples || medium_xcc < 0)
             return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: a complex64 plan of 2^13 ... 2^17 points (2^17 in all rows) with the one-XCD engine is needed");
-        if (!A_ || !chirp_ || !Dt_ || !hs || nn < 2 || 2 * nn - 1 > n || nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: bad arguments");
-        std::vector<T> hf((size_t)nsteps), distinct;
-        for (int64_t s = 0; s < nsteps; ++s) {
-            if (!(hs[s] > 0) || !std::isfinite(hs[s])) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: step %lld is %g km (must be finite and > 0)", (long long)s, hs[s]);
-            hf[(size_t)s] = (T)hs[s];
-            bool seen = false;
-            for (const T d : distinct) seen = seen || std::memcmp(&d, &hf[(size_t)s], sizeof(T)) == 0;
-            if (!seen) distinct.push_back(hf[(size_t)s]);
-            if (distinct.size() > (size_t)kMaxTables) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: more than %d distinct step sizes", kMaxTables);
-        }
+        if (nn < 2 || 2 * nn - 1 > n) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: %lld samples do not fit a line of %lld", (long long)nn, (long long)n);
         if (int rc = use_device()) return rc;
-        cx<T>* A = static_cast<cx<T>*>(A_);
-        const cx<T>* chirp = static_cast<const cx<T>*>(chirp_);
-        const cx<T>* Dt = static_cast<const cx<T>*>(Dt_);
         const unsigned gM = (unsigned)std::min<long long>((n + 255) / 256, 4096);
-        last_launches = 0;
         // the two convolutions' transfer functions, generated and transformed on the device once per length (the slots' tags say what they hold)
         const uint64_t want = 0xC412000000000000ull ^ (uint64_t)nn;
         if (!xfer_tab[0] || !xfer_tab[1] || tags[1] != want || tags[2] != want) {
@@ -1786,6 +1773,29 @@ template <typename T> struct PlanT : PlanBase {
             last_launches += 8;
             tags[1] = tags[2] = want;
         }
+        return SSFM_OK;
+        }
+    }
+    int chirp_medium(void* A_, const void* chirp_, const void* Dt_, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
+        if constexpr (sizeof(T) != 4) { (void)A_; (void)chirp_; (void)Dt_; (void)nn; (void)gamma; (void)hs; (void)nsteps; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
+        else {
+        if (!A_ || !chirp_ || !Dt_ || !hs || nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: bad arguments");
+        std::vector<T> hf((size_t)nsteps), distinct;
+        for (int64_t s = 0; s < nsteps; ++s) {
+            if (!(hs[s] > 0) || !std::isfinite(hs[s])) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: step %lld is %g km (must be finite and > 0)", (long long)s, hs[s]);
+            hf[(size_t)s] = (T)hs[s];
+            bool seen = false;
+            for (const T d : distinct) seen = seen || std::memcmp(&d, &hf[(size_t)s], sizeof(T)) == 0;
+            if (!seen) distinct.push_back(hf[(size_t)s]);
+            if (distinct.size() > (size_t)kMaxTables) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: more than %d distinct step sizes", kMaxTables);
+        }
+        last_launches = 0;
+        if (int rc = chirp_medium_tables(nn)) return rc;
+        const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+        cx<T>* A = static_cast<cx<T>*>(A_);
+        const cx<T>* chirp = static_cast<const cx<T>*>(chirp_);
+        const cx<T>* Dt = static_cast<const cx<T>*>(Dt_);
+        const unsigned gM = (unsigned)std::min<long long>((n + 255) / 256, 4096);
         cx<T>* mulbase = nullptr;
         if (int rc = workspace(0, sizeof(cx<T>) * (size_t)n * distinct.size(), reinterpret_cast<void**>(&mulbase))) return rc;
         MediumChirpArgs<T> a;
@@ -1843,6 +1853,75 @@ template <typename T> struct PlanT : PlanBase {
             last_fell_back = 1;
             return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: the launch's workgroups did not meet within the patience; the field is unchanged");
         }
+        return SSFM_OK;
+        }
+    }
+    // ... and the adaptive run (k_medium_chirp_adapt): the step rule of ssfm_chirp_small_adapt in float32.  Synchronous.
+    int chirp_medium_adapt(void* A_, const void* chirp_, const void* Dt_, int64_t nn, double gamma_d, double length, double phi_max, int64_t max_steps,
+                           double* z_out, int64_t* steps_out) {
+        if constexpr (sizeof(T) != 4) { (void)A_; (void)chirp_; (void)Dt_; (void)nn; (void)gamma_d; (void)length; (void)phi_max; (void)max_steps; (void)z_out; (void)steps_out;
+                                        return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium_adapt: complex64 plans only"); }
+        else {
+        const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
+        if (!medium_adapt_ok || !fused_ok || Ef_fly != 8 || blocks > kBarWords) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium_adapt: the plan's one-launch adaptive engine is off");
+        if (!A_ || !chirp_ || !Dt_ || !(gamma_d != 0.0) || !(length > 0) || !(phi_max > 0) || max_steps < 1 || max_steps > (1ll << 30))
+            return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium_adapt: bad arguments");
+        last_launches = 0;
+        if (int rc = chirp_medium_tables(nn)) return rc;
+        cx<T>* A = static_cast<cx<T>*>(A_);
+        const cx<T>* chirp = static_cast<const cx<T>*>(chirp_);
+        if (zlog_cap < max_steps + 1) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(zlog); zlog = nullptr; zlog_cap = 0;
+            HIP_TRY(hipMalloc(&zlog, sizeof(T) * (max_steps + 1)));
+            zlog_cap = max_steps + 1;
+        }
+        if (int rc = upload_adapt_state((T)gamma_d, (T)length, (T)phi_max, (int)max_steps)) return rc;
+        hipLaunchKernelGGL(k_absmax<T>, dim3(256), dim3(256), 0, stream, (const cx<T>*)A, (long long)nn * batch, st);
+        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(64), 0, stream, st, zlog, 0, 0, 0);
+        if (!medium_st) {
+            HIP_TRY(hipMalloc(&medium_st, sizeof(unsigned long long) * 2 * (kBarShards + kBarWords + 2)));
+            HIP_TRY(hipHostMalloc(&medium_err_host, 2 * sizeof(unsigned)));
+            medium_err_host[0] = medium_err_host[1] = 0u;
+        }
+        HIP_TRY(hipMemsetAsync(medium_st, 0, sizeof(unsigned long long) * (kBarShards + kBarWords + 2), stream));
+        MediumChirpAdaptArgs<T> a;
+        std::memset(&a, 0, sizeof(a));
+        a.F = F; a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.tw2 = tw2;
+        a.H[0] = xfer_tab[0]; a.H[1] = xfer_tab[1]; a.Dt = static_cast<const cx<T>*>(Dt_); a.st = st; a.zlog = zlog;
+        a.bar = medium_st; a.error = reinterpret_cast<unsigned*>(medium_st + kBarShards + kBarWords); a.patience = medium_patience;
+        a.xcc = (unsigned)medium_xcc; a.nblk = (unsigned)blocks;
+        a.gamma = (T)gamma_d; a.inv_len = (T)(1.0 / (double)nn); a.n = (int)nn; a.rows = batch; a.Qf = N2 / Ef;
+        const unsigned gA = (unsigned)std::min<long long>((n * batch + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_cm_pre<T>, dim3(gA), dim3(256), 0, stream, (const cx<T>*)A, chirp, F, (long long)nn, (long long)n, batch);
+        HIP_TRY(launch_medium_chirp_adapt(N1, N2, (int)a.nblk, medium_xccs, stream, a));
+        // (the barriers report through the engine's error word, the hand-over of the maxima through the step state's: the field goes back to the caller
+        // -- the post kernel -- only when both are clear and the run is done)
+        unsigned gave_up[2] = {0u, 0u};
+        StepState<T> fin = {};
+        HIP_TRY(hipMemcpyAsync(&gave_up[0], a.error, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&gave_up[1], reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&fin, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(fin), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        last_launches += 5;
+        last_engine = SSFM_ENGINE_CHIRP_MEDIUM_ADAPT;
+        last_fell_back = 0;
+        if (gave_up[0] != 0u || gave_up[1] != 0u || !fin.done) {
+            medium_adapt_ok = false;
+            ++fallbacks;
+            last_fell_back = 1;
+            return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium_adapt: the launch's workgroups did not meet within the patience; the field is unchanged");
+        }
+        hipLaunchKernelGGL(k_cm_post<T>, dim3(gA), dim3(256), 0, stream, A, chirp, (const cx<T>*)F, (long long)nn, (long long)n, batch, (const unsigned*)a.error);
+        HIP_TRY(hipGetLastError());
+        if (z_out) {
+            std::vector<T> zl((size_t)fin.steps + 1);
+            HIP_TRY(hipMemcpyAsync(zl.data(), zlog, sizeof(T) * zl.size(), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (size_t i = 0; i < zl.size(); ++i) z_out[i] = (double)zl[i];
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (steps_out) *steps_out = fin.steps;
         return SSFM_OK;
         }
     }
@@ -2078,6 +2157,10 @@ int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* i
 }
 int ssfm_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
     WITH_PLAN(plan, P_->chirp_medium(A, chirp, Dt, n, gamma, hs, nsteps));
+}
+int ssfm_chirp_medium_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int64_t max_steps,
+                            double* z_out, int64_t* steps_out) {
+    WITH_PLAN(plan, P_->chirp_medium_adapt(A, chirp, Dt, n, gamma, length, phi_max, max_steps, z_out, steps_out));
 }
 int ssfm_table_from_field(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->table_from_field(slot)); }
 int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }

@@ -446,6 +446,7 @@ __device__ __forceinline__ cf32 expi_f32(float x, float amp) {
     return expi_half_turn(r, __uint_as_float(__float_as_uint(amp) ^ flip));
 }
 // scalar form
+template <typename T> __device__ __forceinline__ T exp_acc(T x);
 template <typename T> __device__ __forceinline__ void sincos_acc(T x, T& s, T& c);
 template <> __device__ __forceinline__ void sincos_acc<float>(float x, float& s, float& c) {
     if (__builtin_expect(fabsf(x) <= kSincosSmallMax, 1)) sincos_f32<false>(x, s, c);
@@ -917,6 +918,13 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         if constexpr (LATE_P) fft_line_hook<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw, load_pold);
         else if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
     }
+    if constexpr ((MODE == TM_MID || MODE == TM_MID_A) && PK) {
+        if (a.keep > 0) {                // (chirp-z: what the convolution left in the line's padding is not part of the field -- nor of its maximum)
+#pragma unroll
+            for (int t = 0; t < E; ++t)
+                if (off + t * stride >= a.keep) v[t] = mk<T>((T)0, (T)0);
+        }
+    }
     // v = time-domain samples A(n1, n2).  Nonlinear operator (reference devices.py:1175-1181):
     // the second half step of the step being finished uses the |A|^2 of its START (pold), the
     // first half step of the next one the |A|^2 of the field after that rotation -- a rotation
@@ -1128,17 +1136,32 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         for (int t = 0; t < E; ++t) v[t].x += phi[t];
     }
     }
-    if constexpr ((MODE == TM_MID && !U16) || MODE == TM_MID_L) {
+    if constexpr (MODE == TM_MID_L) {
+        if (a.s_in != nullptr) {
+            // adaptive runs: `mul` holds D~ (natural order, `keep` entries), the factor exp(D~ h) * hh_next is formed here with the step size of the
+            // state in LDS -- the products in T as the reference forms them, the functions as k_freq<FM_FLY> takes them
+            const T h = a.s_in->h;
+#pragma unroll
+            for (int t = 0; t < E; ++t) {
+                const int m = off + t * stride;
+                if (m < a.keep) {
+                    const cx<T> d = a.mul[m];
+                    const T e = exp_acc<T>(d.x * h) * a.hh_next;
+                    T sn, cs;
+                    sincos_acc<T>(d.y * h, sn, cs);
+                    v[t] = cmul(v[t], mk<T>(e * cs, e * sn));
+                } else v[t] = mk<T>((T)0, (T)0);
+            }
+        } else
         if (a.mul != nullptr) {
 #pragma unroll
             for (int t = 0; t < E; ++t) v[t] = cmul(v[t], a.mul[off + t * stride]);
         }
     }
-    if constexpr (MODE == TM_MID && PK) {
-        if (a.keep > 0) {
+    if constexpr (MODE == TM_MID && !U16) {
+        if (a.mul != nullptr) {
 #pragma unroll
-            for (int t = 0; t < E; ++t)
-                if (off + t * stride >= a.keep) v[t] = mk<T>((T)0, (T)0);
+            for (int t = 0; t < E; ++t) v[t] = cmul(v[t], a.mul[off + t * stride]);
         }
     }
     if constexpr (MODE == TM_MID_A) {
@@ -1791,6 +1814,88 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium_chirp(const MediumChirpA
             time_body<T, N1, C, E, TM_END, true, true>(ta, bid, nblk);
         }
     }
+}
+
+// ------------------------------------------------------------------------------ k_medium_chirp_adapt
+// ... and the ADAPTIVE run of such a field: k_medium_chirp's four passes per step with k_medium_adapt's step control (the maxima of |A|^2 -- of the
+// line below n: |A c| = |A| -- meet in TM_MID_A); exp(D~ h) / n is formed in TM_MID_L from D~ and the step size of the state in LDS.
+template <typename T> struct MediumChirpAdaptArgs {
+    cx<T>* F;
+    cx<T>* Y;
+    T* P;
+    const cx<T>* twA;
+    const cx<T>* twB;
+    const cx<T>* tw1;
+    const cx<T>* tw2;
+    const cx<T>* H[2];
+    const cx<T>* Dt;                   // D~, n entries, natural frequency order
+    AdaptState<T>* st;
+    T* zlog;
+    unsigned long long* bar;
+    unsigned xcc, nblk;
+    unsigned* error;
+    long long patience;
+    T gamma;
+    T inv_len;                         // 1 / n
+    int n;
+    int rows;
+    int Qf;
+};
+template <typename T, int N1, int N2, int E>
+__global__ __launch_bounds__(N1 * 16 / E) void k_medium_chirp_adapt(const MediumChirpAdaptArgs<T> a) {
+    constexpr int C = 16, ROWS = N1 * C / N2;
+    static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
+    const int tid = threadIdx.x;
+#if SSFM_MEDIUM_LOCAL
+    if (xcc_id() != a.xcc) return;
+    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
+    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
+    __syncthreads();
+    const unsigned bid = s_bid[0], nblk = a.nblk;
+    if (bid >= nblk) return;
+#else
+    const unsigned bid = blockIdx.x, nblk = gridDim.x;
+#endif
+    __shared__ __attribute__((aligned(16))) StepState<T> s_state[2];       // [0] the step being taken, [1] where TM_MID_A leaves the next one
+    unsigned long long epoch = 0;
+    StepState<T> S = a.st->cur[0];
+    if (S.done) return;
+    TimeArgs<T> ta;
+    ta.F = a.F; ta.Y = a.Y; ta.P = a.P; ta.twN = nullptr; ta.twA = a.twA; ta.twB = a.twB; ta.tw1 = a.tw1; ta.st = nullptr; ta.zlog = a.zlog;
+    ta.gamma = a.gamma; ta.N2 = N2; ta.rows = a.rows; ta.Qf = a.Qf; ta.step = 0; ta.derive = 0;
+    T pk[E];
+    ta.s_in = &s_state[0]; ta.s_out = &s_state[1]; ta.pkeep = pk; ta.mul = nullptr; ta.keep = a.n;
+    TimeArgs<T> tl = ta;
+    tl.gamma = (T)0; tl.hh_prev = (T)0; tl.hh_next = a.inv_len; tl.mul = a.Dt; tl.zlog = nullptr;
+    FreqArgs<T> fa;
+    fa.F = a.Y; fa.tw2 = a.tw2; fa.st = nullptr; fa.inv_n = (T)0; fa.N1 = N1; fa.rows = a.rows; fa.u16 = 1; fa.step = 0; fa.h = (T)0; fa.amp = (T)0;
+    const T half = (T)0.5;
+    ta.hh_prev = (T)0; ta.hh_next = S.h * half;
+    time_body<T, N1, C, E, TM_BEGIN, true, true>(ta, bid, nblk);
+    if (tid == 0) { s_state[0] = S; s_state[1].steps = -0x7fffffff; }
+    if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;           // (its barriers also publish s_state to the workgroup)
+    ta.st = a.st;
+    for (int step = 0;; ++step) {
+        fa.tab = a.H[0];
+        freq_body<T, N2, ROWS, E, FM_TABLE, true, true>(fa, bid);
+        if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+        time_body<T, N1, C, E, TM_MID_L, true, true>(tl, bid, nblk);
+        if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+        fa.tab = a.H[1];
+        freq_body<T, N2, ROWS, E, FM_TABLE, true, true>(fa, bid);
+        if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+        ta.step = step;
+        time_body<T, N1, C, E, TM_MID_A, true, true>(ta, bid, nblk);
+        __syncthreads();
+        const StepState<T> Sn = s_state[1];
+        if (Sn.steps == -0x7fffffff) return;                   // the hand-over of the maxima ran out of patience (error word set)
+        S = Sn;
+        if (S.done) break;
+        __syncthreads();
+        if (tid == 0) { s_state[0] = S; s_state[1].steps = -0x7fffffff; }
+        if (!medium_barrier(a.bar, a.error, a.patience, epoch, bid, nblk, tid)) return;
+    }
+    if (bid == 0 && tid == 0) a.st->cur[0] = S;                // (the host reads cur[0])
 }
 
 // ------------------------------------------------------------------------------ k_medium_adapt

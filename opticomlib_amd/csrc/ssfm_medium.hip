@@ -89,6 +89,33 @@ hipError_t launch_medium_chirp(int N1, int N2, int nblk, int xccs, hipStream_t s
     return hipErrorInvalidValue;
 }
 
+namespace {
+template <int N1, int N2>
+hipError_t launch_chirp_adapt_shape(int nblk, int xccs, hipStream_t s, const MediumChirpAdaptArgs<float>& a) {
+    using T = float;
+    constexpr int E = 8, C = 16, ROWS = N1 * C / N2;
+    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+                           + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
+    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+                           + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
+    constexpr size_t lds = lds_t > lds_f ? lds_t : lds_f;
+    static hipError_t attr = lds <= 48 * 1024 ? hipSuccess
+        : hipFuncSetAttribute(reinterpret_cast<const void*>(k_medium_chirp_adapt<T, N1, N2, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_medium_chirp_adapt<T, N1, N2, E>), dim3(SSFM_MEDIUM_LOCAL ? xccs * nblk : nblk), dim3(N1 * C / E), lds, s, a);
+    return hipGetLastError();
+}
+}  // namespace
+hipError_t launch_medium_chirp_adapt(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumChirpAdaptArgs<float>& a) {
+    if (N1 == 64 && N2 == 64) return launch_chirp_adapt_shape<64, 64>(nblk, xccs, s, a);
+    if (N1 == 64 && N2 == 128) return launch_chirp_adapt_shape<64, 128>(nblk, xccs, s, a);
+    if (N1 == 128 && N2 == 128) return launch_chirp_adapt_shape<128, 128>(nblk, xccs, s, a);
+    if (N1 == 128 && N2 == 256) return launch_chirp_adapt_shape<128, 256>(nblk, xccs, s, a);
+    if (N1 == 256 && N2 == 256) return launch_chirp_adapt_shape<256, 256>(nblk, xccs, s, a);
+    if (N1 == 256 && N2 == 512) return launch_chirp_adapt_shape<256, 512>(nblk, xccs, s, a);
+    return hipErrorInvalidValue;
+}
+
 bool medium_shape(int N1, int N2) { return (N1 == 64 && (N2 == 64 || N2 == 128)) || (N1 == 128 && (N2 == 128 || N2 == 256)) || (N1 == 256 && (N2 == 256 || N2 == 512)); }
 
 hipError_t launch_medium(int N1, int N2, bool phase_tables, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {

@@ -11,6 +11,8 @@ hipError_t launch_medium(int N1, int N2, bool phase_tables, int nblk, int xccs, 
 hipError_t launch_medium_adapt(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumAdaptArgs<float>& a);
 // the fixed-step chirp-z run on such a plan in one launch (k_medium_chirp)
 hipError_t launch_medium_chirp(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumChirpArgs<float>& a);
+// ... and its adaptive run (k_medium_chirp_adapt)
+hipError_t launch_medium_chirp_adapt(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumChirpAdaptArgs<float>& a);
 // The XCC ids (HW_REG_XCC_ID) the workgroups of a launch on `device` are dealt to, as a bit mask: 0xff on an MI355X in SPX mode, 1 when
 // every XCD is a device of its own.  Found once per device by a probe launch (synchronous); 0 on error.
 unsigned xcc_mask(int device);

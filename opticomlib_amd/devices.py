@@ -403,7 +403,7 @@ def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_ma
             return got
     if prec == _lib.C64 and 2048 < n <= 65536 and not return_steps and bar is None and os.environ.get("SSFM_CHIRP_LOOP", "c") != "python" \
             and os.environ.get("SSFM_MEDIUM", "1") != "0":
-        got = _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, h, dev)
+        got = _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev)
         if got is not None:
             return got
     with _ChirpZ(n, batch, dev) as eng:
@@ -465,22 +465,24 @@ def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gam
         return A, zs, None
 
 
-def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, h, dev):
-    """``precision="complex64"``, FIXED steps, 2048 < n <= 65536 samples that are not a power of two: the whole run in one launch on one XCD on a complex64 line
-    of M >= 2n - 1 points, 2^13 ... 2^17 (k_medium_chirp: four passes per step instead of five launches; round 4).  The arithmetic class of
-    ``_fiber_chirpz_small_c64``.  None: an adaptive run, a plan whose rows do not fit the one-XCD engine (2^17 points in all), more than four step sizes, or
-    a launch whose workgroups did not meet: the general path runs."""
+def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev):
+    """``precision="complex64"``, 2048 < n <= 65536 samples that are not a power of two: the whole run in one launch on one XCD on a complex64 line of
+    M >= 2n - 1 points, 2^13 ... 2^17 (k_medium_chirp / k_medium_chirp_adapt: four passes per step instead of five / seven launches; round 4).  The arithmetic
+    class of ``_fiber_chirpz_small_c64``.  None: a plan whose rows do not fit the one-XCD engine (2^17 points in all), more than four step sizes, or a launch
+    whose workgroups did not meet: the general path runs."""
     n = shape[-1]
     batch = 1 if len(shape) == 1 else shape[0]
     M = 1 << (2 * n - 2).bit_length()
     L = _F32(length)
     if M * batch > (1 << 17) or not float(L) > 0:
         return None
+    adaptive = False
     if h is None:
         b2, b3 = _F32(beta_2), _F32(beta_3)
-        if not bool((b2 == 0 and b3 == 0) or _F32(gamma) == 0):
-            return None
+        adaptive = not bool((b2 == 0 and b3 == 0) or _F32(gamma) == 0)
         hs, zs = np.array([float(L)]), [_F32(0), L]                             # one step of the whole length (reference devices.py:1163-1170)
+        if adaptive and os.environ.get("SSFM_MEDIUM_ADAPT", "1") == "0":
+            return None
     else:
         hs, z_all = step_schedule(length, h, _lib.C64)
         hs, zs = np.asarray(hs, dtype=np.float64), list(z_all)
@@ -498,8 +500,21 @@ def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, ga
         A = A_dev.astype(np.complex64) if A_dev.dtype != np.complex64 else A_dev.copy()          # the caller's array is never modified
         A.shape = (batch, n)
         Dt = _lib.DeviceArray.from_host(np.asarray(linear_operator(n, dt, alpha, beta_2, beta_3, _lib.C64), dtype=np.complex64), np.complex64, dev)
-        if not plan.chirp_medium(A, chirp, Dt, float(_F32(gamma)), hs):
-            return None
+        g = float(_F32(gamma))
+        if not adaptive:
+            if not plan.chirp_medium(A, chirp, Dt, g, hs):
+                return None
+            return A, zs, None
+        zs, z0, max_steps = [_F32(0)], _F32(0), 1 << 17
+        while True:
+            got = plan.chirp_medium_adapt(A, chirp, Dt, g, float(_F32(L - z0)), float(_F32(phi_max)), max_steps)
+            if got is None:
+                return None if z0 == 0 else _raise_chirp_midway()
+            steps, z = got
+            zs += [_F32(z0 + _F32(v)) for v in z[1:]]
+            if steps < max_steps or not (zs[-1] < L):
+                break
+            z0 = zs[-1]
         return A, zs, None
 
 

@@ -24,7 +24,7 @@ def timed(x, reps, **kw):
 
 if __name__ == "__main__":
     gv(**workloads.BENCH_GV)
-    out = ["# n x rows | engine | err vs oracle complex64 (100 steps) | err vs float64 | us per step one-launch (1000 steps, wall) | us per step five-launch form"]
+    out = ["# n x rows | engine | err vs oracle complex64 (100 steps) | err vs float64 | us per step one-launch (1000 steps, wall) | us per step five-launch form || adaptive (20 km, phi_max 0.002): engine, steps, err vs oracle complex64, us per step one-launch | seven-launch form"]
     for n, npol in ((3000, 2), (4095, 1), (8176, 2), (8176, 1), (15060, 2), (16383, 1), (32752, 2), (32752, 1), (40000, 1), (65536 - 3, 1)):
         a = workloads.qpsk_field(1 << 16, seed=n % 997, power_w=4e-3, n_pol=2)[:npol, :n]
         a = a[0] if npol == 1 else a
@@ -42,7 +42,18 @@ if __name__ == "__main__":
         os.environ["SSFM_MEDIUM"] = "0"
         t5, y5 = timed(x, 1, **kw2)
         os.environ["SSFM_MEDIUM"] = "1"
-        line = f"{n:6d} x {npol} | {info:13s} | {e64:.2e} | {e128:.2e} | {t1 * 1e6 / 1000:7.2f} | {t5 * 1e6 / 1000:7.2f}"
+        # adaptive: steps and time per step, both forms; the error against the oracle's adaptive run
+        kwa = dict(length=20.0, phi_max=0.002, **workloads.SMF)
+        ta, ya = timed(x, 1, **kwa)
+        za, _ = oa.FIBER(x, return_steps=True, **kwa)                     # (the general path: its z list gives the step count)
+        ea = relmax(ya.signal, orc.fiber_c64(a, gv.dt, **kwa))
+        infa = get_plan(M, npol, _lib.C64, 0).last_run_info()["engine"] if M * npol <= (1 << 17) else "-"
+        os.environ["SSFM_MEDIUM"] = "0"
+        ta5, _ = timed(x, 1, **kwa)
+        os.environ["SSFM_MEDIUM"] = "1"
+        nst = len(za) - 1
+        line = (f"{n:6d} x {npol} | {info:13s} | {e64:.2e} | {e128:.2e} | {t1 * 1e6 / 1000:7.2f} | {t5 * 1e6 / 1000:7.2f} || {infa} {nst} steps err {ea:.2e} "
+                f"{ta * 1e6 / nst:7.2f} | {ta5 * 1e6 / nst:7.2f}")
         print(line, flush=True)
         out.append(line)
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gpurun_out", "r04_chirp_medium.txt")

@@ -206,7 +206,7 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
     """Lengths that are not powers of two: the whole run queued from C (ssfm_chirp_propagate; adaptive: the step rule evaluated on the device in
     the caller's float32 arithmetic) against the loop that calls one entry point per kernel from Python and waits for every step's maximum
     (SSFM_CHIRP_LOOP=python).  The C loop takes five launches per step -- the middle of a step in one column launch, the step's two ends inside the
-    first and the last -- so the product with exp(D~ h) and the chirp products are rounded in other places than in the host loop's nine: 1e-12.  Up to
+    first and the last -- so the product with exp(D~ h) and the chirp products are rounded in other places than in the host loop's nine: 1e-12 ("c5").  Up to
     2048 samples a fixed-step run is one launch (k_small_chirp; SSFM_CHIRP_SMALL=0 turns it off), with the two half rotations between steps merged
     into one: 1e-12 as well.  (Round 3's nine- and seven-launch forms of the C loop, bit-identical to the host loop, were removed in round 4.)"""
     gv(**workloads.BENCH_GV)
@@ -223,8 +223,8 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
             res[name] = (y, z)
         for name in ("c5", "c"):      # (c5: five launches per step; c: n <= 2048: the whole run in one launch)
             tol = 1e-12 * (1 if "h" in kw else 1e4)                 # (adaptive: a last-bit difference in a maximum moves a step size)
-            if name == "c" and (n <= 2048 or "h" in kw):
-                tol = TOL_100      # (round 4: a complex64 caller's run of up to 2048 samples -- fixed step: 65536 -- is ONE launch on a complex64 line -- the reference's own arithmetic class)
+            if name == "c":
+                tol = TOL_100      # (round 4: a complex64 caller's run of up to 65536 samples is ONE launch on a complex64 line -- the reference's own arithmetic class)
             assert relmax(res[name][0], res["python"][0]) < tol, name
         assert len(res["python"][1]) > 10
         if n <= 2048:
@@ -242,7 +242,9 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
     monkeypatch.setenv("SSFM_CHIRP_LOOP", "python")
     ref = oa.FIBER(x1, **kw).signal
     monkeypatch.setenv("SSFM_CHIRP_LOOP", "c")
-    assert relmax(oa.FIBER(x1, **kw).signal, ref) < (TOL_100 if n <= 2048 else 1e-8)          # (n <= 2048: the complex64 line, see above)
+    assert relmax(oa.FIBER(x1, **kw).signal, ref) < TOL_100                                   # (the complex64 line, see above)
+    monkeypatch.setenv("SSFM_CHIRP_SMALL", "0"); monkeypatch.setenv("SSFM_MEDIUM", "0")
+    assert relmax(oa.FIBER(x1, **kw).signal, ref) < 1e-8                                      # (the complex128 line queued from C)
 
 
 @pytest.mark.parametrize("n,npol", [(3000, 2), (8176, 2), (8176, 1), (15060, 2), (32752, 2), (40000, 1), (65533, 1)])
@@ -251,17 +253,18 @@ def test_any_length_medium_line_in_one_launch_against_oracle(n, npol, monkeypatc
     the whole run in one launch on one XCD on a complex64 line of M >= 2n - 1 points (k_medium_chirp, ssfm_chirp_medium) -- against the oracle's complex64
     run and the float64 restatement after 101 steps (the last one short), the single full-length step of a fibre without nonlinearity, and the five-launch
     complex128 line of the same call (SSFM_MEDIUM=0).  The engine that ran is read back: a silent fall to the general path fails the test."""
-    for k in ("SSFM_MEDIUM", "SSFM_CHIRP_LOOP", "SSFM_FUSED_PATIENCE_TICKS"):
+    for k in ("SSFM_MEDIUM", "SSFM_MEDIUM_ADAPT", "SSFM_ADAPT_FUSED", "SSFM_CHIRP_LOOP", "SSFM_FUSED_PATIENCE_TICKS"):
         monkeypatch.delenv(k, raising=False)
     gv(**workloads.BENCH_GV)
     a = workloads.qpsk_field(1 << 16, seed=n % 997, power_w=4e-3, n_pol=2)[:npol, :n]
     a = a[0] if npol == 1 else a
     x = optical_signal(a)
     M = 1 << (2 * n - 2).bit_length()
-    for kw in (dict(length=50.2, h=0.5, **workloads.SMF), dict(length=40.0, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=0.0)):
+    for kw in (dict(length=50.2, h=0.5, **workloads.SMF), dict(length=40.0, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=0.0),
+               dict(length=12.0, phi_max=0.002, **workloads.SMF)):                  # (adaptive: 50 to 60 steps, k_medium_chirp_adapt)
         y = oa.FIBER(x, **kw).signal
         info = oa.devices.get_plan(M, npol, _lib.C64, 0).last_run_info()
-        assert info["engine"] == "chirp_medium" and not info["fell_back"], info
+        assert info["engine"] == ("chirp_medium_adaptive" if "phi_max" in kw else "chirp_medium") and not info["fell_back"], info
         assert y.dtype == np.complex64 and y.shape == a.shape
         assert relmax(y, orc.fiber_c64(a, gv.dt, **kw)) < TOL_100
         assert relmax(y, orc.fiber_c128(a, gv.dt, **kw)) < TOL_100
@@ -297,6 +300,15 @@ def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run
         np.testing.assert_array_equal(A.to_host(), a)
     finally:
         p.close()
+    p = _lib.Plan(M, 2, _lib.C64)
+    try:
+        A = _lib.DeviceArray.from_host(a, np.complex64, 0)
+        assert p.chirp_medium_adapt(A, chirp, Dt, 1.3, 5.0, 0.004, 1000) is None
+        np.testing.assert_array_equal(A.to_host(), a)
+        info = p.last_run_info()
+        assert info["engine"] == "chirp_medium_adaptive" and info["fell_back"] and info["fallbacks_total"] == 1
+    finally:
+        p.close()
     monkeypatch.delenv("SSFM_FUSED_PATIENCE_TICKS")
     q = _lib.Plan(M, 2, _lib.C64)
     try:
@@ -309,6 +321,14 @@ def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run
             ref = orc.fiber_c64(ref, gv.dt, length=float(h), h=float(h), alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
         assert relmax(A.to_host(), ref) < TOL_100
         assert q.last_run_info()["engine"] == "chirp_medium"
+        A = _lib.DeviceArray.from_host(a, np.complex64, 0)
+        steps, z = q.chirp_medium_adapt(A, chirp, Dt, 1.3, 5.0, 0.004, 1000)
+        zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, length=5.0, phi_max=0.004, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
+        assert abs(steps + 1 - len(zr)) <= 1 and len(z) == steps + 1 and abs(z[-1] - 5.0) < 1e-5
+        m = min(len(z), len(zr)) - 1
+        np.testing.assert_allclose(z[:m], zr[:m], rtol=2e-4)
+        assert relmax(A.to_host(), Ar[-1]) < TOL_100
+        assert q.last_run_info()["engine"] == "chirp_medium_adaptive"
     finally:
         q.close()
 
