@@ -253,8 +253,9 @@ def test_any_length_medium_line_in_one_launch_against_oracle(n, npol, monkeypatc
     the whole run in one launch on one XCD on a complex64 line of M >= 2n - 1 points (k_medium_chirp, ssfm_chirp_medium) -- against the oracle's complex64
     run and the float64 restatement after 101 steps (the last one short), the single full-length step of a fibre without nonlinearity, and the five-launch
     complex128 line of the same call (SSFM_MEDIUM=0).  The engine that ran is read back: a silent fall to the general path fails the test."""
-    for k in ("SSFM_MEDIUM", "SSFM_MEDIUM_ADAPT", "SSFM_ADAPT_FUSED", "SSFM_CHIRP_LOOP", "SSFM_FUSED_PATIENCE_TICKS"):
+    for k in ("SSFM_MEDIUM", "SSFM_MEDIUM_ADAPT", "SSFM_ADAPT_FUSED", "SSFM_CHIRP_LOOP", "SSFM_FUSED_PATIENCE_TICKS", "SSFM_E", "SSFM_EF"):
         monkeypatch.delenv(k, raising=False)
+    oa.devices.release_plans()                  # (a plan reads its knobs when it is made: none made under the knob suite's environment is reused here)
     gv(**workloads.BENCH_GV)
     a = workloads.qpsk_field(1 << 16, seed=n % 997, power_w=4e-3, n_pol=2)[:npol, :n]
     a = a[0] if npol == 1 else a
@@ -282,6 +283,8 @@ def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run
     """ssfm_chirp_medium from the plan level: without patience (SSFM_FUSED_PATIENCE_TICKS=-1) the launch's workgroups give up at their first meeting -- the
     call says so (False), the caller's field is bit for bit what it was, the plan counts a fallback and does not try again; a schedule of more than four
     step sizes is refused before anything is launched; and the same call with patience gives the oracle's result."""
+    for k in ("SSFM_MEDIUM", "SSFM_MEDIUM_ADAPT", "SSFM_ADAPT_FUSED", "SSFM_E", "SSFM_EF"):
+        monkeypatch.delenv(k, raising=False)
     gv(**workloads.BENCH_GV)
     n, M = 5001, 16384
     a = workloads.qpsk_field(1 << 13, seed=9, power_w=4e-3, n_pol=2)[:, :n].astype(np.complex64)
