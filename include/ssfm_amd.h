@@ -353,8 +353,9 @@ void* ssfm_stream(ssfm_plan* plan);
  *   engine            a value of enum ssfm_engine below: the engine that produced the result of the LAST run (after a fallback: the fallback)
  *   fell_back         1: the last run was started on a single-launch engine, gave up and was repeated
  *   fallbacks_total   such repeats over the life of the plan (a plan keeps to the fallback engine after the first)
- *   lanes_share_queue 1: the runtime could not give the plan's lanes hardware queues of their own (more than four high-priority streams
- *                     alive and eight replacement streams all mapped to a taken queue): fixed-step lanes then run one after the other
+ *   lanes_share_queue 1: the plan's lanes could not be given hardware queues on which they run side by side at full rate (ssfm_plan_create probes
+ *                     its lane streams and tries eight replacement streams; more than four high-priority streams alive): fixed-step lanes then
+ *                     run one after the other, or slower than that
  * Any pointer may be NULL.  For a run whose fallback is resolved lazily (see ssfm_field_device_ptr) call ssfm_synchronize first. */
 enum ssfm_engine {
     SSFM_ENGINE_NONE = 0,

@@ -361,17 +361,37 @@ __global__ void k_queue_probe_wait(unsigned* flag, unsigned* seen, long long pat
     *seen = v;
 }
 __global__ void k_queue_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void k_queue_probe_nop() {}
 // 1: b's kernel ran beside a's (queues of their own); 0: it did not within 0.2 ms (one queue -- or a GPU too busy to tell); < 0: HIP error
 int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* two device words */, hipEvent_t ev) {
     unsigned seen = 0u;
     if (hipMemsetAsync(words, 0, 2 * sizeof(unsigned), a) != hipSuccess) return -1;
     if (hipEventRecord(ev, a) != hipSuccess || hipStreamWaitEvent(b, ev, 0) != hipSuccess) return -1;
     hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(1), 0, a, words, words + 1, 20000ll);
+    // ... with a second kernel queued BEHIND the waiting one, as in a run (every launch of a lane waits for the lane's previous one): two hardware queues
+    // that are served by one pipe of the command processor pass the probe without it -- the pipe turns to b's queue when a's has nothing more to
+    // hand out -- but in a run the pipe sits on a's pending dependency and b's launches wait for it (a fresh two-lane plan beside exactly one other used
+    // stream: 28-31 us per step, 65-70 at worst, instead of 11.3; tools/attic/lane_speed_probe.py, profiles/r04_order_dependence.txt)
+    hipLaunchKernelGGL(k_queue_probe_nop, dim3(1), dim3(1), 0, a);
     hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(1), 0, b, words);
     if (hipGetLastError() != hipSuccess) return -1;
     if (hipMemcpyAsync(&seen, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, a) != hipSuccess) return -1;
     if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
     return seen != 0u ? 1 : 0;
+}
+
+// Time [us] of `reps` dependent empty launches on stream a, with as many on stream b (nullptr: none) enqueued in between; < 0: HIP error
+float lane_chain_us(hipStream_t a, hipStream_t b, int reps, hipEvent_t e0, hipEvent_t e1) {
+    if (hipEventRecord(e0, a) != hipSuccess) return -1.f;
+    for (int i = 0; i < reps; ++i) {
+        hipLaunchKernelGGL(k_queue_probe_nop, dim3(1), dim3(1), 0, a);
+        if (b) hipLaunchKernelGGL(k_queue_probe_nop, dim3(1), dim3(1), 0, b);
+    }
+    if (hipGetLastError() != hipSuccess || hipEventRecord(e1, a) != hipSuccess) return -1.f;
+    if (hipStreamSynchronize(a) != hipSuccess || (b && hipStreamSynchronize(b) != hipSuccess)) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+    return ms * 1e3f;
 }
 
 // ----------------------------------------------------------------------------- plan
@@ -656,19 +676,58 @@ template <typename T> struct PlanT : PlanBase {
             // picks the least used queue of the class for a new stream, so the replacement is made BEFORE the old stream is destroyed)
             unsigned* words = nullptr;
             HIP_TRY(hipMalloc(&words, 2 * sizeof(unsigned)));
-            for (int g = 1; g < nlanes; ++g) {
-                for (int attempt = 0; ; ++attempt) {
-                    int ok = 1;
-                    for (int k = 0; k < g && ok == 1; ++k) ok = streams_run_side_by_side(lane_stream[k], lane_stream[g], words, fork_ev);
-                    if (ok == 1) break;
-                    if (ok < 0 || attempt == 7) { lanes_share_queue = true; break; }
-                    hipStream_t fresh = nullptr;
-                    if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio_hi) != hipSuccess) { lanes_share_queue = true; break; }
-                    (void)hipStreamDestroy(lane_stream[g]);
-                    lane_stream[g] = fresh;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            // ... and queues of their own that still get in each other's way.  Seen with a fresh two-lane plan beside exactly one other used stream
+            // (tools/attic/lane_speed_probe.py, profiles/r04_order_dependence.txt): the side-by-side probe passes, the run takes 28-31 us per step
+            // (65-70 at worst) instead of 11.3 -- which hardware queue a stream gets decides it (the fourth one made in the class, by the runtime's
+            // log).  Measured: sixteen dependent empty launches on lane 0 take 29.5 us alone and 31-45 us with as many on the other lane in
+            // between; 64-480 us in the bad state.  A lane is good when the best of three such measurements stays within 1.7 x the best alone.
+            const bool dbg = std::getenv("SSFM_DEBUG_LANE_PROBE") != nullptr;
+            // 0 = good, 1 = on a queue of its own but in the way (score = the ratio), 2 = shares a queue with an earlier lane, < 0: HIP error
+            auto rate = [&](int g, hipStream_t cand, float* score) -> int {
+                *score = 1e30f;
+                for (int k = 0; k < g; ++k) {
+                    const int side = streams_run_side_by_side(lane_stream[k], cand, words, fork_ev);
+                    if (side < 0) return -1;
+                    if (side == 0) return 2;
                 }
+                float solo = 1e30f, both = 1e30f;
+                for (int r = 0; r < 3; ++r) {
+                    const float s1 = lane_chain_us(lane_stream[0], nullptr, 16, e0, e1), b1 = lane_chain_us(lane_stream[0], cand, 16, e0, e1);
+                    if (s1 < 0.f || b1 < 0.f) return -1;
+                    solo = s1 < solo ? s1 : solo; both = b1 < both ? b1 : both;
+                }
+                *score = both / solo;
+                if (dbg) std::fprintf(stderr, "lane probe: lane %d: alone %.1f us, with the other lane %.1f us\n", g, solo, both);
+                return *score > 1.7f ? 1 : 0;
+            };
+            for (int g = 1; g < nlanes; ++g) {
+                float score = 0.f;
+                int state = rate(g, lane_stream[g], &score);
+                // not good: candidates four at a time -- made together, so that the runtime's least-used rule spreads them over the class's hardware
+                // queues -- the first good one (else the best one) replaces the lane's stream, the rest go
+                for (int round = 0; round < 2 && state > 0; ++round) {
+                    hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
+                    for (auto& c : cand)
+                        if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prio_hi) != hipSuccess) c = nullptr;
+                    for (auto& c : cand) {
+                        if (!c || state == 0) continue;
+                        float sc = 0.f;
+                        const int st_c = rate(g, c, &sc);
+                        if (st_c >= 0 && (st_c < state || (st_c == state && sc < score))) {
+                            std::swap(c, lane_stream[g]);
+                            state = st_c; score = sc;
+                        }
+                    }
+                    for (auto& c : cand)
+                        if (c) (void)hipStreamDestroy(c);
+                }
+                if (state != 0) lanes_share_queue = true;
             }
             (void)hipFree(words);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
         const size_t cb = sizeof(cx<T>);
         HIP_TRY(hipMalloc(&F, cb * n * batch));

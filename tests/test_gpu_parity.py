@@ -849,9 +849,13 @@ def test_the_lanes_of_a_plan_get_hardware_queues_of_their_own(monkeypatch):
                 assert p.lanes == 2
                 p.set_linear_operator(D); p.set_field(a)
                 p.propagate_fixed(1.3, hs); p.synchronize()
-                t0 = time.perf_counter()
-                p.propagate_fixed(1.3, hs); p.synchronize()
-                times.append(time.perf_counter() - t0)
+                best = None
+                for rep in range(3):              # (the best of three: a lane that shares a queue is slow every time, a box that is still waking up is not)
+                    t0 = time.perf_counter()
+                    p.propagate_fixed(1.3, hs); p.synchronize()
+                    dt_run = time.perf_counter() - t0
+                    best = dt_run if best is None else min(best, dt_run)
+                times.append(best)
                 assert not p.last_run_info()["lanes_share_queue"], k
             finally:
                 p.close()
@@ -2463,7 +2467,9 @@ def test_no_host_arithmetic_left_in_the_device_paths():
     oa.devices._CHIRPS.clear()
     before = dict(_lib.TRANSFERS)
     y = oa.FIBER(optical_signal.from_device(x), length=2, h=1.0, beta_2=-20.0, gamma=1.0)          # chirp-z: kernels built on the device
-    assert {k: _lib.TRANSFERS[k] - before[k] for k in before} == {"h2d": 1, "d2h": 0}              # (the operator D~ of the odd length)
+    # (the operator D~ of the odd length; once more, in the other precision, when the one-launch engine of the complex64 line gave up and the general path ran)
+    uploads = 2 if os.environ.get("SSFM_FUSED_PATIENCE_TICKS") == "-1" else 1
+    assert {k: _lib.TRANSFERS[k] - before[k] for k in before} == {"h2d": uploads, "d2h": 0}
     e = oa.electrical_signal.from_device(x)
     before = dict(_lib.TRANSFERS)
     f = oa.LPF(e, BW=5e9)
