@@ -1664,6 +1664,9 @@ __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned
         const unsigned long long want = epoch * (nblk / kBarShards);
         const long long t0 = wall_clock64();
         int good = 0;
+        // (Two polls in flight half a round trip apart, so that the last arrival is seen sooner, changed nothing: 4.71 / 5.77 / 8.12 / 12.38 against
+        // 4.59 / 5.74 / 8.07 / 12.17 us per step at 2^13 x 2 / 2^14 / 2^16 x 2 / the 8176-sample chirp-z line -- the wait is for the slowest workgroup's
+        // stores, not for the news of them.  Round 4, tools/medium_time.py.)
         for (;;) {
 #if SSFM_MEDIUM_LOCAL
             unsigned long long got = want;
