@@ -684,7 +684,6 @@ template <typename T> struct PlanT : PlanBase {
             // (65-70 at worst) instead of 11.3 -- which hardware queue a stream gets decides it (the fourth one made in the class, by the runtime's
             // log).  Measured: sixteen dependent empty launches on lane 0 take 29.5 us alone and 31-45 us with as many on the other lane in
             // between; 64-480 us in the bad state.  A lane is good when the best of three such measurements stays within 1.7 x the best alone.
-            const bool dbg = std::getenv("SSFM_DEBUG_LANE_PROBE") != nullptr;
             // 0 = good, 1 = on a queue of its own but in the way (score = the ratio), 2 = shares a queue with an earlier lane, < 0: HIP error
             auto rate = [&](int g, hipStream_t cand, float* score) -> int {
                 *score = 1e30f;
@@ -700,7 +699,6 @@ template <typename T> struct PlanT : PlanBase {
                     solo = s1 < solo ? s1 : solo; both = b1 < both ? b1 : both;
                 }
                 *score = both / solo;
-                if (dbg) std::fprintf(stderr, "lane probe: lane %d: alone %.1f us, with the other lane %.1f us\n", g, solo, both);
                 return *score > 1.7f ? 1 : 0;
             };
             for (int g = 1; g < nlanes; ++g) {
