@@ -362,6 +362,10 @@ __global__ void k_queue_probe_wait(unsigned* flag, unsigned* seen, long long pat
 }
 __global__ void k_queue_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __global__ void k_queue_probe_nop() {}
+__global__ void k_queue_probe_spin(long long ticks) {            // a kernel that takes `ticks` of the 100 MHz clock, like a real one takes its microseconds
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
 // 1: b's kernel ran beside a's (queues of their own); 0: it did not within 0.2 ms (one queue -- or a GPU too busy to tell); < 0: HIP error
 int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* two device words */, hipEvent_t ev) {
     unsigned seen = 0u;
@@ -380,12 +384,15 @@ int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* tw
     return seen != 0u ? 1 : 0;
 }
 
-// Time [us] of `reps` dependent empty launches on stream a, with as many on stream b (nullptr: none) enqueued in between; < 0: HIP error
+#ifndef SSFM_LANE_PROBE_RATIO
+#define SSFM_LANE_PROBE_RATIO 2.0f
+#endif
+// Time [us] of `reps` dependent launches of a 3 us kernel on stream a, with as many on stream b (nullptr: none) enqueued in between; < 0: HIP error
 float lane_chain_us(hipStream_t a, hipStream_t b, int reps, hipEvent_t e0, hipEvent_t e1) {
     if (hipEventRecord(e0, a) != hipSuccess) return -1.f;
     for (int i = 0; i < reps; ++i) {
-        hipLaunchKernelGGL(k_queue_probe_nop, dim3(1), dim3(1), 0, a);
-        if (b) hipLaunchKernelGGL(k_queue_probe_nop, dim3(1), dim3(1), 0, b);
+        hipLaunchKernelGGL(k_queue_probe_spin, dim3(1), dim3(1), 0, a, 300ll);
+        if (b) hipLaunchKernelGGL(k_queue_probe_spin, dim3(1), dim3(1), 0, b, 300ll);
     }
     if (hipGetLastError() != hipSuccess || hipEventRecord(e1, a) != hipSuccess) return -1.f;
     if (hipStreamSynchronize(a) != hipSuccess || (b && hipStreamSynchronize(b) != hipSuccess)) return -1.f;
@@ -682,8 +689,9 @@ template <typename T> struct PlanT : PlanBase {
             // ... and queues of their own that still get in each other's way.  Seen with a fresh two-lane plan beside exactly one other used stream
             // (tools/attic/lane_speed_probe.py, profiles/r04_order_dependence.txt): the side-by-side probe passes, the run takes 28-31 us per step
             // (65-70 at worst) instead of 11.3 -- which hardware queue a stream gets decides it (the fourth one made in the class, by the runtime's
-            // log).  Measured: sixteen dependent empty launches on lane 0 take 29.5 us alone and 31-45 us with as many on the other lane in
-            // between; 64-480 us in the bad state.  A lane is good when the best of three such measurements stays within 1.7 x the best alone.
+            // log).  What tells the states apart: sixteen dependent launches of a kernel that takes 3 us on lane 0 take 62 us alone and 75-87 us with
+            // as many on the other lane enqueued in between; 300-440 us in the bad state.  (Empty kernels do not separate them: 31-71 against 64-480.)
+            // A lane is good when the better of two such measurements stays within 2 x the better alone (good states measured: 1.2-1.7 x; bad: 3.8-7 x).
             // 0 = good, 1 = on a queue of its own but in the way (score = the ratio), 2 = shares a queue with an earlier lane, < 0: HIP error
             auto rate = [&](int g, hipStream_t cand, float* score) -> int {
                 *score = 1e30f;
@@ -693,13 +701,16 @@ template <typename T> struct PlanT : PlanBase {
                     if (side == 0) return 2;
                 }
                 float solo = 1e30f, both = 1e30f;
-                for (int r = 0; r < 3; ++r) {
+                for (int r = 0; r < 2; ++r) {
                     const float s1 = lane_chain_us(lane_stream[0], nullptr, 16, e0, e1), b1 = lane_chain_us(lane_stream[0], cand, 16, e0, e1);
                     if (s1 < 0.f || b1 < 0.f) return -1;
                     solo = s1 < solo ? s1 : solo; both = b1 < both ? b1 : both;
                 }
                 *score = both / solo;
-                return *score > 1.7f ? 1 : 0;
+#ifdef SSFM_LANE_PROBE_DEBUG
+                std::fprintf(stderr, "lane probe: lane %d: alone %.1f us, with the other lane %.1f us\n", g, solo, both);
+#endif
+                return *score > SSFM_LANE_PROBE_RATIO ? 1 : 0;
             };
             for (int g = 1; g < nlanes; ++g) {
                 float score = 0.f;
