@@ -691,7 +691,7 @@ template <typename T> struct PlanT : PlanBase {
             // (65-70 at worst) instead of 11.3 -- which hardware queue a stream gets decides it (the fourth one made in the class, by the runtime's
             // log).  What tells the states apart: sixteen dependent launches of a kernel that takes 3 us on lane 0 take 62 us alone and 75-87 us with
             // as many on the other lane enqueued in between; 300-440 us in the bad state.  (Empty kernels do not separate them: 31-71 against 64-480.)
-            // A lane is good when the better of two such measurements stays within 2 x the better alone (good states measured: 1.2-1.7 x; bad: 3.8-7 x).
+            // A lane is good when the worse of two such measurements stays within 2 x the better alone (good states measured: 1.2-1.7 x; bad: 3.8-7 x).
             // 0 = good, 1 = on a queue of its own but in the way (score = the ratio), 2 = shares a queue with an earlier lane, < 0: HIP error
             auto rate = [&](int g, hipStream_t cand, float* score) -> int {
                 *score = 1e30f;
@@ -700,11 +700,11 @@ template <typename T> struct PlanT : PlanBase {
                     if (side < 0) return -1;
                     if (side == 0) return 2;
                 }
-                float solo = 1e30f, both = 1e30f;
-                for (int r = 0; r < 2; ++r) {
+                float solo = 1e30f, both = 0.f;
+                for (int r = 0; r < 2; ++r) {       // (the slow state is erratic -- one of its readings may look good: the WORSE of two, against the better alone)
                     const float s1 = lane_chain_us(lane_stream[0], nullptr, 16, e0, e1), b1 = lane_chain_us(lane_stream[0], cand, 16, e0, e1);
                     if (s1 < 0.f || b1 < 0.f) return -1;
-                    solo = s1 < solo ? s1 : solo; both = b1 < both ? b1 : both;
+                    solo = s1 < solo ? s1 : solo; both = b1 > both ? b1 : both;
                 }
                 *score = both / solo;
 #ifdef SSFM_LANE_PROBE_DEBUG
