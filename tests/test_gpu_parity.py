@@ -2612,16 +2612,28 @@ def test_adaptive_capture_goes_to_the_host_in_blocks_and_api_order():
 
 
 def test_one_launch_adaptive_run_of_any_length_gives_up_cleanly(monkeypatch):
-    """With no patience for the other row's maximum the one-launch adaptive engine of n <= 2048 stores nothing and the run is queued step by step.
-    (The knob is read when a plan is made: the cached plans -- the 512-point x 2 lines of this length, complex64 and complex128, may be among them,
-    made with patience -- are released first.)"""
+    """With no patience for the other row's maximum the one-launch adaptive engine of n <= 2048 stores nothing and the run is queued step by step: the
+    result is then the general path's, bit for bit.  (The knob is read when a plan is made: the cached plans are released first.  No patience means
+    that the first look must find the other row's word: when the two rows' workgroups happen to run in step it does, the engine finishes and the result
+    is the complex64 line's -- within the tolerance, not the same bits; the plan tells which happened, and a give-up must be seen within ten tries.)"""
     gv(**workloads.BENCH_GV)
-    oa.devices.release_plans()
     x = optical_signal(workloads.qpsk_field(1 << 11, seed=5, power_w=8e-3)[:, :200])
     kw = dict(length=8.0, phi_max=0.004, **workloads.SMF)
     monkeypatch.setenv("SSFM_FUSED_PATIENCE_TICKS", "-1")
-    monkeypatch.setenv("SSFM_CHIRP_SMALL", "0")
-    ref = oa.FIBER(x, **kw).signal
-    monkeypatch.setenv("SSFM_CHIRP_SMALL", "1")
-    y = oa.FIBER(x, **kw).signal
-    np.testing.assert_array_equal(y, ref)
+    gave_up = 0
+    for attempt in range(10):
+        oa.devices.release_plans()
+        monkeypatch.setenv("SSFM_CHIRP_SMALL", "0")
+        ref = oa.FIBER(x, **kw).signal
+        monkeypatch.setenv("SSFM_CHIRP_SMALL", "1")
+        y = oa.FIBER(x, **kw).signal
+        info = oa.devices.get_plan(512, 2, _lib.C64, 0).last_run_info()
+        if info["fell_back"]:
+            gave_up += 1
+            np.testing.assert_array_equal(y, ref)
+            break
+        if info["engine"] != "chirp_small_adaptive":       # the one-launch engine is off in this environment (the knob suite's SSFM_SMALL=0, SSFM_CHIRP_LOOP=python)
+            np.testing.assert_array_equal(y, ref)
+            return
+        assert relmax(y, ref) < TOL_100
+    assert gave_up == 1
