@@ -288,6 +288,12 @@ int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* i
  * (HOST).  Complex128 plans of 256 ... 4096 samples (SSFM_ERR_UNSUPPORTED otherwise, nothing launched).  Asynchronous on the plan's stream after
  * the schedule has been copied. */
 int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
+/* A whole FIXED-STEP chirp-z run on the plan's line (plans in the plain layout: complex128), four launches per step instead of ssfm_chirp_step's five: the
+ * chirp products on either side of a step cancel against the neighbouring steps', so the caller takes them once -- the line holds A c (zero from `keep` =
+ * the field's length up) when this is called and A c again when it returns; slots 0 and 1 hold the two convolutions' tables; mul[which[s]] (DEVICE, plan
+ * length entries each, at most 256 tables) = exp(D~ h_s) / keep below `keep`, zero above; hs (HOST): the nsteps step sizes.  Asynchronous on the plan's
+ * stream.  SSFM_ERR_UNSUPPORTED: a plan in the 16-byte-unit layout (nothing launched).  ssfm_chirp_propagate uses it for schedules of up to four sizes. */
+int ssfm_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep);
 /* The same on a complex64 plan of 2^13 ... 2^17 points whose rows fit the one-XCD engine (2^17 points in all rows, at most 64 workgroups): lengths
  * 2048 < n <= plan length / 2 in ONE launch on one XCD -- four passes per step, the chirps of neighbouring steps cancel (k_medium_chirp) -- between two
  * pointwise launches.  A, chirp, Dt: complex64, DEVICE.  At most four distinct step sizes.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: no such
@@ -368,7 +374,7 @@ enum ssfm_engine {
     SSFM_ENGINE_MEDIUM_ADAPT = 7,      /* adaptive: one launch per run on one XCD */
     SSFM_ENGINE_CHIRP_SMALL = 8,       /* any length <= 2048: fixed step, one launch per run */
     SSFM_ENGINE_CHIRP_SMALL_ADAPT = 9, /* any length <= 2048: adaptive, one launch per run */
-    SSFM_ENGINE_CHIRP_STEPS = 10,      /* any length: five launches per step (seven adaptive) */
+    SSFM_ENGINE_CHIRP_STEPS = 10,      /* any length: four launches per fixed step (five through ssfm_chirp_step), seven adaptive */
     SSFM_ENGINE_CHIRP_MEDIUM = 11,     /* any length, 2048 < n <= 65536, complex64: fixed step, one launch per run on one XCD */
     SSFM_ENGINE_CHIRP_MEDIUM_ADAPT = 12 /* ... adaptive */
 };

@@ -74,6 +74,7 @@ SYMBOLS = {
     "ssfm_chirp_post": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D, _VP]),
     "ssfm_chirp_step": (_I, [_VP, _VP, _VP]),                       # (plan, mul_dev, const ssfm_chirp_io*)
     "ssfm_chirp_small": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
+    "ssfm_chirp_line_run": (_I, [_VP, C.POINTER(_VP), C.POINTER(C.c_ubyte), C.POINTER(_D), _I64, _D, _I64]),
     "ssfm_chirp_medium": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
     "ssfm_chirp_medium_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_chirp_small_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),

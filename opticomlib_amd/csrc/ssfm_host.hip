@@ -55,7 +55,8 @@ template <typename T, int MODE, int N1, int E>
 hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     constexpr int C = cols_per_tile<T>();
     constexpr bool U16 = u16_layout<T>(N1, C, E);          // the field layout between the kernels (ssfm_kernels.hpp "U16")
-    if constexpr (!U16 && MODE > TM_END && MODE != TM_MID_A) return hipErrorInvalidValue;      // (tile-private time-domain modes: U16 plans only)
+    if constexpr (!U16 && MODE > TM_END && MODE != TM_MID_A && MODE != TM_MID_L) return hipErrorInvalidValue;      // (tile-private time-domain modes: U16 plans only)
+    else if constexpr (U16 && MODE == TM_MID_L) return hipErrorInvalidValue;                    // (as a launch of its own: plans in the plain layout)
     else if constexpr (MODE == TM_MID_A && N1 != 128 && N1 != 256) return hipErrorInvalidValue;   // (the fused adaptive kernel: plans of 2^14 ... 2^18 samples)
     else {
     constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
@@ -1714,6 +1715,38 @@ template <typename T> struct PlanT : PlanBase {
         last_launches += 5;
         return SSFM_OK;
     }
+    // A fixed-step chirp-z run on the plan's line (plain layout), the field already there as A c, zero from `keep` up: the chirps on either side of a step
+    // cancel against the neighbouring steps' (c conj(c) = 1; a rotation commutes with them), so a step is FOUR launches -- row pass (slot 0), column
+    // pass with the table product (TM_MID_L, mul[which[s]]: exp(D~ h) / n below keep, zero above), row pass (slot 1), column pass with the second half
+    // rotation of this step and the first of the next in one (the padding set to zero first) -- instead of the five of ssfm_chirp_step; the caller
+    // multiplies by conj(c) when the run is over.
+    int chirp_line_run(const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma_d, int64_t keep) {
+        if (!xfer_tab[0] || !xfer_tab[1]) return fail(SSFM_ERR_STATE, "ssfm_chirp_line_run: slots 0 and 1 must hold tables");
+        if (u16) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_line_run: not for plans in the 16-byte-unit layout");
+        if (!mul || !which || !hs || nsteps < 1 || keep < 2 || keep > n) return fail(SSFM_ERR_INVALID, "ssfm_chirp_line_run: bad arguments");
+        if (int rc = use_device()) return rc;
+        const T gamma = (T)gamma_d, half = (T)0.5;
+        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, (T)0, (T)hs[0] * half, nullptr), E)));
+        for (int64_t s = 0; s < nsteps; ++s) {
+            HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[0], 0, nullptr), Ef)));
+            TimeArgs<T> tl = targs((T)0, (T)0, (T)0, nullptr);
+            tl.mul = static_cast<const cx<T>*>(mul[which[s]]);
+            if (!tl.mul) return fail(SSFM_ERR_INVALID, "ssfm_chirp_line_run: step %lld has no table", (long long)s);
+            HIP_TRY((launch_time<T, TM_MID_L>(N1, batch, stream, tl, E)));
+            HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[1], 0, nullptr), Ef)));
+            if (s + 1 < nsteps) {
+                TimeArgs<T> tm = targs(gamma, (T)hs[s] * half, (T)hs[s + 1] * half, nullptr);
+                tm.keep = (int)keep;
+                HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, tm, E)));
+            } else {
+                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, (T)hs[s] * half, (T)0, nullptr), E)));
+            }
+        }
+        last_launches += 1 + 4 * nsteps;
+        last_engine = SSFM_ENGINE_CHIRP_STEPS;
+        last_fell_back = 0;
+        return SSFM_OK;
+    }
     // A fixed-step chirp-z run of a field of nn <= n / 2 samples per row in ONE launch (k_small_chirp); SSFM_ERR_UNSUPPORTED (nothing launched) when the
     // plan is not a complex128 plan of the one-workgroup-per-row engine.
     int chirp_small(void* A, const void* chirp, const void* Dt, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
@@ -2222,6 +2255,9 @@ int ssfm_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const vo
 int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* io) {
     if (!io) return fail(SSFM_ERR_INVALID, "ssfm_chirp_step: NULL field description");
     WITH_PLAN(plan, P_->apply_tables_mul(mul_dev, io));
+}
+int ssfm_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep) {
+    WITH_PLAN(plan, P_->chirp_line_run(mul, which, hs, nsteps, gamma, keep));
 }
 int ssfm_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
     WITH_PLAN(plan, P_->chirp_medium(A, chirp, Dt, n, gamma, hs, nsteps));

@@ -666,8 +666,8 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
     constexpr bool INV = tm_inverse(MODE), FWD = tm_forward(MODE);
-    static_assert(U16 || MODE <= TM_END || MODE == TM_MID_A, "the tile-private time-domain modes exist for the U16 layout only");
-    static_assert(MODE != TM_MID_L || PK, "TM_MID_L is a pass of the one-launch engines");
+    static_assert(U16 || MODE <= TM_END || MODE == TM_MID_A || MODE == TM_MID_L, "the tile-private time-domain modes exist for the U16 layout only");
+    static_assert(MODE != TM_MID_L || PK || !U16, "TM_MID_L: a pass of the one-launch engines, or a launch of its own on a plan in the plain layout");
     T hh_prev = a.hh_prev, hh_next = a.hh_next;
     const int tid = threadIdx.x;
     SSFM_TRACE_BEGIN(a);
@@ -918,7 +918,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         if constexpr (LATE_P) fft_line_hook<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw, load_pold);
         else if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
     }
-    if constexpr ((MODE == TM_MID || MODE == TM_MID_A) && PK) {
+    if constexpr (((MODE == TM_MID || MODE == TM_MID_A) && PK) || (MODE == TM_MID && !U16)) {
         if (a.keep > 0) {                // (chirp-z: what the convolution left in the line's padding is not part of the field -- nor of its maximum)
 #pragma unroll
             for (int t = 0; t < E; ++t)
@@ -1281,11 +1281,13 @@ template <typename T> struct TimeArgsCold {
     StepState<T>* s_out;
     const cx<T>* mul;
     T* pkeep;
+    int keep;
     ChirpIO<T> cz;
     SSFM_TRACE_ARGS
 };
 template <typename T> __host__ __device__ inline TimeArgsCold<T> time_args_cold(const TimeArgs<T>& a) {
     TimeArgsCold<T> c;
+    c.keep = a.keep;
     c.F = a.F; c.twN = a.twN; c.st = a.st; c.zlog = a.zlog; c.step = a.step; c.derive = a.derive; c.s_in = a.s_in; c.s_out = a.s_out; c.mul = a.mul; c.pkeep = a.pkeep; c.cz = a.cz;
 #if SSFM_TRACE
     c.trace = a.trace; c.trace_slot = a.trace_slot;
@@ -1299,6 +1301,7 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(cx<T>* Y, T*
     TimeArgs<T> a;
     a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.gamma = gamma; a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = rows; a.Qf = Qf;
     a.F = c.F; a.twN = c.twN; a.st = c.st; a.zlog = c.zlog; a.step = c.step; a.derive = c.derive; a.s_in = c.s_in; a.s_out = c.s_out; a.mul = c.mul; a.pkeep = c.pkeep; a.cz = c.cz;
+    a.keep = c.keep;
 #if SSFM_TRACE
     a.trace = c.trace; a.trace_slot = c.trace_slot;
 #endif

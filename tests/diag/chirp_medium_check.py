@@ -24,7 +24,7 @@ def timed(x, reps, **kw):
 
 if __name__ == "__main__":
     gv(**workloads.BENCH_GV)
-    out = ["# n x rows | engine | err vs oracle complex64 (100 steps) | err vs float64 | us per step one-launch (1000 steps, wall) | us per step five-launch form || adaptive (20 km, phi_max 0.002): engine, steps, err vs oracle complex64, us per step one-launch | seven-launch form"]
+    out = ["# n x rows | engine | err vs oracle complex64 (100 steps) | err vs float64 | us per step one-launch (1000 steps, wall) | us per step on the general complex128 line (SSFM_MEDIUM=0: four launches per step; five -- 21.4 / 24.3 / 29.1 us at 3000 x 2 / 8176 x 2 / 32752 x 2 -- before ssfm_chirp_line_run) || adaptive (20 km, phi_max 0.002): engine, steps, err vs oracle complex64, us per step one-launch | seven-launch form"]
     for n, npol in ((3000, 2), (4095, 1), (8176, 2), (8176, 1), (15060, 2), (16383, 1), (32752, 2), (32752, 1), (40000, 1), (65536 - 3, 1)):
         a = workloads.qpsk_field(1 << 16, seed=n % 997, power_w=4e-3, n_pol=2)[:npol, :n]
         a = a[0] if npol == 1 else a
