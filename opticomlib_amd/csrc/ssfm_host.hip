@@ -362,7 +362,6 @@ __global__ void k_queue_probe_wait(unsigned* flag, unsigned* seen, long long pat
     *seen = v;
 }
 __global__ void k_queue_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ void k_queue_probe_nop() {}
 __global__ void k_queue_probe_spin(long long ticks) {            // a kernel that takes `ticks` of the 100 MHz clock, like a real one takes its microseconds
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
@@ -373,11 +372,8 @@ int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* tw
     if (hipMemsetAsync(words, 0, 2 * sizeof(unsigned), a) != hipSuccess) return -1;
     if (hipEventRecord(ev, a) != hipSuccess || hipStreamWaitEvent(b, ev, 0) != hipSuccess) return -1;
     hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(1), 0, a, words, words + 1, 20000ll);
-    // ... with a second kernel queued BEHIND the waiting one, as in a run (every launch of a lane waits for the lane's previous one): two hardware queues
-    // that are served by one pipe of the command processor pass the probe without it -- the pipe turns to b's queue when a's has nothing more to
-    // hand out -- but in a run the pipe sits on a's pending dependency and b's launches wait for it (a fresh two-lane plan beside exactly one other used
-    // stream: 28-31 us per step, 65-70 at worst, instead of 11.3; tools/attic/lane_speed_probe.py, profiles/r04_order_dependence.txt)
-    hipLaunchKernelGGL(k_queue_probe_nop, dim3(1), dim3(1), 0, a);
+    // (a second kernel queued behind the waiting one, as every launch of a run has one, does not change the verdict: tried for the slow state that
+    // lane_chain_us below is there for)
     hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(1), 0, b, words);
     if (hipGetLastError() != hipSuccess) return -1;
     if (hipMemcpyAsync(&seen, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, a) != hipSuccess) return -1;
@@ -1832,9 +1828,8 @@ template <typename T> struct PlanT : PlanBase {
         if (steps_out) *steps_out = out[0];
         return SSFM_OK;
     }
-    // A fixed-step chirp-z run of nn samples per row (2 nn - 1 <= n) on the line of a MEDIUM complex64 plan (2^13 ... 2^17 points) in one launch on one XCD
-    // (k_medium_chirp) between two pointwise launches.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: not such a plan, more than kMaxTables step
-    // sizes, or the launch's workgroups did not meet within the patience (the engine is then off for this plan).
+    // Can this plan run the one-launch chirp-z engine of 2048 < nn <= n / 2 samples (chirp_medium / chirp_medium_adapt below)?  If so, slots 0 and 1
+    // hold the two convolutions' transfer functions for that length when this returns.
     int chirp_medium_tables(int64_t nn) {
         if constexpr (sizeof(T) != 4) { (void)nn; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
         else {
@@ -1877,6 +1872,9 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
         }
     }
+    // A fixed-step chirp-z run of nn samples per row (2 nn - 1 <= n) on the line of a MEDIUM complex64 plan (2^13 ... 2^17 points) in one launch on one XCD
+    // (k_medium_chirp) between two pointwise launches.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: not such a plan, more than kMaxTables step
+    // sizes, or the launch's workgroups did not meet within the patience (the engine is then off for this plan).
     int chirp_medium(void* A_, const void* chirp_, const void* Dt_, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
         if constexpr (sizeof(T) != 4) { (void)A_; (void)chirp_; (void)Dt_; (void)nn; (void)gamma; (void)hs; (void)nsteps; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
         else {
