@@ -241,6 +241,9 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     double mtab_h = 0.0;
     bool mtab_set = false;
     (void)gM; (void)gN; (void)scale;
+    // (An adaptive step without the table launch -- the middle column launch forming exp(D~ h) itself from the control block's step size, six launches
+    // instead of seven -- was measured at the end of round 4 and is not faster: 32.4 / 36.7 / 41.5 against 30.5 / 36.8 / 41.3 us per step at 3000 x 2 /
+    // 15060 x 2 / 32752 x 2: sixteen float64 sincos + exp per thread weigh what the launch saved.)
     auto step = [&](double h, const ChirpCtl* ctl, unsigned long long* mb) -> int {
         if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
             hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
