@@ -547,6 +547,13 @@ def main():
             achieved = b_alg_launch / (avg_us * 1e-6) / 1e9
             gap_us = 1.35                                  # dependent-launch gap on a stream (profiles/r04_c2_stamps_and_trace.txt: 1.2-1.4 us; MI355X_MICROARCH.md "boundary")
             prof = committed_profile_figures(list(launch_us), rows_per_launch)
+            tpk = prof.get("traffic_per_kernel") or {}
+            if tpk and all(tpk.get(k) for k in launch_us):
+                # the step priced by the bytes it REALLY moves (PMC, committed profile): every lane runs one launch of each kernel per step
+                step_bytes = lanes * sum(tpk[k] for k in launch_us)
+                roofline["step_traffic"] = {"bytes_per_step": step_bytes, "rate_GBs": step_bytes / (period_us * 1e-6 * len(launch_us)) / 1e9,
+                                            "frac_of_peak": step_bytes / (period_us * 1e-6 * len(launch_us)) / 1e9 / HBM_PEAK_GBS,
+                                            "note": "PMC bytes per launch (read_from_profiles) x lanes x kernels per step / the measured step time (launch period x kernels per step)"}
             roofline.update({
                 "kernel": dom, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (prof.get("traffic_per_kernel") or {}).get(dom),
