@@ -1314,7 +1314,9 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(cx<T>* Y, T*
 // FM_PHASE: the operator table of a FIBRE (|exp(D~ h)| is the same number at every frequency: Re D~ = -alpha/2,
 // devices.py:1145) holds only the PHASE of every entry, as a 32-bit fraction of a turn (4 bytes per frequency instead of
 // 8: the table is 16 of the 96 bytes a dual-pol sample*step moves); the kernel forms amp * (cos, sin) itself.
-enum FreqMode { FM_TABLE = 0, FM_FLY = 1, FM_FWD_ONLY = 2, FM_PHASE = 3 };
+// (FM_FLY_IM: FM_FLY for an operator whose real part is the same number at every frequency -- a fibre's -alpha/2 -- with `tab` holding the IMAGINARY
+// parts only, four per 16 bytes in FM_PHASE's order, and `amp` the real part: half the operator's bytes, the same arithmetic)
+enum FreqMode { FM_TABLE = 0, FM_FLY = 1, FM_FWD_ONLY = 2, FM_PHASE = 3, FM_FLY_IM = 4 };
 
 template <typename T> struct FreqArgs {
     cx<T>* F;
@@ -1409,6 +1411,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
 
     T h = a.h;
+    constexpr bool FLY = MODE == FM_FLY || MODE == FM_FLY_IM;
     SSFM_TRACE_BEGIN(a);
     const int tid = threadIdx.x;
     const int j = tid % Q;
@@ -1466,8 +1469,19 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         }
     };
     // (the same for the operator itself where the kernel forms exp(D~ h): adaptive runs.  Only with 16-byte elements... of either precision)
-    constexpr bool EARLY_FLY = HEAD && SSFM_EARLY_PHASE != 0 && MODE == FM_FLY;
+    constexpr bool EARLY_FLY = HEAD && SSFM_EARLY_PHASE != 0 && FLY;
     auto load_table = [&]() {
+        if constexpr (MODE == FM_FLY_IM) {
+            static_assert(MODE != FM_FLY_IM || E % 4 == 0, "four imaginary parts per load");
+            typedef T i4_t __attribute__((ext_vector_type(4)));
+            const i4_t* __restrict__ I4 = reinterpret_cast<const i4_t*>(reinterpret_cast<const T*>(a.tab) + (long long)k1 * N2) + j;
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+                const i4_t q = I4[g * Q];
+                m[4 * g] = mk<T>(a.amp, q.x); m[4 * g + 1] = mk<T>(a.amp, q.y); m[4 * g + 2] = mk<T>(a.amp, q.z); m[4 * g + 3] = mk<T>(a.amp, q.w);
+            }
+            return;
+        }
         typedef T m4_t __attribute__((ext_vector_type(4)));
         const m4_t* __restrict__ T4 = reinterpret_cast<const m4_t*>(trow) + j;
 #pragma unroll
@@ -1510,7 +1524,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     } else if (MODE != FM_FWD_ONLY) {
         if constexpr (!EARLY_FLY) load_table();
     }
-    if (MODE == FM_FLY && a.st != nullptr) {
+    if (FLY && a.st != nullptr) {
         // (read after the row and the operator have been asked for: the state was written by the previous launch, a ~2 us miss)
         const StepState<T> S = a.st->cur[a.step & 1];
         if (S.done || a.st->error != 0u) return;             // (error: see k_time<TM_MID_A>)
@@ -1556,7 +1570,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         return;
     }
     SSFM_STAMP(3);
-    if (MODE == FM_FLY && !EARLY_FLY) fly();
+    if (FLY && !EARLY_FLY) fly();
     if (MODE == FM_PHASE && !EARLY_PHASE) phase_factors();
 #pragma unroll
     for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
@@ -2587,6 +2601,15 @@ __global__ void k_make_freq_table(const cx<T>* __restrict__ src, cx<T>* __restri
         d.y = (e * (T)s) * inv_n;
     }
     out[k1 * N2 + freq_tab_pos(k2, Q)] = d;
+}
+// the operator's imaginary parts alone (FM_FLY_IM): out[k1*N2 + freq_phase_pos(k2)] = Im(src[k1 + N1*k2])
+template <typename T>
+__global__ void k_make_imag_table(const cx<T>* __restrict__ src, T* __restrict__ out, int N1, int N2, int Q) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long N = (long long)N1 * N2;
+    if (o >= N) return;
+    const long long k1 = o / N2, k2 = o % N2;
+    out[k1 * N2 + freq_phase_pos(k2, Q)] = src[k1 + (long long)N1 * k2].y;
 }
 // phase table of exp(D~ h) (FM_PHASE): out[k1*N2 + freq_phase_pos(k2)] = round(frac(Im(src[k1 + N1*k2]) * h / 2 pi) * 2^32),
 // the product in T exactly as the reference forms it (complex64 * float32), the rest in double
