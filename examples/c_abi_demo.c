@@ -90,10 +90,10 @@ int main(void) {
     const int adaptive_ok = taken > 1 && fabs(z[taken] - 20.0) < 1e-4 && fabs(energy(back, n) / e_in - exp(-(double)alpha * 20.0)) < 1e-3;
     free(z);
     /* which engine the run took, and whether a single-launch engine had to give way to its fallback (a shared GPU, a profiler) */
-    int engine = 0, fell_back = 0, share = 0;
-    int64_t fallbacks = 0;
-    CHECK(ssfm_last_run_info(plan, &engine, &fell_back, &fallbacks, &share));
-    printf("last run: engine %d, fell back %d, fallbacks of this plan %lld, lanes share a queue %d\n", engine, fell_back, (long long)fallbacks, share);
+    ssfm_run_info info;
+    CHECK(ssfm_last_run_info(plan, &info, sizeof(info)));
+    printf("last run: engine %d, fell back %d, fallbacks of this plan %lld, lanes %d (share a queue %d, remade %d)\n", info.engine, info.fell_back,
+           (long long)info.fallbacks_total, info.lanes, info.lanes_share_queue, info.lanes_remade);
     CHECK(ssfm_plan_destroy(plan));
 
     /* PRBS-7 from the all-ones state: the reference's first 20 bits (tests/devices_test.py:52-71) */

@@ -55,9 +55,10 @@ int main() {
     if (hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(float) * got.size(), 0) != hipSuccess) return 2;
     if (hipMemcpyAsync(pinned, dev, sizeof(float) * got.size(), hipMemcpyDeviceToHost, stream) != hipSuccess) return 2;   // the consumer's work
     if (hipStreamSynchronize(stream) != hipSuccess) return 2;                                                            // ... and its own wait
-    int engine = 0, fell_back = 0, share = 0;
-    int64_t fallbacks = 0;
-    CHECK(ssfm_last_run_info(plan, &engine, &fell_back, &fallbacks, &share));
+    ssfm_run_info info;
+    CHECK(ssfm_last_run_info(plan, &info, sizeof(info)));
+    const int engine = info.engine, fell_back = info.fell_back;
+    const int64_t fallbacks = info.fallbacks_total;
     const bool same = std::memcmp(pinned, want.data(), sizeof(float) * got.size()) == 0;
     std::printf("engine %d fell_back %d fallbacks %lld; stream-ordered copy %s the two-kernel result\n", engine, fell_back, (long long)fallbacks,
                 same ? "equals" : "DIFFERS FROM");

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SSFM_ABI_VERSION 2
+#define SSFM_ABI_VERSION 3
 
 enum ssfm_status {
     SSFM_OK = 0,
@@ -359,10 +359,20 @@ void* ssfm_stream(ssfm_plan* plan);
  *   engine            a value of enum ssfm_engine below: the engine that produced the result of the LAST run (after a fallback: the fallback)
  *   fell_back         1: the last run was started on a single-launch engine, gave up and was repeated
  *   fallbacks_total   such repeats over the life of the plan (a plan keeps to the fallback engine after the first)
- *   lanes_share_queue 1: the plan's lanes could not be given hardware queues on which they run side by side at full rate (ssfm_plan_create probes
- *                     its lane streams and tries eight replacement streams; more than four high-priority streams alive): fixed-step lanes then
- *                     run one after the other, or slower than that
- * Any pointer may be NULL.  For a run whose fallback is resolved lazily (see ssfm_field_device_ptr) call ssfm_synchronize first. */
+ *   lanes             lanes the plan's fixed-step runs drive now: ssfm_num_lanes, or 1 once the plan has dropped its second lane (below)
+ *   lanes_share_queue 1: a lane's stream shares a hardware queue with an earlier lane's and no replacement stream did better (more than four
+ *                     high-priority streams alive): the lanes' kernels run one after the other
+ *   lanes_remade      lane streams replaced at RUN time.  Which hardware queue the runtime gives a stream decides whether a lane's kernels run beside
+ *                     the other lane's at full rate or 3-6 x slower (profiles/r04_order_dependence.txt); ssfm_plan_create rates every lane with the
+ *                     plan's own two kernels (launch period with the other lane running / alone, `lane_score`; good <= 1.6) and replaces a stream
+ *                     that is not good, and every fixed-step run of >= 64 steps on two lanes is looked at afterwards: a launch period
+ *                     (`lane_last_us`) beyond 1.8 x the best the plan has seen (`lane_pair_us`) has the lanes rated again, on scratch fields,
+ *                     and repaired before the next run is enqueued
+ *   lanes_dropped     1: two repairs in a row found no good stream and the plan runs both rows in one launch on one stream from now on
+ *   lane_heals        times a slow run made the plan rate its lanes again (at most 8 over a plan's life)
+ *   lane_alone_us / lane_pair_us / lane_last_us / lane_score   the figures above [us per launch of a lane]; 0 = not measured (one-lane plans)
+ * `info_bytes` = sizeof(ssfm_run_info) of the caller's header (a later library fills as much as the caller knows).  For a run whose fallback is
+ * resolved lazily (see ssfm_field_device_ptr) call ssfm_synchronize first. */
 enum ssfm_engine {
     SSFM_ENGINE_NONE = 0,
     SSFM_ENGINE_TWO_KERNEL = 1,        /* fixed step: two launches per step (k_time, k_freq), one stream per lane */
@@ -378,7 +388,25 @@ enum ssfm_engine {
     SSFM_ENGINE_CHIRP_MEDIUM = 11,     /* any length, 2048 < n <= 65536, complex64: fixed step, one launch per run on one XCD */
     SSFM_ENGINE_CHIRP_MEDIUM_ADAPT = 12 /* ... adaptive */
 };
-int ssfm_last_run_info(ssfm_plan* plan, int* engine, int* fell_back, int64_t* fallbacks_total, int* lanes_share_queue);
+typedef struct ssfm_run_info {
+    int engine;
+    int fell_back;
+    int64_t fallbacks_total;
+    int lanes;
+    int lanes_share_queue;
+    int lanes_remade;
+    int lanes_dropped;
+    int lane_heals;
+    float lane_alone_us;
+    float lane_pair_us;
+    float lane_last_us;
+    float lane_score;
+} ssfm_run_info;
+int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes);
+/* Test hook of the lane health check: mode 1 makes the plan believe a four times better launch period than it has seen (the next long two-lane run looks
+ * slow and the lanes are rated again), mode 2 additionally makes every rating come out bad (the repair fails; the second failure drops the plan to one
+ * lane), 0 back to normal. */
+int ssfm_debug_lane_fault(ssfm_plan* plan, int mode);
 
 /* A device buffer of at least `bytes` bytes owned by the plan (slot 0 ... 3; grows on demand, freed with the plan; contents undefined between
  * calls; a growing call waits for the plan's stream).  For driver loops above this ABI that need scratch memory per call

@@ -83,7 +83,8 @@ SYMBOLS = {
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
     "ssfm_last_propagate_ms": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(_I64)]),
-    "ssfm_last_run_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I64), C.POINTER(_I)]),
+    "ssfm_last_run_info": (_I, [_VP, _VP, C.c_size_t]),
+    "ssfm_debug_lane_fault": (_I, [_VP, _I]),
     "ssfm_plan_workspace": (_I, [_VP, _I, C.c_size_t, C.POINTER(_VP)]),
     "ssfm_set_profiling": (_I, [_VP, _I]),
     "ssfm_kernel_times": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
@@ -107,6 +108,13 @@ ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adap
            "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium", "chirp_medium_adaptive")
 
 
+class RunInfo(C.Structure):
+    """``ssfm_run_info`` of include/ssfm_amd.h."""
+    _fields_ = [("engine", C.c_int), ("fell_back", C.c_int), ("fallbacks_total", C.c_int64), ("lanes", C.c_int), ("lanes_share_queue", C.c_int),
+                ("lanes_remade", C.c_int), ("lanes_dropped", C.c_int), ("lane_heals", C.c_int), ("lane_alone_us", C.c_float), ("lane_pair_us", C.c_float),
+                ("lane_last_us", C.c_float), ("lane_score", C.c_float)]
+
+
 class SsfmError(RuntimeError):
     """A call into the HIP library failed (or the library itself is missing)."""
 
@@ -128,8 +136,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.ssfm_abi_version() != 2:
-        raise SsfmError(f"ABI version mismatch: library reports {lib.ssfm_abi_version()}, binding expects 2")
+    if lib.ssfm_abi_version() != 3:
+        raise SsfmError(f"ABI version mismatch: library reports {lib.ssfm_abi_version()}, binding expects 3")
     _lib = lib
     return lib
 
@@ -766,10 +774,16 @@ class Plan:
         and whether the plan's lanes share a hardware queue (include/ssfm_amd.h ``ssfm_last_run_info``).  Synchronises first: a one-launch
         run of a medium plan knows at its end whether its workgroups met."""
         _check(load().ssfm_synchronize(self._h), "ssfm_synchronize")
-        e, f, t, q = _I(0), _I(0), _I64(0), _I(0)
-        _check(load().ssfm_last_run_info(self._h, C.byref(e), C.byref(f), C.byref(t), C.byref(q)), "ssfm_last_run_info")
-        return {"engine": ENGINES[e.value] if 0 <= e.value < len(ENGINES) else str(e.value), "fell_back": bool(f.value),
-                "fallbacks_total": int(t.value), "lanes_share_queue": bool(q.value)}
+        r = RunInfo()
+        _check(load().ssfm_last_run_info(self._h, C.byref(r), C.sizeof(r)), "ssfm_last_run_info")
+        return {"engine": ENGINES[r.engine] if 0 <= r.engine < len(ENGINES) else str(r.engine), "fell_back": bool(r.fell_back),
+                "fallbacks_total": int(r.fallbacks_total), "lanes": int(r.lanes), "lanes_share_queue": bool(r.lanes_share_queue),
+                "lanes_remade": int(r.lanes_remade), "lanes_dropped": bool(r.lanes_dropped), "lane_heals": int(r.lane_heals), "lane_alone_us": float(r.lane_alone_us),
+                "lane_pair_us": float(r.lane_pair_us), "lane_last_us": float(r.lane_last_us), "lane_score": float(r.lane_score)}
+
+    def lane_fault(self, mode: int):
+        """Test hook of the lane health check (include/ssfm_amd.h ``ssfm_debug_lane_fault``)."""
+        _check(load().ssfm_debug_lane_fault(self._h, int(mode)), "ssfm_debug_lane_fault")
 
     def last_propagate_ms(self):
         ms, n = C.c_float(0), _I64(0)

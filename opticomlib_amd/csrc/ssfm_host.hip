@@ -381,22 +381,14 @@ int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* tw
     return seen != 0u ? 1 : 0;
 }
 
-#ifndef SSFM_LANE_PROBE_RATIO
-#define SSFM_LANE_PROBE_RATIO 2.0f
-#endif
-// Time [us] of `reps` dependent launches of a 3 us kernel on stream a, with as many on stream b (nullptr: none) enqueued in between; < 0: HIP error
-float lane_chain_us(hipStream_t a, hipStream_t b, int reps, hipEvent_t e0, hipEvent_t e1) {
-    if (hipEventRecord(e0, a) != hipSuccess) return -1.f;
-    for (int i = 0; i < reps; ++i) {
-        hipLaunchKernelGGL(k_queue_probe_spin, dim3(1), dim3(1), 0, a, 300ll);
-        if (b) hipLaunchKernelGGL(k_queue_probe_spin, dim3(1), dim3(1), 0, b, 300ll);
-    }
-    if (hipGetLastError() != hipSuccess || hipEventRecord(e1, a) != hipSuccess) return -1.f;
-    if (hipStreamSynchronize(a) != hipSuccess || (b && hipStreamSynchronize(b) != hipSuccess)) return -1.f;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
-    return ms * 1e3f;
-}
+// A lane is good when its launches run beside the other lane's at (nearly) the rate they run alone: the launch period of the plan's OWN kernels with both lanes
+// running within kLaneGoodRatio x the period of lane 0 alone (healthy plans measure 1.15-1.3 x, the slow states of profiles/r04_order_dependence.txt 2.3-6 x,
+// lanes that share a hardware queue 2 x).  At run time a fixed-step run whose own launch period exceeds kLaneSlowRatio x the best period the plan has seen
+// has its lanes rated again (PlanT::lane_health).
+constexpr float kLaneGoodRatio = 1.6f;
+constexpr float kLaneSlowRatio = 1.8f;
+constexpr int kLaneProbeSteps = 12;
+constexpr int kLaneHealsMax = 8;
 
 // ----------------------------------------------------------------------------- plan
 struct PlanBase {
@@ -480,6 +472,20 @@ template <typename T> struct PlanT : PlanBase {
     int last_fell_back = 0;
     int64_t fallbacks = 0;
     bool lanes_share_queue = false;    // the plan's lanes could not be given hardware queues of their own (see streams_run_side_by_side)
+    // ---- lane health (round 5; rate_lane / lane_health / heal_lanes below)
+    int lanes_active = 1;              // lanes a fixed-step run really drives: nlanes, or 1 once a plan that could not be healed has dropped to one lane
+    int lanes_remade = 0;              // lane streams replaced at RUN time (a run came out slow, the lanes were rated again and one was not good)
+    int lanes_dropped = 0;             // 1: the plan gave up its second lane (two healing attempts in a row found no good stream)
+    int lane_heals = 0, lane_strikes = 0;
+    int lane_fault = 0;                // test hook (ssfm_debug_lane_fault): 2 = every rating comes out "in the way"
+    float lane_alone_us = 0.f;         // launch period of lane 0's chain alone on the chip (the plan's own kernels; last rating)
+    float lane_pair_us = 0.f;          // best launch period seen with all lanes running: the last rating's, or a real run's
+    float lane_last_us = 0.f;          // launch period of the last checked fixed-step run (device time / launches per lane)
+    float lane_score = 0.f;            // last rating: period with the other lane / period alone
+    bool lane_check_pending = false;   // the last run was a two-lane run of >= 64 steps whose period has not been looked at yet
+    int64_t lane_check_launches = 0;
+    hipEvent_t lane_e0 = nullptr, lane_e1 = nullptr;      // brackets of a rating measurement
+    hipEvent_t run_e0 = nullptr, run_e1 = nullptr;        // brackets of the last run that lane_health looks at (its own pair: ev0 / ev1 are re-recorded by every entry point)
     // A caller that has asked for ssfm_stream() or ssfm_field_device_ptr() may order its own work behind a run without ssfm_synchronize(): for it a
     // run of the one-launch engine of medium plans is resolved (waited for, checked, repeated on the two-kernel engine if need be) before
     // ssfm_propagate_fixed returns
@@ -609,6 +615,10 @@ template <typename T> struct PlanT : PlanBase {
             if (lane_stream[g]) (void)hipStreamDestroy(lane_stream[g]);
         }
         if (fork_ev) (void)hipEventDestroy(fork_ev);
+        if (lane_e0) (void)hipEventDestroy(lane_e0);
+        if (lane_e1) (void)hipEventDestroy(lane_e1);
+        if (run_e0) (void)hipEventDestroy(run_e0);
+        if (run_e1) (void)hipEventDestroy(run_e1);
         for (auto& p : prof) {
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
             p.ev.clear();
@@ -677,66 +687,7 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, prio_hi));
             HIP_TRY(hipEventCreateWithFlags(&lane_ev[g], hipEventDisableTiming));
         }
-        if (nlanes > 1 && nlanes <= 4) {
-            // every lane on a hardware queue of its own: a stream that shares its queue with an earlier lane of this plan is replaced (the runtime
-            // picks the least used queue of the class for a new stream, so the replacement is made BEFORE the old stream is destroyed)
-            unsigned* words = nullptr;
-            HIP_TRY(hipMalloc(&words, 2 * sizeof(unsigned)));
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            // ... and queues of their own that still get in each other's way.  Seen with a fresh two-lane plan beside exactly one other used stream
-            // (tools/attic/lane_speed_probe.py, profiles/r04_order_dependence.txt): the side-by-side probe passes, the run takes 28-31 us per step
-            // (65-70 at worst) instead of 11.3 -- which hardware queue a stream gets decides it (the fourth one made in the class, by the runtime's
-            // log).  What tells the states apart: sixteen dependent launches of a kernel that takes 3 us on lane 0 take 62 us alone and 75-87 us with
-            // as many on the other lane enqueued in between; 300-440 us in the bad state.  (Empty kernels do not separate them: 31-71 against 64-480.)
-            // A lane is good when the worse of two such measurements stays within 2 x the better alone (good states measured: 1.2-1.7 x; bad: 3.8-7 x).
-            // 0 = good, 1 = on a queue of its own but in the way (score = the ratio), 2 = shares a queue with an earlier lane, < 0: HIP error
-            auto rate = [&](int g, hipStream_t cand, float* score) -> int {
-                *score = 1e30f;
-                for (int k = 0; k < g; ++k) {
-                    const int side = streams_run_side_by_side(lane_stream[k], cand, words, fork_ev);
-                    if (side < 0) return -1;
-                    if (side == 0) return 2;
-                }
-                float solo = 1e30f, both = 0.f;
-                for (int r = 0; r < 2; ++r) {       // (the slow state is erratic -- one of its readings may look good: the WORSE of two, against the better alone)
-                    const float s1 = lane_chain_us(lane_stream[0], nullptr, 16, e0, e1), b1 = lane_chain_us(lane_stream[0], cand, 16, e0, e1);
-                    if (s1 < 0.f || b1 < 0.f) return -1;
-                    solo = s1 < solo ? s1 : solo; both = b1 > both ? b1 : both;
-                }
-                *score = both / solo;
-#ifdef SSFM_LANE_PROBE_DEBUG
-                std::fprintf(stderr, "lane probe: lane %d: alone %.1f us, with the other lane %.1f us\n", g, solo, both);
-#endif
-                return *score > SSFM_LANE_PROBE_RATIO ? 1 : 0;
-            };
-            for (int g = 1; g < nlanes; ++g) {
-                float score = 0.f;
-                int state = rate(g, lane_stream[g], &score);
-                // not good: candidates four at a time -- made together, so that the runtime's least-used rule spreads them over the class's hardware
-                // queues -- the first good one (else the best one) replaces the lane's stream, the rest go
-                for (int round = 0; round < 2 && state > 0; ++round) {
-                    hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
-                    for (auto& c : cand)
-                        if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prio_hi) != hipSuccess) c = nullptr;
-                    for (auto& c : cand) {
-                        if (!c || state == 0) continue;
-                        float sc = 0.f;
-                        const int st_c = rate(g, c, &sc);
-                        if (st_c >= 0 && (st_c < state || (st_c == state && sc < score))) {
-                            std::swap(c, lane_stream[g]);
-                            state = st_c; score = sc;
-                        }
-                    }
-                    for (auto& c : cand)
-                        if (c) (void)hipStreamDestroy(c);
-                }
-                if (state != 0) lanes_share_queue = true;
-            }
-            (void)hipFree(words);
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        }
+        lanes_active = nlanes;
         const size_t cb = sizeof(cx<T>);
         HIP_TRY(hipMalloc(&F, cb * n * batch));
         HIP_TRY(hipMalloc(&P, sizeof(T) * n * batch));
@@ -783,6 +734,183 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipMemsetAsync(P, 0, sizeof(T) * n * batch, stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
+        if (nlanes > 1 && nlanes <= 4) {
+            // every lane on a hardware queue of its own, and one on which its kernels really run beside lane 0's (rate_lane): rated with the plan's own
+            // kernels on its own buffers, which hold nothing yet -- zeros (a transform of zeros is zeros; D~ = 0 is the identity)
+            HIP_TRY(hipEventCreate(&lane_e0));
+            HIP_TRY(hipEventCreate(&lane_e1));
+            HIP_TRY(hipEventCreate(&run_e0));
+            HIP_TRY(hipEventCreate(&run_e1));
+            HIP_TRY(hipMemsetAsync(F, 0, cb * n * batch, stream));
+            if (Y != F) HIP_TRY(hipMemsetAsync(Y, 0, cb * n * batch, stream));
+            HIP_TRY(hipMemsetAsync(dperm, 0, cb * n, stream));
+            if (dperm_fly) HIP_TRY(hipMemsetAsync(dperm_fly, 0, cb * n, stream));
+            bool replaced = false;
+            if (int rc = rate_and_replace_lanes(F, Y, P, &replaced)) return rc;
+            if (!lanes_ok) lane_strikes = 1;          // (no good stream to be had now: the first run that comes out slow and cannot be healed drops the second lane)
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return SSFM_OK;
+    }
+
+    // ---- lane health.  Which hardware queue the runtime gives a lane's stream decides whether its kernels run beside the other lane's at full rate, one
+    // after the other (a shared queue) or 3-6 x slower than that (profiles/r04_order_dependence.txt); nothing in the API says which.  Round 4 rated a
+    // stream at plan creation by a proxy (dependent launches of a 3 us spin kernel) and still met about one slow plan in 25-40 suite runs, silently.
+    // Round 5: (1) the rating is the real thing -- the launch period of the plan's OWN two kernels with both lanes running against lane 0 alone;
+    // (2) every fixed-step run of >= 64 steps is looked at afterwards (lane_health: its device time / launches per lane against the best period the
+    // plan has seen); a run beyond kLaneSlowRatio has the lanes rated again on scratch buffers, a lane that is not good gets another stream
+    // (`lanes_remade`), and a plan that two healing attempts in a row could not repair drops to one lane (`lanes_dropped`: both rows in one launch on
+    // the plan's stream -- slower than two good lanes, 2-4 x faster than two bad ones).  ssfm_last_run_info reports all of it.
+    //
+    // Launch period [us] of `steps` steps of the two-kernel engine (BEGIN, k_freq<FLY>, MID ... END) on the lanes of `mask`, on the buffers given (zeros).
+    // The lanes' queues are held by a spin kernel while the host enqueues, so that the host's enqueue rate is not part of the figure.
+    int measure_lanes(unsigned mask, int steps, cx<T>* Fx, cx<T>* Yx, T* Px, float* us) {
+        cx<T>* F0 = F; cx<T>* Y0 = Y; T* P0 = P;
+        F = Fx; Y = Yx; P = Px;
+        const int rows = batch / nlanes;
+        const T hh = (T)0.0625;
+        auto body = [&]() -> int {
+            hipLaunchKernelGGL(k_queue_probe_spin, dim3(1), dim3(1), 0, stream, (long long)(400 * (2 * steps + 1) * nlanes));       // (100 MHz ticks: 4 us per launch to come -- the host needs ~3)
+            HIP_TRY(hipEventRecord(fork_ev, stream));
+            HIP_TRY(hipEventRecord(lane_e0, stream));
+            for (int g = 1; g < nlanes; ++g)
+                if (mask & (1u << g)) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
+            for (int g = 0; g < nlanes; ++g)
+                if (mask & (1u << g)) HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs((T)1, 0, hh, nullptr, g * rows, g), E)));
+            for (int s_ = 0; s_ < steps; ++s_) {
+                for (int g = 0; g < nlanes; ++g)
+                    if (mask & (1u << g)) HIP_TRY((launch_freq<T, FM_FLY>(N2, N1 * rows, lane_stream[g], fargs_fly(2 * hh, nullptr, g * rows, g), Ef_fly)));
+                for (int g = 0; g < nlanes; ++g) {
+                    if (!(mask & (1u << g))) continue;
+                    if (s_ + 1 < steps) HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs((T)1, hh, hh, nullptr, g * rows, g), E)));
+                    else HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs((T)1, hh, 0, nullptr, g * rows, g), E)));
+                }
+            }
+            for (int g = 1; g < nlanes; ++g) {
+                if (!(mask & (1u << g))) continue;
+                HIP_TRY(hipEventRecord(lane_ev[g], lane_stream[g]));
+                HIP_TRY(hipStreamWaitEvent(stream, lane_ev[g], 0));
+            }
+            HIP_TRY(hipEventRecord(lane_e1, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, lane_e0, lane_e1));
+            *us = ms * 1e3f / (float)(2 * steps + 1);
+            return SSFM_OK;
+        };
+        const int rc = body();
+        F = F0; Y = Y0; P = P0;
+        return rc;
+    }
+    // 0 = good, 1 = on a queue of its own but in lane 0's way (score = the ratio), 2 = shares a hardware queue with an earlier lane; < 0: error (g_err set)
+    int rate_lane(int g, cx<T>* Fx, cx<T>* Yx, T* Px, float* score, float* alone_out, float* pair_out) {
+        *score = 1e30f;
+        unsigned* words = nullptr;
+        if (hipMalloc(&words, 2 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        int shared = 0;
+        for (int k = 0; k < g && !shared; ++k) {
+            const int side = streams_run_side_by_side(lane_stream[k], lane_stream[g], words, fork_ev);
+            if (side < 0) { (void)hipFree(words); return -1; }
+            shared = side == 0;
+        }
+        (void)hipFree(words);
+        if (shared) return 2;
+        float alone = 1e30f, pair = 0.f;
+        for (int r = 0; r < 2; ++r) {           // (the slow state is erratic -- one of its readings may look good: the WORSE of two, against the better alone)
+            float a1 = 0.f, p1 = 0.f;
+            if (measure_lanes(1u, kLaneProbeSteps, Fx, Yx, Px, &a1) != SSFM_OK) return -1;
+            if (measure_lanes(1u | (1u << g), kLaneProbeSteps, Fx, Yx, Px, &p1) != SSFM_OK) return -1;
+            alone = a1 < alone ? a1 : alone;
+            pair = p1 > pair ? p1 : pair;
+        }
+        *score = pair / alone;
+        *alone_out = alone; *pair_out = pair;
+#ifdef SSFM_LANE_PROBE_DEBUG
+        std::fprintf(stderr, "lane rating: lane %d: %.2f us per launch alone, %.2f with lane 0 beside it\n", g, alone, pair);
+#endif
+        if (lane_fault == 2) { *score = 9.f; return 1; }
+        return *score > kLaneGoodRatio ? 1 : 0;
+    }
+    // Rate every lane beyond the first; a lane that is not good tries replacement streams four at a time -- made together, so that the runtime's
+    // least-used rule spreads them over the class's hardware queues -- the first good one (else the best one) replaces the lane's stream, the rest go.
+    int rate_and_replace_lanes(cx<T>* Fx, cx<T>* Yx, T* Px, bool* replaced) {
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        *replaced = false;
+        bool all_good = true;
+        for (int g = 1; g < nlanes; ++g) {
+            float score = 0.f, alone = 0.f, pair = 0.f;
+            int state = rate_lane(g, Fx, Yx, Px, &score, &alone, &pair);
+            if (state < 0) return fail(SSFM_ERR_HIP, "lane rating failed: %s", hipGetErrorString(hipGetLastError()));
+            for (int round = 0; round < 2 && state > 0; ++round) {
+                hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (auto& c : cand)
+                    if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prio_hi) != hipSuccess) { (void)hipGetLastError(); c = nullptr; }
+                for (auto& c : cand) {
+                    if (!c || state == 0) continue;
+                    float sc = 0.f, al = 0.f, pr = 0.f;
+                    std::swap(c, lane_stream[g]);                       // (rated in the lane's place; swapped back unless it is better)
+                    const int st_c = rate_lane(g, Fx, Yx, Px, &sc, &al, &pr);
+                    if (st_c >= 0 && (st_c < state || (st_c == state && sc < score))) { state = st_c; score = sc; alone = al; pair = pr; *replaced = true; }
+                    else std::swap(c, lane_stream[g]);
+                }
+                for (auto& c : cand)
+                    if (c) (void)hipStreamDestroy(c);
+            }
+            if (state != 0) all_good = false;
+            if (state == 2) lanes_share_queue = true;
+            if (g == 1 || score > lane_score) lane_score = score;
+            if (state != 2) { lane_alone_us = alone; if (state == 0) lane_pair_us = pair; }
+        }
+        if (all_good) lanes_share_queue = false;
+        lanes_ok = all_good;
+        return SSFM_OK;
+    }
+    bool lanes_ok = true;
+    // After a two-lane run of >= 64 steps: was it as fast as this plan's lanes can be?  Called before the next run is enqueued and from ssfm_synchronize /
+    // ssfm_last_propagate_ms / ssfm_last_run_info (where the run has ended anyway); waits for the run's closing event.
+    int lane_health() {
+        if (!lane_check_pending) return SSFM_OK;
+        lane_check_pending = false;
+        if (lanes_active < 2 || lane_check_launches <= 0 || !run_e1) return SSFM_OK;
+        HIP_TRY(hipEventSynchronize(run_e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, run_e0, run_e1));
+        lane_last_us = ms * 1e3f / (float)lane_check_launches;
+        if (lane_pair_us <= 0.f || lane_last_us < lane_pair_us) { lane_pair_us = lane_last_us; return SSFM_OK; }
+        if (lane_last_us <= kLaneSlowRatio * lane_pair_us || lane_heals >= kLaneHealsMax) return SSFM_OK;
+        return heal_lanes();
+    }
+    int heal_lanes() {
+        ++lane_heals;
+        HIP_TRY(hipStreamSynchronize(stream));
+        const size_t cb = sizeof(cx<T>) * (size_t)n * batch;
+        cx<T>* Fx = nullptr; cx<T>* Yx = nullptr; T* Px = nullptr;
+        auto drop = [&]() { (void)hipFree(Fx); if (Yx != Fx) (void)hipFree(Yx); (void)hipFree(Px); };
+        if (hipMalloc(&Fx, cb) != hipSuccess) { (void)hipGetLastError(); return SSFM_OK; }       // (no memory for the scratch fields: the run's result is right, only slow)
+        Yx = Fx;
+        if (Y != F && hipMalloc(&Yx, cb) != hipSuccess) { (void)hipGetLastError(); Yx = Fx; drop(); return SSFM_OK; }
+        if (hipMalloc(&Px, sizeof(T) * (size_t)n * batch) != hipSuccess) { (void)hipGetLastError(); drop(); return SSFM_OK; }
+        (void)hipMemsetAsync(Fx, 0, cb, stream);
+        if (Yx != Fx) (void)hipMemsetAsync(Yx, 0, cb, stream);
+        (void)hipMemsetAsync(Px, 0, sizeof(T) * (size_t)n * batch, stream);
+        const float seen = lane_pair_us;
+        bool replaced = false;
+        const int rc = rate_and_replace_lanes(Fx, Yx, Px, &replaced);
+        (void)hipStreamSynchronize(stream);
+        drop();
+        if (rc != SSFM_OK) return rc;
+        if (replaced) ++lanes_remade;
+        if (lanes_ok) {
+            lane_strikes = 0;
+            // nothing wrong with the lanes (any more).  Not replaced: the run was slow for another reason (other work on the GPU, a profiler) -- its period is
+            // the new normal until a faster run is seen, so that every further run at this level is not rated again
+            if (!replaced) lane_pair_us = lane_last_us;
+            else if (seen > 0.f && seen < lane_pair_us) lane_pair_us = seen;
+        } else if (++lane_strikes >= 2) {
+            lanes_active = 1;
+            lanes_dropped = 1;
+        }
         return SSFM_OK;
     }
 
@@ -1132,8 +1260,10 @@ template <typename T> struct PlanT : PlanBase {
     int propagate_fixed(double gamma_d, const T* h, int64_t nsteps, void* snapshots) {
         if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_fixed: call ssfm_set_linear_operator first");
         if (int rc = use_device()) return rc;
+        if (int rc = lane_health()) return rc;             // (the previous run, if it was a long two-lane run: slow lanes are repaired before this one is enqueued)
         const T gamma = (T)gamma_d;
         const int nrows = N1 * batch;
+        const int nlanes = lanes_active;                   // (shadows the configured number: a plan that dropped to one lane drives its rows on one stream)
         last_launches = 0;
         timed = false;
         if (nsteps <= 0) return SSFM_OK;
@@ -1190,6 +1320,8 @@ template <typename T> struct PlanT : PlanBase {
         const T half = (T)0.5;
         for (auto& p : prof) p.n = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
+        const bool health = snapshots == nullptr && !go_small && !go_medium && nlanes > 1 && !profiling && !SSFM_TRACE && nsteps >= 64 && run_e0 != nullptr;
+        if (health) HIP_TRY(hipEventRecord(run_e0, stream));
         // one lane's launches, start to end
         auto lane_run = [&](int g) -> int {
             const int rows = batch / nlanes;
@@ -1335,6 +1467,11 @@ template <typename T> struct PlanT : PlanBase {
         }
         HIP_TRY(hipEventRecord(ev1, stream));
         timed = true;
+        if (health) {
+            HIP_TRY(hipEventRecord(run_e1, stream));
+            lane_check_pending = true;
+            lane_check_launches = 2 * nsteps + 1;
+        }
         if (snapshots != nullptr) HIP_TRY(hipStreamSynchronize(stream));
         return SSFM_OK;
     }
@@ -2121,7 +2258,7 @@ template <typename PT> static int set_field_impl(PT* P_, const void* src, int is
 template <typename PT> static int sync_impl(PT* P_) {
     if (int rc = P_->use_device()) return rc;
     HIP_TRY(hipStreamSynchronize(P_->stream));
-    return SSFM_OK;
+    return P_->lane_health();
 }
 
 template <typename PT> static int last_ms_impl(PT* P_, float* ms, int64_t* launches) {
@@ -2133,6 +2270,21 @@ template <typename PT> static int last_ms_impl(PT* P_, float* ms, int64_t* launc
             HIP_TRY(hipEventElapsedTime(ms, P_->ev0, P_->ev1));
         }
     }
+    return P_->lane_health();
+}
+}  // namespace
+
+namespace {
+template <typename PT> static int run_info_impl(PT* P_, ssfm_run_info* info, size_t bytes) {
+    if (int rc = P_->use_device()) return rc;
+    if (int rc = P_->lane_health()) return rc;
+    ssfm_run_info r;
+    std::memset(&r, 0, sizeof(r));
+    r.engine = P_->last_engine; r.fell_back = P_->last_fell_back; r.fallbacks_total = P_->fallbacks;
+    r.lanes = P_->lanes_active; r.lanes_share_queue = P_->lanes_share_queue ? 1 : 0; r.lanes_remade = P_->lanes_remade; r.lanes_dropped = P_->lanes_dropped;
+    r.lane_heals = P_->lane_heals;
+    r.lane_alone_us = P_->lane_alone_us; r.lane_pair_us = P_->lane_pair_us; r.lane_last_us = P_->lane_last_us; r.lane_score = P_->lane_score;
+    std::memcpy(info, &r, bytes < sizeof(r) ? bytes : sizeof(r));
     return SSFM_OK;
 }
 }  // namespace
@@ -2299,10 +2451,12 @@ void* ssfm_stream(ssfm_plan* plan) {
 
 int ssfm_plan_workspace(ssfm_plan* plan, int slot, size_t bytes, void** out) { WITH_PLAN(plan, P_->workspace(slot, bytes, out)); }
 
-int ssfm_last_run_info(ssfm_plan* plan, int* engine, int* fell_back, int64_t* fallbacks_total, int* lanes_share_queue) {
-    WITH_PLAN(plan, ((engine ? (void)(*engine = P_->last_engine) : (void)0), (fell_back ? (void)(*fell_back = P_->last_fell_back) : (void)0),
-                     (fallbacks_total ? (void)(*fallbacks_total = P_->fallbacks) : (void)0),
-                     (lanes_share_queue ? (void)(*lanes_share_queue = P_->lanes_share_queue ? 1 : 0) : (void)0), (int)SSFM_OK));
+int ssfm_debug_lane_fault(ssfm_plan* plan, int mode) {
+    WITH_PLAN(plan, (P_->lane_fault = mode, P_->lane_pair_us = mode ? P_->lane_pair_us * 0.25f : P_->lane_pair_us, (int)SSFM_OK));
+}
+int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes) {
+    if (!info || info_bytes < 2 * sizeof(int)) return fail(SSFM_ERR_INVALID, "ssfm_last_run_info: info is NULL or too small");
+    WITH_PLAN(plan, run_info_impl(P_, info, info_bytes));
 }
 
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches) { WITH_PLAN(plan, last_ms_impl(P_, ms, launches)); }

@@ -400,14 +400,14 @@ def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_ma
             and os.environ.get("SSFM_CHIRP_SMALL", "1") != "0" and batch <= 16:
         got = _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev)
         if got is not None:
-            return got
+            return got + ("chirp_small_c64",)
     if prec == _lib.C64 and 2048 < n <= 65536 and not return_steps and bar is None and os.environ.get("SSFM_CHIRP_LOOP", "c") != "python" \
             and os.environ.get("SSFM_MEDIUM", "1") != "0":
         got = _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev)
         if got is not None:
-            return got
+            return got + ("chirp_medium_c64",)
     with _ChirpZ(n, batch, dev) as eng:
-        return _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar)
+        return _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar) + ("chirp_line_c128",)
 
 
 _CHIRPS32: "OrderedDict[tuple, object]" = OrderedDict()
@@ -672,7 +672,7 @@ def FIBER(input: optical_signal,
                 bar = None
         if A_dev is None:
             A_dev = _lib.DeviceArray.from_host(np.ascontiguousarray(A, dtype=np.complex128), np.complex128, dev)
-        out, zs, snaps = _fiber_chirpz(A_dev, shape, float(grid.dt), length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar)
+        out, zs, snaps, engine = _fiber_chirpz(A_dev, shape, float(grid.dt), length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar)
         if bar is not None:
             bar.close()
         if return_steps:
@@ -682,6 +682,7 @@ def FIBER(input: optical_signal,
         res.shape = tuple(shape)
         output = _wrap_out(optical_signal, res, NULL)
         output.execution_time = time.time() - t0
+        output.engine = engine                                # which chirp-z line ran: "chirp_small_c64", "chirp_medium_c64" (one launch, complex64) or "chirp_line_c128"
         return back(output)
 
     L = rt(length)

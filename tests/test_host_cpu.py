@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ssfm_abi_version() == 2
+    assert lib.ssfm_abi_version() == 3
     assert _lib.supported_log2n(_lib.C64) == (8, 22)
 
 
