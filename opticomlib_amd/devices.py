@@ -412,6 +412,19 @@ def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_ma
 
 _CHIRPS32: "OrderedDict[tuple, object]" = OrderedDict()
 
+# Accuracy margin of the one-launch complex64 chirp-z line (2048 < n <= 65536; round 5, profiles/r05_chirp_margin.txt).  A step of that line is four
+# padded complex64 transforms of 2-4 x the field's length where the reference's pocketfft makes two of the length itself: measured over 242 random
+# fibres, max|A - A_float64|/peak <= 7.5e-7 x steps^0.75 -- up to 1.7e-5 after 66-93 steps, within the stated 2e-5 (<= 100 steps) of the float64
+# solution but no longer within HALF of it, which is what keeps the line within the tolerance of the ORACLE whenever the oracle itself is (the
+# reference's own complex64 run sits up to 2.6e-5 from the float64 solution for such lengths).  Runs of 32 ... 100 steps therefore take the complex128
+# line (four launches per step, 1e-13 from float64); shorter runs have not accumulated the error yet and from 101 steps on the tolerance is the
+# 1000-step one (3e-4; the line reaches 1.0e-4 there).  `precision="complex128"` always takes the complex128 line.
+_C64_LINE_STEPS_LO, _C64_LINE_STEPS_HI = 31, 100
+
+
+def _c64_line_has_margin(steps: int) -> bool:
+    return steps <= _C64_LINE_STEPS_LO or steps > _C64_LINE_STEPS_HI
+
 
 def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev):
     """``precision="complex64"`` at up to 2048 samples that are not a power of two: the whole run in ONE launch on a complex64 line of M >= 2n - 1 <= 4096 points
@@ -486,7 +499,7 @@ def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, ga
     else:
         hs, z_all = step_schedule(length, h, _lib.C64)
         hs, zs = np.asarray(hs, dtype=np.float64), list(z_all)
-    if len(set(hs.tolist())) > 4:
+    if len(set(hs.tolist())) > 4 or not _c64_line_has_margin(len(hs)):
         return None
     plan = get_plan(M, batch, _lib.C64, dev)
     with plan.lock:
@@ -505,6 +518,19 @@ def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, ga
             if not plan.chirp_medium(A, chirp, Dt, g, hs):
                 return None
             return A, zs, None
+        # adaptive: the step count is the run's own.  One step on a copy gives the first step size; the run's length in steps follows from it
+        # (h grows as the power falls: steps ~ L_eff / h0) -- a run that will end inside the window without margin goes to the complex128 line at once
+        probe = A.copy()
+        got = plan.chirp_medium_adapt(probe, chirp, Dt, g, float(L), float(_F32(phi_max)), 1)
+        if got is None:
+            return None
+        h0 = float(got[1][1]) if got[0] >= 1 else float(L)
+        a_lin = float(_F32(alpha / 4.343))
+        x = a_lin * float(L)
+        l_eff = float(L) if abs(x) < 1e-6 else float(L) * (1.0 - np.exp(-x)) / x
+        est = l_eff / h0 if h0 > 0 else 1.0
+        if 0.85 * _C64_LINE_STEPS_LO < est <= 1.15 * _C64_LINE_STEPS_HI:
+            return None
         zs, z0, max_steps = [_F32(0)], _F32(0), 1 << 17
         while True:
             got = plan.chirp_medium_adapt(A, chirp, Dt, g, float(_F32(L - z0)), float(_F32(phi_max)), max_steps)
@@ -515,6 +541,8 @@ def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, ga
             if steps < max_steps or not (zs[-1] < L):
                 break
             z0 = zs[-1]
+        if not _c64_line_has_margin(len(zs) - 1):              # (the estimate was off: the run is repeated on the complex128 line)
+            return None
         return A, zs, None
 
 

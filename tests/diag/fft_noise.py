@@ -49,4 +49,16 @@ for n, npol, steps in ((4096, 2, 100), (8192, 2, 100), (16384, 1, 100), (65536, 
     o = orc.fiber_c64(a, gv.dt, **kw); t = S.run_f64(a, gv.dt, step_schedule(kw['length'], kw['h'])[0], workloads.SMF)      # (float64 arithmetic on the float32 coefficients and schedule)
     pk = np.max(np.abs(t))
     say(f"{n:6d} x {npol} {steps:4d} steps  engine {getattr(y, 'engine', '?'):24s} HIP {np.max(np.abs(y.signal - t)) / pk:.2e} | oracle {np.max(np.abs(o - t)) / pk:.2e}   HIP-oracle {np.max(np.abs(y.signal - o)) / pk:.2e}")
-open(os.path.join(ROOT, "gpurun_out", "r05_fft_noise.txt"), "w").write("\n".join(out) + "\n")
+say("# 1000 steps (h = 0.125 km): energy against fl32(e^(-alpha h / 2))^(2 x 1000), and the distance from the oracle's strided fixtures where there is one")
+for n, npol in ((8192, 2), (1 << 16, 1), (1 << 20, 2)):
+    a = workloads.qpsk_field(n, seed=2024, n_pol=2)[:npol]
+    kw = dict(length=125.0, h=0.125, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    amp = np.float64(np.exp(np.float32(np.float32(-0.2 / 4.343) / 2) * np.float32(0.125)).astype(np.float32))
+    e_in = np.sum(np.abs(a.astype(np.complex64).astype(np.complex128)) ** 2); e_out = np.sum(np.abs(y.astype(np.complex128)) ** 2)
+    line = f"{n:8d} x {npol}: energy / expected - 1 = {e_out / (e_in * amp ** 2000) - 1:+.2e}"
+    if n <= 8192:
+        o = orc.fiber_c64(a, gv.dt, **kw)
+        line += f"   HIP-oracle {np.max(np.abs(y - o)) / np.max(np.abs(o)):.2e}"
+    say(line)
+open(os.path.join(ROOT, "gpurun_out", os.environ.get("FFT_NOISE_OUT", "r05_fft_noise.txt")), "w").write("\n".join(out) + "\n")

@@ -1,54 +1,30 @@
-"""One-off stress: many random FIBER / DBP configurations (power-of-two and other lengths, fixed and adaptive, both
-polarisation counts) against the oracle.  Prints the worst cases; exits non-zero on a tolerance violation."""
-import os, sys, warnings
-import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
+"""Stress run: many random FIBER / DBP configurations (power-of-two and other lengths, fixed and adaptive, both polarisation counts, loss and gain) against the
+oracle AND the float64 solution (fuzz_cases.judge has the stated bound).  Prints the worst cases with all three distances; exits non-zero on a violation.
+    python tests/diag/fuzz_many.py [count] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_cases as fc
 import opticomlib_amd as oa
 from opticomlib_amd import workloads
 from opticomlib_amd.typing import gv, optical_signal
-from oracle import ssfm_numpy as orc
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 99
 gv(**workloads.BENCH_GV)
-worst = []
-bad = 0
-for i in range(count):
-    pow2 = rng.integers(0, 3) > 0 or os.environ.get("FUZZ_POW2_ONLY") == "1"
-    n = 1 << int(rng.integers(int(os.environ.get("FUZZ_MINLOG2", "8")), int(os.environ.get("FUZZ_MAXLOG2", "14")) + 1)) if pow2 else int(rng.integers(2, 20000))
-    npol = int(rng.integers(1, 3))
-    sign = -1.0 if rng.integers(0, 4) == 0 else 1.0
-    fib = dict(alpha=sign * float(rng.uniform(0, 0.5)), beta_2=sign * float(rng.uniform(-30, 30)),
-               beta_3=sign * float(rng.choice([0.0, rng.uniform(-0.5, 0.5)])), gamma=sign * float(rng.choice([0.0, rng.uniform(0.3, 4)])))
-    length = float(rng.uniform(0.5, 40))
-    kw = dict(length=length, **fib)
-    if rng.integers(0, 2):
-        kw["phi_max"] = float(rng.choice([0.005, 0.01, 0.05]))
-    else:
-        kw["h"] = float(rng.choice([length / 5.7, 0.25, 1.0, 2.0, length * 3]))
-    amp = float(rng.choice([0.01, 0.03, 0.1]))
-    if "phi_max" in kw or rng.integers(0, 2):
-        # band-limited (the adaptive rule h = phi_max / max|A|^2 is numerically chaotic for white noise: the maximum of a
-        # full-band field decorrelates over ~0.06 km, so a 1e-7 difference in h grows ~20x per step -- in the reference too)
-        m = 1 << max(6, (n - 1).bit_length())
-        a = workloads.qpsk_field(m, seed=int(rng.integers(0, 1 << 30)), n_pol=npol, power_w=amp ** 2)[:, :n]
-    else:
-        a = (rng.standard_normal((npol, n)) + 1j * rng.standard_normal((npol, n))) * amp
-    a = a[0] if npol == 1 else a
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
-        y = oa.FIBER(optical_signal(a), **kw).signal
-    steps = len(zr) - 1
-    ref = Ar[-1]
-    err = float(np.max(np.abs(y - ref)) / max(np.max(np.abs(ref)), 1e-30))
-    tol = 2e-5 if steps <= 100 else 3e-4
-    worst.append((err / tol, err, steps, n, npol, kw))
-    if not (err < tol):
-        bad += 1
-worst.sort(key=lambda w: -w[0])
-for w in worst[:6]:
-    print(f"err/tol {w[0]:.2f}  err {w[1]:.2e}  steps {w[2]}  n {w[3]} x {w[4]}  {w[5]}")
-print(f"{count} cases, {bad} beyond tolerance")
+rows, bad, beyond_plain = [], 0, 0
+for i, n, npol, kw, a, pow2 in fc.cases(count, seed, pow2_only=os.environ.get("FUZZ_POW2_ONLY") == "1", minlog2=int(os.environ.get("FUZZ_MINLOG2", "8")),
+                                        maxlog2=int(os.environ.get("FUZZ_MAXLOG2", "14"))):
+    engine, steps, (ok, e_ho, e_ht, e_ot) = fc.run_case(oa, gv, optical_signal, kw, a)
+    tol = fc.tol_of(steps)
+    rows.append((e_ho / tol, e_ho, e_ht, e_ot, steps, n, npol, engine, ok, kw))
+    bad += not ok
+    beyond_plain += e_ho > tol
+rows.sort(key=lambda w: -w[0])
+print("# worst by HIP-oracle / tol: HIP-oracle, HIP-float64, oracle-float64 (max|d|/peak), steps, n x pol, engine")
+for w in rows[:8]:
+    print(f"HIP-oracle/tol {w[0]:.2f}  {w[1]:.2e} {w[2]:.2e} {w[3]:.2e}  steps {w[4]}  n {w[5]} x {w[6]}  {w[7]}{'' if w[8] else '  VIOLATION'}  {w[9]}")
+print("# worst by HIP-float64 / oracle-float64 among the cases beyond half the tolerance from the float64 solution")
+for w in sorted([w for w in rows if w[2] > 0.5 * fc.tol_of(w[4])], key=lambda w: -w[2] / max(w[3], 1e-30))[:5]:
+    print(f"ratio {w[2] / max(w[3], 1e-30):.2f}  {w[1]:.2e} {w[2]:.2e} {w[3]:.2e}  steps {w[4]}  n {w[5]} x {w[6]}  {w[7]}{'' if w[8] else '  VIOLATION'}")
+print(f"{count} cases (seed {seed}): {bad} beyond the stated bound; {beyond_plain} with HIP-oracle > the plain tolerance (the oracle's own distance from float64 is what carries those)")
 sys.exit(1 if bad else 0)
