@@ -151,50 +151,45 @@ int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out
  * reference's LPF (devices.py:1363-1368) and BPF (devices.py:814-823).  Plan-less.
  *   sos  n_sections x 6 float64 (b0 b1 b2 a0 a1 a2, a0 == 1), HOST;  1 <= n_sections <= 4
  *   zi   n_sections x 2 float64 = scipy.signal.sosfilt_zi(sos), HOST
- *   x,y  HOST, batch x n float64 (is_complex = 0) or complex128 interleaved (is_complex = 1); y may alias x */
+ *   x,y  batch x n float64 (is_complex = 0) or complex128 interleaved (is_complex = 1); y may alias x.  on_device = 0: HOST arrays (uploaded, filtered,
+ *        read back); on_device = 1: DEVICE memory of `device` (complex buffers 16-byte aligned), so a field can be filtered where it was
+ *        propagated.  Synchronous. */
 int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
-                     int64_t n, int batch, int is_complex);
-/* The same with x and y in DEVICE memory of `device` (complex buffers 16-byte aligned; y may alias x), so a
- * field can be filtered where it was propagated.  sos and zi stay HOST arrays.  Synchronous. */
-int ssfm_sosfiltfilt_device(int device, const double* sos, const double* zi, int n_sections, const void* x_dev, void* y_dev,
-                            int64_t n, int batch, int is_complex);
-/* Device time [ms] of the kernels of the last ssfm_sosfiltfilt* call on `device` (HIP events on the
- * filter's stream, transfers excluded). */
-int ssfm_sosfiltfilt_last_ms(int device, float* ms);
-/* Kernel launches of the last ssfm_sosfiltfilt* call on `device`: 1 when the whole forward-backward pass ran as one
+                     int64_t n, int batch, int is_complex, int on_device);
+/* The last ssfm_sosfiltfilt call on `device` (either pointer nullable): device time [ms] of its kernels (HIP events on the filter's stream, transfers
+ * excluded), and its kernel launches: 1 when the whole forward-backward pass ran as one
  * launch (every workgroup of the call resident at once: up to about 2.3 M real or complex samples in all on an
  * MI355X, at most 512 groups of 3072 samples per row), 3 otherwise (longer calls; SSFM_SOS_ONE_LAUNCH=0; a call
  * whose workgroups did not all get to run side by side within SSFM_SOS_PATIENCE_US -- default 2000 -- is
  * repeated in this form, and after three such calls in a row the next 1000 calls skip the one-launch form).  The two
  * forms agree to rounding (the one-launch form uses fused multiply-adds), not bit for bit. */
-int ssfm_sosfiltfilt_last_launches(int device, int* launches);
+int ssfm_sosfiltfilt_last(int device, float* ms, int* launches);
 
 /* Square-law detection of the reference's PD (devices.py:1512-1515): i_ph = r * (x * x.conj()).real summed
  * over the polarisations, signal and noise kept apart as the reference's signal algebra does
  * (typing.py:1337-1344): i_sig = r * sum_p |s_p|^2,  i_noise = r * sum_p Re(s_p n_p* + n_p s_p* + n_p n_p*).
- *   sig, noise   HOST, n_pol x n complex128; noise may be NULL (then i_noise must be NULL)
+ *   sig, noise   n_pol x n complex128; noise may be NULL (then i_noise must be NULL)
  *   post   factor applied to the summed currents (1 for currents; R_load of devices.py:1547 for voltages)
- *   i_sig, i_noise   HOST, n float64 */
-int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise);
-
-/* The same on DEVICE buffers (16-byte aligned).  Synchronous. */
-int ssfm_square_law_device(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise);
+ *   i_sig, i_noise   n float64
+ *   on_device   0: all four are HOST arrays; 1: DEVICE buffers (16-byte aligned).  Synchronous. */
+int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise, int on_device);
 
 /* ---- device-resident signals ----------------------------------------------------------------------
  * Raw HBM buffers that a host-side signal object can own between calls, so that a chain such as
  * FIBER -> DBP -> BPF -> PD moves nothing over PCIe until a result is looked at.  The reference keeps
  * every signal as a NumPy array (typing.py:1022-1165, :2124-2196); the host mirror's `.signal` /
  * `.noise` are materialised lazily from these.  All calls are synchronous.
- *   ssfm_device_alloc / _free   pooled per (device, size); pass the allocation size to _free
- *   ssfm_device_copy            kind 0 host->device, 1 device->host, 2 device->device
- *   ssfm_device_convert         complex64 <-> complex128, or SSFM_F64_REAL -> either (zero imaginary part); `count` elements
+ *   ssfm_device_alloc / _free   pooled per (device, size); pass the allocation size to _free.  device = SSFM_HOST_PINNED: a page-locked HOST buffer
+ *                               (pooled by size) for results that are read back -- the destination of a device-to-host copy
+ *   ssfm_device_copy            kind 0 host->device, 1 device->host, 2 device->device, 3 `bytes` zero bytes (src ignored: the empty y polarisation an
+ *                               EDFA gives a single-polarisation input, devices.py:924)
+ *   ssfm_device_convert         complex64 <-> complex128, SSFM_F64_REAL -> either (zero imaginary part), or complex128 -> SSFM_F64_REAL (the real
+ *                               part); `count` elements
  *   ssfm_device_add             dst = a + b, `count` complex elements of `precision` */
+#define SSFM_HOST_PINNED (-1)
 int ssfm_device_alloc(int device, size_t bytes, void** out);
 int ssfm_device_free(int device, void* ptr, size_t bytes);
 int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind);
-/* Page-locked host buffers (pooled by size) for results that are read back: the destination of a device-to-host copy. */
-int ssfm_host_alloc(size_t bytes, void** out);
-int ssfm_host_free(void* ptr, size_t bytes);
 int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
 int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
 /* Device random numbers and the few float64 array operations the receiver front-end needs around them.
@@ -202,20 +197,17 @@ int ssfm_device_add(int device, void* dst, const void* a, const void* b, int pre
  * Box-Muller on two 53-bit uniforms per pair -- the documented generator behind PD / EDFA with rng="device" (the
  * reference draws from NumPy's global generator, devices.py:1521-1527, :930; the default rng="numpy" reproduces
  * those draws on the host).  sum3: out = (a + b + c + offset) * scale (a, b, c nullable); scale_add: dst = a*factor
- * (+ b); mean: mean of a (+ b).  All on `n` float64 elements in DEVICE memory, synchronous. */
+ * (+ b).  All on `n` float64 elements in DEVICE memory, synchronous. */
 int ssfm_device_randn(int device, double* out_dev, int64_t n, uint64_t seed, uint64_t stream, double mean, double std);
 int ssfm_device_sum3(int device, double* out_dev, const double* a, const double* b, const double* c, double offset, double scale, int64_t n);
 int ssfm_device_scale_add(int device, double* dst, const double* a, double factor, const double* b, int64_t n);
-int ssfm_device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out);
-/* dst = running sum of src (numpy.cumsum; the laser's Wiener phase, devices.py:490) and the minimum of a, n float64 on the DEVICE. */
+/* dst = running sum of src (numpy.cumsum; the laser's Wiener phase, devices.py:490), n float64 on the DEVICE. */
 int ssfm_device_cumsum(int device, double* dst, const double* src, int64_t n);
-int ssfm_device_min(int device, const double* a, int64_t n, double* min_out);
 /* Elementwise transmitter work on DEVICE arrays (csrc/transmitter.hip), synchronous:
  * ssfm_mzm: the Mach-Zehnder transfer of devices.py:762-778 -- g = k (drive + bias) [+ k drive_noise], h = sqrt_loss (cos g +
  *   j half_eta sin g), out = in * h for signal and (nullable) noise, n_pol x n complex128; polarisation `dead_pol` of a
  *   dual-polarisation input is emptied; the drive is n float64 (drive_complex = 0) or complex128 (1);
- * ssfm_device_axpb: dst = src * alpha + beta on n float64 (is_complex = 0) or complex128 (1; beta to the real part);
- * ssfm_device_real: dst (float64) = real part of src (complex128). */
+ * ssfm_device_axpb: dst = src * alpha + beta on n float64 (is_complex = 0) or complex128 (1; beta to the real part). */
 int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, const void* in_noise, int n_pol, int64_t n, const void* drive,
              const void* drive_noise, int drive_complex, double k, double bias, double sqrt_loss, double half_eta, int dead_pol);
 /* LASER (devices.py:353-510) over t = linspace(0, stop, n) (t_i = i*step): out = amp [exp(j phase)] [sqrt(1 + rin)] [exp(j w t)],
@@ -223,107 +215,84 @@ int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, con
  * arrays drawn by the caller, `w` = 2 pi df with has_df.  `out`: n float64 when neither phase nor df is given, else n complex128. */
 int ssfm_laser(int device, void* out, int64_t n, double amp, const double* phase, const double* rin, int has_df, double w, double step, double stop);
 int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, double beta, int64_t n, int is_complex);
-int ssfm_device_real(int device, double* dst, const void* src, int64_t n);
 /* Small DEVICE-array helpers that keep the transmitter / amplifier off the host, synchronous:
- * ssfm_device_mean2: numpy.mean of n float64 (out[0]) or complex128 values (out[0] + j out[1]) -- the DC level that
- *   AC coupling removes (DAC, devices.py:339-340);  ssfm_device_shift: dst = src + (re + j im);
- * ssfm_device_zero: `bytes` zero bytes (the empty y polarisation an EDFA gives a single-polarisation input, devices.py:924);
- * ssfm_device_power: mean |x|^2 of each of `rows` rows of n float64 / complex128 values -> out[rows] (HOST). */
-int ssfm_device_mean2(int device, const void* src, int64_t n, int is_complex, double* out);
+ * ssfm_device_shift: dst = src + (re + j im);
+ * ssfm_device_reduce: the reductions a device-resident signal needs, results on the HOST --
+ *   SSFM_REDUCE_MEAN   out[0] = mean of the n float64 of a (+ b, nullable: the mean of the elementwise sum; the photocurrent's mean, devices.py:1521)
+ *   SSFM_REDUCE_MEAN2  numpy.mean of n float64 (out[0]) or complex128 values (out[0] + j out[1]) of a -- the DC level that AC coupling removes (DAC, devices.py:339-340)
+ *   SSFM_REDUCE_POWER  out[r] = mean |x|^2 of each of `rows` rows of n float64 / complex128 values of a
+ *   SSFM_REDUCE_MIN    out[0] = the minimum of the n float64 of a
+ * (b, rows and is_complex are ignored where a kind has no use for them). */
+enum { SSFM_REDUCE_MEAN = 0, SSFM_REDUCE_MEAN2 = 1, SSFM_REDUCE_POWER = 2, SSFM_REDUCE_MIN = 3 };
 int ssfm_device_shift(int device, void* dst, const void* src, int64_t n, int is_complex, double re, double im);
-int ssfm_device_zero(int device, void* dst, size_t bytes);
-int ssfm_device_power(int device, const void* src, int rows, int64_t n, int is_complex, double* out);
+int ssfm_device_reduce(int device, int kind, const void* a, const void* b, int rows, int64_t n, int is_complex, double* out);
 /* PRBS (reference devices.py:63-182): `len` bits of the Fibonacci LFSR x^order + x^t2 + 1 (orders 7, 9, 11, 15, 20,
  * 23, 31; taps of devices.py:134-142) started from the non-zero state `seed` (the caller has applied devices.py:143-149:
  * modulo 2^order, default all ones, 0 -> 1), one uint8 0/1 per bit in DEVICE memory; the sequence and the register state
  * after `len` shifts (`final_state`, nullable HOST word: return_seed, devices.py:181) are bit for bit the reference's.
  * Every thread jumps to its 256-bit chunk with powers of the shift matrix over GF(2) and walks it as devices.py:170-175.
- * ssfm_load_bits: plan field (complex128, batch 1) <- the bits as amplitudes 0.0 / 1.0 zero-stuffed to `up` samples per
- * bit (ssfm_load_symbols for bits that are already on the device: PRBS -> DAC without a host copy).
+ * (ssfm_load_symbols with src_kind 1 takes the bits from the device as they lie: PRBS -> DAC without a host copy.)
  * ssfm_load_qpsk: plan field (complex128, `rows` rows of plan_n) <- the QPSK-like test symbols of the benchmark
  * configurations: row r, symbol k = ((2 b0 - 1) + j (2 b1 - 1)) / sqrt(2) from bits 2 (r nsym + k) and
- * + 1, at sample k sps + sps / 2, zeros elsewhere.  The two loaders are asynchronous on the plan's stream. */
+ * + 1, at sample k sps + sps / 2, zeros elsewhere.  Asynchronous on the plan's stream. */
 int ssfm_prbs(int device, void* bits_dev, int64_t len, int order, uint32_t seed, uint32_t* final_state);
-int ssfm_load_bits(ssfm_plan* plan, int64_t plan_n, const void* bits_dev, int64_t nbits, int up);
 int ssfm_load_qpsk(ssfm_plan* plan, int64_t plan_n, int rows, const void* bits_dev, int64_t nsym, int sps);
 /* Free / total HBM of the device and the bytes held in the library's buffer pool (nullable). */
 int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes);
 
 /* ---- lengths that are not powers of two (the reference takes any N: numpy.fft, devices.py:1178-1180) --------
- * Bluestein's identity maps a length-N transform onto the circular convolution of a power-of-two plan of length
- * M >= 2N - 1 (complex128).  ssfm_transfer_table keeps a transfer function H (HOST, M complex, the plan's type) on
- * the device in slot 0 or 1; ssfm_apply_table does x <- ifft(fft(x) * H) on the plan's field WITHOUT waiting for the
- * host; the chirp kernels move a caller-owned DEVICE field A (batch x N complex128, natural order) into and out of
- * the plan's field buffer and apply the step's elementwise operators (csrc/chirpz.hip has the algebra):
- *   ssfm_chirp_pre   F = A exp(i gamma |A|^2 hh) c, zero-padded; P (nullable) receives |A|^2
- *   ssfm_chirp_mid   F = F exp(tab h) (mode 0, tab = D~)  or  F tab (mode 1, tab = a transfer function), N entries
- *   ssfm_chirp_post  A = F conj(c) / N exp(i gamma P hh); maxbits_dev (nullable, 8 bytes) = bit pattern of max |A|^2
- * `plan_n` / `batch` are the plan's own length and batch; all asynchronous on the plan's stream. */
+ * Bluestein's identity maps a length-n transform onto the circular convolution of a power-of-two plan of length
+ * M >= 2n - 1, with the chirp c_m = exp(-i pi m^2 / n):
+ *     fft_n(x)_k  = c_k       sum_m (x_m c_m)        conj(c)_{k-m}
+ *     ifft_n(X)_m = conj(c_m) sum_k (X_k conj(c_k))  c_{m-k}  / n
+ * (csrc/chirpz.hip has the algebra of a split step).  Round 5: the exported surface is FIVE calls -- round 4 exported the step's twelve
+ * fragments (chirp_pre / _mid / _post / _step / _line_run / _small / _medium ...), which only one particular caller could sequence correctly;
+ * they are internal now (csrc/ssfm_common.hpp) and every engine is chosen inside.
+ *
+ * ssfm_transfer_table keeps a transfer function H (HOST, plan length complex, the plan's type) on the device in slot 0 or 1;
+ * ssfm_apply_table does x <- ifft(fft(x) * H) on the plan's field WITHOUT waiting for the host (also the DAC's pulse shaping, below). */
 int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot);
 int ssfm_apply_table(ssfm_plan* plan, int slot);
-/* x <- ifft(fft(ifft(fft(x) * H0) * mul) * H1) on the plan's field: ssfm_apply_table(plan, 0), a pointwise product with the time-domain table `mul`
- * (plan length entries, DEVICE, the plan's precision, the same for every row), ssfm_apply_table(plan, 1) -- with the middle (inverse pass, product,
- * forward pass) in one launch: five launches instead of seven.  Plans in the plain layout (complex128).  Asynchronous. */
-int ssfm_apply_tables_mul(ssfm_plan* plan, const void* mul_dev);
-/* One whole chirp-z step in FIVE launches: ssfm_apply_tables_mul with ssfm_chirp_pre folded into its first column launch and ssfm_chirp_post into
- * its last (the caller's field A, `n` complex128 per row, is read and written directly; the plan's field buffer is not touched).
- *   A <- [ifft_n(fft_n(A exp(i gamma |A|^2 hh)) * D)] exp(i gamma |A|^2 hh)   with D = the time-domain table `mul_dev` between the two convolutions
- * P (n float64 per row) receives |A|^2 of the step's start.  h_dev (nullable, DEVICE double): hh = *h_dev / 2 instead of `hh`;  done_dev (nullable,
- * DEVICE int): the first and the last launch do nothing when it is set;  maxbits_dev (nullable, DEVICE 8 bytes): atomic maximum of the bit pattern
- * of |A|^2 after the step.  complex128 plans (SSFM_ERR_UNSUPPORTED otherwise, nothing launched).  Asynchronous on the plan's stream. */
-typedef struct ssfm_chirp_io {
-    void* A;
-    void* P;
-    const void* chirp;
-    int64_t n;
-    double gamma, hh;
-    const void* h_dev;
-    const void* done_dev;
-    void* maxbits_dev;
-} ssfm_chirp_io;
-int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* io);
-/* A whole FIXED-step run of a field of n <= plan length / 2 samples per row (DEVICE, complex128, natural order, advanced in place) in ONE launch: a
- * workgroup per row keeps the row in registers and does the four line transforms of every step itself (k_small_chirp, csrc/ssfm_kernels.hpp).
- * chirp (n complex128, DEVICE) as ssfm_device_chirp writes it, Dt = D~ (n complex128, DEVICE, natural frequency order), hs: nsteps step sizes [km]
- * (HOST).  Complex128 plans of 256 ... 4096 samples (SSFM_ERR_UNSUPPORTED otherwise, nothing launched).  Asynchronous on the plan's stream after
- * the schedule has been copied. */
-int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
-/* A whole FIXED-STEP chirp-z run on the plan's line (plans in the plain layout: complex128), four launches per step instead of ssfm_chirp_step's five: the
- * chirp products on either side of a step cancel against the neighbouring steps', so the caller takes them once -- the line holds A c (zero from `keep` =
- * the field's length up) when this is called and A c again when it returns; slots 0 and 1 hold the two convolutions' tables; mul[which[s]] (DEVICE, plan
- * length entries each, at most 256 tables) = exp(D~ h_s) / keep below `keep`, zero above; hs (HOST): the nsteps step sizes.  Asynchronous on the plan's
- * stream.  SSFM_ERR_UNSUPPORTED: a plan in the 16-byte-unit layout (nothing launched).  ssfm_chirp_propagate uses it for schedules of up to four sizes. */
-int ssfm_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep);
-/* The same on a complex64 plan of 2^13 ... 2^17 points whose rows fit the one-XCD engine (2^17 points in all rows, at most 64 workgroups): lengths
- * 2048 < n <= plan length / 2 in ONE launch on one XCD -- four passes per step, the chirps of neighbouring steps cancel (k_medium_chirp) -- between two
- * pointwise launches.  A, chirp, Dt: complex64, DEVICE.  At most four distinct step sizes.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was: no such
- * plan or schedule, or the launch's workgroups did not meet within the patience (the engine is then off for this plan). */
-int ssfm_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);
-/* ... and its ADAPTIVE run (the rule of ssfm_chirp_small_adapt in float32 arithmetic; k_medium_chirp_adapt): z_out (HOST, nullable, max_steps + 1 entries)
- * receives z after every step, *steps_out the steps taken.  Synchronous.  SSFM_ERR_UNSUPPORTED with A as it was, as above. */
-int ssfm_chirp_medium_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int64_t max_steps,
-                            double* z_out, int64_t* steps_out);
-/* ... and the ADAPTIVE run (h = phi_max / (|gamma| max |A|^2) over all rows, clamped to what is left of `length`; the rule of ssfm_chirp_propagate, in
- * float32 arithmetic when f32 != 0) in one launch: the rows' workgroups exchange their maxima through memory every step (k_small_chirp_adapt).  At
- * most 16 rows.  z_out (HOST, nullable, max_steps + 1 entries) receives z after every step, *steps_out the steps taken.  Synchronous.
- * SSFM_ERR_UNSUPPORTED with the field as it came: no such plan, or the rows' workgroups did not meet within the patience (SSFM_FUSED_PATIENCE_TICKS; a
- * device too busy to keep them resident together; rows that had finished by then are put back from a copy taken before the launch) --
- * ssfm_chirp_propagate then queues the run step by step. */
-int ssfm_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int f32,
-                           int64_t max_steps, double* z_out, int64_t* steps_out);
-/* The chirp c_m = exp(-i pi m^2 / n) of that identity, generated on the device with its phase reduced exactly in
- * integers: ssfm_device_chirp writes c (conj = 0) or conj(c) (1), n complex128, into DEVICE memory (synchronous);
- * ssfm_load_chirp_kernel writes the convolution kernel v[m] = v[plan_n - m] = conj(c_m) (which = 0, forward transform) or
- * c_m (which = 1, inverse) into the plan's field, from where ssfm_table_from_field makes it the resident transfer
- * function of a slot -- neither a host transform nor an upload (the reference: numpy.fft, devices.py:1178-1180). */
+/* The chirp c (conj = 0) or conj(c) (1), n complex128, into DEVICE memory, its phase reduced exactly in integers (synchronous). */
 int ssfm_device_chirp(int device, void* out_dev, int64_t n, int conj);
-int ssfm_load_chirp_kernel(ssfm_plan* plan, int64_t plan_n, int64_t n, int which);
+/* One-time set-up of a COMPLEX128 plan of plan_n >= 2n - 1 points for fields of n samples: both convolution kernels of the identity
+ * (v[m] = v[plan_n - m] = conj(c_m) and c_m) are generated in the plan's field and transformed there into the resident transfer functions of
+ * slots 0 and 1 -- neither a host transform nor an upload.  What ssfm_chirp_propagate / _transfer / _fourier rely on.  Asynchronous; the
+ * plan's field is consumed. */
+int ssfm_chirp_setup(ssfm_plan* plan, int64_t plan_n, int64_t n);
+/* A whole FIBER / DBP run on a field of ANY length, driven from C on the complex128 line: A (batch x n complex128, DEVICE) is
+ * advanced in place, P is scratch (batch x n float64, DEVICE), chirp = c (ssfm_device_chirp), Dt = D~ (n complex128, DEVICE, natural
+ * frequency order); the plan: complex128, plan_n >= 2n - 1, prepared by ssfm_chirp_setup(plan, plan_n, n).  hs != NULL: fixed step, `nsteps`
+ * step sizes (HOST; steps of length 0 are the identity).  hs == NULL: the adaptive rule of devices.py:1172-1196, h = phi_max / (|gamma| max|A|^2)
+ * clamped to the rest of `length`, evaluated on the device in float32 (f32 != 0: the reference's arithmetic in complex64 mode) or float64; z_out
+ * (HOST, nullable, max_steps + 1 doubles) receives z after every step, *steps_out the steps taken.  Engines, chosen inside: the whole run in one
+ * launch for plan_n <= 4096 (a workgroup per row); four launches per fixed step for schedules of up to four step sizes (the chirps of neighbouring
+ * steps cancel: one pointwise launch before and after the run); five otherwise, seven per adaptive step.  A caller that wants the field after
+ * every step (return_steps) calls it a step at a time (nsteps = 1, or max_steps = 1 over the rest of the length).  Synchronous. */
+int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, void* P, const void* chirp, const void* Dt, int64_t n, double gamma,
+                         const double* hs, int64_t nsteps, double length, double phi_max, int f32, int64_t max_steps, double* z_out, int64_t* steps_out);
+/* The same run for complex64 callers in ONE launch on a complex64 line: the plan is COMPLEX64 and its length is the line's, M = 2^k >= 2n - 1 -- a
+ * workgroup per row for M <= 4096 (at most 16 rows in adaptive mode), the one-XCD engine for M = 2^13 ... 2^17 with at most 2^17 points in all rows
+ * (four passes per step; fixed step: at most four distinct sizes).  A, chirp (c rounded to complex64), Dt: complex64, DEVICE; needs no
+ * ssfm_chirp_setup (the line's tables are the plan's own).  hs / nsteps / length / phi_max / max_steps / z_out / steps_out as above, the adaptive rule
+ * in float32.  Synchronous except for a fixed-step run with M <= 4096 (asynchronous on the plan's stream).  SSFM_ERR_UNSUPPORTED with A as it was: the
+ * plan has no such engine or schedule, or the launch's workgroups did not meet within their patience (the engine is then off for this plan) -- the
+ * caller takes ssfm_chirp_propagate.  (The reference transforms such a length in single precision itself -- pocketfft's Bluestein -- so this is its
+ * arithmetic class; its accuracy margin and when a caller should prefer the complex128 line: opticomlib_amd/devices.py _c64_line_has_margin.) */
+int ssfm_chirp_propagate_c64(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps,
+                             double length, double phi_max, int64_t max_steps, double* z_out, int64_t* steps_out);
+/* x <- ifft_n(fft_n(x) * tab) (exponent = 0: DM's H for any length, devices.py:1019-1035) or * exp(tab) (exponent != 0) for every row of the DEVICE array
+ * A (batch x n complex128, in place); tab: n complex128, DEVICE.  Plan as for ssfm_chirp_propagate.  Asynchronous on the plan's stream. */
+int ssfm_chirp_transfer(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* tab, int64_t n, int exponent);
+/* numpy.fft.fft (inverse = 0, unscaled) or ifft (inverse != 0, with its 1/n) of every row of A (batch x n complex128, DEVICE, in place);
+ * chirp = c, chirp_conj = conj(c).  The reference's signal('w') / signal('t'), typing.py:1421-1462.  Asynchronous on the plan's stream. */
+int ssfm_chirp_fourier(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* chirp_conj, int64_t n, int inverse);
 /* Pulse shaping of the reference's DAC (upfir, utils.py:1949-1981) on a complex128 plan of batch 1: ssfm_load_padded
  * writes `n_src` float64 (src_complex = 0) or complex128 (1) samples from DEVICE memory into the field, zero-padded;
- * ssfm_table_from_field makes slot <- fft(field) (the field is consumed); ssfm_load_symbols writes `nsym` float64
- * amplitudes (DEVICE; the bits as 0.0 / 1.0) zero-stuffed to `up` samples per symbol with the sample at up / 2; ssfm_apply_table then convolves.  Asynchronous. */
+ * ssfm_table_from_field makes slot <- fft(field) (the field is consumed); ssfm_load_symbols writes `nsym` symbols --
+ * float64 amplitudes (src_kind 0) or uint8 bits taken as 0.0 / 1.0 (src_kind 1), DEVICE -- zero-stuffed to `up` samples per symbol with the sample at up / 2; ssfm_apply_table then convolves.  Asynchronous. */
 int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src);
-int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const double* sym_dev, int64_t nsym, int up);
+int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_kind, int64_t nsym, int up);
 /* The DAC's built-in pulses (utils.py:1791-1947) generated in the field instead of uploaded: `npts` samples over
  * t_i = i*step + start (t_{npts-1} = stop: numpy.linspace), zero-padded.  kind 0 nrz (params: -T/2, T/2); 1 gaussian
  * exp(-((p0 + j p1) t)^pow2m) with (p0, p1) = alpha (1 + j c); 2 raised cosine (2 beta, pi beta, value where
@@ -331,22 +300,12 @@ int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const double* sym_dev, in
  * 1/(4 beta)); 4 sinc.  `params`: 7 doubles on the HOST.  Asynchronous. */
 int ssfm_load_pulse(ssfm_plan* plan, int64_t plan_n, int kind, int64_t npts, double start, double step, double stop, int pow2m, const double* params);
 int ssfm_table_from_field(ssfm_plan* plan, int slot);
-int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh);
-int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode);
-int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh,
-                    void* maxbits_dev);
-/* A whole FIBER / DBP run on a field of ANY length through the three kernels above and ssfm_apply_table, driven from C (the per-kernel entry
- * points cost a host call each, and an adaptive run driven from the host waits for every step's maximum): A (batch x n complex128, DEVICE) is
- * advanced in place, P is scratch (batch x n float64, DEVICE), chirp / Dt as for ssfm_chirp_pre / _mid; slots 0 and 1 of the plan hold the
- * chirp kernels.  hs != NULL: fixed step, `nsteps` step sizes (HOST).  hs == NULL: the adaptive rule of devices.py:1172-1196,
- * h = phi_max / (|gamma| max|A|^2) clamped to the rest of `length`, evaluated on the device in float32 (f32 != 0: the reference's arithmetic
- * in complex64 mode) or float64; z_out (HOST, max_steps + 1 doubles, nullable) receives z after every step, *steps_out the steps taken.
- * Synchronous. */
-int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, void* P, const void* chirp, const void* Dt, int64_t n, double gamma,
-                         const double* hs, int64_t nsteps, double length, double phi_max, int f32, int64_t max_steps, double* z_out, int64_t* steps_out);
-
-/* Forward FFT of every row into HOST `dst` (natural frequency order, unscaled) -- validation aid. */
-int ssfm_debug_fft(ssfm_plan* plan, void* dst);
+/* Validation aids behind one entry point.  SSFM_DEBUG_FFT: the forward FFT of every row of the plan's field into HOST `dst` (natural frequency order,
+ * unscaled).  SSFM_DEBUG_LANE_FAULT: test hook of the lane health check (ssfm_last_run_info) -- arg 1 makes the plan believe a four times better launch
+ * period than it has seen (the next long two-lane run looks slow and the lanes are rated again), arg 2 additionally makes every rating come out bad (the
+ * repair fails; the second failure drops the plan to one lane), arg 0 back to normal. */
+enum { SSFM_DEBUG_FFT = 0, SSFM_DEBUG_LANE_FAULT = 1 };
+int ssfm_debug(ssfm_plan* plan, int what, int64_t arg, void* dst);
 
 int ssfm_synchronize(ssfm_plan* plan);
 /* The plan's hipStream_t (as void*), so callers can record events around propagate calls or order their own work behind a run (see
@@ -359,7 +318,8 @@ void* ssfm_stream(ssfm_plan* plan);
  *   engine            a value of enum ssfm_engine below: the engine that produced the result of the LAST run (after a fallback: the fallback)
  *   fell_back         1: the last run was started on a single-launch engine, gave up and was repeated
  *   fallbacks_total   such repeats over the life of the plan (a plan keeps to the fallback engine after the first)
- *   lanes             lanes the plan's fixed-step runs drive now: ssfm_num_lanes, or 1 once the plan has dropped its second lane (below)
+ *   lanes             row groups ("lanes") the plan's fixed-step runs drive now on separate streams: `lanes_configured` (env SSFM_LANES, default 2 from 2^20
+ *                     samples in all, never more than the batch; one kernel launch covers batch / lanes rows), or 1 once the plan has dropped its second lane (below)
  *   lanes_share_queue 1: a lane's stream shares a hardware queue with an earlier lane's and no replacement stream did better (more than four
  *                     high-priority streams alive): the lanes' kernels run one after the other
  *   lanes_remade      lane streams replaced at RUN time.  Which hardware queue the runtime gives a stream decides whether a lane's kernels run beside
@@ -393,6 +353,7 @@ typedef struct ssfm_run_info {
     int fell_back;
     int64_t fallbacks_total;
     int lanes;
+    int lanes_configured;
     int lanes_share_queue;
     int lanes_remade;
     int lanes_dropped;
@@ -403,15 +364,7 @@ typedef struct ssfm_run_info {
     float lane_score;
 } ssfm_run_info;
 int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes);
-/* Test hook of the lane health check: mode 1 makes the plan believe a four times better launch period than it has seen (the next long two-lane run looks
- * slow and the lanes are rated again), mode 2 additionally makes every rating come out bad (the repair fails; the second failure drops the plan to one
- * lane), 0 back to normal. */
-int ssfm_debug_lane_fault(ssfm_plan* plan, int mode);
 
-/* A device buffer of at least `bytes` bytes owned by the plan (slot 0 ... 3; grows on demand, freed with the plan; contents undefined between
- * calls; a growing call waits for the plan's stream).  For driver loops above this ABI that need scratch memory per call
- * (ssfm_chirp_propagate: its exp(D~ h) table, step control block and z log) without a hipMalloc / hipFree pair each time. */
-int ssfm_plan_workspace(ssfm_plan* plan, int slot, size_t bytes, void** out);
 
 /* Time of the last propagate call measured with HIP events on the plan's stream [ms], and the
  * number of kernel launches it made.  Valid after ssfm_synchronize. */
@@ -429,9 +382,6 @@ int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
  * After ssfm_synchronize, ssfm_kernel_times returns per class the number of launches and the summed
  * event-to-event time in ms (a dependent-launch gap is counted with the launch that follows it). */
 int ssfm_set_profiling(ssfm_plan* plan, int mode);
-/* Number of row groups ("lanes") a fixed-step run drives on separate streams (env SSFM_LANES,
- * default 2, never more than the batch): one kernel launch covers batch/lanes rows. */
-int ssfm_num_lanes(ssfm_plan* plan, int* lanes);
 /* What the plan's staging buffers hold, owned by the plan: `which` 0 labels the linear operator set with
  * ssfm_set_linear_operator, 1 / 2 the resident transfer function of slot 0 / 1.  A caller labels what it has staged
  * (any non-zero 64-bit tag, e.g. a hash of the fibre parameters) and asks later whether it is still there; EVERY entry

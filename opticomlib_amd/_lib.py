@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSFM_LIB") or os.path.join(_HERE, "_ssfm_amd.so")   # SSFM_LIB: dev override
 
 C64, C128 = 0, 1
+HOST_PINNED = -1                       # ssfm_device_alloc / _free: a page-locked host buffer
+REDUCE_MEAN, REDUCE_MEAN2, REDUCE_POWER, REDUCE_MIN = 0, 1, 2, 3      # ssfm_device_reduce
 _CDTYPE = {C64: np.complex64, C128: np.complex128}
 _RDTYPE = {C64: np.float32, C128: np.float64}
 
@@ -38,12 +40,9 @@ SYMBOLS = {
     "ssfm_adaptive_finish": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
     "ssfm_apply_transfer": (_I, [_VP, _VP]),
     "ssfm_apply_dispersion": (_I, [_VP, _D, _D, _VP]),
-    "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
-    "ssfm_sosfiltfilt_device": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I]),
-    "ssfm_sosfiltfilt_last_ms": (_I, [_I, C.POINTER(C.c_float)]),
-    "ssfm_sosfiltfilt_last_launches": (_I, [_I, C.POINTER(C.c_int)]),
-    "ssfm_square_law": (_I, [_I, _VP, _VP, _I, _I64, _D, _D, _VP, _VP]),
-    "ssfm_square_law_device": (_I, [_I, _VP, _VP, _I, _I64, _D, _D, _VP, _VP]),
+    "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I, _I]),
+    "ssfm_sosfiltfilt_last": (_I, [_I, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "ssfm_square_law": (_I, [_I, _VP, _VP, _I, _I64, _D, _D, _VP, _VP, _I]),
     "ssfm_device_alloc": (_I, [_I, C.c_size_t, C.POINTER(_VP)]),
     "ssfm_device_free": (_I, [_I, _VP, C.c_size_t]),
     "ssfm_device_copy": (_I, [_I, _VP, _VP, C.c_size_t, _I]),
@@ -52,53 +51,35 @@ SYMBOLS = {
     "ssfm_device_randn": (_I, [_I, _VP, _I64, C.c_uint64, C.c_uint64, _D, _D]),
     "ssfm_device_sum3": (_I, [_I, _VP, _VP, _VP, _VP, _D, _D, _I64]),
     "ssfm_device_scale_add": (_I, [_I, _VP, _VP, _D, _VP, _I64]),
-    "ssfm_host_alloc": (_I, [C.c_size_t, C.POINTER(_VP)]),
-    "ssfm_host_free": (_I, [_VP, C.c_size_t]),
-    "ssfm_device_mean": (_I, [_I, _VP, _VP, _I64, C.POINTER(_D)]),
     "ssfm_device_cumsum": (_I, [_I, _VP, _VP, _I64]),
-    "ssfm_device_min": (_I, [_I, _VP, _I64, C.POINTER(_D)]),
     "ssfm_mzm": (_I, [_I, _VP, _VP, _VP, _VP, _I, _I64, _VP, _VP, _I, _D, _D, _D, _D, _I]),
     "ssfm_device_axpb": (_I, [_I, _VP, _VP, _D, _D, _I64, _I]),
-    "ssfm_device_real": (_I, [_I, _VP, _VP, _I64]),
     "ssfm_device_mem_info": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ssfm_transfer_table": (_I, [_VP, _VP, _I]),
     "ssfm_apply_table": (_I, [_VP, _I]),
-    "ssfm_apply_tables_mul": (_I, [_VP, _VP]),
     "ssfm_load_padded": (_I, [_VP, _I64, _VP, _I, _I64]),
-    "ssfm_load_symbols": (_I, [_VP, _I64, _VP, _I64, _I]),
+    "ssfm_load_symbols": (_I, [_VP, _I64, _VP, _I, _I64, _I]),
     "ssfm_laser": (_I, [_I, _VP, _I64, _D, _VP, _VP, _I, _D, _D, _D]),
     "ssfm_load_pulse": (_I, [_VP, _I64, _I, _I64, _D, _D, _D, _I, _VP]),
     "ssfm_table_from_field": (_I, [_VP, _I]),
-    "ssfm_chirp_pre": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D]),
-    "ssfm_chirp_mid": (_I, [_VP, _I64, _I, _VP, _I64, _D, _I]),
-    "ssfm_chirp_post": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _D, _D, _VP]),
-    "ssfm_chirp_step": (_I, [_VP, _VP, _VP]),                       # (plan, mul_dev, const ssfm_chirp_io*)
-    "ssfm_chirp_small": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
-    "ssfm_chirp_line_run": (_I, [_VP, C.POINTER(_VP), C.POINTER(C.c_ubyte), C.POINTER(_D), _I64, _D, _I64]),
-    "ssfm_chirp_medium": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64]),
-    "ssfm_chirp_medium_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I64, C.POINTER(_D), C.POINTER(_I64)]),
-    "ssfm_chirp_small_adapt": (_I, [_VP, _VP, _VP, _VP, _I64, _D, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
     "ssfm_chirp_propagate": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64, _D, _D, _I, _I64, C.POINTER(_D), C.POINTER(_I64)]),
-    "ssfm_debug_fft": (_I, [_VP, _VP]),
     "ssfm_synchronize": (_I, [_VP]),
     "ssfm_stream": (_VP, [_VP]),
     "ssfm_last_propagate_ms": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(_I64)]),
     "ssfm_last_run_info": (_I, [_VP, _VP, C.c_size_t]),
-    "ssfm_debug_lane_fault": (_I, [_VP, _I]),
-    "ssfm_plan_workspace": (_I, [_VP, _I, C.c_size_t, C.POINTER(_VP)]),
     "ssfm_set_profiling": (_I, [_VP, _I]),
     "ssfm_kernel_times": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
-    "ssfm_num_lanes": (_I, [_VP, C.POINTER(_I)]),
     "ssfm_plan_set_tag": (_I, [_VP, _I, C.c_uint64]),
     "ssfm_plan_get_tag": (_I, [_VP, _I, C.POINTER(C.c_uint64)]),
     "ssfm_device_chirp": (_I, [_I, _VP, _I64, _I]),
-    "ssfm_load_chirp_kernel": (_I, [_VP, _I64, _I64, _I]),
-    "ssfm_device_mean2": (_I, [_I, _VP, _I64, _I, C.POINTER(_D)]),
+    "ssfm_chirp_setup": (_I, [_VP, _I64, _I64]),
+    "ssfm_chirp_propagate_c64": (_I, [_VP, _VP, _VP, _VP, _I64, _D, C.POINTER(_D), _I64, _D, _D, _I64, C.POINTER(_D), C.POINTER(_I64)]),
+    "ssfm_chirp_transfer": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _I]),
+    "ssfm_chirp_fourier": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _I64, _I]),
+    "ssfm_device_reduce": (_I, [_I, _I, _VP, _VP, _I, _I64, _I, C.POINTER(_D)]),
+    "ssfm_debug": (_I, [_VP, _I, _I64, _VP]),
     "ssfm_device_shift": (_I, [_I, _VP, _VP, _I64, _I, _D, _D]),
-    "ssfm_device_zero": (_I, [_I, _VP, C.c_size_t]),
-    "ssfm_device_power": (_I, [_I, _VP, _I, _I64, _I, C.POINTER(_D)]),
     "ssfm_prbs": (_I, [_I, _VP, _I64, _I, C.c_uint32, C.POINTER(C.c_uint32)]),
-    "ssfm_load_bits": (_I, [_VP, _I64, _VP, _I64, _I]),
     "ssfm_load_qpsk": (_I, [_VP, _I64, _I, _VP, _I64, _I]),
 }
 
@@ -110,7 +91,7 @@ ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adap
 
 class RunInfo(C.Structure):
     """``ssfm_run_info`` of include/ssfm_amd.h."""
-    _fields_ = [("engine", C.c_int), ("fell_back", C.c_int), ("fallbacks_total", C.c_int64), ("lanes", C.c_int), ("lanes_share_queue", C.c_int),
+    _fields_ = [("engine", C.c_int), ("fell_back", C.c_int), ("fallbacks_total", C.c_int64), ("lanes", C.c_int), ("lanes_configured", C.c_int), ("lanes_share_queue", C.c_int),
                 ("lanes_remade", C.c_int), ("lanes_dropped", C.c_int), ("lane_heals", C.c_int), ("lane_alone_us", C.c_float), ("lane_pair_us", C.c_float),
                 ("lane_last_us", C.c_float), ("lane_score", C.c_float)]
 
@@ -184,7 +165,7 @@ def sosfiltfilt(sos: np.ndarray, zi: np.ndarray, x: np.ndarray, device: int = 0)
     n = xs.shape[-1]
     batch = int(xs.size // n) if n else 0
     y = np.empty_like(xs)
-    _check_filter(load().ssfm_sosfiltfilt(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _ptr(xs), _ptr(y), n, batch, int(is_c)),
+    _check_filter(load().ssfm_sosfiltfilt(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _ptr(xs), _ptr(y), n, batch, int(is_c), 0),
                   "ssfm_sosfiltfilt")
     return y
 
@@ -194,8 +175,8 @@ def sosfiltfilt_device(sos: np.ndarray, zi: np.ndarray, x_ptr: int, y_ptr: int, 
     """The same on DEVICE buffers (raw pointers; float64 or interleaved complex128, ``batch`` rows of ``n``)."""
     sos = np.ascontiguousarray(sos, dtype=np.float64)
     zi = np.ascontiguousarray(zi, dtype=np.float64)
-    _check_filter(load().ssfm_sosfiltfilt_device(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _VP(x_ptr), _VP(y_ptr), int(n), int(batch),
-                                                 int(bool(is_complex))), "ssfm_sosfiltfilt_device")
+    _check_filter(load().ssfm_sosfiltfilt(int(device), _ptr(sos), _ptr(zi), sos.shape[0], _VP(x_ptr), _VP(y_ptr), int(n), int(batch),
+                                          int(bool(is_complex)), 1), "ssfm_sosfiltfilt")
 
 
 def square_law(signal: np.ndarray, noise, r: float, device: int = 0):
@@ -206,27 +187,27 @@ def square_law(signal: np.ndarray, noise, r: float, device: int = 0):
     n_pol = 1 if s.ndim == 1 else s.shape[0]
     i_sig = np.empty(n, dtype=np.float64)
     if noise is None:
-        _check(load().ssfm_square_law(int(device), _ptr(s), None, n_pol, n, float(r), 1.0, _ptr(i_sig), None), "ssfm_square_law")
+        _check(load().ssfm_square_law(int(device), _ptr(s), None, n_pol, n, float(r), 1.0, _ptr(i_sig), None, 0), "ssfm_square_law")
         return i_sig, None
     nz = np.ascontiguousarray(noise, dtype=np.complex128)
     if nz.shape != s.shape:
         raise ValueError(f"signal and noise shapes differ: {s.shape} vs {nz.shape}")
     i_noise = np.empty(n, dtype=np.float64)
-    _check(load().ssfm_square_law(int(device), _ptr(s), _ptr(nz), n_pol, n, float(r), 1.0, _ptr(i_sig), _ptr(i_noise)), "ssfm_square_law")
+    _check(load().ssfm_square_law(int(device), _ptr(s), _ptr(nz), n_pol, n, float(r), 1.0, _ptr(i_sig), _ptr(i_noise), 0), "ssfm_square_law")
     return i_sig, i_noise
 
 
 def sosfiltfilt_last_ms(device: int = 0) -> float:
     """Device time [ms] of the kernels of the last filter call on ``device``."""
     ms = C.c_float()
-    _check(load().ssfm_sosfiltfilt_last_ms(int(device), C.byref(ms)), "ssfm_sosfiltfilt_last_ms")
+    _check(load().ssfm_sosfiltfilt_last(int(device), C.byref(ms), None), "ssfm_sosfiltfilt_last")
     return float(ms.value)
 
 
 def sosfiltfilt_last_launches(device: int = 0) -> int:
     """Kernel launches of the last filter call on ``device``: 1 (one-launch form) or 3."""
     k = C.c_int()
-    _check(load().ssfm_sosfiltfilt_last_launches(int(device), C.byref(k)), "ssfm_sosfiltfilt_last_launches")
+    _check(load().ssfm_sosfiltfilt_last(int(device), None, C.byref(k)), "ssfm_sosfiltfilt_last")
     return int(k.value)
 
 
@@ -241,14 +222,14 @@ class _PinnedBlock:
     def __init__(self, shape, dtype):
         self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = _VP()
-        _check(load().ssfm_host_alloc(self.nbytes, C.byref(p)), "ssfm_host_alloc")
+        _check(load().ssfm_device_alloc(HOST_PINNED, self.nbytes, C.byref(p)), "ssfm_device_alloc")
         self.ptr = int(p.value)
         self.__array_interface__ = {"data": (self.ptr, False), "shape": tuple(shape), "typestr": np.dtype(dtype).str, "version": 3}
 
     def __del__(self):
         try:
             if self.ptr and _lib is not None:
-                _lib.ssfm_host_free(_VP(self.ptr), self.nbytes)
+                _lib.ssfm_device_free(HOST_PINNED, _VP(self.ptr), self.nbytes)
             self.ptr = 0
         except Exception:
             pass
@@ -383,7 +364,7 @@ def scale_add_device(a: DeviceArray, factor: float, b=None) -> DeviceArray:
 
 def mean_device(a: DeviceArray, b=None) -> float:
     m = _D()
-    _check(load().ssfm_device_mean(a.device, _VP(a.ptr), None if b is None else _VP(b.ptr), a.size, C.byref(m)), "ssfm_device_mean")
+    _check(load().ssfm_device_reduce(a.device, REDUCE_MEAN, _VP(a.ptr), None if b is None else _VP(b.ptr), 1, a.size, 0, C.byref(m)), "ssfm_device_reduce")
     return float(m.value)
 
 
@@ -405,7 +386,7 @@ def mean2_device(a: DeviceArray):
     """``numpy.mean`` of a float64 / complex128 device array (a Python float or complex)."""
     m = (_D * 2)()
     cplx = a.dtype.kind == "c"
-    _check(load().ssfm_device_mean2(a.device, _VP(a.ptr), a.size, int(cplx), m), "ssfm_device_mean2")
+    _check(load().ssfm_device_reduce(a.device, REDUCE_MEAN2, _VP(a.ptr), None, 1, a.size, int(cplx), m), "ssfm_device_reduce")
     return complex(m[0], m[1]) if cplx else float(m[0])
 
 
@@ -419,14 +400,14 @@ def shift_device(a: DeviceArray, value) -> DeviceArray:
 
 def zeros_device(shape, dtype, device: int = 0) -> DeviceArray:
     out = DeviceArray(shape, dtype, device)
-    _check(load().ssfm_device_zero(out.device, _VP(out.ptr), out.nbytes), "ssfm_device_zero")
+    _check(load().ssfm_device_copy(out.device, _VP(out.ptr), None, out.nbytes, 3), "ssfm_device_copy")
     return out
 
 
 def power_device(ptr: int, rows: int, n: int, is_complex: bool, device: int = 0) -> np.ndarray:
     """Mean ``|x|^2`` of each of ``rows`` rows of ``n`` values at device address ``ptr``."""
     out = (_D * int(rows))()
-    _check(load().ssfm_device_power(int(device), _VP(ptr), int(rows), int(n), int(bool(is_complex)), out), "ssfm_device_power")
+    _check(load().ssfm_device_reduce(int(device), REDUCE_POWER, _VP(ptr), None, int(rows), int(n), int(bool(is_complex)), out), "ssfm_device_reduce")
     return np.array(out[:], dtype=np.float64)
 
 
@@ -440,7 +421,7 @@ def prbs_device(order: int, length: int, seed: int, device: int = 0):
 
 def real_device(a: DeviceArray) -> DeviceArray:
     out = DeviceArray(a.shape, np.float64, a.device)
-    _check(load().ssfm_device_real(a.device, _VP(out.ptr), _VP(a.ptr), a.size), "ssfm_device_real")
+    _check(load().ssfm_device_convert(a.device, _VP(a.ptr), C128, _VP(out.ptr), F64_REAL, a.size), "ssfm_device_convert")
     return out
 
 
@@ -465,7 +446,7 @@ def cumsum_device(a: DeviceArray) -> DeviceArray:
 
 def min_device(a: DeviceArray) -> float:
     m = C.c_double()
-    _check(load().ssfm_device_min(a.device, _VP(a.ptr), a.size, C.byref(m)), "ssfm_device_min")
+    _check(load().ssfm_device_reduce(a.device, REDUCE_MIN, _VP(a.ptr), None, 1, a.size, 0, C.byref(m)), "ssfm_device_reduce")
     return float(m.value)
 
 
@@ -490,8 +471,8 @@ def square_law_device(signal: DeviceArray, noise, r: float, post: float = 1.0):
     n_pol = 1 if signal.ndim == 1 else signal.shape[0]
     i_sig = DeviceArray((n,), np.float64, signal.device)
     i_noise = None if noise is None else DeviceArray((n,), np.float64, signal.device)
-    _check(load().ssfm_square_law_device(signal.device, _VP(signal.ptr), None if noise is None else _VP(noise.ptr), n_pol, n, float(r), float(post),
-                                         _VP(i_sig.ptr), None if noise is None else _VP(i_noise.ptr)), "ssfm_square_law_device")
+    _check(load().ssfm_square_law(signal.device, _VP(signal.ptr), None if noise is None else _VP(noise.ptr), n_pol, n, float(r), float(post),
+                                  _VP(i_sig.ptr), None if noise is None else _VP(i_noise.ptr), 1), "ssfm_square_law")
     return i_sig, i_noise
 
 
@@ -643,19 +624,20 @@ class Plan:
 
     def load_symbols(self, sym: "DeviceArray", up: int):
         """field <- the float64 amplitudes ``sym`` zero-stuffed to ``up`` samples per symbol (sample at ``up // 2``)."""
-        _check(load().ssfm_load_symbols(self._h, self.n, _VP(sym.ptr), sym.size, int(up)), "ssfm_load_symbols")
+        _check(load().ssfm_load_symbols(self._h, self.n, _VP(sym.ptr), 0, sym.size, int(up)), "ssfm_load_symbols")
 
     def load_bits(self, bits: "DeviceArray", up: int):
         """field <- device-resident bits (uint8) as amplitudes 0.0 / 1.0, zero-stuffed to ``up`` samples per bit."""
-        _check(load().ssfm_load_bits(self._h, self.n, _VP(bits.ptr), bits.size, int(up)), "ssfm_load_bits")
+        _check(load().ssfm_load_symbols(self._h, self.n, _VP(bits.ptr), 1, bits.size, int(up)), "ssfm_load_symbols")
 
     def load_qpsk(self, bits: "DeviceArray", nsym: int, sps: int):
         """field rows <- QPSK-like symbols from device-resident bits (``ssfm_load_qpsk``)."""
         _check(load().ssfm_load_qpsk(self._h, self.n, self.batch, _VP(bits.ptr), int(nsym), int(sps)), "ssfm_load_qpsk")
 
-    def load_chirp_kernel(self, n: int, which: int):
-        """field <- Bluestein's convolution kernel for length ``n`` (0: forward, 1: inverse), generated on the device."""
-        _check(load().ssfm_load_chirp_kernel(self._h, self.n, int(n), int(which)), "ssfm_load_chirp_kernel")
+    def chirp_setup(self, n: int):
+        """Slots 0 / 1 <- the transfer functions of Bluestein's two convolutions for fields of ``n`` samples, generated and transformed on the device
+        (``ssfm_chirp_setup``; the plan's field is consumed)."""
+        _check(load().ssfm_chirp_setup(self._h, self.n, int(n)), "ssfm_chirp_setup")
 
     def load_pulse(self, kind: int, npts: int, start: float, step: float, stop: float, pow2m: int, params):
         """field <- one of the DAC's built-in pulses over ``linspace(start, stop, npts)``, zero-padded (``ssfm_load_pulse``)."""
@@ -665,16 +647,13 @@ class Plan:
     def table_from_field(self, slot: int):
         _check(load().ssfm_table_from_field(self._h, int(slot)), "ssfm_table_from_field")
 
-    def chirp_pre(self, A: "DeviceArray", P, chirp: "DeviceArray", gamma: float, hh: float):
-        _check(load().ssfm_chirp_pre(self._h, self.n, self.batch, _VP(A.ptr), None if P is None else _VP(P.ptr), _VP(chirp.ptr), A.shape[-1],
-                                     float(gamma), float(hh)), "ssfm_chirp_pre")
+    def chirp_transfer(self, A: "DeviceArray", chirp: "DeviceArray", tab: "DeviceArray", exponent: bool):
+        """Rows of ``A`` (batch, n complex128) <- ifft(fft(row) * tab), or * exp(tab) with ``exponent`` (``ssfm_chirp_transfer``); asynchronous."""
+        _check(load().ssfm_chirp_transfer(self._h, self.n, self.batch, _VP(A.ptr), _VP(chirp.ptr), _VP(tab.ptr), A.shape[-1], 1 if exponent else 0), "ssfm_chirp_transfer")
 
-    def chirp_mid(self, tab: "DeviceArray", h: float, mode: int):
-        _check(load().ssfm_chirp_mid(self._h, self.n, self.batch, _VP(tab.ptr), tab.shape[-1], float(h), int(mode)), "ssfm_chirp_mid")
-
-    def chirp_post(self, A: "DeviceArray", P, chirp: "DeviceArray", gamma: float, hh: float, maxbits=None):
-        _check(load().ssfm_chirp_post(self._h, self.n, self.batch, _VP(A.ptr), None if P is None else _VP(P.ptr), _VP(chirp.ptr), A.shape[-1],
-                                      float(gamma), float(hh), None if maxbits is None else _VP(maxbits.ptr)), "ssfm_chirp_post")
+    def chirp_fourier(self, A: "DeviceArray", chirp: "DeviceArray", chirp_conj: "DeviceArray", inverse: bool):
+        """Rows of ``A`` (batch, n complex128) <- numpy.fft.fft / ifft of the row (``ssfm_chirp_fourier``); asynchronous."""
+        _check(load().ssfm_chirp_fourier(self._h, self.n, self.batch, _VP(A.ptr), _VP(chirp.ptr), _VP(chirp_conj.ptr), A.shape[-1], 1 if inverse else 0), "ssfm_chirp_fourier")
 
     def chirp_propagate(self, A: "DeviceArray", P: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, hs=None, *, length: float = 0.0,
                         phi_max: float = 0.0, f32: bool = True, max_steps: int = 1 << 20):
@@ -694,59 +673,35 @@ class Plan:
                "ssfm_chirp_propagate")
         return int(steps.value), z[: int(steps.value) + 1]
 
-    def chirp_small(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, hs) -> bool:
-        """A fixed-step chirp-z run of ``A`` (batch, n <= plan length / 2; the PLAN's precision) in one launch (ssfm_chirp_small).  False: this plan has no
-        such engine (nothing was launched)."""
-        hs = np.ascontiguousarray(hs, dtype=np.float64)
-        hs = hs[hs != 0.0]                      # (a step of length zero is the identity)
-        if hs.size == 0:
+    def chirp_propagate_c64(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, hs=None, *, length: float = 0.0, phi_max: float = 0.0,
+                            max_steps: int = 1 << 17):
+        """A chirp-z run of ``A`` (batch, n <= plan length / 2; complex64) in ONE launch on this complex64 plan's line (``ssfm_chirp_propagate_c64``): a
+        workgroup per row up to 4096 points of line, the one-XCD engine above.  ``hs``: float64 host array of step sizes (fixed step; a step of length zero is
+        the identity) -> True, or None for the adaptive rule over ``length`` -> (steps, z).  False / None: the plan has no such engine or schedule, or the
+        launch's workgroups did not meet -- ``A`` is then as it was."""
+        steps = _I64(0)
+        if hs is not None:
+            hs = np.ascontiguousarray(hs, dtype=np.float64)
+            hs = hs[hs != 0.0]
+            if hs.size == 0:
+                return True
+            rc = load().ssfm_chirp_propagate_c64(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), hs.ctypes.data_as(C.POINTER(_D)), hs.size,
+                                                 0.0, 0.0, 1, None, C.byref(steps))
+            if rc == 2:
+                return False
+            _check(rc, "ssfm_chirp_propagate_c64")
             return True
-        rc = load().ssfm_chirp_small(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), hs.ctypes.data_as(C.POINTER(_D)), hs.size)
-        if rc == 2:
-            return False
-        _check(rc, "ssfm_chirp_small")
-        return True
-
-    def chirp_medium(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, hs) -> bool:
-        """A fixed-step chirp-z run of ``A`` (batch, 2048 < n <= plan length / 2; complex64) in one launch on one XCD between two pointwise ones
-        (ssfm_chirp_medium; synchronous).  False: this plan has no such engine, the schedule has more than four step sizes, or the launch's workgroups did not
-        meet -- ``A`` is then as it was."""
-        hs = np.ascontiguousarray(hs, dtype=np.float64)
-        hs = hs[hs != 0.0]                      # (a step of length zero is the identity)
-        if hs.size == 0:
-            return True
-        rc = load().ssfm_chirp_medium(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), hs.ctypes.data_as(C.POINTER(_D)), hs.size)
-        if rc == 2:
-            return False
-        _check(rc, "ssfm_chirp_medium")
-        return True
-
-    def chirp_medium_adapt(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, length: float, phi_max: float, max_steps: int):
-        """The adaptive run of ``chirp_medium`` (ssfm_chirp_medium_adapt).  Returns (steps, z) or None (``A`` as it was)."""
         z = np.zeros(int(max_steps) + 1, np.float64)
-        steps = _I64(0)
-        rc = load().ssfm_chirp_medium_adapt(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), float(length), float(phi_max),
-                                            int(max_steps), z.ctypes.data_as(C.POINTER(_D)), C.byref(steps))
+        rc = load().ssfm_chirp_propagate_c64(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), None, 0, float(length), float(phi_max),
+                                             int(max_steps), z.ctypes.data_as(C.POINTER(_D)), C.byref(steps))
         if rc == 2:
             return None
-        _check(rc, "ssfm_chirp_medium_adapt")
-        return int(steps.value), z[: int(steps.value) + 1]
-
-    def chirp_small_adapt(self, A: "DeviceArray", chirp: "DeviceArray", Dt: "DeviceArray", gamma: float, length: float, phi_max: float, f32: bool, max_steps: int):
-        """The adaptive run in one launch (ssfm_chirp_small_adapt).  Returns (steps, z) or None when the plan has no such engine or its rows' workgroups did not
-        meet (the field is then as it came)."""
-        z = np.zeros(int(max_steps) + 1, dtype=np.float64)
-        steps = _I64(0)
-        rc = load().ssfm_chirp_small_adapt(self._h, _VP(A.ptr), _VP(chirp.ptr), _VP(Dt.ptr), A.shape[-1], float(gamma), float(length), float(phi_max), 1 if f32 else 0,
-                                           int(max_steps), z.ctypes.data_as(C.POINTER(_D)), C.byref(steps))
-        if rc == 2:
-            return None
-        _check(rc, "ssfm_chirp_small_adapt")
+        _check(rc, "ssfm_chirp_propagate_c64")
         return int(steps.value), z[: int(steps.value) + 1]
 
     def debug_fft(self) -> np.ndarray:
         out = host_empty((self.batch, self.n), self.cdtype)
-        _check(load().ssfm_debug_fft(self._h, _ptr(out)), "ssfm_debug_fft")
+        _check(load().ssfm_debug(self._h, 0, 0, _ptr(out)), "ssfm_debug")
         return out
 
     def synchronize(self):
@@ -758,9 +713,10 @@ class Plan:
 
     @property
     def lanes(self) -> int:
-        n = _I(0)
-        _check(load().ssfm_num_lanes(self._h, C.byref(n)), "ssfm_num_lanes")
-        return n.value
+        """Row groups a fixed-step run drives on separate streams, as configured at creation (``ssfm_run_info.lanes_configured``)."""
+        r = RunInfo()
+        _check(load().ssfm_last_run_info(self._h, C.byref(r), C.sizeof(r)), "ssfm_last_run_info")
+        return int(r.lanes_configured)
 
     def kernel_times(self):
         """{'k_time': (launches, total_ms), 'k_freq': (launches, total_ms)} of the last profiled run."""
@@ -782,8 +738,8 @@ class Plan:
                 "lane_pair_us": float(r.lane_pair_us), "lane_last_us": float(r.lane_last_us), "lane_score": float(r.lane_score)}
 
     def lane_fault(self, mode: int):
-        """Test hook of the lane health check (include/ssfm_amd.h ``ssfm_debug_lane_fault``)."""
-        _check(load().ssfm_debug_lane_fault(self._h, int(mode)), "ssfm_debug_lane_fault")
+        """Test hook of the lane health check (include/ssfm_amd.h ``ssfm_debug``, SSFM_DEBUG_LANE_FAULT)."""
+        _check(load().ssfm_debug(self._h, 1, int(mode), None), "ssfm_debug")
 
     def last_propagate_ms(self):
         ms, n = C.c_float(0), _I64(0)

@@ -123,8 +123,8 @@ struct Target {
 };
 int target_of(ssfm_plan* plan, long long n, long long M, Target* t) {
     if (!plan) return fail(SSFM_ERR_INVALID, "null plan");
-    t->F = static_cast<double2*>(ssfm_field_device_ptr(plan));
-    t->stream = static_cast<hipStream_t>(ssfm_stream(plan));
+    t->F = static_cast<double2*>(ssfm::plan_field(plan));              // (the internal accessors: taking them does not make the plan's one-launch runs synchronous)
+    t->stream = static_cast<hipStream_t>(ssfm::plan_stream(plan));
     t->M = M;
     if (!t->F) return fail(SSFM_ERR_INVALID, "plan has no field buffer");
     if (n < 2 || M < 2 * n - 1) return fail(SSFM_ERR_INVALID, "chirp-z: plan length %lld is shorter than 2 * %lld - 1", M, n);
@@ -133,7 +133,8 @@ int target_of(ssfm_plan* plan, long long n, long long M, Target* t) {
 
 }  // namespace
 
-extern "C" int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh) {
+namespace {
+int chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh) {
     Target t;
     if (int rc = target_of(plan, n, plan_n, &t)) return rc;
     if (!A || !chirp) return fail(SSFM_ERR_INVALID, "ssfm_chirp_pre: NULL argument");
@@ -143,7 +144,7 @@ extern "C" int ssfm_chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const 
     return SSFM_OK;
 }
 
-extern "C" int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode) {
+int chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode) {
     Target t;
     if (int rc = target_of(plan, n, plan_n, &t)) return rc;
     if (!tab || mode < 0 || mode > 1) return fail(SSFM_ERR_INVALID, "ssfm_chirp_mid: bad argument");
@@ -152,16 +153,40 @@ extern "C" int ssfm_chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const 
     return SSFM_OK;
 }
 
-extern "C" int ssfm_chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh,
-                               void* maxbits_dev) {
+int chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh, void* maxbits_dev, double scale) {
     Target t;
     if (int rc = target_of(plan, n, plan_n, &t)) return rc;
     if (!A || !chirp || (gamma != 0.0 && !P)) return fail(SSFM_ERR_INVALID, "ssfm_chirp_post: NULL argument");
     if (maxbits_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), t.stream));
     hipLaunchKernelGGL(k_chirp_post, dim3(blocks_for((long long)n * batch)), dim3(256), 0, t.stream, (double2*)A, (const double*)P, (const double2*)chirp,
-                       (const double2*)t.F, (long long)n, t.M, batch, gamma, hh, 1.0 / (double)n, (unsigned long long*)maxbits_dev, (const ChirpCtl*)nullptr);
+                       (const double2*)t.F, (long long)n, t.M, batch, gamma, hh, scale, (unsigned long long*)maxbits_dev, (const ChirpCtl*)nullptr);
     HIP_TRY(hipGetLastError());
     return SSFM_OK;
+}
+}  // namespace
+
+// x <- ifft_n(fft_n(x) * tab) (exponent = 0: DM's H, any transfer function) or * exp(tab) (exponent != 0) for every row of the DEVICE array A (batch x n
+// complex128, in place) on a complex128 plan of plan_n >= 2n - 1 points that ssfm_chirp_setup has prepared for n; `tab`: n complex128 on the DEVICE.
+// Asynchronous on the plan's stream.  (reference: DM for any length, devices.py:1019-1035 over numpy.fft)
+extern "C" int ssfm_chirp_transfer(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* tab, int64_t n, int exponent) {
+    if (int rc = chirp_pre(plan, plan_n, batch, A, nullptr, chirp, n, 0.0, 0.0)) return rc;
+    if (int rc = ssfm_apply_table(plan, 0)) return rc;
+    if (int rc = chirp_mid(plan, plan_n, batch, tab, n, exponent ? 1.0 : 0.0, exponent ? 0 : 1)) return rc;
+    if (int rc = ssfm_apply_table(plan, 1)) return rc;
+    return chirp_post(plan, plan_n, batch, A, nullptr, chirp, n, 0.0, 0.0, nullptr, 1.0 / (double)n);
+}
+// fft (inverse = 0, unscaled like numpy.fft.fft) or ifft (inverse != 0, with its 1/n) of every row of A (batch x n complex128, DEVICE, in place):
+//   fft(x)_k = c_k sum_m (x_m c_m) conj(c)_{k-m};   ifft(X)_m = conj(c_m) / n sum_k (X_k conj(c_k)) c_{m-k}.     chirp = c, chirp_conj = conj(c) (ssfm_device_chirp).
+// Asynchronous on the plan's stream.  (reference: signal('w') / signal('t'), typing.py:1421-1462)
+extern "C" int ssfm_chirp_fourier(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* chirp_conj, int64_t n, int inverse) {
+    if (inverse) {
+        if (int rc = chirp_pre(plan, plan_n, batch, A, nullptr, chirp_conj, n, 0.0, 0.0)) return rc;
+        if (int rc = ssfm_apply_table(plan, 1)) return rc;
+        return chirp_post(plan, plan_n, batch, A, nullptr, chirp, n, 0.0, 0.0, nullptr, 1.0 / (double)n);         // * conj(c) / n
+    }
+    if (int rc = chirp_pre(plan, plan_n, batch, A, nullptr, chirp, n, 0.0, 0.0)) return rc;
+    if (int rc = ssfm_apply_table(plan, 0)) return rc;
+    return chirp_post(plan, plan_n, batch, A, nullptr, chirp_conj, n, 0.0, 0.0, nullptr, 1.0);                     // * c: fft carries no 1/n
 }
 
 // ------------------------------------------------------------------------------- a whole run from C
@@ -229,6 +254,11 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     Target t;
     if (int rc = target_of(plan, n, plan_n, &t)) return rc;
     if (!A || !P || !chirp || !Dt) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: NULL argument");
+    {
+        int prec = 0, pb = 0;
+        const int64_t pn = ssfm::plan_length(plan, &pb, &prec);
+        if (prec != SSFM_C128 || pn != plan_n || pb != batch) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: a complex128 plan of %lld x %d is needed", (long long)plan_n, batch);
+    }
     const unsigned gM = blocks_for(t.M * batch), gN = blocks_for((long long)n * batch);
     const double scale = 1.0 / (double)n;
     // A step is FIVE launches (seven in adaptive mode): the middle of it -- inverse pass of the first convolution, product with exp(D~ h), forward pass
@@ -237,7 +267,7 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     // (The nine- and seven-launch forms this grew out of in round 3 -- 33 / 25.6 against 22 us per step at n = 2032, profiles/r03_anyn_small.txt --
     // were removed in round 4 together with their environment switches.)
     double2* mtab = nullptr;
-    if (int rc = ssfm_plan_workspace(plan, 0, sizeof(double2) * (size_t)t.M, reinterpret_cast<void**>(&mtab))) return rc;
+    if (int rc = ssfm::plan_workspace(plan, 0, sizeof(double2) * (size_t)t.M, reinterpret_cast<void**>(&mtab))) return rc;
     double mtab_h = 0.0;
     bool mtab_set = false;
     (void)gM; (void)gN; (void)scale;
@@ -249,10 +279,10 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
             hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
             mtab_h = h; mtab_set = true;
         }
-        ssfm_chirp_io io;
+        ssfm::ChirpStepIO io;
         io.A = A; io.P = P; io.chirp = chirp; io.n = n; io.gamma = gamma; io.hh = 0.5 * h;
         io.h_dev = ctl ? &ctl->h : nullptr; io.done_dev = ctl ? &ctl->done : nullptr; io.maxbits_dev = mb;
-        return ssfm_chirp_step(plan, mtab, &io);
+        return ssfm::plan_chirp_step(plan, mtab, &io);
     };
     std::vector<double> hs_used;
     if (hs) {
@@ -271,7 +301,7 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
         // plans of up to 4096 samples (n <= 2048): the whole schedule in one launch, a workgroup per row (k_small_chirp).  SSFM_CHIRP_SMALL=0: off.
         const char* se = std::getenv("SSFM_CHIRP_SMALL");
         if (nsteps > 0 && t.M <= 4096 && !(se && std::atoi(se) == 0)) {
-            const int rc = ssfm_chirp_small(plan, A, chirp, Dt, n, gamma, hs, nsteps);
+            const int rc = ssfm::plan_chirp_small(plan, A, chirp, Dt, n, gamma, hs, nsteps);
             if (rc == SSFM_OK) {
                 HIP_TRY(hipStreamSynchronize(t.stream));
                 if (steps_out) *steps_out = nsteps_given;
@@ -294,7 +324,7 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
             }
             if (distinct.size() <= 4) {
                 double2* tabs = nullptr;
-                if (int rc = ssfm_plan_workspace(plan, 0, sizeof(double2) * (size_t)t.M * distinct.size(), reinterpret_cast<void**>(&tabs))) return rc;
+                if (int rc = ssfm::plan_workspace(plan, 3, sizeof(double2) * (size_t)t.M * distinct.size(), reinterpret_cast<void**>(&tabs))) return rc;       // (a slot of its own: `mtab` above stays valid for the step loop below)
                 const void* mulp[4] = {nullptr, nullptr, nullptr, nullptr};
                 for (size_t i = 0; i < distinct.size(); ++i) {
                     hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, tabs + i * (size_t)t.M, (long long)n, t.M, distinct[i],
@@ -304,7 +334,7 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
                 hipLaunchKernelGGL(k_chirp_pre, dim3(blocks_for(t.M * batch)), dim3(256), 0, t.stream, (const double2*)A, (double*)nullptr, (const double2*)chirp, t.F,
                                    (long long)n, t.M, batch, 0.0, 0.0, (const ChirpCtl*)nullptr);
                 HIP_TRY(hipGetLastError());
-                const int rc = ssfm_chirp_line_run(plan, mulp, which.data(), hs, nsteps, gamma, n);
+                const int rc = ssfm::plan_chirp_line_run(plan, mulp, which.data(), hs, nsteps, gamma, n);
                 if (rc == SSFM_OK) {
                     hipLaunchKernelGGL(k_chirp_post, dim3(blocks_for((long long)n * batch)), dim3(256), 0, t.stream, (double2*)A, (const double*)nullptr, (const double2*)chirp,
                                        (const double2*)t.F, (long long)n, t.M, batch, 0.0, 0.0, 1.0, (unsigned long long*)nullptr, (const ChirpCtl*)nullptr);
@@ -327,14 +357,14 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     {   // plans of up to 4096 samples: the whole adaptive run in one launch (k_small_chirp_adapt)
         const char* se = std::getenv("SSFM_CHIRP_SMALL");
         if (t.M <= 4096 && gamma != 0.0 && !(se && std::atoi(se) == 0)) {
-            const int rc = ssfm_chirp_small_adapt(plan, A, chirp, Dt, n, gamma, length, phi_max, f32, max_steps, z_out, steps_out);
+            const int rc = ssfm::plan_chirp_small_adapt(plan, A, chirp, Dt, n, gamma, length, phi_max, f32, max_steps, z_out, steps_out);
             if (rc != SSFM_ERR_UNSUPPORTED) return rc;
         }
     }
     ChirpCtl* ctl = nullptr;
     double* zlog = nullptr;
-    if (int wrc = ssfm_plan_workspace(plan, 1, sizeof(ChirpCtl), reinterpret_cast<void**>(&ctl))) return wrc;
-    if (int wrc = ssfm_plan_workspace(plan, 2, sizeof(double) * (size_t)(max_steps + 1), reinterpret_cast<void**>(&zlog))) return wrc;
+    if (int wrc = ssfm::plan_workspace(plan, 1, sizeof(ChirpCtl), reinterpret_cast<void**>(&ctl))) return wrc;
+    if (int wrc = ssfm::plan_workspace(plan, 2, sizeof(double) * (size_t)(max_steps + 1), reinterpret_cast<void**>(&zlog))) return wrc;
     int rc = SSFM_OK;
     ChirpCtl now;
     std::memset(&now, 0, sizeof(now));
@@ -365,6 +395,29 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
         if (steps_out) *steps_out = now.steps;
     } while (false);
     return rc;
+}
+
+// The one-launch engines of complex64 callers behind one entry point: a run of a field of n samples per row (DEVICE, complex64, natural order, advanced in
+// place) on a COMPLEX64 plan whose length is the line's, M = 2^k >= 2n - 1 -- a workgroup per row for M <= 4096 (k_small_chirp[_adapt]), the one-XCD engine for
+// M = 2^13 ... 2^17 with at most 2^17 points in all rows (k_medium_chirp[_adapt]).  chirp (n complex64, DEVICE; ssfm_device_chirp rounded), Dt = D~ (n
+// complex64, DEVICE, natural frequency order).  hs != NULL: fixed step, `nsteps` sizes (HOST; the medium engine: at most four distinct ones).  hs == NULL:
+// the adaptive rule of devices.py:1172-1196 in float32 arithmetic over `length`, at most max_steps steps; z_out (HOST, nullable, max_steps + 1 entries)
+// receives z after every step, *steps_out the steps taken.  Synchronous for the medium engine and adaptive runs; a fixed-step small run is asynchronous on the
+// plan's stream.  SSFM_ERR_UNSUPPORTED with A as it was: the plan has no such engine, or its workgroups did not meet within their patience (the caller takes
+// the complex128 line: ssfm_chirp_propagate).
+extern "C" int ssfm_chirp_propagate_c64(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps,
+                                        double length, double phi_max, int64_t max_steps, double* z_out, int64_t* steps_out) {
+    int prec = 0, batch = 0;
+    const int64_t M = ssfm::plan_length(plan, &batch, &prec);
+    if (M <= 0) return fail(SSFM_ERR_INVALID, "null plan");
+    if (prec != SSFM_C64) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_propagate_c64: a complex64 plan is needed");
+    if (hs) {
+        const int rc = M <= 4096 ? ssfm::plan_chirp_small(plan, A, chirp, Dt, n, gamma, hs, nsteps) : ssfm::plan_chirp_medium(plan, A, chirp, Dt, n, gamma, hs, nsteps);
+        if (rc == SSFM_OK && steps_out) *steps_out = nsteps;
+        return rc;
+    }
+    if (M <= 4096) return ssfm::plan_chirp_small_adapt(plan, A, chirp, Dt, n, gamma, length, phi_max, 1, max_steps, z_out, steps_out);
+    return ssfm::plan_chirp_medium_adapt(plan, A, chirp, Dt, n, gamma, length, phi_max, max_steps, z_out, steps_out);
 }
 
 // --------------------------------------------------------------------------------- pulse shaping (DAC)
@@ -484,7 +537,11 @@ extern "C" int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src
     return SSFM_OK;
 }
 
-extern "C" int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const double* sym_dev, int64_t nsym, int up) {
+namespace ssfm { SSFM_INTERNAL int plan_load_bits(ssfm_plan* plan, int64_t plan_n, const void* bits_dev, int64_t nbits, int up); }      // (prbs.hip)
+extern "C" int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_kind, int64_t nsym, int up) {
+    if (src_kind == 1) return ssfm::plan_load_bits(plan, plan_n, src_dev, nsym, up);
+    if (src_kind != 0) return fail(SSFM_ERR_INVALID, "ssfm_load_symbols: src_kind %d", src_kind);
+    const double* sym_dev = static_cast<const double*>(src_dev);
     Target t;
     if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
     if (!sym_dev || nsym < 1 || up < 1 || nsym * up > plan_n) return fail(SSFM_ERR_INVALID, "ssfm_load_symbols: %lld symbols x %d samples for a plan of %lld", (long long)nsym, up, (long long)plan_n);
@@ -541,11 +598,17 @@ extern "C" int ssfm_device_chirp(int device, void* out_dev, int64_t n, int conj)
     return SSFM_OK;
 }
 
-extern "C" int ssfm_load_chirp_kernel(ssfm_plan* plan, int64_t plan_n, int64_t n, int which) {
+// Both convolution kernels of Bluestein's identity for fields of n samples, generated in the plan's field and transformed there into the resident transfer
+// functions of slots 0 (forward transform) and 1 (inverse): what every other ssfm_chirp_* call on a complex128 plan of plan_n >= 2n - 1 points relies on.
+// Neither a host transform nor an upload.  Asynchronous on the plan's stream; the plan's field is consumed.
+extern "C" int ssfm_chirp_setup(ssfm_plan* plan, int64_t plan_n, int64_t n) {
     Target t;
     if (int rc = target_of(plan, n, plan_n, &t)) return rc;
-    if (which < 0 || which > 1 || n > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_load_chirp_kernel: bad argument");
-    hipLaunchKernelGGL(k_chirp_kernel, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, t.F, (long long)n, t.M, which);
-    HIP_TRY(hipGetLastError());
+    if (n > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_chirp_setup: bad argument");
+    for (int which = 0; which < 2; ++which) {
+        hipLaunchKernelGGL(k_chirp_kernel, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, t.F, (long long)n, t.M, which);
+        HIP_TRY(hipGetLastError());
+        if (int rc = ssfm_table_from_field(plan, which)) return rc;
+    }
     return SSFM_OK;
 }

@@ -128,8 +128,16 @@ __global__ __launch_bounds__(256) void k_min(const double* __restrict__ a, long 
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_real_part(double* __restrict__ dst, const double2* __restrict__ src, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i].x;
+}
+int host_alloc(size_t bytes, void** out);
+int host_free(void* ptr, size_t bytes);
+}
 extern "C" int ssfm_device_alloc(int device, size_t bytes, void** out) {
     if (!out || bytes == 0) return fail(SSFM_ERR_INVALID, "ssfm_device_alloc: bytes=%zu", bytes);
+    if (device == SSFM_HOST_PINNED) return host_alloc(bytes, out);
     if (int rc = use(device)) return rc;
     Pool& p = g_pool[device];
     {
@@ -160,6 +168,7 @@ extern "C" int ssfm_device_alloc(int device, size_t bytes, void** out) {
 
 extern "C" int ssfm_device_free(int device, void* ptr, size_t bytes) {
     if (!ptr) return SSFM_OK;
+    if (device == SSFM_HOST_PINNED) return host_free(ptr, bytes);
     if (int rc = use(device)) return rc;
     Pool& p = g_pool[device];
     {
@@ -178,8 +187,8 @@ extern "C" int ssfm_device_free(int device, void* ptr, size_t bytes) {
 // runtime lock and later unlock the destination pages (measured on the MI355X box: two 2 MiB read-backs leave the NEXT
 // transfer of the process stalled for 20 ms) and takes page faults on every first touch; into a pooled page-locked
 // buffer it is one DMA at link speed.  Pooled by size like the device buffers.
-extern "C" int ssfm_host_alloc(size_t bytes, void** out) {
-    if (!out || bytes == 0) return fail(SSFM_ERR_INVALID, "ssfm_host_alloc: bytes=%zu", bytes);
+namespace {
+int host_alloc(size_t bytes, void** out) {
     {
         std::lock_guard<std::mutex> lock(g_host_pool.mu);
         auto it = g_host_pool.free_by_size.find(bytes);
@@ -194,8 +203,7 @@ extern "C" int ssfm_host_alloc(size_t bytes, void** out) {
     return SSFM_OK;
 }
 
-extern "C" int ssfm_host_free(void* ptr, size_t bytes) {
-    if (!ptr) return SSFM_OK;
+int host_free(void* ptr, size_t bytes) {
     {
         std::lock_guard<std::mutex> lock(g_host_pool.mu);
         if (bytes > 0 && g_host_pool.cached_bytes + bytes <= kMaxCachedHostBytes) {
@@ -207,11 +215,13 @@ extern "C" int ssfm_host_free(void* ptr, size_t bytes) {
     HIP_TRY(hipHostFree(ptr));
     return SSFM_OK;
 }
+}  // namespace
 
 extern "C" int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind) {
-    if (!dst || !src) return fail(SSFM_ERR_INVALID, "ssfm_device_copy: NULL argument");
-    if (kind < 0 || kind > 2) return fail(SSFM_ERR_INVALID, "ssfm_device_copy: kind=%d (0 host->device, 1 device->host, 2 device->device)", kind);
+    if (!dst || (!src && kind != 3)) return fail(SSFM_ERR_INVALID, "ssfm_device_copy: NULL argument");
+    if (kind < 0 || kind > 3) return fail(SSFM_ERR_INVALID, "ssfm_device_copy: kind=%d (0 host->device, 1 device->host, 2 device->device, 3 zero bytes)", kind);
     if (int rc = use(device)) return rc;
+    if (kind == 3) { HIP_TRY(hipMemset(dst, 0, bytes)); return SSFM_OK; }
     const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     HIP_TRY(hipMemcpy(dst, src, bytes, k));
     if (kind == 2) HIP_TRY(hipDeviceSynchronize());          // device-to-device hipMemcpy may return early
@@ -230,6 +240,8 @@ extern "C" int ssfm_device_convert(int device, const void* src, int src_precisio
         hipLaunchKernelGGL((k_widen<double>), dim3(blocks_for(count)), dim3(256), 0, 0, (const double*)src, (double*)dst, (long long)count);
     else if (src_precision == SSFM_F64_REAL && dst_precision == SSFM_C64)
         hipLaunchKernelGGL((k_widen<float>), dim3(blocks_for(count)), dim3(256), 0, 0, (const double*)src, (float*)dst, (long long)count);
+    else if (src_precision == SSFM_C128 && dst_precision == SSFM_F64_REAL)
+        hipLaunchKernelGGL(k_real_part, dim3(blocks_for(count)), dim3(256), 0, 0, (double*)dst, (const double2*)src, (long long)count);
     else
         return fail(SSFM_ERR_INVALID, "ssfm_device_convert: precisions %d -> %d", src_precision, dst_precision);
     HIP_TRY(hipGetLastError());
@@ -354,8 +366,9 @@ extern "C" int ssfm_device_scale_add(int device, double* dst, const double* a, d
     return SSFM_OK;
 }
 
-extern "C" int ssfm_device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out) {
-    if (!a || !mean_out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_mean: bad argument");
+namespace ssfm { SSFM_INTERNAL int device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out); SSFM_INTERNAL int device_min(int device, const double* a, int64_t n, double* min_out); }
+int ssfm::device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out) {
+    if (!a || !mean_out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_reduce (mean): bad argument");
     if (int rc = use(device)) return rc;
     constexpr int kBlocks = 1024;
     double* partial = nullptr;
@@ -364,7 +377,7 @@ extern "C" int ssfm_device_mean(int device, const double* a, const double* b, in
     double host[kBlocks];
     hipError_t e = hipMemcpy(host, partial, sizeof(host), hipMemcpyDeviceToHost);
     (void)ssfm_device_free(device, partial, sizeof(double) * kBlocks);
-    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_mean: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_reduce (mean): %s", hipGetErrorString(e));
     double acc = 0.0;
     for (int i = 0; i < kBlocks; ++i) acc += host[i];
     *mean_out = acc / (double)n;
@@ -389,8 +402,8 @@ extern "C" int ssfm_device_cumsum(int device, double* dst, const double* src, in
     return SSFM_OK;
 }
 
-extern "C" int ssfm_device_min(int device, const double* a, int64_t n, double* min_out) {
-    if (!a || !min_out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_min: bad argument");
+int ssfm::device_min(int device, const double* a, int64_t n, double* min_out) {
+    if (!a || !min_out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_reduce (min): bad argument");
     if (int rc = use(device)) return rc;
     constexpr int kBlocks = 1024;
     double* partial = nullptr;
@@ -399,7 +412,7 @@ extern "C" int ssfm_device_min(int device, const double* a, int64_t n, double* m
     double host[kBlocks];
     hipError_t e = hipMemcpy(host, partial, sizeof(host), hipMemcpyDeviceToHost);
     (void)ssfm_device_free(device, partial, sizeof(double) * kBlocks);
-    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_min: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(SSFM_ERR_HIP, "ssfm_device_reduce (min): %s", hipGetErrorString(e));
     double m = host[0];
     for (int i = 1; i < kBlocks; ++i) m = host[i] < m ? host[i] : m;
     *min_out = m;

@@ -56,13 +56,14 @@ Scratch g_scratch[kMaxDevices];
 
 }  // namespace
 
-extern "C" int ssfm_square_law_device(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise) {
-    if (!sig || !i_sig) return fail(SSFM_ERR_INVALID, "ssfm_square_law_device: NULL argument");
-    if ((noise == nullptr) != (i_noise == nullptr)) return fail(SSFM_ERR_INVALID, "ssfm_square_law_device: noise and i_noise must be given together");
-    if (n_pol < 1 || n_pol > 2 || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_square_law_device: n_pol=%d n=%lld", n_pol, (long long)n);
+namespace {
+int square_law_device(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise) {
+    if (!sig || !i_sig) return fail(SSFM_ERR_INVALID, "ssfm_square_law: NULL argument");
+    if ((noise == nullptr) != (i_noise == nullptr)) return fail(SSFM_ERR_INVALID, "ssfm_square_law: noise and i_noise must be given together");
+    if (n_pol < 1 || n_pol > 2 || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_square_law: n_pol=%d n=%lld", n_pol, (long long)n);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
-        return fail(SSFM_ERR_NO_DEVICE, "ssfm_square_law_device: device %d not available", device);
+        return fail(SSFM_ERR_NO_DEVICE, "ssfm_square_law: device %d not available", device);
     HIP_TRY(hipSetDevice(device));
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     if (noise)
@@ -75,7 +76,9 @@ extern "C" int ssfm_square_law_device(int device, const void* sig, const void* n
     return SSFM_OK;
 }
 
-extern "C" int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise) {
+}  // namespace
+extern "C" int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise, int on_device) {
+    if (on_device) return square_law_device(device, sig, noise, n_pol, n, r, post, i_sig, i_noise);
     if (!sig || !i_sig) return fail(SSFM_ERR_INVALID, "ssfm_square_law: NULL argument");
     if ((noise == nullptr) != (i_noise == nullptr)) return fail(SSFM_ERR_INVALID, "ssfm_square_law: noise and i_noise must be given together");
     if (n_pol < 1 || n_pol > 2 || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_square_law: n_pol=%d n=%lld", n_pol, (long long)n);

@@ -17,6 +17,7 @@
 #include "ssfm_common.hpp"
 
 using ssfm::fail;
+namespace ssfm { SSFM_INTERNAL int plan_load_bits(ssfm_plan* plan, int64_t plan_n, const void* bits_dev, int64_t nbits, int up); }
 
 namespace {
 
@@ -152,12 +153,13 @@ extern "C" int ssfm_prbs(int device, void* bits_dev, int64_t len, int order, uin
     return SSFM_OK;
 }
 
-extern "C" int ssfm_load_bits(ssfm_plan* plan, int64_t plan_n, const void* bits_dev, int64_t nbits, int up) {
+// (behind ssfm_load_symbols(..., src_kind = 1), csrc/chirpz.hip)
+int ssfm::plan_load_bits(ssfm_plan* plan, int64_t plan_n, const void* bits_dev, int64_t nbits, int up) {
     if (!plan) return fail(SSFM_ERR_INVALID, "null plan");
-    double2* F = static_cast<double2*>(ssfm_field_device_ptr(plan));
+    double2* F = static_cast<double2*>(ssfm::plan_field(plan));
     if (!F || !bits_dev || nbits < 1 || up < 1 || nbits * up > plan_n)
-        return fail(SSFM_ERR_INVALID, "ssfm_load_bits: %lld bits x %d samples for a plan of %lld", (long long)nbits, up, (long long)plan_n);
-    hipLaunchKernelGGL(k_load_bits, dim3(blocks_for(plan_n)), dim3(256), 0, static_cast<hipStream_t>(ssfm_stream(plan)), (const uint8_t*)bits_dev,
+        return fail(SSFM_ERR_INVALID, "ssfm_load_symbols: %lld bits x %d samples for a plan of %lld", (long long)nbits, up, (long long)plan_n);
+    hipLaunchKernelGGL(k_load_bits, dim3(blocks_for(plan_n)), dim3(256), 0, static_cast<hipStream_t>(ssfm::plan_stream(plan)), (const uint8_t*)bits_dev,
                        (long long)nbits, up, F, (long long)plan_n);
     HIP_TRY(hipGetLastError());
     return SSFM_OK;
@@ -165,10 +167,10 @@ extern "C" int ssfm_load_bits(ssfm_plan* plan, int64_t plan_n, const void* bits_
 
 extern "C" int ssfm_load_qpsk(ssfm_plan* plan, int64_t plan_n, int rows, const void* bits_dev, int64_t nsym, int sps) {
     if (!plan) return fail(SSFM_ERR_INVALID, "null plan");
-    double2* F = static_cast<double2*>(ssfm_field_device_ptr(plan));
+    double2* F = static_cast<double2*>(ssfm::plan_field(plan));
     if (!F || !bits_dev || nsym < 1 || sps < 1 || rows < 1 || nsym * sps > plan_n)
         return fail(SSFM_ERR_INVALID, "ssfm_load_qpsk: %lld symbols x %d samples for a plan of %lld", (long long)nsym, sps, (long long)plan_n);
-    hipLaunchKernelGGL(k_load_qpsk, dim3(blocks_for(plan_n * rows)), dim3(256), 0, static_cast<hipStream_t>(ssfm_stream(plan)), (const uint8_t*)bits_dev,
+    hipLaunchKernelGGL(k_load_qpsk, dim3(blocks_for(plan_n * rows)), dim3(256), 0, static_cast<hipStream_t>(ssfm::plan_stream(plan)), (const uint8_t*)bits_dev,
                        (long long)nsym, rows, sps, F, (long long)plan_n);
     HIP_TRY(hipGetLastError());
     return SSFM_OK;

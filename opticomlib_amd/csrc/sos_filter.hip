@@ -48,15 +48,10 @@ namespace {
 #endif
 // Samples per thread.  Two lengths (profiles/r03_sosfilt.txt, section 11): SOS_CHUNK for the three-launch form and for short calls
 // (first version: 16 -> 121 us, 32 -> 130 us, 64 -> 158 us per call at 2^20 x 2 complex; later 8 -> 101, 12 -> 90, 16 -> 97; 12 is 4-14 %
-// faster than 16 for every shape from 2^14 to 2^20 x 2), SOS_CHUNK_LONG for the one-launch form of long calls: fewer threads pay the
+// faster than 16 for every shape from 2^14 to 2^20 x 2), kChunkLong for the one-launch form of long calls: fewer threads pay the
 // per-chunk scan and look-back, two workgroups per CU instead of three hold the same samples (2^20 x 2 complex128: 47.5 -> 39.8 us,
 // 2^20 real 33.0 -> 25.3; short calls lose 10-20 % with it).
-#ifndef SOS_CHUNK_LONG
-#define SOS_CHUNK_LONG 18
-#endif
-#ifndef SOS_APPLY_WAVES
-#define SOS_APPLY_WAVES 3
-#endif
+constexpr int kChunkLong = 18;
 constexpr int kWave = 64;          // lanes per wavefront
 #ifndef SOS_WAVES
 #define SOS_WAVES 4
@@ -75,15 +70,9 @@ struct SosCoefs {
     double b0[kMaxSections], b1[kMaxSections], b2[kMaxSections], a1[kMaxSections], a2[kMaxSections];
 };
 
-// SOS_WT: the 16-byte sample stores go out write-through (sc1), as the propagator's do -- the next kernel's readers sit on
+// The 16-byte sample stores go out write-through (sc1), as the propagator's do -- the next kernel's readers sit on
 // other CUs, so a dirty line in this XCD's L2 only adds a flush at the kernel boundary.  2^20 x 2 complex: 90.5 -> 87.5 us,
 // other shapes unchanged; non-temporal loads measured 4 % slower (profiles/r02_sosfilt_policy_ab.txt).
-#ifndef SOS_WT
-#define SOS_WT 1
-#endif
-#ifndef SOS_FUSE
-#define SOS_FUSE 1
-#endif
 // One direction of the forward-backward pass.  Rows hold CH interleaved channels.
 struct SosPass {
     const double* src;      // forward: caller's x; backward: y1 (padded forward output, [row][m][CH])
@@ -159,7 +148,7 @@ constexpr int kChunk = SOS_CHUNK;
 #include "sos_filter_impl.inc"
 }  // namespace chunk_short
 namespace chunk_long {
-constexpr int kChunk = SOS_CHUNK_LONG;
+constexpr int kChunk = kChunkLong;
 #include "sos_filter_impl.inc"
 }  // namespace chunk_long
 
@@ -223,27 +212,14 @@ int sosfiltfilt_impl(int device, const double* sos, const double* zi, int n_sect
 }  // namespace
 
 extern "C" int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
-                                int64_t n, int batch, int is_complex) {
-    return sosfiltfilt_impl(device, sos, zi, n_sections, x, y, n, batch, is_complex, false);
+                                int64_t n, int batch, int is_complex, int on_device) {
+    return sosfiltfilt_impl(device, sos, zi, n_sections, x, y, n, batch, is_complex, on_device != 0);
 }
 
-extern "C" int ssfm_sosfiltfilt_device(int device, const double* sos, const double* zi, int n_sections, const void* x_dev, void* y_dev,
-                                       int64_t n, int batch, int is_complex) {
-    return sosfiltfilt_impl(device, sos, zi, n_sections, x_dev, y_dev, n, batch, is_complex, true);
-}
-
-extern "C" int ssfm_sosfiltfilt_last_launches(int device, int* launches) {
-    if (!launches) return fail(SSFM_ERR_INVALID, "launches is NULL");
-    if (device < 0 || device >= kMaxDevices) return fail(SSFM_ERR_NO_DEVICE, "ssfm_sosfiltfilt_last_launches: device %d", device);
+extern "C" int ssfm_sosfiltfilt_last(int device, float* ms, int* launches) {
+    if (device < 0 || device >= kMaxDevices) return fail(SSFM_ERR_NO_DEVICE, "ssfm_sosfiltfilt_last: device %d", device);
     std::lock_guard<std::mutex> lock(g_ws[device].mu);
-    *launches = g_ws[device].last_launches;
-    return SSFM_OK;
-}
-
-extern "C" int ssfm_sosfiltfilt_last_ms(int device, float* ms) {
-    if (!ms) return fail(SSFM_ERR_INVALID, "ms is NULL");
-    if (device < 0 || device >= kMaxDevices) return fail(SSFM_ERR_NO_DEVICE, "ssfm_sosfiltfilt_last_ms: device %d", device);
-    std::lock_guard<std::mutex> lock(g_ws[device].mu);
-    *ms = g_ws[device].last_ms;
+    if (ms) *ms = g_ws[device].last_ms;
+    if (launches) *launches = g_ws[device].last_launches;
     return SSFM_OK;
 }

@@ -32,13 +32,7 @@ namespace {
 constexpr int kLog2Min = 8, kLog2Max = 22;
 // C, columns per k_time tile: one 128-byte line per row segment in either precision.  (complex128 used 16 as well
 // at first: 512-thread workgroups, one per CU; with 8 the two precisions have the same workgroup shape, two per CU.)
-#ifndef SSFM_COLS_C128
-#define SSFM_COLS_C128 8
-#endif
-#ifndef SSFM_COLS_C64
-#define SSFM_COLS_C64 16
-#endif
-template <typename T> constexpr int cols_per_tile() { return sizeof(T) == 8 ? SSFM_COLS_C128 : SSFM_COLS_C64; }
+template <typename T> constexpr int cols_per_tile() { return sizeof(T) == 8 ? 8 : 16; }
 constexpr int kMaxTables = 4;
 
 // rows per k_freq workgroup: at least 64 threads where the row count allows (N1 >= 16 rows per batch entry)
@@ -59,7 +53,7 @@ hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     else if constexpr (U16 && MODE == TM_MID_L) return hipErrorInvalidValue;                    // (as a launch of its own: plans in the plain layout)
     else if constexpr (MODE == TM_MID_A && N1 != 128 && N1 != 256) return hipErrorInvalidValue;   // (the fused adaptive kernel: plans of 2^14 ... 2^18 samples)
     else {
-    constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+    constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                          + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
@@ -89,7 +83,7 @@ hipError_t launch_time(int N1, int batch, hipStream_t s, TimeArgs<T> a, int E) {
 template <typename T, int MODE, int N2, int E, bool U16>
 hipError_t launch_freq_u(int nrows, hipStream_t s, const FreqArgs<T>& a) {
     constexpr int ROWS = freq_rows(N2, E);
-    constexpr size_t lds = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+    constexpr size_t lds = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
                          + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
     static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
@@ -129,10 +123,8 @@ hipError_t launch_freq(int N2, int nrows, hipStream_t s, FreqArgs<T> a, int E) {
 
 // k_small: one workgroup per row, the whole schedule in one launch.  Points per thread: 8 up to 2048 samples and for
 // complex128 (more wavefronts per row; complex128 with 16 would not fit the registers), 16 for complex64 rows of 4096 / 8192.
-#ifndef SSFM_SMALL_E16_MIN
-#define SSFM_SMALL_E16_MIN 4096
-#endif
-template <typename T> constexpr int small_points(int n) { return sizeof(T) == 4 && n >= SSFM_SMALL_E16_MIN ? 16 : 8; }
+constexpr int kSmallE16Min = 4096;
+template <typename T> constexpr int small_points(int n) { return sizeof(T) == 4 && n >= kSmallE16Min ? 16 : 8; }
 template <typename T> constexpr bool small_supported(int n) {
     return n >= 256 && n <= (sizeof(T) == 4 ? 8192 : 4096) && (n & (n - 1)) == 0;
 }
@@ -213,13 +205,10 @@ template <typename T> __global__ __launch_bounds__(256) void k_cm_post(cx<T>* __
 
 // k_small_chirp: lengths that are not powers of two on one line of the plan's length (complex128), the whole schedule in one launch
 // Points per thread: as k_small.  With 8 points on 512 threads the kernels of the 4096-point line spill (320 bytes of scratch per lane: a workgroup
-// of 512 threads has 256 registers per thread); with 16 points on 256 threads (-DSSFM_CHIRP_E16=1) they do not (256 + 120 accumulation registers),
+// of 512 threads has 256 registers per thread); with 16 points on 256 threads (measured in round 4) they do not (256 + 120 accumulation registers),
 // but four wavefronts per workgroup hide less: fixed step 12.6 us per step at n = 2032 either way, adaptive 23.3 against 16.7 (eight exp(D~ h) per
 // thread and step instead of four).  So 8.
-#ifndef SSFM_CHIRP_E16
-#define SSFM_CHIRP_E16 0
-#endif
-template <typename T> constexpr int chirp_points(int n) { return n == 4096 && SSFM_CHIRP_E16 ? 16 : small_points<T>(n); }
+template <typename T> constexpr int chirp_points(int n) { return small_points<T>(n); }
 template <typename T, int N>
 hipError_t launch_small_chirp_n(int rows, hipStream_t s, const SmallChirpArgs<T>& a) {
     constexpr int E = chirp_points<T>(N);
@@ -695,8 +684,8 @@ template <typename T> struct PlanT : PlanBase {
         Y = F;
         if (u16) HIP_TRY(hipMalloc(&Y, cb * n * batch));
         // inter-pass twiddles W_N^(k1 n2): either the n-entry table in k_time's thread order, or (U16 plans) the two
-        // small factor tables the kernel multiplies (ssfm_kernels.hpp SSFM_TWN_COMPUTE)
-        if (SSFM_TWN_COMPUTE && (u16 || (sizeof(T) == 8 && SSFM_C128_TWC))) {
+        // small factor tables the kernel multiplies (ssfm_kernels.hpp twn_compute)
+        if (u16 || sizeof(T) == 8) {
             const long long nA = (long long)(N1 / E) * N2, nB = (long long)E * N2;      // [tile][j][c], j < N1/E;  [tile][t][c], t < E
             HIP_TRY(hipMalloc(&twA, cb * nA));
             HIP_TRY(hipMalloc(&twB, cb * nB));
@@ -1034,7 +1023,7 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
     // fixed-step runs of a dual-polarisation plan of long rows: one launch per row (see run_medium)
-    bool medium_rows_split() const { return SSFM_MEDIUM_LOCAL && medium_split_ok && batch == 2 && n >= (1ll << 16); }
+    bool medium_rows_split() const { return medium_split_ok && batch == 2 && n >= (1ll << 16); }
     // the whole schedule in one launch (k_medium); `distinct` holds at most kMaxTables step sizes
     int run_medium(T gamma, double gamma_d, const T* h, int64_t nsteps, const std::vector<T>& distinct, bool phase) {
         if constexpr (sizeof(T) != 4) { (void)gamma; (void)gamma_d; (void)h; (void)nsteps; (void)distinct; (void)phase; return fail(SSFM_ERR_STATE, "the medium engine is complex64 only"); }
@@ -1290,8 +1279,8 @@ template <typename T> struct PlanT : PlanBase {
         const long long med_samples = medium_rows_split() ? n : n * batch;
         const bool med_elig = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !profiling
                                && snapshots == nullptr && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
-                               && med_blocks % kBarShards == 0 && med_blocks <= 64 && (!SSFM_MEDIUM_LOCAL || med_samples <= medium_max_samples) && (use_phase || !phase_tables || !op_flat_re);
-        const bool go_small = small_sched && snapshots == nullptr && !(med_elig && SSFM_MEDIUM_LOCAL && n >= 8192);
+                               && med_blocks % kBarShards == 0 && med_blocks <= 64 && med_samples <= medium_max_samples && (use_phase || !phase_tables || !op_flat_re);
+        const bool go_small = small_sched && snapshots == nullptr && !(med_elig && n >= 8192);
         const bool go_medium = med_elig && !go_small;
         last_fell_back = 0;
         last_engine = (go_small || (small_sched && snapshots != nullptr)) ? SSFM_ENGINE_SMALL : go_medium ? SSFM_ENGINE_MEDIUM : SSFM_ENGINE_TWO_KERNEL;
@@ -1512,7 +1501,7 @@ template <typename T> struct PlanT : PlanBase {
         bool med_adapt = false;
         if constexpr (sizeof(T) == 4) {
             const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
-            med_adapt = SSFM_MEDIUM_LOCAL && medium_ok && medium_adapt_ok && fused_ok && !capture && !single_step && u16 && E == 8 && Ef == 8 && Ef_fly == 8 && medium_shape(N1, N2)
+            med_adapt = medium_ok && medium_adapt_ok && fused_ok && !capture && !single_step && u16 && E == 8 && Ef == 8 && Ef_fly == 8 && medium_shape(N1, N2)
                         && twA != nullptr && blocks % kBarShards == 0 && blocks <= kBarWords && n * batch <= medium_max_samples;
         }
         if (small && !capture && small_adapt_supported<T>((int)n, batch) && !(med_adapt && n == 4096 && batch == 2)) {
@@ -1845,7 +1834,7 @@ template <typename T> struct PlanT : PlanBase {
     // launch (k_time<TM_MID> with TimeArgs::mul).  Five launches instead of seven.  Plain layout only (complex128 plans; complex64 plans of the plain layout).
     // `io` (nullable; complex128 plans): a chirp-z step's two ends folded into the first and the last launch (ChirpIO, ssfm_kernels.hpp) -- the caller's
     // field in, the caller's field out, the plan's own field buffer untouched.
-    int apply_tables_mul(const void* mul_dev, const ssfm_chirp_io* io = nullptr) {
+    int apply_tables_mul(const void* mul_dev, const ssfm::ChirpStepIO* io = nullptr) {
         if (!xfer_tab[0] || !xfer_tab[1]) return fail(SSFM_ERR_STATE, "ssfm_apply_tables_mul: slots 0 and 1 must hold tables");
         if (u16) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_apply_tables_mul: not for plans in the 16-byte-unit layout");
         if (!mul_dev) return fail(SSFM_ERR_INVALID, "ssfm_apply_tables_mul: NULL table");
@@ -1993,7 +1982,7 @@ template <typename T> struct PlanT : PlanBase {
         if constexpr (sizeof(T) != 4) { (void)nn; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
         else {
         const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
-        if (!SSFM_MEDIUM_LOCAL || !medium_ok || !u16 || E != 8 || Ef != 8 || !medium_shape(N1, N2) || n < 8192 || blocks % kBarShards != 0 || blocks > 64
+        if (!medium_ok || !u16 || E != 8 || Ef != 8 || !medium_shape(N1, N2) || n < 8192 || blocks % kBarShards != 0 || blocks > 64
             || n * batch > medium_max_samples || medium_xcc < 0)
             return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: a complex64 plan of 2^13 ... 2^17 points (2^17 in all rows) with the one-XCD engine is needed");
         if (nn < 2 || 2 * nn - 1 > n) return fail(SSFM_ERR_INVALID, "ssfm_chirp_medium: %lld samples do not fit a line of %lld", (long long)nn, (long long)n);
@@ -2281,11 +2270,22 @@ template <typename PT> static int run_info_impl(PT* P_, ssfm_run_info* info, siz
     ssfm_run_info r;
     std::memset(&r, 0, sizeof(r));
     r.engine = P_->last_engine; r.fell_back = P_->last_fell_back; r.fallbacks_total = P_->fallbacks;
-    r.lanes = P_->lanes_active; r.lanes_share_queue = P_->lanes_share_queue ? 1 : 0; r.lanes_remade = P_->lanes_remade; r.lanes_dropped = P_->lanes_dropped;
+    r.lanes = P_->lanes_active; r.lanes_configured = P_->nlanes; r.lanes_share_queue = P_->lanes_share_queue ? 1 : 0; r.lanes_remade = P_->lanes_remade; r.lanes_dropped = P_->lanes_dropped;
     r.lane_heals = P_->lane_heals;
     r.lane_alone_us = P_->lane_alone_us; r.lane_pair_us = P_->lane_pair_us; r.lane_last_us = P_->lane_last_us; r.lane_score = P_->lane_score;
     std::memcpy(info, &r, bytes < sizeof(r) ? bytes : sizeof(r));
     return SSFM_OK;
+}
+}  // namespace
+
+namespace {
+// A caller that takes the stream or the field pointer may order its own work behind a run without ssfm_synchronize -- also behind a run that is ALREADY
+// queued: a one-launch run of a medium plan that is still pending is resolved here (waited for, checked, repeated on the two-kernel engine if its
+// workgroups did not meet), so that what the caller orders on the stream finds the run's real result.  nullptr (ssfm_last_error set) if that fails.
+template <typename PT> static bool mark_external(PT* P_) {
+    P_->external_order = true;
+    if (!P_->medium_pending) return true;
+    return P_->use_device() == SSFM_OK && P_->finish_medium() == SSFM_OK;
 }
 }  // namespace
 
@@ -2368,10 +2368,9 @@ int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device) {
 }
 void* ssfm_field_device_ptr(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); P_->external_order = true; return P_->F; }
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return mark_external(P_) ? P_->F : nullptr; }
     auto* P_ = static_cast<PlanT<double>*>(plan->impl);
-    P_->external_order = true;
-    return P_->F;
+    return mark_external(P_) ? P_->F : nullptr;
 }
 
 int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, void* snapshots) {
@@ -2406,53 +2405,32 @@ int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out
     WITH_PLAN(plan, P_->apply_dispersion(dt_s, D_s2, H_out));
 }
 
-int ssfm_debug_fft(ssfm_plan* plan, void* dst) {
-    if (!dst) return fail(SSFM_ERR_INVALID, "dst is NULL");
-    WITH_PLAN(plan, P_->debug_fft(dst));
-}
-
 int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot) {
     if (!H_host) return fail(SSFM_ERR_INVALID, "H_host is NULL");
     WITH_PLAN(plan, P_->transfer_table(H_host, slot));
 }
 int ssfm_apply_table(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->apply_table(slot)); }
-int ssfm_apply_tables_mul(ssfm_plan* plan, const void* mul_dev) { WITH_PLAN(plan, P_->apply_tables_mul(mul_dev)); }
-int ssfm_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
-    WITH_PLAN(plan, P_->chirp_small(A, chirp, Dt, n, gamma, hs, nsteps));
-}
-int ssfm_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int f32,
-                           int64_t max_steps, double* z_out, int64_t* steps_out) {
-    WITH_PLAN(plan, P_->chirp_small_adapt(A, chirp, Dt, n, gamma, length, phi_max, f32, max_steps, z_out, steps_out));
-}
-int ssfm_chirp_step(ssfm_plan* plan, const void* mul_dev, const ssfm_chirp_io* io) {
-    if (!io) return fail(SSFM_ERR_INVALID, "ssfm_chirp_step: NULL field description");
-    WITH_PLAN(plan, P_->apply_tables_mul(mul_dev, io));
-}
-int ssfm_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep) {
-    WITH_PLAN(plan, P_->chirp_line_run(mul, which, hs, nsteps, gamma, keep));
-}
-int ssfm_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
-    WITH_PLAN(plan, P_->chirp_medium(A, chirp, Dt, n, gamma, hs, nsteps));
-}
-int ssfm_chirp_medium_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int64_t max_steps,
-                            double* z_out, int64_t* steps_out) {
-    WITH_PLAN(plan, P_->chirp_medium_adapt(A, chirp, Dt, n, gamma, length, phi_max, max_steps, z_out, steps_out));
-}
 int ssfm_table_from_field(ssfm_plan* plan, int slot) { WITH_PLAN(plan, P_->table_from_field(slot)); }
 int ssfm_synchronize(ssfm_plan* plan) { WITH_PLAN(plan, sync_impl(P_)); }
 
 void* ssfm_stream(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); P_->external_order = true; return P_->stream; }
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return mark_external(P_) ? P_->stream : nullptr; }
     auto* P_ = static_cast<PlanT<double>*>(plan->impl);
-    P_->external_order = true;
-    return P_->stream;
+    return mark_external(P_) ? P_->stream : nullptr;
 }
 
-int ssfm_plan_workspace(ssfm_plan* plan, int slot, size_t bytes, void** out) { WITH_PLAN(plan, P_->workspace(slot, bytes, out)); }
 
-int ssfm_debug_lane_fault(ssfm_plan* plan, int mode) {
-    WITH_PLAN(plan, (P_->lane_fault = mode, P_->lane_pair_us = mode ? P_->lane_pair_us * 0.25f : P_->lane_pair_us, (int)SSFM_OK));
+int ssfm_debug(ssfm_plan* plan, int what, int64_t arg, void* dst) {
+    if (what == SSFM_DEBUG_FFT) {
+        if (!dst) return fail(SSFM_ERR_INVALID, "ssfm_debug: dst is NULL");
+        WITH_PLAN(plan, P_->debug_fft(dst));
+    }
+    if (what == SSFM_DEBUG_LANE_FAULT) {
+        const int mode = (int)arg;
+        WITH_PLAN(plan, (P_->lane_fault = mode, P_->lane_pair_us = mode ? P_->lane_pair_us * 0.25f : P_->lane_pair_us, (int)SSFM_OK));
+    }
+    return fail(SSFM_ERR_INVALID, "ssfm_debug: what = %d", what);
 }
 int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes) {
     if (!info || info_bytes < 2 * sizeof(int)) return fail(SSFM_ERR_INVALID, "ssfm_last_run_info: info is NULL or too small");
@@ -2462,10 +2440,6 @@ int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes) 
 int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches) { WITH_PLAN(plan, last_ms_impl(P_, ms, launches)); }
 
 int ssfm_set_profiling(ssfm_plan* plan, int mode) { WITH_PLAN(plan, (P_->profiling = mode != 0, P_->prof_mode = mode, (int)SSFM_OK)); }
-int ssfm_num_lanes(ssfm_plan* plan, int* lanes) {
-    if (!lanes) return fail(SSFM_ERR_INVALID, "NULL output");
-    WITH_PLAN(plan, (*lanes = P_->nlanes, (int)SSFM_OK));
-}
 int ssfm_plan_set_tag(ssfm_plan* plan, int which, uint64_t tag) {
     if (which < 0 || which > 2) return fail(SSFM_ERR_INVALID, "ssfm_plan_set_tag: which = %d", which);
     WITH_PLAN(plan, (P_->tags[which] = tag, (int)SSFM_OK));
@@ -2480,3 +2454,47 @@ int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]) {
 }
 
 }  // extern "C"
+
+// ---- the library's own cross-unit entry points (ssfm_common.hpp): not part of the C ABI
+namespace ssfm {
+void* plan_stream(ssfm_plan* plan) {
+    if (!plan || !plan->impl) return nullptr;
+    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->stream;
+    return static_cast<PlanT<double>*>(plan->impl)->stream;
+}
+void* plan_field(ssfm_plan* plan) {
+    if (!plan || !plan->impl) return nullptr;
+    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->F;
+    return static_cast<PlanT<double>*>(plan->impl)->F;
+}
+int64_t plan_length(ssfm_plan* plan, int* batch, int* precision) {
+    if (!plan || !plan->impl) return 0;
+    if (precision) *precision = plan->impl->precision;
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); if (batch) *batch = P_->batch; return P_->n; }
+    auto* P_ = static_cast<PlanT<double>*>(plan->impl);
+    if (batch) *batch = P_->batch;
+    return P_->n;
+}
+int plan_workspace(ssfm_plan* plan, int slot, size_t bytes, void** out) { WITH_PLAN(plan, P_->workspace(slot, bytes, out)); }
+int plan_chirp_step(ssfm_plan* plan, const void* mul_dev, const ChirpStepIO* io) {
+    if (!io) return fail(SSFM_ERR_INVALID, "chirp step: NULL field description");
+    WITH_PLAN(plan, P_->apply_tables_mul(mul_dev, io));
+}
+int plan_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep) {
+    WITH_PLAN(plan, P_->chirp_line_run(mul, which, hs, nsteps, gamma, keep));
+}
+int plan_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
+    WITH_PLAN(plan, P_->chirp_small(A, chirp, Dt, n, gamma, hs, nsteps));
+}
+int plan_chirp_small_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int f32,
+                           int64_t max_steps, double* z_out, int64_t* steps_out) {
+    WITH_PLAN(plan, P_->chirp_small_adapt(A, chirp, Dt, n, gamma, length, phi_max, f32, max_steps, z_out, steps_out));
+}
+int plan_chirp_medium(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
+    WITH_PLAN(plan, P_->chirp_medium(A, chirp, Dt, n, gamma, hs, nsteps));
+}
+int plan_chirp_medium_adapt(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, double length, double phi_max, int64_t max_steps,
+                            double* z_out, int64_t* steps_out) {
+    WITH_PLAN(plan, P_->chirp_medium_adapt(A, chirp, Dt, n, gamma, length, phi_max, max_steps, z_out, steps_out));
+}
+}  // namespace ssfm

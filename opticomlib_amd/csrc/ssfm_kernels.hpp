@@ -15,66 +15,27 @@
 #pragma once
 #include "wgfft.hpp"
 
-// Timing-only ablation knobs for tools/ablate.sh (results are WRONG when any is set).
-#ifndef SSFM_ABL_NO_TWN
-#define SSFM_ABL_NO_TWN 0
+// Timing-only ablation builds for tools/ablate.sh (results are WRONG when any bit is set): -DSSFM_ABLATE=<bits>
+//   1 no inter-pass twiddle loads   2 no |A|^2 traffic   4 no operator table loads   8 no transforms   16 no nonlinear rotation
+#ifndef SSFM_ABLATE
+#define SSFM_ABLATE 0
 #endif
-#ifndef SSFM_ABL_NO_P
-#define SSFM_ABL_NO_P 0
-#endif
-#ifndef SSFM_ABL_NO_TAB
-#define SSFM_ABL_NO_TAB 0
-#endif
-#ifndef SSFM_ABL_NO_FFT
-#define SSFM_ABL_NO_FFT 0
-#endif
-#ifndef SSFM_ABL_NO_NL
-#define SSFM_ABL_NO_NL 0
-#endif
-#ifndef SSFM_LATE_TAB
-#define SSFM_LATE_TAB 0
-#endif
-#ifndef SSFM_WORD_BARRIER_ALL
-#define SSFM_WORD_BARRIER_ALL 1
-#endif
-#ifndef SSFM_RELAXED_BARRIER
-#define SSFM_RELAXED_BARRIER 1
-#endif
-#ifndef SSFM_LATE_P
-#define SSFM_LATE_P 2
-#endif
-// SSFM_HEAD_ORDER 1: the small tables a workgroup stages through LDS (stage twiddles, the inter-pass twiddle factors) are asked for BEFORE the
-// field loads and committed to LDS while the field is on its way (wgfft.hpp line_twiddles_prefetch); 0: in the order of round 3
-#ifndef SSFM_HEAD_ORDER
-#define SSFM_HEAD_ORDER 1
-#endif
-#ifndef SSFM_EARLY_PHASE
-#define SSFM_EARLY_PHASE 1
-#endif
-#ifndef SSFM_KERNARG_UPFRONT
-#define SSFM_KERNARG_UPFRONT 0          // (superseded by the kernel-argument preload of k_time / k_freq: the leading scalars are in SGPRs when the wave starts)
-#endif
+#define SSFM_ABL_NO_TWN ((SSFM_ABLATE & 1) != 0)
+#define SSFM_ABL_NO_P ((SSFM_ABLATE & 2) != 0)
+#define SSFM_ABL_NO_TAB ((SSFM_ABLATE & 4) != 0)
+#define SSFM_ABL_NO_FFT ((SSFM_ABLATE & 8) != 0)
+#define SSFM_ABL_NO_NL ((SSFM_ABLATE & 16) != 0)
 
-#ifndef SSFM_LATE_P_C128
-#define SSFM_LATE_P_C128 1
-#endif
-// 1: form the inter-pass twiddles in the kernel from two small tables (U16 plans); 0: stream the N-entry table.
-// One complex multiply per point against 8 bytes per point of table traffic: 20.8 vs 21.6 us per step alone, 18.1 vs
-// 20.7 together with the memory policy below (profiles/r02_ab_u16_sc1_twnc.txt)
-#ifndef SSFM_TWN_COMPUTE
-#define SSFM_TWN_COMPUTE 1
-#endif
-// SSFM_C128_POLICY: 1 = complex128 plans (16-byte elements as they are) use the same memory policy and in-kernel twiddles
-#ifndef SSFM_C128_POLICY
-#define SSFM_C128_POLICY 0
-#endif
-template <typename T, bool U16> __host__ __device__ constexpr bool stream_policy() { return U16 || (sizeof(T) == 8 && SSFM_C128_POLICY != 0); }
-// SSFM_C128_TWC: in-kernel inter-pass twiddles for complex128 plans too (C1 43.7 -> 42.8 us per step, and 16 MiB less table
-// memory per 2^20 plan; the write-through / non-temporal policy LOSES 2 % there: profiles/r02_c128_policy_ab.txt)
-#ifndef SSFM_C128_TWC
-#define SSFM_C128_TWC 1
-#endif
-template <typename T, bool U16> __host__ __device__ constexpr bool twn_compute() { return SSFM_TWN_COMPUTE != 0 && (U16 || (sizeof(T) == 8 && SSFM_C128_TWC != 0)); }
+// Decided by measurement in rounds 2-4 and no longer switchable (the A/Bs are under profiles/: r02_ab_u16_sc1_twnc.txt, r02_ab_policy.txt,
+// r02_c128_policy_ab.txt, r03_ablation_and_knobs.txt, r03_relaxed_barrier.txt, r04_c2_micro.txt, r04_c1_variants.txt):
+//  * the small tables a workgroup stages through LDS are asked for BEFORE the field loads, k_freq's phase / operator loads go out before the field loads
+//    and the factors are formed while the field is on its way; kernel arguments arrive preloaded in SGPRs;
+//  * |A|^2 of the step's start is loaded after the inverse transform's first stage (every mode that reads it, both precisions);
+//  * inter-pass twiddles W_N^(k1 n2) are formed in the kernel from two small tables: U16 plans (20.8 vs 21.6 us per step alone, 18.1 vs 20.7 with the memory
+//    policy) and complex128 plans (43.7 -> 42.8); the write-through / non-temporal policy is for the U16 plans only (it loses 2 % in complex128);
+//  * in-kernel barriers that only atomics or acknowledged write-through data cross carry no fence (an agent-scope fence writes back / invalidates the XCD's L2).
+template <typename T, bool U16> __host__ __device__ constexpr bool stream_policy() { return U16; }
+template <typename T, bool U16> __host__ __device__ constexpr bool twn_compute() { return U16 || sizeof(T) == 8; }
 
 // Launch-level trace for tools/trace_timeline.py (diagnostic builds only: -DSSFM_TRACE=1).  Every
 // workgroup folds its start / end time (s_memrealtime, 100 MHz) into 4 words of its launch's slot.
@@ -198,11 +159,8 @@ __host__ __device__ __forceinline__ long long time_tw_pos(long long k1, long lon
 // (h, j mod 4, c8) loads the unit of row j + Q1 (2g + h), and ONE v_permlane32_swap per dword hands the h = 1
 // column's half to lane + 32 and takes that lane's h = 0 half (wavefront shuffle instead of a second pass
 // through memory): afterwards every thread holds rows 2g and 2g+1 of ITS column, as in the plain layout.
-#ifndef SSFM_U16
-#define SSFM_U16 1
-#endif
 template <typename T> __host__ __device__ constexpr bool u16_layout(int N1, int C, int E) {
-    return SSFM_U16 != 0 && sizeof(T) == 4 && C == 16 && ((N1 / E) % 4) == 0 && N1 / E >= 4;
+    return sizeof(T) == 4 && C == 16 && ((N1 / E) % 4) == 0 && N1 / E >= 4;
 }
 // natural column of position `pos` of a row in the U16 order (inverse of freq_tab_pos)
 __host__ __device__ __forceinline__ long long u16_col_of_pos(long long pos, int Qf) {
@@ -253,9 +211,9 @@ template <typename T> struct TimeArgs {
                               // reads and writes the same columns, every kernel works in place.  U16 layout: a tile's
                               // columns and its positions in the row order differ, so BEGIN / END go from one buffer to the other
     T* P;                     // stale |A|^2, tile-major (private to k_time)
-    const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]                      (SSFM_TWN_COMPUTE == 0)
+    const cx<T>* twN;         // W_N^(k1*n2) at [k1*N2 + n2]                      (plans without the in-kernel twiddles)
     const cx<T>* twA;         // [tile][j][c] = W_N^(j n2),        j < N1/E   W_N^(k1 n2) = twA * twB,  k1 = j + t N1/E,
-    const cx<T>* twB;         // [tile][t][c] = W_N^(t n2 N1/E),   t < E      n2 = column c of the tile  (SSFM_TWN_COMPUTE == 1)
+    const cx<T>* twB;         // [tile][t][c] = W_N^(t n2 N1/E),   t < E      n2 = column c of the tile  (twn_compute plans)
     const cx<T>* tw1;         // W_N1^q
     AdaptState<T>* st;        // nullptr in fixed-step mode
     T* zlog;                  // adaptive mode: z after every step
@@ -339,9 +297,6 @@ template <bool BIG> __device__ __forceinline__ void sincos_f32(float x, float& s
 // (relative truncation z^2/120 < 8e-9, an eighth of the float32 half-ulp) with z = x^2 -- both halves of ONE packed fma, then one fma
 // and one product: 4 instructions per point instead of 11 (k_time spends 2/3 of a SIMD's issue slots when both lanes run, so instructions
 // are time: profiles/r04_c2_micro.txt)
-#ifndef SSFM_SINCOS_MICRO
-#define SSFM_SINCOS_MICRO 1
-#endif
 constexpr float kSincosMicroMax = 0.03125f;
 __device__ __forceinline__ cf32 expi_micro(float x) {
     const float z = x * x;
@@ -354,7 +309,7 @@ template <int E> __device__ __forceinline__ void rotate_all(cf32 (&v)[E], const 
 #pragma unroll
     for (int t = 0; t < E; ++t) amax = fmaxf(amax, fabsf(phi[t]));
     const bool big = !(amax <= kSincosSmallMax);           // also true for NaN
-    if (SSFM_SINCOS_MICRO != 0 && __builtin_expect(amax <= kSincosMicroMax, 1)) {
+    if (__builtin_expect(amax <= kSincosMicroMax, 1)) {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmul(v[t], expi_micro(phi[t]));
     } else if (__builtin_expect(amax <= kSincosTinyMax, 1)) {
@@ -461,63 +416,36 @@ template <> __device__ __forceinline__ void sincos_acc<double>(double x, double&
 // (tools/trace_timeline.py, profiles/r02_launch_timeline.txt): gap 2.4 us behind plain stores, 1.5 us behind
 // write-through ones; timing-only ablations that REMOVE the table loads make the kernels slower (23.5 vs 21.2 us per
 // step, profiles/r02_ablation_lanes2.txt): with less read traffic fewer dirty lines are evicted while the kernel runs.
-//   SSFM_STORE_MODE 1: field stores write-through (sc1).  Needs the 16-byte units of the U16 layout: an 8-byte sc1
-//                      store runs at 0.4x the rate (round 1 measured 22.4 vs 21.2 us per step with it).
-//   SSFM_P_WT 1:       the |A|^2 buffer likewise (its 16-byte tile-major stores).
-//   SSFM_NT_LOADS 1:   field and |A|^2 are read once per kernel: non-temporal loads.  Only together with the
-//                      write-through stores (alone it LOSES: 23.7 vs 21.6 us per step -- again the dirty lines).
+//   field stores write-through (sc1).  Needs the 16-byte units of the U16 layout: an 8-byte sc1 store runs at 0.4x the rate (round 1 measured 22.4 vs
+//     21.2 us per step with it);
+//   the |A|^2 buffer likewise (its 16-byte tile-major stores);
+//   field and |A|^2 are read once per kernel: non-temporal loads.  Only together with the write-through stores (alone it LOSES: 23.7 vs 21.6 us per
+//     step -- again the dirty lines).
 // A/B on MI355X, C2 single field / 4 fields resident, us per (field-)step (profiles/r02_ab_u16_sc1_twnc.txt, r02_ab_policy.txt):
 //   plain 21.6 / 15.0   sc1 22.3 / 15.7   sc1 + P 20.7 / 15.4   + in-kernel twiddles 19.7 / 15.0   + nt loads 18.1 / 15.1
 // Everything outside the U16 path (complex128, the small 8-byte layouts, the time-order side) keeps plain accesses.
-#ifndef SSFM_STORE_MODE
-#define SSFM_STORE_MODE 1
-#endif
-#ifndef SSFM_P_NT
-#define SSFM_P_NT 0
-#endif
-#ifndef SSFM_P_WT
-#define SSFM_P_WT 1
-#endif
-#ifndef SSFM_NT_LOADS
-#define SSFM_NT_LOADS 1
-#endif
-// SSFM_P16: the stale |A|^2 of the large complex64 plans (16 points per thread, unit layout) crosses the launch boundary as 16-bit fixed
+// P16: the stale |A|^2 of the large complex64 plans (16 points per thread, unit layout) crosses the launch boundary as 16-bit fixed
 // point relative to the THREAD's own maximum: 2 x 16 bytes + one 4-byte scale per thread instead of 4 x 16 bytes -- 9 instead of 16 of the 91
 // bytes a dual-polarisation sample*step moves.  |A|^2 only ever enters the phase h/2 gamma |A|^2 (devices.py:1175,1181), so what counts is the
 // ABSOLUTE error of that phase: at most 2^-17 of the thread's largest phase (7.6e-6 of <= 0.05 rad; the float32 product itself carries 6e-8
 // relative).  The buffer is private to a tile (the same thread reads back what it wrote), so the scale needs no agreement between threads.
-#ifndef SSFM_P16
-#define SSFM_P16 1
-#endif
-template <typename T, bool U16, int E> __host__ __device__ constexpr bool p16_layout() { return SSFM_P16 != 0 && U16 && sizeof(T) == 4 && E == 16; }
+template <typename T, bool U16, int E> __host__ __device__ constexpr bool p16_layout() { return U16 && sizeof(T) == 4 && E == 16; }
 template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V* p) {
-    if constexpr (NT && SSFM_NT_LOADS != 0) return __builtin_nontemporal_load(p);
+    if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // 16-byte unit of the U16 layout
 __device__ __forceinline__ void stream_store(f32x4* p, f32x4 v) {
-#if SSFM_STORE_MODE == 1
     // The s_nop 1 are the two wait states a VALU write to the data registers of a > 8-byte store needs after it on
     // gfx940+: the compiler inserts them for its own stores but cannot see into an asm statement (without them the
     // next address computation overwrote the data of the store before it had been read)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-#elif SSFM_STORE_MODE == 2
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
 }
 __device__ __forceinline__ void stream_store(f64x4* p, f64x4 v) { *p = v; }
 __device__ __forceinline__ void stream_store(cf32* p, cf32 v) { *p = v; }
-__device__ __forceinline__ void stream_store(cf64* p, cf64 v) {
-#if SSFM_C128_POLICY
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void stream_store(cf64* p, cf64 v) { *p = v; }
 
 // k_time's exchange buffer: element e of column c at [e][c].  SW = 0: as it is -- the plain lane order (16 lanes = the 16
 // columns of one row) reads and writes whole 128-byte rows, conflict-free.  SW = log2(first radix) (U16 lane order: a
@@ -581,58 +509,32 @@ template <typename T> __device__ __forceinline__ StepState<T> step_state(const A
 
 
 // ------------------------------------------------------------------------------ k_time
-// Alternating LDS exchanges between two buffers saves one barrier per exchange but doubles the LDS
-// footprint; measured on MI355X it is SLOWER (23.2 -> 25.6 us per step): fewer workgroups of the
-// concurrently running kernels fit a CU.  Kept selectable, off.
-#ifndef SSFM_LDS_DOUBLE_BUFFER
-#define SSFM_LDS_DOUBLE_BUFFER 0
-#endif
-template <typename T> __host__ __device__ constexpr bool lds_double_buffer() { return SSFM_LDS_DOUBLE_BUFFER != 0 && sizeof(T) == 4; }
+// (Alternating the LDS exchanges between two buffers saves one barrier per exchange but doubles the LDS footprint; measured on MI355X it is SLOWER,
+// 23.2 -> 25.6 us per step in round 1 and 18.1 vs 16.5 in round 4: fewer workgroups of the concurrently running kernels fit a CU.  Removed in round 5.)
 // waves per SIMD to ask for: enough for two workgroups of THREADS threads per CU in complex64
-#ifndef SSFM_MIN_WAVES_256
-#define SSFM_MIN_WAVES_256 2
-#endif
 // (a 512-thread workgroup with 16 points per thread needs the full 256 registers: one workgroup per CU)
-// complex128 kernels: waves per SIMD to ask the register allocator for (experiment knob; 1 = no constraint)
-#ifndef SSFM_MIN_WAVES_C128
-#define SSFM_MIN_WAVES_C128 1
-#endif
 __host__ __device__ constexpr int min_waves(int threads, int tsize, int e = 16) {
-    return tsize == 4 && threads >= 256 ? (threads == 256 ? SSFM_MIN_WAVES_256 : (e == 16 ? 2 : threads / 128))
-                                        : (tsize == 8 && e == 8 ? SSFM_MIN_WAVES_C128 : 1);
+    return tsize == 4 && threads >= 256 ? (threads == 256 ? 2 : (e == 16 ? 2 : threads / 128)) : 1;
 }
-
-// (SSFM_CAP_WAVES: complex64 workgroups of 256 threads are meant to sit two per CU -- a launch of one lane is 256 of
-// them, both lanes together fill the chip evenly.  A kernel that needs fewer than 171 registers would be admitted
-// three per CU and the dispatcher packs them unevenly; the attribute pins the register budget to two waves per SIMD.)
-#ifndef SSFM_CAP_WAVES
-#define SSFM_CAP_WAVES 1
-#endif
-#if SSFM_CAP_WAVES
+// complex64 workgroups of 256 threads are meant to sit two per CU -- a launch of one lane is 256 of them, both lanes together fill the chip evenly.  A
+// kernel that needs fewer than 171 registers would be admitted three per CU and the dispatcher packs them unevenly; the attribute pins the register
+// budget to two waves per SIMD.
 #define SSFM_KERNEL_BOUNDS(threads, tsize, e) \
     __launch_bounds__(threads) __attribute__((amdgpu_waves_per_eu(min_waves(threads, tsize, e), (tsize) == 4 && (threads) == 256 ? 2 : 8)))
-#else
-#define SSFM_KERNEL_BOUNDS(threads, tsize, e) __launch_bounds__(threads, min_waves(threads, tsize, e))
-#endif
 // 16 bytes at byte offset `off` of the buffer behind `rsrc`, sc1: agent-scope coherent (served past this CU's L1) and tracked by the
 // compiler's wait counters -- how a workgroup reads what ANOTHER workgroup of the same launch has stored (k_medium)
-// SSFM_MEDIUM_LOCAL (default): k_medium's workgroups all sit on ONE XCD and meet in that XCD's L2 -- plain stores (the CU's L1 writes
-// through), loads with sc0 nt (they miss the L1 and are answered by the L2), barrier counters as L2 atomics: a store + barrier + load
-// round costs 1.1-1.3 us for 16-32 workgroups against 2.1-2.8 us across the XCDs, which meet in memory (tools/xcd_barrier_probe.hip,
-// profiles/r03_xcd_barrier.txt; sc0 alone or an L1 invalidate + plain load return STALE data).  0: sc1 stores / sc1 loads / agent-scope atomics.
-#ifndef SSFM_MEDIUM_LOCAL
-#define SSFM_MEDIUM_LOCAL 1
-#endif
-#ifndef SSFM_MEDIUM_PKEEP
-#define SSFM_MEDIUM_PKEEP 1
-#endif
+// k_medium's workgroups all sit on ONE XCD and meet in that XCD's L2 -- plain stores (the CU's L1 writes through), loads with sc0 nt (they miss
+// the L1 and are answered by the L2), the barrier a flag word per workgroup: a store + barrier + load round costs 1.1-1.3 us for 16-32 workgroups
+// against 2.1-2.8 us across the XCDs, which meet in memory (tools/xcd_barrier_probe.hip, profiles/r03_xcd_barrier.txt; sc0 alone or an L1
+// invalidate + plain load return STALE data).  (The form across the XCDs -- sc1 stores / sc1 loads / agent-scope atomics -- was round 3's first
+// k_medium, 8.0-12.0 vs 8.0-10.5 us per step, removed in round 5; |A|^2 stays in registers between a workgroup's column passes: -4...-5 %.)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4_t load16_sc1(__amdgpu_buffer_rsrc_t rsrc, int off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SSFM_MEDIUM_LOCAL ? 3 /* sc0 nt */ : 16 /* sc1 */);
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 3 /* sc0 nt */);
 }
 // a field store of a pass: write-through to memory, except inside k_medium on one XCD (see above)
 template <bool PK, typename P, typename V> __device__ __forceinline__ void pass_store(P* p, V v) {
-    if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) *p = v;
+    if constexpr (PK) *p = v;
     else stream_store(p, v);
 }
 // an atomic add executed in this XCD's L2, returning the old value
@@ -671,13 +573,6 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     T hh_prev = a.hh_prev, hh_next = a.hh_next;
     const int tid = threadIdx.x;
     SSFM_TRACE_BEGIN(a);
-#if SSFM_KERNARG_UPFRONT
-    if constexpr (!PK) {
-        // every kernel argument the head of the kernel needs, asked for in ONE scalar-load clause at the entry: left to itself the compiler fetches
-        // Y and P in a later block, behind a second wait (a scalar-cache miss of its own) that stands in front of the field loads
-        asm volatile("" : : "s"(a.Y), "s"(a.P), "s"(a.F), "s"(a.twA), "s"(a.twB), "s"(a.tw1), "s"(a.N2), "s"(a.rows), "s"(a.st));
-    }
-#endif
     // plain: thread = j * C + c.  U16: lane = h * 32 + (j mod 4) * 8 + c8, column c = h * 8 + c8 (see "U16" above)
     const int c = U16 ? (((tid >> 5) & 1) << 3) | (tid & 7) : tid % C;
     const int j = U16 ? ((tid >> 6) << 2) | ((tid >> 3) & 3) : tid / C;
@@ -715,7 +610,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     LineTw<T, N1, E> tw;
     constexpr bool TWC = twn_compute<T, U16>();
     constexpr int NT = N1 * C / E;
-    constexpr bool HEAD = SSFM_HEAD_ORDER != 0 && MODE != TM_UNPACK;
+    constexpr bool HEAD = MODE != TM_UNPACK;
     constexpr int NBS = (E * C + NT - 1) / NT;     // loads per thread of the tile's E x C inter-pass factors
     TwStaged<T, N1, E, NT> tws;
     cx<T> bs_pre[NBS];
@@ -779,28 +674,19 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         }
         if (!loaded) {
 #pragma unroll
-        for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0 && MODE != TM_BEGIN)>(&src[off + t * stride]);
+        for (int t = 0; t < E; ++t) v[t] = src[off + t * stride];
         }
     }
-    cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * N1 * C : 0);
+    cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? N1 * C : 0);
     if constexpr (MODE == TM_UNPACK) {
         // nothing but the field moves
-    } else if constexpr (TWC && HEAD) {
+    } else if constexpr (TWC) {
+        // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q1 t n2): the second factor depends on (t, column) only, the tile's E x C values go through LDS once
+        // (asked for at the head, above); 1 MiB of tables instead of an 8 MiB stream per row, both stored tile by tile in the order they are read
 #pragma unroll
         for (int i = 0; i < NBS; ++i) {
             const int e = tid + i * NT;
             if (e < E * C) Bs[e] = bs_pre[i];
-        }
-    } else if constexpr (TWC) {
-        // W_N^((j + t Q) n2) = W_N^(j n2) * W_N^(Q t n2): the second factor depends on (t, column) only,
-        // the tile's E x C values go through LDS once; 1 MiB of tables instead of an 8 MiB stream per row.
-        // (both tables are stored tile by tile in the order they are read here: 2 KiB + 2 KiB of contiguous lines per
-        // workgroup; indexed as twB[t n2] / twA[j n2] they were 512 gathers of 8 bytes, 2.4 MB of sectors per launch)
-        if (SSFM_ABL_NO_TWN) {
-            for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = mk<T>((T)1, (T)0);
-        } else {
-        for (int e = tid; e < E * C; e += N1 * C / E) Bs[e] = a.twB[(long long)tile * (E * C) + e];
-        wA = a.twA[(long long)tile * (Q * C) + ltid];
         }
     } else {
         typedef T w4_t __attribute__((ext_vector_type(4)));
@@ -813,13 +699,13 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             w[2 * g + 1] = mk<T>(q.z, q.w);
         }
     }
-    // SSFM_LATE_P: |A|^2 of the step's start is only needed after the inverse transform: its loads are issued after the
+    // |A|^2 of the step's start is only needed after the inverse transform: its loads are issued after the
     // transform's first stage instead of with the field loads -- a smaller burst at the head of the kernel, which the tail of the
     // other lane's kernel queues behind (launch timeline: the last workgroup of a launch ends 2-3 us after the first).  Six
     // interleaved rounds, 2^20 x 2: 16.97 against 17.52 us per step (profiles/r03_ablation_and_knobs.txt)
     auto load_pold = [&]() {
         if constexpr (MODE == TM_MID_L) return;
-        if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
+        if constexpr (PK) {
 #pragma unroll
             for (int t = 0; t < E; ++t) pold[t] = a.pkeep[t];
             return;
@@ -846,7 +732,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             pold[4 * g] = q.x; pold[4 * g + 1] = q.y; pold[4 * g + 2] = q.z; pold[4 * g + 3] = q.w;
         }
     };
-    constexpr bool LATE_P = SSFM_LATE_P != 0 && (U16 || (sizeof(T) == 8 && SSFM_LATE_P_C128 != 0)) && (SSFM_LATE_P == 2 ? INV : MODE == TM_MID);       // (2: every mode that reads |A|^2)
+    constexpr bool LATE_P = (U16 || sizeof(T) == 8) && INV;       // (every mode that reads |A|^2)
     if (INV && !LATE_P) load_pold();
     // The step control state (adaptive runs) is read HERE, after every global load of the tile has been issued: it was written
     // by the previous launch, so its load is a miss of ~2 us that would otherwise stand in front of the whole kernel.  (A launch
@@ -882,11 +768,8 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     }
     cx<T>* ldsT = Bs + (TWC ? E * C : 0);
     if constexpr (MODE != TM_UNPACK) {
-        if constexpr (HEAD) {
-            line_twiddles_issue_regs<T, N1, E>(tw, j, a.tw1);
-            line_twiddles_commit<T, N1, E, NT>(tws, ldsT, tid);
-        } else
-        line_twiddles_issue<T, N1, E>(tw, j, a.tw1, ldsT, tid, N1 * C / E);
+        line_twiddles_issue_regs<T, N1, E>(tw, j, a.tw1);
+        line_twiddles_commit<T, N1, E, NT>(tws, ldsT, tid);
         if (fft_tw_lds_entries(N1, E) > 0 || TWC) __syncthreads();
         if constexpr (TWC) {
             w[0] = wA;
@@ -915,8 +798,8 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         }
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmulc(v[t], w[t]);
-        if constexpr (LATE_P) fft_line_hook<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw, load_pold);
-        else if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
+        if constexpr (LATE_P) fft_line_hook<T, N1, E, +1, 0, CI>(v, lds, 0, j, idx, tw, load_pold);
+        else if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, +1, 0, CI>(v, lds, 0, j, idx, tw);
     }
     if constexpr (((MODE == TM_MID || MODE == TM_MID_A) && PK) || (MODE == TM_MID && !U16)) {
         if (a.keep > 0) {                // (chirp-z: what the convolution left in the line's padding is not part of the field -- nor of its maximum)
@@ -934,7 +817,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     T pnew[E];
     bool fwd_active = true;               // TM_MID_A: false when this step ends the run
     auto store_pnew = [&]() {
-        if constexpr (PK && SSFM_MEDIUM_PKEEP != 0) {
+        if constexpr (PK) {
             if (FWD) {
 #pragma unroll
                 for (int t = 0; t < E; ++t) a.pkeep[t] = pnew[t];
@@ -966,14 +849,8 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             for (int g = 0; g < E / 4; ++g) {
                 p4_t q;
                 q.x = pnew[4 * g]; q.y = pnew[4 * g + 1]; q.z = pnew[4 * g + 2]; q.w = pnew[4 * g + 3];
-#if SSFM_P_NT
-                __builtin_nontemporal_store(q, &Pb[g * PSTR]);
-#elif SSFM_P_WT
                 if constexpr (sizeof(T) == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(&Pb[g * PSTR]), "v"(q) : "memory");
                 else Pb[g * PSTR] = q;
-#else
-                Pb[g * PSTR] = q;
-#endif
             }
         }
     };
@@ -1004,7 +881,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         constexpr int NWAVES_A = (N1 * C / E + 63) / 64;
         if ((tid & 63) == 0) wave_max_a[tid >> 6] = pmax;
         __syncthreads();
-        if (sizeof(T) == 4 && (SSFM_WORD_BARRIER_ALL || nblk > (unsigned)kAdaptSlots)) {
+        if (sizeof(T) == 4) {
             // ---- large grids: every workgroup publishes ONE word, a wavefront of every workgroup reads them all
             if (tid < 64) {
                 const int set = a.step & 1;
@@ -1014,7 +891,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                     T m = wave_max_a[0];
 #pragma unroll
                     for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
-                    if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) st_l2_u64(&a.st->wgmax[set][mine], epoch | (float_bits<T>(m) & 0xffffffffull));
+                    if constexpr (PK) st_l2_u64(&a.st->wgmax[set][mine], epoch | (float_bits<T>(m) & 0xffffffffull));
                     else __hip_atomic_store(&a.st->wgmax[set][mine], epoch | (float_bits<T>(m) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const unsigned long long* words = a.st->wgmax[set];
@@ -1032,7 +909,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                     for (int i = 0; i < kAdaptWords / 64; ++i) {
                         if (pending & (1u << i)) {
                             unsigned long long wd;
-                            if constexpr (PK && SSFM_MEDIUM_LOCAL != 0) wd = ld_l2_u64(&words[(unsigned)tid + 64u * (unsigned)i]);
+                            if constexpr (PK) wd = ld_l2_u64(&words[(unsigned)tid + 64u * (unsigned)i]);
                             else wd = __hip_atomic_load(&words[(unsigned)tid + 64u * (unsigned)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((wd >> 32) == (epoch >> 32)) {
                                 pending &= ~(1u << i);
@@ -1067,18 +944,14 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
 #pragma unroll
                 for (int w = 1; w < NWAVES_A; ++w) m = wave_max_a[w] > m ? wave_max_a[w] : m;
                 atomicMax(&a.st->slots[set][bid % kAdaptSlots], float_bits<T>(m));
-#if SSFM_RELAXED_BARRIER
                 // Only atomics cross this barrier (the slots, read back with agent-scope loads below), so no fence is needed -- an agent-scope
                 // release / acquire writes back / invalidates the XCD's whole L2 on gfx950 -- just the order: the maximum is acknowledged
                 // before the arrival is counted.
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
                 __hip_atomic_fetch_add(&a.st->arrive[set], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-                __hip_atomic_fetch_add(&a.st->arrive[set], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#endif
                 const long long t0 = wall_clock64();                  // 100 MHz
                 for (;;) {
-                    if (__hip_atomic_load(&a.st->arrive[set], SSFM_RELAXED_BARRIER ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= nblk) { good = 1; break; }
+                    if (__hip_atomic_load(&a.st->arrive[set], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nblk) { good = 1; break; }
                     if (wall_clock64() - t0 > a.st->patience) break;  // (20 ms) the grid is not running as a whole -- give up, never hang
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -1241,10 +1114,10 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         SSFM_TRACE_END(a);
         return;
     }
-    // exchanges alternate between two LDS buffers; the forward transform continues the count
+    // (one LDS buffer: a transform that follows another starts with a barrier before its first exchange, XP = 1)
     constexpr int NX = fft_nstages(N1, E) - 1;      // exchanges of the inverse transform
-    constexpr int XP_FWD = ((MODE != TM_MID && MODE != TM_MID_A && MODE != TM_MID_L) || NX == 0) ? 0 : (lds_double_buffer<T>() ? (NX & 1) : 1);
-    if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, CI>(v, lds, lds_double_buffer<T>() ? N1 * C : 0, j, idx, tw);
+    constexpr int XP_FWD = ((MODE != TM_MID && MODE != TM_MID_A && MODE != TM_MID_L) || NX == 0) ? 0 : 1;
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, CI>(v, lds, 0, j, idx, tw);
     if (U16) {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmul(v[t], w[t]);
@@ -1431,15 +1304,12 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     LineTw<T, N2, E> tw;
     SSFM_STAMP(0);
     typedef T u4_t __attribute__((ext_vector_type(4)));
-    constexpr bool HEAD = SSFM_HEAD_ORDER != 0;
-    // SSFM_EARLY_PHASE: the phase loads go out BEFORE the field loads (results return in issue order) and amp * exp(i phase) is formed while the
+    // the phase loads go out BEFORE the field loads (results return in issue order) and amp * exp(i phase) is formed while the
     // field is on its way -- 200 instructions per thread off the workgroup's critical path (the head of a kernel is a wait of 1-2 us)
-    constexpr bool EARLY_PHASE = HEAD && SSFM_EARLY_PHASE != 0 && MODE == FM_PHASE && !SSFM_LATE_TAB;
+    constexpr bool EARLY_PHASE = MODE == FM_PHASE;
     TwStaged<T, N2, E, ROWS * N2 / E> tws;
-    if constexpr (HEAD) line_twiddles_prefetch<T, N2, E, ROWS * N2 / E>(tws, a.tw2, tid);
+    line_twiddles_prefetch<T, N2, E, ROWS * N2 / E>(tws, a.tw2, tid);
     unsigned pu[E];
-    // SSFM_LATE_TAB (experiment): the phase loads are issued after the first stage of the forward transform instead of with the
-    // field loads -- a smaller burst at the head of the kernel, which the tail of the other lane's kernel queues behind
     double pt[sizeof(T) == 8 ? E : 1];          // complex128: the phases as float64 turn fractions, slots 2g and 2g+1 side by side (freq_tab_pos)
     auto load_phases = [&]() {
         if constexpr (sizeof(T) == 8) {
@@ -1469,7 +1339,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         }
     };
     // (the same for the operator itself where the kernel forms exp(D~ h): adaptive runs.  Only with 16-byte elements... of either precision)
-    constexpr bool EARLY_FLY = HEAD && SSFM_EARLY_PHASE != 0 && FLY;
+    constexpr bool EARLY_FLY = FLY;
     auto load_table = [&]() {
         if constexpr (MODE == FM_FLY_IM) {
             static_assert(MODE != FM_FLY_IM || E % 4 == 0, "four imaginary parts per load");
@@ -1514,16 +1384,11 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < E; ++t) v[t] = stream_load<(sizeof(T) == 8 && SSFM_C128_POLICY != 0)>(&Frow[j + t * Q]);
+        for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
     }
-    cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? (lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) : 0);
-    if constexpr (HEAD) line_twiddles_issue_regs<T, N2, E>(tw, j, a.tw2);
-    else line_twiddles_issue<T, N2, E>(tw, j, a.tw2, ldsT, tid, ROWS * N2 / E);
-    if (MODE == FM_PHASE) {
-        if (!SSFM_LATE_TAB && !EARLY_PHASE) load_phases();
-    } else if (MODE != FM_FWD_ONLY) {
-        if constexpr (!EARLY_FLY) load_table();
-    }
+    cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? ROWS * row_lds_elems(N2, E) : 0);
+    line_twiddles_issue_regs<T, N2, E>(tw, j, a.tw2);
+    if constexpr (MODE == FM_TABLE) load_table();
     if (FLY && a.st != nullptr) {
         // (read after the row and the operator have been asked for: the state was written by the previous launch, a ~2 us miss)
         const StepState<T> S = a.st->cur[a.step & 1];
@@ -1535,7 +1400,7 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SSFM_STAMP(2);
 #endif
-    if constexpr (HEAD) line_twiddles_commit<T, N2, E, ROWS * N2 / E>(tws, ldsT, tid);
+    line_twiddles_commit<T, N2, E, ROWS * N2 / E>(tws, ldsT, tid);
     auto fly = [&]() {
         // exp(D~ h): real factor exp(Re*h), phase Im*h (reference devices.py:1179), then 1/N
         T ph[E];
@@ -1560,22 +1425,17 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     }
     if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
-    if (MODE == FM_PHASE && SSFM_LATE_TAB) {
-        fft_line_hook<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw, load_phases);
-    } else
-    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
         for (int t = 0; t < E; ++t) pass_store<PK>(&Frow[j + t * Q], v[t]);
         return;
     }
     SSFM_STAMP(3);
-    if (FLY && !EARLY_FLY) fly();
-    if (MODE == FM_PHASE && !EARLY_PHASE) phase_factors();
 #pragma unroll
     for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
     SSFM_STAMP(4);
-    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : (lds_double_buffer<T>() ? ((fft_nstages(N2, E) - 1) & 1) : 1)), RI>(v, lds, lds_double_buffer<T>() ? ROWS * row_lds_elems(N2, E) : 0, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : 1), RI>(v, lds, 0, j, idx, tw);
     SSFM_STAMP(5);
     if (U16) {
 #pragma unroll
@@ -1655,9 +1515,6 @@ template <typename T> struct MediumArgs {
     int Qf;
 };
 constexpr int kBarShards = 8;
-#ifndef SSFM_MEDIUM_WORDS
-#define SSFM_MEDIUM_WORDS 1
-#endif
 constexpr int kBarWords = 64;          // one-XCD form: a flag word per workgroup (no atomics), behind the shards; then the error word and the ticket counter
 
 // every workgroup of the launch has passed here `epoch` times once each counter shows epoch * nblk / 8 arrivals
@@ -1668,16 +1525,9 @@ __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned
     __syncthreads();
     ++epoch;
     if (tid < 64) {
-#if SSFM_MEDIUM_LOCAL
-        // every workgroup raises its own word to the epoch; a wavefront of every workgroup reads them all (one per lane)
-#if SSFM_MEDIUM_WORDS
+        // every workgroup raises its own word to the epoch; a wavefront of every workgroup reads them all (one per lane).  No atomics at all: sharded
+        // L2 atomics were 0.4-0.6 us per step slower
         if (tid == 0) st_l2_u64(&bar[kBarShards + bid], epoch);
-#else
-        if (tid == 0) l2_add_u64(&bar[bid & (kBarShards - 1)], 1ull);
-#endif
-#else
-        if (tid == 0) __hip_atomic_fetch_add(&bar[bid & (kBarShards - 1)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
         const unsigned long long want = epoch * (nblk / kBarShards);
         const long long t0 = wall_clock64();
         int good = 0;
@@ -1685,16 +1535,8 @@ __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned
         // 4.59 / 5.74 / 8.07 / 12.17 us per step at 2^13 x 2 / 2^14 / 2^16 x 2 / the 8176-sample chirp-z line -- the wait is for the slowest workgroup's
         // stores, not for the news of them.  Round 4, tools/medium_time.py.)
         for (;;) {
-#if SSFM_MEDIUM_LOCAL
             unsigned long long got = want;
-#if SSFM_MEDIUM_WORDS
             if ((unsigned)tid < nblk) got = ld_l2_u64(&bar[kBarShards + tid]) >= epoch ? want : 0ull;
-#else
-            if (tid < kBarShards) got = l2_add_u64(&bar[tid], 0ull);
-#endif
-#else
-            const unsigned long long got = tid < kBarShards ? __hip_atomic_load(&bar[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
-#endif
             if (__all(got >= want)) { good = 1; break; }
             if (wall_clock64() - t0 > patience) break;
             __builtin_amdgcn_s_sleep(1);
@@ -1705,24 +1547,24 @@ __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // (no instruction: the loads of the next pass stay below)
     return s_bar_ok[0] != 0;
 }
+// The one-XCD engines are launched with 8 x nblk workgroups, dealt round robin to the XCDs: the ones on XCD `xcc` take the tiles in the order they arrive
+// (the others leave); should fewer than nblk arrive there, the first barrier runs out of patience and the host repeats the run on the launch-per-pass engine.
+__device__ __forceinline__ bool medium_ticket(const unsigned xcc, unsigned long long* bar, const unsigned nblk, const int tid, unsigned& bid) {
+    if (xcc_id() != xcc) return false;
+    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
+    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(bar + kBarShards + kBarWords + 1, 1ull);
+    __syncthreads();
+    bid = s_bid[0];
+    return bid < nblk;
+}
 template <typename T, int N1, int N2, int E, int FMODE>
 __global__ __launch_bounds__(N1 * 16 / E) void k_medium(const MediumArgs<T> a) {
     constexpr int C = 16, ROWS = N1 * C / N2;
     static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
     const int tid = threadIdx.x;
-#if SSFM_MEDIUM_LOCAL
-    // launched with 8 x nblk workgroups, dealt round robin to the XCDs: the ones on XCD a.xcc take the tiles in the order they arrive
-    // (the others leave); should fewer than nblk arrive there, the first barrier runs out of patience and the host repeats the run
-    // on the two-kernel engine
-    if (xcc_id() != a.xcc) return;
-    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
-    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
-    __syncthreads();
-    const unsigned bid = s_bid[0], nblk = a.nblk;
-    if (bid >= nblk) return;
-#else
-    const unsigned bid = blockIdx.x, nblk = gridDim.x;
-#endif
+    const unsigned nblk = a.nblk;
+    unsigned bid;
+    if (!medium_ticket(a.xcc, a.bar, nblk, tid, bid)) return;
     unsigned long long epoch = 0;
     T pk[E];
     TimeArgs<T> ta;
@@ -1788,16 +1630,9 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium_chirp(const MediumChirpA
     constexpr int C = 16, ROWS = N1 * C / N2;
     static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
     const int tid = threadIdx.x;
-#if SSFM_MEDIUM_LOCAL
-    if (xcc_id() != a.xcc) return;
-    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
-    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
-    __syncthreads();
-    const unsigned bid = s_bid[0], nblk = a.nblk;
-    if (bid >= nblk) return;
-#else
-    const unsigned bid = blockIdx.x, nblk = gridDim.x;
-#endif
+    const unsigned nblk = a.nblk;
+    unsigned bid;
+    if (!medium_ticket(a.xcc, a.bar, nblk, tid, bid)) return;
     unsigned long long epoch = 0;
     T pk[E];
     TimeArgs<T> ta;
@@ -1866,16 +1701,9 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium_chirp_adapt(const Medium
     constexpr int C = 16, ROWS = N1 * C / N2;
     static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
     const int tid = threadIdx.x;
-#if SSFM_MEDIUM_LOCAL
-    if (xcc_id() != a.xcc) return;
-    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
-    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
-    __syncthreads();
-    const unsigned bid = s_bid[0], nblk = a.nblk;
-    if (bid >= nblk) return;
-#else
-    const unsigned bid = blockIdx.x, nblk = gridDim.x;
-#endif
+    const unsigned nblk = a.nblk;
+    unsigned bid;
+    if (!medium_ticket(a.xcc, a.bar, nblk, tid, bid)) return;
     __shared__ __attribute__((aligned(16))) StepState<T> s_state[2];       // [0] the step being taken, [1] where TM_MID_A leaves the next one
     unsigned long long epoch = 0;
     StepState<T> S = a.st->cur[0];
@@ -1948,16 +1776,9 @@ __global__ __launch_bounds__(N1 * 16 / E) void k_medium_adapt(const MediumAdaptA
     constexpr int C = 16, ROWS = N1 * C / N2;
     static_assert(ROWS >= 1 && ROWS * N2 == N1 * C, "the two passes share the workgroup shape");
     const int tid = threadIdx.x;
-#if SSFM_MEDIUM_LOCAL
-    if (xcc_id() != a.xcc) return;
-    __shared__ __attribute__((aligned(16))) unsigned s_bid[4];
-    if (tid == 0) s_bid[0] = (unsigned)l2_add_u64(a.bar + kBarShards + kBarWords + 1, 1ull);
-    __syncthreads();
-    const unsigned bid = s_bid[0], nblk = a.nblk;
-    if (bid >= nblk) return;
-#else
-    const unsigned bid = blockIdx.x, nblk = gridDim.x;
-#endif
+    const unsigned nblk = a.nblk;
+    unsigned bid;
+    if (!medium_ticket(a.xcc, a.bar, nblk, tid, bid)) return;
     __shared__ __attribute__((aligned(16))) StepState<T> s_state[2];       // [0] the step being taken, [1] where TM_MID_A leaves the next one
     unsigned long long epoch = 0;
     StepState<T> S = a.st->cur[0];

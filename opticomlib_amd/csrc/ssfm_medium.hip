@@ -13,15 +13,15 @@ template <int N1, int N2, int FMODE>
 hipError_t launch_shape(int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {
     using T = float;
     constexpr int E = 8, C = 16, ROWS = N1 * C / N2;
-    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                            + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
-    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
                            + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
     constexpr size_t lds = lds_t > lds_f ? lds_t : lds_f;
     static hipError_t attr = lds <= 48 * 1024 ? hipSuccess
         : hipFuncSetAttribute(reinterpret_cast<const void*>(k_medium<T, N1, N2, E, FMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_medium<T, N1, N2, E, FMODE>), dim3(SSFM_MEDIUM_LOCAL ? xccs * nblk : nblk), dim3(N1 * C / E), lds, s, a);
+    hipLaunchKernelGGL((k_medium<T, N1, N2, E, FMODE>), dim3(xccs * nblk), dim3(N1 * C / E), lds, s, a);
     return hipGetLastError();
 }
 template <int FMODE> hipError_t launch_mode(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a) {
@@ -40,15 +40,15 @@ template <int N1, int N2>
 hipError_t launch_adapt_shape(int nblk, int xccs, hipStream_t s, const MediumAdaptArgs<float>& a) {
     using T = float;
     constexpr int E = 8, C = 16, ROWS = N1 * C / N2;
-    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                            + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
-    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
                            + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
     constexpr size_t lds = lds_t > lds_f ? lds_t : lds_f;
     static hipError_t attr = lds <= 48 * 1024 ? hipSuccess
         : hipFuncSetAttribute(reinterpret_cast<const void*>(k_medium_adapt<T, N1, N2, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_medium_adapt<T, N1, N2, E>), dim3(SSFM_MEDIUM_LOCAL ? xccs * nblk : nblk), dim3(N1 * C / E), lds, s, a);
+    hipLaunchKernelGGL((k_medium_adapt<T, N1, N2, E>), dim3(xccs * nblk), dim3(N1 * C / E), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -67,15 +67,15 @@ template <int N1, int N2>
 hipError_t launch_chirp_shape(int nblk, int xccs, hipStream_t s, const MediumChirpArgs<float>& a) {
     using T = float;
     constexpr int E = 8, C = 16, ROWS = N1 * C / N2;
-    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                            + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
-    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
                            + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
     constexpr size_t lds = lds_t > lds_f ? lds_t : lds_f;
     static hipError_t attr = lds <= 48 * 1024 ? hipSuccess
         : hipFuncSetAttribute(reinterpret_cast<const void*>(k_medium_chirp<T, N1, N2, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_medium_chirp<T, N1, N2, E>), dim3(SSFM_MEDIUM_LOCAL ? xccs * nblk : nblk), dim3(N1 * C / E), lds, s, a);
+    hipLaunchKernelGGL((k_medium_chirp<T, N1, N2, E>), dim3(xccs * nblk), dim3(N1 * C / E), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -94,15 +94,15 @@ template <int N1, int N2>
 hipError_t launch_chirp_adapt_shape(int nblk, int xccs, hipStream_t s, const MediumChirpAdaptArgs<float>& a) {
     using T = float;
     constexpr int E = 8, C = 16, ROWS = N1 * C / N2;
-    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
+    constexpr size_t lds_t = (fft_nstages(N1, E) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                            + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
-    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)(lds_double_buffer<T>() ? 2 : 1) * ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
+    constexpr size_t lds_f = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
                            + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
     constexpr size_t lds = lds_t > lds_f ? lds_t : lds_f;
     static hipError_t attr = lds <= 48 * 1024 ? hipSuccess
         : hipFuncSetAttribute(reinterpret_cast<const void*>(k_medium_chirp_adapt<T, N1, N2, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_medium_chirp_adapt<T, N1, N2, E>), dim3(SSFM_MEDIUM_LOCAL ? xccs * nblk : nblk), dim3(N1 * C / E), lds, s, a);
+    hipLaunchKernelGGL((k_medium_chirp_adapt<T, N1, N2, E>), dim3(xccs * nblk), dim3(N1 * C / E), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace

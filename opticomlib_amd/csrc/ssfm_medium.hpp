@@ -5,7 +5,7 @@
 namespace ssfm {
 bool medium_shape(int N1, int N2);
 // complex64 plans in the 16-byte-unit layout, 8 points per thread, nblk = (N2 / 16) * rows workgroups (a multiple of 8, at most 64)
-// (launched with `xccs` x nblk workgroups when the engine keeps to one XCD, see SSFM_MEDIUM_LOCAL)
+// (launched with `xccs` x nblk workgroups when the engine keeps to one XCD: ssfm_kernels.hpp medium_ticket)
 hipError_t launch_medium(int N1, int N2, bool phase_tables, int nblk, int xccs, hipStream_t s, const MediumArgs<float>& a);
 // the adaptive run of such a plan in one launch (k_medium_adapt)
 hipError_t launch_medium_adapt(int N1, int N2, int nblk, int xccs, hipStream_t s, const MediumAdaptArgs<float>& a);

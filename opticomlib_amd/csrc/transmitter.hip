@@ -124,15 +124,6 @@ extern "C" int ssfm_device_axpb(int device, void* dst, const void* src, double a
     return SSFM_OK;
 }
 
-extern "C" int ssfm_device_real(int device, double* dst, const void* src, int64_t n) {
-    if (!dst || !src || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_real: bad argument");
-    if (int rc = use_dev(device)) return rc;
-    hipLaunchKernelGGL(k_real, dim3(blocks_of(n)), dim3(256), 0, 0, dst, (const double2*)src, (long long)n);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    return SSFM_OK;
-}
-
 extern "C" int ssfm_laser(int device, void* out, int64_t n, double amp, const double* phase, const double* rin, int has_df, double w, double step, double stop) {
     if (!out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_laser: bad argument");
     if (int rc = use_dev(device)) return rc;
@@ -190,8 +181,9 @@ int reduce_sum(int device, const double* a, long long n, int stride, int offset,
 
 }  // namespace
 
-extern "C" int ssfm_device_mean2(int device, const void* src, int64_t n, int is_complex, double* out) {
-    if (!src || !out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_mean2: bad argument");
+namespace {
+int device_mean2(int device, const void* src, int64_t n, int is_complex, double* out) {
+    if (!src || !out || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_reduce (mean2): bad argument");
     if (int rc = use_dev(device)) return rc;
     const int stride = is_complex ? 2 : 1;
     for (int k = 0; k < stride; ++k) {
@@ -202,8 +194,8 @@ extern "C" int ssfm_device_mean2(int device, const void* src, int64_t n, int is_
     return SSFM_OK;
 }
 
-extern "C" int ssfm_device_power(int device, const void* src, int rows, int64_t n, int is_complex, double* out) {
-    if (!src || !out || n < 1 || rows < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_power: bad argument");
+int device_power(int device, const void* src, int rows, int64_t n, int is_complex, double* out) {
+    if (!src || !out || n < 1 || rows < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_reduce (power): bad argument");
     if (int rc = use_dev(device)) return rc;
     const int stride = is_complex ? 2 : 1;
     for (int r = 0; r < rows; ++r) {
@@ -214,6 +206,22 @@ extern "C" int ssfm_device_power(int device, const void* src, int rows, int64_t 
     return SSFM_OK;
 }
 
+}  // namespace
+namespace ssfm { SSFM_INTERNAL int device_mean(int device, const double* a, const double* b, int64_t n, double* mean_out); SSFM_INTERNAL int device_min(int device, const double* a, int64_t n, double* min_out); }
+// One entry point for the reductions a device-resident signal needs (all synchronous, results on the HOST):
+//   SSFM_REDUCE_MEAN   out[0] = mean of the n float64 of a (+ b, nullable: the mean of the elementwise sum)
+//   SSFM_REDUCE_MEAN2  numpy.mean of n float64 (out[0]) or complex128 values (out[0] + j out[1]) of a
+//   SSFM_REDUCE_POWER  out[r] = mean |x|^2 of each of `rows` rows of n float64 / complex128 values of a
+//   SSFM_REDUCE_MIN    out[0] = minimum of the n float64 of a
+extern "C" int ssfm_device_reduce(int device, int kind, const void* a, const void* b, int rows, int64_t n, int is_complex, double* out) {
+    switch (kind) {
+        case SSFM_REDUCE_MEAN:  return ssfm::device_mean(device, (const double*)a, (const double*)b, n, out);
+        case SSFM_REDUCE_MEAN2: return device_mean2(device, a, n, is_complex, out);
+        case SSFM_REDUCE_POWER: return device_power(device, a, rows, n, is_complex, out);
+        case SSFM_REDUCE_MIN:   return ssfm::device_min(device, (const double*)a, n, out);
+    }
+    return fail(SSFM_ERR_INVALID, "ssfm_device_reduce: kind %d", kind);
+}
 extern "C" int ssfm_device_shift(int device, void* dst, const void* src, int64_t n, int is_complex, double re, double im) {
     if (!dst || !src || n < 1) return fail(SSFM_ERR_INVALID, "ssfm_device_shift: bad argument");
     if (int rc = use_dev(device)) return rc;
@@ -223,9 +231,3 @@ extern "C" int ssfm_device_shift(int device, void* dst, const void* src, int64_t
     return SSFM_OK;
 }
 
-extern "C" int ssfm_device_zero(int device, void* dst, size_t bytes) {
-    if (!dst) return fail(SSFM_ERR_INVALID, "ssfm_device_zero: NULL");
-    if (int rc = use_dev(device)) return rc;
-    HIP_TRY(hipMemset(dst, 0, bytes));
-    return SSFM_OK;
-}

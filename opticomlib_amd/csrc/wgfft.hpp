@@ -23,9 +23,6 @@
 #ifndef SSFM_STAMPS
 #define SSFM_STAMPS 0
 #endif
-#ifndef SSFM_ABL_LOCALX
-#define SSFM_ABL_LOCALX 0
-#endif
 #if SSFM_STAMPS
 extern __device__ unsigned long long* g_stamp_buf;
 #define SSFM_STAMP(i)                                                                         \
@@ -69,23 +66,9 @@ __device__ __forceinline__ cf64 mul_mi(cf64 a) { cf64 r; r.x = a.y; r.y = -a.x; 
 __device__ __forceinline__ cf64 mul_pi(cf64 a) { cf64 r; r.x = -a.y; r.y = a.x; return r; }
 __device__ __forceinline__ cf64 scale2(cf64 a, cf64 s) { return a * s; }
 
-// SSFM_SCALAR_FP32 = 1 (experiment, with -fno-slp-vectorize): plain component-wise float arithmetic instead of the packed forms.
-// Measured issue cost on MI355X (tools/ubench_pk_issue.hip, profiles/r03_ubench_pk_issue.txt): a v_pk_fma_f32 costs a lone wave
-// 9.0 cycles against 12.2 for the two v_fma_f32 it replaces, but with two or more waves per SIMD 6.0 / 5.3 against 4.2 / 3.8.
-#ifndef SSFM_SCALAR_FP32
-#define SSFM_SCALAR_FP32 0
-#endif
-#if SSFM_SCALAR_FP32
-__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { cf32 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
-__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { cf32 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
-__device__ __forceinline__ cf32 scale2(cf32 a, cf32 s) { cf32 r; r.x = a.x * s.x; r.y = a.y * s.y; return r; }
-__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { cf32 r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r; }
-__device__ __forceinline__ cf32 cmulc(cf32 a, cf32 b) { cf32 r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r; }
-__device__ __forceinline__ cf32 add_mi(cf32 a, cf32 d) { cf32 r; r.x = a.x + d.y; r.y = a.y - d.x; return r; }
-__device__ __forceinline__ cf32 add_pi(cf32 a, cf32 d) { cf32 r; r.x = a.x - d.y; r.y = a.y + d.x; return r; }
-__device__ __forceinline__ cf32 mul_mi(cf32 a) { cf32 r; r.x = a.y; r.y = -a.x; return r; }
-__device__ __forceinline__ cf32 mul_pi(cf32 a) { cf32 r; r.x = -a.y; r.y = a.x; return r; }
-#else
+// (Plain component-wise float arithmetic instead of the packed forms, built with -fno-slp-vectorize, is SLOWER in every configuration -- C2 18.4 vs 17.2 us per step,
+// profiles/r03_ubench_pk_issue.txt: a v_pk_fma_f32 costs a lone wave 9.0 cycles against 12.2 for the two v_fma_f32 it replaces, and the kernels' compute
+// phases run with one wave per SIMD most of the time.  That arm was removed in round 5.)
 // ---- float forms: packed FP32 with modifiers (VOP3P).  op_sel[i] / op_sel_hi[i] pick the half of
 // source i that feeds the low / high result lane; neg_lo / neg_hi negate a source per lane.
 __device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return a + b; }      // v_pk_add_f32
@@ -126,7 +109,6 @@ __device__ __forceinline__ cf32 mul_pi(cf32 a) {                // (-a.y, a.x)
     return r;
 }
 
-#endif
 
 // Tables hold forward twiddles exp(-i*theta); DIR < 0 = forward, DIR > 0 = inverse (conjugate).
 template <int DIR, typename C> __device__ __forceinline__ C cmuld(C a, C w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
@@ -261,22 +243,13 @@ __host__ __device__ constexpr int fft_ls(int L, int s, int E) {   // product of 
 // the thread's position in the line, and the forward and the inverse transform share them.
 //
 // complex128 cannot afford that: 3 x 15 twiddles of 4 registers each are 180 of the 256 a thread can have, and
-// the 16-point kernels spilled to AGPRs and scratch.  There (SSFM_TW_LAZY_C128) a thread keeps only WHERE its
+// the 16-point kernels spilled to AGPRs and scratch.  There a thread keeps only WHERE its
 // twiddles are -- the workgroup's LDS copy of a small stage, its own column of the global table for a large
 // one -- and loads each factor when a stage needs it (twice per kernel: forward and inverse transform).
-#ifndef SSFM_TW_LAZY_C128
-#define SSFM_TW_LAZY_C128 1
-#endif
 // (Only with 16 points per thread, i.e. the 2^21 / 2^22 plans: with 8 points per thread the registers suffice and
-// keeping the twiddles is 2 % faster -- C1 46.6 vs 47.6 us per step.)
-#ifndef SSFM_TW_LAZY_C64
-#define SSFM_TW_LAZY_C64 0      // experiment: frees ~90 registers of k_freq; see DESIGN.md
-#endif
-#ifndef SSFM_TW_LAZY_C128_ROWS
-#define SSFM_TW_LAZY_C128_ROWS 0      // experiment: also for 8-point-per-thread lines of >= 2048 points (k_freq of C1)
-#endif
+// keeping the twiddles is 2 % faster -- C1 46.6 vs 47.6 us per step; for complex64 and for 8-point rows of >= 2048 points it was measured and lost.)
 template <typename T, int E, int L = 0> __host__ __device__ constexpr bool tw_lazy() {
-    return sizeof(T) == 8 ? (SSFM_TW_LAZY_C128 != 0 && (E == 16 || (SSFM_TW_LAZY_C128_ROWS != 0 && L >= 2048))) : SSFM_TW_LAZY_C64 != 0;
+    return sizeof(T) == 8 && E == 16;
 }
 
 template <typename T, int L, int E, bool LAZY = tw_lazy<T, E, L>()> struct LineTw {
@@ -300,15 +273,12 @@ __host__ __device__ constexpr int fft_tw_slots_of(int L, int S, int E) { return 
 __host__ __device__ constexpr int fft_tw_ku(int L, int S, int E) { return fft_ls(L, S, E) < L / E ? fft_ls(L, S, E) : L / E; }
 // a stage whose table is small is staged through LDS (shared by the workgroup's lines too)
 __host__ __device__ constexpr bool fft_tw_via_lds(int L, int S, int E) { return fft_tw_slots_of(L, S, E) * fft_tw_ku(L, S, E) <= 512; }
-// SSFM_TW_PAIR: a complex64 stage that every thread reads straight from the global table (the last stage of a 4096-point row: 15 factors
+// A complex64 stage that every thread reads straight from the global table (the last stage of a 4096-point row: 15 factors
 // per thread) stores the factors of slots 2p and 2p+1 side by side: 8 loads of 16 bytes per lane instead of 15 of 8 -- a vector-memory
 // instruction costs a wave the same issue time whether a lane moves 8 or 16 bytes (tools/ubench_load_issue.hip), and these loads stand
 // at the head of k_freq behind the field's.  ts = sizeof of the real type.
-#ifndef SSFM_TW_PAIR
-#define SSFM_TW_PAIR 1
-#endif
 __host__ __device__ constexpr bool fft_tw_paired(int L, int S, int E, int ts) {
-    return SSFM_TW_PAIR != 0 && ts == 4 && SSFM_TW_LAZY_C64 == 0 && !fft_tw_via_lds(L, S, E);
+    return ts == 4 && !fft_tw_via_lds(L, S, E);
 }
 // table entries of stage S (always an even number, so that every stage starts on a 16-byte boundary)
 __host__ __device__ constexpr int fft_tw_stage_entries(int L, int S, int E, int ts) {
@@ -509,14 +479,7 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
 #endif
     if constexpr (S < M - 1) {
         cx<T>* dst = lds + ((XP + S) & 1) * BUF;
-#if SSFM_ABL_LOCALX
-        // timing-only ablation (results WRONG): what the 4096-point row transforms would save if the second exchange of the forward and the
-        // first of the inverse transform needed no workgroup barrier (bit 0), or no exchange took any (bit 1)
-        constexpr bool no_bar = ((SSFM_ABL_LOCALX & 1) && L == 4096 && ((DIR < 0 && S == 1) || (DIR > 0 && S == 0))) || ((SSFM_ABL_LOCALX & 2) && L == 4096);
-#else
-        constexpr bool no_bar = false;
-#endif
-        if (!no_bar && BUF == 0 && (S > 0 || XP != 0)) __syncthreads();   // single buffer: its readers must be done
+        if (BUF == 0 && (S > 0 || XP != 0)) __syncthreads();   // single buffer: its readers must be done
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int jb = j + i * Q;
@@ -525,7 +488,7 @@ __device__ __forceinline__ void fft_stage(cx<T> (&v)[E], cx<T>* lds, const int B
 #pragma unroll
             for (int u = 0; u < R; ++u) dst[idx(base + u * LS)] = v[i + u * NB];
         }
-        if (!no_bar) __syncthreads();
+        __syncthreads();
     }
 }
 

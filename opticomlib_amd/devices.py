@@ -291,10 +291,9 @@ class _ChirpZ:
     def _ensure_tables(self):
         want = _tag("chirp", self.n)
         if self.plan.tag(1) != want or self.plan.tag(2) != want:
-            # both convolution kernels are generated AND transformed on the device (csrc/chirpz.hip): no host FFT, no upload
+            # both convolution kernels are generated AND transformed on the device (ssfm_chirp_setup): no host FFT, no upload
+            self.plan.chirp_setup(self.n)
             for slot in (0, 1):
-                self.plan.load_chirp_kernel(self.n, slot)
-                self.plan.table_from_field(slot)
                 self.plan.set_tag(1 + slot, want)
 
     # the engine works in the plan's field buffer and table slots: its users hold the plan's lock for their whole sequence
@@ -307,40 +306,15 @@ class _ChirpZ:
         self.plan.lock.release()
         return False
 
-    def step(self, A, P, Dt, gamma: float, h: float, maxbits=None):
-        """One symmetric split step of size ``h`` on the device array ``A`` (batch, n), in place."""
-        pl = self.plan
-        pl.chirp_pre(A, P, self.chirp, gamma, 0.5 * h)
-        pl.apply_table(0)
-        pl.chirp_mid(Dt, h, 0)
-        pl.apply_table(1)
-        pl.chirp_post(A, P, self.chirp, gamma, 0.5 * h, maxbits)
-
     def transfer(self, A, H, exponent=False):
         """``A <- ifft(fft(A) * H)`` (or ``* exp(H)`` with ``exponent``) for a device table ``H`` of n entries, in place."""
-        pl = self.plan
-        pl.chirp_pre(A, None, self.chirp, 0.0, 0.0)
-        pl.apply_table(0)
-        pl.chirp_mid(H, 1.0 if exponent else 0.0, 0 if exponent else 1)
-        pl.apply_table(1)
-        pl.chirp_post(A, None, self.chirp, 0.0, 0.0, None)
-
+        self.plan.chirp_transfer(A, self.chirp, H, exponent)
 
     def fourier(self, A, inverse: bool):
-        """``fft`` (or ``ifft``) of every row of the device array ``A`` (batch, n); returns a new device array.
-        fft(x)_k = c_k sum_n (x_n c_n) conj(c)_{k-n};  ifft(X)_n = conj(c_n) / N sum_k (X_k conj(c_k)) c_{n-k}."""
-        pl = self.plan
-        if inverse:
-            pl.chirp_pre(A, None, self.chirp_conj, 0.0, 0.0)
-            pl.apply_table(1)
-            pl.chirp_post(A, None, self.chirp, 0.0, 0.0, None)        # * conj(c) / N
-            pl.synchronize()
-            return A
-        pl.chirp_pre(A, None, self.chirp, 0.0, 0.0)
-        pl.apply_table(0)
-        pl.chirp_post(A, None, self.chirp_conj, 0.0, 0.0, None)       # * c / N
-        pl.synchronize()
-        return _lib.axpb_device(A, float(self.n), 0.0)                # fft carries no 1/N
+        """``fft`` (or ``ifft``) of every row of the device array ``A`` (batch, n), in place; returns ``A``."""
+        self.plan.chirp_fourier(A, self.chirp, self.chirp_conj, inverse)
+        self.plan.synchronize()
+        return A
 
 
 def _fourier(obj, domain, shift=False):
@@ -385,11 +359,6 @@ def _fourier(obj, domain, shift=False):
     return _wrap_out(type(obj), outs[0], outs[1] if len(outs) > 1 else NULL, **kw)
 
 
-def _max_abs2(maxbits: "_lib.DeviceArray", plan) -> float:
-    plan.synchronize()
-    return float(maxbits.to_host().view(np.float64)[0])
-
-
 def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, return_steps, prec, dev, bar):
     """FIBER for a length that is not a power of two (same semantics as the fused engine: float32 coefficients
     and step arithmetic in complex64 mode, reference devices.py:1137-1161, 1172-1196)."""
@@ -415,8 +384,8 @@ _CHIRPS32: "OrderedDict[tuple, object]" = OrderedDict()
 # Accuracy margin of the one-launch complex64 chirp-z line (2048 < n <= 65536; round 5, profiles/r05_chirp_margin.txt).  A step of that line is four
 # padded complex64 transforms of 2-4 x the field's length where the reference's pocketfft makes two of the length itself: measured over 242 random
 # fibres, max|A - A_float64|/peak <= 7.5e-7 x steps^0.75 -- up to 1.7e-5 after 66-93 steps, within the stated 2e-5 (<= 100 steps) of the float64
-# solution but no longer within HALF of it, which is what keeps the line within the tolerance of the ORACLE whenever the oracle itself is (the
-# reference's own complex64 run sits up to 2.6e-5 from the float64 solution for such lengths).  Runs of 32 ... 100 steps therefore take the complex128
+# solution but no longer within HALF of it, which is what keeps the line within the tolerance of the REFERENCE's own complex64 run whenever that run
+# itself is (it sits up to 2.6e-5 from the float64 solution for such lengths).  Runs of 32 ... 100 steps therefore take the complex128
 # line (four launches per step, 1e-13 from float64); shorter runs have not accumulated the error yet and from 101 steps on the tolerance is the
 # 1000-step one (3e-4; the line reaches 1.0e-4 there).  `precision="complex128"` always takes the complex128 line.
 _C64_LINE_STEPS_LO, _C64_LINE_STEPS_HI = 31, 100
@@ -455,13 +424,13 @@ def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gam
         if h is None:
             b2, b3 = _F32(beta_2), _F32(beta_3)
             if bool((b2 == 0 and b3 == 0) or _F32(gamma) == 0):                  # one step of the whole length (reference devices.py:1163-1170)
-                if not plan.chirp_small(A, chirp, Dt, g, np.array([float(L)])):
+                if not plan.chirp_propagate_c64(A, chirp, Dt, g, np.array([float(L)])):
                     return None
                 zs = [_F32(0), L]
             else:
                 zs, z0, max_steps = [_F32(0)], _F32(0), 1 << 17
                 while True:
-                    got = plan.chirp_small_adapt(A, chirp, Dt, g, float(_F32(L - z0)), float(_F32(phi_max)), True, max_steps)
+                    got = plan.chirp_propagate_c64(A, chirp, Dt, g, None, length=float(_F32(L - z0)), phi_max=float(_F32(phi_max)), max_steps=max_steps)
                     if got is None:
                         return None if z0 == 0 else _raise_chirp_midway()
                     steps, z = got
@@ -471,7 +440,7 @@ def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gam
                     z0 = zs[-1]
         else:
             hs, z_all = step_schedule(length, h, _lib.C64)
-            if not plan.chirp_small(A, chirp, Dt, g, np.asarray(hs, dtype=np.float64)):
+            if not plan.chirp_propagate_c64(A, chirp, Dt, g, np.asarray(hs, dtype=np.float64)):
                 return None
             zs = list(z_all)
         plan.synchronize()
@@ -515,13 +484,13 @@ def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, ga
         Dt = _lib.DeviceArray.from_host(np.asarray(linear_operator(n, dt, alpha, beta_2, beta_3, _lib.C64), dtype=np.complex64), np.complex64, dev)
         g = float(_F32(gamma))
         if not adaptive:
-            if not plan.chirp_medium(A, chirp, Dt, g, hs):
+            if not plan.chirp_propagate_c64(A, chirp, Dt, g, hs):
                 return None
             return A, zs, None
         # adaptive: the step count is the run's own.  One step on a copy gives the first step size; the run's length in steps follows from it
         # (h grows as the power falls: steps ~ L_eff / h0) -- a run that will end inside the window without margin goes to the complex128 line at once
         probe = A.copy()
-        got = plan.chirp_medium_adapt(probe, chirp, Dt, g, float(L), float(_F32(phi_max)), 1)
+        got = plan.chirp_propagate_c64(probe, chirp, Dt, g, None, length=float(L), phi_max=float(_F32(phi_max)), max_steps=1)
         if got is None:
             return None
         h0 = float(got[1][1]) if got[0] >= 1 else float(L)
@@ -533,7 +502,7 @@ def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, ga
             return None
         zs, z0, max_steps = [_F32(0)], _F32(0), 1 << 17
         while True:
-            got = plan.chirp_medium_adapt(A, chirp, Dt, g, float(_F32(L - z0)), float(_F32(phi_max)), max_steps)
+            got = plan.chirp_propagate_c64(A, chirp, Dt, g, None, length=float(_F32(L - z0)), phi_max=float(_F32(phi_max)), max_steps=max_steps)
             if got is None:
                 return None if z0 == 0 else _raise_chirp_midway()
             steps, z = got
@@ -560,7 +529,6 @@ def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, g
     A.shape = (batch, n)
     P = _lib.DeviceArray((batch, n), np.float64, dev)
     Dt = _lib.DeviceArray.from_host(np.asarray(linear_operator(n, dt, alpha, beta_2, beta_3, prec), dtype=np.complex128), np.complex128, dev)
-    mb = _lib.DeviceArray((1,), np.float64, dev)
     g = float(rt(gamma))
     L = rt(length)
     zs, snaps = [rt(0)], ([A.copy()] if return_steps else None)
@@ -588,44 +556,37 @@ def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, g
             eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.asarray(hs, dtype=np.float64))
             zs = list(z_all)
         return A, zs, snaps
+    # A caller that wants the field after every step (return_steps), a progress bar, or SSFM_CHIRP_LOOP=python: the same C entry point a step at a time
+    # (ssfm_chirp_propagate with one step size, or -- adaptive -- with max_steps = 1 over what is left of the length: the step rule is evaluated on the
+    # device in the caller's arithmetic either way, so the schedule is the whole run's bit for bit)
+    def after_step(hk):
+        if return_steps:
+            snaps.append(A.copy())
+        if bar is not None:
+            bar.update(min(100.0 * float(hk) / float(L), max(0.0, 100.0 - bar.n)))
+            bar.set_postfix(FFTs=2 * steps)
     if h is None:
         b2, b3 = rt(beta_2), rt(beta_3)
         single = bool((b2 == 0 and b3 == 0) or rt(gamma) == 0)
-
-        def next_h(amax):
-            with np.errstate(divide="ignore"):
-                return rt(phi_max) / (abs(rt(gamma)) * rt(amax))
-        if single:
-            hcur = L
-        else:
-            a0 = A.to_host()                                    # max |A|^2 of the input (one download)
-            hcur = next_h(np.max(a0.real ** 2 + a0.imag ** 2))
-        hcur = rt(min(hcur, L))
         z = rt(0)
         while z < L:
-            z = rt(z + hcur)
-            eng.step(A, P, Dt, g, float(hcur), mb)
+            if single:
+                eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(L)]))
+                hk = L
+            else:
+                _, zz = eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, None, length=float(rt(L - z)), phi_max=float(rt(phi_max)), f32=(prec == _lib.C64), max_steps=1)
+                hk = rt(zz[1])
+            z = rt(z + hk)
             steps += 1
             zs.append(z)
-            if return_steps:
-                eng.plan.synchronize()                          # copies run on the default stream
-                snaps.append(A.copy())
-            if bar is not None:
-                bar.update(min(100.0 * float(hcur) / float(L), max(0.0, 100.0 - bar.n)))
-                bar.set_postfix(FFTs=2 * steps)
-            hcur = rt(min(next_h(_max_abs2(mb, eng.plan)), rt(L - z)))
+            after_step(hk)
     else:
         hs, z_all = step_schedule(length, h, prec)
         for k, hk in enumerate(hs):
-            eng.step(A, P, Dt, g, float(hk))
-            if return_steps:
-                eng.plan.synchronize()
-                snaps.append(A.copy())
-        steps = hs.size
+            eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(hk)]))
+            steps += 1
+            after_step(hk)
         zs = list(z_all)
-        if bar is not None:
-            bar.update(100)
-            bar.set_postfix(FFTs=2 * int(steps))
     eng.plan.synchronize()
     return A, zs, snaps
 

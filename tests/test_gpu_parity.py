@@ -250,7 +250,7 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
 @pytest.mark.parametrize("n,npol", [(3000, 2), (8176, 2), (8176, 1), (15060, 2), (32752, 2), (40000, 1), (65533, 1)])
 def test_any_length_medium_line_in_one_launch_against_oracle(n, npol, monkeypatch):
     """complex64 callers, fixed steps, 2048 < n <= 65536 (the reference's own generators: PRBS-9 / -11 words at 16 samples per bit are 8176 / 32752 samples):
-    the whole run in one launch on one XCD on a complex64 line of M >= 2n - 1 points (k_medium_chirp, ssfm_chirp_medium) -- against the oracle's complex64
+    the whole run in one launch on one XCD on a complex64 line of M >= 2n - 1 points (k_medium_chirp behind ssfm_chirp_propagate_c64) -- against the oracle's complex64
     run and the float64 restatement after 101 steps (the last one short), the single full-length step of a fibre without nonlinearity, and the five-launch
     complex128 line of the same call (SSFM_MEDIUM=0).  The engine that ran is read back: a silent fall to the general path fails the test."""
     for k in ("SSFM_MEDIUM", "SSFM_MEDIUM_ADAPT", "SSFM_ADAPT_FUSED", "SSFM_CHIRP_LOOP", "SSFM_FUSED_PATIENCE_TICKS", "SSFM_E", "SSFM_EF"):
@@ -289,7 +289,7 @@ def test_any_length_medium_line_in_one_launch_against_oracle(n, npol, monkeypatc
 
 
 def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run(monkeypatch):
-    """ssfm_chirp_medium from the plan level: without patience (SSFM_FUSED_PATIENCE_TICKS=-1) the launch's workgroups give up at their first meeting -- the
+    """The one-XCD chirp-z engine from the plan level (ssfm_chirp_propagate_c64): without patience (SSFM_FUSED_PATIENCE_TICKS=-1) the launch's workgroups give up at their first meeting -- the
     call says so (False), the caller's field is bit for bit what it was, the plan counts a fallback and does not try again; a schedule of more than four
     step sizes is refused before anything is launched; and the same call with patience gives the oracle's result."""
     for k in ("SSFM_MEDIUM", "SSFM_MEDIUM_ADAPT", "SSFM_ADAPT_FUSED", "SSFM_E", "SSFM_EF"):
@@ -304,18 +304,18 @@ def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run
     p = _lib.Plan(M, 2, _lib.C64)
     try:
         A = _lib.DeviceArray.from_host(a, np.complex64, 0)
-        assert p.chirp_medium(A, chirp, Dt, 1.3, hs) is False
+        assert p.chirp_propagate_c64(A, chirp, Dt, 1.3, hs) is False
         np.testing.assert_array_equal(A.to_host(), a)
         info = p.last_run_info()
         assert info["engine"] == "chirp_medium" and info["fell_back"] and info["fallbacks_total"] == 1
-        assert p.chirp_medium(A, chirp, Dt, 1.3, hs) is False            # (the engine is off for this plan now)
+        assert p.chirp_propagate_c64(A, chirp, Dt, 1.3, hs) is False            # (the engine is off for this plan now)
         np.testing.assert_array_equal(A.to_host(), a)
     finally:
         p.close()
     p = _lib.Plan(M, 2, _lib.C64)
     try:
         A = _lib.DeviceArray.from_host(a, np.complex64, 0)
-        assert p.chirp_medium_adapt(A, chirp, Dt, 1.3, 5.0, 0.004, 1000) is None
+        assert p.chirp_propagate_c64(A, chirp, Dt, 1.3, None, length=5.0, phi_max=0.004, max_steps=1000) is None
         np.testing.assert_array_equal(A.to_host(), a)
         info = p.last_run_info()
         assert info["engine"] == "chirp_medium_adaptive" and info["fell_back"] and info["fallbacks_total"] == 1
@@ -325,16 +325,16 @@ def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run
     q = _lib.Plan(M, 2, _lib.C64)
     try:
         A = _lib.DeviceArray.from_host(a, np.complex64, 0)
-        assert q.chirp_medium(A, chirp, Dt, 1.3, np.array([0.5, 0.4, 0.3, 0.2, 0.1])) is False
+        assert q.chirp_propagate_c64(A, chirp, Dt, 1.3, np.array([0.5, 0.4, 0.3, 0.2, 0.1])) is False
         np.testing.assert_array_equal(A.to_host(), a)
-        assert q.chirp_medium(A, chirp, Dt, 1.3, hs) is True
+        assert q.chirp_propagate_c64(A, chirp, Dt, 1.3, hs) is True
         ref = a
         for h in hs:
             ref = orc.fiber_c64(ref, gv.dt, length=float(h), h=float(h), alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
         assert relmax(A.to_host(), ref) < TOL_100
         assert q.last_run_info()["engine"] == "chirp_medium"
         A = _lib.DeviceArray.from_host(a, np.complex64, 0)
-        steps, z = q.chirp_medium_adapt(A, chirp, Dt, 1.3, 5.0, 0.004, 1000)
+        steps, z = q.chirp_propagate_c64(A, chirp, Dt, 1.3, None, length=5.0, phi_max=0.004, max_steps=1000)
         zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, length=5.0, phi_max=0.004, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
         assert abs(steps + 1 - len(zr)) <= 1 and len(z) == steps + 1 and abs(z[-1] - 5.0) < 1e-5
         m = min(len(z), len(zr)) - 1
@@ -1288,7 +1288,7 @@ def test_sosfiltfilt_both_workgroup_shapes(waves, monkeypatch):
 
 
 def test_sosfiltfilt_on_device_buffers():
-    """ssfm_sosfiltfilt_device on the field buffers of complex128 plans: same result as the host entry
+    """ssfm_sosfiltfilt(on_device = 1) on the field buffers of complex128 plans: same result as the host entry
     point, out of place and in place (a propagated field is filtered where it lies)."""
     from scipy import signal as sg
     sos = sg.bessel(4, 0.1, "low", norm="mag", output="sos")
@@ -1704,7 +1704,7 @@ def test_laser_and_mzm_against_golden(golden_dir):
 
 
 def test_device_cumsum_min_and_laser_with_the_device_generator():
-    """ssfm_device_cumsum against numpy.cumsum (tile edges, one tile, many tiles), ssfm_device_min, and the laser's
+    """ssfm_device_cumsum against numpy.cumsum (tile edges, one tile, many tiles), ssfm_device_reduce(SSFM_REDUCE_MIN), and the laser's
     phase / intensity noise from the device generator: the statistics of the reference's model."""
     rng = np.random.default_rng(11)
     for n in (1, 2, 255, 4096, 4097, 3 * 4096 - 1, 300_000, (1 << 20) + 7, 1 << 21):

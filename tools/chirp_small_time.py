@@ -1,5 +1,5 @@
 """Per-step time of chirp-z runs (lengths that are not powers of two) from the difference of a short and a long run: fixed step and adaptive,
-the one-launch engines of n <= 2048 (default) or the launch-per-pass loop (SSFM_CHIRP_SMALL=0).  SSFM_CHIRP_DEBUG=1 adds the enqueue / total split (dev aid)."""
+the one-launch engines of n <= 2048 (default) or the launch-per-pass loop (SSFM_CHIRP_SMALL=0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
