@@ -110,6 +110,25 @@ void* ssfm_field_device_ptr(ssfm_plan* plan);
 int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps,
                          void* snapshots);
 
+/* z-resolved capture that does not stall the loop.  The reference's return_steps keeps the field after EVERY step
+ * (devices.py:1150-1152,1184-1186: 16 GiB for the 1000-step run of a 2^20-sample dual-polarisation field) and its consumers plot a few hundred of them
+ * (devices.py:2326-2563); ssfm_propagate_fixed(..., snapshots) reproduces that.  This entry point takes
+ *   every     > 0 with `fields`: the field after every `every`-th step and after the last one, behind the input (snapshot 0):
+ *             1 + ceil(nsteps / every) snapshots of batch x n complex values of the plan's type; 0 with fields == NULL: none
+ *   fields    HOST -- page-locked (ssfm_device_alloc(SSFM_HOST_PINNED, ...)) for the transfers to run beside the kernels -- or NULL
+ *   scalars   HOST or NULL: (nsteps + 1) x batch x 2 doubles -- after every step s (0: the input) and for every row the mean and the maximum of |A|^2 (the
+ *             column kernels have |A|^2 in registers: every wavefront stores its sum and maximum, a small kernel adds them up behind the run in a fixed order)
+ * and keeps the fused two-kernel engine: only a capture step splits the column launch in two; a stream of its own copies the field into one of two plan-owned
+ * device blocks and sends full blocks to `fields` while the run goes on; nothing waits for the host.  Asynchronous: `fields` / `scalars` are valid after
+ * ssfm_synchronize.  The run itself is ssfm_propagate_fixed's, kernel for kernel: a capture step only ADDS a launch that writes the time-order field of that step
+ * beside it, so the end field and every snapshot are bit for bit what a plain run of that many steps leaves. */
+typedef struct ssfm_capture {
+    int64_t every;
+    void* fields;
+    double* scalars;
+} ssfm_capture;
+int ssfm_propagate_fixed_capture(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, const ssfm_capture* cap);
+
 /* Adaptive run (reference devices.py:1155-1156, 1193-1196): h = phi_max / max(|gamma| |A|^2),
  * maximum over all rows of the plan, clamped to length - z; z and h live on the device.
  *   single_step  the caller's evaluation of `(beta_2 == 0 and beta_3 == 0) or gamma == 0`

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSFM_LIB") or os.path.join(_HERE, "_ssfm_amd.so")   # SSFM_LIB: dev override
 
 C64, C128 = 0, 1
+F64_REAL = 2                           # ssfm_device_convert only: real float64 values
 HOST_PINNED = -1                       # ssfm_device_alloc / _free: a page-locked host buffer
 REDUCE_MEAN, REDUCE_MEAN2, REDUCE_POWER, REDUCE_MIN = 0, 1, 2, 3      # ssfm_device_reduce
 _CDTYPE = {C64: np.complex64, C128: np.complex128}
@@ -35,6 +36,7 @@ SYMBOLS = {
     "ssfm_field_device_ptr": (_VP, [_VP]),
     "ssfm_propagate_fixed": (_I, [_VP, _D, _VP, _I64, _VP]),
     "ssfm_propagate_adaptive": (_I, [_VP, _D, _D, _D, _I, _I64, C.POINTER(_I64), C.POINTER(_D), _VP]),
+    "ssfm_propagate_fixed_capture": (_I, [_VP, _D, _VP, _I64, _VP]),
     "ssfm_adaptive_begin": (_I, [_VP, _D, _D, _D, _I, _I64, _I]),
     "ssfm_adaptive_run": (_I, [_VP, _I64, _VP, C.POINTER(_I64), C.POINTER(_I)]),
     "ssfm_adaptive_finish": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
@@ -87,6 +89,11 @@ SYMBOLS = {
 # enum ssfm_engine of include/ssfm_amd.h, by value
 ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adaptive_fused", "small_adaptive", "medium_adaptive",
            "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium", "chirp_medium_adaptive")
+
+
+class Capture(C.Structure):
+    """``ssfm_capture`` of include/ssfm_amd.h."""
+    _fields_ = [("every", C.c_int64), ("fields", C.c_void_p), ("scalars", C.c_void_p)]
 
 
 class RunInfo(C.Structure):
@@ -235,12 +242,13 @@ class _PinnedBlock:
             pass
 
 
-def host_empty(shape, dtype) -> np.ndarray:
+def host_empty(shape, dtype, limit: int = 256 << 20) -> np.ndarray:
     """Uninitialised array for a device-to-host copy: page-locked when that is available (no page faults, no on-the-fly
-    locking of the destination by the runtime), plain ``np.empty`` otherwise or for empty shapes."""
+    locking of the destination by the runtime), plain ``np.empty`` otherwise, for empty shapes and beyond ``limit`` bytes
+    (the every-step captures of many GiB stay pageable)."""
     shape = tuple(int(d) for d in shape)
     nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-    if nbytes == 0 or nbytes > (256 << 20):                  # (z-resolved captures of many GiB stay pageable)
+    if nbytes == 0 or nbytes > limit:
         return np.empty(shape, dtype=dtype)
     try:
         return np.asarray(_PinnedBlock(shape, dtype))
@@ -568,6 +576,34 @@ class Plan:
         _check(load().ssfm_propagate_fixed(self._h, float(gamma), _ptr(hs), hs.size,
                                            _ptr(snap) if snap is not None else None), "ssfm_propagate_fixed")
         return snap
+
+    def propagate_fixed_capture(self, gamma: float, h_schedule, every=None, scalars: bool = False) -> dict:
+        """A fixed-step run with a z-resolved capture that does not stall it (``ssfm_propagate_fixed_capture``): the field after every ``every``-th step
+        (and the input, and the last step) into page-locked memory while the run goes on, and / or the per-step scalars.  Returns a dict with
+        ``steps`` (indices of the captured steps, 0 = the input), ``fields`` (len(steps), batch, n) and, with ``scalars``, ``power`` and ``peak``
+        (nsteps + 1, batch): mean and maximum of |A|^2 of every row after every step.  Synchronous at this level (the C call is not)."""
+        hs = np.ascontiguousarray(h_schedule, dtype=self.rdtype)
+        if hs.size < 1:
+            raise ValueError("the schedule is empty")
+        out, cap = {}, Capture(0, None, None)
+        if every is not None:
+            every = int(every)
+            if every < 1:
+                raise ValueError(f"every = {every}")
+            idx = list(range(0, hs.size, every)) + [hs.size]
+            out["steps"] = np.asarray(idx, dtype=np.int64)
+            # (page-locked up to 8 GiB: the transfers of a strided capture run beside the kernels only into page-locked memory)
+            out["fields"] = host_empty((len(idx), self.batch, self.n), self.cdtype, limit=8 << 30)
+            cap.every, cap.fields = every, out["fields"].ctypes.data
+        raw = None
+        if scalars:
+            raw = host_empty((hs.size + 1, self.batch, 2), np.float64)
+            cap.scalars = raw.ctypes.data
+        _check(load().ssfm_propagate_fixed_capture(self._h, float(gamma), _ptr(hs), hs.size, C.byref(cap)), "ssfm_propagate_fixed_capture")
+        self.synchronize()
+        if raw is not None:
+            out["power"], out["peak"] = raw[..., 0].copy(), raw[..., 1].copy()
+        return out
 
     def propagate_adaptive(self, gamma, length, phi_max, single_step, max_steps=1 << 16, snapshots=False):
         """Adaptive run; returns ``(steps, z float64 (steps + 1,), snapshots or None)``.  A z-resolved capture is taken in

@@ -55,6 +55,14 @@ hipError_t launch_time_n1(dim3 grid, hipStream_t s, const TimeArgs<T>& a) {
     else {
     constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)N1 * C * sizeof(cx<T>) : 0) + (size_t)E * C * sizeof(cx<T>)
                          + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<T>);
+    if constexpr (MODE == TM_BEGIN || MODE == TM_MID || MODE == TM_END) {
+        if (a.scal != nullptr) {             // a capture run with the scalar log: the instantiation that keeps it (ssfm_kernels.hpp time_body, LOG)
+            static hipError_t attr_log = allow_lds(k_time<T, N1, C, E, MODE, U16, true>, lds);
+            if (attr_log != hipSuccess) return attr_log;
+            hipLaunchKernelGGL((k_time<T, N1, C, E, MODE, U16, true>), grid, dim3(N1 * C / E), lds, s, SSFM_TIME_KERNEL_ARGS(a));
+            return hipGetLastError();
+        }
+    }
     static hipError_t attr = allow_lds(k_time<T, N1, C, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((k_time<T, N1, C, E, MODE, U16>), grid, dim3(N1 * C / E), lds, s, SSFM_TIME_KERNEL_ARGS(a));
@@ -385,6 +393,7 @@ struct PlanBase {
     virtual ~PlanBase() {}
 };
 
+constexpr int kMaxLanesConst = 8;
 template <typename T> struct PlanT : PlanBase {
     int device = 0;
     int64_t n = 0;
@@ -475,6 +484,17 @@ template <typename T> struct PlanT : PlanBase {
     int64_t lane_check_launches = 0;
     hipEvent_t lane_e0 = nullptr, lane_e1 = nullptr;      // brackets of a rating measurement
     hipEvent_t run_e0 = nullptr, run_e1 = nullptr;        // brackets of the last run that lane_health looks at (its own pair: ev0 / ev1 are re-recorded by every entry point)
+    // ---- z-resolved capture that does not stall the loop (propagate_fixed_capture, round 5): a stream of its own for the copies, two plan-owned device
+    // blocks of snapshots that take turns (one is filled by device-to-device copies while the other goes to the host), the scalar log
+    hipStream_t cap_stream = nullptr;
+    std::vector<hipEvent_t> cap_ev_ends[kMaxLanesConst];  // per lane and snapshot: the lane's END of that capture step ...
+    std::vector<hipEvent_t> cap_ev_copies;                // ... per snapshot: the copy that read the field behind them
+    hipEvent_t cap_ev_done = nullptr;
+    char* cap_block[2] = {nullptr, nullptr};
+    size_t cap_block_bytes = 0;
+    double* cap_scal = nullptr;                           // the wavefronts' pairs, then the reduced log
+    size_t cap_scal_bytes = 0;
+    bool cap_pending = false;                             // copies of the last capture run may still be on their way: ssfm_synchronize waits for them
     // A caller that has asked for ssfm_stream() or ssfm_field_device_ptr() may order its own work behind a run without ssfm_synchronize(): for it a
     // run of the one-launch engine of medium plans is resolved (waited for, checked, repeated on the two-kernel engine if need be) before
     // ssfm_propagate_fixed returns
@@ -608,6 +628,12 @@ template <typename T> struct PlanT : PlanBase {
         if (lane_e1) (void)hipEventDestroy(lane_e1);
         if (run_e0) (void)hipEventDestroy(run_e0);
         if (run_e1) (void)hipEventDestroy(run_e1);
+        if (cap_stream) (void)hipStreamSynchronize(cap_stream);
+        for (auto& v : cap_ev_ends) for (hipEvent_t e : v) (void)hipEventDestroy(e);
+        for (hipEvent_t e : cap_ev_copies) (void)hipEventDestroy(e);
+        if (cap_ev_done) (void)hipEventDestroy(cap_ev_done);
+        (void)hipFree(cap_block[0]); (void)hipFree(cap_block[1]); (void)hipFree(cap_scal);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (auto& p : prof) {
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
             p.ev.clear();
@@ -1246,6 +1272,30 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
 
+    // What a capture run (propagate_fixed_capture) adds to propagate_fixed's lanes: where the scalar log of a step goes, and what happens at a capture step.
+    struct CapRun {
+        int64_t every = 0;                  // > 0: snapshots
+        char* host = nullptr;               // the caller's buffer
+        double* scal = nullptr;             // the wavefronts' pairs: [step][row][per_row][2]
+        size_t step_doubles = 0;
+        int per_row = 0;
+        size_t fb = 0;
+        int64_t per_block = 0, in_block = 0, flushed = 0;
+        int blk = 0;
+        std::atomic<int64_t> ends_done[kMaxLanesConst];     // snapshots whose END event a lane has recorded
+        std::atomic<int64_t> copies_done{0};                // snapshots whose copy has been queued
+        std::atomic<int> failed{0};
+        double* scal_at(int64_t step, int row0) const { return scal ? scal + step_doubles * (size_t)step + (size_t)row0 * per_row * 2 : nullptr; }
+        bool wait_for(std::atomic<int64_t>& c, int64_t want) {
+            while (c.load(std::memory_order_acquire) < want) {
+                if (failed.load()) return false;
+                std::this_thread::yield();
+            }
+            return true;
+        }
+    };
+    CapRun* cap_run = nullptr;              // set around the propagate_fixed call of a capture run
+
     int propagate_fixed(double gamma_d, const T* h, int64_t nsteps, void* snapshots) {
         if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_fixed: call ssfm_set_linear_operator first");
         if (int rc = use_device()) return rc;
@@ -1280,8 +1330,8 @@ template <typename T> struct PlanT : PlanBase {
         const bool med_elig = medium_ok && sizeof(T) == 4 && u16 && E == 8 && Ef == 8 && medium_shape(N1, N2) && use_tables && !profiling
                                && snapshots == nullptr && twA != nullptr && nsteps >= 2 && nsteps <= 0x7fffffff
                                && med_blocks % kBarShards == 0 && med_blocks <= 64 && med_samples <= medium_max_samples && (use_phase || !phase_tables || !op_flat_re);
-        const bool go_small = small_sched && snapshots == nullptr && !(med_elig && n >= 8192);
-        const bool go_medium = med_elig && !go_small;
+        const bool go_small = small_sched && snapshots == nullptr && !(med_elig && n >= 8192) && cap_run == nullptr;      // (a capture run: the two-kernel engine)
+        const bool go_medium = med_elig && !go_small && cap_run == nullptr;
         last_fell_back = 0;
         last_engine = (go_small || (small_sched && snapshots != nullptr)) ? SSFM_ENGINE_SMALL : go_medium ? SSFM_ENGINE_MEDIUM : SSFM_ENGINE_TWO_KERNEL;
         if (use_tables && !go_small && !go_medium)
@@ -1309,25 +1359,72 @@ template <typename T> struct PlanT : PlanBase {
         const T half = (T)0.5;
         for (auto& p : prof) p.n = 0;
         HIP_TRY(hipEventRecord(ev0, stream));
-        const bool health = snapshots == nullptr && !go_small && !go_medium && nlanes > 1 && !profiling && !SSFM_TRACE && nsteps >= 64 && run_e0 != nullptr;
+        const bool health = snapshots == nullptr && !go_small && !go_medium && nlanes > 1 && !profiling && !SSFM_TRACE && nsteps >= 64 && run_e0 != nullptr && cap_run == nullptr;
         if (health) HIP_TRY(hipEventRecord(run_e0, stream));
         // one lane's launches, start to end
+        // one lane's launches, start to end.  A capture run (cap_run) adds: the scalar log's address to the column launches, and at a capture step an END
+        // launch BESIDE the run -- it only reads the half-transformed field and leaves this step's time-order field in F (once the copy of the previous
+        // snapshot has read what it overwrites); the MID behind it continues exactly as a run without capture does, so the snapshots and the end field are a
+        // plain run's, bit for bit.  The copy stream takes F into a device block behind every lane's END (lane 0's thread queues it: the lanes' threads meet
+        // through two counters) and sends full blocks to the host while the run goes on.
         auto lane_run = [&](int g) -> int {
             const int rows = batch / nlanes;
-            ++last_launches;
-            HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], targs(gamma, 0, h[0] * half, nullptr, g * rows, g), E)));
-            for (int64_t s = 0; s < nsteps; ++s) {
-                HIP_TRY(freq_rows(h[s], g * rows, rows, lane_stream[g]));
+            CapRun* const cr = cap_run;
+            auto body = [&]() -> int {
+                TimeArgs<T> tb = targs(gamma, 0, h[0] * half, nullptr, g * rows, g);
+                if (cr) tb.scal = cr->scal_at(0, g * rows);
                 ++last_launches;
-                if (s + 1 < nsteps)
-                    HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows, g), E)));
-                else
-                    HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], targs(gamma, h[s] * half, 0, nullptr, g * rows, g), E)));
-            }
-            return SSFM_OK;
+                HIP_TRY((launch_time<T, TM_BEGIN>(N1, rows, lane_stream[g], tb, E)));
+                int64_t k = 1;                                       // the next snapshot
+                for (int64_t s = 0; s < nsteps; ++s) {
+                    HIP_TRY(freq_rows(h[s], g * rows, rows, lane_stream[g]));
+                    const bool last = s + 1 == nsteps;
+                    const bool snap = cr && cr->every > 0 && (last || (s + 1) % cr->every == 0);
+                    if (snap || last) {
+                        if (cr && cr->every > 0) {
+                            if (!cr->wait_for(cr->copies_done, k)) return SSFM_ERR_HIP;
+                            HIP_TRY(hipStreamWaitEvent(lane_stream[g], cap_ev_copies[k - 1], 0));
+                        }
+                        TimeArgs<T> te = targs(gamma, h[s] * half, 0, nullptr, g * rows, g);
+                        if (cr && last) te.scal = cr->scal_at(s + 1, g * rows);
+                        ++last_launches;
+                        HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], te, E)));
+                        if (snap) {
+                            HIP_TRY(hipEventRecord(cap_ev_ends[g][k], lane_stream[g]));
+                            cr->ends_done[g].store(k + 1, std::memory_order_release);
+                            if (g == 0) {
+                                for (int o = 0; o < nlanes; ++o) {
+                                    if (!cr->wait_for(cr->ends_done[o], k + 1)) return SSFM_ERR_HIP;
+                                    HIP_TRY(hipStreamWaitEvent(cap_stream, cap_ev_ends[o][k], 0));
+                                }
+                                HIP_TRY(hipMemcpyAsync(cap_block[cr->blk] + cr->fb * (size_t)cr->in_block, F, cr->fb, hipMemcpyDeviceToDevice, cap_stream));
+                                HIP_TRY(hipEventRecord(cap_ev_copies[k], cap_stream));
+                                ++cr->in_block;
+                                if (cr->in_block == cr->per_block || last) {
+                                    HIP_TRY(hipMemcpyAsync(cr->host + cr->fb * (size_t)cr->flushed, cap_block[cr->blk], cr->fb * (size_t)cr->in_block, hipMemcpyDeviceToHost, cap_stream));
+                                    cr->flushed += cr->in_block; cr->in_block = 0; cr->blk ^= 1;      // (the copy stream is in order: a block's transfer is behind it before anything is copied into it again)
+                                }
+                                cr->copies_done.store(k + 1, std::memory_order_release);
+                            }
+                            ++k;
+                        }
+                    }
+                    if (!last) {
+                        TimeArgs<T> tm = targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows, g);
+                        if (cr) tm.scal = cr->scal_at(s + 1, g * rows);
+                        ++last_launches;
+                        HIP_TRY((launch_time<T, TM_MID>(N1, rows, lane_stream[g], tm, E)));
+                    }
+                }
+                return SSFM_OK;
+            };
+            const int rc = body();
+            if (rc != SSFM_OK && cr) cr->failed.store(1);
+            return rc;
         };
         auto enqueue_steps = [&]() -> int {
-            if (nlanes > 1 && lane_threads && !profiling && nsteps >= 16) {
+            if (cap_run != nullptr && nlanes == 1) return lane_run(0);
+            if (nlanes > 1 && ((lane_threads && !profiling && nsteps >= 16) || cap_run != nullptr)) {
                 // every lane from a host thread of its own (LaneWorker): lane 0 from this one
                 HIP_TRY(hipEventRecord(fork_ev, stream));
                 for (int g = 1; g < nlanes; ++g) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
@@ -1462,6 +1559,104 @@ template <typename T> struct PlanT : PlanBase {
             lane_check_launches = 2 * nsteps + 1;
         }
         if (snapshots != nullptr) HIP_TRY(hipStreamSynchronize(stream));
+        return SSFM_OK;
+    }
+
+    // ---- z-resolved capture with a stride and a scalar log (the reference collects the field after EVERY step, devices.py:1150-1152,
+    // 1184-1186 -- 16 GiB for the headline run -- and its consumers, devices.py:2326-2563, plot a few hundred of them).  The run keeps the fused two-kernel
+    // engine: only at a capture step is the column kernel split into END (which leaves the time-order field in F) and the next step's BEGIN; a stream of its
+    // own copies F into one of two plan-owned device blocks as soon as every lane's END is through, and sends a full block to the caller's (page-locked)
+    // buffer while the run goes on -- the loop never waits for the host or for PCIe; the next capture's END waits (on the device) for the copy that read F.
+    // The scalar log costs two atomics per wavefront in the column kernels (time_body, TimeArgs::scal).  Asynchronous: the buffers are valid after
+    // ssfm_synchronize.
+    static int64_t capture_count(int64_t nsteps, int64_t every) { return every > 0 ? 1 + (nsteps + every - 1) / every : 0; }
+    int propagate_fixed_capture(double gamma_d, const T* h, int64_t nsteps, int64_t every, void* fields_host, double* scalars_host) {
+        if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_fixed_capture: call ssfm_set_linear_operator first");
+        if (nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: nsteps=%lld", (long long)nsteps);
+        if ((fields_host != nullptr) != (every > 0)) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: `fields` and `every` > 0 go together");
+        if (!fields_host && !scalars_host) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: nothing to capture");
+        if (int rc = use_device()) return rc;
+        if (int rc = lane_health()) return rc;
+        for (int64_t s = 0; s < nsteps; ++s)
+            if (!(h[s] > (T)0) || !std::isfinite((double)h[s]))
+                return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: step %lld is %g km (must be finite and > 0)", (long long)s, (double)h[s]);
+        const int nl = lanes_active;
+        // the capture's own resources, made on first use
+        if (!cap_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));       // (normal priority: the plan's high-priority class keeps its hardware queues for the lanes)
+            HIP_TRY(hipEventCreateWithFlags(&cap_ev_done, hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamSynchronize(cap_stream));                                      // (the previous capture run's copies, should any be left)
+        const size_t fb = sizeof(cx<T>) * (size_t)n * batch;
+        const int64_t nsnap = capture_count(nsteps, every);
+        int64_t per_block = 0;
+        if (fields_host) {
+            // a block leaves for the host as soon as it is full: small blocks (8 MiB; one snapshot of a large field) keep the transfers beside the run and
+            // leave little of them behind its end
+            per_block = (int64_t)std::max<size_t>(1, std::min<size_t>((size_t(8) << 20) / fb, 64));
+            per_block = std::min<int64_t>(per_block, nsnap);
+            if (cap_block_bytes < fb * (size_t)per_block) {
+                (void)hipFree(cap_block[0]); (void)hipFree(cap_block[1]); cap_block[0] = cap_block[1] = nullptr; cap_block_bytes = 0;
+                HIP_TRY(hipMalloc(&cap_block[0], fb * (size_t)per_block));
+                HIP_TRY(hipMalloc(&cap_block[1], fb * (size_t)per_block));
+                cap_block_bytes = fb * (size_t)per_block;
+            }
+        }
+        // the scalar log: a pair per wavefront of the column kernels, row and step; reduced to a pair per row and step behind the run (k_scal_reduce)
+        const int per_row = (N2 / cols_per_tile<T>()) * ((N1 * cols_per_tile<T>() / E + 63) / 64);
+        const size_t step_doubles = (size_t)batch * per_row * 2, raw_b = sizeof(double) * step_doubles * (size_t)(nsteps + 1);
+        const size_t red_b = sizeof(double) * 2 * (size_t)batch * (size_t)(nsteps + 1);
+        if (scalars_host && cap_scal_bytes < raw_b + red_b) {
+            (void)hipFree(cap_scal); cap_scal = nullptr; cap_scal_bytes = 0;
+            HIP_TRY(hipMalloc(&cap_scal, raw_b + red_b));
+            cap_scal_bytes = raw_b + red_b;
+        }
+        // Events of the capture points: one per lane and snapshot (an event that is recorded again before its waiter has been queued would tie a copy to
+        // a LATER END -- which itself waits for that copy), one per copy.  Made once, kept by the plan.
+        while ((int64_t)cap_ev_copies.size() < nsnap) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            cap_ev_copies.push_back(e);
+        }
+        for (int g = 0; g < nl; ++g)
+            while ((int64_t)cap_ev_ends[g].size() < nsnap) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                cap_ev_ends[g].push_back(e);
+            }
+        CapRun cr;
+        cr.every = fields_host ? every : 0; cr.host = static_cast<char*>(fields_host); cr.scal = scalars_host ? cap_scal : nullptr;
+        cr.step_doubles = step_doubles; cr.per_row = per_row; cr.fb = fb; cr.per_block = per_block;
+        for (auto& e : cr.ends_done) e.store(0);
+        // the input is snapshot 0: the copy stream reads F behind everything queued on the plan's stream so far
+        if (fields_host) {
+            HIP_TRY(hipEventRecord(fork_ev, stream));
+            HIP_TRY(hipStreamWaitEvent(cap_stream, fork_ev, 0));
+            HIP_TRY(hipMemcpyAsync(cap_block[0], F, fb, hipMemcpyDeviceToDevice, cap_stream));
+            HIP_TRY(hipEventRecord(cap_ev_copies[0], cap_stream));
+            cr.in_block = 1;
+            if (cr.in_block == cr.per_block) {
+                HIP_TRY(hipMemcpyAsync(cr.host, cap_block[0], fb, hipMemcpyDeviceToHost, cap_stream));
+                cr.flushed = 1; cr.in_block = 0; cr.blk = 1;
+            }
+            cr.copies_done.store(1);
+            for (int g = 0; g < nl; ++g) cr.ends_done[g].store(1);
+        }
+        cap_run = &cr;
+        const int run_rc = propagate_fixed(gamma_d, h, nsteps, nullptr);             // (the run itself: propagate_fixed's lanes with the hooks above)
+        cap_run = nullptr;
+        if (run_rc != SSFM_OK) { (void)hipDeviceSynchronize(); return run_rc; }
+        if (scalars_host) {
+            // the log goes to the host behind the run: a pair (mean |A|^2, max |A|^2) per row and step
+            double* red = cap_scal + step_doubles * (size_t)(nsteps + 1);
+            HIP_TRY(hipStreamWaitEvent(cap_stream, ev1, 0));
+            hipLaunchKernelGGL(k_scal_reduce<0>, dim3((unsigned)((nsteps + 1) * batch)), dim3(64), 0, cap_stream, (const double*)cap_scal, red, per_row, 1.0 / (double)n);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(scalars_host, red, red_b, hipMemcpyDeviceToHost, cap_stream));
+        }
+        HIP_TRY(hipEventRecord(cap_ev_done, cap_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, cap_ev_done, 0));          // (whatever is ordered on the plan's stream next -- ssfm_synchronize included -- comes behind the copies)
+        cap_pending = true;
         return SSFM_OK;
     }
 
@@ -2382,6 +2577,13 @@ int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, 
     return static_cast<PlanT<double>*>(plan->impl)->propagate_fixed(gamma, static_cast<const double*>(h_schedule), nsteps, snapshots);
 }
 
+int ssfm_propagate_fixed_capture(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, const ssfm_capture* cap) {
+    if (!h_schedule || !cap) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: NULL argument");
+    if (!plan || !plan->impl) return fail(SSFM_ERR_INVALID, "null plan");
+    if (plan->impl->precision == SSFM_C64)
+        return static_cast<PlanT<float>*>(plan->impl)->propagate_fixed_capture(gamma, static_cast<const float*>(h_schedule), nsteps, cap->every, cap->fields, cap->scalars);
+    return static_cast<PlanT<double>*>(plan->impl)->propagate_fixed_capture(gamma, static_cast<const double*>(h_schedule), nsteps, cap->every, cap->fields, cap->scalars);
+}
 int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double phi_max, int single_step,
                             int64_t max_steps, int64_t* steps_out, double* z_out, void* snapshots) {
     WITH_PLAN(plan, P_->propagate_adaptive(gamma, length, phi_max, single_step, max_steps, steps_out, z_out, snapshots));

@@ -233,6 +233,9 @@ template <typename T> struct TimeArgs {
     T* pkeep;                 // PK: the thread's E values of |A|^2 stay in registers from one column pass to the next (the same workgroup has the tile
                               // every time) instead of going through the P buffer
     int keep = 0;             // PK, TM_MID: > 0 = the samples from this position of the row on are set to zero behind the rotation (chirp-z: the line's padding)
+    double* scal = nullptr;   // per-step scalar log of a z-resolved capture (ssfm_propagate_fixed_capture), this launch's step and first row: [row][wavefront of the
+                              // launch's row][2] doubles -- every wavefront stores the sum and the maximum of ITS |A|^2 (one 16-byte store, no atomics: k_scal_reduce
+                              // adds them up in a fixed order behind the run); nullptr: none
     ChirpIO<T> cz = {};       // chirp-z steps (plain layout, TM_BEGIN / TM_END): see ChirpIO
     SSFM_TRACE_ARGS
 };
@@ -557,10 +560,41 @@ __device__ __forceinline__ unsigned xcc_id() {
     return v & 15u;
 }
 
+// Sum (MAX = false) or maximum of a value over the live lanes of a wavefront, for lane 0: the 16 lanes of a row by four DPP steps (quad swaps, then the
+// two mirrors -- lanes that already agree pairwise need no true butterfly), the rows by v_readlane.  About a dozen VALU instructions; a butterfly of
+// ds_bpermute (__shfl_xor) is six dependent trips through the LDS pipeline, ~0.5 us on a wave's critical path (measured: the scalar log of a capture
+// cost 14 % of a step with it).  NT: threads of the workgroup (the smallest plans run less than a wavefront).
+template <int CTRL> __device__ __forceinline__ float dpp_move(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
+template <int CTRL> __device__ __forceinline__ double dpp_move(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ float lane_value(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ __forceinline__ double lane_value(double x, int lane) {
+    const long long b = __double_as_longlong(x);
+    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), lane) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane));
+}
+template <int NT, bool MAX, typename T> __device__ __forceinline__ double wave_total(T x) {
+    auto op = [](T p, T q) -> T { if constexpr (MAX) return q > p ? q : p; else return p + q; };
+    x = op(x, dpp_move<0xB1>(x));            // quad_perm [1,0,3,2]
+    x = op(x, dpp_move<0x4E>(x));            // quad_perm [2,3,0,1]
+    x = op(x, dpp_move<0x141>(x));           // row_half_mirror
+    x = op(x, dpp_move<0x140>(x));           // row_mirror: all 16 lanes of a row hold the row's total
+    constexpr int ROWS16 = NT < 16 ? 1 : (NT < 64 ? NT : 64) / 16;      // (lanes beyond the workgroup's threads are not live: a DPP read of them gives 0, which neither a sum nor a maximum of |A|^2 minds)
+    T r = lane_value(x, 0);
+#pragma unroll
+    for (int i = 1; i < ROWS16; ++i) r = op(r, lane_value(x, 16 * i));
+    return (double)r;
+}
+
 // The body of k_time for workgroup `bid` of `nblk`.  PK: called from the persistent kernel of the medium plans (k_medium), where
 // the field between the passes was stored by other workgroups of the SAME launch: it is read with sc1 loads (the stores are
 // write-through already), MI355X_MICROARCH.md "Valid forms".
-template <typename T, int N1, int C, int E, int MODE, bool U16, bool PK = false>
+// LOG: the instantiation that keeps the scalar log of a capture run (TimeArgs::scal).  A template parameter rather than a test of the pointer: the kernels of
+// every other run are then the very code they were without it -- the same registers, the same contractions, the same bits (a run-time branch in the column
+// kernels changed which products the compiler fuses, and the adaptive step's z log with them, in the last bit).
+template <typename T, int N1, int C, int E, int MODE, bool U16, bool PK = false, bool LOG = false>
 __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned bid, const unsigned nblk) {
     constexpr int Q = N1 / E;                      // threads per column
     static_assert(!U16 || (sizeof(T) == 4 && C == 16 && Q % 4 == 0 && E % 2 == 0), "U16 layout: complex64, 16 columns, whole waves of 4 j");
@@ -815,6 +849,22 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     T pmax = (T)0;
     T phi[E];
     T pnew[E];
+    // z-resolved scalars (ssfm_propagate_fixed_capture): a wavefront's sum and maximum of |A|^2, taken where |A|^2 is in registers (below) and stored at the
+    // very END of the kernel, behind the field stores, write-through like them.  Not earlier: the store is inline assembly, which the compiler's wait counters
+    // do not see -- a later `s_waitcnt vmcnt` meant for this kernel's loads would wait for the store's trip to memory as well (measured: + 2 us per launch);
+    // and not a plain store: a kernel that leaves any line dirty in its XCD's L2 pays ~0.9 us more at its end.
+    double log_sum = 0.0, log_max = 0.0;
+    auto log_store = [&]() {
+        if constexpr (LOG) {
+            if ((tid & 63) == 0) {
+                constexpr int NW = (NT + 63) / 64;
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+                d2_t q; q.x = log_sum; q.y = log_max;
+                d2_t* dst = &reinterpret_cast<d2_t*>(a.scal)[((long long)brow * (a.N2 / C) + tile) * NW + (tid >> 6)];
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(q) : "memory");
+            }
+        }
+    };
     bool fwd_active = true;               // TM_MID_A: false when this step ends the run
     auto store_pnew = [&]() {
         if constexpr (PK) {
@@ -1000,6 +1050,17 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         phi[t] = ph;
         pmax = p > pmax ? p : pmax;
     }
+    if constexpr (LOG) {
+        // z-resolved scalars (ssfm_propagate_fixed_capture): the field's power and peak after the step this launch ends (BEGIN: of the input) -- |A|^2 is in
+        // registers here anyway; a wavefront stores the sum and the maximum of its values as one 16-byte pair of its own (no atomics, nothing waits).
+        {
+            T sum = pnew[0];
+#pragma unroll
+            for (int t = 1; t < E; ++t) sum += pnew[t];
+            log_sum = wave_total<NT, false>(sum);
+            log_max = wave_total<NT, true>(pmax);
+        }
+    }
     }
     if constexpr (MODE != TM_MID_L) {
     store_pnew();
@@ -1111,6 +1172,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 atomicMax(&a.st->slots[a.step & 1][bid % kAdaptSlots], float_bits<T>(m));
             }
         }
+        log_store();
         SSFM_TRACE_END(a);
         return;
     }
@@ -1132,6 +1194,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
 #pragma unroll
         for (int t = 0; t < E; ++t) pass_store<PK>(&Yb[off + t * stride], cmul(v[t], w[t]));
     }
+    log_store();
 #if SSFM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1144,6 +1207,25 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
 // scalar and pointer arguments, not for aggregates, 14 dwords at most (16 user SGPRs less the segment pointer).  So the two kernels of a step take
 // what their heads need as leading scalars and the rest -- the fields of the other modes -- as a trailing struct that is fetched where it is used.  (k_medium and the
 // single-launch engines call time_body / freq_body themselves and keep their structs.)
+// The scalar log of a capture: `per` (sum, max) pairs per (step, row), as the column kernels' wavefronts left them -> out[(step, row)] = (mean |A|^2, max |A|^2).
+// One wavefront per (step, row), a fixed order of additions: the log is reproducible bit for bit.
+template <int UNUSED = 0> __global__ __launch_bounds__(64) void k_scal_reduce(const double* __restrict__ raw, double* __restrict__ out, int per, double inv_n) {      // (a template: one definition across the translation units)
+    const long long item = blockIdx.x;
+    const double* r = raw + item * (long long)per * 2;
+    double sum = 0.0, mx = 0.0;
+    for (int i = threadIdx.x; i < per; i += 64) {
+        sum += r[2 * i];
+        mx = r[2 * i + 1] > mx ? r[2 * i + 1] : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        const double other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    if (threadIdx.x == 0) { out[2 * item] = sum * inv_n; out[2 * item + 1] = mx; }
+}
+
 template <typename T> struct TimeArgsCold {
     cx<T>* F;
     const cx<T>* twN;
@@ -1155,30 +1237,31 @@ template <typename T> struct TimeArgsCold {
     const cx<T>* mul;
     T* pkeep;
     int keep;
+    double* scal;
     ChirpIO<T> cz;
     SSFM_TRACE_ARGS
 };
 template <typename T> __host__ __device__ inline TimeArgsCold<T> time_args_cold(const TimeArgs<T>& a) {
     TimeArgsCold<T> c;
-    c.keep = a.keep;
+    c.keep = a.keep; c.scal = a.scal;
     c.F = a.F; c.twN = a.twN; c.st = a.st; c.zlog = a.zlog; c.step = a.step; c.derive = a.derive; c.s_in = a.s_in; c.s_out = a.s_out; c.mul = a.mul; c.pkeep = a.pkeep; c.cz = a.cz;
 #if SSFM_TRACE
     c.trace = a.trace; c.trace_slot = a.trace_slot;
 #endif
     return c;
 }
-template <typename T, int N1, int C, int E, int MODE, bool U16 = false>
+template <typename T, int N1, int C, int E, int MODE, bool U16 = false, bool LOG = false>
 __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(cx<T>* Y, T* P, const cx<T>* twA, const cx<T>* twB, const cx<T>* tw1, int N2, int rows, int Qf,
                                                                      T gamma, T hh_prev, T hh_next, const TimeArgsCold<T> c) {
     // (14 dwords are preloaded: the five pointers, N2, rows, Qf and gamma -- what stands in front of the first load; the two half steps follow by scalar load)
     TimeArgs<T> a;
     a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.gamma = gamma; a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = rows; a.Qf = Qf;
     a.F = c.F; a.twN = c.twN; a.st = c.st; a.zlog = c.zlog; a.step = c.step; a.derive = c.derive; a.s_in = c.s_in; a.s_out = c.s_out; a.mul = c.mul; a.pkeep = c.pkeep; a.cz = c.cz;
-    a.keep = c.keep;
+    a.keep = c.keep; a.scal = c.scal;
 #if SSFM_TRACE
     a.trace = c.trace; a.trace_slot = c.trace_slot;
 #endif
-    time_body<T, N1, C, E, MODE, U16, false>(a, blockIdx.x, gridDim.x);
+    time_body<T, N1, C, E, MODE, U16, false, LOG>(a, blockIdx.x, gridDim.x);
 }
 // host side: the launch of k_time from a TimeArgs
 #define SSFM_TIME_KERNEL_ARGS(a) (a).Y, (a).P, (a).twA, (a).twB, (a).tw1, (a).N2, (a).rows, (a).Qf, (a).gamma, (a).hh_prev, (a).hh_next, ssfm::time_args_cold(a)

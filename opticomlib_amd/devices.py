@@ -604,7 +604,8 @@ def FIBER(input: optical_signal,
           return_steps: bool = False,
           *,
           precision="complex64",
-          device=None):
+          device=None,
+          every: int = None):
     """Optical fibre: symmetric split-step Fourier solution of the scalar NLSE per polarisation.
 
     Parameters as the reference (``devices.py:1038-1083``): ``length`` [km], ``alpha`` [dB/km],
@@ -614,7 +615,11 @@ def FIBER(input: optical_signal,
     with ``return_steps``, ``(z float64 (S+1,), A_z (S+1, [2,] N))``.
 
     Extensions (keyword-only, defaults keep the reference's behaviour): ``precision``
-    ``"complex64"`` (the reference's arithmetic) or ``"complex128"``; ``device`` index.
+    ``"complex64"`` (the reference's arithmetic) or ``"complex128"``; ``device`` index; ``every``
+    (with ``return_steps`` and a fixed ``h`` on a power-of-two length): keep the field after every
+    ``every``-th step only (plus the input and the last step) -- the run stays on the fused engine and the
+    snapshots travel to page-locked host memory beside it (``ssfm_propagate_fixed_capture``); the reference
+    keeps every step, 16 GiB for the 1000-step run of a 2^20-sample dual-polarisation field.
     """
     t0 = time.time()
     input, grid, back = _adopt(input, "optical_signal")
@@ -665,8 +670,9 @@ def FIBER(input: optical_signal,
         if bar is not None:
             bar.close()
         if return_steps:
-            A_z = np.stack([s_.to_host() for s_ in snaps]).astype(plan_dtype).reshape((len(snaps),) + tuple(shape))
-            return np.asarray(zs, dtype=np.float64), A_z
+            keep = _every_index(len(snaps) - 1, every)
+            A_z = np.stack([snaps[k].to_host() for k in keep]).astype(plan_dtype).reshape((len(keep),) + tuple(shape))
+            return np.asarray(zs, dtype=np.float64)[keep], A_z
         res = out if out.dtype == plan_dtype else out.astype(plan_dtype)
         res.shape = tuple(shape)
         output = _wrap_out(optical_signal, res, NULL)
@@ -678,11 +684,21 @@ def FIBER(input: optical_signal,
     plan = get_plan(n, batch, prec, dev)
     with plan.lock:
         return back(_fiber_on_plan(plan, A, A_dev, shape, float(grid.dt), L, length, alpha, beta_2, beta_3, gamma, phi_max, h,
-                                   show_progress, return_steps, prec, plan_dtype, rt, dev, t0))
+                                   show_progress, return_steps, prec, plan_dtype, rt, dev, t0, every))
+
+
+def _every_index(steps: int, every):
+    """Indices of the snapshots ``every`` keeps of a run of ``steps`` steps: 0 (the input), every ``every``-th step, the last one."""
+    if every is None:
+        return list(range(steps + 1))
+    every = int(every)
+    if every < 1:
+        raise ValueError(f"every = {every}")
+    return list(range(0, steps, every)) + [steps]
 
 
 def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, gamma, phi_max, h, show_progress, return_steps,
-                   prec, plan_dtype, rt, dev, t0):
+                   prec, plan_dtype, rt, dev, t0, every=None):
     """The fused two-kernel engine behind ``FIBER`` (the caller holds the plan's lock for the whole sequence)."""
     n = shape[-1]
     batch = 1 if len(shape) == 1 else shape[0]
@@ -711,7 +727,10 @@ def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, 
         hs, z = step_schedule(length, h, prec)
         steps = hs.size
         snaps = None
-        if return_steps:
+        if return_steps and every is not None and steps:
+            cap = plan.propagate_fixed_capture(gamma, hs, every=every)
+            snaps, z, every = cap["fields"], np.asarray(z)[cap["steps"]], None              # (thinned already)
+        elif return_steps:
             snaps = plan.propagate_fixed(gamma, hs, snapshots=True) if steps else plan.get_field().reshape(1, batch, n)
         elif bar is not None and steps:
             done = 0
@@ -730,6 +749,9 @@ def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, 
         bar.close()
 
     if return_steps:
+        if every is not None and snaps.shape[0] == len(z):         # (the adaptive run, or a run of no steps: every snapshot was taken; thinned here)
+            keep = _every_index(snaps.shape[0] - 1, every)
+            snaps, z = snaps[keep], np.asarray(z)[keep]
         A_z = snaps.reshape((snaps.shape[0],) + shape)
         return np.asarray(z, dtype=np.float64), A_z
     if KEEP_ON_DEVICE:

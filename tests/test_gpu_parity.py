@@ -885,6 +885,70 @@ def test_a_stream_ordered_consumer_never_sees_a_run_that_gave_up(tmp_path):
     assert "engine 1 fell_back 1 fallbacks 1; stream-ordered copy equals the two-kernel result" in r.stdout
 
 
+def test_strided_capture_golden_and_against_every_step(golden_dir):
+    """``FIBER(return_steps=True, every=k)`` (ssfm_propagate_fixed_capture): the reference's return_steps golden vector sub-sampled, and -- bit for bit -- the
+    rows of this library's own every-step capture; strides that divide the run, that do not, and one longer than the run."""
+    g = np.load(os.path.join(golden_dir, "return_steps_1k.npz"))
+    spec = CASES["return_steps_1k"]
+    x = _signal(spec)
+    kw = dict(spec["kw"])
+    kw.pop("return_steps")
+    z_all, A_all = oa.FIBER(x, return_steps=True, **kw)
+    np.testing.assert_array_equal(z_all, g["z"])
+    for every in (1, 2, 3, 5, 7):
+        z, A_z = oa.FIBER(x, return_steps=True, every=every, **kw)
+        keep = list(range(0, 5, every)) + [5]
+        assert A_z.dtype == np.complex64 and A_z.shape == (len(keep),) + A_all.shape[1:]
+        np.testing.assert_array_equal(z, g["z"][keep])
+        assert relmax(A_z, g["A_z"][keep]) < TOL_100
+        # the every-step capture of a plan this small is taken by the one-launch engine, the strided one by the two-kernel engine: the same arithmetic class
+        assert relmax(A_z, A_all[keep]) < 2e-6
+
+
+@pytest.mark.parametrize("log2n,npol,lanes", [(14, 2, 1), (16, 1, 1), (19, 2, 2), (20, 2, 2)])
+def test_strided_capture_and_scalar_log_against_the_plain_run(log2n, npol, lanes, monkeypatch):
+    """ssfm_propagate_fixed_capture at the plan level, one lane and two: every snapshot is bit for bit the field a plain run of that many steps leaves (the same
+    kernels in the same order: a capture step only splits the column launch), the run's end is the plain run's end, and the scalar log -- power and peak of
+    every row after every step, accumulated inside the column kernels -- agrees with the snapshots' own."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    monkeypatch.setenv("SSFM_LANES", str(lanes))
+    a = workloads.qpsk_field(n, seed=31, n_pol=2)[:npol].astype(np.complex64)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    hs = np.array([0.25] * 22 + [0.125], dtype=np.float32)
+    p = _lib.Plan(n, npol, _lib.C64)
+    try:
+        assert p.lanes == lanes
+        p.set_linear_operator(D)
+        p.set_field(a)
+        cap = p.propagate_fixed_capture(1.3, hs, every=5, scalars=True)
+        end = p.get_field()
+        assert list(cap["steps"]) == [0, 5, 10, 15, 20, 23] and p.last_run_info()["engine"] == "two_kernel"
+        np.testing.assert_array_equal(cap["fields"][0], a)
+        np.testing.assert_array_equal(cap["fields"][-1], end)
+        for k, s_ in enumerate(cap["steps"][1:], start=1):
+            p.set_field(a); p.propagate_fixed(1.3, hs[:s_]); p.synchronize()
+            want = p.get_field()
+            if p.last_run_info()["engine"] == "two_kernel":
+                np.testing.assert_array_equal(cap["fields"][k], want)
+            else:                                                    # (plans the one-launch engines take: another order of the same operations)
+                assert relmax(cap["fields"][k], want) < 5e-6
+        power = np.mean(np.abs(cap["fields"].astype(np.complex128)) ** 2, axis=-1)
+        peak = np.max(np.abs(cap["fields"].astype(np.complex128)) ** 2, axis=-1)
+        assert cap["power"].shape == (24, npol) and cap["peak"].shape == (24, npol)
+        np.testing.assert_allclose(cap["power"][cap["steps"]], power, rtol=5e-6)         # (the log sums |A|^2 in float32, as the kernels hold it)
+        np.testing.assert_allclose(cap["peak"][cap["steps"]], peak, rtol=2e-6)
+        assert np.all(np.diff(cap["power"], axis=0) < 0)              # 0.2 dB/km: the power falls at every step
+        # scalars alone: no field leaves the device, the run is the plain run
+        p.set_field(a)
+        only = p.propagate_fixed_capture(1.3, hs, scalars=True)
+        assert "fields" not in only
+        np.testing.assert_array_equal(only["power"], cap["power"])                        # (the log is reduced in a fixed order: reproducible bit for bit)
+        np.testing.assert_array_equal(only["peak"], cap["peak"])
+    finally:
+        p.close()
+
+
 def test_the_lanes_of_a_plan_get_hardware_queues_of_their_own(monkeypatch):
     """The runtime maps the streams of a priority class onto four hardware queues; with 3 (mod 4) other streams of the class alive the second
     lane of a new plan used to land on the queue of the first (profiles/r04_order_dependence.txt): lanes one after the other; and lanes on queues of
