@@ -143,6 +143,28 @@ def gpu_numa_nodes():
     return nodes
 
 
+def visible_gpu_order(n_physical, env=None):
+    """Physical indices of the GPUs this process will see, in the order HIP numbers them: ROCR_VISIBLE_DEVICES filters (and reorders) first, then
+    HIP_VISIBLE_DEVICES (or CUDA_VISIBLE_DEVICES) picks among what is left.  Entries that are not plain indices (UUIDs) leave the mapping unknown: None."""
+    env = os.environ if env is None else env
+    order = list(range(n_physical))
+    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in env else "CUDA_VISIBLE_DEVICES"):
+        val = env.get(name)
+        if val is None or val.strip() == "":
+            continue
+        picked = []
+        for part in val.split(","):
+            part = part.strip()
+            if not part.lstrip("-").isdigit():
+                return None
+            k = int(part)
+            if k < 0 or k >= len(order):
+                break                                             # (the runtime stops at the first invalid entry)
+            picked.append(order[k])
+        order = picked
+    return order
+
+
 def plan_affinity(local_rank, world, nodes, node_cpus, allowed):
     """The CPU set of rank `local_rank`: the allowed cores of its GPU's NUMA node, dealt evenly to the ranks whose GPUs share that node
     (rank r takes every k-th core from its position among them).  None = leave the affinity alone (unknown topology, or too few cores)."""
@@ -165,6 +187,11 @@ def pin_to_gpu_node(local_rank, world):
     try:
         allowed = os.sched_getaffinity(0)
         nodes = gpu_numa_nodes()
+        # a launcher that masks or reorders the devices (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): rank r's GPU is the r-th VISIBLE one
+        order = visible_gpu_order(len(nodes))
+        if order is None:
+            return f"unchanged ({len(allowed)} cores; the visible-devices mask is not a list of indices)"
+        nodes = [nodes[k] for k in order]
         import glob
         node_cpus = {}
         for nd in glob.glob("/sys/devices/system/node/node[0-9]*"):

@@ -121,7 +121,8 @@ int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, 
  * and keeps the fused two-kernel engine: only a capture step splits the column launch in two; a stream of its own copies the field into one of two plan-owned
  * device blocks and sends full blocks to `fields` while the run goes on; nothing waits for the host.  Asynchronous: `fields` / `scalars` are valid after
  * ssfm_synchronize.  The run itself is ssfm_propagate_fixed's, kernel for kernel: a capture step only ADDS a launch that writes the time-order field of that step
- * beside it, so the end field and every snapshot are bit for bit what a plain run of that many steps leaves. */
+ * beside it, so the end field and every snapshot are bit for bit what a plain run of that many steps leaves (with `scalars` the column kernels are another
+ * instantiation -- the log is compiled in, not tested for -- and agree with the plain run's to the last bits of a fused product). */
 typedef struct ssfm_capture {
     int64_t every;
     void* fields;

@@ -432,6 +432,9 @@ template <> __device__ __forceinline__ void sincos_acc<double>(double x, double&
 // bytes a dual-polarisation sample*step moves.  |A|^2 only ever enters the phase h/2 gamma |A|^2 (devices.py:1175,1181), so what counts is the
 // ABSOLUTE error of that phase: at most 2^-17 of the thread's largest phase (7.6e-6 of <= 0.05 rad; the float32 product itself carries 6e-8
 // relative).  The buffer is private to a tile (the same thread reads back what it wrote), so the scale needs no agreement between threads.
+// Stated bound: absolute phase error <= 2^-17 x the thread's largest half-step phase, per half step -- inside the suite's 2e-5 @ 100 steps for peaks up to
+// ~0.1 rad per half step (tests/test_gpu_parity.py::test_the_16_bit_stale_power_holds_its_stated_phase_bound; the reference's adaptive rule keeps 0.005 ... 0.05,
+// the benchmark configurations 4e-4).  A fixed h that turns more per step is outside it (as it is outside any sensible splitting error).
 template <typename T, bool U16, int E> __host__ __device__ constexpr bool p16_layout() { return U16 && sizeof(T) == 4 && E == 16; }
 template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
@@ -849,8 +852,8 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     T pmax = (T)0;
     T phi[E];
     T pnew[E];
-    // z-resolved scalars (ssfm_propagate_fixed_capture): a wavefront's sum and maximum of |A|^2, taken where |A|^2 is in registers (below) and stored at the
-    // very END of the kernel, behind the field stores, write-through like them.  Not earlier: the store is inline assembly, which the compiler's wait counters
+    // z-resolved scalars (ssfm_propagate_fixed_capture): a wavefront's sum and maximum of |A|^2, taken where |A|^2 is in registers (below) and stored behind
+    // the kernel's last transform, just ahead of the field stores and write-through like them.  Not earlier: the store is inline assembly, which the compiler's wait counters
     // do not see -- a later `s_waitcnt vmcnt` meant for this kernel's loads would wait for the store's trip to memory as well (measured: + 2 us per launch);
     // and not a plain store: a kernel that leaves any line dirty in its XCD's L2 pays ~0.9 us more at its end.
     double log_sum = 0.0, log_max = 0.0;
@@ -1180,6 +1183,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     constexpr int NX = fft_nstages(N1, E) - 1;      // exchanges of the inverse transform
     constexpr int XP_FWD = ((MODE != TM_MID && MODE != TM_MID_A && MODE != TM_MID_L) || NX == 0) ? 0 : 1;
     if (!SSFM_ABL_NO_FFT) fft_line<T, N1, E, -1, XP_FWD, CI>(v, lds, 0, j, idx, tw);
+    log_store();                 // (behind the kernel's last load, ahead of its field stores: see log_store)
     if (U16) {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = cmul(v[t], w[t]);
@@ -1194,7 +1198,6 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
 #pragma unroll
         for (int t = 0; t < E; ++t) pass_store<PK>(&Yb[off + t * stride], cmul(v[t], w[t]));
     }
-    log_store();
 #if SSFM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -2597,8 +2600,10 @@ template <typename T> __global__ void k_absmax(const cx<T>* __restrict__ F, long
 template <typename T> __global__ void k_step_control(AdaptState<T>* st, T* zlog, int phase, int single_step, int step) {
     if (phase == 0) {
         const unsigned long long mb = slots_max<T>(st, 1);
-        if (threadIdx.x < kAdaptSlots)
-            st->slots[0][threadIdx.x] = 0ull; st->slots[1][threadIdx.x] = 0ull;
+        if (threadIdx.x < kAdaptSlots) {            // (both stores inside the guard: the kernel is launched with 64 threads, but nothing here may depend on that)
+            st->slots[0][threadIdx.x] = 0ull;
+            st->slots[1][threadIdx.x] = 0ull;
+        }
         if (threadIdx.x != 0) return;
         T h;
         if (single_step) h = st->length;

@@ -137,3 +137,19 @@ def test_bench_ranks_keep_stdout_for_the_json_line():
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"value": 2}\n'
     assert "RCCL version" in r.stderr and "chatter" in r.stderr
+
+
+def test_bench_maps_ranks_to_numa_nodes_through_the_visible_devices_mask():
+    """A driver that masks or reorders devices (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): rank r's GPU is the r-th VISIBLE one, and its CPU set follows."""
+    import bench
+    assert bench.visible_gpu_order(8, {}) == list(range(8))
+    assert bench.visible_gpu_order(8, {"HIP_VISIBLE_DEVICES": "4,5,6,7"}) == [4, 5, 6, 7]
+    assert bench.visible_gpu_order(8, {"ROCR_VISIBLE_DEVICES": "7,6,5,4", "HIP_VISIBLE_DEVICES": "1,0"}) == [6, 7]
+    assert bench.visible_gpu_order(8, {"CUDA_VISIBLE_DEVICES": "2"}) == [2]
+    assert bench.visible_gpu_order(8, {"HIP_VISIBLE_DEVICES": "0,9,1"}) == [0]            # the runtime stops at the first invalid entry
+    assert bench.visible_gpu_order(8, {"HIP_VISIBLE_DEVICES": "GPU-abc"}) is None
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    cpus = {0: set(range(0, 64)), 1: set(range(64, 128))}
+    vis = [nodes[k] for k in bench.visible_gpu_order(8, {"HIP_VISIBLE_DEVICES": "4,5"})]
+    assert bench.plan_affinity(0, 2, vis, cpus, set(range(128))) == set(range(64, 96))
+    assert bench.plan_affinity(1, 2, vis, cpus, set(range(128))) == set(range(96, 128))
