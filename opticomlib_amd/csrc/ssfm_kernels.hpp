@@ -954,6 +954,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 // a lane asks again only for the words it has not seen complete (512 workgroups x 512 words per round would be 2 MiB of
                 // 8-byte uncached reads per round: the first form of this loop made the hand-over 6 us long)
                 unsigned pending = 0u;
+                unsigned rounds_ = 0u;
 #pragma unroll
                 for (int i = 0; i < kAdaptWords / 64; ++i)
                     if ((unsigned)tid + 64u * (unsigned)i < total) pending |= 1u << i;
@@ -972,8 +973,10 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                         }
                     }
                     if (__all(pending == 0u)) { good = 1; break; }
-                    if (wall_clock64() - t0 > a.st->patience) break;              // the grid is not running as a whole -- give up, never hang
-                    __builtin_amdgcn_s_sleep(4);
+                    // (the clock is looked at every 16th round only -- s_memrealtime is a trip through the scalar memory path -- and the rounds are 64 instead of
+                    // 256 cycles apart: 22.95 -> 22.43 us per step of the 652-step run at 2^20 x 2, profiles/r05_adaptive.txt)
+                    if ((++rounds_ & 15u) == 0u && wall_clock64() - t0 > a.st->patience) break;              // the grid is not running as a whole -- give up, never hang
+                    __builtin_amdgcn_s_sleep(1);
                 }
                 if (good) {
 #pragma unroll
@@ -1624,8 +1627,8 @@ __device__ __forceinline__ bool medium_barrier(unsigned long long* bar, unsigned
             unsigned long long got = want;
             if ((unsigned)tid < nblk) got = ld_l2_u64(&bar[kBarShards + tid]) >= epoch ? want : 0ull;
             if (__all(got >= want)) { good = 1; break; }
-            if (wall_clock64() - t0 > patience) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > patience) break;                  // (looking at the clock only every 16th round changes nothing here: 4.59 / 5.70 / 5.82 against
+            __builtin_amdgcn_s_sleep(1);                                //  4.61 / 5.70 / 5.81 us per step at 2^13 x 2 / 2^14 / 2^14 x 2, profiles/r05_adaptive.txt)
         }
         if (tid == 0) { s_bar_ok[0] = good; if (!good) atomicExch(error, 1u); }
     }
