@@ -43,3 +43,15 @@ for what in "c1:tools/c1_prof.py" "adaptive:tools/adaptive_prof.py" "sos:tools/s
   find ${T}_${name}prof -name "*kernel_trace.csv" -size +1M -delete
 done
 python tools/cfg_times.py > ${T}_cfg_times.txt 2>&1; cat ${T}_cfg_times.txt
+# round 5: SQ counters of the complex128 kernels (configuration C1), its kernels alone / beside each other / with two fields resident, the adaptive long run,
+# the capture beside the run, the lanes test 200 times in one process
+rm -rf ${T}_c1sq
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d ${T}_c1sq -- python3 tools/c1_prof.py > /dev/null 2> ${T}_c1sq.err
+python tools/sq_summary.py ${T}_c1sq "k_freq_c128=k_freq<double" "k_time_mid_c128=k_time<double, 256, 8, 8, 1" > ${T}_c1_sq.txt; cat ${T}_c1_sq.txt
+find ${T}_c1sq -name "*.csv" -size +1M -delete
+{ PREC=c128 POL=1 STEPS=100 python tools/step_time.py "C1, one polarisation (one lane: its kernels alone on the chip)";
+  PREC=c128 POL=2 STEPS=100 python tools/step_time.py "C1 (two lanes)";
+  PREC=c128 POL=2 FIELDS=2 STEPS=100 python tools/step_time.py "C1, two fields resident (four lanes)";
+  python tools/attic/adapt_long.py; } > ${T}_c1_alone.txt 2>&1; cat ${T}_c1_alone.txt
+python tools/capture_time.py > /dev/null 2>&1; cp gpurun_out/r05_capture_time.txt ${T}_capture_time.txt; cat ${T}_capture_time.txt
+python tests/diag/lane_stability.py 200 > /dev/null 2>&1; cp gpurun_out/r05_lane_stability.txt ${T}_lane_stability.txt; tail -1 ${T}_lane_stability.txt
