@@ -484,17 +484,20 @@ template <typename T> struct PlanT : PlanBase {
     int64_t lane_check_launches = 0;
     hipEvent_t lane_e0 = nullptr, lane_e1 = nullptr;      // brackets of a rating measurement
     hipEvent_t run_e0 = nullptr, run_e1 = nullptr;        // brackets of the last run that lane_health looks at (its own pair: ev0 / ev1 are re-recorded by every entry point)
-    // ---- z-resolved capture that does not stall the loop (propagate_fixed_capture, round 5): a stream of its own for the copies, two plan-owned device
-    // blocks of snapshots that take turns (one is filled by device-to-device copies while the other goes to the host), the scalar log
+    // ---- z-resolved capture that does not stall the loop (propagate_fixed_capture, round 5): a stream of its own for the transfers, a ring of plan-owned
+    // device blocks of snapshots (filled by the capture steps' END launches, sent to the host by a helper thread -- cap_worker -- as they fill), the scalar log.
+    // Nothing on the device waits across streams: a stream blocked on another stream's event slows every other queue's launches (see propagate_fixed_capture).
+    static constexpr int kCapBlocksMax = 8;
     hipStream_t cap_stream = nullptr;
-    std::vector<hipEvent_t> cap_ev_ends[kMaxLanesConst];  // per lane and snapshot: the lane's END of that capture step ...
-    std::vector<hipEvent_t> cap_ev_copies;                // ... per snapshot: the copy that read the field behind them
-    hipEvent_t cap_ev_done = nullptr;
-    char* cap_block[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> cap_ev_ends[kMaxLanesConst];  // per lane and flush: the lane's END that filled the block
+    hipEvent_t cap_ev_in = nullptr;                       // on the plan's stream, ahead of the run: the input is in F
+    char* cap_blocks = nullptr;                           // kCapBlocksMax blocks at most, cap_block_bytes each
     size_t cap_block_bytes = 0;
+    int cap_nblocks = 0;
     double* cap_scal = nullptr;                           // the wavefronts' pairs, then the reduced log
     size_t cap_scal_bytes = 0;
-    bool cap_pending = false;                             // copies of the last capture run may still be on their way: ssfm_synchronize waits for them
+    LaneWorker cap_worker;                                // the helper thread of a capture run
+    bool cap_pending = false;                             // a capture run's helper may still be at work: the next entry point (use_device) joins it
     // A caller that has asked for ssfm_stream() or ssfm_field_device_ptr() may order its own work behind a run without ssfm_synchronize(): for it a
     // run of the one-launch engine of medium plans is resolved (waited for, checked, repeated on the two-kernel engine if need be) before
     // ssfm_propagate_fixed returns
@@ -603,6 +606,7 @@ template <typename T> struct PlanT : PlanBase {
     T inv_n() const { return (T)1 / (T)n; }
 
     int free_all() {
+        cap_worker.stop();                                  // (finishes a capture run's transfers first)
         for (auto& w : lane_worker) w.stop();
         if (stream) (void)hipStreamSynchronize(stream);
         void* bufs[] = {F, Y != F ? Y : nullptr, P, twN, twA, twB, tw1, tw2, tw2_fly, dnat, dperm, dperm_fly, dimag_fly, scratch, st, zlog, xfer_tab[0], xfer_tab[1]};
@@ -630,9 +634,8 @@ template <typename T> struct PlanT : PlanBase {
         if (run_e1) (void)hipEventDestroy(run_e1);
         if (cap_stream) (void)hipStreamSynchronize(cap_stream);
         for (auto& v : cap_ev_ends) for (hipEvent_t e : v) (void)hipEventDestroy(e);
-        for (hipEvent_t e : cap_ev_copies) (void)hipEventDestroy(e);
-        if (cap_ev_done) (void)hipEventDestroy(cap_ev_done);
-        (void)hipFree(cap_block[0]); (void)hipFree(cap_block[1]); (void)hipFree(cap_scal);
+        if (cap_ev_in) (void)hipEventDestroy(cap_ev_in);
+        (void)hipFree(cap_blocks); (void)hipFree(cap_scal);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (auto& p : prof) {
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
@@ -1017,6 +1020,10 @@ template <typename T> struct PlanT : PlanBase {
 
     int use_device() {
         HIP_TRY(hipSetDevice(device));
+        if (cap_pending) {                 // a capture run's helper thread: its transfers are complete when it returns
+            cap_pending = false;
+            if (int rc = cap_worker.wait()) return rc;
+        }
         return medium_pending ? finish_medium() : (int)SSFM_OK;
     }
     // A single-launch run of a medium plan is asynchronous like every run; whether one of its barriers ran out of patience is known
@@ -1273,27 +1280,35 @@ template <typename T> struct PlanT : PlanBase {
     }
 
     // What a capture run (propagate_fixed_capture) adds to propagate_fixed's lanes: where the scalar log of a step goes, and what happens at a capture step.
+    // Snapshot 0 (the input) and the last one (the end field) go to the host straight from F; the snapshots in between are written by the capture steps'
+    // END launches into slot j % per_block of device block (j / per_block) % nblocks, j = snapshot number - 1, and a block is sent ("flushed") when it is
+    // full -- by the helper thread, which waits ON THE HOST for the lanes' END events and tells the lanes' threads, through `flushes_done`, when a block may
+    // be written again.
     struct CapRun {
         int64_t every = 0;                  // > 0: snapshots
         char* host = nullptr;               // the caller's buffer
+        double* scalars_host = nullptr;
         double* scal = nullptr;             // the wavefronts' pairs: [step][row][per_row][2]
         size_t step_doubles = 0;
-        int per_row = 0;
+        int per_row = 0, nblocks = 0, nlanes = 0;
         size_t fb = 0;
-        int64_t per_block = 0, in_block = 0, flushed = 0;
-        int blk = 0;
-        std::atomic<int64_t> ends_done[kMaxLanesConst];     // snapshots whose END event a lane has recorded
-        std::atomic<int64_t> copies_done{0};                // snapshots whose copy has been queued
+        int64_t per_block = 0, nsnap = 0, nflush = 0, nsteps = 0;
+        std::atomic<int64_t> ends_done[kMaxLanesConst];     // flushes whose last END event a lane has recorded
+        std::atomic<int64_t> flushes_done{0};               // flushes whose transfer is complete (their block may be written again)
+        std::atomic<int64_t> input_done{0};                 // the input's transfer is complete (F may be written)
+        std::atomic<int64_t> run_queued{0};                 // 1: the run is queued (ev1 recorded), 2: it failed
         std::atomic<int> failed{0};
         double* scal_at(int64_t step, int row0) const { return scal ? scal + step_doubles * (size_t)step + (size_t)row0 * per_row * 2 : nullptr; }
         bool wait_for(std::atomic<int64_t>& c, int64_t want) {
-            while (c.load(std::memory_order_acquire) < want) {
+            for (unsigned spins = 0; c.load(std::memory_order_acquire) < want; ++spins) {
                 if (failed.load()) return false;
-                std::this_thread::yield();
+                if (spins < 4096u) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
             return true;
         }
     };
+    CapRun cap_cr;                          // (a member: the helper thread works on it after propagate_fixed_capture has returned)
     CapRun* cap_run = nullptr;              // set around the propagate_fixed call of a capture run
 
     int propagate_fixed(double gamma_d, const T* h, int64_t nsteps, void* snapshots) {
@@ -1361,15 +1376,16 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipEventRecord(ev0, stream));
         const bool health = snapshots == nullptr && !go_small && !go_medium && nlanes > 1 && !profiling && !SSFM_TRACE && nsteps >= 64 && run_e0 != nullptr && cap_run == nullptr;
         if (health) HIP_TRY(hipEventRecord(run_e0, stream));
-        // one lane's launches, start to end
         // one lane's launches, start to end.  A capture run (cap_run) adds: the scalar log's address to the column launches, and at a capture step an END
-        // launch BESIDE the run -- it only reads the half-transformed field and leaves this step's time-order field in F (once the copy of the previous
-        // snapshot has read what it overwrites); the MID behind it continues exactly as a run without capture does, so the snapshots and the end field are a
-        // plain run's, bit for bit.  The copy stream takes F into a device block behind every lane's END (lane 0's thread queues it: the lanes' threads meet
-        // through two counters) and sends full blocks to the host while the run goes on.
+        // launch BESIDE the run -- it only reads the half-transformed field and writes this step's time-order field straight into a slot of a device block
+        // (no copy of F); the MID behind it continues exactly as a run without capture does, so the snapshots and the end field are a plain run's, bit for
+        // bit.  The lane records an event behind the END that fills a block; the helper thread sends the block to the host once every lane's event is
+        // through.  Before a block is written again the lane's THREAD waits (on the host) until the helper has seen its transfer complete: the lanes'
+        // threads run ahead of the GPU by at most the ring of blocks, the GPU never waits as long as PCIe keeps up.
         auto lane_run = [&](int g) -> int {
             const int rows = batch / nlanes;
             CapRun* const cr = cap_run;
+            const bool snaps = cr && cr->every > 0;
             auto body = [&]() -> int {
                 TimeArgs<T> tb = targs(gamma, 0, h[0] * half, nullptr, g * rows, g);
                 if (cr) tb.scal = cr->scal_at(0, g * rows);
@@ -1379,37 +1395,29 @@ template <typename T> struct PlanT : PlanBase {
                 for (int64_t s = 0; s < nsteps; ++s) {
                     HIP_TRY(freq_rows(h[s], g * rows, rows, lane_stream[g]));
                     const bool last = s + 1 == nsteps;
-                    const bool snap = cr && cr->every > 0 && (last || (s + 1) % cr->every == 0);
-                    if (snap || last) {
-                        if (cr && cr->every > 0) {
-                            if (!cr->wait_for(cr->copies_done, k)) return SSFM_ERR_HIP;
-                            HIP_TRY(hipStreamWaitEvent(lane_stream[g], cap_ev_copies[k - 1], 0));
-                        }
+                    if (snaps && !last && (s + 1) % cr->every == 0) {
+                        const int64_t j = k - 1, fl = j / cr->per_block, slot = j % cr->per_block;
+                        const int blk = (int)(fl % cr->nblocks);
+                        if (slot == 0 && fl >= cr->nblocks && !cr->wait_for(cr->flushes_done, fl - cr->nblocks + 1))      // the block is written again
+                            return fail(SSFM_ERR_HIP, "ssfm_propagate_fixed_capture: the transfers failed");
                         TimeArgs<T> te = targs(gamma, h[s] * half, 0, nullptr, g * rows, g);
-                        if (cr && last) te.scal = cr->scal_at(s + 1, g * rows);
+                        te.F = reinterpret_cast<cx<T>*>(cap_blocks + cap_block_bytes * (size_t)blk + cr->fb * (size_t)slot) + (size_t)(g * rows) * n;
                         ++last_launches;
                         HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], te, E)));
-                        if (snap) {
-                            HIP_TRY(hipEventRecord(cap_ev_ends[g][k], lane_stream[g]));
-                            cr->ends_done[g].store(k + 1, std::memory_order_release);
-                            if (g == 0) {
-                                for (int o = 0; o < nlanes; ++o) {
-                                    if (!cr->wait_for(cr->ends_done[o], k + 1)) return SSFM_ERR_HIP;
-                                    HIP_TRY(hipStreamWaitEvent(cap_stream, cap_ev_ends[o][k], 0));
-                                }
-                                HIP_TRY(hipMemcpyAsync(cap_block[cr->blk] + cr->fb * (size_t)cr->in_block, F, cr->fb, hipMemcpyDeviceToDevice, cap_stream));
-                                HIP_TRY(hipEventRecord(cap_ev_copies[k], cap_stream));
-                                ++cr->in_block;
-                                if (cr->in_block == cr->per_block || last) {
-                                    HIP_TRY(hipMemcpyAsync(cr->host + cr->fb * (size_t)cr->flushed, cap_block[cr->blk], cr->fb * (size_t)cr->in_block, hipMemcpyDeviceToHost, cap_stream));
-                                    cr->flushed += cr->in_block; cr->in_block = 0; cr->blk ^= 1;      // (the copy stream is in order: a block's transfer is behind it before anything is copied into it again)
-                                }
-                                cr->copies_done.store(k + 1, std::memory_order_release);
-                            }
-                            ++k;
+                        if (slot == cr->per_block - 1 || k == cr->nsnap - 2) {          // the block is full (or the last one of the run): it leaves
+                            HIP_TRY(hipEventRecord(cap_ev_ends[g][fl], lane_stream[g]));
+                            cr->ends_done[g].store(fl + 1, std::memory_order_release);
                         }
+                        ++k;
                     }
-                    if (!last) {
+                    if (last) {
+                        if (snaps && !cr->wait_for(cr->input_done, 1))                 // (the input's transfer reads F, which this launch overwrites)
+                            return fail(SSFM_ERR_HIP, "ssfm_propagate_fixed_capture: the transfers failed");
+                        TimeArgs<T> te = targs(gamma, h[s] * half, 0, nullptr, g * rows, g);
+                        if (cr) te.scal = cr->scal_at(s + 1, g * rows);
+                        ++last_launches;
+                        HIP_TRY((launch_time<T, TM_END>(N1, rows, lane_stream[g], te, E)));
+                    } else {
                         TimeArgs<T> tm = targs(gamma, h[s] * half, h[s + 1] * half, nullptr, g * rows, g);
                         if (cr) tm.scal = cr->scal_at(s + 1, g * rows);
                         ++last_launches;
@@ -1564,42 +1572,90 @@ template <typename T> struct PlanT : PlanBase {
 
     // ---- z-resolved capture with a stride and a scalar log (the reference collects the field after EVERY step, devices.py:1150-1152,
     // 1184-1186 -- 16 GiB for the headline run -- and its consumers, devices.py:2326-2563, plot a few hundred of them).  The run keeps the fused two-kernel
-    // engine: only at a capture step is the column kernel split into END (which leaves the time-order field in F) and the next step's BEGIN; a stream of its
-    // own copies F into one of two plan-owned device blocks as soon as every lane's END is through, and sends a full block to the caller's (page-locked)
-    // buffer while the run goes on -- the loop never waits for the host or for PCIe; the next capture's END waits (on the device) for the copy that read F.
-    // The scalar log costs two atomics per wavefront in the column kernels (time_body, TimeArgs::scal).  Asynchronous: the buffers are valid after
-    // ssfm_synchronize.
+    // engine: a capture step ADDS an END launch beside the run, which writes that step's time-order field into a slot of a ring of plan-owned device
+    // blocks; a helper thread sends a full block to the caller's (page-locked) buffer on a stream of its own while the run goes on.  The input and the end
+    // field go straight from F.  The scalar log is a 16-byte store per wavefront of the column kernels (time_body<..., LOG>, TimeArgs::scal), reduced behind
+    // the run.  Asynchronous: the buffers are valid after ssfm_synchronize (or any later call on the plan).
+    //
+    // NOTHING on the device waits across streams, and that is the point of the helper thread.  The first form of this function ordered the transfers with
+    // events (hipStreamWaitEvent on the copy stream behind every lane's END, on the lanes behind the transfers): a stream that sits blocked on an event
+    // which is milliseconds away slows the launches of EVERY other queue of the process -- the command processor keeps polling the blocked barrier packet
+    // between their dispatches.  tools/attic/barrier_cost.hip, profiles/r05_barrier_cost.txt: two chains of 8.9 us kernels take 17.8 ms with an idle
+    // third stream, 19.9 / 21.9 / 40 ms with a third stream blocked on an event 5 / 10 / 40 ms away (whatever its priority), 17.7 ms with a spinning
+    // wavefront in its place.  In the capture run that was 1.2-1.4 ms per call (the copy stream's wait for the end of the run, queued 8 ms early -- the
+    // host enqueues ahead) and 0.1 ms per snapshot (the marker behind each 0.7 ms transfer): +18-21 % at every = 100 (profiles/r05_capture_ab.txt).
+    // Host waits (hipEventSynchronize, hipStreamSynchronize) put nothing into a queue.
     static int64_t capture_count(int64_t nsteps, int64_t every) { return every > 0 ? 1 + (nsteps + every - 1) / every : 0; }
+    int capture_helper() {
+        CapRun* const cr = &cap_cr;
+        auto body = [&]() -> int {
+            const bool snaps = cr->every > 0;
+            if (snaps) {                                                // snapshot 0: the input, from F
+                HIP_TRY(hipEventSynchronize(cap_ev_in));
+                HIP_TRY(hipMemcpyAsync(cr->host, F, cr->fb, hipMemcpyDeviceToHost, cap_stream));
+                HIP_TRY(hipStreamSynchronize(cap_stream));
+                cr->input_done.store(1, std::memory_order_release);
+            }
+            for (int64_t fl = 0; fl < cr->nflush; ++fl) {
+                for (int g = 0; g < cr->nlanes; ++g) {
+                    if (!cr->wait_for(cr->ends_done[g], fl + 1)) return fail(SSFM_ERR_HIP, "ssfm_propagate_fixed_capture: the run failed");
+                    HIP_TRY(hipEventSynchronize(cap_ev_ends[g][fl]));
+                }
+                const int64_t first = fl * cr->per_block, count = std::min<int64_t>(cr->per_block, cr->nsnap - 2 - first);
+                HIP_TRY(hipMemcpyAsync(cr->host + cr->fb * (size_t)(1 + first), cap_blocks + cap_block_bytes * (size_t)(fl % cr->nblocks), cr->fb * (size_t)count,
+                                       hipMemcpyDeviceToHost, cap_stream));
+                HIP_TRY(hipStreamSynchronize(cap_stream));
+                cr->flushes_done.store(fl + 1, std::memory_order_release);
+            }
+            if (!cr->wait_for(cr->run_queued, 1) || cr->run_queued.load() != 1) return fail(SSFM_ERR_HIP, "ssfm_propagate_fixed_capture: the run failed");
+            HIP_TRY(hipEventSynchronize(ev1));                         // the end of the run on the plan's stream: every lane has joined
+            if (snaps) HIP_TRY(hipMemcpyAsync(cr->host + cr->fb * (size_t)(cr->nsnap - 1), F, cr->fb, hipMemcpyDeviceToHost, cap_stream));      // the end field is the last snapshot
+            if (cr->scalars_host) {
+                // the log goes to the host behind the run: a pair (mean |A|^2, max |A|^2) per row and step
+                double* red = cr->scal + cr->step_doubles * (size_t)(cr->nsteps + 1);
+                hipLaunchKernelGGL(k_scal_reduce<0>, dim3((unsigned)((cr->nsteps + 1) * batch)), dim3(64), 0, cap_stream, (const double*)cr->scal, red, cr->per_row, 1.0 / (double)n);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(cr->scalars_host, red, sizeof(double) * 2 * (size_t)batch * (size_t)(cr->nsteps + 1), hipMemcpyDeviceToHost, cap_stream));
+            }
+            HIP_TRY(hipStreamSynchronize(cap_stream));
+            return SSFM_OK;
+        };
+        const int rc = body();
+        if (rc != SSFM_OK) cr->failed.store(1);
+        return rc;
+    }
     int propagate_fixed_capture(double gamma_d, const T* h, int64_t nsteps, int64_t every, void* fields_host, double* scalars_host) {
         if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_fixed_capture: call ssfm_set_linear_operator first");
         if (nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: nsteps=%lld", (long long)nsteps);
         if ((fields_host != nullptr) != (every > 0)) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: `fields` and `every` > 0 go together");
         if (!fields_host && !scalars_host) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: nothing to capture");
-        if (int rc = use_device()) return rc;
+        if (int rc = use_device()) return rc;                          // (joins the previous capture run's helper)
         if (int rc = lane_health()) return rc;
         for (int64_t s = 0; s < nsteps; ++s)
             if (!(h[s] > (T)0) || !std::isfinite((double)h[s]))
                 return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: step %lld is %g km (must be finite and > 0)", (long long)s, (double)h[s]);
         const int nl = lanes_active;
-        // the capture's own resources, made on first use
+        // the capture's own resources, made on first use (the copy stream: normal priority -- the plan's high-priority class keeps its queues for the lanes)
         if (!cap_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));       // (normal priority: the plan's high-priority class keeps its hardware queues for the lanes)
-            HIP_TRY(hipEventCreateWithFlags(&cap_ev_done, hipEventDisableTiming));
+            HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&cap_ev_in, hipEventDisableTiming));
         }
-        HIP_TRY(hipStreamSynchronize(cap_stream));                                      // (the previous capture run's copies, should any be left)
         const size_t fb = sizeof(cx<T>) * (size_t)n * batch;
         const int64_t nsnap = capture_count(nsteps, every);
-        int64_t per_block = 0;
-        if (fields_host) {
+        int64_t per_block = 1, nflush = 0;
+        int nblocks = 0;
+        if (fields_host && nsnap > 2) {
             // a block leaves for the host as soon as it is full: small blocks (8 MiB; one snapshot of a large field) keep the transfers beside the run and
-            // leave little of them behind its end
+            // leave little of them behind its end; a ring of up to eight (1 GiB at most) lets the lanes' threads enqueue that far ahead of the transfers
             per_block = (int64_t)std::max<size_t>(1, std::min<size_t>((size_t(8) << 20) / fb, 64));
-            per_block = std::min<int64_t>(per_block, nsnap);
-            if (cap_block_bytes < fb * (size_t)per_block) {
-                (void)hipFree(cap_block[0]); (void)hipFree(cap_block[1]); cap_block[0] = cap_block[1] = nullptr; cap_block_bytes = 0;
-                HIP_TRY(hipMalloc(&cap_block[0], fb * (size_t)per_block));
-                HIP_TRY(hipMalloc(&cap_block[1], fb * (size_t)per_block));
-                cap_block_bytes = fb * (size_t)per_block;
+            per_block = std::min<int64_t>(per_block, nsnap - 2);
+            nflush = (nsnap - 2 + per_block - 1) / per_block;
+            const size_t bb = fb * (size_t)per_block;
+            nblocks = (int)std::min<int64_t>(nflush, std::max<int64_t>(2, std::min<int64_t>(kCapBlocksMax, (int64_t)((size_t(1) << 30) / bb))));
+            if (cap_block_bytes != bb || cap_nblocks < nblocks) {
+                (void)hipFree(cap_blocks); cap_blocks = nullptr; cap_block_bytes = 0; cap_nblocks = 0;
+                HIP_TRY(hipMalloc(&cap_blocks, bb * (size_t)nblocks));
+                cap_block_bytes = bb; cap_nblocks = nblocks;
             }
         }
         // the scalar log: a pair per wavefront of the column kernels, row and step; reduced to a pair per row and step behind the run (k_scal_reduce)
@@ -1611,51 +1667,34 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipMalloc(&cap_scal, raw_b + red_b));
             cap_scal_bytes = raw_b + red_b;
         }
-        // Events of the capture points: one per lane and snapshot (an event that is recorded again before its waiter has been queued would tie a copy to
-        // a LATER END -- which itself waits for that copy), one per copy.  Made once, kept by the plan.
-        while ((int64_t)cap_ev_copies.size() < nsnap) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            cap_ev_copies.push_back(e);
-        }
+        // an event per lane and flush (an event that is recorded again before its waiter has looked at it would tie a transfer to a LATER END)
         for (int g = 0; g < nl; ++g)
-            while ((int64_t)cap_ev_ends[g].size() < nsnap) {
+            while ((int64_t)cap_ev_ends[g].size() < nflush) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 cap_ev_ends[g].push_back(e);
             }
-        CapRun cr;
-        cr.every = fields_host ? every : 0; cr.host = static_cast<char*>(fields_host); cr.scal = scalars_host ? cap_scal : nullptr;
-        cr.step_doubles = step_doubles; cr.per_row = per_row; cr.fb = fb; cr.per_block = per_block;
+        CapRun& cr = cap_cr;
+        cr.every = fields_host ? every : 0; cr.host = static_cast<char*>(fields_host); cr.scalars_host = scalars_host; cr.scal = scalars_host ? cap_scal : nullptr;
+        cr.step_doubles = step_doubles; cr.per_row = per_row; cr.fb = fb; cr.per_block = per_block; cr.nsnap = nsnap; cr.nflush = nflush; cr.nsteps = nsteps;
+        cr.nblocks = nblocks; cr.nlanes = nl;
         for (auto& e : cr.ends_done) e.store(0);
-        // the input is snapshot 0: the copy stream reads F behind everything queued on the plan's stream so far
-        if (fields_host) {
-            HIP_TRY(hipEventRecord(fork_ev, stream));
-            HIP_TRY(hipStreamWaitEvent(cap_stream, fork_ev, 0));
-            HIP_TRY(hipMemcpyAsync(cap_block[0], F, fb, hipMemcpyDeviceToDevice, cap_stream));
-            HIP_TRY(hipEventRecord(cap_ev_copies[0], cap_stream));
-            cr.in_block = 1;
-            if (cr.in_block == cr.per_block) {
-                HIP_TRY(hipMemcpyAsync(cr.host, cap_block[0], fb, hipMemcpyDeviceToHost, cap_stream));
-                cr.flushed = 1; cr.in_block = 0; cr.blk = 1;
-            }
-            cr.copies_done.store(1);
-            for (int g = 0; g < nl; ++g) cr.ends_done[g].store(1);
-        }
+        cr.flushes_done.store(0); cr.input_done.store(0); cr.run_queued.store(0); cr.failed.store(0);
+        if (fields_host) HIP_TRY(hipEventRecord(cap_ev_in, stream));     // (the input is in F once everything queued on the plan's stream so far is through)
+        cap_worker.start(device);
+        cap_worker.submit([this] { return capture_helper(); });
         cap_run = &cr;
         const int run_rc = propagate_fixed(gamma_d, h, nsteps, nullptr);             // (the run itself: propagate_fixed's lanes with the hooks above)
         cap_run = nullptr;
-        if (run_rc != SSFM_OK) { (void)hipDeviceSynchronize(); return run_rc; }
-        if (scalars_host) {
-            // the log goes to the host behind the run: a pair (mean |A|^2, max |A|^2) per row and step
-            double* red = cap_scal + step_doubles * (size_t)(nsteps + 1);
-            HIP_TRY(hipStreamWaitEvent(cap_stream, ev1, 0));
-            hipLaunchKernelGGL(k_scal_reduce<0>, dim3((unsigned)((nsteps + 1) * batch)), dim3(64), 0, cap_stream, (const double*)cap_scal, red, per_row, 1.0 / (double)n);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(scalars_host, red, red_b, hipMemcpyDeviceToHost, cap_stream));
+        cr.run_queued.store(run_rc == SSFM_OK ? 1 : 2, std::memory_order_release);
+        if (run_rc != SSFM_OK) {
+            const std::string err = ssfm::g_err;
+            cr.failed.store(1);
+            (void)cap_worker.wait();
+            (void)hipDeviceSynchronize();
+            std::snprintf(ssfm::g_err, sizeof(ssfm::g_err), "%s", err.c_str());
+            return run_rc;
         }
-        HIP_TRY(hipEventRecord(cap_ev_done, cap_stream));
-        HIP_TRY(hipStreamWaitEvent(stream, cap_ev_done, 0));          // (whatever is ordered on the plan's stream next -- ssfm_synchronize included -- comes behind the copies)
         cap_pending = true;
         return SSFM_OK;
     }

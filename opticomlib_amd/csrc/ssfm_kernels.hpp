@@ -954,7 +954,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 // a lane asks again only for the words it has not seen complete (512 workgroups x 512 words per round would be 2 MiB of
                 // 8-byte uncached reads per round: the first form of this loop made the hand-over 6 us long)
                 unsigned pending = 0u;
-                unsigned rounds_ = 0u;
+                unsigned rounds_ = a.st->patience < 0 ? 15u : 0u;          // (no patience at all -- the give-up test's setting: the first incomplete round ends the wait)
 #pragma unroll
                 for (int i = 0; i < kAdaptWords / 64; ++i)
                     if ((unsigned)tid + 64u * (unsigned)i < total) pending |= 1u << i;

@@ -905,6 +905,43 @@ def test_strided_capture_golden_and_against_every_step(golden_dir):
         assert relmax(A_z, A_all[keep]) < 2e-6
 
 
+@pytest.mark.parametrize("log2n,nsteps,every,check", [(14, 400, 1, (1, 33, 257, 399)), (20, 24, 2, (2, 12, 18, 22))])
+def test_strided_capture_with_more_snapshots_than_device_blocks(log2n, nsteps, every, check):
+    """The snapshots between the input and the end wait in a ring of at most eight device blocks (32 snapshots of a 2^14 x 2 field each, one of a 2^20 x 2
+    field) that the helper thread empties while the run goes on: a run with more flushes than blocks writes blocks again -- every snapshot is still the
+    plain run's of that many steps, bit for bit (spot-checked), and all of them follow the every-step capture of the three-launch form."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=37, n_pol=2).astype(np.complex64)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    hs = np.full(nsteps, 0.05, dtype=np.float32)
+    p = _lib.Plan(n, 2, _lib.C64)
+    try:
+        p.set_linear_operator(D)
+        p.set_field(a)
+        cap = p.propagate_fixed_capture(1.3, hs, every=every)
+        end = p.get_field()
+        assert len(cap["steps"]) == nsteps // every + 1 and len(cap["steps"]) - 2 > 8 * (32 if log2n == 14 else 1)
+        np.testing.assert_array_equal(cap["fields"][0], a)
+        np.testing.assert_array_equal(cap["fields"][-1], end)
+        for s_ in check:
+            p.set_field(a); p.propagate_fixed(1.3, hs[:s_]); p.synchronize()
+            if p.last_run_info()["engine"] == "two_kernel":
+                np.testing.assert_array_equal(cap["fields"][s_ // every], p.get_field())
+            else:                                                    # (plans the one-launch engines take: another order of the same operations, up to 399 steps)
+                assert relmax(cap["fields"][s_ // every], p.get_field()) < 0.5 * TOL_100
+        if log2n == 14:
+            p.set_field(a)
+            every_step = p.propagate_fixed(1.3, hs, snapshots=True)
+            assert relmax(cap["fields"], every_step[cap["steps"]]) < 0.5 * TOL_100
+        # a second capture run on the same plan right behind the first (the helper of the first is joined by the next call on the plan)
+        p.set_field(a)
+        again = p.propagate_fixed_capture(1.3, hs, every=every)
+        np.testing.assert_array_equal(again["fields"], cap["fields"])
+    finally:
+        p.close()
+
+
 @pytest.mark.parametrize("log2n,npol,lanes", [(14, 2, 1), (16, 1, 1), (19, 2, 2), (20, 2, 2)])
 def test_strided_capture_and_scalar_log_against_the_plain_run(log2n, npol, lanes, monkeypatch):
     """ssfm_propagate_fixed_capture at the plan level, one lane and two: every snapshot is bit for bit the field a plain run of that many steps leaves (the same

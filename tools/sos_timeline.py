@@ -10,6 +10,6 @@ dt = np.complex128 if cplx else np.float64
 x = _lib.DeviceArray.from_host(np.random.default_rng(1).standard_normal((rows, n)).astype(dt), dt, 0)
 y = _lib.DeviceArray(x.shape, dt, 0)
 for _ in range(20): _lib.sosfiltfilt_device(sos, zi, x.ptr, y.ptr, n, rows, cplx, 0)
-os.environ["SOS_TIMELINE_DUMP"] = "1"
+os.environ["SOS_TIMELINE_DUMP"] = os.environ.get("SOS_TL_PATH", "1")          # (a path: every workgroup's line goes there)
 _lib.sosfiltfilt_device(sos, zi, x.ptr, y.ptr, n, rows, cplx, 0)
 print("kernels %.1f us" % (_lib.sosfiltfilt_last_ms() * 1e3))
