@@ -118,11 +118,12 @@ int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, 
  *   fields    HOST -- page-locked (ssfm_device_alloc(SSFM_HOST_PINNED, ...)) for the transfers to run beside the kernels -- or NULL
  *   scalars   HOST or NULL: (nsteps + 1) x batch x 2 doubles -- after every step s (0: the input) and for every row the mean and the maximum of |A|^2 (the
  *             column kernels have |A|^2 in registers: every wavefront stores its sum and maximum, a small kernel adds them up behind the run in a fixed order)
- * and keeps the fused two-kernel engine: only a capture step splits the column launch in two; a stream of its own copies the field into one of two plan-owned
- * device blocks and sends full blocks to `fields` while the run goes on; nothing waits for the host.  Asynchronous: `fields` / `scalars` are valid after
- * ssfm_synchronize.  The run itself is ssfm_propagate_fixed's, kernel for kernel: a capture step only ADDS a launch that writes the time-order field of that step
- * beside it, so the end field and every snapshot are bit for bit what a plain run of that many steps leaves (with `scalars` the column kernels are another
- * instantiation -- the log is compiled in, not tested for -- and agree with the plain run's to the last bits of a fused product). */
+ * and keeps the fused two-kernel engine: a capture step ADDS a launch that writes the time-order field of that step into a ring of plan-owned device
+ * blocks; a helper thread of the plan sends full blocks to `fields` on a stream of its own while the run goes on (the GPU never waits for the host, nor one
+ * stream for another: DESIGN.md 8b).  Asynchronous: the call returns when the run is enqueued; `fields` / `scalars` are valid after ssfm_synchronize or
+ * any later call on the plan, and must stay valid until then.  The run itself is ssfm_propagate_fixed's, kernel for kernel, so the end field and every
+ * snapshot are bit for bit what a plain run of that many steps leaves (with `scalars` the column kernels are another instantiation -- the log is
+ * compiled in, not tested for -- and agree with the plain run's to the last bits of a fused product). */
 typedef struct ssfm_capture {
     int64_t every;
     void* fields;

@@ -102,6 +102,9 @@ struct Workspace {
     double* link_T = nullptr;
     unsigned* link_flag = nullptr;
     size_t link_T_cap = 0, link_flag_cap = 0;
+    unsigned long long* link_U = nullptr;    // totals that carry their own validity: 16-byte units {value, tag} (sos_filter_impl.inc group_start)
+    size_t link_U_cap = 0;
+    unsigned long long link_tag = 0;         // the call counter the tags are; never repeated, never 0
     unsigned epoch = 0;
     int* status = nullptr;
     int give_ups = 0;                    // calls IN A ROW that fell back to three launches after waiting in vain; from kMaxGiveUps on the form rests
