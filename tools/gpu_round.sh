@@ -55,3 +55,12 @@ find ${T}_c1sq -name "*.csv" -size +1M -delete
   python tools/attic/adapt_long.py; } > ${T}_c1_alone.txt 2>&1; cat ${T}_c1_alone.txt
 python tools/capture_time.py > /dev/null 2>&1; cp gpurun_out/r05_capture_time.txt ${T}_capture_time.txt; cat ${T}_capture_time.txt
 python tests/diag/lane_stability.py 200 > /dev/null 2>&1; cp gpurun_out/r05_lane_stability.txt ${T}_lane_stability.txt; tail -1 ${T}_lane_stability.txt
+# round 5, late: the one-launch filter after the hand-over change (shapes, the phase timeline of every workgroup -- needs build/var/_ssfm_tl.so -- SQ counters
+# of k_filtfilt), and the cost of a blocked stream-wait packet (tools/attic/barrier_cost.hip, built into build/barrier_cost)
+{ for r in 1 2 3; do echo "== round $r"; python3 tools/filter_shapes.py; done; } > ${T}_sos_shapes.txt 2>&1; tail -6 ${T}_sos_shapes.txt
+if [ -f build/var/_ssfm_tl.so ]; then
+  { echo "== 2^20 x 2 complex128"; SSFM_LIB=$PWD/build/var/_ssfm_tl.so SOS_TL_PATH=$PWD/${T}_sos_timeline_all.txt python3 tools/sos_timeline.py
+    echo "== 2^16 real"; SSFM_LIB=$PWD/build/var/_ssfm_tl.so LOG2N=16 ROWS=1 CPLX=0 python3 tools/sos_timeline.py; } > ${T}_sos_timeline.txt 2>&1
+fi
+[ -x build/barrier_cost ] && { timeout 60 ./build/barrier_cost 5; timeout 60 ./build/barrier_cost 10; timeout 90 ./build/barrier_cost 40; } > ${T}_barrier_cost.txt 2>&1
+bash tools/gpu_pmc_sos.sh ${TAG}_sos_pmc > ${T}_sos_sq.txt 2>&1; tail -6 ${T}_sos_sq.txt
