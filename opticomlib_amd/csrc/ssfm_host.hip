@@ -492,6 +492,8 @@ template <typename T> struct PlanT : PlanBase {
     std::vector<hipEvent_t> cap_ev_ends[kMaxLanesConst];  // per lane and flush: the lane's END that filled the block
     hipEvent_t cap_ev_in = nullptr;                       // on the plan's stream, ahead of the run: the input is in F
     char* cap_blocks = nullptr;                           // kCapBlocksMax blocks at most, cap_block_bytes each
+    char* cap_in = nullptr;                               // plans whose engine works in place (Y == F): a copy of the input, taken ahead of the run
+    size_t cap_in_bytes = 0;
     size_t cap_block_bytes = 0;
     int cap_nblocks = 0;
     double* cap_scal = nullptr;                           // the wavefronts' pairs, then the reduced log
@@ -635,7 +637,7 @@ template <typename T> struct PlanT : PlanBase {
         if (cap_stream) (void)hipStreamSynchronize(cap_stream);
         for (auto& v : cap_ev_ends) for (hipEvent_t e : v) (void)hipEventDestroy(e);
         if (cap_ev_in) (void)hipEventDestroy(cap_ev_in);
-        (void)hipFree(cap_blocks); (void)hipFree(cap_scal);
+        (void)hipFree(cap_blocks); (void)hipFree(cap_in); (void)hipFree(cap_scal);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (auto& p : prof) {
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
@@ -1411,7 +1413,7 @@ template <typename T> struct PlanT : PlanBase {
                         ++k;
                     }
                     if (last) {
-                        if (snaps && !cr->wait_for(cr->input_done, 1))                 // (the input's transfer reads F, which this launch overwrites)
+                        if (snaps && !in_place() && !cr->wait_for(cr->input_done, 1))    // (the input's transfer reads F, which this launch overwrites)
                             return fail(SSFM_ERR_HIP, "ssfm_propagate_fixed_capture: the transfers failed");
                         TimeArgs<T> te = targs(gamma, h[s] * half, 0, nullptr, g * rows, g);
                         if (cr) te.scal = cr->scal_at(s + 1, g * rows);
@@ -1586,13 +1588,14 @@ template <typename T> struct PlanT : PlanBase {
     // host enqueues ahead) and 0.1 ms per snapshot (the marker behind each 0.7 ms transfer): +18-21 % at every = 100 (profiles/r05_capture_ab.txt).
     // Host waits (hipEventSynchronize, hipStreamSynchronize) put nothing into a queue.
     static int64_t capture_count(int64_t nsteps, int64_t every) { return every > 0 ? 1 + (nsteps + every - 1) / every : 0; }
+    bool in_place() const { return static_cast<const void*>(Y) == static_cast<const void*>(F); }
     int capture_helper() {
         CapRun* const cr = &cap_cr;
         auto body = [&]() -> int {
             const bool snaps = cr->every > 0;
             if (snaps) {                                                // snapshot 0: the input, from F
                 HIP_TRY(hipEventSynchronize(cap_ev_in));
-                HIP_TRY(hipMemcpyAsync(cr->host, F, cr->fb, hipMemcpyDeviceToHost, cap_stream));
+                HIP_TRY(hipMemcpyAsync(cr->host, in_place() ? cap_in : reinterpret_cast<const char*>(F), cr->fb, hipMemcpyDeviceToHost, cap_stream));
                 HIP_TRY(hipStreamSynchronize(cap_stream));
                 cr->input_done.store(1, std::memory_order_release);
             }
@@ -1680,7 +1683,19 @@ template <typename T> struct PlanT : PlanBase {
         cr.nblocks = nblocks; cr.nlanes = nl;
         for (auto& e : cr.ends_done) e.store(0);
         cr.flushes_done.store(0); cr.input_done.store(0); cr.run_queued.store(0); cr.failed.store(0);
-        if (fields_host) HIP_TRY(hipEventRecord(cap_ev_in, stream));     // (the input is in F once everything queued on the plan's stream so far is through)
+        if (fields_host) {
+            // the input is in F once everything queued on the plan's stream so far is through.  The plans whose engine transforms F in place (Y == F:
+            // complex128 and the complex64 plans outside the unit layout) overwrite it with their first launch: they keep a copy, made on the plan's stream
+            if (in_place()) {
+                if (cap_in_bytes < fb) {
+                    (void)hipFree(cap_in); cap_in = nullptr; cap_in_bytes = 0;
+                    HIP_TRY(hipMalloc(&cap_in, fb));
+                    cap_in_bytes = fb;
+                }
+                HIP_TRY(hipMemcpyAsync(cap_in, F, fb, hipMemcpyDeviceToDevice, stream));
+            }
+            HIP_TRY(hipEventRecord(cap_ev_in, stream));
+        }
         cap_worker.start(device);
         cap_worker.submit([this] { return capture_helper(); });
         cap_run = &cr;

@@ -905,6 +905,40 @@ def test_strided_capture_golden_and_against_every_step(golden_dir):
         assert relmax(A_z, A_all[keep]) < 2e-6
 
 
+@pytest.mark.parametrize("prec,log2n,npol", [("c128", 16, 2), ("c128", 20, 2), ("c128", 12, 1), ("c64", 10, 1)])
+def test_strided_capture_on_plans_whose_engine_works_in_place(prec, log2n, npol):
+    """complex128 plans and the complex64 plans outside the unit layout transform the field buffer in place: their first launch overwrites the input, which
+    the capture therefore copies ahead of the run (found by tests/diag/capture_stress.py: the input snapshot of such plans raced with the run).  Input,
+    snapshots, end field and the scalar log, with and without the log, twice on the same plan."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    P, dt, rt, tol = (_lib.C128, np.complex128, np.float64, 1e-10) if prec == "c128" else (_lib.C64, np.complex64, np.float32, 5e-6)
+    a = workloads.qpsk_field(n, seed=41, n_pol=2)[:npol].astype(dt)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    hs = np.full(10, 0.05, dtype=rt)
+    p = _lib.Plan(n, npol, P)
+    try:
+        p.set_linear_operator(D)
+        for log in (False, True, False):
+            p.set_field(a)
+            cap = p.propagate_fixed_capture(1.3, hs, every=3, scalars=log)
+            end = p.get_field()
+            assert list(cap["steps"]) == [0, 3, 6, 9, 10]
+            np.testing.assert_array_equal(cap["fields"][0], a)
+            np.testing.assert_array_equal(cap["fields"][-1], end)
+            for k, s_ in enumerate(cap["steps"][1:], start=1):
+                p.set_field(a); p.propagate_fixed(1.3, hs[:s_]); p.synchronize()
+                if p.last_run_info()["engine"] == "two_kernel" and not log:
+                    np.testing.assert_array_equal(cap["fields"][k], p.get_field())
+                else:
+                    assert relmax(cap["fields"][k], p.get_field()) < tol
+            if log:
+                power = np.mean(np.abs(cap["fields"].astype(np.complex128)) ** 2, axis=-1)
+                np.testing.assert_allclose(cap["power"][cap["steps"]], power, rtol=1e-12 if prec == "c128" else 5e-6)
+    finally:
+        p.close()
+
+
 @pytest.mark.parametrize("log2n,nsteps,every,check", [(14, 400, 1, (1, 33, 257, 399)), (20, 24, 2, (2, 12, 18, 22))])
 def test_strided_capture_with_more_snapshots_than_device_blocks(log2n, nsteps, every, check):
     """The snapshots between the input and the end wait in a ring of at most eight device blocks (32 snapshots of a 2^14 x 2 field each, one of a 2^20 x 2
