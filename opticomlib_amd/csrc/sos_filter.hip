@@ -38,7 +38,6 @@
 #include <vector>
 
 #include "ssfm_common.hpp"
-namespace ssfm { unsigned xcc_mask(int device); }       // (ssfm_medium.hip: which XCC ids a launch's workgroups are dealt to)
 
 using ssfm::fail;
 
@@ -106,7 +105,6 @@ struct Workspace {
     unsigned long long* link_U = nullptr;    // totals that carry their own validity: 16-byte units {value, tag} (sos_filter_impl.inc group_start)
     size_t link_U_cap = 0;
     unsigned long long link_tag = 0;         // the call counter the tags are; never repeated, never 0
-    bool one_xcd_off = false;                // the one-XCD form of short calls found the dispatcher dealing differently: not used again
     unsigned epoch = 0;
     int* status = nullptr;
     int give_ups = 0;                    // calls IN A ROW that fell back to three launches after waiting in vain; from kMaxGiveUps on the form rests
@@ -147,10 +145,6 @@ inline bool one_launch_enabled() {
 inline long long one_launch_patience() {
     if (const char* e = std::getenv("SSFM_SOS_PATIENCE_US")) { const long long v = std::atoll(e); if (v > 0) return v * 100; }
     return 200000;
-}
-inline bool one_xcd_enabled() {
-    const char* e = std::getenv("SSFM_SOS_ONE_XCD");
-    return !(e && std::atoi(e) == 0);
 }
 namespace chunk_short {
 constexpr int kChunk = SOS_CHUNK;
