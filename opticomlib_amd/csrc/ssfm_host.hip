@@ -621,6 +621,7 @@ template <typename T> struct PlanT : PlanBase {
         (void)hipFree(fused_backup);
         (void)hipFree(medium_st);
         if (medium_err_host) (void)hipHostFree(medium_err_host);
+        if (adapt_look) (void)hipHostFree(adapt_look);
         if (medium_ev2) (void)hipEventDestroy(medium_ev2);
         if (medium_stream2) (void)hipStreamDestroy(medium_stream2);
         (void)hipFree(d_hs);
@@ -1767,7 +1768,16 @@ template <typename T> struct PlanT : PlanBase {
         }
         return adaptive_begin_chunked(gamma, (T)length, (T)phi_max, single_step, (int)max_steps, capture);
     }
+    static constexpr int kAdaptChunkMax = 512;          // steps queued between two looks at the state, at most
     AdaptState<T> adapt_host;          // staging copy of the run's parameters (a member: the copy below is asynchronous)
+    // what the host reads back during an adaptive run (the step state, the give-up word) lands in page-locked memory: a transfer of a few bytes into
+    // pageable memory goes through the runtime's staging path (measured per look at the state: profiles/r05_adaptive_looks.txt)
+    struct AdaptLook { StepState<T> now; unsigned gave_up; unsigned pad[3]; };
+    AdaptLook* adapt_look = nullptr;
+    int ensure_adapt_look() {
+        if (!adapt_look) HIP_TRY(hipHostMalloc(&adapt_look, sizeof(AdaptLook), hipHostMallocDefault));
+        return SSFM_OK;
+    }
     int upload_adapt_state(T gamma, T length, T phi_max, int max_steps) {
         std::memset(&adapt_host, 0, sizeof(adapt_host));
         adapt_host.length = length;
@@ -1791,9 +1801,10 @@ template <typename T> struct PlanT : PlanBase {
         HIP_TRY(hipGetLastError());
         // the first step size comes back at once: it tells how many steps to queue before the first look at the state
         // (a run of a few dozen steps is then two or three chunks, not five: every look is a 25 us stall)
-        StepState<T> first;
-        HIP_TRY(hipMemcpyAsync(&first, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(first), hipMemcpyDeviceToHost, stream));
+        if (int rc = ensure_adapt_look()) return rc;
+        HIP_TRY(hipMemcpyAsync(&adapt_look->now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur), sizeof(StepState<T>), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        const StepState<T> first = adapt_look->now;
         ar = AdaptRun();
         ar.now = first;
         ar.active = true;
@@ -1914,9 +1925,11 @@ template <typename T> struct PlanT : PlanBase {
         if (snap && ar.tile_private) return fail(SSFM_ERR_STATE, "ssfm_adaptive_run: the run was not begun with capture");
         const int first_step = ar.now.steps;
         auto estimate = [&]() {              // about (L - z) / h steps remain (the step only shrinks towards the clamp at L)
+            // Three quarters of them are queued before the next look at the state (a look drains the queue: 25-40 us) -- but the last two dozen all at
+            // once and two more: launches behind the end of the run find `done` and leave (a few us each), where the looks of a tail of 7, 2, 1 steps cost more
             const double remain = ar.now.h > (T)0 ? ((double)ar.length - (double)ar.now.z) / (double)ar.now.h : 1.0;
-            const int est = remain > 1e6 ? 128 : (int)(0.75 * remain) + 1;
-            return est < 2 ? 2 : (est > 128 ? 128 : est);
+            const int est = remain > 1e6 ? kAdaptChunkMax : (remain <= 24.0 ? (int)remain + 3 : (int)(0.75 * remain) + 1);
+            return est < 2 ? 2 : (est > kAdaptChunkMax ? kAdaptChunkMax : est);
         };
         int chunk = snap ? 1 : estimate();
         const bool fly_imag = fly_imag_ready();
@@ -1950,11 +1963,13 @@ template <typename T> struct PlanT : PlanBase {
                 ++last_launches;
             }
             const int before = ar.now.steps;
-            unsigned gave_up = 0;
-            HIP_TRY(hipMemcpyAsync(&ar.now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur) + sizeof(StepState<T>) * (ar.step & 1),
-                                   sizeof(ar.now), hipMemcpyDeviceToHost, stream));
-            if (ar.fused) HIP_TRY(hipMemcpyAsync(&gave_up, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(gave_up), hipMemcpyDeviceToHost, stream));
+            adapt_look->gave_up = 0u;
+            HIP_TRY(hipMemcpyAsync(&adapt_look->now, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, cur) + sizeof(StepState<T>) * (ar.step & 1),
+                                   sizeof(StepState<T>), hipMemcpyDeviceToHost, stream));
+            if (ar.fused) HIP_TRY(hipMemcpyAsync(&adapt_look->gave_up, reinterpret_cast<const char*>(st) + offsetof(AdaptState<T>, error), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            ar.now = adapt_look->now;
+            const unsigned gave_up = adapt_look->gave_up;
             if (ar.fused && gave_up) {
                 // the grid did not run as a whole (another job holds CUs): the same run again on the three-launch engine
                 const AdaptRun keep = ar;
