@@ -64,3 +64,6 @@ if [ -f build/var/_ssfm_tl.so ]; then
 fi
 [ -x build/barrier_cost ] && { timeout 60 ./build/barrier_cost 5; timeout 60 ./build/barrier_cost 10; timeout 90 ./build/barrier_cost 40; } > ${T}_barrier_cost.txt 2>&1
 bash tools/gpu_pmc_sos.sh ${TAG}_sos_pmc > ${T}_sos_sq.txt 2>&1; tail -6 ${T}_sos_sq.txt
+# the randomised capture stress (two seeds) and the fixed costs of an adaptive run
+{ python3 tests/diag/capture_stress.py 120 5 | tail -3; python3 tests/diag/capture_stress.py 120 11 | tail -3; } > ${T}_capture_stress.txt 2>&1; tail -2 ${T}_capture_stress.txt
+python3 tools/attic/adaptive_fixed_costs.py > ${T}_adaptive_fixed_costs.txt 2>&1; cat ${T}_adaptive_fixed_costs.txt
