@@ -28,6 +28,12 @@
 //
 // Traffic per real sample: forward 8 (chunk) + 8 + 8 (apply: read x, write y1), backward the same
 // = 48 B against the algorithmic 16 B (read x once, write y once).
+//
+// That is the THREE-LAUNCH form (orders 5-8 of long calls, SSFM_SOS_ONE_LAUNCH=0, and the fallback).  Calls whose workgroups are all resident at
+// once take ONE launch (k_filtfilt, sos_filter_impl.inc): a workgroup keeps its chunks in registers / LDS from the first load to the last store and
+// meets the others twice through the group totals -- 16 B per real sample.  Round 5: the totals of orders up to 4 cross as 16-byte units {value, tag}
+// that carry their own validity (no flag, no acknowledgement awaited), the wavefront scan runs inside DPP rows; 32-33 us for 2^20 x 2 complex128
+// (profiles/r05_sos_handover_ab.txt).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
