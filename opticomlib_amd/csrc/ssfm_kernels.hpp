@@ -591,6 +591,19 @@ template <int NT, bool MAX, typename T> __device__ __forceinline__ double wave_t
     return (double)r;
 }
 
+// maximum of a 32-bit unsigned value over the 64 lanes of a wavefront, for every lane (see wave_total)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true); x = o > x ? o : x;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true); x = o > x ? o : x;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true); x = o > x ? o : x;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true); x = o > x ? o : x;
+    unsigned r = (unsigned)__builtin_amdgcn_readlane((int)x, 0);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) { const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)x, 16 * i); r = q > r ? q : r; }
+    return r;
+}
+
 // The body of k_time for workgroup `bid` of `nblk`.  PK: called from the persistent kernel of the medium plans (k_medium), where
 // the field between the passes was stored by other workgroups of the SAME launch: it is read with sc1 loads (the stores are
 // write-through already), MI355X_MICROARCH.md "Valid forms".
@@ -920,11 +933,9 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         // launch's 21 MB of writes under the wait): 28.5 against 27.3 -- the workgroup's word is queued behind those stores.  profiles/r04_adaptive.txt)
         // ---- the step control, inside the launch: every workgroup delivers its maximum, waits until all have, and replays
         // step_advance() on the same 64 slots (the same float operations: the same bits in every workgroup)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const T other = __shfl_xor(pmax, o);
-            pmax = other > pmax ? other : pmax;
-        }
+        // (the wavefront's maximum by DPP rows and v_readlane, not a ds_bpermute butterfly: six dependent trips through the LDS pipe on the path to the
+        // meeting -- with the one behind the poll below 22.4 -> 21.x us per step at 2^20 x 2, profiles/r05_adaptive.txt)
+        pmax = (T)wave_total<64, true>(pmax);
         // (every static a multiple of 16 bytes: they precede the dynamic LDS region, whose base must stay 16-byte aligned)
         __shared__ __attribute__((aligned(16))) T wave_max_a[16];
         __shared__ __attribute__((aligned(16))) StepState<T> s_next_[2];
@@ -978,13 +989,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                     if ((++rounds_ & 15u) == 0u && wall_clock64() - t0 > a.st->patience) break;              // the grid is not running as a whole -- give up, never hang
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (good) {
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const unsigned long long other = __shfl_xor(mb, o);
-                        mb = other > mb ? other : mb;
-                    }
-                }
+                if (good) mb = (unsigned long long)wave_max_u32((unsigned)mb);          // (the words' low halves: the bit patterns of non-negative floats order like the floats)
                 if (tid == 0) {
                     s_ok = good;
                     if (good) s_next = step_advance<T>(a.st, S_this, mb);
