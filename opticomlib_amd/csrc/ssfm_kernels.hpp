@@ -1167,11 +1167,7 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
         }
         if (a.st != nullptr) {
             // max |A|^2 of the workgroup -> its slot; the next BEGIN reads the slots (see AdaptState)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const T other = __shfl_xor(pmax, o);
-                pmax = other > pmax ? other : pmax;
-            }
+            pmax = (T)wave_total<N1 * C / E, true>(pmax);
             __shared__ T wave_max[16];
             constexpr int NWAVES = (N1 * C / E + 63) / 64;
             if ((tid & 63) == 0) wave_max[tid >> 6] = pmax;
@@ -2206,10 +2202,7 @@ __global__ __launch_bounds__(N / E) void k_small_chirp_adapt(const SmallChirpAda
     }
     // the maximum of |A|^2 over all rows: exchange number `tag` (1, 2, ...).  false: out of patience
     auto all_rows_max = [&](double mine, unsigned tag, double& out) -> bool {
-        for (int o = 32; o > 0; o >>= 1) {
-            const double other = __shfl_xor(mine, o);
-            mine = other > mine ? other : mine;
-        }
+        mine = wave_total<N / E, true>(mine);
         if ((j & 63) == 0) s_red[j >> 6] = mine;
         __syncthreads();
         if (j == 0) {
@@ -2390,11 +2383,7 @@ __global__ __launch_bounds__(ROWS * N / E) void k_small_adapt(const SmallAdaptAr
     // max over the workgroup of a per-thread value (bit patterns of non-negative numbers are monotone)
     int par = 0;
     auto wg_max = [&](T x) -> unsigned long long {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const T other = __shfl_xor(x, o);
-            x = other > x ? other : x;
-        }
+        x = (T)wave_total<ROWS * Q, true>(x);          // (DPP rows + v_readlane: see wave_total -- a butterfly of shuffles is six trips through the LDS pipe, every step)
         if ((tid & 63) == 0) wave_max[par][tid >> 6] = float_bits<T>(x);
         __syncthreads();
         unsigned long long mb = wave_max[par][0];
