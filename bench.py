@@ -67,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the C1 (complex128) figure reported beside the headline")
     ap.add_argument("--cpu-manycore", type=int, default=0, help="also time the tidied CPU variant on this many processes (0 = skip)")
     ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4"], default="auto")
+    ap.add_argument("--launch-timeout", type=float, default=600.0,
+                    help="wall-clock budget [s] of a self-launched multi-rank run: beyond it the ranks' process group is killed, what every rank last "
+                         "logged is printed, and the exit code is 124 (0 = no limit)")
     return ap.parse_args(argv)
 
 
@@ -209,11 +212,80 @@ def pin_to_gpu_node(local_rank, world):
         return f"unchanged ({type(e).__name__}: {e})"
 
 
+def progress(msg):
+    """A rank's milestone on stderr, `[bench rank R +T.Ts] msg`: what a self-launching parent shows for every rank when the run exceeds its budget."""
+    r = os.environ.get("RANK", "0")
+    print(f"[bench rank {r} +{time.perf_counter() - _T_START:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T_START = time.perf_counter()
+
+
+def run_ranks(cmd, env, timeout_s, out=sys.stderr):
+    """Run the rank launcher `cmd` as a FRESH child in a process group of its own (never a re-exec: nothing here has touched a GPU, and nothing that has
+    may exec), forward its stderr line by line while remembering what every rank logged last, and give it `timeout_s` seconds of wall clock (0: no limit).
+    Beyond the budget the whole process group is killed (SIGTERM, then SIGKILL), every rank's last lines are printed and the exit code is 124 -- a hung
+    RCCL initialisation on a node this repository has never seen then costs the budget, not the caller's whole lease.  Returns (rc, stdout bytes)."""
+    import signal
+    import subprocess
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    last = {}                                                   # rank (or "-") -> its last few stderr lines
+    chunks = []
+
+    def pump_err():
+        for raw in iter(proc.stderr.readline, b""):
+            t = raw.decode(errors="replace").rstrip("\n")
+            print(t, file=out, flush=True)
+            key = "-"
+            if t.startswith("[bench rank "):
+                key = t[len("[bench rank "):].split(" ", 1)[0].rstrip("]")
+            elif t.startswith("[rank") or t.startswith("[default"):      # torch.distributed.run's own prefixes
+                key = t[1:].split("]", 1)[0]
+            last.setdefault(key, []).append(t)
+            del last[key][:-3]
+
+    def pump_out():
+        for raw in iter(lambda: proc.stdout.read(65536), b""):
+            chunks.append(raw)
+
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for th in threads:
+        th.start()
+    timed_out = False
+    try:
+        proc.wait(timeout=timeout_s if timeout_s and timeout_s > 0 else None)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(proc.pid, sig)                        # (start_new_session: the child's pid is its process group's id -- exactly the ranks, nothing else)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+    for th in threads:
+        th.join(timeout=5.0)
+    if timed_out:
+        print(f"bench.py: the ranks did not finish within --launch-timeout {timeout_s:.0f} s; their process group was killed.  Last lines per rank:", file=out)
+        for key in sorted(last):
+            for t in last[key]:
+                print(f"    rank {key}: {t}", file=out)
+        if not last:
+            print("    (no rank had logged anything)", file=out)
+        out.flush()
+        return 124, b"".join(chunks)
+    return proc.returncode, b"".join(chunks)
+
+
 def self_launch(args, argv):
     """Start the ranks as a fresh child (nothing in THIS process has touched a GPU, torch is not even imported) and
-    hand on its exit code.  The child's rank 0 writes the JSON line to the stdout it inherits."""
+    hand on its exit code.  The child's rank 0 writes the JSON line to the stdout it inherits.  The child runs in a process group of its own under a
+    wall-clock budget (--launch-timeout, default 600 s): see run_ranks."""
     import socket
-    import subprocess
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -224,9 +296,9 @@ def self_launch(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     sys.stdout.flush()
     # the ranks keep their stdout clean themselves (guard_stdout); should anything still reach it, only the last JSON line is passed on
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    rc, stdout_bytes = run_ranks(cmd, env, args.launch_timeout)
     line = None
-    for raw in proc.stdout.decode(errors="replace").splitlines():
+    for raw in stdout_bytes.decode(errors="replace").splitlines():
         t = raw.strip()
         if t.startswith("{") and t.endswith("}"):
             try:
@@ -239,7 +311,7 @@ def self_launch(args, argv):
             print(raw, file=sys.stderr)
     if line is not None:
         print(line, flush=True)
-    return proc.returncode
+    return rc
 
 
 def cpu_baseline(a, dt, fibre, sample_steps):

@@ -20,15 +20,17 @@
  *   devices.py:1150-1152,1184-1186 return_steps    `snapshots` argument of both propagate calls
  *   devices.py:1204 (.get() / wrap)                ssfm_get_field
  *   devices.py:1027-1029 (DM: ifft(fft(x)*H))      ssfm_apply_transfer / ssfm_apply_dispersion (H generated on the device)
- *   devices.py:1363-1368, :814-823 (LPF / BPF:     ssfm_sosfiltfilt, ssfm_sosfiltfilt_device
- *     scipy.signal.sosfiltfilt)
- *   devices.py:1512-1515 (PD: r * |x|^2, pol sum)  ssfm_square_law, ssfm_square_law_device
- *   devices.py:1521-1549, :930-936 (PD / EDFA      ssfm_device_randn (rng = "device"), _mean, _sum3, _scale_add
+ *   devices.py:1363-1368, :814-823 (LPF / BPF:     ssfm_sosfiltfilt (`on_device` flag: host or device arrays; ssfm_sosfiltfilt_last
+ *     scipy.signal.sosfiltfilt)                    says which form the last call took)
+ *   devices.py:1512-1515 (PD: r * |x|^2, pol sum)  ssfm_square_law (`on_device` flag)
+ *   devices.py:1521-1549, :930-936 (PD / EDFA      ssfm_device_randn (rng = "device"), ssfm_device_reduce (mean / min / max), ssfm_device_sum3,
+ *                                                  ssfm_device_scale_add
  *     noise currents, gain and ASE loading)
- *   numpy.fft of any N (devices.py:1178-1180)      ssfm_chirp_pre / _mid / _post on a power-of-two plan
+ *   numpy.fft of any N (devices.py:1178-1180)      ssfm_chirp_setup, ssfm_chirp_propagate / _propagate_c64 (FIBER / DBP), ssfm_chirp_transfer
+ *                                                  (DM), ssfm_chirp_fourier (signal('w') / ('t')) on a power-of-two plan
  *   utils.py:1791-1981 (DAC: pulses, upfir)        ssfm_load_pulse / _load_padded / _load_symbols, ssfm_table_from_field,
- *                                                  ssfm_apply_table, ssfm_device_axpb / _real
- *   devices.py:480-510 (LASER), :762-778 (MZM)     ssfm_laser (+ ssfm_device_cumsum / _min), ssfm_mzm
+ *                                                  ssfm_apply_table, ssfm_device_axpb (real part: `is_complex` flag)
+ *   devices.py:480-510 (LASER), :762-778 (MZM)     ssfm_laser (+ ssfm_device_cumsum, ssfm_device_reduce), ssfm_mzm
  *   (none: NumPy arrays are the reference's only   ssfm_device_alloc / _free / _copy / _convert / _add
  *     data format)                                 -- device-resident signals between calls
  *
@@ -54,6 +56,11 @@ extern "C" {
 
 #define SSFM_ABI_VERSION 3
 
+/* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY dynamic symbols (nm -D: 59 + the runtime's). */
+#ifndef SSFM_API
+#define SSFM_API __attribute__((visibility("default")))
+#endif
+
 enum ssfm_status {
     SSFM_OK = 0,
     SSFM_ERR_INVALID = 1,      /* bad argument (message in ssfm_last_error) */
@@ -70,26 +77,26 @@ typedef struct ssfm_plan ssfm_plan;
 
 /* Library / device discovery.  ssfm_device_count never initialises a HIP context beyond
  * hipGetDeviceCount. */
-int ssfm_abi_version(void);
-int ssfm_device_count(int* count);
-const char* ssfm_last_error(void);
+SSFM_API int ssfm_abi_version(void);
+SSFM_API int ssfm_device_count(int* count);
+SSFM_API const char* ssfm_last_error(void);
 
 /* Smallest / largest supported log2(n) for a precision (currently 8..22). */
-int ssfm_supported_log2n(int precision, int* lo, int* hi);
+SSFM_API int ssfm_supported_log2n(int precision, int* lo, int* hi);
 
 /* Allocate every device buffer once: field, stale |A|^2, operator tables, twiddles. */
-int ssfm_plan_create(ssfm_plan** out, int device, int64_t n, int batch, int precision);
-int ssfm_plan_destroy(ssfm_plan* plan);
+SSFM_API int ssfm_plan_create(ssfm_plan** out, int device, int64_t n, int batch, int precision);
+SSFM_API int ssfm_plan_destroy(ssfm_plan* plan);
 
 /* D~(w) [1/km], complex (precision's element type), length n, natural FFT order, HOST memory.
  * Shared by all rows.  (reference devices.py:1145) */
-int ssfm_set_linear_operator(ssfm_plan* plan, const void* dtilde_host);
+SSFM_API int ssfm_set_linear_operator(ssfm_plan* plan, const void* dtilde_host);
 
 /* Copy a (batch, n) complex field in / out of the plan.  `is_device` != 0: the pointer is
  * device memory on the plan's device. Both calls are ordered on the plan's stream;
  * ssfm_get_field returns after the copy has completed. */
-int ssfm_set_field(ssfm_plan* plan, const void* src, int is_device);
-int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device);
+SSFM_API int ssfm_set_field(ssfm_plan* plan, const void* src, int is_device);
+SSFM_API int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device);
 /* Device address of the plan's resident field (batch*n complex), natural time order
  * between propagate calls.
  * WHEN THE FIELD IS VALID.  Runs are asynchronous: the result is in the field buffer once ssfm_synchronize / ssfm_get_field has
@@ -99,7 +106,7 @@ int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device);
  * when the GPU does not run them side by side; the run is then repeated on the launch-per-pass engine -- BEFORE it returns (for such
  * plans the call is then synchronous).  Every other engine either needs no fallback or resolves it inside the call already.
  * ssfm_last_run_info tells which engine a run took and whether it fell back. */
-void* ssfm_field_device_ptr(ssfm_plan* plan);
+SSFM_API void* ssfm_field_device_ptr(ssfm_plan* plan);
 
 /* Fixed-step run (reference devices.py:1172-1196 with h given).
  *   gamma        nonlinear coefficient [1/(W km)] (rounded to the plan's real type)
@@ -107,7 +114,7 @@ void* ssfm_field_device_ptr(ssfm_plan* plan);
  *   snapshots    NULL, or HOST buffer for (nsteps+1, batch, n) complex: the field before the
  *                first step and after every step (reference return_steps, devices.py:1184-1186)
  * Asynchronous on the plan's stream unless snapshots != NULL; see ssfm_synchronize. */
-int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps,
+SSFM_API int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps,
                          void* snapshots);
 
 /* z-resolved capture that does not stall the loop.  The reference's return_steps keeps the field after EVERY step
@@ -129,7 +136,7 @@ typedef struct ssfm_capture {
     void* fields;
     double* scalars;
 } ssfm_capture;
-int ssfm_propagate_fixed_capture(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, const ssfm_capture* cap);
+SSFM_API int ssfm_propagate_fixed_capture(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, const ssfm_capture* cap);
 
 /* Adaptive run (reference devices.py:1155-1156, 1193-1196): h = phi_max / max(|gamma| |A|^2),
  * maximum over all rows of the plan, clamped to length - z; z and h live on the device.
@@ -140,7 +147,7 @@ int ssfm_propagate_fixed_capture(ssfm_plan* plan, double gamma, const void* h_sc
  *   z_out        NULL or HOST float64[max_steps+1]: z after every step (z_out[0] = 0)
  *   snapshots    NULL or HOST (max_steps+1, batch, n) complex
  * Synchronous (the step count is only known at the end). */
-int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double phi_max,
+SSFM_API int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double phi_max,
                             int single_step, int64_t max_steps, int64_t* steps_out, double* z_out,
                             void* snapshots);
 
@@ -153,19 +160,19 @@ int ssfm_propagate_adaptive(ssfm_plan* plan, double gamma, double length, double
  * Between ssfm_adaptive_begin and ssfm_adaptive_finish the plan's field buffer (ssfm_get_field, ssfm_field_device_ptr) is only
  * defined when the run was begun with capture != 0: without a capture the field of a complex64 plan stays in an internal
  * tile-private order between steps, and ssfm_adaptive_finish produces the time-order field. */
-int ssfm_adaptive_begin(ssfm_plan* plan, double gamma, double length, double phi_max, int single_step, int64_t max_steps, int capture);
-int ssfm_adaptive_run(ssfm_plan* plan, int64_t budget, void* snapshots, int64_t* steps_total, int* done);
-int ssfm_adaptive_finish(ssfm_plan* plan, int64_t* steps_out, double* z_out);
+SSFM_API int ssfm_adaptive_begin(ssfm_plan* plan, double gamma, double length, double phi_max, int single_step, int64_t max_steps, int capture);
+SSFM_API int ssfm_adaptive_run(ssfm_plan* plan, int64_t budget, void* snapshots, int64_t* steps_total, int* done);
+SSFM_API int ssfm_adaptive_finish(ssfm_plan* plan, int64_t* steps_out, double* z_out);
 
 /* out = ifft(fft(field) * H) on every row; H complex, length n, natural FFT order, HOST.
  * (reference DM, devices.py:1027-1029) */
-int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host);
+SSFM_API int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host);
 
 /* DM with the transfer function generated on the device (reference devices.py:1025-1029):
  * H(w_k) = exp(+1j w_k^2 D/2), w_k = 2 pi fftfreq(n, dt)[k] in float64 with the reference's operation
  * order, D in s^2 (the caller has applied devices.py:1025's `D *= 1e-12**2`).  If H_out != NULL the
  * natural-order H (n complex, precision's type, HOST) is returned as well (for retH). */
-int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out);
+SSFM_API int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out);
 
 /* Zero-phase IIR filtering with a cascade of second-order sections = scipy.signal.sosfiltfilt(sos, x,
  * axis=-1) (odd padding of 3*ntaps samples, steady-state initial conditions): the arithmetic of the
@@ -175,7 +182,7 @@ int ssfm_apply_dispersion(ssfm_plan* plan, double dt_s, double D_s2, void* H_out
  *   x,y  batch x n float64 (is_complex = 0) or complex128 interleaved (is_complex = 1); y may alias x.  on_device = 0: HOST arrays (uploaded, filtered,
  *        read back); on_device = 1: DEVICE memory of `device` (complex buffers 16-byte aligned), so a field can be filtered where it was
  *        propagated.  Synchronous. */
-int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
+SSFM_API int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sections, const void* x, void* y,
                      int64_t n, int batch, int is_complex, int on_device);
 /* The last ssfm_sosfiltfilt call on `device` (either pointer nullable): device time [ms] of its kernels (HIP events on the filter's stream, transfers
  * excluded), and its kernel launches: 1 when the whole forward-backward pass ran as one
@@ -184,7 +191,7 @@ int ssfm_sosfiltfilt(int device, const double* sos, const double* zi, int n_sect
  * whose workgroups did not all get to run side by side within SSFM_SOS_PATIENCE_US -- default 2000 -- is
  * repeated in this form, and after three such calls in a row the next 1000 calls skip the one-launch form).  The two
  * forms agree to rounding (the one-launch form uses fused multiply-adds), not bit for bit. */
-int ssfm_sosfiltfilt_last(int device, float* ms, int* launches);
+SSFM_API int ssfm_sosfiltfilt_last(int device, float* ms, int* launches);
 
 /* Square-law detection of the reference's PD (devices.py:1512-1515): i_ph = r * (x * x.conj()).real summed
  * over the polarisations, signal and noise kept apart as the reference's signal algebra does
@@ -193,7 +200,7 @@ int ssfm_sosfiltfilt_last(int device, float* ms, int* launches);
  *   post   factor applied to the summed currents (1 for currents; R_load of devices.py:1547 for voltages)
  *   i_sig, i_noise   n float64
  *   on_device   0: all four are HOST arrays; 1: DEVICE buffers (16-byte aligned).  Synchronous. */
-int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise, int on_device);
+SSFM_API int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, int64_t n, double r, double post, double* i_sig, double* i_noise, int on_device);
 
 /* ---- device-resident signals ----------------------------------------------------------------------
  * Raw HBM buffers that a host-side signal object can own between calls, so that a chain such as
@@ -208,34 +215,34 @@ int ssfm_square_law(int device, const void* sig, const void* noise, int n_pol, i
  *                               part); `count` elements
  *   ssfm_device_add             dst = a + b, `count` complex elements of `precision` */
 #define SSFM_HOST_PINNED (-1)
-int ssfm_device_alloc(int device, size_t bytes, void** out);
-int ssfm_device_free(int device, void* ptr, size_t bytes);
-int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind);
-int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
-int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
+SSFM_API int ssfm_device_alloc(int device, size_t bytes, void** out);
+SSFM_API int ssfm_device_free(int device, void* ptr, size_t bytes);
+SSFM_API int ssfm_device_copy(int device, void* dst, const void* src, size_t bytes, int kind);
+SSFM_API int ssfm_device_convert(int device, const void* src, int src_precision, void* dst, int dst_precision, int64_t count);
+SSFM_API int ssfm_device_add(int device, void* dst, const void* a, const void* b, int precision, int64_t count);
 /* Device random numbers and the few float64 array operations the receiver front-end needs around them.
  * ssfm_device_randn: out[i] = mean + std * N(0,1), Philox4x32-10 keyed by `seed`, counter = (pair index, `stream`),
  * Box-Muller on two 53-bit uniforms per pair -- the documented generator behind PD / EDFA with rng="device" (the
  * reference draws from NumPy's global generator, devices.py:1521-1527, :930; the default rng="numpy" reproduces
  * those draws on the host).  sum3: out = (a + b + c + offset) * scale (a, b, c nullable); scale_add: dst = a*factor
  * (+ b).  All on `n` float64 elements in DEVICE memory, synchronous. */
-int ssfm_device_randn(int device, double* out_dev, int64_t n, uint64_t seed, uint64_t stream, double mean, double std);
-int ssfm_device_sum3(int device, double* out_dev, const double* a, const double* b, const double* c, double offset, double scale, int64_t n);
-int ssfm_device_scale_add(int device, double* dst, const double* a, double factor, const double* b, int64_t n);
+SSFM_API int ssfm_device_randn(int device, double* out_dev, int64_t n, uint64_t seed, uint64_t stream, double mean, double std);
+SSFM_API int ssfm_device_sum3(int device, double* out_dev, const double* a, const double* b, const double* c, double offset, double scale, int64_t n);
+SSFM_API int ssfm_device_scale_add(int device, double* dst, const double* a, double factor, const double* b, int64_t n);
 /* dst = running sum of src (numpy.cumsum; the laser's Wiener phase, devices.py:490), n float64 on the DEVICE. */
-int ssfm_device_cumsum(int device, double* dst, const double* src, int64_t n);
+SSFM_API int ssfm_device_cumsum(int device, double* dst, const double* src, int64_t n);
 /* Elementwise transmitter work on DEVICE arrays (csrc/transmitter.hip), synchronous:
  * ssfm_mzm: the Mach-Zehnder transfer of devices.py:762-778 -- g = k (drive + bias) [+ k drive_noise], h = sqrt_loss (cos g +
  *   j half_eta sin g), out = in * h for signal and (nullable) noise, n_pol x n complex128; polarisation `dead_pol` of a
  *   dual-polarisation input is emptied; the drive is n float64 (drive_complex = 0) or complex128 (1);
  * ssfm_device_axpb: dst = src * alpha + beta on n float64 (is_complex = 0) or complex128 (1; beta to the real part). */
-int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, const void* in_noise, int n_pol, int64_t n, const void* drive,
+SSFM_API int ssfm_mzm(int device, void* out_sig, void* out_noise, const void* in_sig, const void* in_noise, int n_pol, int64_t n, const void* drive,
              const void* drive_noise, int drive_complex, double k, double bias, double sqrt_loss, double half_eta, int dead_pol);
 /* LASER (devices.py:353-510) over t = linspace(0, stop, n) (t_i = i*step): out = amp [exp(j phase)] [sqrt(1 + rin)] [exp(j w t)],
  * the factors in the reference's order; `phase` (running sum of the Wiener increments) and `rin` are nullable float64 DEVICE
  * arrays drawn by the caller, `w` = 2 pi df with has_df.  `out`: n float64 when neither phase nor df is given, else n complex128. */
-int ssfm_laser(int device, void* out, int64_t n, double amp, const double* phase, const double* rin, int has_df, double w, double step, double stop);
-int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, double beta, int64_t n, int is_complex);
+SSFM_API int ssfm_laser(int device, void* out, int64_t n, double amp, const double* phase, const double* rin, int has_df, double w, double step, double stop);
+SSFM_API int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, double beta, int64_t n, int is_complex);
 /* Small DEVICE-array helpers that keep the transmitter / amplifier off the host, synchronous:
  * ssfm_device_shift: dst = src + (re + j im);
  * ssfm_device_reduce: the reductions a device-resident signal needs, results on the HOST --
@@ -245,8 +252,8 @@ int ssfm_device_axpb(int device, void* dst, const void* src, double alpha, doubl
  *   SSFM_REDUCE_MIN    out[0] = the minimum of the n float64 of a
  * (b, rows and is_complex are ignored where a kind has no use for them). */
 enum { SSFM_REDUCE_MEAN = 0, SSFM_REDUCE_MEAN2 = 1, SSFM_REDUCE_POWER = 2, SSFM_REDUCE_MIN = 3 };
-int ssfm_device_shift(int device, void* dst, const void* src, int64_t n, int is_complex, double re, double im);
-int ssfm_device_reduce(int device, int kind, const void* a, const void* b, int rows, int64_t n, int is_complex, double* out);
+SSFM_API int ssfm_device_shift(int device, void* dst, const void* src, int64_t n, int is_complex, double re, double im);
+SSFM_API int ssfm_device_reduce(int device, int kind, const void* a, const void* b, int rows, int64_t n, int is_complex, double* out);
 /* PRBS (reference devices.py:63-182): `len` bits of the Fibonacci LFSR x^order + x^t2 + 1 (orders 7, 9, 11, 15, 20,
  * 23, 31; taps of devices.py:134-142) started from the non-zero state `seed` (the caller has applied devices.py:143-149:
  * modulo 2^order, default all ones, 0 -> 1), one uint8 0/1 per bit in DEVICE memory; the sequence and the register state
@@ -256,10 +263,10 @@ int ssfm_device_reduce(int device, int kind, const void* a, const void* b, int r
  * ssfm_load_qpsk: plan field (complex128, `rows` rows of plan_n) <- the QPSK-like test symbols of the benchmark
  * configurations: row r, symbol k = ((2 b0 - 1) + j (2 b1 - 1)) / sqrt(2) from bits 2 (r nsym + k) and
  * + 1, at sample k sps + sps / 2, zeros elsewhere.  Asynchronous on the plan's stream. */
-int ssfm_prbs(int device, void* bits_dev, int64_t len, int order, uint32_t seed, uint32_t* final_state);
-int ssfm_load_qpsk(ssfm_plan* plan, int64_t plan_n, int rows, const void* bits_dev, int64_t nsym, int sps);
+SSFM_API int ssfm_prbs(int device, void* bits_dev, int64_t len, int order, uint32_t seed, uint32_t* final_state);
+SSFM_API int ssfm_load_qpsk(ssfm_plan* plan, int64_t plan_n, int rows, const void* bits_dev, int64_t nsym, int sps);
 /* Free / total HBM of the device and the bytes held in the library's buffer pool (nullable). */
-int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes);
+SSFM_API int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, size_t* pooled_bytes);
 
 /* ---- lengths that are not powers of two (the reference takes any N: numpy.fft, devices.py:1178-1180) --------
  * Bluestein's identity maps a length-n transform onto the circular convolution of a power-of-two plan of length
@@ -272,15 +279,15 @@ int ssfm_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes, si
  *
  * ssfm_transfer_table keeps a transfer function H (HOST, plan length complex, the plan's type) on the device in slot 0 or 1;
  * ssfm_apply_table does x <- ifft(fft(x) * H) on the plan's field WITHOUT waiting for the host (also the DAC's pulse shaping, below). */
-int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot);
-int ssfm_apply_table(ssfm_plan* plan, int slot);
+SSFM_API int ssfm_transfer_table(ssfm_plan* plan, const void* H_host, int slot);
+SSFM_API int ssfm_apply_table(ssfm_plan* plan, int slot);
 /* The chirp c (conj = 0) or conj(c) (1), n complex128, into DEVICE memory, its phase reduced exactly in integers (synchronous). */
-int ssfm_device_chirp(int device, void* out_dev, int64_t n, int conj);
+SSFM_API int ssfm_device_chirp(int device, void* out_dev, int64_t n, int conj);
 /* One-time set-up of a COMPLEX128 plan of plan_n >= 2n - 1 points for fields of n samples: both convolution kernels of the identity
  * (v[m] = v[plan_n - m] = conj(c_m) and c_m) are generated in the plan's field and transformed there into the resident transfer functions of
  * slots 0 and 1 -- neither a host transform nor an upload.  What ssfm_chirp_propagate / _transfer / _fourier rely on.  Asynchronous; the
  * plan's field is consumed. */
-int ssfm_chirp_setup(ssfm_plan* plan, int64_t plan_n, int64_t n);
+SSFM_API int ssfm_chirp_setup(ssfm_plan* plan, int64_t plan_n, int64_t n);
 /* A whole FIBER / DBP run on a field of ANY length, driven from C on the complex128 line: A (batch x n complex128, DEVICE) is
  * advanced in place, P is scratch (batch x n float64, DEVICE), chirp = c (ssfm_device_chirp), Dt = D~ (n complex128, DEVICE, natural
  * frequency order); the plan: complex128, plan_n >= 2n - 1, prepared by ssfm_chirp_setup(plan, plan_n, n).  hs != NULL: fixed step, `nsteps`
@@ -290,7 +297,7 @@ int ssfm_chirp_setup(ssfm_plan* plan, int64_t plan_n, int64_t n);
  * launch for plan_n <= 4096 (a workgroup per row); four launches per fixed step for schedules of up to four step sizes (the chirps of neighbouring
  * steps cancel: one pointwise launch before and after the run); five otherwise, seven per adaptive step.  A caller that wants the field after
  * every step (return_steps) calls it a step at a time (nsteps = 1, or max_steps = 1 over the rest of the length).  Synchronous. */
-int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, void* P, const void* chirp, const void* Dt, int64_t n, double gamma,
+SSFM_API int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, void* P, const void* chirp, const void* Dt, int64_t n, double gamma,
                          const double* hs, int64_t nsteps, double length, double phi_max, int f32, int64_t max_steps, double* z_out, int64_t* steps_out);
 /* The same run for complex64 callers in ONE launch on a complex64 line: the plan is COMPLEX64 and its length is the line's, M = 2^k >= 2n - 1 -- a
  * workgroup per row for M <= 4096 (at most 16 rows in adaptive mode), the one-XCD engine for M = 2^13 ... 2^17 with at most 2^17 points in all rows
@@ -300,38 +307,38 @@ int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, vo
  * plan has no such engine or schedule, or the launch's workgroups did not meet within their patience (the engine is then off for this plan) -- the
  * caller takes ssfm_chirp_propagate.  (The reference transforms such a length in single precision itself -- pocketfft's Bluestein -- so this is its
  * arithmetic class; its accuracy margin and when a caller should prefer the complex128 line: opticomlib_amd/devices.py _c64_line_has_margin.) */
-int ssfm_chirp_propagate_c64(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps,
+SSFM_API int ssfm_chirp_propagate_c64(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps,
                              double length, double phi_max, int64_t max_steps, double* z_out, int64_t* steps_out);
 /* x <- ifft_n(fft_n(x) * tab) (exponent = 0: DM's H for any length, devices.py:1019-1035) or * exp(tab) (exponent != 0) for every row of the DEVICE array
  * A (batch x n complex128, in place); tab: n complex128, DEVICE.  Plan as for ssfm_chirp_propagate.  Asynchronous on the plan's stream. */
-int ssfm_chirp_transfer(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* tab, int64_t n, int exponent);
+SSFM_API int ssfm_chirp_transfer(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* tab, int64_t n, int exponent);
 /* numpy.fft.fft (inverse = 0, unscaled) or ifft (inverse != 0, with its 1/n) of every row of A (batch x n complex128, DEVICE, in place);
  * chirp = c, chirp_conj = conj(c).  The reference's signal('w') / signal('t'), typing.py:1421-1462.  Asynchronous on the plan's stream. */
-int ssfm_chirp_fourier(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* chirp_conj, int64_t n, int inverse);
+SSFM_API int ssfm_chirp_fourier(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* chirp, const void* chirp_conj, int64_t n, int inverse);
 /* Pulse shaping of the reference's DAC (upfir, utils.py:1949-1981) on a complex128 plan of batch 1: ssfm_load_padded
  * writes `n_src` float64 (src_complex = 0) or complex128 (1) samples from DEVICE memory into the field, zero-padded;
  * ssfm_table_from_field makes slot <- fft(field) (the field is consumed); ssfm_load_symbols writes `nsym` symbols --
  * float64 amplitudes (src_kind 0) or uint8 bits taken as 0.0 / 1.0 (src_kind 1), DEVICE -- zero-stuffed to `up` samples per symbol with the sample at up / 2; ssfm_apply_table then convolves.  Asynchronous. */
-int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src);
-int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_kind, int64_t nsym, int up);
+SSFM_API int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src);
+SSFM_API int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_kind, int64_t nsym, int up);
 /* The DAC's built-in pulses (utils.py:1791-1947) generated in the field instead of uploaded: `npts` samples over
  * t_i = i*step + start (t_{npts-1} = stop: numpy.linspace), zero-padded.  kind 0 nrz (params: -T/2, T/2); 1 gaussian
  * exp(-((p0 + j p1) t)^pow2m) with (p0, p1) = alpha (1 + j c); 2 raised cosine (2 beta, pi beta, value where
  * 1 - (2 beta t)^2 ~ 0); 3 root raised cosine (beta, 4 beta, 1 - beta, 1 + beta, 1/(4 beta), value at 0, value at
  * 1/(4 beta)); 4 sinc.  `params`: 7 doubles on the HOST.  Asynchronous. */
-int ssfm_load_pulse(ssfm_plan* plan, int64_t plan_n, int kind, int64_t npts, double start, double step, double stop, int pow2m, const double* params);
-int ssfm_table_from_field(ssfm_plan* plan, int slot);
+SSFM_API int ssfm_load_pulse(ssfm_plan* plan, int64_t plan_n, int kind, int64_t npts, double start, double step, double stop, int pow2m, const double* params);
+SSFM_API int ssfm_table_from_field(ssfm_plan* plan, int slot);
 /* Validation aids behind one entry point.  SSFM_DEBUG_FFT: the forward FFT of every row of the plan's field into HOST `dst` (natural frequency order,
  * unscaled).  SSFM_DEBUG_LANE_FAULT: test hook of the lane health check (ssfm_last_run_info) -- arg 1 makes the plan believe a four times better launch
  * period than it has seen (the next long two-lane run looks slow and the lanes are rated again), arg 2 additionally makes every rating come out bad (the
  * repair fails; the second failure drops the plan to one lane), arg 0 back to normal. */
 enum { SSFM_DEBUG_FFT = 0, SSFM_DEBUG_LANE_FAULT = 1 };
-int ssfm_debug(ssfm_plan* plan, int what, int64_t arg, void* dst);
+SSFM_API int ssfm_debug(ssfm_plan* plan, int what, int64_t arg, void* dst);
 
-int ssfm_synchronize(ssfm_plan* plan);
+SSFM_API int ssfm_synchronize(ssfm_plan* plan);
 /* The plan's hipStream_t (as void*), so callers can record events around propagate calls or order their own work behind a run (see
  * "WHEN THE FIELD IS VALID" at ssfm_field_device_ptr). */
-void* ssfm_stream(ssfm_plan* plan);
+SSFM_API void* ssfm_stream(ssfm_plan* plan);
 
 /* Which engine the plan's last run took, and whether it had to be repeated on a fallback.  The engines differ in speed only (same results
  * within the stated tolerances); the single-launch ones need the GPU to run all their workgroups side by side and fall back, after a bounded
@@ -365,7 +372,7 @@ enum ssfm_engine {
     SSFM_ENGINE_MEDIUM_ADAPT = 7,      /* adaptive: one launch per run on one XCD */
     SSFM_ENGINE_CHIRP_SMALL = 8,       /* any length <= 2048: fixed step, one launch per run */
     SSFM_ENGINE_CHIRP_SMALL_ADAPT = 9, /* any length <= 2048: adaptive, one launch per run */
-    SSFM_ENGINE_CHIRP_STEPS = 10,      /* any length: four launches per fixed step (five through ssfm_chirp_step), seven adaptive */
+    SSFM_ENGINE_CHIRP_STEPS = 10,      /* any length: four launches per fixed step (five through the library-internal chirp step of a host-driven loop), seven adaptive */
     SSFM_ENGINE_CHIRP_MEDIUM = 11,     /* any length, 2048 < n <= 65536, complex64: fixed step, one launch per run on one XCD */
     SSFM_ENGINE_CHIRP_MEDIUM_ADAPT = 12 /* ... adaptive */
 };
@@ -384,12 +391,12 @@ typedef struct ssfm_run_info {
     float lane_last_us;
     float lane_score;
 } ssfm_run_info;
-int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes);
+SSFM_API int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes);
 
 
 /* Time of the last propagate call measured with HIP events on the plan's stream [ms], and the
  * number of kernel launches it made.  Valid after ssfm_synchronize. */
-int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
+SSFM_API int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
 
 /* Kernel timing of ssfm_propagate_fixed with HIP events on the streams the kernels are launched on.
  *   mode 0  off
@@ -402,16 +409,16 @@ int ssfm_last_propagate_ms(ssfm_plan* plan, float* ms, int64_t* launches);
  *           only those single-launch intervals: launches sampled and their summed duration per class
  * After ssfm_synchronize, ssfm_kernel_times returns per class the number of launches and the summed
  * event-to-event time in ms (a dependent-launch gap is counted with the launch that follows it). */
-int ssfm_set_profiling(ssfm_plan* plan, int mode);
+SSFM_API int ssfm_set_profiling(ssfm_plan* plan, int mode);
 /* What the plan's staging buffers hold, owned by the plan: `which` 0 labels the linear operator set with
  * ssfm_set_linear_operator, 1 / 2 the resident transfer function of slot 0 / 1.  A caller labels what it has staged
  * (any non-zero 64-bit tag, e.g. a hash of the fibre parameters) and asks later whether it is still there; EVERY entry
  * point that overwrites or reuses the buffer (a new operator, ssfm_apply_transfer, ssfm_apply_dispersion with H_out,
  * ssfm_transfer_table, ssfm_table_from_field) clears the label, so a cached operator can never be stale.  0 = unknown.
  * (The reference recomputes D~ on every call, devices.py:1137-1145; this only saves the O(N) set-up of a repeated call.) */
-int ssfm_plan_set_tag(ssfm_plan* plan, int which, uint64_t tag);
-int ssfm_plan_get_tag(ssfm_plan* plan, int which, uint64_t* tag);
-int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]);
+SSFM_API int ssfm_plan_set_tag(ssfm_plan* plan, int which, uint64_t tag);
+SSFM_API int ssfm_plan_get_tag(ssfm_plan* plan, int which, uint64_t* tag);
+SSFM_API int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]);
 
 #ifdef __cplusplus
 }

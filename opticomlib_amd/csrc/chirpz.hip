@@ -121,8 +121,17 @@ struct Target {
     hipStream_t stream;
     long long M;
 };
-int target_of(ssfm_plan* plan, long long n, long long M, Target* t) {
+// Every chirp-z entry point works on the field buffer of a COMPLEX128 plan of exactly `M` points per row and at least `rows` rows: checked here, once for
+// all of them (only ssfm_chirp_propagate checked; a complex64 plan or a mismatched plan_n / batch wrote past the end of the field).
+int target_of(ssfm_plan* plan, long long n, long long M, int rows, Target* t) {
     if (!plan) return fail(SSFM_ERR_INVALID, "null plan");
+    {
+        int prec = 0, pb = 0;
+        const int64_t pn = ssfm::plan_length(plan, &pb, &prec);
+        if (prec != SSFM_C128 || pn != M || rows < 1 || pb < rows)
+            return fail(SSFM_ERR_INVALID, "chirp-z: a complex128 plan of %lld points x >= %d rows is needed (this one: %s, %lld x %d)", M, rows,
+                        prec == SSFM_C128 ? "complex128" : "complex64", (long long)pn, pb);
+    }
     t->F = static_cast<double2*>(ssfm::plan_field(plan));              // (the internal accessors: taking them does not make the plan's one-launch runs synchronous)
     t->stream = static_cast<hipStream_t>(ssfm::plan_stream(plan));
     t->M = M;
@@ -136,7 +145,7 @@ int target_of(ssfm_plan* plan, long long n, long long M, Target* t) {
 namespace {
 int chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P, const void* chirp, int64_t n, double gamma, double hh) {
     Target t;
-    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (int rc = target_of(plan, n, plan_n, batch, &t)) return rc;
     if (!A || !chirp) return fail(SSFM_ERR_INVALID, "ssfm_chirp_pre: NULL argument");
     hipLaunchKernelGGL(k_chirp_pre, dim3(blocks_for(t.M * batch)), dim3(256), 0, t.stream, (const double2*)A, (double*)P, (const double2*)chirp, t.F,
                        (long long)n, t.M, batch, gamma, hh, (const ChirpCtl*)nullptr);
@@ -146,7 +155,7 @@ int chirp_pre(ssfm_plan* plan, int64_t plan_n, int batch, const void* A, void* P
 
 int chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64_t n, double h, int mode) {
     Target t;
-    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (int rc = target_of(plan, n, plan_n, batch, &t)) return rc;
     if (!tab || mode < 0 || mode > 1) return fail(SSFM_ERR_INVALID, "ssfm_chirp_mid: bad argument");
     hipLaunchKernelGGL(k_chirp_mid, dim3(blocks_for(t.M * batch)), dim3(256), 0, t.stream, (const double2*)tab, t.F, (long long)n, t.M, batch, h, mode, (const ChirpCtl*)nullptr);
     HIP_TRY(hipGetLastError());
@@ -155,7 +164,7 @@ int chirp_mid(ssfm_plan* plan, int64_t plan_n, int batch, const void* tab, int64
 
 int chirp_post(ssfm_plan* plan, int64_t plan_n, int batch, void* A, const void* P, const void* chirp, int64_t n, double gamma, double hh, void* maxbits_dev, double scale) {
     Target t;
-    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (int rc = target_of(plan, n, plan_n, batch, &t)) return rc;
     if (!A || !chirp || (gamma != 0.0 && !P)) return fail(SSFM_ERR_INVALID, "ssfm_chirp_post: NULL argument");
     if (maxbits_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), t.stream));
     hipLaunchKernelGGL(k_chirp_post, dim3(blocks_for((long long)n * batch)), dim3(256), 0, t.stream, (double2*)A, (const double*)P, (const double2*)chirp,
@@ -252,7 +261,7 @@ __global__ void k_chirp_control(ChirpCtl* __restrict__ ctl, double* __restrict__
 extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, void* P, const void* chirp, const void* Dt, int64_t n, double gamma,
                                     const double* hs, int64_t nsteps, double length, double phi_max, int f32, int64_t max_steps, double* z_out, int64_t* steps_out) {
     Target t;
-    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (int rc = target_of(plan, n, plan_n, batch, &t)) return rc;
     if (!A || !P || !chirp || !Dt) return fail(SSFM_ERR_INVALID, "ssfm_chirp_propagate: NULL argument");
     {
         int prec = 0, pb = 0;
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(256) void k_load_pulse(PulseSpec ps, double2* __res
 
 extern "C" int ssfm_load_padded(ssfm_plan* plan, int64_t plan_n, const void* src_dev, int src_complex, int64_t n_src) {
     Target t;
-    if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
+    if (int rc = target_of(plan, 2, plan_n, 1, &t)) return rc;      // (no length relation to check here)
     if (!src_dev || n_src < 1 || n_src > plan_n) return fail(SSFM_ERR_INVALID, "ssfm_load_padded: %lld source samples for a plan of %lld", (long long)n_src, (long long)plan_n);
     hipLaunchKernelGGL(k_load_padded, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double*)src_dev, src_complex, (long long)n_src, t.F, t.M);
     HIP_TRY(hipGetLastError());
@@ -543,7 +552,7 @@ extern "C" int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const void* sr
     if (src_kind != 0) return fail(SSFM_ERR_INVALID, "ssfm_load_symbols: src_kind %d", src_kind);
     const double* sym_dev = static_cast<const double*>(src_dev);
     Target t;
-    if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
+    if (int rc = target_of(plan, 2, plan_n, 1, &t)) return rc;      // (no length relation to check here)
     if (!sym_dev || nsym < 1 || up < 1 || nsym * up > plan_n) return fail(SSFM_ERR_INVALID, "ssfm_load_symbols: %lld symbols x %d samples for a plan of %lld", (long long)nsym, up, (long long)plan_n);
     hipLaunchKernelGGL(k_load_symbols, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, sym_dev, (long long)nsym, up, t.F, t.M);
     HIP_TRY(hipGetLastError());
@@ -552,7 +561,7 @@ extern "C" int ssfm_load_symbols(ssfm_plan* plan, int64_t plan_n, const void* sr
 
 extern "C" int ssfm_load_pulse(ssfm_plan* plan, int64_t plan_n, int kind, int64_t npts, double start, double step, double stop, int pow2m, const double* params) {
     Target t;
-    if (int rc = target_of(plan, 2, plan_n, &t)) return rc;      // (no length relation to check here)
+    if (int rc = target_of(plan, 2, plan_n, 1, &t)) return rc;      // (no length relation to check here)
     if (kind < 0 || kind > 4 || npts < 1 || npts > plan_n || !params) return fail(SSFM_ERR_INVALID, "ssfm_load_pulse: kind %d, %lld points for a plan of %lld", kind, (long long)npts, (long long)plan_n);
     if (kind == 1 && (pow2m < 2 || pow2m > 98 || (pow2m & 1))) return fail(SSFM_ERR_INVALID, "ssfm_load_pulse: gaussian order 2m = %d outside 2 ... 98", pow2m);
     PulseSpec ps{kind, pow2m, (long long)npts, start, step, stop, params[0], params[1], params[2], params[3], params[4], params[5], params[6]};
@@ -603,7 +612,7 @@ extern "C" int ssfm_device_chirp(int device, void* out_dev, int64_t n, int conj)
 // Neither a host transform nor an upload.  Asynchronous on the plan's stream; the plan's field is consumed.
 extern "C" int ssfm_chirp_setup(ssfm_plan* plan, int64_t plan_n, int64_t n) {
     Target t;
-    if (int rc = target_of(plan, n, plan_n, &t)) return rc;
+    if (int rc = target_of(plan, n, plan_n, 1, &t)) return rc;
     if (n > (1ll << 30)) return fail(SSFM_ERR_INVALID, "ssfm_chirp_setup: bad argument");
     for (int which = 0; which < 2; ++which) {
         hipLaunchKernelGGL(k_chirp_kernel, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, t.F, (long long)n, t.M, which);

@@ -309,7 +309,7 @@ class LaneWorker {
             std::unique_lock<std::mutex> lk(m_);
             for (;;) {
                 cv_.wait(lk, [this] { return has_job_ || quit_; });
-                if (quit_) return;
+                if (!has_job_) return;                       // (quit_: a job handed over but not yet picked up still runs -- a capture run's transfers, a lane's launches)
                 std::function<int()> job = std::move(job_);
                 has_job_ = false;
                 lk.unlock();
@@ -2548,8 +2548,15 @@ namespace {
 // workgroups did not meet), so that what the caller orders on the stream finds the run's real result.  nullptr (ssfm_last_error set) if that fails.
 template <typename PT> static bool mark_external(PT* P_) {
     P_->external_order = true;
-    if (!P_->medium_pending) return true;
-    return P_->use_device() == SSFM_OK && P_->finish_medium() == SSFM_OK;
+    // (a capture run's helper thread copies the end field from F on a stream of its own: it is joined here, before the caller can order anything that
+    // writes F behind the run -- ADVICE r5: the snapshots' validity "after any later call on the plan" includes these two calls)
+    if (!P_->medium_pending && !P_->cap_pending) return true;
+    return P_->use_device() == SSFM_OK;               // (joins the capture helper, resolves a pending one-launch run)
+}
+// The library's own cross-unit accessors (chirpz.hip writes F on the plan's stream through them): the same join.
+template <typename PT> static bool join_helpers(PT* P_) {
+    if (!P_->medium_pending && !P_->cap_pending) return true;
+    return P_->use_device() == SSFM_OK;
 }
 }  // namespace
 
@@ -2730,13 +2737,15 @@ int ssfm_kernel_times(ssfm_plan* plan, int64_t counts[2], double total_ms[2]) {
 namespace ssfm {
 void* plan_stream(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->stream;
-    return static_cast<PlanT<double>*>(plan->impl)->stream;
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return join_helpers(P_) ? P_->stream : nullptr; }
+    auto* P_ = static_cast<PlanT<double>*>(plan->impl);
+    return join_helpers(P_) ? P_->stream : nullptr;
 }
 void* plan_field(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) return static_cast<PlanT<float>*>(plan->impl)->F;
-    return static_cast<PlanT<double>*>(plan->impl)->F;
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return join_helpers(P_) ? (void*)P_->F : nullptr; }
+    auto* P_ = static_cast<PlanT<double>*>(plan->impl);
+    return join_helpers(P_) ? (void*)P_->F : nullptr;
 }
 int64_t plan_length(ssfm_plan* plan, int* batch, int* precision) {
     if (!plan || !plan->impl) return 0;

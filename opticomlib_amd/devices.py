@@ -19,7 +19,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import _lib
+from . import _lib, accuracy
 from .typing import NULL, binary_sequence, electrical_signal, gv, optical_signal
 
 _F32 = np.float32
@@ -381,18 +381,16 @@ def _fiber_chirpz(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_ma
 
 _CHIRPS32: "OrderedDict[tuple, object]" = OrderedDict()
 
-# Accuracy margin of the one-launch complex64 chirp-z line (2048 < n <= 65536; round 5, profiles/r05_chirp_margin.txt).  A step of that line is four
+# Accuracy margin of the one-launch complex64 chirp-z line (2048 < n <= 65536; profiles/r05_chirp_margin.txt).  A step of that line is four
 # padded complex64 transforms of 2-4 x the field's length where the reference's pocketfft makes two of the length itself: measured over 242 random
-# fibres, max|A - A_float64|/peak <= 7.5e-7 x steps^0.75 -- up to 1.7e-5 after 66-93 steps, within the stated 2e-5 (<= 100 steps) of the float64
-# solution but no longer within HALF of it, which is what keeps the line within the tolerance of the REFERENCE's own complex64 run whenever that run
-# itself is (it sits up to 2.6e-5 from the float64 solution for such lengths).  Runs of 32 ... 100 steps therefore take the complex128
-# line (four launches per step, 1e-13 from float64); shorter runs have not accumulated the error yet and from 101 steps on the tolerance is the
-# 1000-step one (3e-4; the line reaches 1.0e-4 there).  `precision="complex128"` always takes the complex128 line.
-_C64_LINE_STEPS_LO, _C64_LINE_STEPS_HI = 31, 100
-
-
-def _c64_line_has_margin(steps: int) -> bool:
-    return steps <= _C64_LINE_STEPS_LO or steps > _C64_LINE_STEPS_HI
+# fibres, max|A - A_float64|/peak <= 7.5e-7 x steps^0.75.  The reference's own complex64 run sits up to the tolerance itself from the float64
+# solution for such lengths, so the line may use HALF of the stated bound -- `accuracy.tol(steps)`, ONE bound continuous in the number of steps
+# (2e-5 up to 100 steps, the log-log line to 3e-4 at 1000, proportional beyond).  Where the law exceeds half the bound the run takes the complex128
+# line (four launches per step, 1e-13 from float64): 32 ... 758 steps, DERIVED from the law and the bound (`accuracy.c64_line_window`).  Round 5's
+# window, 32 ... 100, was fitted to the step at 101 steps of the tolerance the tests then used (2e-5 up to 100 steps, 3e-4 from 101): a 101-step
+# run is 2.4e-5 from the float64 solution by the line's own law.  `precision="complex128"` always takes the complex128 line.
+_c64_line_has_margin = accuracy.c64_line_has_margin
+_C64_LINE_NO_MARGIN = accuracy.c64_line_window()          # (first, last) step count without margin: (32, 758)
 
 
 def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev):
@@ -498,7 +496,7 @@ def _fiber_chirpz_medium_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, ga
         x = a_lin * float(L)
         l_eff = float(L) if abs(x) < 1e-6 else float(L) * (1.0 - np.exp(-x)) / x
         est = l_eff / h0 if h0 > 0 else 1.0
-        if 0.85 * _C64_LINE_STEPS_LO < est <= 1.15 * _C64_LINE_STEPS_HI:
+        if 0.85 * _C64_LINE_NO_MARGIN[0] <= est <= 1.15 * _C64_LINE_NO_MARGIN[1]:
             return None
         zs, z0, max_steps = [_F32(0)], _F32(0), 1 << 17
         while True:

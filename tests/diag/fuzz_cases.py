@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from opticomlib_amd import workloads
+from opticomlib_amd import accuracy, workloads
 from oracle import ssfm_numpy as orc
 
 F32 = np.float32
@@ -59,12 +59,15 @@ def truth_f64(a, dt, hs, kw):
 
 
 def tol_of(steps):
-    """2e-5 up to 100 steps, 3e-4 at 1000; beyond that the error's systematic part grows with the steps."""
-    return 2e-5 if steps <= 100 else 3e-4 * max(1.0, steps / 1000.0)
+    """SURVEY.md 8(c) states 2e-5 at 100 steps and 3e-4 at 1000: ONE bound continuous in the step count (opticomlib_amd.accuracy.tol: flat up to 100
+    steps, the log-log line between the two points, proportional to the steps beyond).  Rounds 3-5 used a step function (3e-4 from step 101)."""
+    return accuracy.tol(steps)
 
 
 def judge(y, oracle_out, truth, steps):
-    """(ok, HIP-oracle, HIP-float64, oracle-float64), distances as max|d| / peak.  The stated bound, round 5, has two halves:
+    """(ok, HIP-oracle, HIP-float64, oracle-float64), distances as max|d| / peak.  THE BUILDER'S RESTATEMENT of the contract (SURVEY.md 8(c) only states
+    the plain bound against the reference's own run; callers report the count beyond the plain bound `e_ho <= tol` beside this one: `plain_ok`).
+    The restated bound, round 5, has two halves:
       (1) against the float64 solution: within the tolerance, or at most 1.5 x as far from it as the oracle is;
       (2) against the oracle: within the tolerance, or -- where the oracle's own distance from the float64 solution leaves no room for that -- within
           2.5 x that distance (what (1) allows the two to be apart at most).
@@ -78,6 +81,12 @@ def judge(y, oracle_out, truth, steps):
     tol = tol_of(steps)
     ok = e_ht <= max(tol, 1.5 * e_ot) and e_ho <= max(tol, 2.5 * e_ot)
     return ok, e_ho, e_ht, e_ot
+
+
+def plain_ok(e_ho, steps):
+    """The contract as SURVEY.md 8(c) states it: within tol(steps) of the reference's own complex64 run -- nothing else.  Reported by the stress runs as a
+    separate count so that rounds stay comparable."""
+    return e_ho <= tol_of(steps)
 
 
 def run_case(oa, gv, optical_signal, kw, a):

@@ -21,7 +21,8 @@ if __name__ == "__main__":
     lo = int(os.environ.get("FUZZ_MIN_N", "2049"))
     gv(**workloads.BENCH_GV)
     if os.environ.get("FUZZ_ROUTE") == "c64":                       # every run on the one-launch complex64 lines, whatever its length in steps
-        oa.devices._C64_LINE_STEPS_LO = 1 << 30
+        oa.devices._c64_line_has_margin = lambda steps: True
+        oa.devices._C64_LINE_NO_MARGIN = (1 << 30, 1 << 30)
     print("# i n x pol steps mode | B = |gamma| sum_k h_k max|A_k|^2 [rad] | HIP-oracle HIP-f64 oracle-f64 | engine")
     for i, n, npol, kw, a, pow2 in cases(count, seed):
         if pow2 or n < lo:

@@ -129,6 +129,49 @@ def test_bench_self_launch_passes_only_the_json_line(tmp_path, monkeypatch):
     assert "RCCL version" in r.stderr and "Gloo" in r.stderr
 
 
+def test_bench_self_launch_kills_ranks_that_hang_and_says_where_they_were(tmp_path):
+    """a rank launcher that never returns (a hung RCCL initialisation on a node this repository has never seen) costs the
+    --launch-timeout budget, not the caller's lease: the child's whole process group is killed -- the ranks it started included --, every rank's last
+    log lines are printed, and the exit code is 124."""
+    import time
+    sys.path.insert(0, ROOT)
+    fake = tmp_path / "torch" / "distributed"
+    fake.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (fake / "__init__.py").write_text("")
+    pidfile = tmp_path / "rank1.pid"
+    (fake / "run.py").write_text(
+        "import os, subprocess, sys, time\n"
+        "print('[bench rank 0 +0.1s] init_process_group(nccl) ...', file=sys.stderr, flush=True)\n"
+        "p = subprocess.Popen([sys.executable, '-c', 'import sys, time; print(\"[bench rank 1 +0.1s] init_process_group(nccl) ...\", file=sys.stderr, flush=True); time.sleep(3600)'])\n"
+        f"open({str(pidfile)!r}, 'w').write(str(p.pid))\n"
+        "time.sleep(3600)\n")
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.self_launch(bench.parse_args(['--gpus', '2', '--launch-timeout', '3']), ['--gpus', '2']))") % (str(tmp_path), ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, PYTHONPATH=str(tmp_path)))
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 40
+    assert r.stdout == ""
+    assert "did not finish within --launch-timeout 3 s" in r.stderr
+    assert "rank 0: [bench rank 0 +0.1s] init_process_group(nccl) ..." in r.stderr and "rank 1: [bench rank 1 +0.1s] init_process_group(nccl) ..." in r.stderr
+    pid = int(pidfile.read_text())
+    for _ in range(50):                                       # the grandchild (a rank) went with the group
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        # (a zombie still answers kill 0 until it is reaped by init: look at its state)
+        try:
+            if open(f"/proc/{pid}/stat").read().split(")")[1].split()[0] == "Z":
+                break
+        except OSError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("a rank survived the launcher's death")
+
+
 def test_bench_ranks_keep_stdout_for_the_json_line():
     """guard_stdout(): whatever a library writes to file descriptor 1 afterwards (RCCL's banner is a C-level printf) lands on stderr."""
     code = ("import sys, os; sys.path.insert(0, %r); import bench; bench.guard_stdout(); os.write(1, b'RCCL version : x\\n'); "

@@ -6,6 +6,10 @@
 Stated tolerances: complex64, fixed h: max|d|/peak <= 2e-5 up to 100 steps,
 <= 3e-4 at 1000 steps (the reference's own complex64 noise floor against float64 is 5e-6 /
 8e-5); adaptive: the same bound at z = L with the step count within +-1; complex128: <= 1e-10.
+Round 6: ONE continuous bound, `opticomlib_amd.accuracy.tol(steps)` (2e-5 up to 100 steps, the log-log
+line to 3e-4 at 1000, proportional to the steps beyond) -- `TOL_100` / `TOL_1000` below are tol(100) /
+tol(1000) and are only used for runs of at most 100 / of exactly 1000 steps.  Every comparison goes through
+`margins.within`, which writes the error it measured beside its bound (profiles/r06_parity_margins.txt).
 """
 import os
 import warnings
@@ -21,13 +25,11 @@ from oracle import ssfm_numpy as orc
 
 pytestmark = pytest.mark.gpu
 
-TOL_100 = 2e-5
-TOL_1000 = 3e-4
-TOL_C128 = 1e-10
+from margins import relmax, steps_of, within
+from opticomlib_amd.accuracy import TOL_C128, tol as tol_at
 
-
-def relmax(a, b):
-    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+TOL_100 = tol_at(100)        # 2e-5: runs of up to 100 steps
+TOL_1000 = tol_at(1000)      # 3e-4: runs of exactly 1000 steps (anything between states tol_at(steps))
 
 
 def _npts(case):
@@ -83,21 +85,21 @@ def test_fiber_dbp_golden(golden_dir, name):
     x = _signal(case)
     fn = oa.FIBER if case["func"] == "FIBER" else oa.DBP
     kw = dict(case["kw"])
-    nsteps_ref = len(g["z"]) - 1 if "z" in g else 100
-    tol = TOL_1000 if nsteps_ref > 100 else TOL_100
+    nsteps_ref = len(g["z"]) - 1 if "z" in g else (steps_of(kw) or 1)      # (adaptive goldens without a z log are the single-step cases)
+    tol = tol_at(nsteps_ref)
     if kw.get("return_steps"):
         z, A_z = fn(x, **kw)
         assert z.dtype == np.float64 and A_z.dtype == np.complex64
         assert A_z.shape == g["A_z"].shape
         np.testing.assert_array_equal(z, g["z"])
-        assert relmax(A_z, g["A_z"]) < tol
+        assert within(A_z, g["A_z"], tol, steps=nsteps_ref, what="golden A_z, every step")
         return
     y = fn(x, **kw)
     assert isinstance(y, optical_signal) and y.noise is NULL
     assert y.signal.dtype == np.complex64 and y.signal.shape == g["out"].shape
     assert y.n_pol == (2 if g["out"].ndim == 2 else 1)
     assert y.execution_time > 0
-    assert relmax(y.signal, g["out"]) < tol
+    assert within(y.signal, g["out"], tol, steps=nsteps_ref, what="golden out")
     if "z" in g:
         z, A_z = fn(x, return_steps=True, **kw)
         if kw.get("h") is not None:
@@ -106,7 +108,9 @@ def test_fiber_dbp_golden(golden_dir, name):
             assert abs(len(z) - len(g["z"])) <= 1                 # adaptive: chaotic in the last bit
             m = min(len(z), len(g["z"])) - 1
             np.testing.assert_allclose(z[:m], g["z"][:m], rtol=2e-4)
-        assert relmax(A_z[-1], g["out"]) < tol
+        # (adaptive: the bound of the run's own step count; a +-1 mismatch is a different splitting of the last stretch and is
+        # held to the same bound -- the goldens' adaptive runs are 29 ... 60 steps, far from where that matters)
+        assert within(A_z[-1], g["out"], tol, steps=len(z) - 1, what="golden out, return_steps run")
 
 
 def test_fiber_then_dbp_golden(golden_dir):
@@ -115,8 +119,8 @@ def test_fiber_then_dbp_golden(golden_dir):
     x = _signal(case)
     mid = oa.FIBER(x, **case["kw"])
     out = oa.DBP(mid, **case["kw"])
-    assert relmax(mid.signal, g["mid"]) < TOL_100
-    assert relmax(out.signal, g["out"]) < TOL_100
+    assert within(mid.signal, g["mid"], kw=case["kw"], what="golden FIBER leg")
+    assert within(out.signal, g["out"], steps=2 * steps_of(case["kw"]), what="golden FIBER + DBP")
     # KAT-3: not the identity -- parity is against the reference's DBP output, not the input
     assert np.max(np.abs(out.signal - x.signal)) > 1e-3
 
@@ -134,9 +138,9 @@ def test_dm_golden(golden_dir, name):
     else:
         y = r
     assert y.signal.dtype == np.complex128 and y.n_pol == x.n_pol
-    assert relmax(y.signal, g["out"]) < 1e-13
+    assert within(y.signal, g["out"], 1e-13)
     if "out_noise" in g:
-        assert relmax(y.noise, g["out_noise"]) < 1e-13
+        assert within(y.noise, g["out_noise"], 1e-13)
     else:
         assert y.noise is NULL
 
@@ -150,7 +154,7 @@ def test_c128_against_reference_twin(golden_dir, name):
     y = oa.FIBER(x, precision="complex128", **kw)
     assert y.signal.dtype == np.complex128
     want = g["A_last"] * np.exp(-(kw["alpha"] / 4.343) * g["z"][-1] / 2)
-    assert relmax(y.signal, want) < TOL_C128
+    assert within(y.signal, want, TOL_C128)
 
 
 # ----------------------------------------------------------------------- lengths that are not powers of two
@@ -166,13 +170,13 @@ def test_any_length_fixed_step_against_oracle(n, npol):
     y = oa.FIBER(optical_signal(a), **kw)
     assert y.signal.dtype == np.complex64 and y.signal.shape == a.shape and y.n_pol == npol
     ref = orc.fiber_c64(a, gv.dt, **kw)
-    assert relmax(y.signal, ref) < TOL_100
+    assert within(y.signal, ref, kw=kw, what="oracle")
     z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
     zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
     np.testing.assert_array_equal(z, zr)
-    assert A_z.shape == Ar.shape and A_z.dtype == np.complex64 and relmax(A_z, Ar) < TOL_100
+    assert A_z.shape == Ar.shape and A_z.dtype == np.complex64 and within(A_z, Ar, kw=kw, what="oracle, every step")
     back = oa.DBP(y, **kw)                                             # device-resident input of odd length
-    assert relmax(back.signal, orc.dbp_c64(ref, gv.dt, **kw)) < TOL_100
+    assert within(back.signal, orc.dbp_c64(ref, gv.dt, **kw), steps=2 * steps_of(kw), what="oracle FIBER + DBP")
 
 
 @pytest.mark.parametrize("n", [3000, 5001])
@@ -186,18 +190,18 @@ def test_any_length_adaptive_complex128_and_dm(n):
     assert abs(len(z) - len(zr)) <= 1 and abs(z[-1] - 10.0) < 1e-4
     m = min(len(z), len(zr)) - 1
     np.testing.assert_allclose(z[:m], zr[:m], rtol=2e-4)
-    assert relmax(A_z[-1], Ar[-1]) < TOL_100
+    assert within(A_z[-1], Ar[-1], steps=len(z) - 1, what=f"oracle adaptive, return_steps ({len(z) - 1} vs {len(zr) - 1} steps)")
     y = oa.FIBER(optical_signal(a), **kw).signal
-    assert relmax(y, Ar[-1]) < TOL_100
+    assert within(y, Ar[-1], steps=len(zr) - 1, what="oracle adaptive")
     # complex128 extension against the float64 restatement
     kwf = dict(length=5, h=0.5, **workloads.SMF)
     y128 = oa.FIBER(optical_signal(a), precision="complex128", **kwf).signal
-    assert y128.dtype == np.complex128 and relmax(y128, orc.fiber_c128(a, gv.dt, **kwf)) < TOL_C128
+    assert y128.dtype == np.complex128 and within(y128, orc.fiber_c128(a, gv.dt, **kwf), TOL_C128, kw=kwf, what="float64 restatement")
     # DM: signal and noise apart, H as the reference forms it
     nz = 0.1 * a[::-1].copy()
     d, H = oa.DM(optical_signal(a, nz), D=-150.0, retH=True)
     ds, dn = orc.dm_c128(a, gv.dt, -150.0, noise=nz)
-    assert relmax(d.signal, ds) < 1e-12 and relmax(d.noise, dn) < 1e-12
+    assert within(d.signal, ds, 1e-12) and within(d.noise, dn, 1e-12)
     np.testing.assert_allclose(H, np.fft.fftshift(orc.dm_transfer(n, gv.dt, -150.0)), rtol=0, atol=1e-15)
 
 
@@ -225,7 +229,7 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
             tol = 1e-12 * (1 if "h" in kw else 1e4)                 # (adaptive: a last-bit difference in a maximum moves a step size)
             if name == "c":
                 tol = TOL_100      # (round 4: a complex64 caller's run of up to 65536 samples is ONE launch on a complex64 line -- the reference's own arithmetic class)
-            assert relmax(res[name][0], res["python"][0]) < tol, name
+            assert within(res[name][0], res["python"][0], tol, steps=len(res["python"][1]) - 1, what=f"the run driven from C ({name}) against the host loop"), name
         assert len(res["python"][1]) > 10
         if n <= 2048:
             # the complex128 line in one launch (precision="complex128") against the complex128 host loop: 1e-12 as before
@@ -233,26 +237,29 @@ def test_any_length_run_driven_from_c_against_the_host_loop(n, monkeypatch):
             r128 = oa.FIBER(x, precision="complex128", **kw).signal
             monkeypatch.setenv("SSFM_CHIRP_LOOP", "c"); monkeypatch.setenv("SSFM_CHIRP_SMALL", "1")
             y128 = oa.FIBER(x, precision="complex128", **kw).signal
-            assert y128.dtype == np.complex128 and relmax(y128, r128) < 1e-12 * (1 if "h" in kw else 1e4)
+            assert y128.dtype == np.complex128 and within(y128, r128, 1e-12 * (1 if "h" in kw else 1e4))
             # ... and the complex64 line against the oracle (the reference's complex64 run of the same field)
             y64 = oa.FIBER(x, **kw).signal
-            assert y64.dtype == np.complex64 and relmax(y64, orc.fiber_c64(a, gv.dt, **kw)) < TOL_100
+            zo, Ao = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+            assert y64.dtype == np.complex64 and within(y64, Ao[-1], steps=len(zo) - 1, what="oracle, complex64 one-launch line")
     # one polarisation (a single row: the one-launch adaptive engine has nobody to exchange maxima with)
     x1, kw = optical_signal(a[0]), dict(length=8.0, phi_max=0.004, **workloads.SMF)
     monkeypatch.setenv("SSFM_CHIRP_LOOP", "python")
     ref = oa.FIBER(x1, **kw).signal
     monkeypatch.setenv("SSFM_CHIRP_LOOP", "c")
-    assert relmax(oa.FIBER(x1, **kw).signal, ref) < TOL_100                                   # (the complex64 line, see above)
+    assert within(oa.FIBER(x1, **kw).signal, ref, TOL_100, what="one polarisation, adaptive: the run driven from C against the host loop")  # (the complex64 line, see above)
     monkeypatch.setenv("SSFM_CHIRP_SMALL", "0"); monkeypatch.setenv("SSFM_MEDIUM", "0")
-    assert relmax(oa.FIBER(x1, **kw).signal, ref) < 1e-8                                      # (the complex128 line queued from C)
+    assert within(oa.FIBER(x1, **kw).signal, ref, 1e-8)  # (the complex128 line queued from C)
 
 
 @pytest.mark.parametrize("n,npol", [(3000, 2), (8176, 2), (8176, 1), (15060, 2), (32752, 2), (40000, 1), (65533, 1)])
 def test_any_length_medium_line_in_one_launch_against_oracle(n, npol, monkeypatch):
     """complex64 callers, fixed steps, 2048 < n <= 65536 (the reference's own generators: PRBS-9 / -11 words at 16 samples per bit are 8176 / 32752 samples):
     the whole run in one launch on one XCD on a complex64 line of M >= 2n - 1 points (k_medium_chirp behind ssfm_chirp_propagate_c64) -- against the oracle's complex64
-    run and the float64 restatement after 101 steps (the last one short), the single full-length step of a fibre without nonlinearity, and the five-launch
-    complex128 line of the same call (SSFM_MEDIUM=0).  The engine that ran is read back: a silent fall to the general path fails the test."""
+    run and the float64 restatement after 31 steps (the last one short: the longest run below the window in which the line has no margin, round 6), the single
+    full-length step of a fibre without nonlinearity, and the five-launch complex128 line of the same call (SSFM_MEDIUM=0).  The engine that ran is read back: a
+    silent fall to the general path fails the test.  Then the window itself (opticomlib_amd.accuracy: 32 ... 758 steps, derived from the line's measured error law
+    7.5e-7 x steps^0.75 against half of the continuous bound tol(steps)): runs inside it take the complex128 line, a run beyond it (800 steps) the one launch again."""
     for k in ("SSFM_MEDIUM", "SSFM_MEDIUM_ADAPT", "SSFM_ADAPT_FUSED", "SSFM_CHIRP_LOOP", "SSFM_FUSED_PATIENCE_TICKS", "SSFM_E", "SSFM_EF"):
         monkeypatch.delenv(k, raising=False)
     oa.devices.release_plans()                  # (a plan reads its knobs when it is made: none made under the knob suite's environment is reused here)
@@ -261,7 +268,7 @@ def test_any_length_medium_line_in_one_launch_against_oracle(n, npol, monkeypatc
     a = a[0] if npol == 1 else a
     x = optical_signal(a)
     M = 1 << (2 * n - 2).bit_length()
-    for kw in (dict(length=50.2, h=0.5, **workloads.SMF), dict(length=40.0, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=0.0),
+    for kw in (dict(length=15.2, h=0.5, **workloads.SMF), dict(length=40.0, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=0.0),
                dict(length=4.0, phi_max=0.002, **workloads.SMF)):                   # (adaptive: 17 to 20 steps, k_medium_chirp_adapt)
         out = oa.FIBER(x, **kw)
         y = out.signal
@@ -269,23 +276,35 @@ def test_any_length_medium_line_in_one_launch_against_oracle(n, npol, monkeypatc
         assert out.engine == "chirp_medium_c64", (out.engine, kw)
         assert info["engine"] == ("chirp_medium_adaptive" if "phi_max" in kw else "chirp_medium") and not info["fell_back"], info
         assert y.dtype == np.complex64 and y.shape == a.shape
-        assert relmax(y, orc.fiber_c64(a, gv.dt, **kw)) < TOL_100
-        assert relmax(y, orc.fiber_c128(a, gv.dt, **kw)) < TOL_100
+        zo, Ao = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+        ns = len(zo) - 1
+        assert within(y, Ao[-1], steps=ns, what="oracle")
+        assert within(y, orc.fiber_c128(a, gv.dt, **kw), steps=ns, what="float64 restatement")
         monkeypatch.setenv("SSFM_MEDIUM", "0")
         y5 = oa.FIBER(x, **kw).signal
         monkeypatch.delenv("SSFM_MEDIUM")
-        assert relmax(y, y5) < TOL_100
+        assert within(y, y5, steps=ns, what="the complex128 line of the same call")
     kw = dict(length=10.0, h=0.5, **workloads.SMF)
     y = oa.FIBER(x, **kw)
     back = oa.DBP(y, **kw)                                                                                # device-resident input of odd length
-    assert relmax(back.signal, orc.dbp_c64(orc.fiber_c64(a, gv.dt, **kw), gv.dt, **kw)) < TOL_100
-    # Runs of 32 ... 100 steps, where the complex64 line has used up half of the stated tolerance (devices._C64_LINE_STEPS_LO / _HI, round 5), take the
+    assert within(back.signal, orc.dbp_c64(orc.fiber_c64(a, gv.dt, **kw), gv.dt, **kw), steps=2 * steps_of(kw), what="oracle FIBER + DBP")
+    # Runs of 32 ... 758 steps, where the complex64 line's own error law exceeds half of the stated tolerance (accuracy.c64_line_has_margin), take the
     # complex128 line -- fixed step by the count, adaptive by the estimate from the first step size: the float64 solution to the coefficients' rounding
-    for kw in (dict(length=30.0, h=0.5, **workloads.SMF), dict(length=12.0, phi_max=0.002, **workloads.SMF)):      # 60 steps; 50 to 60 steps
+    from opticomlib_amd import accuracy
+    assert accuracy.c64_line_window() == (32, 758) and oa.devices._C64_LINE_NO_MARGIN == (32, 758)
+    for kw in (dict(length=30.0, h=0.5, **workloads.SMF), dict(length=12.0, phi_max=0.002, **workloads.SMF),      # 60 steps; 50 to 60 steps
+               dict(length=50.2, h=0.5, **workloads.SMF)):                                                          # 101 steps: round 5 ran these on the complex64 line
         out = oa.FIBER(x, **kw)
         assert out.engine == "chirp_line_c128", (out.engine, kw)
-        assert relmax(out.signal, orc.fiber_c128(a, gv.dt, **kw)) < 5e-6
-        assert relmax(out.signal, orc.fiber_c64(a, gv.dt, **kw)) < TOL_100
+        zo, Ao = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+        assert within(out.signal, orc.fiber_c128(a, gv.dt, **kw), 5e-6, steps=len(zo) - 1, what="float64 restatement (complex128 line)")
+        assert within(out.signal, Ao[-1], steps=len(zo) - 1, what="oracle (complex128 line)")
+    if n == 3000:      # beyond the window: 800 steps on the one-launch line again, inside tol(800) = 2.3e-4 of the oracle and of the float64 restatement
+        kw = dict(length=100.0, h=0.125, **workloads.SMF)
+        out = oa.FIBER(x, **kw)
+        assert out.engine == "chirp_medium_c64" and steps_of(kw) == 800, (out.engine, steps_of(kw))
+        assert within(out.signal, orc.fiber_c64(a, gv.dt, **kw), kw=kw, what="oracle, 800 steps on the complex64 line")
+        assert within(out.signal, orc.fiber_c128(a, gv.dt, **kw), 0.5 * tol_at(800), kw=kw, what="float64 restatement, 800 steps on the complex64 line (half the bound)")
 
 
 def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run(monkeypatch):
@@ -331,7 +350,7 @@ def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run
         ref = a
         for h in hs:
             ref = orc.fiber_c64(ref, gv.dt, length=float(h), h=float(h), alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=1.3)
-        assert relmax(A.to_host(), ref) < TOL_100
+        assert within(A.to_host(), ref, steps=len(hs), what="oracle, step by step")
         assert q.last_run_info()["engine"] == "chirp_medium"
         A = _lib.DeviceArray.from_host(a, np.complex64, 0)
         steps, z = q.chirp_propagate_c64(A, chirp, Dt, 1.3, None, length=5.0, phi_max=0.004, max_steps=1000)
@@ -339,7 +358,7 @@ def test_the_medium_chirp_line_hands_the_field_back_untouched_when_it_cannot_run
         assert abs(steps + 1 - len(zr)) <= 1 and len(z) == steps + 1 and abs(z[-1] - 5.0) < 1e-5
         m = min(len(z), len(zr)) - 1
         np.testing.assert_allclose(z[:m], zr[:m], rtol=2e-4)
-        assert relmax(A.to_host(), Ar[-1]) < TOL_100
+        assert within(A.to_host(), Ar[-1], steps=steps, what=f"oracle adaptive ({steps} vs {len(zr) - 1} steps)")
         assert q.last_run_info()["engine"] == "chirp_medium_adaptive"
     finally:
         q.close()
@@ -419,7 +438,7 @@ def test_fixed_step_against_oracle(k, npol, steps):
     y = oa.FIBER(optical_signal(a), **kw).signal
     ref = orc.fiber_c64(a, gv.dt, **kw)
     assert y.shape == ref.shape
-    assert relmax(y, ref) < TOL_100
+    assert within(y, ref, kw=kw, what="oracle")
 
 
 def test_thousand_steps_against_oracle():
@@ -429,7 +448,7 @@ def test_thousand_steps_against_oracle():
     kw = dict(length=125, h=0.125, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), **kw).signal
     ref = orc.fiber_c64(a, gv.dt, **kw)
-    assert relmax(y, ref) < TOL_1000
+    assert within(y, ref, kw=kw, what="oracle, C2's schedule at 2^13 x 2")
 
 
 @pytest.mark.parametrize("phi_max", [0.01, 0.05])
@@ -441,9 +460,11 @@ def test_adaptive_against_oracle(phi_max):
     zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
     assert abs(len(z) - len(zr)) <= 1
     assert abs(z[-1] - 30.0) < 1e-4 and np.all(np.diff(z) > 0)
-    assert relmax(A_z[-1], Ar[-1]) < TOL_100 * 5        # a +-1 step-count difference changes the splitting error
+    # "the same bound after both reach z = L" -- the plain bound of the run's own step count, also on a +-1 mismatch
+    # (rounds 1-5 allowed 5 x; the measured distance is 2e-6 ... 7e-6, profiles/r06_parity_margins.txt)
+    assert within(A_z[-1], Ar[-1], steps=len(z) - 1, what=f"oracle adaptive, return_steps ({len(z) - 1} vs {len(zr) - 1} steps)")
     y = oa.FIBER(optical_signal(a), **kw).signal
-    assert relmax(y, Ar[-1]) < TOL_100 * 5
+    assert within(y, Ar[-1], steps=len(zr) - 1, what="oracle adaptive")
 
 
 def test_adaptive_gamma_zero_and_no_dispersion_single_step():
@@ -456,7 +477,7 @@ def test_adaptive_gamma_zero_and_no_dispersion_single_step():
             zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
             np.testing.assert_array_equal(z, zr)
             assert len(z) == 2
-            assert relmax(A_z[-1], Ar[-1]) < TOL_100
+            assert within(A_z[-1], Ar[-1], steps=1, what="oracle, single step")
 
 
 def test_c128_against_oracle_dual_pol():
@@ -465,10 +486,10 @@ def test_c128_against_oracle_dual_pol():
     kw = dict(length=10, h=1.0, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal
     ref = orc.fiber_c128(a, gv.dt, **kw)
-    assert relmax(y, ref) < TOL_C128
+    assert within(y, ref, TOL_C128, kw=kw, what="float64 restatement")
     # and the complex64 path sits at the reference's float32 noise floor from it
     y32 = oa.FIBER(optical_signal(a), **kw).signal
-    assert relmax(y32, ref) < TOL_100
+    assert within(y32, ref, kw=kw, what="complex64 run against the float64 restatement")
 
 
 @pytest.mark.parametrize("log2n, length", [(12, 20), (18, 3), (19, 2)])
@@ -480,7 +501,7 @@ def test_c128_adaptive_against_oracle(log2n, length):
     kw = dict(length=length, phi_max=0.05, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal
     ref = orc.fiber_c128(a, gv.dt, **kw)
-    assert relmax(y, ref) < 1e-7          # step sizes agree to rounding; splitting error tracks
+    assert within(y, ref, 1e-7)  # step sizes agree to rounding; splitting error tracks
     if log2n >= 18:
         hs = np.linspace(0.05, 0.35, 2 * length * 5 // 2)          # more distinct step sizes than operator tables
         hs = hs * (length / hs.sum())
@@ -497,7 +518,7 @@ def test_c128_adaptive_against_oracle(log2n, length):
         for h_ in hs:                                               # the loop of oracle/ssfm_numpy.fiber_c128 over a given schedule
             N_hat = 1j * workloads.SMF["gamma"] * np.abs(want) ** 2
             want = np.fft.ifft(np.fft.fft(want * np.exp(h_ / 2 * N_hat)) * np.exp(D * h_)) * np.exp(h_ / 2 * N_hat)
-        assert relmax(got, want) < TOL_C128
+        assert within(got, want, TOL_C128)
 
 
 # ----------------------------------------------------------------------- reference's own tests
@@ -523,7 +544,7 @@ def test_pure_spm_closed_form():
     L, al, g = 12.0, 0.2, 2.0
     y = oa.FIBER(optical_signal(a), length=L, alpha=al, gamma=g, precision="complex128").signal
     want = a * np.exp(-(al / 4.343) * L / 2) * np.exp(1j * g * np.abs(a) ** 2 * L)
-    assert relmax(y, want) < 1e-12
+    assert within(y, want, 1e-12)
 
 
 def test_linear_fiber_equals_DM():
@@ -532,7 +553,7 @@ def test_linear_fiber_equals_DM():
     a = workloads.qpsk_field(1 << 13, seed=6)
     y = oa.FIBER(optical_signal(a), length=40, beta_2=-20.0, precision="complex128").signal
     d = oa.DM(optical_signal(a), D=-20.0 * 40).signal
-    assert relmax(y, d) < 1e-11
+    assert within(y, d, 1e-11)
 
 
 # ----------------------------------------------------------------------- full benchmark size
@@ -547,7 +568,7 @@ def test_full_size_against_oracle_few_steps():
     kw = dict(length=6 * 0.125, h=0.125, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), **kw).signal
     ref = orc.fiber_c64(a, gv.dt, **kw)
-    assert relmax(y, ref) < TOL_100
+    assert within(y, ref, kw=kw, what="oracle, 2^20 x 2")
 
 
 def test_full_size_properties_1000_steps():
@@ -565,7 +586,7 @@ def test_full_size_properties_1000_steps():
     y0 = oa.FIBER(optical_signal(a[0]), **kw).signal                     # one polarisation alone
     np.testing.assert_array_equal(y0, y[0])
     y128 = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal
-    assert relmax(y, y128) < TOL_1000
+    assert within(y, y128, kw=kw, what="complex64 run against the complex128 run, C2")
 
 
 def test_full_size_c2_against_the_strided_fixture(golden_dir):
@@ -574,8 +595,7 @@ def test_full_size_c2_against_the_strided_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, "c2_full_strided.npz"))
     y = oa.FIBER(optical_signal(_bench_field()), length=125, h=0.125, **workloads.SMF).signal
     assert y.shape == (2, 1 << 20) and y.dtype == np.complex64
-    peak = np.max(np.abs(g["samples"]))
-    assert np.max(np.abs(y[:, ::257] - g["samples"])) / peak < TOL_1000
+    assert within(y[:, ::257], g["samples"], steps=1000, what="C2 full size, the oracle's strided fixture")
     y2 = np.abs(y.astype(np.complex128)) ** 2
     np.testing.assert_allclose(np.mean(y2, axis=-1), g["power"], rtol=1e-4)
     np.testing.assert_allclose(np.sum(y2), float(g["energy"]), rtol=1e-4)
@@ -586,7 +606,7 @@ def test_full_size_c1_against_the_strided_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, "c1_full_strided.npz"))
     y = oa.FIBER(optical_signal(_bench_field()), length=100, h=1.0, precision="complex128", **workloads.SMF).signal
     assert y.shape == (2, 1 << 20) and y.dtype == np.complex128
-    assert np.max(np.abs(y[:, ::257] - g["samples"])) / np.max(np.abs(g["samples"])) < TOL_C128
+    assert within(y[:, ::257], g["samples"], TOL_C128, steps=100, what="C1 full size, the float64 restatement's strided fixture")
     np.testing.assert_allclose(np.mean(np.abs(y) ** 2, axis=-1), g["power"], rtol=1e-11)
     np.testing.assert_allclose(np.sum(np.abs(y) ** 2), float(g["energy"]), rtol=1e-11)
 
@@ -606,7 +626,7 @@ def test_full_size_c3_batch_and_c4_chain():
     kw4 = dict(length=4, h=1.0, **workloads.SMF)
     got = od.propagate_channels(np.stack([a, a]), gv.dt, dbp=True, **kw4)[1]
     ref = orc.dbp_c64(orc.fiber_c64(a, gv.dt, **kw4), gv.dt, **kw4)
-    assert relmax(got, ref) < TOL_100
+    assert within(got, ref, steps=2 * steps_of(kw4), what="oracle FIBER + DBP, 2^20 x 2")
 
 
 def test_full_size_c128_100_steps_roundtrip_structure():
@@ -616,7 +636,7 @@ def test_full_size_c128_100_steps_roundtrip_structure():
     lin = dict(length=100, h=1.0, alpha=0.2, beta_2=-21.7, beta_3=0.13)
     y = oa.FIBER(optical_signal(a), precision="complex128", **lin)
     back = oa.DBP(y, precision="complex128", **lin).signal
-    assert relmax(back, a) < 1e-10
+    assert within(back, a, 1e-10)
     kw = dict(length=100, h=1.0, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), precision="complex128", **kw)
     back = oa.DBP(y, precision="complex128", **kw).signal
@@ -649,9 +669,9 @@ def test_bessel_filters_golden(golden_dir, name):
         y = oa.BPF(x, **kw)
         assert isinstance(y, optical_signal) and y.n_pol == x.n_pol and y.signal.dtype == np.complex128
     assert y.signal.shape == g["out"].shape
-    assert relmax(y.signal, g["out"]) < TOL_FILT
+    assert within(y.signal, g["out"], TOL_FILT)
     if "out_noise" in g:
-        assert relmax(y.noise, g["out_noise"]) < TOL_FILT
+        assert within(y.noise, g["out_noise"], TOL_FILT)
     else:
         assert y.noise is NULL
 
@@ -665,14 +685,14 @@ def test_bessel_filters_full_size_against_oracle_and_scipy():
     a = workloads.qpsk_field(1 << 20, seed=77)
     y = oa.BPF(optical_signal(a), BW=60e9).signal
     sos, zi = fo.bessel_sos(4, 30e9, gv.fs)
-    assert relmax(y, sg.sosfiltfilt(sos, a, axis=-1)) < TOL_FILT
+    assert within(y, sg.sosfiltfilt(sos, a, axis=-1), TOL_FILT)
     p = np.abs(a[0]) ** 2
     z = oa.LPF(p, BW=20e9).signal
     sos, zi = fo.bessel_sos(4, 20e9, gv.fs)
-    assert relmax(z, sg.sosfiltfilt(sos, p)) < TOL_FILT
+    assert within(z, sg.sosfiltfilt(sos, p), TOL_FILT)
     b = workloads.qpsk_field(1 << 14, seed=78)
     out, _ = fo.bpf(b, 60e9, gv.fs)
-    assert relmax(oa.BPF(optical_signal(b), BW=60e9).signal, out) < TOL_FILT
+    assert within(oa.BPF(optical_signal(b), BW=60e9).signal, out, TOL_FILT)
 
 
 @pytest.mark.parametrize("order", [1, 2, 3, 5, 8])
@@ -690,9 +710,9 @@ def test_sosfiltfilt_lengths_and_orders_against_scipy(order, n):
         return
     rng = np.random.default_rng(order * 1000 + n)
     x = rng.standard_normal(n).cumsum() * 0.05 + rng.standard_normal(n)
-    assert relmax(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x)) < TOL_FILT
+    assert within(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x), TOL_FILT)
     xc = (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n)))
-    assert relmax(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1)) < TOL_FILT
+    assert within(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1), TOL_FILT)
 
 
 @pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
@@ -725,20 +745,20 @@ def test_single_launch_engine_against_the_two_kernel_engine(log2n, prec, monkeyp
         single = n <= (8192 if prec == _lib.C64 else 4096)
         assert launches == (1 if small == "1" and single else 1 + 2 * hs.size)
     tol = 2e-6 if prec == _lib.C64 else 1e-12
-    assert relmax(got["1"], got["0"]) < tol
+    assert within(got["1"], got["0"], tol, steps=hs.size, what="one-launch engine against the two-kernel engine")
     if prec == _lib.C128:
         Dn = orc.linear_operator_c128(n, gv.dt, 0.2, -21.7, 0.13)
         want = a.copy()
         for h_ in hs:
             N_hat = 1j * 1.3 * np.abs(want) ** 2
             want = np.fft.ifft(np.fft.fft(want * np.exp(h_ / 2 * N_hat), axis=-1) * np.exp(Dn * h_), axis=-1) * np.exp(h_ / 2 * N_hat)
-        assert relmax(got["1"], want) < TOL_C128
+        assert within(got["1"], want, TOL_C128, steps=hs.size, what="float64 restatement, step by step")
     else:
         Dc = orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13)
         want = a.copy()
         for h_ in hs:
             want = orc.ssfm_step_c64(want, Dc, np.float32(1.3), np.float32(h_))
-        assert relmax(got["1"], want) < TOL_100
+        assert within(got["1"], want, steps=hs.size, what="oracle, step by step")
 
 
 @pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
@@ -781,12 +801,17 @@ def test_single_launch_adaptive_run_against_the_chunked_engine(log2n, rows, prec
     assert s1 > 3 and abs(s1 - s0) <= 1 and abs(z1[-1] - 6.0) < 1e-5
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6 if prec == _lib.C64 else 1e-12)
-    assert relmax(f1, f0) < (5 * TOL_100 if prec == _lib.C64 else 1e-9)
+    # two engines of this library on the same adaptive run (both within tol of the oracle: test_adaptive_*): the plain bound of the run's step count
+    assert within(f1, f0, (tol_at(max(s1, s0)) if prec == _lib.C64 else 1e-9), steps=s1, what=f"one-launch adaptive engine against the chunked engine ({s1} vs {s0} steps)")
     sb, zb, fb = res["budget"]
     assert sb == s0 and np.array_equal(zb, z0) and np.array_equal(fb, f0)
     if prec == _lib.C128:
         ref = orc.fiber_c128(a if rows > 1 else a[0], gv.dt, 6.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.02)
-        assert relmax(f1, ref) < 1e-7
+        assert within(f1, ref, 1e-7, steps=s1, what="float64 restatement, adaptive")
+    else:
+        zo, Ao = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 6.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.02, return_steps=True)
+        assert abs(len(zo) - 1 - s1) <= 1
+        assert within(f1 if rows > 1 else f1[0], Ao[-1], steps=s1, what=f"oracle adaptive ({s1} vs {len(zo) - 1} steps)")
 
 
 @pytest.mark.parametrize("prec", [_lib.C64, _lib.C128])
@@ -817,8 +842,8 @@ def test_single_launch_capture_against_the_two_kernel_engine(prec, monkeypatch):
     np.testing.assert_array_equal(s1[-1], f1)
     tol = 2e-6 if prec == _lib.C64 else 1e-12
     for k in range(1, hs.size + 1):
-        assert relmax(s1[k], s0[k]) < tol
-    assert relmax(f1, f0) < tol
+        assert within(s1[k], s0[k], tol, steps=k, what="one-launch capture against the two-kernel engine")
+    assert within(f1, f0, tol, steps=hs.size, what="one-launch capture against the two-kernel engine, end field")
 
 
 @pytest.mark.parametrize("log2n, rows", [(14, 1), (14, 2), (15, 1), (15, 2), (16, 1), (16, 2), (17, 1), (17, 2), (16, 4)])
@@ -864,7 +889,7 @@ def test_medium_single_launch_engine_against_the_two_kernel_engine(log2n, rows, 
     A = a.copy()
     for h_ in hs:
         A = orc.ssfm_step_c64(A, orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13), np.float32(1.3), h_)
-    assert relmax(got["1"][0][0], A) < TOL_100
+    assert within(got["1"][0][0], A, steps=hs.size, what="oracle, step by step")
 
 
 def test_a_stream_ordered_consumer_never_sees_a_run_that_gave_up(tmp_path):
@@ -900,9 +925,9 @@ def test_strided_capture_golden_and_against_every_step(golden_dir):
         keep = list(range(0, 5, every)) + [5]
         assert A_z.dtype == np.complex64 and A_z.shape == (len(keep),) + A_all.shape[1:]
         np.testing.assert_array_equal(z, g["z"][keep])
-        assert relmax(A_z, g["A_z"][keep]) < TOL_100
+        assert within(A_z, g["A_z"][keep], steps=5, what=f"golden return_steps, every={every}")
         # the every-step capture of a plan this small is taken by the one-launch engine, the strided one by the two-kernel engine: the same arithmetic class
-        assert relmax(A_z, A_all[keep]) < 2e-6
+        assert within(A_z, A_all[keep], 2e-6, steps=5, what="strided capture against this library's every-step capture")
 
 
 @pytest.mark.parametrize("prec,log2n,npol", [("c128", 16, 2), ("c128", 20, 2), ("c128", 12, 1), ("c64", 10, 1)])
@@ -931,7 +956,7 @@ def test_strided_capture_on_plans_whose_engine_works_in_place(prec, log2n, npol)
                 if p.last_run_info()["engine"] == "two_kernel" and not log:
                     np.testing.assert_array_equal(cap["fields"][k], p.get_field())
                 else:
-                    assert relmax(cap["fields"][k], p.get_field()) < tol
+                    assert within(cap["fields"][k], p.get_field(), tol, steps=s_, what="snapshot against a plain run of that many steps")
             if log:
                 power = np.mean(np.abs(cap["fields"].astype(np.complex128)) ** 2, axis=-1)
                 np.testing.assert_allclose(cap["power"][cap["steps"]], power, rtol=1e-12 if prec == "c128" else 5e-6)
@@ -963,11 +988,11 @@ def test_strided_capture_with_more_snapshots_than_device_blocks(log2n, nsteps, e
             if p.last_run_info()["engine"] == "two_kernel":
                 np.testing.assert_array_equal(cap["fields"][s_ // every], p.get_field())
             else:                                                    # (plans the one-launch engines take: another order of the same operations, up to 399 steps)
-                assert relmax(cap["fields"][s_ // every], p.get_field()) < 0.5 * TOL_100
+                assert within(cap["fields"][s_ // every], p.get_field(), 0.5 * tol_at(s_), steps=s_, what="snapshot (two-kernel engine) against a plain run (one-launch engine)")
         if log2n == 14:
             p.set_field(a)
             every_step = p.propagate_fixed(1.3, hs, snapshots=True)
-            assert relmax(cap["fields"], every_step[cap["steps"]]) < 0.5 * TOL_100
+            assert within(cap["fields"], every_step[cap["steps"]], 0.5 * tol_at(nsteps), steps=nsteps, what="strided capture against the every-step capture, all snapshots")
         # a second capture run on the same plan right behind the first (the helper of the first is joined by the next call on the plan)
         p.set_field(a)
         again = p.propagate_fixed_capture(1.3, hs, every=every)
@@ -1003,12 +1028,12 @@ def test_strided_capture_and_scalar_log_against_the_plain_run(log2n, npol, lanes
             if p.last_run_info()["engine"] == "two_kernel":
                 np.testing.assert_array_equal(cap["fields"][k], want)
             else:                                                    # (plans the one-launch engines take: another order of the same operations)
-                assert relmax(cap["fields"][k], want) < 5e-6
+                assert within(cap["fields"][k], want, 5e-6, steps=s_, what="snapshot against a plain run (one-launch engine)")
         # with the scalar log the column kernels are another instantiation (the log is a template parameter, so that every other run keeps its kernels to the
         # last instruction): the same operations, fields equal to the last bits of a fused product
         p.set_field(a)
         log = p.propagate_fixed_capture(1.3, hs, every=5, scalars=True)
-        assert relmax(log["fields"], cap["fields"]) < 0.5 * TOL_100          # (two roundings of the same 23 steps: the distance two engines of this library keep)
+        assert within(log["fields"], cap["fields"], 0.5 * TOL_100, steps=23, what="capture with the scalar log against the capture without")  # (two roundings of the same 23 steps: the distance two engines of this library keep)
         cap = log
         power = np.mean(np.abs(cap["fields"].astype(np.complex128)) ** 2, axis=-1)
         peak = np.max(np.abs(cap["fields"].astype(np.complex128)) ** 2, axis=-1)
@@ -1046,7 +1071,7 @@ def test_the_16_bit_stale_power_holds_its_stated_phase_bound(half_phase, steps, 
     kw = dict(length=h * steps, h=h, alpha=0.2, beta_2=-21.7, beta_3=0.13, gamma=gamma)
     out = oa.FIBER(optical_signal(a), **kw)
     assert out.engine == "two_kernel"
-    assert relmax(out.signal, orc.fiber_c64(a, gv.dt, **kw)) < bound
+    assert within(out.signal, orc.fiber_c64(a, gv.dt, **kw), bound, kw=kw, what=f"oracle, {half_phase} rad per half step")
 
 
 def test_the_lanes_of_a_plan_get_hardware_queues_of_their_own(monkeypatch):
@@ -1160,12 +1185,12 @@ def test_plans_of_8192_samples_take_the_one_xcd_engine(rows, monkeypatch):
             p.close()
     assert got["default"][1] == 1 and got["small"][1] == 1 and got["two-kernel"][1] > 10
     np.testing.assert_array_equal(got["default"][0], got["two-kernel"][0])
-    assert relmax(got["default"][0], got["small"][0]) < TOL_100
+    assert within(got["default"][0], got["small"][0], steps=hs.size, what="one-XCD engine against the one-workgroup engine")
     if rows <= 2:
         A = a.copy()
         for h_ in hs:
             A = orc.ssfm_step_c64(A, orc.linear_operator_c64(n, gv.dt, 0.2, -21.7, 0.13), np.float32(1.3), h_)
-        assert relmax(got["default"][0], A) < TOL_100
+        assert within(got["default"][0], A, steps=hs.size, what="oracle, step by step")
 
 
 def test_medium_single_launch_engine_on_several_plans_at_once(monkeypatch):
@@ -1270,14 +1295,15 @@ def test_fused_adaptive_column_kernel_against_the_three_launch_engine(log2n, row
     assert abs(s1 - s0) <= 1
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6 if prec == _lib.C64 else 1e-12)
-    assert relmax(f1, f0) < (5 * TOL_100 if prec == _lib.C64 else 1e-9)
-    if True:                       # every size against the oracle directly
+    assert within(f1, f0, (tol_at(max(s1, s0)) if prec == _lib.C64 else 1e-9), steps=s1, what=f"fused adaptive kernel against three launches per step ({s1} vs {s0} steps)")
+    if True:                       # every size against the oracle directly: the plain bound of the run's own step count ("the same bound after both reach z = L")
         if prec == _lib.C128:
             ref = orc.fiber_c128(a if rows > 1 else a[0], gv.dt, 4.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.002)
-            assert relmax(f1, ref) < 1e-7
+            assert within(f1, ref, 1e-7, steps=s1, what="float64 restatement, adaptive")
         else:
-            ref = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 4.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.002)
-            assert relmax(f1, ref) < TOL_1000
+            zo, Ao = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 4.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.002, return_steps=True)
+            assert abs(len(zo) - 1 - s1) <= 1
+            assert within(f1 if rows > 1 else f1[0], Ao[-1], steps=s1, what=f"oracle adaptive ({s1} vs {len(zo) - 1} steps)")
 
 
 @pytest.mark.parametrize("log2n, rows", [(12, 2), (13, 1), (13, 2), (14, 1), (14, 2), (14, 4), (15, 2), (16, 1), (16, 2), (17, 1)])
@@ -1320,10 +1346,11 @@ def test_medium_adaptive_run_in_one_launch(log2n, rows, monkeypatch):
     assert abs(s1 - s0) <= 1
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6)
-    assert relmax(f1, f0) < 5 * TOL_100
-    if rows <= 2:                  # (the reference takes one or two polarisations) every size against the oracle directly
-        ref = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 5.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.003)
-        assert relmax(f1, ref) < TOL_1000
+    assert within(f1, f0, steps=max(s1, s0), what=f"one-launch adaptive engine against two launches per step ({s1} vs {s0} steps)")
+    if rows <= 2:                  # (the reference takes one or two polarisations) every size against the oracle directly, at the plain bound of the step count
+        zo, Ao = orc.fiber_c64(a if rows > 1 else a[0], gv.dt, 5.0, 0.2, -21.7, 0.13, 1.3, phi_max=0.003, return_steps=True)
+        assert abs(len(zo) - 1 - s1) <= 1
+        assert within(f1 if rows > 1 else f1[0], Ao[-1], steps=s1, what=f"oracle adaptive ({s1} vs {len(zo) - 1} steps)")
 
 
 @pytest.mark.parametrize("log2n, rows", [(18, 2), (19, 1), (19, 2), (20, 2)])
@@ -1359,7 +1386,7 @@ def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch, g
         assert abs(steps - (len(zo) - 1)) <= 1, (steps, len(zo) - 1)
         k = min(steps, len(zo) - 1, 12)
         np.testing.assert_allclose(np.asarray(z)[:k + 1], zo[:k + 1], rtol=5e-6, atol=1e-7)
-        assert relmax(f[:, ::257], so) < TOL_1000, relmax(f[:, ::257], so)
+        assert within(f[:, ::257], so, steps=steps, what=f"the oracle's full-size adaptive fixture ({steps} vs {len(zo) - 1} steps)")
         np.testing.assert_allclose(np.mean(np.abs(f.astype(np.complex128)) ** 2, axis=-1), po, rtol=1e-4)
     s1, z1, f1, l1 = res["1"]
     s0, z0, f0, l0 = res["0"]
@@ -1368,7 +1395,7 @@ def test_fused_adaptive_column_kernel_on_large_grids(log2n, rows, monkeypatch, g
     assert abs(s1 - s0) <= 1
     k = min(s1, s0, 12)
     np.testing.assert_allclose(z1[:k], z0[:k], rtol=2e-6)
-    assert relmax(f1, f0) < 5 * TOL_100
+    assert within(f1, f0, steps=max(s1, s0), what=f"fused adaptive kernel against three launches per step ({s1} vs {s0} steps)")
 
 
 def test_fused_adaptive_kernel_gives_up_and_the_run_falls_back(monkeypatch):
@@ -1442,12 +1469,12 @@ def test_sosfiltfilt_both_workgroup_shapes(waves, monkeypatch):
         zi = sg.sosfilt_zi(sos)
         rng = np.random.default_rng(n)
         x = rng.standard_normal(n).cumsum() * 0.05 + rng.standard_normal(n)
-        assert relmax(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x)) < TOL_FILT
+        assert within(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x), TOL_FILT)
         xc = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n)))
-        assert relmax(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1)) < TOL_FILT
+        assert within(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1), TOL_FILT)
         # the other shape right after: the tables of the group level are rebuilt for it
         monkeypatch.setenv("SOS_WAVES_FORCE", "4" if waves == "2" else "2")
-        assert relmax(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x)) < TOL_FILT
+        assert within(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x), TOL_FILT)
         monkeypatch.setenv("SOS_WAVES_FORCE", waves)
 
 
@@ -1503,8 +1530,8 @@ def test_sosfiltfilt_in_one_launch_and_in_three(order, n, rows, cplx, monkeypatc
     monkeypatch.setenv("SSFM_SOS_ONE_LAUNCH", "0")
     three = _lib.sosfiltfilt(sos, zi, x)
     assert _lib.sosfiltfilt_last_launches() == 3
-    assert relmax(one, want) < TOL_FILT and relmax(three, want) < TOL_FILT
-    assert relmax(one, three) < 1e-13
+    assert within(one, want, TOL_FILT) and within(three, want, TOL_FILT)
+    assert within(one, three, 1e-13)
     if order <= 4:
         assert launches_default == 1                                   # (orders 5 to 8 fit one workgroup per CU: the longest calls fall back)
 
@@ -1527,10 +1554,10 @@ def test_sosfiltfilt_one_launch_gives_up_cleanly(monkeypatch):
         _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, q.field_device_ptr, n, 2, True)
         # (a 1 us wait may or may not be enough on an idle GPU: either form is acceptable, the result is not)
         assert _lib.sosfiltfilt_last_launches() in (1, 3)
-        assert relmax(q.get_field(), want) < TOL_FILT
+        assert within(q.get_field(), want, TOL_FILT)
         assert np.array_equal(p.get_field(), x)
         _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, p.field_device_ptr, n, 2, True)      # in place
-        assert relmax(p.get_field(), want) < TOL_FILT
+        assert within(p.get_field(), want, TOL_FILT)
     finally:
         p.close()
         q.close()
@@ -1544,7 +1571,7 @@ def test_narrow_filters_warn_and_stay_within_the_documented_bound():
     with pytest.warns(RuntimeWarning, match="below fs/500"):
         y = oa.LPF(x, BW=gv.fs / 2000).signal
     sos = sg.bessel(4, gv.fs / 2000, "low", fs=gv.fs, norm="mag", output="sos")
-    assert relmax(y, sg.sosfiltfilt(sos, x)) < 5 * 5e-20 * 2000 ** 3
+    assert within(y, sg.sosfiltfilt(sos, x), 5 * 5e-20 * 2000 ** 3)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         oa.LPF(x, BW=gv.fs / 300)                                      # no warning in the usual range
@@ -1580,9 +1607,9 @@ def test_receiver_front_end_golden(golden_dir, name):
         assert isinstance(y, optical_signal) and y.n_pol == 2 and y.signal.dtype == np.complex128
     assert y.execution_time > 0
     assert y.signal.shape == g["out"].shape
-    assert relmax(y.signal, g["out"]) < TOL_FRONT
+    assert within(y.signal, g["out"], TOL_FRONT)
     if "out_noise" in g:
-        assert relmax(y.noise, g["out_noise"]) < TOL_FRONT
+        assert within(y.noise, g["out_noise"], TOL_FRONT)
     else:
         assert y.noise is NULL
 
@@ -1643,8 +1670,8 @@ def test_adaptive_large_grid_against_oracle():
         zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
         assert len(z) == len(zr) and len(z) > 10
         np.testing.assert_allclose(z, zr, rtol=2e-5)
-        assert relmax(A_z[-1], Ar[-1]) < TOL_100
-        assert relmax(oa.FIBER(optical_signal(a), **kw).signal, Ar[-1]) < TOL_100
+        assert within(A_z[-1], Ar[-1], steps=len(z) - 1, what="oracle adaptive, return_steps")
+        assert within(oa.FIBER(optical_signal(a), **kw).signal, Ar[-1], steps=len(z) - 1, what="oracle adaptive")
 
 
 def test_arbitrary_step_schedule_through_the_abi():
@@ -1667,7 +1694,7 @@ def test_arbitrary_step_schedule_through_the_abi():
         A = a.astype(np.complex64)
         for h_ in hs:
             A = orc.ssfm_step_c64(A, D, np.float32(1.3), h_)
-        assert relmax(got, A) < TOL_100
+        assert within(got, A, steps=hs.size, what="oracle, step by step")
 
 
 # ----------------------------------------------------------------------- randomised parameters
@@ -1704,12 +1731,12 @@ def test_random_parameters_against_oracle(i, k, npol, power, kw):
         z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
         y = oa.FIBER(optical_signal(a), **kw).signal
     steps = len(zr) - 1
-    tol = TOL_100 if steps <= 100 else TOL_1000
+    tol = tol_at(steps)
     if "h" in kw:
         np.testing.assert_array_equal(z, zr)
     else:
         assert abs(len(z) - len(zr)) <= 1
-    assert relmax(A_z[-1], Ar[-1]) < tol and relmax(y, Ar[-1]) < tol
+    assert within(A_z[-1], Ar[-1], tol, steps=len(z) - 1, what=f"oracle, return_steps ({len(z) - 1} vs {steps} steps)") and within(y, Ar[-1], tol, steps=steps, what="oracle")
     assert y.shape == a.shape and y.dtype == np.complex64
 
 
@@ -1779,7 +1806,7 @@ def test_pd_and_edfa_with_the_device_generator():
     yd = oa.PD(xin, BW=20e9, rng="device")
     np.random.seed(0)
     yh = oa.PD(xin, BW=20e9)
-    assert relmax(yd.signal, yh.signal) < 1e-12
+    assert within(yd.signal, yh.signal, 1e-12)
     assert abs(np.mean(yd.noise) - np.mean(yh.noise)) < 0.05 * np.std(yh.noise) and abs(np.std(yd.noise) / np.std(yh.noise) - 1) < 0.05
     for mode in ("ase-only", "ase-thermal", "ase-shot", "thermal-shot", "ALL"):
         assert oa.PD(xin, BW=20e9, include_noise=mode, rng="device").noise.shape == (1 << 14,)
@@ -1798,7 +1825,7 @@ def test_pd_and_edfa_with_the_device_generator():
     np.random.seed(1)
     eh = oa.EDFA(xin, G=G, NF=NF, BW=60e9)
     edv = oa.EDFA(xin, G=G, NF=NF, BW=60e9, rng="device")
-    assert relmax(edv.signal, eh.signal) < 1e-12
+    assert within(edv.signal, eh.signal, 1e-12)
     assert abs(np.mean(np.abs(edv.noise) ** 2) / np.mean(np.abs(eh.noise) ** 2) - 1) < 0.05
 
 
@@ -1817,7 +1844,7 @@ def test_dac_golden(golden_dir, name):
     y = oa.DAC(seq, **kw)
     assert isinstance(y, electrical_signal) and y.noise is NULL and y.execution_time > 0
     assert y.signal.shape == g["out"].shape and y.signal.dtype == g["out"].dtype
-    assert relmax(y.signal, g["out"]) < 1e-12
+    assert within(y.signal, g["out"], 1e-12)
 
 
 def test_laser_and_mzm_against_golden(golden_dir):
@@ -1835,15 +1862,15 @@ def test_laser_and_mzm_against_golden(golden_dir):
                 np.random.seed(case["np_seed"])
             y = oa.LASER(**case["kw"])
             assert y.on_device and y.n_pol == 1 and y.noise is NULL and y.signal.dtype == g["out"].dtype
-            assert relmax(y.signal, g["out"]) < 1e-14
+            assert within(y.signal, g["out"], 1e-14)
             continue
         sig, noi = case_input(case)
         v, vn = case_drive(case)
         x = optical_signal(sig) if noi is None else optical_signal(sig, noi)
         y = oa.MZM(x, v if vn is None else electrical_signal(v, vn), **case["kw"])
-        assert y.signal.shape == g["out"].shape and relmax(y.signal, g["out"]) < 1e-14
+        assert y.signal.shape == g["out"].shape and within(y.signal, g["out"], 1e-14)
         if "out_noise" in g:
-            assert relmax(y.noise, g["out_noise"]) < 1e-14
+            assert within(y.noise, g["out_noise"], 1e-14)
         else:
             assert y.noise is NULL
         np.testing.assert_array_equal(x.signal, sig)                  # the input is not modified
@@ -1856,7 +1883,7 @@ def test_laser_and_mzm_against_golden(golden_dir):
         got = oa.MZM(cw, drive, bias=0.5, loss_dB=3).signal
         gt = k * (np.asarray(drive) + 0.5)
         want = cw.signal * (loss ** 0.5 * (np.cos(gt) + 1j * (2 * (10 ** -2.6) ** 0.5) / 2 * np.sin(gt)))
-        assert relmax(got, want) < 1e-14
+        assert within(got, want, 1e-14)
     with pytest.raises(ValueError):
         oa.MZM(cw, np.ones(100))                                      # lengths that do not broadcast
     # all options of the laser at 2^20 samples, seeded: same draws as the oracle
@@ -1864,7 +1891,7 @@ def test_laser_and_mzm_against_golden(golden_dir):
     gv(sps=16, R=10e9, N=1 << 16)
     np.random.seed(5); got = oa.LASER(P0=3, lw=1e5, rin=-150, df=2e9).signal
     np.random.seed(5); want = tx.laser(gv.t, gv.dt, gv.fs, 3, lw=1e5, rin=-150, df=2e9)
-    assert got.dtype == want.dtype == np.complex128 and relmax(got, want) < 1e-13
+    assert got.dtype == want.dtype == np.complex128 and within(got, want, 1e-13)
 
 
 def test_device_cumsum_min_and_laser_with_the_device_generator():
@@ -1979,10 +2006,10 @@ def test_transmitter_stays_on_the_device():
     assert _lib.TRANSFERS["d2h"] == before["d2h"]
     w1, _ = tx.mzm(np.full(4096, amp), None, tx.dac(bits.data, 16, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5), None, gv.fs, bias=-2.5, Vpi=5.0, loss_dB=3)
     w2, w2n = tx.mzm(c2_sig, c2_noi, tx.dac(bits.data, 16, gv.fs, pulse_shape="nrz", Vpp=2.0, coupling="AC"), None, gv.fs, bias=0.3, Vpi=4.0, ER_dB=30, pol="y")
-    assert relmax(m1.signal, w1) < 1e-14
-    assert relmax(m2.signal, w2) < 1e-14 and relmax(m2.noise, w2n) < 1e-14 and not m2.signal[0].any()
-    assert f.signal.dtype == np.float64 and relmax(f.signal, np.full(4096, amp)) < 1e-12     # a real envelope stays real through the filter
-    assert relmax(y.signal, orc.fiber_c64(w1, gv.dt, length=10, h=1.0, **workloads.SMF)) < 2e-5
+    assert within(m1.signal, w1, 1e-14)
+    assert within(m2.signal, w2, 1e-14) and within(m2.noise, w2n, 1e-14) and not m2.signal[0].any()
+    assert f.signal.dtype == np.float64 and within(f.signal, np.full(4096, amp), 1e-12)  # a real envelope stays real through the filter
+    assert within(y.signal, orc.fiber_c64(w1, gv.dt, length=10, h=1.0, **workloads.SMF), steps=10, what="oracle, device-resident chain")
 
 
 def test_dac_inputs_errors_and_long_sequence():
@@ -2007,7 +2034,7 @@ def test_dac_inputs_errors_and_long_sequence():
         oa.DAC("010", coupling="XX")
     bits = oa.PRBS(15, len=1 << 15).data                          # 2^19 samples: a convolution of 2^20 points
     y = oa.DAC(bits, pulse_shape="gaussian", Vpp=5.0, offset=-2.5).signal
-    assert relmax(y, tx.dac(bits, 16, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5)) < 1e-12
+    assert within(y, tx.dac(bits, 16, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5), 1e-12)
 
 
 def test_mzm_with_filter_and_the_transmitter_chain(golden_dir):
@@ -2021,7 +2048,7 @@ def test_mzm_with_filter_and_the_transmitter_chain(golden_dir):
     sig, _ = case_input(case)
     v, _ = case_drive(case)
     y = oa.MZM(optical_signal(sig), v, **case["kw"])
-    assert relmax(y.signal, g["out"]) < TOL_FILT and not y.signal[0].any()
+    assert within(y.signal, g["out"], TOL_FILT) and not y.signal[0].any()
     gv(sps=64, R=10e9, N=1 << 10)
     seq = oa.PRBS(order=9, len=gv.N)
     drive = oa.DAC(seq, Vpp=5.0, offset=-2.5, pulse_shape="gaussian")
@@ -2029,16 +2056,17 @@ def test_mzm_with_filter_and_the_transmitter_chain(golden_dir):
     bits = seq.data
     want_v = tx.dac(bits, 64, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5)
     want_m, _ = tx.mzm(tx.laser(gv.t, gv.dt, gv.fs, 5), None, want_v, None, gv.fs, bias=-2.5, Vpi=5.0, loss_dB=3, ER_dB=26)
-    assert mod.signal.shape == (1 << 16,) and relmax(mod.signal, want_m) < 1e-12
+    assert mod.signal.shape == (1 << 16,) and within(mod.signal, want_m, 1e-12)
     kw = dict(length=50, alpha=0.2, beta_2=-20, gamma=2)
     out = oa.FIBER(mod, **kw)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
-        ref = orc.fiber_c64(want_m, gv.dt, **kw)
-    assert relmax(out.signal, ref) < TOL_100
+        zo, Ao = orc.fiber_c64(want_m, gv.dt, return_steps=True, **kw)
+        ref = Ao[-1]
+    assert within(out.signal, ref, steps=len(zo) - 1, what="oracle, the reference's example link (adaptive)")
     rx = oa.PD(out, BW=gv.R * 0.75, include_noise="none")
     want_rx, _ = fe.pd(ref, None, gv.fs, gv.R * 0.75, include_noise="none")
-    assert relmax(rx.signal, want_rx) < 1e-4                            # |E|^2 of fields that agree to 2e-5
+    assert within(rx.signal, want_rx, 1e-4)  # |E|^2 of fields that agree to 2e-5
 
 
 # ----------------------------------------------------------------------- device-resident signals
@@ -2139,7 +2167,7 @@ def test_read_back_arrays_are_ordinary_numpy_arrays():
     y = oa.FIBER(optical_signal(x * 0.01), length=5, h=1.0, **workloads.SMF)
     s1 = y.signal
     od.release_plans()
-    assert relmax(s1, orc.fiber_c64((x * 0.01), gv.dt, length=5, h=1.0, **workloads.SMF)) < 2e-5
+    assert within(s1, orc.fiber_c64((x * 0.01), gv.dt, length=5, h=1.0, **workloads.SMF), steps=5, what="oracle")
     assert _lib.host_empty((0,), np.float64).size == 0
     import pickle
     np.testing.assert_array_equal(pickle.loads(pickle.dumps(s1)), s1)
@@ -2192,18 +2220,18 @@ def test_signal_call_is_the_fourier_transform_on_the_device():
                 if shift:
                     ws, wn = np.fft.fftshift(ws, axes=-1), np.fft.fftshift(wn, axes=-1)
                 assert W.signal.dtype == np.complex128 and W.signal.shape == shape
-                assert relmax(W.signal, ws) < 1e-13 and relmax(W.noise, wn) < 1e-13
+                assert within(W.signal, ws, 1e-13) and within(W.noise, wn, 1e-13)
                 T = x("t", shift=shift)
                 ts = np.fft.ifft(sig, axis=-1)
-                assert relmax(T.signal, np.fft.ifftshift(ts, axes=-1) if shift else ts) < 1e-13
+                assert within(T.signal, np.fft.ifftshift(ts, axes=-1) if shift else ts, 1e-13)
             back = x("f")("t")                                         # device-resident all the way
-            assert relmax(back.signal, sig) < 1e-13 and relmax(back.noise, noi) < 1e-13
+            assert within(back.signal, sig, 1e-13) and within(back.noise, noi, 1e-13)
     v = rng.standard_normal(1000)
     E = electrical_signal(v)("w")
-    assert isinstance(E, electrical_signal) and E.noise is NULL and relmax(E.signal, np.fft.fft(v)) < 1e-13
+    assert isinstance(E, electrical_signal) and E.noise is NULL and within(E.signal, np.fft.fft(v), 1e-13)
     c64 = optical_signal((rng.standard_normal(512) + 1j * rng.standard_normal(512)).astype(np.complex64))
     assert c64("w").signal.dtype == np.fft.fft(c64.signal).dtype == np.complex64
-    assert relmax(c64("w").signal, np.fft.fft(c64.signal.astype(complex))) < 1e-6
+    assert within(c64("w").signal, np.fft.fft(c64.signal.astype(complex)), 1e-6)
     with pytest.raises(ValueError, match="domain"):
         c64("x")
     with pytest.raises(ValueError, match="no CPU fallback"):
@@ -2236,7 +2264,7 @@ def test_sum_and_real_gain_of_device_resident_signals_stay_on_the_device():
     np.testing.assert_array_equal(half.signal, 0.5 * (a + b))
     np.testing.assert_array_equal(atten.signal, (a + b) * 10 ** (-0.3))
     np.testing.assert_array_equal(atten.noise, noisy.noise * 10 ** (-0.3))
-    assert relmax(out.signal, orc.fiber_c64(0.5 * (a + b), gv.dt, length=5, h=1.0, **workloads.SMF)) < 2e-5
+    assert within(out.signal, orc.fiber_c64(0.5 * (a + b), gv.dt, length=5, h=1.0, **workloads.SMF), steps=5, what="oracle")
     # everything else keeps the host path: other types, shapes, complex factors
     np.testing.assert_array_equal((both * (1 + 1j)).signal, (a + b) * (1 + 1j))
     np.testing.assert_array_equal((both + 1.0).signal, (a + b) + 1.0)
@@ -2382,7 +2410,7 @@ def test_fiber_then_dbp_prbs_realisations_against_oracle():
         y = oa.FIBER(optical_signal(a), **kw)
         x_hat = oa.DBP(y, **kw).signal
         ref = orc.dbp_c64(orc.fiber_c64(a, gv.dt, **kw), gv.dt, **kw)
-        assert relmax(x_hat, ref) < TOL_100
+        assert within(x_hat, ref, steps=2 * steps_of(kw), what="oracle FIBER + DBP, PRBS realisation")
         assert relmax(x_hat, a.astype(np.complex64)) > 10 * relmax(x_hat, ref)
 
 
@@ -2394,7 +2422,7 @@ def test_progress_bar_path_agrees():
     kw = dict(length=30, h=0.3, **workloads.SMF)
     y0 = oa.FIBER(optical_signal(a), **kw).signal
     y1 = oa.FIBER(optical_signal(a), show_progress=True, **kw).signal
-    assert relmax(y1, y0) < 1e-5
+    assert within(y1, y0, 1e-5, kw=kw, what="progress-bar run against the plain run")
 
 
 def test_progress_bar_on_every_engine(capsys):
@@ -2405,9 +2433,9 @@ def test_progress_bar_on_every_engine(capsys):
         for kw in (dict(length=5, h=0.5, **workloads.SMF), dict(length=5, phi_max=0.02, **workloads.SMF)):
             y0 = oa.FIBER(optical_signal(a), **kw).signal
             y1 = oa.FIBER(optical_signal(a), show_progress=True, **kw).signal
-            assert relmax(y1, y0) < 1e-5
+            assert within(y1, y0, 1e-5)
             z, A_z = oa.FIBER(optical_signal(a), show_progress=True, return_steps=True, **kw)
-            assert relmax(A_z[-1], y0) < 1e-5 and len(z) == A_z.shape[0]
+            assert within(A_z[-1], y0, 1e-5) and len(z) == A_z.shape[0]
 
 
 def test_zero_and_negative_length_return_the_cast_input():
@@ -2453,12 +2481,12 @@ def test_propagate_channels_fiber_then_dbp_on_device():
         via_host = oa.DBP(oa.FIBER(optical_signal(fields[c]), **kw), **kw).signal
         np.testing.assert_array_equal(outs[c], via_host)
     ref = orc.dbp_c64(orc.fiber_c64(fields[0], gv.dt, **kw), gv.dt, **kw)
-    assert relmax(outs[0], ref) < TOL_100
+    assert within(outs[0], ref, steps=2 * steps_of(kw), what="oracle FIBER + DBP")
     one = od.propagate_channels(fields[:1], gv.dt, dbp=True, **kw)             # single unit: host-API branch
     np.testing.assert_array_equal(one[0], outs[0])
     odd = fields[:2, :, :3000]                                                 # not a power of two: one by one, chirp-z
     got = od.propagate_channels(odd, gv.dt, **kw)
-    assert relmax(got[1], orc.fiber_c64(odd[1], gv.dt, **kw)) < TOL_100
+    assert within(got[1], orc.fiber_c64(odd[1], gv.dt, **kw), kw=kw, what="oracle, 3000 samples")
 
 
 # ----------------------------------------------------------------------- symmetries of the propagator
@@ -2472,10 +2500,10 @@ def test_symmetries_shift_and_global_phase(prec, tol):
     kw = dict(length=20, h=0.5, precision=prec, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), **kw).signal
     ys = oa.FIBER(optical_signal(np.roll(a, 12345, axis=-1)), **kw).signal
-    assert relmax(ys, np.roll(y, 12345, axis=-1)) < tol
+    assert within(ys, np.roll(y, 12345, axis=-1), tol, steps=40, what="shift symmetry")
     ph = np.exp(0.7j)
     yp = oa.FIBER(optical_signal(a * ph), **kw).signal
-    assert relmax(yp, y * ph) < tol
+    assert within(yp, y * ph, tol, steps=40, what="global phase symmetry")
 
 
 def test_gaussian_broadening_and_soliton_closed_forms():
@@ -2523,7 +2551,7 @@ def test_linearity_without_kerr_effect():
     f = lambda x: oa.FIBER(optical_signal(x), **kw).signal
     lhs = f(0.3 * x1 + (0.2 - 0.9j) * x2)
     rhs = 0.3 * f(x1) + (0.2 - 0.9j) * f(x2)
-    assert relmax(lhs, rhs) < 1e-12
+    assert within(lhs, rhs, 1e-12)
 
 
 def test_two_to_the_22_against_oracle():
@@ -2533,9 +2561,9 @@ def test_two_to_the_22_against_oracle():
     kw = dict(length=3 * 0.25, h=0.25, **workloads.SMF)
     y = oa.FIBER(optical_signal(a), **kw).signal
     ref = orc.fiber_c64(a, gv.dt, **kw)
-    assert relmax(y, ref) < TOL_100
+    assert within(y, ref, kw=kw, what="oracle, 2^22 x 1")
     y21 = oa.FIBER(optical_signal(a[: 1 << 21]), **kw).signal
-    assert relmax(y21, orc.fiber_c64(a[: 1 << 21], gv.dt, **kw)) < TOL_100
+    assert within(y21, orc.fiber_c64(a[: 1 << 21], gv.dt, **kw), kw=kw, what="oracle, 2^21 x 1")
 
 
 # ----------------------------------------------------------------------- PRBS on the device
@@ -2613,7 +2641,7 @@ def test_c4_realisation_generated_on_the_device():
             assert _lib.TRANSFERS["h2d"] == before               # (the first call uploads the shaping filter once)
         assert got.shape == (2, n) and got.dtype == np.complex64
         g = got.to_host()
-        assert relmax(g, want) < 3e-7
+        assert within(g, want, 3e-7)
         np.testing.assert_allclose(np.mean(np.abs(g.astype(np.complex128)) ** 2, axis=-1), 1e-3, rtol=1e-6)
     np.testing.assert_array_equal(workloads.prbs_field(n, seed=5).astype(np.complex64).shape, (2, n))
 
@@ -2627,13 +2655,13 @@ def test_full_size_c4_against_the_strided_fixture(golden_dir):
     gv(**workloads.BENCH_GV)
     n = 1 << 20
     a = workloads.prbs_field_device(n, seed=int(g["seed"]))
-    assert relmax(a.to_host()[:, ::257], g["input_samples"]) < 3e-7
+    assert within(a.to_host()[:, ::257], g["input_samples"], 3e-7)
     kw = dict(length=100, h=1.0, **workloads.SMF)
     y = oa.FIBER(optical_signal.from_device(a), **kw)
     x = oa.DBP(y, **kw)
-    for got, key in ((y.signal, "fiber"), (x.signal, "dbp")):
-        peak = np.max(np.abs(g[key + "_samples"]))
-        assert np.max(np.abs(got[:, ::257] - g[key + "_samples"])) / peak < 6e-5          # 100 / 200 steps: between the 2e-5 @ 100 and 3e-4 @ 1000 bounds
+    for got, key, ns in ((y.signal, "fiber", 100), (x.signal, "dbp", 200)):
+        # the FIBER leg at tol(100) = 2e-5, FIBER + DBP at tol(200) = 4.5e-5 (rounds 4-5 held both to 6e-5)
+        assert within(got[:, ::257], g[key + "_samples"], steps=ns, what=f"C4 full size, the oracle's strided fixture, {key} leg")
         p2 = np.abs(got.astype(np.complex128)) ** 2
         np.testing.assert_allclose(np.mean(p2, axis=-1), g[key + "_power"], rtol=1e-4)
         np.testing.assert_allclose(np.sum(p2), float(g[key + "_energy"]), rtol=1e-4)
@@ -2661,7 +2689,7 @@ def test_sweeping_a_parameter_through_minus_one_and_minus_two_restages_the_opera
                 kw[name] = val
                 okw = {k: (orc_sign * v if k in ("alpha", "beta_2", "beta_3", "gamma") else v) for k, v in kw.items()}
                 want = orc.fiber_c64(a, gv.dt, **okw)
-                assert relmax(fn(x, **kw).signal, want) < TOL_100, (fn.__name__, name, val)
+                assert within(fn(x, **kw).signal, want, kw=kw, what=f"oracle, {fn.__name__} {name}={val}"), (fn.__name__, name, val)
 
 
 def test_interleaved_users_of_one_plan_never_see_a_stale_table():
@@ -2683,19 +2711,19 @@ def test_interleaved_users_of_one_plan_never_see_a_stale_table():
     want_w = np.fft.fft(odd)
 
     def fiber():
-        assert relmax(oa.FIBER(optical_signal(a), precision="complex128", **kw).signal, want_f) < TOL_C128
+        assert within(oa.FIBER(optical_signal(a), precision="complex128", **kw).signal, want_f, TOL_C128)
 
     def dm():
-        assert relmax(oa.DM(optical_signal(a), D=-300.0).signal, want_dm) < 1e-12
+        assert within(oa.DM(optical_signal(a), D=-300.0).signal, want_dm, 1e-12)
 
     def dac():
-        assert relmax(oa.DAC(bits, Vpp=1.5, pulse_shape="gaussian").signal, want_dac) < 1e-12
+        assert within(oa.DAC(bits, Vpp=1.5, pulse_shape="gaussian").signal, want_dac, 1e-12)
 
     def odd_fiber():
-        assert relmax(oa.FIBER(optical_signal(odd), **kw).signal, want_odd) < TOL_100
+        assert within(oa.FIBER(optical_signal(odd), **kw).signal, want_odd, TOL_100)
 
     def spectrum():
-        assert relmax(optical_signal(odd)("w").signal, want_w) < 1e-12
+        assert within(optical_signal(odd)("w").signal, want_w, 1e-12)
 
     users = [fiber, dm, dac, odd_fiber, spectrum]
     import itertools
@@ -2739,13 +2767,13 @@ def test_no_host_arithmetic_left_in_the_device_paths():
     assert _lib.TRANSFERS == before and f._raw("signal").dtype == np.float64
     from scipy import signal as sg
     sos = sg.bessel(4, 5e9, "low", fs=gv.fs, norm="mag", output="sos")
-    assert relmax(f.signal, sg.sosfiltfilt(sos, x.to_host().real)) < 1e-11
+    assert within(f.signal, sg.sosfiltfilt(sos, x.to_host().real), 1e-11)
     bits = rng.integers(0, 2, 128).astype(np.uint8)
     before = _lib.TRANSFERS["d2h"]
     v = oa.DAC(bits, pulse_shape="gaussian", c=0.7, coupling="AC")                                 # complex pulse, AC coupled
     assert _lib.TRANSFERS["d2h"] == before and v._raw("signal").dtype == np.complex128
     from oracle import transmitter_numpy as tx
-    assert relmax(v.signal, tx.dac(bits, 16, gv.fs, pulse_shape="gaussian", c=0.7, coupling="AC")) < 1e-12
+    assert within(v.signal, tx.dac(bits, 16, gv.fs, pulse_shape="gaussian", c=0.7, coupling="AC"), 1e-12)
     one_pol = optical_signal.from_device(_lib.DeviceArray.from_host(rng.standard_normal(2048) + 0j, np.complex128))
     np.random.seed(1)
     before = _lib.TRANSFERS["d2h"]
@@ -2793,7 +2821,7 @@ def test_propagate_channels_over_rccl_matches_single_process(tmp_path, world):
     want_fixed = od.propagate_channels(f, w.DT, **w.FIXED)
     want_dbp = od.propagate_channels(f, w.DT, dbp=True, **w.FIXED)
     want_adapt = od.propagate_channels(f[:3], w.DT, **w.ADAPT)
-    assert relmax(want_fixed[0], orc.fiber_c64(f[0], w.DT, **w.FIXED)) < TOL_100        # and the single-process result is the oracle's
+    assert within(want_fixed[0], orc.fiber_c64(f[0], w.DT, **w.FIXED), kw=w.FIXED, what="oracle")  # and the single-process result is the oracle's
     for rank in range(world):
         got = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         for k in range(n_units):
@@ -2842,12 +2870,13 @@ def test_adaptive_capture_goes_to_the_host_in_blocks_and_api_order():
     assert A_z.base is None or A_z.base.nbytes == A_z.nbytes       # a compact array: nothing of max_steps + 1 fields is kept alive
     np.testing.assert_array_equal(A_z[0], a.astype(np.complex64))
     y = oa.FIBER(optical_signal(a), **kw).signal
-    assert relmax(A_z[-1], y) < 5 * TOL_100              # capture runs the chunked engine step by step, the plain run of a plan this small is one launch
+    # (capture runs the chunked engine step by step, the plain run of a plan this small is one launch: two engines, the bound of the run's step count)
+    assert within(A_z[-1], y, steps=steps, what="adaptive capture against the plain adaptive run")
     zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
-    assert abs(len(zr) - len(z)) <= 1 and relmax(A_z[-1], Ar[-1]) < TOL_1000
+    assert abs(len(zr) - len(z)) <= 1 and within(A_z[-1], Ar[-1], steps=steps, what=f"oracle adaptive ({steps} vs {len(zr) - 1} steps)")
     k = min(len(z), len(zr)) // 2
     np.testing.assert_allclose(z[:k], zr[:k], rtol=2e-4)
-    assert relmax(A_z[70], Ar[70]) < TOL_100 * 5          # a snapshot beyond the first block boundary
+    assert within(A_z[70], Ar[70], steps=70, what="oracle adaptive, snapshot 70 (beyond the first block boundary)")
     p = _lib.Plan(n, 2, _lib.C64)
     try:
         lib = _lib.load()
@@ -2898,5 +2927,5 @@ def test_one_launch_adaptive_run_of_any_length_gives_up_cleanly(monkeypatch):
         if info["engine"] != "chirp_small_adaptive":       # the one-launch engine is off in this environment (the knob suite's SSFM_SMALL=0, SSFM_CHIRP_LOOP=python)
             np.testing.assert_array_equal(y, ref)
             return
-        assert relmax(y, ref) < TOL_100
+        assert within(y, ref, TOL_100, what="one-launch adaptive chirp-z engine against the complex128 line")
     assert gave_up == 1

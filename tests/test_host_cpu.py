@@ -331,3 +331,47 @@ def test_plan_labels_do_not_collide_like_python_hashes():
     assert _tag("gauss-shape", 4096, 16) != _tag("gauss-shape", 16, 4096)
     with pytest.raises(TypeError):
         _tag("x", [1, 2])
+
+
+def test_the_stated_tolerance_is_one_continuous_bound_and_the_routing_window_follows_from_it():
+    """opticomlib_amd.accuracy: SURVEY.md 8(c)'s two points (2e-5 @ 100 steps, 3e-4 @ 1000) joined by a log-log line, flat below, proportional
+    beyond -- no step anywhere; the complex64 chirp-z line's window is derived from its measured error law against HALF of that bound."""
+    from opticomlib_amd import accuracy as acc
+    assert acc.tol(1) == acc.tol(100) == 2e-5 and abs(acc.tol(1000) - 3e-4) < 1e-18 and abs(acc.tol(2000) - 6e-4) < 1e-18
+    s = np.arange(1, 5000)
+    t = np.array([acc.tol(k) for k in s])
+    assert np.all(np.diff(t) >= 0) and np.max(t[1:] / t[:-1]) < 1.013            # monotone, and no jump: at most the line's own slope per step
+    assert abs(acc.tol(101) / acc.tol(100) - 1) < 0.012                            # (rounds 3-5: a factor 15 here)
+    lo, hi = acc.c64_line_window()
+    assert (lo, hi) == (32, 758)
+    assert acc.c64_line_has_margin(lo - 1) and not acc.c64_line_has_margin(lo) and not acc.c64_line_has_margin(hi) and acc.c64_line_has_margin(hi + 1)
+    assert all(acc.c64_line_error(k) <= 0.5 * acc.tol(k) for k in (1, 10, 31, 759, 1000, 5000))
+    assert devices._c64_line_has_margin is acc.c64_line_has_margin and devices._C64_LINE_NO_MARGIN == (lo, hi)
+
+
+def test_the_dynamic_symbol_table_is_the_c_abi_and_nothing_else():
+    """-fvisibility=hidden + csrc/exports.map: `nm -D --defined-only` of the shared library lists the 59 prototypes of include/ssfm_amd.h, no C++
+    symbol, no kernel handle (round 5: 535 of them)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert names == set(_lib.SYMBOLS), names ^ set(_lib.SYMBOLS)
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "hipfft" not in und.lower() and "rocfft" not in und.lower() and "torch" not in und.lower()
+
+
+def test_every_entry_point_the_documents_name_exists():
+    """the header's own mapping table, DESIGN.md and INTEGRATION.md named entry points that the ABI fold of round 5 had removed.  Every
+    full `ssfm_...` name in those texts is a declared prototype (or a type / constant of the header, or one of the names listed as REMOVED)."""
+    hdr = open(os.path.join(ROOT, "include", "ssfm_amd.h")).read()
+    known = set(_lib.SYMBOLS) | set(re.findall(r"\b(ssfm_[a-z0-9_]+)\b", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    removed_ok = re.compile(r"removed|hidden|round 4 exported|folded|no longer|internal|were|became|used to", re.I)
+    for name in ("include/ssfm_amd.h", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, name)).read()
+        for m in re.finditer(r"\b(ssfm_[a-z0-9_]+)\b", text):
+            w = m.group(1)
+            if w in known or w.endswith("_") or w in ("ssfm_amd", "ssfm_host", "ssfm_kernels", "ssfm_common", "ssfm_medium", "ssfm_numpy"):
+                continue
+            line = text[text.rfind("\n", 0, m.start()) + 1: text.find("\n", m.end())]
+            para = text[max(0, m.start() - 600): m.end() + 300]
+            assert removed_ok.search(para), f"{name}: `{w}` is not an entry point of the ABI: {line.strip()[:160]}"
