@@ -457,10 +457,12 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        progress(f"init_process_group({backend}) of {world} rank(s), GPU {local_rank} ...")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        progress("process group up")
 
     from opticomlib_amd import _lib, devices, workloads
     from opticomlib_amd import dist as od
@@ -552,20 +554,34 @@ def main():
         torch.cuda.synchronize()
 
     # plan set-up, not part of the protocol's warm-up: first touch of every buffer and table
+    progress(f"plans made ({workload}, {fields_here} field(s) here); first pass ...")
     one_step()
     fence()
     for _ in range(args.warmup):
         one_step()
     fence()
+    progress(f"warm-up done; timing {args.steps} step(s) ...")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_here = elapsed
+    progress(f"timed region done: {elapsed / max(args.steps, 1) * 1e3:.2f} ms per bench step on this rank")
+    ranks_seen, per_rank_s = 1, [elapsed_here]
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev_t = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank answers: a sum of ones over the group, and each rank's OWN time beside the maximum -- a slow or missing rank shows in the one JSON line
+        ones = torch.ones(1, dtype=torch.float64, device=dev_t)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+        mine = torch.tensor([elapsed_here], dtype=torch.float64, device=dev_t)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_s = [float(v.item()) for v in every]
 
     ms_dev, launches = plan.last_propagate_ms() if plan is not None else (0.0, 0)
     run_info = plan.last_run_info() if plan is not None else None          # which engine ran, whether it fell back, whether the lanes share a queue
@@ -590,6 +606,7 @@ def main():
             got = gather()
         fence()
         gather_ms = (time.perf_counter() - tg) / reps * 1e3
+        progress(f"gather done: {gather_ms:.2f} ms")
         collectives = dict(od.COLLECTIVES)
         if rank == 0:
             g = got.to_host()
@@ -705,6 +722,7 @@ def main():
         "value": value,
         "unit": "sample*steps/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -726,6 +744,8 @@ def main():
         "engine": run_info,
         "us_per_ssfm_step": elapsed / args.steps / steps_per_field * 1e6 / max(fields_here, 1),
         "us_per_ssfm_step_note": "wall time of a bench step / SSFM steps per field / fields on this GPU (per field-step)",
+        "us_per_ssfm_step_by_rank": [v / args.steps / steps_per_field * 1e6 / max(len(od.shard(total_fields, r, world)), 1) for r, v in enumerate(per_rank_s)],
+        "us_per_ssfm_step_by_rank_note": "every rank's OWN wall time of the timed region per field-step (`value` uses the maximum over ranks); `ranks_seen` = an all-reduce of ones",
         "output_power_W_per_field": checks,
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -81,7 +81,11 @@ SSFM_API int ssfm_abi_version(void);
 SSFM_API int ssfm_device_count(int* count);
 SSFM_API const char* ssfm_last_error(void);
 
-/* Smallest / largest supported log2(n) for a precision (currently 8..22). */
+/* Smallest / largest supported log2(n) for a precision (currently 8..24).  Rows of more than 2^22 samples run as "split plans" (round 6: R = 2 ... 16
+ * sub-sequences of 2^20 samples through the same kernels plus a pointwise launch across them, csrc/ssfm_split.hpp): ssfm_set_field / _get_field /
+ * _field_device_ptr, ssfm_set_linear_operator, ssfm_propagate_fixed (with `snapshots`), ssfm_propagate_adaptive / ssfm_adaptive_*, ssfm_apply_transfer and
+ * ssfm_apply_dispersion work as for any plan; the entry points that treat the plan's field buffer as ONE line (ssfm_transfer_table / _apply_table /
+ * _table_from_field, the ssfm_chirp_* and ssfm_load_* calls, ssfm_propagate_fixed_capture) return SSFM_ERR_UNSUPPORTED for them. */
 SSFM_API int ssfm_supported_log2n(int precision, int* lo, int* hi);
 
 /* Allocate every device buffer once: field, stale |A|^2, operator tables, twiddles. */
@@ -374,7 +378,9 @@ enum ssfm_engine {
     SSFM_ENGINE_CHIRP_SMALL_ADAPT = 9, /* any length <= 2048: adaptive, one launch per run */
     SSFM_ENGINE_CHIRP_STEPS = 10,      /* any length: four launches per fixed step (five through the library-internal chirp step of a host-driven loop), seven adaptive */
     SSFM_ENGINE_CHIRP_MEDIUM = 11,     /* any length, 2048 < n <= 65536, complex64: fixed step, one launch per run on one XCD */
-    SSFM_ENGINE_CHIRP_MEDIUM_ADAPT = 12 /* ... adaptive */
+    SSFM_ENGINE_CHIRP_MEDIUM_ADAPT = 12, /* ... adaptive */
+    SSFM_ENGINE_SPLIT = 13,            /* more than 2^22 samples per row, fixed step: four launches per step (csrc/ssfm_split.hpp) */
+    SSFM_ENGINE_SPLIT_ADAPT = 14       /* ... adaptive: five launches per step */
 };
 typedef struct ssfm_run_info {
     int engine;

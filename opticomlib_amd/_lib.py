@@ -88,7 +88,8 @@ SYMBOLS = {
 
 # enum ssfm_engine of include/ssfm_amd.h, by value
 ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adaptive_fused", "small_adaptive", "medium_adaptive",
-           "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium", "chirp_medium_adaptive")
+           "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium", "chirp_medium_adaptive", "split", "split_adaptive")
+DIRECT_LOG2_MAX = 22      # rows of more than 2^22 samples are split plans (csrc/ssfm_split.hpp): propagation, DM and field transfers -- no tables, chirp-z or strided capture
 
 
 class Capture(C.Structure):
@@ -152,10 +153,11 @@ def device_count() -> int:
     return n.value if rc == 0 else 0
 
 
-def supported_log2n(precision=C64):
+def supported_log2n(precision=C64, direct=False):
+    """(lo, hi) of log2(samples per row) a plan takes; ``direct``: of the plans whose field buffer is one line (what the chirp-z path and the transfer tables need)."""
     lo, hi = _I(0), _I(0)
     _check(load().ssfm_supported_log2n(precision, C.byref(lo), C.byref(hi)), "ssfm_supported_log2n")
-    return lo.value, hi.value
+    return lo.value, (min(hi.value, DIRECT_LOG2_MAX) if direct else hi.value)
 
 
 def _ptr(a: np.ndarray):

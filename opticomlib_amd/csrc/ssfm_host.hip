@@ -24,12 +24,14 @@
 #include "ssfm_common.hpp"
 #include "ssfm_kernels.hpp"
 #include "ssfm_medium.hpp"
+#include "ssfm_split.hpp"
 
 using namespace ssfm;
 
 namespace {
 
-constexpr int kLog2Min = 8, kLog2Max = 22;
+constexpr int kLog2Min = 8, kLog2Max = 24;      // (above 2^22: split plans, ssfm_split.hpp)
+constexpr int kLog2MaxDirect = 22;                // the two-kernel engine's own range: N1 <= 512 column points x N2 <= 8192 row points
 // C, columns per k_time tile: one 128-byte line per row segment in either precision.  (complex128 used 16 as well
 // at first: 512-thread workgroups, one per CU; with 8 the two precisions have the same workgroup shape, two per CU.)
 template <typename T> constexpr int cols_per_tile() { return sizeof(T) == 8 ? 8 : 16; }
@@ -109,6 +111,13 @@ hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {
 }
 template <typename T, int MODE, int E>
 hipError_t launch_freq_e(int N2, int nrows, hipStream_t s, const FreqArgs<T>& a) {
+    if constexpr (MODE == FM_INV_ONLY) {          // (the inverse half of a split plan's row pass: its sub-sequences are 2^20 ... 2^22 samples long)
+        switch (N2) {
+            case 4096: return launch_freq_n2<T, MODE, 4096, E>(nrows, s, a);
+            case 8192: if constexpr (E == 16) return launch_freq_n2<T, MODE, 8192, E>(nrows, s, a); else break;
+        }
+        return hipErrorInvalidValue;
+    } else
     switch (N2) {
         case 16:   return launch_freq_n2<T, MODE, 16, E>(nrows, s, a);
         case 32:   return launch_freq_n2<T, MODE, 32, E>(nrows, s, a);
@@ -127,6 +136,36 @@ template <typename T, int MODE>
 hipError_t launch_freq(int N2, int nrows, hipStream_t s, FreqArgs<T> a, int E) {
     a.rows = nrows / a.N1;
     return E == 8 ? launch_freq_e<T, MODE, 8>(N2, nrows, s, a) : launch_freq_e<T, MODE, 16>(N2, nrows, s, a);
+}
+
+template <typename T, int MODE, int R>
+hipError_t launch_split_mid_r(hipStream_t s, const SplitArgs<T>& a) {
+    constexpr int V = sizeof(T) == 4 ? 2 : 1;
+    const long long units = (long long)a.N1 * a.N2 / V;
+    hipLaunchKernelGGL((k_split_mid<T, R, MODE>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+template <typename T, int MODE>
+hipError_t launch_split_mid(int R, hipStream_t s, const SplitArgs<T>& a) {
+    switch (R) {
+        case 2:  return launch_split_mid_r<T, MODE, 2>(s, a);
+        case 4:  return launch_split_mid_r<T, MODE, 4>(s, a);
+        case 8:  return launch_split_mid_r<T, MODE, 8>(s, a);
+        case 16: return launch_split_mid_r<T, MODE, 16>(s, a);
+    }
+    return hipErrorInvalidValue;
+}
+template <typename T, bool TO_SUB>
+hipError_t launch_split_shuffle(int R, hipStream_t s, cx<T>* sub, cx<T>* nat, long long M, int rows) {
+    const dim3 grid((unsigned)((M * rows + 255) / 256));
+    switch (R) {
+        case 2:  hipLaunchKernelGGL((k_split_shuffle<T, 2, TO_SUB>), grid, dim3(256), 0, s, sub, nat, M, rows); break;
+        case 4:  hipLaunchKernelGGL((k_split_shuffle<T, 4, TO_SUB>), grid, dim3(256), 0, s, sub, nat, M, rows); break;
+        case 8:  hipLaunchKernelGGL((k_split_shuffle<T, 8, TO_SUB>), grid, dim3(256), 0, s, sub, nat, M, rows); break;
+        case 16: hipLaunchKernelGGL((k_split_shuffle<T, 16, TO_SUB>), grid, dim3(256), 0, s, sub, nat, M, rows); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 // k_small: one workgroup per row, the whole schedule in one launch.  Points per thread: 8 up to 2048 samples and for
@@ -457,12 +496,81 @@ template <typename T> struct PlanT : PlanBase {
     T* zlog = nullptr;
     int64_t zlog_cap = 0;
     bool have_op = false;
+    // ---- split plans (ssfm_split.hpp; round 6): rows of more than 2^22 samples.  `n` / `batch` / N1 / N2 below describe the SUB-SEQUENCES (n = M samples,
+    // batch = rows x R of them) that every kernel of this file works on; `n_full` / `batch_full` are what the caller sees.  The caller's field lives in
+    // `Fnat` in natural time order; F holds its sub-sequences x_a[m] = x[a + R m] while runs are in flight (`sub_valid` / `nat_valid`: which of the two
+    // is current -- k_split_shuffle converts lazily, so back-to-back runs do not pay it).
+    int split_R = 1;
+    int64_t n_full = 0;
+    int batch_full = 0;
+    cx<T>* Fnat = nullptr;
+    double2* split_twA = nullptr;      // W_N^(a k1), W_N^(a N1 k2) in double (one rounding of their product in k_split_mid)
+    double2* split_twB = nullptr;
+    cx<T>* dsplit = nullptr;           // D~ in the split order [p][k1][k2] (SM_FLY: adaptive runs, more step sizes than tables), lazily
+    bool dsplit_valid = false;
+    bool sub_valid = true, nat_valid = false;
+    bool is_split() const { return split_R > 1; }
+    T inv_n_full() const { return (T)1 / (T)n_full; }
+    // the sub-sequences are current in F (before a run)
+    int ensure_sub() {
+        if (!is_split() || sub_valid) return SSFM_OK;
+        HIP_TRY((launch_split_shuffle<T, true>(split_R, stream, F, Fnat, (long long)n, batch_full)));
+        sub_valid = true;
+        return SSFM_OK;
+    }
+    // the natural-order field is current in Fnat (before the caller looks at it)
+    int ensure_nat() {
+        if (!is_split() || nat_valid) return SSFM_OK;
+        HIP_TRY((launch_split_shuffle<T, false>(split_R, stream, F, Fnat, (long long)n, batch_full)));
+        nat_valid = true;
+        return SSFM_OK;
+    }
+    void ran() { if (is_split()) { sub_valid = true; nat_valid = false; } }      // a run has advanced F
+    // ... and a caller that holds the field's address (ssfm_field_device_ptr / ssfm_stream: `external_order`) finds the natural-order field behind the run on
+    // the plan's stream -- and may WRITE it there before the next run, which therefore starts from Fnat again
+    int publish_if_external() {
+        if (!is_split() || !external_order) return SSFM_OK;
+        if (int rc = ensure_nat()) return rc;
+        sub_valid = false;
+        return SSFM_OK;
+    }
+    cx<T>* user_field() { return is_split() ? Fnat : F; }
+    // the time-order field after a step -> `dst` (DEVICE): a z-resolved capture's snapshot
+    hipError_t put_time_order(void* dst) {
+        if (is_split()) return launch_split_shuffle<T, false>(split_R, stream, F, static_cast<cx<T>*>(dst), (long long)n, batch_full);
+        return hipMemcpyAsync(dst, F, sizeof(cx<T>) * (size_t)n * batch, hipMemcpyDeviceToDevice, stream);
+    }
+    // the row pass of a split plan: forward row transforms, the pointwise middle (twiddles, radix-R butterfly across the sub-sequences, operator, back),
+    // inverse row transforms.  `table`: exp(D~ h) / N in the split order (SM_TABLE), or nullptr: formed in the launch from D~ (SM_FLY; `s` != nullptr:
+    // the step size is the device's)
+    hipError_t split_freq(const cx<T>* table, T h, const AdaptState<T>* s, int step, int row0, int rows, hipStream_t st_) {
+        FreqArgs<T> fa = fargs(nullptr, 0, s, row0, rows > 0 ? row0 / rows : 0);         // (`s`: launches behind the end of an adaptive run find `done` and leave)
+        fa.step = step;
+        hipError_t e = launch_freq<T, FM_FWD_ONLY>(N2, N1 * rows, st_, fa, Ef);
+        if (e != hipSuccess) return e;
+        SplitArgs<T> sa;
+        sa.Y = Y + (size_t)row0 * n; sa.G = table ? table : dsplit; sa.twA = split_twA; sa.twB = split_twB; sa.st = s; sa.h = h; sa.inv_n = inv_n_full();
+        sa.step = step; sa.N1 = N1; sa.N2 = N2; sa.rows_outer = rows / split_R;
+        e = table ? launch_split_mid<T, SM_TABLE>(split_R, st_, sa) : launch_split_mid<T, SM_FLY>(split_R, st_, sa);
+        if (e != hipSuccess) return e;
+        return launch_freq<T, FM_INV_ONLY>(N2, N1 * rows, st_, fa, Ef);
+    }
+    // D~ in the split order, for SM_FLY
+    int split_fly_ready() {
+        if (dsplit_valid) return SSFM_OK;
+        if (!dsplit) HIP_TRY(hipMalloc(&dsplit, sizeof(cx<T>) * (size_t)n_full));
+        hipLaunchKernelGGL((k_make_split_table<T, 0>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)dnat, dsplit, N1, N2, split_R, (T)0, inv_n_full());
+        HIP_TRY(hipGetLastError());
+        dsplit_valid = true;
+        return SSFM_OK;
+    }
+    int no_split(const char* what) { return is_split() ? fail(SSFM_ERR_UNSUPPORTED, "%s: not for plans of more than 2^%d samples per row", what, kLog2MaxDirect) : (int)SSFM_OK; }
     // What the staging buffers hold is the PLAN's knowledge, not the caller's: tags[0] labels the linear operator in
     // dnat / dperm, tags[1 + slot] the resident transfer function of a slot.  A caller that has staged something
     // labels it (ssfm_plan_set_tag) and asks later whether it is still there (ssfm_plan_get_tag); every entry point
     // that overwrites or reuses a buffer clears its label here, so a stale label cannot survive.  0 = nothing known.
     uint64_t tags[3] = {0, 0, 0};
-    void drop_operator() { have_op = false; tags[0] = 0; dimag_valid = false; for (auto& t : tabs) t.valid = false; for (auto& t : stabs) t.valid = false; }
+    void drop_operator() { have_op = false; tags[0] = 0; dimag_valid = false; dsplit_valid = false; for (auto& t : tabs) t.valid = false; for (auto& t : stabs) t.valid = false; }
     bool timed = false;
     std::atomic<int64_t> last_launches{0};
     // what the last run really did (ssfm_last_run_info): a single-launch engine that falls back is otherwise invisible to the caller
@@ -615,6 +723,7 @@ template <typename T> struct PlanT : PlanBase {
         for (void* b : bufs) (void)hipFree(b);
         for (auto& t : tabs) (void)hipFree(t.ptr);
         for (auto& t : stabs) (void)hipFree(t.ptr);
+        (void)hipFree(Fnat); (void)hipFree(split_twA); (void)hipFree(split_twB); (void)hipFree(dsplit);
         (void)hipFree(tw_small);
         (void)hipFree(tw_chirp);
         (void)hipFree(dsmall);
@@ -652,6 +761,25 @@ template <typename T> struct PlanT : PlanBase {
     ~PlanT() override { free_all(); }
 
     int init(int dev, int64_t n_, int batch_) {
+        n_full = n_; batch_full = batch_;
+        {
+            int kf = 0;
+            while ((1ll << kf) < n_) ++kf;
+            int above = kLog2MaxDirect;
+            if (const char* e = std::getenv("SSFM_SPLIT_ABOVE")) { const int v = std::atoi(e); if (v >= kSplitLog2M && v < kLog2MaxDirect) above = v; }      // (tests: split plans of 2^21 / 2^22 samples)
+            if (kf > above) {
+                // a split plan: R sub-sequences of M = 2^20 samples per row (the size the two-kernel engine runs best at; SSFM_SPLIT_LOG2M = 21 | 22: diagnostics)
+                int lm = kSplitLog2M;
+                if (const char* e = std::getenv("SSFM_SPLIT_LOG2M")) { const int v = std::atoi(e); if (v >= 20 && v <= kLog2MaxDirect) lm = v; }
+                if (lm >= kf) lm = kf - 1;
+                while ((1 << (kf - lm)) > kSplitMaxR) ++lm;
+                split_R = 1 << (kf - lm);
+                if ((long long)batch_ * split_R > 65535) return fail(SSFM_ERR_INVALID, "batch=%d rows of 2^%d samples: too many sub-sequences", batch_, kf);
+                n_ = 1ll << lm;
+                batch_ *= split_R;
+                sub_valid = false; nat_valid = true;
+            }
+        }
         device = dev; n = n_; batch = batch_;
         int k = 0;
         while ((1ll << k) < n) ++k;
@@ -700,8 +828,8 @@ template <typename T> struct PlanT : PlanBase {
         int want = (long long)batch * n >= (1ll << 20) ? 2 : 1;
         if (const char* e = std::getenv("SSFM_LANES")) want = std::atoi(e);
         nlanes = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
-        if (nlanes > batch) nlanes = batch;
-        while (batch % nlanes) --nlanes;
+        if (nlanes > batch_full) nlanes = batch_full;
+        while (batch_full % nlanes) --nlanes;            // (a lane holds whole rows: all sub-sequences of a row of a split plan)
         lane_stream[0] = stream;
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
         for (int g = 1; g < nlanes; ++g) {
@@ -730,8 +858,17 @@ template <typename T> struct PlanT : PlanBase {
         }
         if (int rc = make_line_table(&tw1, N1, E)) return rc;
         if (int rc = make_line_table(&tw2, N2, Ef)) return rc;
-        HIP_TRY(hipMalloc(&dnat, cb * n));
+        HIP_TRY(hipMalloc(&dnat, cb * n_full));
         HIP_TRY(hipMalloc(&dperm, cb * n));
+        if (is_split()) {
+            HIP_TRY(hipMalloc(&Fnat, cb * n_full * batch_full));
+            HIP_TRY(hipMemsetAsync(Fnat, 0, cb * n_full * batch_full, stream));
+            HIP_TRY(hipMalloc(&split_twA, sizeof(double2) * (size_t)split_R * N1));
+            HIP_TRY(hipMalloc(&split_twB, sizeof(double2) * (size_t)split_R * N2));
+            const long long nt = (long long)split_R * (N1 + N2);
+            hipLaunchKernelGGL(k_make_split_twiddles, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, split_twA, split_twB, N1, N2, split_R);
+            HIP_TRY(hipGetLastError());
+        }
         if (Ef_fly != Ef) {
             if (int rc = make_line_table(&tw2_fly, N2, Ef_fly)) return rc;
             HIP_TRY(hipMalloc(&dperm_fly, cb * n));
@@ -1144,12 +1281,20 @@ template <typename T> struct PlanT : PlanBase {
         {
             const T* d = static_cast<const T*>(host);             // (re, im) pairs
             bool flat = true;
-            for (int64_t i = 1; i < n && flat; ++i) flat = std::memcmp(&d[2 * i], &d[0], sizeof(T)) == 0;
+            for (int64_t i = 1; i < n_full && flat; ++i) flat = std::memcmp(&d[2 * i], &d[0], sizeof(T)) == 0;
             op_flat_re = flat;
             op_re0 = d[0];
             dimag_valid = false;
+            dsplit_valid = false;
         }
-        HIP_TRY(hipMemcpyAsync(dnat, host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(dnat, host, sizeof(cx<T>) * n_full, hipMemcpyHostToDevice, stream));
+        if (is_split()) {           // (the operator's split-order forms are made where they are used: tables_for, split_fly_ready)
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (auto& t : tabs) t.valid = false;
+            have_op = true;
+            tags[0] = 0;
+            return SSFM_OK;
+        }
         hipLaunchKernelGGL((k_make_freq_table<T, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)dnat, dperm, N1, N2, N2 / Ef, (T)0, inv_n());
         if (dperm_fly)
@@ -1189,9 +1334,12 @@ template <typename T> struct PlanT : PlanBase {
             rr = (v + 1) % kMaxTables;
             pinned[v] = true;
             t.valid = false;
-            if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n));
+            if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n_full));
             t.kind = kind;
-            if (one_line)
+            if (is_split())
+                hipLaunchKernelGGL((k_make_split_table<T, 2>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream,
+                                   (const cx<T>*)dnat, t.ptr, N1, N2, split_R, distinct[i], inv_n_full());
+            else if (one_line)
                 hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                                    (const cx<T>*)dnat, t.ptr, 1, (int)n, (int)n / small_points<T>((int)n), distinct[i], inv_n());
             else if (kind == 1)
@@ -1250,7 +1398,8 @@ template <typename T> struct PlanT : PlanBase {
     }
 
     int copy_field_out(void* dst, bool is_device, bool wait) {
-        HIP_TRY(hipMemcpyAsync(dst, F, sizeof(cx<T>) * n * batch, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+        if (int rc = ensure_nat()) return rc;
+        HIP_TRY(hipMemcpyAsync(dst, user_field(), sizeof(cx<T>) * n * batch, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
         if (wait) HIP_TRY(hipStreamSynchronize(stream));
         return SSFM_OK;
     }
@@ -1340,7 +1489,9 @@ template <typename T> struct PlanT : PlanBase {
         // a fibre's operator has one modulus for all frequencies: 4-byte phase tables (ssfm_kernels.hpp FM_PHASE)
         // (complex128: float64 turn fractions, 8 instead of 16 bytes per frequency -- measured -2.5 % at 2^20 x 2 (39.5 against 40.5 us per step) and
         // +5 % at 2^16 x 2, where nothing hides the float64 sincos: from 2^20 samples in all)
-        const bool use_phase = use_tables && phase_tables && op_flat_re && (sizeof(T) == 8 ? n * batch >= (1ll << 20) : u16);
+        const bool use_phase = use_tables && phase_tables && op_flat_re && (sizeof(T) == 8 ? n * batch >= (1ll << 20) : u16) && !is_split();
+        if (int rc = ensure_sub()) return rc;
+        if (is_split() && !use_tables) if (int rc = split_fly_ready()) return rc;
         // plans of 2^12 ... 2^17 samples in the unit layout: the whole schedule in one launch on one XCD (ssfm_kernels.hpp k_medium).  Measured against the
         // one-workgroup-per-row kernel of the small plans (k_small): 5.4 against 6.4 us per step at 8192 samples, 5.6 against 3.5 at 4096 -- so from 8192 on
         const long long med_blocks = (long long)(N2 / cols_per_tile<T>()) * (medium_rows_split() ? 1 : batch);
@@ -1351,12 +1502,20 @@ template <typename T> struct PlanT : PlanBase {
         const bool go_small = small_sched && snapshots == nullptr && !(med_elig && n >= 8192) && cap_run == nullptr;      // (a capture run: the two-kernel engine)
         const bool go_medium = med_elig && !go_small && cap_run == nullptr;
         last_fell_back = 0;
-        last_engine = (go_small || (small_sched && snapshots != nullptr)) ? SSFM_ENGINE_SMALL : go_medium ? SSFM_ENGINE_MEDIUM : SSFM_ENGINE_TWO_KERNEL;
+        last_engine = (go_small || (small_sched && snapshots != nullptr)) ? SSFM_ENGINE_SMALL : go_medium ? SSFM_ENGINE_MEDIUM : is_split() ? SSFM_ENGINE_SPLIT : SSFM_ENGINE_TWO_KERNEL;
         if (use_tables && !go_small && !go_medium)
             if (int rc = tables_for(distinct, tabptr.data(), false, use_phase ? 1 : 0)) return rc;
         auto freq_rows = [&](T hs, int row0, int rows, hipStream_t st_) -> hipError_t {
             const int lane_ = rows > 0 ? row0 / rows : 0;
             ++last_launches;
+            if (is_split()) {
+                const cx<T>* tp = nullptr;
+                if (use_tables)
+                    for (size_t i = 0; i < distinct.size(); ++i)
+                        if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
+                last_launches += 2;
+                return split_freq(tp, hs, nullptr, 0, row0, rows, st_);
+            }
             if (use_tables) {
                 const cx<T>* tp = nullptr;
                 for (size_t i = 0; i < distinct.size(); ++i)
@@ -1525,7 +1684,7 @@ template <typename T> struct PlanT : PlanBase {
             int64_t block = (int64_t)std::min<size_t>((size_t)(nsteps + 1), std::max<size_t>(1, std::min<size_t>(free_b / 2, size_t(8) << 30) / fb));
             char* dsnap = nullptr;
             HIP_TRY(hipMalloc(&dsnap, fb * (size_t)block));
-            if (!(small_sched && block == nsteps + 1)) last_engine = SSFM_ENGINE_TWO_KERNEL;
+            if (!(small_sched && block == nsteps + 1)) last_engine = is_split() ? SSFM_ENGINE_SPLIT : SSFM_ENGINE_TWO_KERNEL;
             if (small_sched && block == nsteps + 1) {
                 // a small plan whose whole capture fits the device: the single launch writes every snapshot itself
                 hipError_t e = hipMemcpyAsync(dsnap, F, fb, hipMemcpyDeviceToDevice, stream);             // the input
@@ -1548,7 +1707,7 @@ template <typename T> struct PlanT : PlanBase {
                 return SSFM_OK;
             };
             int64_t first = 0, held = 0;                    // snapshots [first, first + held) are in dsnap
-            auto capture = [&]() -> hipError_t { return hipMemcpyAsync(dsnap + fb * held++, F, fb, hipMemcpyDeviceToDevice, stream); };
+            auto capture = [&]() -> hipError_t { return put_time_order(dsnap + fb * held++); };
             hipError_t ce = capture();
             for (int64_t s = 0; s < nsteps && ce == hipSuccess; ++s) {
                 if (held == block) { if (int rc = flush(first, held)) return rc; first += held; held = 0; }
@@ -1562,12 +1721,14 @@ template <typename T> struct PlanT : PlanBase {
             if (int rc = flush(first, held)) return rc;
             HIP_TRY(hipFree(dsnap));
         }
+        ran();
+        if (int rc = publish_if_external()) return rc;          // (a caller that orders its own work on the stream finds the natural-order field)
         HIP_TRY(hipEventRecord(ev1, stream));
         timed = true;
         if (health) {
             HIP_TRY(hipEventRecord(run_e1, stream));
             lane_check_pending = true;
-            lane_check_launches = 2 * nsteps + 1;
+            lane_check_launches = (is_split() ? 4 : 2) * nsteps + 1;
         }
         if (snapshots != nullptr) HIP_TRY(hipStreamSynchronize(stream));
         return SSFM_OK;
@@ -1633,6 +1794,7 @@ template <typename T> struct PlanT : PlanBase {
         if (nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: nsteps=%lld", (long long)nsteps);
         if ((fields_host != nullptr) != (every > 0)) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: `fields` and `every` > 0 go together");
         if (!fields_host && !scalars_host) return fail(SSFM_ERR_INVALID, "ssfm_propagate_fixed_capture: nothing to capture");
+        if (int rc = no_split("ssfm_propagate_fixed_capture")) return rc;
         if (int rc = use_device()) return rc;                          // (joins the previous capture run's helper)
         if (int rc = lane_health()) return rc;
         for (int64_t s = 0; s < nsteps; ++s)
@@ -1791,6 +1953,8 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
     int adaptive_begin_chunked(T gamma, T length, T phi_max, int single_step, int max_steps, int capture) {
+        if (int rc = ensure_sub()) return rc;
+        if (is_split()) if (int rc = split_fly_ready()) return rc;
         if (int rc = upload_adapt_state(gamma, length, phi_max, max_steps)) return rc;
         if (!single_step) {
             hipLaunchKernelGGL(k_absmax<T>, dim3(1024), dim3(256), 0, stream, (const cx<T>*)F, (long long)n * batch, st);
@@ -1826,7 +1990,7 @@ template <typename T> struct PlanT : PlanBase {
         int cus = 0;
         if (col_blocks > kAdaptSlots && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || col_blocks > 2ll * cus || col_blocks % 64 != 0))
             fused_max = kAdaptSlots;                              // (the whole grid must be resident at once: two workgroups per CU)
-        ar.fused = fused_ok && !capture && (N1 == 128 || N1 == 256) && col_blocks <= fused_max;
+        ar.fused = fused_ok && !capture && (N1 == 128 || N1 == 256) && col_blocks <= fused_max && !is_split();
         if (ar.fused) {
             const size_t fb = sizeof(cx<T>) * n * batch;
             if (!fused_backup) HIP_TRY(hipMalloc(&fused_backup, fb));
@@ -1932,9 +2096,9 @@ template <typename T> struct PlanT : PlanBase {
             return est < 2 ? 2 : (est > kAdaptChunkMax ? kAdaptChunkMax : est);
         };
         int chunk = snap ? 1 : estimate();
-        const bool fly_imag = fly_imag_ready();
+        const bool fly_imag = !is_split() && fly_imag_ready();
         while (!ar.now.done && ar.now.steps - first_step < budget) {
-            last_engine = ar.fused ? SSFM_ENGINE_ADAPT_FUSED : SSFM_ENGINE_ADAPT_3;
+            last_engine = is_split() ? SSFM_ENGINE_SPLIT_ADAPT : ar.fused ? SSFM_ENGINE_ADAPT_FUSED : SSFM_ENGINE_ADAPT_3;
             if ((int64_t)chunk > budget - (ar.now.steps - first_step)) chunk = (int)(budget - (ar.now.steps - first_step));
             for (int i = 0; i < chunk; ++i, ++ar.step) {
                 TimeArgs<T> tb = targs(ar.gamma, 0, 0, st), te = tb;
@@ -1947,6 +2111,10 @@ template <typename T> struct PlanT : PlanBase {
                 else HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E)));
                 FreqArgs<T> fa = fargs_fly(0, st);
                 fa.step = ar.step;
+                if (is_split()) {
+                    HIP_TRY(split_freq(nullptr, 0, st, ar.step, 0, batch, stream));
+                    last_launches += 2;
+                } else
                 if (fly_imag) {           // (half the operator's bytes: 23.7 -> 22.6 us per step at 2^20 x 2, the same bits)
                     fa.tab = reinterpret_cast<const cx<T>*>(dimag_fly); fa.amp = op_re0;
                     HIP_TRY((launch_freq<T, FM_FLY_IM>(N2, nrows, stream, fa, Ef_fly)));
@@ -1981,8 +2149,10 @@ template <typename T> struct PlanT : PlanBase {
                 chunk = estimate();
                 continue;
             }
-            if (snap && ar.now.steps == before + 1)          // (chunk = 1: the step just launched was really taken)
+            if (snap && ar.now.steps == before + 1) {        // (chunk = 1: the step just launched was really taken)
+                ran();
                 if (int rc = copy_field_out(snap + fb * (size_t)(before - first_step), false, true)) return rc;
+            }
             if (!snap && !ar.now.done) chunk = estimate();       // do not queue far beyond the end
         }
         if (steps_total) *steps_total = ar.now.steps;
@@ -2002,6 +2172,8 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY((launch_time<T, TM_UNPACK>(N1, batch, stream, targs(ar.gamma, 0, 0, nullptr), E)));      // Y buffer -> time-order field
             ++last_launches;
         }
+        if (ar.now.steps > 0) ran();
+        if (int rc = publish_if_external()) return rc;
         HIP_TRY(hipEventRecord(ev1, stream));
         timed = true;
         if (steps_out) *steps_out = ar.now.steps;
@@ -2032,19 +2204,27 @@ template <typename T> struct PlanT : PlanBase {
         if (int rc = use_device()) return rc;
         const int nrows = N1 * batch;
         if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
-        cx<T>* hperm = scratch;   // n entries are enough
+        cx<T>* hperm = scratch;   // n entries are enough (a split plan: n_full <= n * batch)
         // dnat is a staging buffer: the propagator's own D~ must be re-set after a DM call
-        HIP_TRY(hipMemcpyAsync(dnat, H_host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(dnat, H_host, sizeof(cx<T>) * n_full, hipMemcpyHostToDevice, stream));
         drop_operator();
+        if (int rc = ensure_sub()) return rc;
+        if (is_split())
+            hipLaunchKernelGGL((k_make_split_table<T, 1>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)dnat, hperm, N1, N2, split_R, (T)0, inv_n_full());
+        else
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)dnat, hperm, N1, N2, N2 / Ef, (T)0, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev0, stream));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        if (is_split()) HIP_TRY(split_freq(hperm, 0, nullptr, 0, 0, batch, stream));
+        else
         HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), Ef)));
         HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        ran();
+        if (int rc = publish_if_external()) return rc;
         HIP_TRY(hipEventRecord(ev1, stream));
-        last_launches = 3;
+        last_launches = is_split() ? 5 : 3;
         timed = true;
         HIP_TRY(hipStreamSynchronize(stream));   // H_host may be released by the caller
         return SSFM_OK;
@@ -2060,19 +2240,27 @@ template <typename T> struct PlanT : PlanBase {
             hnat = dnat;
             drop_operator();
         }
-        const double val = 1.0 / ((double)n * dt_s);
+        const double val = 1.0 / ((double)n_full * dt_s);
+        if (int rc = ensure_sub()) return rc;
+        if (is_split())
+            hipLaunchKernelGGL(k_make_split_dm_table<T>, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, hperm, hnat, N1, N2, split_R, val, D_s2, inv_n_full());
+        else
         hipLaunchKernelGGL(k_make_dm_table<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            hperm, hnat, N1, N2, N2 / Ef, val, D_s2, inv_n());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev0, stream));
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        if (is_split()) HIP_TRY(split_freq(hperm, 0, nullptr, 0, 0, batch, stream));
+        else
         HIP_TRY((launch_freq<T, FM_TABLE>(N2, nrows, stream, fargs(hperm, 0, nullptr), Ef)));
         HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
+        ran();
+        if (int rc = publish_if_external()) return rc;
         HIP_TRY(hipEventRecord(ev1, stream));
-        last_launches = 3;
+        last_launches = is_split() ? 5 : 3;
         timed = true;
         if (H_out) {
-            HIP_TRY(hipMemcpyAsync(H_out, hnat, sizeof(cx<T>) * n, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(H_out, hnat, sizeof(cx<T>) * n_full, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
         return SSFM_OK;
@@ -2082,6 +2270,7 @@ template <typename T> struct PlanT : PlanBase {
     // host synchronisation: the building block of the chirp-z path for sizes that are not powers of two.
     int transfer_table(const void* H_host, int slot) {
         if (slot < 0 || slot > 1) return fail(SSFM_ERR_INVALID, "ssfm_transfer_table: slot %d", slot);
+        if (int rc = no_split("ssfm_transfer_table")) return rc;
         if (int rc = use_device()) return rc;
         if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
         HIP_TRY(hipMemcpyAsync(dnat, H_host, sizeof(cx<T>) * n, hipMemcpyHostToDevice, stream));      // dnat = staging
@@ -2099,6 +2288,7 @@ template <typename T> struct PlanT : PlanBase {
     // `io` (nullable; complex128 plans): a chirp-z step's two ends folded into the first and the last launch (ChirpIO, ssfm_kernels.hpp) -- the caller's
     // field in, the caller's field out, the plan's own field buffer untouched.
     int apply_tables_mul(const void* mul_dev, const ssfm::ChirpStepIO* io = nullptr) {
+        if (int rc = no_split("ssfm_apply_tables_mul")) return rc;
         if (!xfer_tab[0] || !xfer_tab[1]) return fail(SSFM_ERR_STATE, "ssfm_apply_tables_mul: slots 0 and 1 must hold tables");
         if (u16) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_apply_tables_mul: not for plans in the 16-byte-unit layout");
         if (!mul_dev) return fail(SSFM_ERR_INVALID, "ssfm_apply_tables_mul: NULL table");
@@ -2129,6 +2319,7 @@ template <typename T> struct PlanT : PlanBase {
     // rotation of this step and the first of the next in one (the padding set to zero first) -- instead of the five of ssfm_chirp_step; the caller
     // multiplies by conj(c) when the run is over.
     int chirp_line_run(const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma_d, int64_t keep) {
+        if (int rc = no_split("chirp-z")) return rc;
         if (!xfer_tab[0] || !xfer_tab[1]) return fail(SSFM_ERR_STATE, "ssfm_chirp_line_run: slots 0 and 1 must hold tables");
         if (u16) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_line_run: not for plans in the 16-byte-unit layout");
         if (!mul || !which || !hs || nsteps < 1 || keep < 2 || keep > n) return fail(SSFM_ERR_INVALID, "ssfm_chirp_line_run: bad arguments");
@@ -2158,6 +2349,7 @@ template <typename T> struct PlanT : PlanBase {
     // A fixed-step chirp-z run of a field of nn <= n / 2 samples per row in ONE launch (k_small_chirp); SSFM_ERR_UNSUPPORTED (nothing launched) when the
     // plan is not a complex128 plan of the one-workgroup-per-row engine.
     int chirp_small(void* A, const void* chirp, const void* Dt, int64_t nn, double gamma, const double* hs, int64_t nsteps) {
+        if (int rc = no_split("chirp-z")) return rc;
         if (!small || !tw_small || n > 4096) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_small: a plan of 256 ... 4096 samples is needed");
         if (!A || !chirp || !Dt || !hs || nn < 2 || 2 * nn - 1 > n || nsteps < 1 || nsteps > 0x7fffffff) return fail(SSFM_ERR_INVALID, "ssfm_chirp_small: bad arguments");
         for (int64_t s = 0; s < nsteps; ++s)
@@ -2243,6 +2435,7 @@ template <typename T> struct PlanT : PlanBase {
     // Can this plan run the one-launch chirp-z engine of 2048 < nn <= n / 2 samples (chirp_medium / chirp_medium_adapt below)?  If so, slots 0 and 1
     // hold the two convolutions' transfer functions for that length when this returns.
     int chirp_medium_tables(int64_t nn) {
+        if (int rc = no_split("chirp-z")) return rc;
         if constexpr (sizeof(T) != 4) { (void)nn; return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_medium: complex64 plans only"); }
         else {
         const long long blocks = (long long)(N2 / cols_per_tile<T>()) * batch;
@@ -2438,6 +2631,7 @@ template <typename T> struct PlanT : PlanBase {
     }
     // slot <- fft(field): the field itself becomes a resident transfer function (row 0; the field is consumed)
     int table_from_field(int slot) {
+        if (int rc = no_split("ssfm_table_from_field")) return rc;
         if (slot < 0 || slot > 1) return fail(SSFM_ERR_INVALID, "ssfm_table_from_field: slot %d", slot);
         if (int rc = use_device()) return rc;
         if (!xfer_tab[slot]) HIP_TRY(hipMalloc(&xfer_tab[slot], sizeof(cx<T>) * n));
@@ -2461,6 +2655,7 @@ template <typename T> struct PlanT : PlanBase {
         return SSFM_OK;
     }
     int apply_table(int slot) {
+        if (int rc = no_split("ssfm_apply_table")) return rc;
         if (slot < 0 || slot > 1 || !xfer_tab[slot]) return fail(SSFM_ERR_STATE, "ssfm_apply_table: slot %d holds no table", slot);
         if (int rc = use_device()) return rc;
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(0, 0, 0, nullptr), E)));
@@ -2471,6 +2666,7 @@ template <typename T> struct PlanT : PlanBase {
     }
 
     int debug_fft(void* dst) {
+        if (int rc = no_split("ssfm_debug")) return rc;
         if (int rc = use_device()) return rc;
         const int nrows = N1 * batch;
         if (!scratch) HIP_TRY(hipMalloc(&scratch, sizeof(cx<T>) * n * batch));
@@ -2503,7 +2699,8 @@ struct ssfm_plan {
 namespace {
 template <typename PT> static int set_field_impl(PT* P_, const void* src, int is_device) {
     if (int rc = P_->use_device()) return rc;
-    HIP_TRY(hipMemcpyAsync(P_->F, src, sizeof(*P_->F) * P_->n * P_->batch, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, P_->stream));
+    HIP_TRY(hipMemcpyAsync(P_->user_field(), src, sizeof(*P_->F) * P_->n * P_->batch, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, P_->stream));
+    if (P_->is_split()) { P_->nat_valid = true; P_->sub_valid = false; }
     if (!is_device) HIP_TRY(hipStreamSynchronize(P_->stream));
     return SSFM_OK;
 }
@@ -2550,6 +2747,7 @@ template <typename PT> static bool mark_external(PT* P_) {
     P_->external_order = true;
     // (a capture run's helper thread copies the end field from F on a stream of its own: it is joined here, before the caller can order anything that
     // writes F behind the run -- ADVICE r5: the snapshots' validity "after any later call on the plan" includes these two calls)
+    if (P_->is_split() && (P_->use_device() != SSFM_OK || P_->publish_if_external() != SSFM_OK)) return false;      // (the natural-order field, queued on the plan's stream; the caller may write it)
     if (!P_->medium_pending && !P_->cap_pending) return true;
     return P_->use_device() == SSFM_OK;               // (joins the capture helper, resolves a pending one-launch run)
 }
@@ -2639,9 +2837,9 @@ int ssfm_get_field(ssfm_plan* plan, void* dst, int is_device) {
 }
 void* ssfm_field_device_ptr(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return mark_external(P_) ? P_->F : nullptr; }
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return mark_external(P_) ? P_->user_field() : nullptr; }
     auto* P_ = static_cast<PlanT<double>*>(plan->impl);
-    return mark_external(P_) ? P_->F : nullptr;
+    return mark_external(P_) ? P_->user_field() : nullptr;
 }
 
 int ssfm_propagate_fixed(ssfm_plan* plan, double gamma, const void* h_schedule, int64_t nsteps, void* snapshots) {
@@ -2743,17 +2941,18 @@ void* plan_stream(ssfm_plan* plan) {
 }
 void* plan_field(ssfm_plan* plan) {
     if (!plan || !plan->impl) return nullptr;
-    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return join_helpers(P_) ? (void*)P_->F : nullptr; }
+    // (the library's other units work on the field buffer as a line of `plan_length` points: not for split plans, whose F holds sub-sequences)
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); return join_helpers(P_) && !P_->is_split() ? (void*)P_->F : nullptr; }
     auto* P_ = static_cast<PlanT<double>*>(plan->impl);
-    return join_helpers(P_) ? (void*)P_->F : nullptr;
+    return join_helpers(P_) && !P_->is_split() ? (void*)P_->F : nullptr;
 }
 int64_t plan_length(ssfm_plan* plan, int* batch, int* precision) {
     if (!plan || !plan->impl) return 0;
     if (precision) *precision = plan->impl->precision;
-    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); if (batch) *batch = P_->batch; return P_->n; }
+    if (plan->impl->precision == SSFM_C64) { auto* P_ = static_cast<PlanT<float>*>(plan->impl); if (batch) *batch = P_->batch_full; return P_->n_full; }
     auto* P_ = static_cast<PlanT<double>*>(plan->impl);
-    if (batch) *batch = P_->batch;
-    return P_->n;
+    if (batch) *batch = P_->batch_full;
+    return P_->n_full;
 }
 int plan_workspace(ssfm_plan* plan, int slot, size_t bytes, void** out) { WITH_PLAN(plan, P_->workspace(slot, bytes, out)); }
 int plan_chirp_step(ssfm_plan* plan, const void* mul_dev, const ChirpStepIO* io) {

@@ -1279,7 +1279,9 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(cx<T>* Y, T*
 // 8: the table is 16 of the 96 bytes a dual-pol sample*step moves); the kernel forms amp * (cos, sin) itself.
 // (FM_FLY_IM: FM_FLY for an operator whose real part is the same number at every frequency -- a fibre's -alpha/2 -- with `tab` holding the IMAGINARY
 // parts only, four per 16 bytes in FM_PHASE's order, and `amp` the real part: half the operator's bytes, the same arithmetic)
-enum FreqMode { FM_TABLE = 0, FM_FLY = 1, FM_FWD_ONLY = 2, FM_PHASE = 3, FM_FLY_IM = 4 };
+enum FreqMode { FM_TABLE = 0, FM_FLY = 1, FM_FWD_ONLY = 2, FM_PHASE = 3, FM_FLY_IM = 4, FM_INV_ONLY = 5 };
+// (FM_FWD_ONLY: the plan's layout in, the forward row transform, the PLAIN transposed spectrum out; FM_INV_ONLY, round 6: the plain transposed spectrum in,
+// the unnormalised inverse row transform, the plan's layout out -- the two halves of a row pass around k_split_mid, ssfm_split.hpp)
 
 template <typename T> struct FreqArgs {
     cx<T>* F;
@@ -1454,7 +1456,8 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     };
     if constexpr (EARLY_PHASE) load_phases();
     if constexpr (EARLY_FLY) load_table();
-    if (U16) {
+    constexpr bool INV_ONLY = MODE == FM_INV_ONLY;
+    if (U16 && !INV_ONLY) {
         // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
         if constexpr (PK && sizeof(T) == 4) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Frow, 0, N2 * (int)sizeof(cx<T>), 0x00020000);
@@ -1479,8 +1482,9 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     cx<T>* ldsT = lds + (fft_nstages(N2, E) > 1 ? ROWS * row_lds_elems(N2, E) : 0);
     line_twiddles_issue_regs<T, N2, E>(tw, j, a.tw2);
     if constexpr (MODE == FM_TABLE) load_table();
-    if (FLY && a.st != nullptr) {
+    if ((FLY || MODE == FM_FWD_ONLY || MODE == FM_INV_ONLY) && a.st != nullptr) {
         // (read after the row and the operator have been asked for: the state was written by the previous launch, a ~2 us miss)
+        // (the two halves of a split plan's row pass: launches queued behind the end of an adaptive run leave the field alone, like every other kernel)
         const StepState<T> S = a.st->cur[a.step & 1];
         if (S.done || a.st->error != 0u) return;             // (error: see k_time<TM_MID_A>)
         h = S.h;
@@ -1515,15 +1519,17 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     }
     if (fft_tw_lds_entries(N2, E) > 0) __syncthreads();
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
-    if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, -1, 0, RI>(v, lds, 0, j, idx, tw);
+    if (!SSFM_ABL_NO_FFT && !INV_ONLY) fft_line<T, N2, E, -1, 0, RI>(v, lds, 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
 #pragma unroll
         for (int t = 0; t < E; ++t) pass_store<PK>(&Frow[j + t * Q], v[t]);
         return;
     }
     SSFM_STAMP(3);
+    if constexpr (!INV_ONLY) {
 #pragma unroll
     for (int t = 0; t < E; ++t) v[t] = cmul(v[t], m[t]);
+    }
     SSFM_STAMP(4);
     if (!SSFM_ABL_NO_FFT) fft_line<T, N2, E, +1, (fft_nstages(N2, E) == 1 ? 0 : 1), RI>(v, lds, 0, j, idx, tw);
     SSFM_STAMP(5);

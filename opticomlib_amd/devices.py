@@ -88,14 +88,15 @@ def _is_fast_size(n: int, precision: int) -> bool:
 
 
 def _check_size(n: int, precision: int):
-    """Any length from 2 up to 2^21 samples per polarisation runs on the GPU: powers of two in [2^8, 2^22] through
-    the fused engine, every other length through the chirp-z path on a power-of-two plan of >= 2n - 1 points."""
+    """Any length from 2 up to 2^21 samples per polarisation runs on the GPU, and powers of two up to 2^24: powers of two in [2^8, 2^22] through
+    the fused engine, 2^23 and 2^24 as split plans (round 6), every other length through the chirp-z path on a power-of-two plan of >= 2n - 1 <= 2^22 points."""
     if _is_fast_size(n, precision):
         return
-    _, hi = _lib.supported_log2n(_lib.C128)
+    _, hi = _lib.supported_log2n(_lib.C128, direct=True)
+    _, top = _lib.supported_log2n(_lib.C128)
     if n < 2 or 2 * n - 1 > (1 << hi):
         raise ValueError(
-            f"the MI355X fibre path takes 2 ... 2^{hi - 1} samples per polarisation (powers of two up to 2^{hi}), "
+            f"the MI355X fibre path takes 2 ... 2^{hi - 1} samples per polarisation (powers of two up to 2^{top}), "
             f"got {n} (there is no CPU fallback)")
 
 
@@ -329,7 +330,7 @@ def _fourier(obj, domain, shift=False):
     shape = tuple(raws[0].shape)
     n = shape[-1]
     rows = 1 if len(shape) == 1 else shape[0]
-    _, hi = _lib.supported_log2n(_lib.C128)
+    _, hi = _lib.supported_log2n(_lib.C128, direct=True)
     if n < 2 or 2 * n - 1 > (1 << hi):
         raise ValueError(f"the device transform takes 2 ... 2^{hi - 1} samples per row, got {n} (there is no CPU fallback)")
     single = all(np.dtype(a.dtype) in (np.dtype(np.complex64), np.dtype(np.float32)) for a in raws)   # NumPy >= 2 keeps single precision
@@ -725,7 +726,15 @@ def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, 
         hs, z = step_schedule(length, h, prec)
         steps = hs.size
         snaps = None
-        if return_steps and every is not None and steps:
+        if return_steps and every is not None and steps and n > (1 << _lib.DIRECT_LOG2_MAX):
+            # a split plan (more than 2^22 samples per row) has no capture beside the run: `every` steps per call, the field read back in between
+            k = _every_index(steps, every)
+            fields = [plan.get_field()]
+            for a0, a1 in zip(k[:-1], k[1:]):
+                plan.propagate_fixed(gamma, hs[a0:a1])
+                fields.append(plan.get_field())
+            snaps, z, every = np.stack(fields), np.asarray(z)[k], None
+        elif return_steps and every is not None and steps:
             cap = plan.propagate_fixed_capture(gamma, hs, every=every)
             snaps, z, every = cap["fields"], np.asarray(z)[cap["steps"]], None              # (thinned already)
         elif return_steps:
@@ -1205,7 +1214,7 @@ def _upfir_device(bits, h, up: int, dev: int, spec=None) -> "_lib.DeviceArray":
         taps, cplx = spec[0][1], spec[1]
     full = n + taps - 1
     M = 1 << max(8, (full - 1).bit_length())
-    lo, hi = _lib.supported_log2n(_lib.C128)
+    lo, hi = _lib.supported_log2n(_lib.C128, direct=True)
     if M > (1 << hi):
         raise ValueError(f"DAC: {bits.size} bits x {up} samples with a {taps}-tap pulse exceed the device path (2^{hi} points)")
     plan = get_plan(M, 1, _lib.C128, dev)

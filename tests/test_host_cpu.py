@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.ssfm_abi_version() == 3
-    assert _lib.supported_log2n(_lib.C64) == (8, 22)
+    assert _lib.supported_log2n(_lib.C64) == (8, 24) and _lib.supported_log2n(_lib.C64, direct=True) == (8, 22)
 
 
 def test_no_cpu_fallback_without_device():
@@ -60,7 +60,9 @@ def test_unsupported_size_raises_value_error():
             devices._check_size(n, _lib.C64)
     with pytest.raises(ValueError, match="samples per polarisation"):
         devices._check_size(1, _lib.C64)
-    for n in (2, 3, 64, 255, 256, 3000, 100003, 1 << 21, 1 << 22):
+    with pytest.raises(ValueError, match="samples per polarisation"):
+        devices._check_size(1 << 25, _lib.C64)
+    for n in (2, 3, 64, 255, 256, 3000, 100003, 1 << 21, 1 << 22, 1 << 23, 1 << 24):          # (2^23, 2^24: split plans, round 6)
         devices._check_size(n, _lib.C64)                            # accepted
     assert devices._is_fast_size(4096, _lib.C64) and not devices._is_fast_size(3000, _lib.C64) and not devices._is_fast_size(128, _lib.C64)
 
@@ -370,7 +372,7 @@ def test_every_entry_point_the_documents_name_exists():
         text = open(os.path.join(ROOT, name)).read()
         for m in re.finditer(r"\b(ssfm_[a-z0-9_]+)\b", text):
             w = m.group(1)
-            if w in known or w.endswith("_") or w in ("ssfm_amd", "ssfm_host", "ssfm_kernels", "ssfm_common", "ssfm_medium", "ssfm_numpy"):
+            if w in known or w.endswith("_") or w in ("ssfm_amd", "ssfm_host", "ssfm_kernels", "ssfm_common", "ssfm_medium", "ssfm_numpy", "ssfm_split"):
                 continue
             line = text[text.rfind("\n", 0, m.start()) + 1: text.find("\n", m.end())]
             para = text[max(0, m.start() - 600): m.end() + 300]
