@@ -168,6 +168,24 @@ SSFM_API int ssfm_adaptive_begin(ssfm_plan* plan, double gamma, double length, d
 SSFM_API int ssfm_adaptive_run(ssfm_plan* plan, int64_t budget, void* snapshots, int64_t* steps_total, int* done);
 SSFM_API int ssfm_adaptive_finish(ssfm_plan* plan, int64_t* steps_out, double* z_out);
 
+/* A z-resolved capture of an ADAPTIVE run that keeps the run's own engine (round 6; the reference's consumer of return_steps calls FIBER with h = None,
+ * devices.py:2342).  Between ssfm_adaptive_begin(capture = 0) and the first ssfm_adaptive_run(snapshots = NULL): the field after every `every`-th step
+ * (every > 0), or after the steps of an ascending list of step numbers (`steps`, 1-based; e.g. the steps that first reach given z positions, taken from the z
+ * log of a run of the same field -- an adaptive run repeats bit for bit), into `fields`: HOST memory (page-locked for the transfers to run beside the
+ * kernels) for `capacity` snapshots of batch x n complex values.  The input and the end field are not among them (ssfm_get_field before and after).  A capture
+ * step adds ONE launch to the run (the step's time-order field into a ring of plan-owned device blocks); the snapshots of a chunk of queued steps travel
+ * while the next chunk runs.  `taken[k]` = step number of snapshot k, `*n_taken` = their count: both valid after ssfm_adaptive_finish. */
+typedef struct ssfm_adaptive_capture {
+    int64_t every;
+    const int64_t* steps;
+    int64_t n_steps;
+    void* fields;
+    int64_t capacity;
+    int64_t* taken;
+    int64_t* n_taken;
+} ssfm_adaptive_capture;
+SSFM_API int ssfm_adaptive_set_capture(ssfm_plan* plan, const ssfm_adaptive_capture* cap);
+
 /* out = ifft(fft(field) * H) on every row; H complex, length n, natural FFT order, HOST.
  * (reference DM, devices.py:1027-1029) */
 SSFM_API int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host);

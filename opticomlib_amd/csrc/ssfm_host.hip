@@ -1549,6 +1549,7 @@ template <typename T> struct PlanT : PlanBase {
             CapRun* const cr = cap_run;
             const bool snaps = cr && cr->every > 0;
             auto body = [&]() -> int {
+                // (round 6 A/B: starting lane 1 of a complex128 run 5 ... 40 us late changes nothing -- 38.6-39.4 against 38.6-38.9 us per step, profiles/r06_c1_ab.txt)
                 TimeArgs<T> tb = targs(gamma, 0, h[0] * half, nullptr, g * rows, g);
                 if (cr) tb.scal = cr->scal_at(0, g * rows);
                 ++last_launches;
@@ -1894,6 +1895,68 @@ template <typename T> struct PlanT : PlanBase {
         int single_step = 0;           // the single-launch kernel (budget covers the run) and the chunked engine
         T phi_max = 0;
     } ar;
+    // ---- z-resolved capture of an adaptive run that keeps the run's engine (ssfm_adaptive_set_capture, round 6).  The reference's own consumer calls FIBER with
+    // h = None and return_steps (devices.py:2342); ssfm_adaptive_run(snapshots) reproduces that with three launches per step and a host wait per step.  Here the run
+    // keeps its engine (two launches per step, fused, where the plan has it) and a capture step ADDS a launch: k_time<TM_END> behind the step's row pass reads
+    // the half-transformed field and writes that step's time-order field into a slot of a ring of plan-owned device blocks (as ssfm_propagate_fixed_capture does);
+    // the step number is the host's when it enqueues, the step SIZE the device's (cur[step & 1]: what the fused column launch behind it uses), a launch queued
+    // behind the end of the run finds `done` and leaves.  An adaptive run is queued in chunks with a look at the state in between (that look exists anyway):
+    // a chunk's snapshots go to one half of the ring and travel to the host on a stream of their own while the next chunk runs into the other half.
+    struct AdaptCap {
+        bool on = false;
+        int64_t every = 0;
+        std::vector<int64_t> list;     // or: ascending step numbers (1-based: the field AFTER step s)
+        size_t next_in_list = 0;
+        char* host = nullptr;
+        int64_t capacity = 0;
+        int64_t* taken = nullptr;      // step number of every snapshot written
+        int64_t* n_taken = nullptr;
+        int64_t count = 0;             // snapshots written to the host buffer so far (or queued for it)
+        int half_slots = 0;
+        int chunk_no = 0;
+    } acap;
+    bool acap_wants(int64_t after) {
+        if (!acap.on) return false;
+        if (acap.every > 0) return after % acap.every == 0;
+        while (acap.next_in_list < acap.list.size() && acap.list[acap.next_in_list] < after) ++acap.next_in_list;
+        return acap.next_in_list < acap.list.size() && acap.list[acap.next_in_list] == after;
+    }
+    int adaptive_set_capture(int64_t every, const int64_t* steps, int64_t n_steps, void* fields_host, int64_t capacity, int64_t* taken, int64_t* n_taken) {
+        if (!ar.active) return fail(SSFM_ERR_STATE, "ssfm_adaptive_set_capture: call ssfm_adaptive_begin first");
+        if (ar.step != 0 || (!ar.deferred && ar.now.steps != 0)) return fail(SSFM_ERR_STATE, "ssfm_adaptive_set_capture: the run has started");
+        if ((every > 0) == (steps != nullptr && n_steps > 0)) return fail(SSFM_ERR_INVALID, "ssfm_adaptive_set_capture: either a stride or a list of step numbers");
+        if (!fields_host || capacity < 1 || !taken || !n_taken) return fail(SSFM_ERR_INVALID, "ssfm_adaptive_set_capture: NULL argument");
+        if (int rc = no_split("ssfm_adaptive_set_capture")) return rc;
+        if (int rc = use_device()) return rc;
+        acap = AdaptCap();
+        acap.on = true; acap.every = every > 0 ? every : 0;
+        if (every <= 0) {
+            acap.list.assign(steps, steps + n_steps);
+            for (size_t i = 0; i < acap.list.size(); ++i)
+                if (acap.list[i] < 1 || (i && acap.list[i] <= acap.list[i - 1])) { acap.on = false; return fail(SSFM_ERR_INVALID, "ssfm_adaptive_set_capture: step numbers must ascend from 1"); }
+        }
+        acap.host = static_cast<char*>(fields_host); acap.capacity = capacity; acap.taken = taken; acap.n_taken = n_taken;
+        *n_taken = 0;
+        const size_t fb = sizeof(cx<T>) * (size_t)n * batch;
+        // the ring: two halves of up to 32 snapshots, 1 GiB in all at most
+        int half = (int)std::max<size_t>(1, std::min<size_t>(32, (size_t(512) << 20) / fb));
+        acap.half_slots = half;
+        const size_t need = fb * (size_t)half * 2;
+        if (cap_block_bytes * (size_t)cap_nblocks < need) {
+            (void)hipFree(cap_blocks); cap_blocks = nullptr; cap_block_bytes = 0; cap_nblocks = 0;
+            HIP_TRY(hipMalloc(&cap_blocks, need));
+            cap_block_bytes = need; cap_nblocks = 1;
+        }
+        if (!cap_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&cap_ev_in, hipEventDisableTiming));
+        }
+        if (ar.deferred) {            // (a small plan: the capture needs the launch-per-pass engine)
+            const AdaptRun keep = ar;
+            if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
+        }
+        return SSFM_OK;
+    }
 
     int adaptive_begin(double gamma_d, double length, double phi_max, int single_step, int64_t max_steps, int capture) {
         if (!have_op) return fail(SSFM_ERR_STATE, "ssfm_propagate_adaptive: call ssfm_set_linear_operator first");
@@ -1908,6 +1971,7 @@ template <typename T> struct PlanT : PlanBase {
         last_launches = 0;
         last_fell_back = 0;
         last_engine = SSFM_ENGINE_NONE;
+        acap.on = false;
         HIP_TRY(hipEventRecord(ev0, stream));
         // (4096 x 2: the one-XCD engine, 8.1 us per step, before the one-workgroup kernel that holds both rows, 10.4)
         bool med_adapt = false;
@@ -2097,9 +2161,18 @@ template <typename T> struct PlanT : PlanBase {
         };
         int chunk = snap ? 1 : estimate();
         const bool fly_imag = !is_split() && fly_imag_ready();
+        if (acap.on && snap) return fail(SSFM_ERR_STATE, "ssfm_adaptive_run: either ssfm_adaptive_set_capture or `snapshots`");
         while (!ar.now.done && ar.now.steps - first_step < budget) {
             last_engine = is_split() ? SSFM_ENGINE_SPLIT_ADAPT : ar.fused ? SSFM_ENGINE_ADAPT_FUSED : SSFM_ENGINE_ADAPT_3;
             if ((int64_t)chunk > budget - (ar.now.steps - first_step)) chunk = (int)(budget - (ar.now.steps - first_step));
+            // a capture run: this chunk's snapshots go to half (chunk_no & 1) of the ring, whose transfers of two chunks ago are waited for ON THE HOST
+            std::vector<int64_t> chunk_caps;
+            char* ring_half = nullptr;
+            if (acap.on) {
+                if (acap.every > 0 && (int64_t)chunk > acap.every * acap.half_slots) chunk = (int)(acap.every * acap.half_slots);
+                if (acap.chunk_no >= 2) HIP_TRY(hipStreamSynchronize(cap_stream));
+                ring_half = cap_blocks + fb * (size_t)acap.half_slots * (size_t)(acap.chunk_no & 1);
+            }
             for (int i = 0; i < chunk; ++i, ++ar.step) {
                 TimeArgs<T> tb = targs(ar.gamma, 0, 0, st), te = tb;
                 tb.step = te.step = ar.step;
@@ -2120,6 +2193,15 @@ template <typename T> struct PlanT : PlanBase {
                     HIP_TRY((launch_freq<T, FM_FLY_IM>(N2, nrows, stream, fa, Ef_fly)));
                 } else
                 HIP_TRY((launch_freq<T, FM_FLY>(N2, nrows, stream, fa, Ef_fly)));
+                if (acap.on && acap_wants((int64_t)ar.step + 1) && acap.count + (int64_t)chunk_caps.size() < acap.capacity) {
+                    // the capture step's extra launch: this step's time-order field into a ring slot (the step size is the device's: cur[step & 1])
+                    TimeArgs<T> tc = te;
+                    tc.F = reinterpret_cast<cx<T>*>(ring_half + fb * chunk_caps.size());
+                    HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, tc, E)));
+                    ++last_launches;
+                    chunk_caps.push_back((int64_t)ar.step + 1);
+                    if ((int)chunk_caps.size() >= acap.half_slots) chunk = i + 1;          // (the half is full: look at the state, send it)
+                }
                 if (ar.fused) HIP_TRY((launch_time<T, TM_MID_A>(N1, batch, stream, te, E)));
                 else if (ar.tile_private) HIP_TRY((launch_time<T, TM_END_Y>(N1, batch, stream, te, E)));
                 else HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, te, E)));
@@ -2138,9 +2220,20 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipStreamSynchronize(stream));
             ar.now = adapt_look->now;
             const unsigned gave_up = adapt_look->gave_up;
+            if (acap.on && !(ar.fused && gave_up)) {
+                // the chunk has run (the look above waited for it): its snapshots of steps really taken leave for the host beside the next chunk
+                for (size_t k = 0; k < chunk_caps.size(); ++k) {
+                    if (chunk_caps[k] > (int64_t)ar.now.steps) break;                       // (queued behind the end of the run: never written)
+                    HIP_TRY(hipMemcpyAsync(acap.host + fb * (size_t)acap.count, ring_half + fb * k, fb, hipMemcpyDeviceToHost, cap_stream));
+                    acap.taken[acap.count++] = chunk_caps[k];
+                }
+                *acap.n_taken = acap.count;
+                ++acap.chunk_no;
+            }
             if (ar.fused && gave_up) {
                 // the grid did not run as a whole (another job holds CUs): the same run again on the three-launch engine
                 const AdaptRun keep = ar;
+                if (acap.on) { HIP_TRY(hipStreamSynchronize(cap_stream)); acap.count = 0; acap.next_in_list = 0; acap.chunk_no = 0; *acap.n_taken = 0; }
                 fused_ok = false;
                 last_fell_back = 1;
                 ++fallbacks;
@@ -2168,6 +2261,7 @@ template <typename T> struct PlanT : PlanBase {
             if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
         }
         ar.active = false;
+        if (acap.on) { HIP_TRY(hipStreamSynchronize(cap_stream)); acap.on = false; }          // (the caller's snapshots are complete)
         if (ar.tile_private && ar.now.steps > 0) {
             HIP_TRY((launch_time<T, TM_UNPACK>(N1, batch, stream, targs(ar.gamma, 0, 0, nullptr), E)));      // Y buffer -> time-order field
             ++last_launches;
@@ -2870,6 +2964,10 @@ int ssfm_adaptive_run(ssfm_plan* plan, int64_t budget, void* snapshots, int64_t*
     WITH_PLAN(plan, P_->adaptive_run(budget, snapshots, steps_total, done));
 }
 int ssfm_adaptive_finish(ssfm_plan* plan, int64_t* steps_out, double* z_out) { WITH_PLAN(plan, P_->adaptive_finish(steps_out, z_out)); }
+int ssfm_adaptive_set_capture(ssfm_plan* plan, const ssfm_adaptive_capture* cap) {
+    if (!cap) return fail(SSFM_ERR_INVALID, "ssfm_adaptive_set_capture: NULL description");
+    WITH_PLAN(plan, P_->adaptive_set_capture(cap->every, cap->steps, cap->n_steps, cap->fields, cap->capacity, cap->taken, cap->n_taken));
+}
 
 int ssfm_apply_transfer(ssfm_plan* plan, const void* H_host) {
     if (!H_host) return fail(SSFM_ERR_INVALID, "H_host is NULL");

@@ -387,11 +387,11 @@ _CHIRPS32: "OrderedDict[tuple, object]" = OrderedDict()
 # fibres, max|A - A_float64|/peak <= 7.5e-7 x steps^0.75.  The reference's own complex64 run sits up to the tolerance itself from the float64
 # solution for such lengths, so the line may use HALF of the stated bound -- `accuracy.tol(steps)`, ONE bound continuous in the number of steps
 # (2e-5 up to 100 steps, the log-log line to 3e-4 at 1000, proportional beyond).  Where the law exceeds half the bound the run takes the complex128
-# line (four launches per step, 1e-13 from float64): 32 ... 758 steps, DERIVED from the law and the bound (`accuracy.c64_line_window`).  Round 5's
+# line (four launches per step, 1e-13 from float64): 27 ... 1031 steps, DERIVED from the law and the bound (`accuracy.c64_line_window`).  Round 5's
 # window, 32 ... 100, was fitted to the step at 101 steps of the tolerance the tests then used (2e-5 up to 100 steps, 3e-4 from 101): a 101-step
 # run is 2.4e-5 from the float64 solution by the line's own law.  `precision="complex128"` always takes the complex128 line.
 _c64_line_has_margin = accuracy.c64_line_has_margin
-_C64_LINE_NO_MARGIN = accuracy.c64_line_window()          # (first, last) step count without margin: (32, 758)
+_C64_LINE_NO_MARGIN = accuracy.c64_line_window()          # (first, last) step count without margin: (27, 1031)
 
 
 def _fiber_chirpz_small_c64(A_dev, shape, dt, length, alpha, beta_2, beta_3, gamma, phi_max, h, dev):

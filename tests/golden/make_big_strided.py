@@ -48,3 +48,11 @@ out["fixed23_samples"], out["fixed23_power"] = y[::STRIDE], pw(y)
 out["dbp23_samples"], out["dbp23_power"] = x[::STRIDE], pw(x)
 print(f"2^23 x 1, 4 fixed steps + DBP: {time.time() - t:.0f} s", flush=True)
 np.savez(os.path.join(HERE, "big_strided.npz"), _versions=np.array([np.__version__]), stride=np.array(STRIDE), **out)
+
+# (appended in the same round) the long run: 100 of C2's steps on the 2^23-sample field -- the oracle needs about 3 s per step there
+if len(sys.argv) > 1 and sys.argv[1] == "long":
+    t = time.time()
+    kw = dict(length=12.5, h=0.125, **workloads.SMF)
+    y = orc.fiber_c64(b, dt, **kw)
+    np.savez(os.path.join(HERE, "big_strided_100.npz"), _versions=np.array([np.__version__]), stride=np.array(STRIDE), samples=y[::STRIDE], power=pw(y))
+    print(f"2^23 x 1, 100 fixed steps: {time.time() - t:.0f} s", flush=True)

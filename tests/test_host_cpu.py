@@ -345,9 +345,9 @@ def test_the_stated_tolerance_is_one_continuous_bound_and_the_routing_window_fol
     assert np.all(np.diff(t) >= 0) and np.max(t[1:] / t[:-1]) < 1.013            # monotone, and no jump: at most the line's own slope per step
     assert abs(acc.tol(101) / acc.tol(100) - 1) < 0.012                            # (rounds 3-5: a factor 15 here)
     lo, hi = acc.c64_line_window()
-    assert (lo, hi) == (32, 758)
+    assert (lo, hi) == (27, 1031)
     assert acc.c64_line_has_margin(lo - 1) and not acc.c64_line_has_margin(lo) and not acc.c64_line_has_margin(hi) and acc.c64_line_has_margin(hi + 1)
-    assert all(acc.c64_line_error(k) <= 0.5 * acc.tol(k) for k in (1, 10, 31, 759, 1000, 5000))
+    assert all(acc.c64_line_error(k) <= 0.5 * acc.tol(k) for k in (1, 10, 26, 1032, 2000, 5000))
     assert devices._c64_line_has_margin is acc.c64_line_has_margin and devices._C64_LINE_NO_MARGIN == (lo, hi)
 
 
