@@ -40,6 +40,7 @@ SYMBOLS = {
     "ssfm_adaptive_begin": (_I, [_VP, _D, _D, _D, _I, _I64, _I]),
     "ssfm_adaptive_run": (_I, [_VP, _I64, _VP, C.POINTER(_I64), C.POINTER(_I)]),
     "ssfm_adaptive_finish": (_I, [_VP, C.POINTER(_I64), C.POINTER(_D)]),
+    "ssfm_adaptive_set_capture": (_I, [_VP, _VP]),
     "ssfm_apply_transfer": (_I, [_VP, _VP]),
     "ssfm_apply_dispersion": (_I, [_VP, _D, _D, _VP]),
     "ssfm_sosfiltfilt": (_I, [_I, _VP, _VP, _I, _VP, _VP, _I64, _I, _I, _I]),
@@ -90,6 +91,12 @@ SYMBOLS = {
 ENGINES = ("none", "two_kernel", "small", "medium", "adaptive_3_launches", "adaptive_fused", "small_adaptive", "medium_adaptive",
            "chirp_small", "chirp_small_adaptive", "chirp_steps", "chirp_medium", "chirp_medium_adaptive", "split", "split_adaptive")
 DIRECT_LOG2_MAX = 22      # rows of more than 2^22 samples are split plans (csrc/ssfm_split.hpp): propagation, DM and field transfers -- no tables, chirp-z or strided capture
+
+
+class AdaptiveCapture(C.Structure):
+    """``ssfm_adaptive_capture`` of include/ssfm_amd.h."""
+    _fields_ = [("every", C.c_int64), ("steps", C.POINTER(C.c_int64)), ("n_steps", C.c_int64), ("fields", C.c_void_p), ("capacity", C.c_int64),
+                ("taken", C.POINTER(C.c_int64)), ("n_taken", C.POINTER(C.c_int64))]
 
 
 class Capture(C.Structure):
@@ -633,6 +640,44 @@ class Plan:
         if blocks is not None:
             snap = blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=0)       # a compact copy: nothing of the blocks stays alive
         return s, z, snap
+
+    def propagate_adaptive_capture(self, gamma, length, phi_max, every=None, steps=None, capacity=None, max_steps=1 << 16, fields=None):
+        """An adaptive run with a z-resolved capture that keeps the run's engine (``ssfm_adaptive_set_capture``): the field after every ``every``-th step, or
+        after the (1-based, ascending) step numbers ``steps``.  Returns ``(n_steps, z float64 (n_steps + 1,), taken int64 (k,), fields (k, batch, n))`` --
+        the input and the end field are not among the snapshots (``get_field`` before and after).  ``fields``: a destination made earlier
+        (``host_empty((capacity, batch, n), cdtype)``: page-locking a GiB takes longer than the run)."""
+        lib = load()
+        if (every is None) == (steps is None):
+            raise ValueError("either `every` or `steps`")
+        if steps is not None:
+            want = np.ascontiguousarray(steps, dtype=np.int64)
+            if want.size == 0:
+                raise ValueError("`steps` is empty")
+            capacity = want.size if capacity is None else int(capacity)
+        else:
+            every = int(every)
+            if every < 1:
+                raise ValueError(f"every = {every}")
+            want = None
+            if capacity is None:
+                raise ValueError("a strided capture of an adaptive run needs a `capacity` (snapshots): the run's length in steps is its own")
+        capacity = max(1, int(capacity))
+        if fields is None:
+            fields = host_empty((capacity, self.batch, self.n), self.cdtype, limit=8 << 30)
+        elif fields.shape != (capacity, self.batch, self.n) or fields.dtype != self.cdtype or not fields.flags.c_contiguous:
+            raise ValueError("`fields` must be a C-contiguous (capacity, batch, n) array of the plan's type")
+        taken = np.zeros(capacity, dtype=np.int64)
+        n_taken = C.c_int64(0)
+        cap = AdaptiveCapture(every if want is None else 0, want.ctypes.data_as(C.POINTER(C.c_int64)) if want is not None else None, 0 if want is None else want.size,
+                              fields.ctypes.data, capacity, taken.ctypes.data_as(C.POINTER(C.c_int64)), C.pointer(n_taken))
+        nsteps, done = _I64(0), _I(0)
+        _check(lib.ssfm_adaptive_begin(self._h, float(gamma), float(length), float(phi_max), 0, int(max_steps), 0), "ssfm_adaptive_begin")
+        _check(lib.ssfm_adaptive_set_capture(self._h, C.byref(cap)), "ssfm_adaptive_set_capture")
+        _check(lib.ssfm_adaptive_run(self._h, int(max_steps), None, C.byref(nsteps), C.byref(done)), "ssfm_adaptive_run")
+        z = np.zeros(nsteps.value + 1, dtype=np.float64)
+        _check(lib.ssfm_adaptive_finish(self._h, C.byref(nsteps), z.ctypes.data_as(C.POINTER(_D))), "ssfm_adaptive_finish")
+        k = int(n_taken.value)
+        return nsteps.value, z, taken[:k].copy(), fields[:k]
 
     def apply_transfer(self, H: np.ndarray):
         h = np.ascontiguousarray(H, dtype=self.cdtype)

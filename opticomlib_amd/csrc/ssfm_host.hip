@@ -747,6 +747,7 @@ template <typename T> struct PlanT : PlanBase {
         if (cap_stream) (void)hipStreamSynchronize(cap_stream);
         for (auto& v : cap_ev_ends) for (hipEvent_t e : v) (void)hipEventDestroy(e);
         if (cap_ev_in) (void)hipEventDestroy(cap_ev_in);
+        for (auto& e : acap_ev) if (e) (void)hipEventDestroy(e);
         (void)hipFree(cap_blocks); (void)hipFree(cap_in); (void)hipFree(cap_scal);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (auto& p : prof) {
@@ -1915,6 +1916,7 @@ template <typename T> struct PlanT : PlanBase {
         int half_slots = 0;
         int chunk_no = 0;
     } acap;
+    hipEvent_t acap_ev[2] = {nullptr, nullptr};      // behind the transfers of the chunk that used half 0 / 1 of the ring (the host waits for it before that half is written again)
     bool acap_wants(int64_t after) {
         if (!acap.on) return false;
         if (acap.every > 0) return after % acap.every == 0;
@@ -1951,6 +1953,7 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&cap_ev_in, hipEventDisableTiming));
         }
+        for (auto& e : acap_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (ar.deferred) {            // (a small plan: the capture needs the launch-per-pass engine)
             const AdaptRun keep = ar;
             if (int rc = adaptive_begin_chunked(keep.gamma, keep.length, keep.phi_max, keep.single_step, keep.max_steps, 0)) return rc;
@@ -2169,8 +2172,16 @@ template <typename T> struct PlanT : PlanBase {
             std::vector<int64_t> chunk_caps;
             char* ring_half = nullptr;
             if (acap.on) {
-                if (acap.every > 0 && (int64_t)chunk > acap.every * acap.half_slots) chunk = (int)(acap.every * acap.half_slots);
-                if (acap.chunk_no >= 2) HIP_TRY(hipStreamSynchronize(cap_stream));
+                // (short chunks: a chunk's snapshots only leave at the look behind it, and the transfers should run beside the NEXT chunk's kernels -- four
+                // snapshots per chunk, 64 steps at least; a look drains the queue for ~40 us)
+                if (acap.every > 0 && (int64_t)chunk > std::max<int64_t>(64, acap.every * 4)) chunk = (int)std::max<int64_t>(64, acap.every * 4);
+                // ... and a chunk ends right behind a capture step where it can, so that the snapshot leaves at once (the last ones of a run would otherwise
+                // travel behind its end)
+                if (acap.every > 0 && (int64_t)chunk > acap.every) {
+                    const int64_t end = (((int64_t)ar.step + chunk) / acap.every) * acap.every;
+                    if (end > (int64_t)ar.step) chunk = (int)(end - (int64_t)ar.step);
+                }
+                if (acap.chunk_no >= 2) HIP_TRY(hipEventSynchronize(acap_ev[acap.chunk_no & 1]));      // (the transfers of the chunk before the last: NOT the last chunk's, which run beside this one)
                 ring_half = cap_blocks + fb * (size_t)acap.half_slots * (size_t)(acap.chunk_no & 1);
             }
             for (int i = 0; i < chunk; ++i, ++ar.step) {
@@ -2200,7 +2211,7 @@ template <typename T> struct PlanT : PlanBase {
                     HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, tc, E)));
                     ++last_launches;
                     chunk_caps.push_back((int64_t)ar.step + 1);
-                    if ((int)chunk_caps.size() >= acap.half_slots) chunk = i + 1;          // (the half is full: look at the state, send it)
+                    if ((int)chunk_caps.size() >= acap.half_slots || (acap.every == 0 && chunk_caps.size() >= 4 && i + 1 >= 64)) chunk = i + 1;          // (the half is full / enough to send: look at the state)
                 }
                 if (ar.fused) HIP_TRY((launch_time<T, TM_MID_A>(N1, batch, stream, te, E)));
                 else if (ar.tile_private) HIP_TRY((launch_time<T, TM_END_Y>(N1, batch, stream, te, E)));
@@ -2228,6 +2239,7 @@ template <typename T> struct PlanT : PlanBase {
                     acap.taken[acap.count++] = chunk_caps[k];
                 }
                 *acap.n_taken = acap.count;
+                HIP_TRY(hipEventRecord(acap_ev[acap.chunk_no & 1], cap_stream));
                 ++acap.chunk_no;
             }
             if (ar.fused && gave_up) {

@@ -604,7 +604,8 @@ def FIBER(input: optical_signal,
           *,
           precision="complex64",
           device=None,
-          every: int = None):
+          every: int = None,
+          z_list=None):
     """Optical fibre: symmetric split-step Fourier solution of the scalar NLSE per polarisation.
 
     Parameters as the reference (``devices.py:1038-1083``): ``length`` [km], ``alpha`` [dB/km],
@@ -618,7 +619,11 @@ def FIBER(input: optical_signal,
     (with ``return_steps`` and a fixed ``h`` on a power-of-two length): keep the field after every
     ``every``-th step only (plus the input and the last step) -- the run stays on the fused engine and the
     snapshots travel to page-locked host memory beside it (``ssfm_propagate_fixed_capture``); the reference
-    keeps every step, 16 GiB for the 1000-step run of a 2^20-sample dual-polarisation field.
+    keeps every step, 16 GiB for the 1000-step run of a 2^20-sample dual-polarisation field.  With the adaptive step
+    (``h=None``, the reference's default and what its own consumer of ``return_steps`` uses, ``devices.py:2342``) ``every`` and
+    ``z_list`` (round 6) keep the run's own engine as well (``ssfm_adaptive_set_capture``): ``z_list`` = positions [km] -- for each
+    the field after the first step that reaches it (the input for z <= 0, the end field beyond the length).  The run is
+    made twice: once for its z log (an adaptive run repeats bit for bit), once with the capture at the steps that follow from it.
     """
     t0 = time.time()
     input, grid, back = _adopt(input, "optical_signal")
@@ -670,6 +675,9 @@ def FIBER(input: optical_signal,
             bar.close()
         if return_steps:
             keep = _every_index(len(snaps) - 1, every)
+            if z_list is not None:                      # the first step that reaches each position (0: the input; the last: the end field)
+                zs64 = np.asarray(zs, dtype=np.float64)
+                keep = [int(min(np.searchsorted(zs64, v, side="left"), len(snaps) - 1)) for v in np.asarray(z_list, dtype=np.float64).ravel()]
             A_z = np.stack([snaps[k].to_host() for k in keep]).astype(plan_dtype).reshape((len(keep),) + tuple(shape))
             return np.asarray(zs, dtype=np.float64)[keep], A_z
         res = out if out.dtype == plan_dtype else out.astype(plan_dtype)
@@ -683,7 +691,7 @@ def FIBER(input: optical_signal,
     plan = get_plan(n, batch, prec, dev)
     with plan.lock:
         return back(_fiber_on_plan(plan, A, A_dev, shape, float(grid.dt), L, length, alpha, beta_2, beta_3, gamma, phi_max, h,
-                                   show_progress, return_steps, prec, plan_dtype, rt, dev, t0, every))
+                                   show_progress, return_steps, prec, plan_dtype, rt, dev, t0, every, z_list))
 
 
 def _every_index(steps: int, every):
@@ -696,8 +704,35 @@ def _every_index(steps: int, every):
     return list(range(0, steps, every)) + [steps]
 
 
+def _adaptive_capture(plan, gamma, length, phi_max, every, z_list, batch, n):
+    """``FIBER(h=None, return_steps=True, every=k | z_list=[...])`` on a power-of-two plan: the run once for its z log, the input restored, the run again
+    with the capture at the step numbers that follow (``Plan.propagate_adaptive_capture``).  Returns (z of the kept snapshots, snapshots)."""
+    x0 = _lib.DeviceArray((batch, n), plan.cdtype, plan.device)
+    plan.get_field_device(x0.ptr)
+    first = plan.get_field().reshape(1, batch, n)
+    # (the first pass on the engine the capture will run on: a capture that never fires -- the one-launch engines of the small plans find their
+    # step sizes in another order of operations, and their z log differs from the launch-per-pass engines' in the last bits)
+    steps, z, _, _ = plan.propagate_adaptive_capture(gamma, length, phi_max, steps=np.array([1 << 40], dtype=np.int64))
+    if z_list is not None:
+        zl = np.asarray(z_list, dtype=np.float64).ravel()
+        keep = [int(min(np.searchsorted(z, rt_z, side="left"), steps)) for rt_z in zl]          # the first step with z_step >= z (0: the input; steps: the end)
+    else:
+        keep = _every_index(steps, every)
+    want = sorted({k for k in keep if 0 < k < steps})
+    got = {0: first[0]}
+    if want:
+        plan.set_field_device(x0.ptr)
+        steps2, z2, taken, fields = plan.propagate_adaptive_capture(gamma, length, phi_max, steps=np.asarray(want, dtype=np.int64))
+        if steps2 != steps or not np.array_equal(z2, z) or list(taken) != want:
+            raise _lib.SsfmError(f"the adaptive run did not repeat ({steps} / {steps2} steps, {len(taken)} of {len(want)} snapshots)")
+        for k, f in zip(want, fields):
+            got[k] = f
+    got[steps] = plan.get_field().reshape(batch, n) if steps else first[0]
+    return np.asarray(z)[keep], np.stack([got[k] for k in keep])
+
+
 def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, gamma, phi_max, h, show_progress, return_steps,
-                   prec, plan_dtype, rt, dev, t0, every=None):
+                   prec, plan_dtype, rt, dev, t0, every=None, z_list=None):
     """The fused two-kernel engine behind ``FIBER`` (the caller holds the plan's lock for the whole sequence)."""
     n = shape[-1]
     batch = 1 if len(shape) == 1 else shape[0]
@@ -721,7 +756,15 @@ def _fiber_on_plan(plan, A, A_dev, shape, dt, L, length, alpha, beta_2, beta_3, 
     if h is None:
         b2, b3, g = rt(beta_2), rt(beta_3), rt(gamma)
         single = bool((b2 == 0 and b3 == 0) or g == 0)
-        steps, z, snaps = plan.propagate_adaptive(gamma, length, phi_max, single, snapshots=return_steps)
+        if return_steps and (every is not None or z_list is not None) and not single and n <= (1 << _lib.DIRECT_LOG2_MAX) and float(L) > 0:
+            z, snaps = _adaptive_capture(plan, gamma, length, phi_max, every, z_list, batch, n)
+            steps, every, z_list = len(z) - 1, None, None                         # (thinned already)
+        else:
+            steps, z, snaps = plan.propagate_adaptive(gamma, length, phi_max, single, snapshots=return_steps)
+            if return_steps and z_list is not None:                              # (a single step, a split plan: every snapshot was taken; picked here)
+                zl = np.asarray(z_list, dtype=np.float64).ravel()
+                keep = [int(min(np.searchsorted(np.asarray(z, dtype=np.float64), v, side="left"), len(z) - 1)) for v in zl]
+                snaps, z, every = snaps[keep], np.asarray(z)[keep], None
     else:
         hs, z = step_schedule(length, h, prec)
         steps = hs.size
@@ -787,11 +830,13 @@ def DBP(input: optical_signal,
         return_steps: bool = False,
         *,
         precision="complex64",
-        device=None):
+        device=None,
+        every: int = None,
+        z_list=None):
     """Digital back-propagation = ``FIBER`` with every operator negated (``devices.py:1280-1283``)."""
     return FIBER(input, length=length, alpha=-alpha, beta_2=-beta_2, beta_3=-beta_3, gamma=-gamma,
                  phi_max=phi_max, h=h, show_progress=show_progress, return_steps=return_steps,
-                 precision=precision, device=device)
+                 precision=precision, device=device, every=every, z_list=z_list)
 
 
 # ------------------------------------------------------------------ DM

@@ -3092,3 +3092,90 @@ def test_two_to_the_23_long_run_against_the_oracle_fixture(golden_dir):
     np.testing.assert_allclose(np.mean(np.abs(y.signal.astype(np.complex128)) ** 2), float(g["power"]), rtol=1e-4)
     oa.devices.release_plans()
     _BIG.clear()
+
+
+# ----------------------------------------------------------------------- adaptive runs with a capture that keeps the run's engine (round 6)
+@pytest.mark.parametrize("log2n,npol,prec", [(14, 2, "c64"), (18, 2, "c64"), (20, 2, "c64"), (16, 2, "c128")])
+def test_adaptive_capture_keeps_the_engine_and_every_snapshot_is_a_plain_run_stopped_there(log2n, npol, prec):
+    """ssfm_adaptive_set_capture (the reference's own consumer of return_steps runs FIBER with h = None, devices.py:2342): the run keeps its
+    engine -- two launches per step, fused, where the plan has it -- and a capture step adds one launch.  The z log is the plain run's bit for bit, the end
+    field is the plain run's bit for bit, a capture AT the last step is that end field bit for bit (the capture's launch and the run's last launch apply the
+    same half rotation to the same data), and every snapshot agrees with the field a plain run leaves when it is stopped after that many steps -- a budgeted run,
+    which takes the launch-per-pass engine (END and BEGIN apart where the fused kernel merges their rotations): two engines of this library, half the tolerance."""
+    n = 1 << log2n
+    gv(**workloads.BENCH_GV)
+    P, cd = (_lib.C64, np.complex64) if prec == "c64" else (_lib.C128, np.complex128)
+    a = workloads.qpsk_field(n, seed=90 + log2n, n_pol=2, power_w=10e-3)[:npol].astype(cd)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13, P)
+    p = _lib.Plan(n, npol, P)
+    try:
+        p.set_linear_operator(D)
+        p.set_field(a)
+        steps, z, _ = p.propagate_adaptive(1.3, 6.0, 0.004, False)
+        plain_end, plain_engine = p.get_field(), p.last_run_info()["engine"]
+        assert steps > 30
+        every = 7
+        p.set_field(a)
+        s2, z2, taken, fields = p.propagate_adaptive_capture(1.3, 6.0, 0.004, every=every, capacity=steps // every + 2)
+        info = p.last_run_info()
+        one_launch = plain_engine in ("medium_adaptive", "small_adaptive")      # (a plan whose plain run is ONE launch: the capture takes the launch-per-pass engine)
+        assert s2 == steps
+        if one_launch:
+            np.testing.assert_allclose(z2, z, rtol=5e-6)
+            assert within(p.get_field(), plain_end, steps=steps, what="adaptive capture run (launch per pass) against the plain run (one launch)")
+            z, plain_end = z2, p.get_field()
+        else:
+            assert np.array_equal(z2, z) and info["engine"] == plain_engine, (info, plain_engine)
+            np.testing.assert_array_equal(p.get_field(), plain_end)
+        assert list(taken) == list(range(every, steps + 1, every)) and fields.shape == (len(taken), npol, n)
+        for k in (0, len(taken) // 2, len(taken) - 1):
+            s_ = int(taken[k])
+            p.set_field(a)
+            lib = _lib.load()
+            st, dn = _lib._I64(0), _lib._I(0)
+            _lib._check(lib.ssfm_adaptive_begin(p._h, 1.3, 6.0, 0.004, 0, 1 << 16, 0), "begin")
+            _lib._check(lib.ssfm_adaptive_run(p._h, s_, None, _lib.C.byref(st), _lib.C.byref(dn)), "run")           # a plain run stopped after s_ steps
+            zb = np.zeros(st.value + 1)
+            _lib._check(lib.ssfm_adaptive_finish(p._h, _lib.C.byref(st), zb.ctypes.data_as(_lib.C.POINTER(_lib._D))), "finish")
+            assert st.value == s_
+            np.testing.assert_allclose(zb, z[: s_ + 1], rtol=5e-6)               # (the launch-per-pass engine finds the same step sizes to the rounding of a maximum)
+            stopped = p.get_field()
+            if np.array_equal(fields[k], stopped):
+                continue
+            assert within(fields[k], stopped, 0.5 * tol_at(s_) if prec == "c64" else 1e-12, steps=s_, what=f"adaptive capture against a plain run stopped at step {s_}")
+        # a list of step numbers instead of a stride
+        want = np.array([1, 2, steps // 2, steps - 1, steps], dtype=np.int64)
+        p.set_field(a)
+        s3, z3, taken3, fields3 = p.propagate_adaptive_capture(1.3, 6.0, 0.004, steps=want)
+        assert s3 == steps and np.array_equal(z3, z) and list(taken3) == list(want)
+        np.testing.assert_array_equal(fields3[-1], plain_end)                                   # the capture at the last step is the end field
+        if steps // 2 % every == 0:
+            np.testing.assert_array_equal(fields3[2], fields[steps // 2 // every - 1])
+    finally:
+        p.close()
+
+
+def test_fiber_adaptive_return_steps_with_a_stride_and_with_positions(golden_dir):
+    """FIBER(h=None, return_steps=True, every=k / z_list=[...]) through the host mirror: the golden adaptive vector's z log reproduced and sub-sampled, the
+    snapshots those of the every-step capture (the reference's return_steps), the positions picked as the first step that reaches each z."""
+    case = CASES["kat1_adaptive_2pol"]
+    g = np.load(os.path.join(golden_dir, "kat1_adaptive_2pol.npz"))
+    x = _signal(case)
+    kw = dict(case["kw"])
+    z_all, A_all = oa.FIBER(x, return_steps=True, **kw)                       # every step (three launches per step, the host waits per step)
+    assert abs(len(z_all) - len(g["z"])) <= 1
+    m = min(len(z_all), len(g["z"])) - 1
+    np.testing.assert_allclose(z_all[:m], g["z"][:m], rtol=2e-4)
+    S = len(z_all) - 1
+    z5, A5 = oa.FIBER(x, return_steps=True, every=5, **kw)
+    keep = list(range(0, S, 5)) + [S]
+    np.testing.assert_array_equal(z5, z_all[keep])
+    assert A5.shape == (len(keep),) + A_all.shape[1:] and A5.dtype == np.complex64
+    assert within(A5, A_all[keep], 0.5 * tol_at(S), steps=S, what="adaptive strided capture against the every-step capture")
+    assert within(A5[-1], g["out"], steps=S, what="golden out, adaptive strided capture")
+    zl = [0.0, 0.3, float(z_all[7]), 5.0, 9.999, 10.0, 12.0]
+    zp, Ap = oa.FIBER(x, return_steps=True, z_list=zl, **kw)
+    idx = [int(min(np.searchsorted(z_all, v, side="left"), S)) for v in zl]
+    assert idx[0] == 0 and idx[2] == 7 and idx[-1] == S and idx[-2] == S
+    np.testing.assert_array_equal(zp, z_all[idx])
+    assert within(Ap, A_all[idx], 0.5 * tol_at(S), steps=S, what="adaptive capture at given z against the every-step capture")
