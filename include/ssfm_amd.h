@@ -414,6 +414,11 @@ typedef struct ssfm_run_info {
     float lane_pair_us;
     float lane_last_us;
     float lane_score;
+    /* round 6 (appended: callers built against the shorter struct pass its size and are not written beyond it) */
+    int lanes_from_pool;        /* 1: this plan's pair of lane streams came rated from the process's pool -- no probe launches at its creation */
+    int pad_;
+    int64_t lane_ratings_total; /* process-wide: two-lane plans whose creation rated fresh streams (about 7 ms of probe launches each) */
+    int64_t lane_pairs_reused;  /* process-wide: two-lane plans that took a rated pair from the pool instead */
 } ssfm_run_info;
 SSFM_API int ssfm_last_run_info(ssfm_plan* plan, ssfm_run_info* info, size_t info_bytes);
 

@@ -108,7 +108,8 @@ class RunInfo(C.Structure):
     """``ssfm_run_info`` of include/ssfm_amd.h."""
     _fields_ = [("engine", C.c_int), ("fell_back", C.c_int), ("fallbacks_total", C.c_int64), ("lanes", C.c_int), ("lanes_configured", C.c_int), ("lanes_share_queue", C.c_int),
                 ("lanes_remade", C.c_int), ("lanes_dropped", C.c_int), ("lane_heals", C.c_int), ("lane_alone_us", C.c_float), ("lane_pair_us", C.c_float),
-                ("lane_last_us", C.c_float), ("lane_score", C.c_float)]
+                ("lane_last_us", C.c_float), ("lane_score", C.c_float), ("lanes_from_pool", C.c_int), ("pad_", C.c_int), ("lane_ratings_total", C.c_int64),
+                ("lane_pairs_reused", C.c_int64)]
 
 
 class SsfmError(RuntimeError):
@@ -818,7 +819,8 @@ class Plan:
         return {"engine": ENGINES[r.engine] if 0 <= r.engine < len(ENGINES) else str(r.engine), "fell_back": bool(r.fell_back),
                 "fallbacks_total": int(r.fallbacks_total), "lanes": int(r.lanes), "lanes_share_queue": bool(r.lanes_share_queue),
                 "lanes_remade": int(r.lanes_remade), "lanes_dropped": bool(r.lanes_dropped), "lane_heals": int(r.lane_heals), "lane_alone_us": float(r.lane_alone_us),
-                "lane_pair_us": float(r.lane_pair_us), "lane_last_us": float(r.lane_last_us), "lane_score": float(r.lane_score)}
+                "lane_pair_us": float(r.lane_pair_us), "lane_last_us": float(r.lane_last_us), "lane_score": float(r.lane_score),
+                "lanes_from_pool": bool(r.lanes_from_pool), "lane_ratings_total": int(r.lane_ratings_total), "lane_pairs_reused": int(r.lane_pairs_reused)}
 
     def lane_fault(self, mode: int):
         """Test hook of the lane health check (include/ssfm_amd.h ``ssfm_debug``, SSFM_DEBUG_LANE_FAULT)."""

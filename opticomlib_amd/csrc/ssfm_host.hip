@@ -423,8 +423,35 @@ int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* tw
 // has its lanes rated again (PlanT::lane_health).
 constexpr float kLaneGoodRatio = 1.6f;
 constexpr float kLaneSlowRatio = 1.8f;
+constexpr float kLaneSuspectRatio = 1.3f;        // two checked runs in a row beyond this (round 6: profiles/r05_final_lane_stability.txt had one plan at 1.37 x that 1.8 never sees)
+constexpr int kLaneDroppedCooldown = 32;         // runs after which a plan that dropped to one lane tries its second lane again
 constexpr int kLaneProbeSteps = 12;
 constexpr int kLaneHealsMax = 8;
+
+// Rated lane pairs outlive their plan (round 6): rating a fresh pair costs ~7 ms of probe launches (k_queue_probe_spin was 25 % of an
+// adaptive profile), and what the rating finds out -- which hardware queues the runtime gave the two streams -- is a property of the STREAMS, not of the plan.
+// A two-lane plan that ends with good lanes hands its pair (the plan's stream and lane 1's) to a per-device pool instead of destroying it; the next two-lane
+// plan of the process on that device takes a pooled pair with its rating and skips the probes.  The run-time check (lane_health) stays as it is.
+struct LanePair { int device; hipStream_t main, lane; float score, alone_us, pair_us; };
+struct LanePool {
+    std::mutex m;
+    std::vector<LanePair> free;
+    static constexpr size_t kMax = 8;
+    bool take(int device, LanePair* out) {
+        std::lock_guard<std::mutex> lk(m);
+        for (size_t i = free.size(); i-- > 0;)
+            if (free[i].device == device) { *out = free[i]; free.erase(free.begin() + (long)i); return true; }
+        return false;
+    }
+    bool give(const LanePair& p) {
+        std::lock_guard<std::mutex> lk(m);
+        if (free.size() >= kMax) return false;
+        free.push_back(p);
+        return true;
+    }
+};
+LanePool& lane_pool() { static LanePool* p = new LanePool(); return *p; }        // (never destroyed: plans may be closed from atexit handlers)
+std::atomic<long long> g_lane_ratings{0}, g_lane_pairs_reused{0};                  // process-wide: ratings made at plan creation / pairs taken from the pool
 
 // ----------------------------------------------------------------------------- plan
 struct PlanBase {
@@ -582,7 +609,8 @@ template <typename T> struct PlanT : PlanBase {
     int lanes_active = 1;              // lanes a fixed-step run really drives: nlanes, or 1 once a plan that could not be healed has dropped to one lane
     int lanes_remade = 0;              // lane streams replaced at RUN time (a run came out slow, the lanes were rated again and one was not good)
     int lanes_dropped = 0;             // 1: the plan gave up its second lane (two healing attempts in a row found no good stream)
-    int lane_heals = 0, lane_strikes = 0;
+    int lane_heals = 0, lane_strikes = 0, lane_suspect = 0, lane_dropped_runs = 0;
+    bool lanes_from_pool = false;      // this plan's lane pair came rated from the process's pool (no probe launches at creation)
     int lane_fault = 0;                // test hook (ssfm_debug_lane_fault): 2 = every rating comes out "in the way"
     float lane_alone_us = 0.f;         // launch period of lane 0's chain alone on the chip (the plan's own kernels; last rating)
     float lane_pair_us = 0.f;          // best launch period seen with all lanes running: the last rating's, or a real run's
@@ -735,6 +763,14 @@ template <typename T> struct PlanT : PlanBase {
         if (medium_stream2) (void)hipStreamDestroy(medium_stream2);
         (void)hipFree(d_hs);
         for (void* w : work) (void)hipFree(w);
+        // a good pair of lane streams goes to the pool with its rating (lane_pool above) instead of being destroyed
+        bool pooled = false;
+        if (nlanes == 2 && lanes_ok && !lanes_dropped && !lanes_share_queue && lane_fault == 0 && stream && lane_stream[1] && lane_stream[1] != stream
+            && !std::getenv("SSFM_LANE_POOL_OFF")) {
+            (void)hipStreamSynchronize(lane_stream[1]);
+            pooled = lane_pool().give(LanePair{device, stream, lane_stream[1], lane_score, lane_alone_us, lane_pair_us});
+            if (pooled) lane_stream[1] = nullptr;
+        }
         for (int g = 1; g < kMaxLanes; ++g) {
             if (lane_ev[g]) (void)hipEventDestroy(lane_ev[g]);
             if (lane_stream[g]) (void)hipStreamDestroy(lane_stream[g]);
@@ -756,7 +792,7 @@ template <typename T> struct PlanT : PlanBase {
         }
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream && !pooled) (void)hipStreamDestroy(stream);
         return SSFM_OK;
     }
     ~PlanT() override { free_all(); }
@@ -798,7 +834,19 @@ template <typename T> struct PlanT : PlanBase {
         // starved the normal one: 26 instead of 16 us per field-step with 4 fields).
         int prio_lo = 0, prio_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_hi));
+        {
+            // a plan that will drive two lanes takes a rated pair of streams from the process's pool where there is one (lane_pool above)
+            int want2 = (long long)batch * n >= (1ll << 20) ? 2 : 1;
+            if (const char* e = std::getenv("SSFM_LANES")) want2 = std::atoi(e);
+            LanePair lp;
+            if (want2 == 2 && batch_full >= 2 && batch_full % 2 == 0 && !std::getenv("SSFM_LANE_POOL_OFF") && lane_pool().take(device, &lp)) {
+                stream = lp.main; lane_stream[1] = lp.lane;
+                lane_score = lp.score; lane_alone_us = 0.f; lane_pair_us = 0.f;           // (the periods are this plan's own kernels': the first long run sets them)
+                lanes_from_pool = true;
+                ++g_lane_pairs_reused;
+            }
+        }
+        if (!stream) HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         // measured: complex64 with 8 points per thread (twice the waves, one more exchange) is 10 % slower;
@@ -833,8 +881,11 @@ template <typename T> struct PlanT : PlanBase {
         while (batch_full % nlanes) --nlanes;            // (a lane holds whole rows: all sub-sequences of a row of a split plan)
         lane_stream[0] = stream;
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        if (lanes_from_pool && nlanes != 2) {           // (cannot happen with the rule above; a pooled lane stream must not leak)
+            (void)hipStreamDestroy(lane_stream[1]); lane_stream[1] = nullptr; lanes_from_pool = false;
+        }
         for (int g = 1; g < nlanes; ++g) {
-            HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, prio_hi));
+            if (!(lanes_from_pool && g == 1)) HIP_TRY(hipStreamCreateWithPriority(&lane_stream[g], hipStreamNonBlocking, prio_hi));
             HIP_TRY(hipEventCreateWithFlags(&lane_ev[g], hipEventDisableTiming));
         }
         lanes_active = nlanes;
@@ -905,7 +956,11 @@ template <typename T> struct PlanT : PlanBase {
             HIP_TRY(hipMemsetAsync(dperm, 0, cb * n, stream));
             if (dperm_fly) HIP_TRY(hipMemsetAsync(dperm_fly, 0, cb * n, stream));
             bool replaced = false;
-            if (int rc = rate_and_replace_lanes(F, Y, P, &replaced)) return rc;
+            if (lanes_from_pool && nlanes == 2) lanes_ok = true;               // (rated by the plan that made the pair; lane_health watches the runs as for any plan)
+            else {
+                ++g_lane_ratings;
+                if (int rc = rate_and_replace_lanes(F, Y, P, &replaced)) return rc;
+            }
             if (!lanes_ok) lane_strikes = 1;          // (no good stream to be had now: the first run that comes out slow and cannot be healed drops the second lane)
             HIP_TRY(hipStreamSynchronize(stream));
         }
@@ -1029,6 +1084,14 @@ template <typename T> struct PlanT : PlanBase {
     // After a two-lane run of >= 64 steps: was it as fast as this plan's lanes can be?  Called before the next run is enqueued and from ssfm_synchronize /
     // ssfm_last_propagate_ms / ssfm_last_run_info (where the run has ended anyway); waits for the run's closing event.
     int lane_health() {
+        if (lanes_dropped && nlanes == 2 && ++lane_dropped_runs >= kLaneDroppedCooldown && lane_heals < kLaneHealsMax) {
+            // a plan that gave up its second lane under contention that may have passed: one more rating on scratch fields; good lanes come back
+            lane_dropped_runs = 0;
+            const int before = lane_strikes;
+            if (int rc = heal_lanes()) return rc;
+            if (lanes_ok) { lanes_active = nlanes; lanes_dropped = 0; lane_strikes = 0; }
+            else lane_strikes = before;
+        }
         if (!lane_check_pending) return SSFM_OK;
         lane_check_pending = false;
         if (lanes_active < 2 || lane_check_launches <= 0 || !run_e1) return SSFM_OK;
@@ -1036,9 +1099,13 @@ template <typename T> struct PlanT : PlanBase {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, run_e0, run_e1));
         lane_last_us = ms * 1e3f / (float)lane_check_launches;
-        if (lane_pair_us <= 0.f || lane_last_us < lane_pair_us) { lane_pair_us = lane_last_us; return SSFM_OK; }
-        if (lane_last_us <= kLaneSlowRatio * lane_pair_us || lane_heals >= kLaneHealsMax) return SSFM_OK;
-        return heal_lanes();
+        if (lane_pair_us <= 0.f || lane_last_us < lane_pair_us) { lane_pair_us = lane_last_us; lane_suspect = 0; return SSFM_OK; }
+        if (lane_heals >= kLaneHealsMax) return SSFM_OK;
+        if (lane_last_us > kLaneSlowRatio * lane_pair_us) { lane_suspect = 0; return heal_lanes(); }
+        // a second look for the moderately slow: one such run is other work on the GPU, two in a row are rated
+        if (lane_last_us > kLaneSuspectRatio * lane_pair_us) { if (++lane_suspect >= 2) { lane_suspect = 0; return heal_lanes(); } }
+        else lane_suspect = 0;
+        return SSFM_OK;
     }
     int heal_lanes() {
         ++lane_heals;
@@ -2840,6 +2907,7 @@ template <typename PT> static int run_info_impl(PT* P_, ssfm_run_info* info, siz
     r.lanes = P_->lanes_active; r.lanes_configured = P_->nlanes; r.lanes_share_queue = P_->lanes_share_queue ? 1 : 0; r.lanes_remade = P_->lanes_remade; r.lanes_dropped = P_->lanes_dropped;
     r.lane_heals = P_->lane_heals;
     r.lane_alone_us = P_->lane_alone_us; r.lane_pair_us = P_->lane_pair_us; r.lane_last_us = P_->lane_last_us; r.lane_score = P_->lane_score;
+    r.lanes_from_pool = P_->lanes_from_pool ? 1 : 0; r.lane_ratings_total = g_lane_ratings.load(); r.lane_pairs_reused = g_lane_pairs_reused.load();
     std::memcpy(info, &r, bytes < sizeof(r) ? bytes : sizeof(r));
     return SSFM_OK;
 }

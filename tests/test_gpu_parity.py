@@ -1089,6 +1089,7 @@ def test_the_lanes_of_a_plan_get_hardware_queues_of_their_own(monkeypatch):
     gv(**workloads.BENCH_GV)
     n = 1 << 19
     monkeypatch.setenv("SSFM_LANES", "2")
+    monkeypatch.setenv("SSFM_LANE_POOL_OFF", "1")                 # (every plan of this test makes and rates FRESH streams; the pool of rated pairs has a test of its own below)
     a = workloads.qpsk_field(n, seed=4).astype(np.complex64)
     D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
     hs = np.full(300, 0.125, np.float32)
@@ -3179,3 +3180,43 @@ def test_fiber_adaptive_return_steps_with_a_stride_and_with_positions(golden_dir
     assert idx[0] == 0 and idx[2] == 7 and idx[-1] == S and idx[-2] == S
     np.testing.assert_array_equal(zp, z_all[idx])
     assert within(Ap, A_all[idx], 0.5 * tol_at(S), steps=S, what="adaptive capture at given z against the every-step capture")
+
+
+def test_a_rated_pair_of_lane_streams_outlives_its_plan(monkeypatch):
+    """Round 6: rating a fresh pair of lane streams costs ~7 ms of probe launches per two-lane plan, and what it finds out is a property
+    of the streams.  A two-lane plan that ends with good lanes hands its pair to the process's pool; the next two-lane plan on the device takes it with its
+    rating: no rating at its creation (the process-wide count stands still), the same step time, the same bits -- and lane_health still watches its runs."""
+    import time
+    for k in ("SSFM_LANES", "SSFM_LANE_POOL_OFF", "SSFM_E", "SSFM_EF"):
+        monkeypatch.delenv(k, raising=False)
+    oa.devices.release_plans()
+    gv(**workloads.BENCH_GV)
+    n = 1 << 20
+    a = workloads.qpsk_field(n, seed=4).astype(np.complex64)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    hs = np.full(200, 0.125, np.float32)
+    outs, infos, created = [], [], []
+    for k in range(4):
+        t0 = time.perf_counter()
+        p = _lib.Plan(n, 2, _lib.C64)
+        created.append(time.perf_counter() - t0)
+        try:
+            assert p.lanes == 2
+            p.set_linear_operator(D); p.set_field(a)
+            p.propagate_fixed(1.3, hs); p.synchronize()
+            t0 = time.perf_counter(); p.propagate_fixed(1.3, hs); p.synchronize(); t = time.perf_counter() - t0
+            p.set_field(a); p.propagate_fixed(1.3, hs)
+            outs.append(p.get_field())
+            info = p.last_run_info()
+            info["step_us"] = t / hs.size * 1e6
+            infos.append(info)
+        finally:
+            p.close()
+    assert [i["lanes_from_pool"] for i in infos[1:]] == [True, True, True], infos
+    assert infos[3]["lane_ratings_total"] == infos[0]["lane_ratings_total"], infos               # no plan after the first rated anything
+    assert infos[3]["lane_pairs_reused"] >= infos[0]["lane_pairs_reused"] + 3
+    assert all(i["lanes"] == 2 and not i["lanes_dropped"] and i["lane_last_us"] > 0 for i in infos), infos
+    assert max(i["step_us"] for i in infos) < 1.35 * min(i["step_us"] for i in infos), infos
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+    print(f"plan creation: {created[0] * 1e3:.1f} ms with a rating, {min(created[1:]) * 1e3:.1f} ms with a pooled pair")
