@@ -392,7 +392,7 @@ def committed_profile_figures(kernels, rows_per_launch):
     passes): read from the newest committed summaries under profiles/ and reported under `from_profiles`, apart from
     what this run measured."""
     out = {}
-    for stats_name in ("r05_final_kernel_stats.csv", "r04_final_kernel_stats.csv", "r03_final_kernel_stats.csv", "r02_final_kernel_stats.csv"):
+    for stats_name in ("r06_final_kernel_stats.csv", "r05_final_kernel_stats.csv", "r04_final_kernel_stats.csv", "r03_final_kernel_stats.csv", "r02_final_kernel_stats.csv"):
         stats = os.path.join(ROOT, "profiles", stats_name)
         if not os.path.exists(stats):
             continue
@@ -409,7 +409,7 @@ def committed_profile_figures(kernels, rows_per_launch):
         except Exception:
             pass
         break
-    for pmc_name in ("r05_final_pmc_traffic.json", "r04_final_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for pmc_name in ("r06_final_pmc_traffic.json", "r05_final_pmc_traffic.json", "r04_final_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if not os.path.exists(pmc):
             continue

@@ -95,10 +95,17 @@ hipError_t launch_freq_u(int nrows, hipStream_t s, const FreqArgs<T>& a) {
     constexpr int ROWS = freq_rows(N2, E);
     constexpr size_t lds = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<T>) : 0)
                          + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<T>);
+    if constexpr (MODE == FM_FWD_ONLY || MODE == FM_INV_ONLY) {
+        static hipError_t attr_h = allow_lds(k_freq_half<T, N2, ROWS, E, MODE, U16>, lds);
+        if (attr_h != hipSuccess) return attr_h;
+        hipLaunchKernelGGL((k_freq_half<T, N2, ROWS, E, MODE, U16>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, SSFM_FREQ_KERNEL_ARGS(a));
+        return hipGetLastError();
+    } else {
     static hipError_t attr = allow_lds(k_freq<T, N2, ROWS, E, MODE, U16>, lds);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((k_freq<T, N2, ROWS, E, MODE, U16>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, SSFM_FREQ_KERNEL_ARGS(a));
     return hipGetLastError();
+    }
 }
 template <typename T, int MODE, int N2, int E>
 hipError_t launch_freq_n2(int nrows, hipStream_t s, const FreqArgs<T>& a) {

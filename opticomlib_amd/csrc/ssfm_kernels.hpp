@@ -1601,6 +1601,23 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(cx<T>* F,
 #endif
     freq_body<T, N2, ROWS, E, MODE, U16, false>(a, blockIdx.x);
 }
+// The two halves of a split plan's row pass (FM_FWD_ONLY, FM_INV_ONLY: one transform, no operator, 113-122 registers) without the two-per-CU pin of k_freq: they
+// stream rows of a field that no cache holds (2^23 samples and more per row), and three or four workgroups per CU hide more of that latency than two.
+template <typename T, int N2, int ROWS, int E, int MODE, bool U16 = false>
+__global__ __launch_bounds__(ROWS * N2 / E) void k_freq_half(cx<T>* F, const cx<T>* tab, const cx<T>* tw2, const AdaptState<T>* st, T h, T amp, T inv_n, int step, int N1,
+                                                            int rows, int u16
+#if SSFM_TRACE
+                                                            , unsigned long long* trace, int trace_slot
+#endif
+                                                            ) {
+    static_assert(MODE == FM_FWD_ONLY || MODE == FM_INV_ONLY, "k_freq_half: the transform-only modes");
+    FreqArgs<T> a;
+    a.F = F; a.tab = tab; a.tw2 = tw2; a.st = st; a.h = h; a.amp = amp; a.inv_n = inv_n; a.step = step; a.N1 = N1; a.rows = rows; a.u16 = u16;
+#if SSFM_TRACE
+    a.trace = trace; a.trace_slot = trace_slot;
+#endif
+    freq_body<T, N2, ROWS, E, MODE, U16, false>(a, blockIdx.x);
+}
 #if SSFM_TRACE
 #define SSFM_FREQ_KERNEL_ARGS(a) (a).F, (a).tab, (a).tw2, (a).st, (a).h, (a).amp, (a).inv_n, (a).step, (a).N1, (a).rows, (a).u16, (a).trace, (a).trace_slot
 #else

@@ -1,5 +1,5 @@
 """The lanes test of the GPU suite, many times in one process: fresh two-lane plans of 2^19 x 2 beside 0 ... 5 other live plans, every plan's
-step time and what its lane health check had to do.   python tests/diag/lane_stability.py [rounds]  ->  gpurun_out/r05_lane_stability.txt"""
+step time and what its lane health check had to do.   python tests/diag/lane_stability.py [rounds]  ->  gpurun_out/lane_stability.txt"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -50,7 +50,8 @@ for r, k, first, best, i, t_make in rows:
 bests = np.array([x[3] for x in rows]); firsts = np.array([x[2] for x in rows]); makes = np.array([x[5] for x in rows])
 out.append(f"# {len(rows)} plans in {rounds} rounds: best-of-three us per step min {bests.min():.2f} median {np.median(bests):.2f} max {bests.max():.2f}; first run median {np.median(firsts):.2f} max {firsts.max():.2f}; "
            f"plans still slow after their first run (> 1.35 x the best plan): {slow}; run-time heals {heals}, streams remade at run time {remade}, plans dropped to one lane {dropped}; "
-           f"plan creation median {np.median(makes):.1f} ms max {makes.max():.1f} ms")
+           f"plan creation median {np.median(makes):.1f} ms max {makes.max():.1f} ms; pairs from the pool: {sum(1 for x in rows if x[4].get('lanes_from_pool'))}, "
+           f"ratings at plan creation in the process: {rows[-1][4].get('lane_ratings_total')}")
 print("\n".join(out[-12:]))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-open(os.path.join(ROOT, "gpurun_out", "r05_lane_stability.txt"), "w").write("\n".join(out) + "\n")
+open(os.path.join(ROOT, "gpurun_out", "lane_stability.txt"), "w").write("\n".join(out) + "\n")

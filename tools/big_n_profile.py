@@ -6,14 +6,14 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["TMPDIR"] = "/tmp"
-STEPS = 20
+STEPS = 100
 
 
 def short(name):
     m = re.match(r"(?:void )?(?:ssfm::)?(k_[a-z_]+)<([^>]*)>", name)
     if not m:
-        return name[:40]
-    return f"{m.group(1)}<{m.group(2)[:28]}>"
+        return name[:60]
+    return f"{m.group(1)}<{m.group(2)[:44]}>"
 
 
 def run(cmd, **kw):
@@ -40,18 +40,31 @@ for k in (21, 22, 23, 24):
                     acc[row["Kernel_Name"]].append(float(row["Counter_Value"]) * 1024)
         pmc[C] = {kk: sum(v) / len(v) for kk, v in acc.items()}
     n = 1 << k
-    print(f"   {'kernel':52s} {'calls':>6s} {'avg us':>9s} {'FETCHx2 MB':>11s} {'WRITE MB':>9s} {'algorithmic MB':>15s}")
-    tot_bytes = 0.0
+    # the kernels of a step (the plan's lanes run one launch of each per step, each over one row = one polarisation): two-kernel engine k_time<MID> + k_freq<PHASE>;
+    # split plans k_time<MID>, k_freq<FWD_ONLY>, k_split_mid, k_freq<INV_ONLY>.  (The other instantiations in the trace are BEGIN / END and the lane rating.)
+    def in_step(name):
+        if "k_split_mid" in name:
+            return True
+        m = re.search(r"k_time<[a-z]+, \d+, \d+, \d+, (\d+)", name)
+        if m:
+            return m.group(1) == "1"
+        m = re.search(r"k_freq<[a-z]+, \d+, \d+, \d+, (\d+)", name)
+        if m:
+            return m.group(1) in (("2", "5") if k > 22 else ("3",))
+        return False
+    print(f"   {'kernel (one launch = one lane = one polarisation)':62s} {'calls':>6s} {'avg us':>9s} {'FETCHx2 MB':>11s} {'WRITE MB':>9s} {'algorithmic MB':>15s}")
+    tot_bytes, tot_us = 0.0, 0.0
+    alg_launch = 2 * 8 * n                                          # one row read once + written once
     for name, (calls, us) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-        if calls < STEPS or not ("k_time" in name or "k_freq" in name or "k_split" in name):
+        if not in_step(name):
             continue
         fe, wr = pmc["FETCH_SIZE"].get(name), pmc["WRITE_SIZE"].get(name)
-        per_step = calls / (2.0 * STEPS)                      # launches per step (two runs of STEPS steps)
-        alg = 2 * 2 * 8 * n / max(per_step, 1e-9) if "k_split" not in name else 2 * 2 * 8 * n
         if fe is not None and wr is not None:
-            tot_bytes += per_step * (2 * fe + wr)
-        print(f"   {short(name):52s} {calls:6d} {us:9.2f} {'' if fe is None else f'{2 * fe / 1e6:11.1f}'} {'' if wr is None else f'{wr / 1e6:9.1f}'} {alg / 1e6:15.1f}")
+            tot_bytes += 2 * (2 * fe + wr)                          # two lanes
+        tot_us += us
+        print(f"   {short(name):62s} {calls:6d} {us:9.2f} {'' if fe is None else f'{2 * fe / 1e6:11.1f}'} {'' if wr is None else f'{wr / 1e6:9.1f}'} {alg_launch / 1e6:15.1f}")
     m = re.search(r"([\d.]+) us per step", plain)
     if m and tot_bytes:
         us = float(m.group(1))
-        print(f"   traffic per step {tot_bytes / 1e6:.0f} MB = {tot_bytes / (32.0 * n):.2f} x the algorithmic {32 * n / 1e6:.0f} MB; {tot_bytes / us / 1e6:.2f} TB/s at the un-profiled step time", flush=True)
+        print(f"   a lane's kernels of one step: {tot_us:.1f} us under the profiler; PMC traffic per step (both lanes) {tot_bytes / 1e6:.0f} MB = {tot_bytes / (32.0 * n):.2f} x the algorithmic "
+              f"{32 * n / 1e6:.0f} MB; {tot_bytes / us / 1e6:.2f} TB/s at the un-profiled step time; step_frac {32 * n / us * 1e6 / 8e12:.3f}", flush=True)
