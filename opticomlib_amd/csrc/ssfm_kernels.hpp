@@ -842,6 +842,8 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             w[0] = wA;
 #pragma unroll
             for (int t = 1; t < E; ++t) w[t] = cmul(wA, Bs[t * C + c]);
+            // (round 6 diagnostic, profiles/r06_fourstep_error.txt: these factors rounded ONCE from double instead of formed as a float32 product change the engines'
+            // distance from the float64 solution by nothing -- 1.25 / 1.50 / 1.71e-5 -> 1.21 / 1.53 / 1.74e-5 at 2^12 / 2^14 / 2^16 after 83 steps)
         }
         line_twiddles_fetch<T, N1, E>(tw, j, ldsT);
     }
