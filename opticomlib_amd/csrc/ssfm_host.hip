@@ -544,6 +544,7 @@ template <typename T> struct PlanT : PlanBase {
     bool dsplit_valid = false;
     bool sub_valid = true, nat_valid = false;
     bool is_split() const { return split_R > 1; }
+    int split_qf() const { return u16 ? N2 / Ef : 0; }          // the order of a sub-row between the row-pass halves: the plan's unit layout, or plain
     T inv_n_full() const { return (T)1 / (T)n_full; }
     // the sub-sequences are current in F (before a run)
     int ensure_sub() {
@@ -577,15 +578,18 @@ template <typename T> struct PlanT : PlanBase {
     // the row pass of a split plan: forward row transforms, the pointwise middle (twiddles, radix-R butterfly across the sub-sequences, operator, back),
     // inverse row transforms.  `table`: exp(D~ h) / N in the split order (SM_TABLE), or nullptr: formed in the launch from D~ (SM_FLY; `s` != nullptr:
     // the step size is the device's)
-    hipError_t split_freq(const cx<T>* table, T h, const AdaptState<T>* s, int step, int row0, int rows, hipStream_t st_) {
+    hipError_t split_freq(const cx<T>* table, T h, const AdaptState<T>* s, int step, int row0, int rows, hipStream_t st_, bool phase = false, T amp = (T)0) {
         FreqArgs<T> fa = fargs(nullptr, 0, s, row0, rows > 0 ? row0 / rows : 0);         // (`s`: launches behind the end of an adaptive run find `done` and leave)
         fa.step = step;
+        if (u16) fa.u16 = 2;                 // (the unit layout between the two halves as well: 16-byte accesses on both sides of k_split_mid)
         hipError_t e = launch_freq<T, FM_FWD_ONLY>(N2, N1 * rows, st_, fa, Ef);
         if (e != hipSuccess) return e;
         SplitArgs<T> sa;
         sa.Y = Y + (size_t)row0 * n; sa.G = table ? table : dsplit; sa.twA = split_twA; sa.twB = split_twB; sa.st = s; sa.h = h; sa.inv_n = inv_n_full();
-        sa.step = step; sa.N1 = N1; sa.N2 = N2; sa.rows_outer = rows / split_R;
-        e = table ? launch_split_mid<T, SM_TABLE>(split_R, st_, sa) : launch_split_mid<T, SM_FLY>(split_R, st_, sa);
+        sa.step = step; sa.N1 = N1; sa.N2 = N2; sa.rows_outer = rows / split_R; sa.Qf = split_qf();
+        sa.amp = amp;
+        if constexpr (sizeof(T) == 4) { if (table && phase) e = launch_split_mid<T, SM_PHASE>(split_R, st_, sa); else e = table ? launch_split_mid<T, SM_TABLE>(split_R, st_, sa) : launch_split_mid<T, SM_FLY>(split_R, st_, sa); }
+        else e = table ? launch_split_mid<T, SM_TABLE>(split_R, st_, sa) : launch_split_mid<T, SM_FLY>(split_R, st_, sa);
         if (e != hipSuccess) return e;
         return launch_freq<T, FM_INV_ONLY>(N2, N1 * rows, st_, fa, Ef);
     }
@@ -593,7 +597,7 @@ template <typename T> struct PlanT : PlanBase {
     int split_fly_ready() {
         if (dsplit_valid) return SSFM_OK;
         if (!dsplit) HIP_TRY(hipMalloc(&dsplit, sizeof(cx<T>) * (size_t)n_full));
-        hipLaunchKernelGGL((k_make_split_table<T, 0>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)dnat, dsplit, N1, N2, split_R, (T)0, inv_n_full());
+        hipLaunchKernelGGL((k_make_split_table<T, 0>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)dnat, dsplit, N1, N2, split_R, (T)0, inv_n_full(), split_qf());
         HIP_TRY(hipGetLastError());
         dsplit_valid = true;
         return SSFM_OK;
@@ -1411,9 +1415,12 @@ template <typename T> struct PlanT : PlanBase {
             t.valid = false;
             if (!t.ptr) HIP_TRY(hipMalloc(&t.ptr, sizeof(cx<T>) * n_full));
             t.kind = kind;
-            if (is_split())
+            if (is_split() && kind == 1)
+                hipLaunchKernelGGL(k_make_split_phase_table<T>, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream,
+                                   (const cx<T>*)dnat, reinterpret_cast<unsigned*>(t.ptr), N1, N2, split_R, distinct[i], split_qf());
+            else if (is_split())
                 hipLaunchKernelGGL((k_make_split_table<T, 2>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream,
-                                   (const cx<T>*)dnat, t.ptr, N1, N2, split_R, distinct[i], inv_n_full());
+                                   (const cx<T>*)dnat, t.ptr, N1, N2, split_R, distinct[i], inv_n_full(), split_qf());
             else if (one_line)
                 hipLaunchKernelGGL((k_make_freq_table<T, 2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                                    (const cx<T>*)dnat, t.ptr, 1, (int)n, (int)n / small_points<T>((int)n), distinct[i], inv_n());
@@ -1564,7 +1571,7 @@ template <typename T> struct PlanT : PlanBase {
         // a fibre's operator has one modulus for all frequencies: 4-byte phase tables (ssfm_kernels.hpp FM_PHASE)
         // (complex128: float64 turn fractions, 8 instead of 16 bytes per frequency -- measured -2.5 % at 2^20 x 2 (39.5 against 40.5 us per step) and
         // +5 % at 2^16 x 2, where nothing hides the float64 sincos: from 2^20 samples in all)
-        const bool use_phase = use_tables && phase_tables && op_flat_re && (sizeof(T) == 8 ? n * batch >= (1ll << 20) : u16) && !is_split();
+        const bool use_phase = use_tables && phase_tables && op_flat_re && (sizeof(T) == 8 ? n * batch >= (1ll << 20) && !is_split() : u16);      // (split plans: 4-byte phases in complex64)
         if (int rc = ensure_sub()) return rc;
         if (is_split() && !use_tables) if (int rc = split_fly_ready()) return rc;
         // plans of 2^12 ... 2^17 samples in the unit layout: the whole schedule in one launch on one XCD (ssfm_kernels.hpp k_medium).  Measured against the
@@ -1589,7 +1596,8 @@ template <typename T> struct PlanT : PlanBase {
                     for (size_t i = 0; i < distinct.size(); ++i)
                         if (std::memcmp(&distinct[i], &hs, sizeof(T)) == 0) tp = tabptr[i];
                 last_launches += 2;
-                return split_freq(tp, hs, nullptr, 0, row0, rows, st_);
+                const T xr = op_re0 * hs;
+                return split_freq(tp, hs, nullptr, 0, row0, rows, st_, use_phase, (T)std::exp((double)xr) * inv_n_full());
             }
             if (use_tables) {
                 const cx<T>* tp = nullptr;
@@ -2390,7 +2398,7 @@ template <typename T> struct PlanT : PlanBase {
         drop_operator();
         if (int rc = ensure_sub()) return rc;
         if (is_split())
-            hipLaunchKernelGGL((k_make_split_table<T, 1>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)dnat, hperm, N1, N2, split_R, (T)0, inv_n_full());
+            hipLaunchKernelGGL((k_make_split_table<T, 1>), dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, (const cx<T>*)dnat, hperm, N1, N2, split_R, (T)0, inv_n_full(), split_qf());
         else
         hipLaunchKernelGGL((k_make_freq_table<T, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            (const cx<T>*)dnat, hperm, N1, N2, N2 / Ef, (T)0, inv_n());
@@ -2423,7 +2431,7 @@ template <typename T> struct PlanT : PlanBase {
         const double val = 1.0 / ((double)n_full * dt_s);
         if (int rc = ensure_sub()) return rc;
         if (is_split())
-            hipLaunchKernelGGL(k_make_split_dm_table<T>, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, hperm, hnat, N1, N2, split_R, val, D_s2, inv_n_full());
+            hipLaunchKernelGGL(k_make_split_dm_table<T>, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, stream, hperm, hnat, N1, N2, split_R, val, D_s2, inv_n_full(), split_qf());
         else
         hipLaunchKernelGGL(k_make_dm_table<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                            hperm, hnat, N1, N2, N2 / Ef, val, D_s2, inv_n());

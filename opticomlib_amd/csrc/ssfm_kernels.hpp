@@ -1492,7 +1492,9 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     if constexpr (EARLY_PHASE) load_phases();
     if constexpr (EARLY_FLY) load_table();
     constexpr bool INV_ONLY = MODE == FM_INV_ONLY;
-    if (U16 && !INV_ONLY) {
+    // (a.u16 == 2: the two halves of a split plan's row pass keep the UNIT layout between them -- 16-byte accesses on both sides of k_split_mid, which is pointwise and
+    // only needs to know which frequency a position holds; a.u16 == 1: the plain transposed spectrum, what ssfm_debug's forward transform hands out)
+    if (U16 && (!INV_ONLY || a.u16 == 2)) {
         // U16 layout: register slots 2g and 2g+1 (elements j + Q 2g, j + Q (2g+1)) lie side by side in the row
         if constexpr (PK && sizeof(T) == 4) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Frow, 0, N2 * (int)sizeof(cx<T>), 0x00020000);
@@ -1556,6 +1558,15 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
     line_twiddles_fetch<T, N2, E>(tw, j, ldsT);
     if (!SSFM_ABL_NO_FFT && !INV_ONLY) fft_line<T, N2, E, -1, 0, RI>(v, lds, 0, j, idx, tw);
     if (MODE == FM_FWD_ONLY) {
+        if (U16 && a.u16 == 2) {
+#pragma unroll
+            for (int g = 0; g < E / 2; ++g) {
+                u4_t q;
+                q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
+                pass_store<PK>(reinterpret_cast<u4_t*>(Frow) + g * Q + j, q);
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < E; ++t) pass_store<PK>(&Frow[j + t * Q], v[t]);
         return;

@@ -14,8 +14,11 @@
 // One split step = k_time<MID> (unchanged: inverse column pass, both half rotations, forward column pass -- on sub-rows), k_freq<FM_FWD_ONLY> (row pass forward),
 // k_split_mid, k_freq<FM_INV_ONLY> (row pass inverse): FOUR passes over the field instead of two -- the minimum for a transform of three factors when the
 // pass on either side of the operator is fused with it and the passes on either side of the nonlinear step with each other.  Algorithmic bytes stay 2 P E per
-// sample and step; the design floor doubles.  Between k_freq<FM_FWD_ONLY> and k_freq<FM_INV_ONLY> a sub-row lies in the PLAIN
-// transposed order [k1][k2] (q = k1 + N1 k2) whatever the plan's layout between its own kernels is; k_split_mid is pointwise, so only its tables know the order.
+// sample and step; the design floor doubles.  Between the two halves of the row pass a sub-row keeps the plan's own order -- the 16-byte
+// unit layout of the complex64 plans (FreqArgs::u16 == 2), the plain transposed order [k1][k2] (q = k1 + N1 k2) otherwise; k_split_mid is pointwise, so only its
+// tables and its twiddle look-up know the order (split_k2_of_pos).  A fibre's operator (one modulus for all frequencies) travels as 4-byte phases in complex64
+// (SM_PHASE, as k_freq<FM_PHASE>): A/B over three rounds (profiles/r06_split_ab.txt): 2^23 x 2 203-207 -> 194 us per step, 2^24 x 2 450-479 -> 440-449; the unit
+// layout alone: nothing.
 #pragma once
 #include "ssfm_kernels.hpp"
 
@@ -24,7 +27,7 @@ namespace ssfm {
 constexpr int kSplitLog2M = 20;            // sub-sequence length of a split plan (env SSFM_SPLIT_LOG2M = 20 | 21 | 22 overrides: diagnostics)
 constexpr int kSplitMaxR = 16;
 
-enum SplitMode { SM_TABLE = 0, SM_FLY = 1 };
+enum SplitMode { SM_TABLE = 0, SM_FLY = 1, SM_PHASE = 2 };       // SM_PHASE (complex64, a fibre's operator: one modulus for all frequencies): 4-byte phases, as k_freq<FM_PHASE>
 
 template <typename T> struct SplitArgs {
     cx<T>* Y;                 // the sub-rows between the two row passes: rows_outer x R sub-rows of M, plain transposed order
@@ -34,10 +37,14 @@ template <typename T> struct SplitArgs {
     const AdaptState<T>* st;  // SM_FLY: step size source when non-null
     T h;                      // SM_FLY with st == nullptr
     T inv_n;                  // 1 / N (SM_FLY)
+    T amp;                    // SM_PHASE: exp(Re D~ h) / N, the modulus of every table entry
     int step;
     int N1, N2;
     int rows_outer;           // rows of N samples covered by this launch
+    int Qf;                   // > 0: the sub-rows lie in the plan's 16-byte-unit order between the row-pass halves (position -> k2 by u16_col_of_pos); 0: plain order
 };
+// the row frequency k2 at position `pos` of a sub-row between the two halves of the row pass
+__host__ __device__ __forceinline__ long long split_k2_of_pos(long long pos, int Qf) { return Qf > 0 ? u16_col_of_pos(pos, Qf) : pos; }
 
 // One thread: V consecutive positions (16 bytes) of all R sub-rows of every outer row -- twiddles and operator formed once, applied to every row.
 template <typename T, int R, int MODE>
@@ -48,7 +55,10 @@ __global__ __launch_bounds__(256) void k_split_mid(const SplitArgs<T> a) {
     const long long unit = (long long)blockIdx.x * 256 + threadIdx.x;
     if (unit * V >= M) return;
     const long long p0 = unit * V;
-    const int k1 = (int)(p0 / a.N2), k2 = (int)(p0 % a.N2);          // (N2 is even: the V positions share k1)
+    const int k1 = (int)(p0 / a.N2);                                 // (N2 is even: the V positions share k1)
+    int k2v[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) k2v[v] = (int)split_k2_of_pos(p0 % a.N2 + v, a.Qf);
     T h = a.h;
     if (MODE == SM_FLY && a.st != nullptr) {
         const StepState<T> S = a.st->cur[a.step & 1];
@@ -57,11 +67,22 @@ __global__ __launch_bounds__(256) void k_split_mid(const SplitArgs<T> a) {
     }
     // the operator of the R frequencies q + M p behind every position
     cx<T> g[R][V];
+    if constexpr (MODE == SM_PHASE) {
+        typedef unsigned uv_t __attribute__((ext_vector_type(V)));
+        const unsigned* Gu = reinterpret_cast<const unsigned*>(a.G);
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            const uv_t q = *reinterpret_cast<const uv_t*>(Gu + (long long)p * M + p0);
+#pragma unroll
+            for (int v = 0; v < V; ++v) g[p][v] = phase32_factor(q[v], a.amp);
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < R; ++p) {
         const v4_t q = *reinterpret_cast<const v4_t*>(a.G + (long long)p * M + p0);
 #pragma unroll
         for (int v = 0; v < V; ++v) g[p][v] = mk<T>(q[2 * v], q[2 * v + 1]);
+    }
     }
     if constexpr (MODE == SM_FLY) {
         // exp(D~ h) / N: the reference's products in T (devices.py:1179), as k_freq<FM_FLY> forms them
@@ -85,7 +106,7 @@ __global__ __launch_bounds__(256) void k_split_mid(const SplitArgs<T> a) {
         const double2 A = a.twA[s * a.N1 + k1];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const double2 B = a.twB[(long long)s * a.N2 + k2 + v];
+            const double2 B = a.twB[(long long)s * a.N2 + k2v[v]];
             w[s][v] = mk<T>((T)(A.x * B.x - A.y * B.y), (T)(A.x * B.y + A.y * B.x));
         }
     }
@@ -124,12 +145,12 @@ __global__ __launch_bounds__(256) void k_split_mid(const SplitArgs<T> a) {
 
 // out[p][k1][k2] = f(src[(k1 + N1 k2) + M p]); MODE 0: copy (D~ for SM_FLY), 1: * inv_n (a transfer function), 2: exp(src h) * inv_n (k_make_freq_table's arithmetic)
 template <typename T, int MODE>
-__global__ void k_make_split_table(const cx<T>* __restrict__ src, cx<T>* __restrict__ out, int N1, int N2, int R, T h, T inv_n) {
+__global__ void k_make_split_table(const cx<T>* __restrict__ src, cx<T>* __restrict__ out, int N1, int N2, int R, T h, T inv_n, int Qf) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long M = (long long)N1 * N2;
     if (o >= M * R) return;
     const long long p = o / M, r = o % M;
-    const long long k1 = r / N2, k2 = r % N2;
+    const long long k1 = r / N2, k2 = split_k2_of_pos(r % N2, Qf);
     cx<T> d = src[k1 + (long long)N1 * k2 + M * p];
     if (MODE == 1) { d.x *= inv_n; d.y *= inv_n; }
     if (MODE == 2) {
@@ -142,14 +163,27 @@ __global__ void k_make_split_table(const cx<T>* __restrict__ src, cx<T>* __restr
     }
     out[o] = d;
 }
+// phase table of exp(D~ h) in the split order (k_make_phase_table's arithmetic: the reference's float32 product Im(D~) h taken to double, the turn fraction in 32 bits)
+template <typename T>
+__global__ void k_make_split_phase_table(const cx<T>* __restrict__ src, unsigned* __restrict__ out, int N1, int N2, int R, T h, int Qf) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long M = (long long)N1 * N2;
+    if (o >= M * R) return;
+    const long long p = o / M, r = o % M;
+    const long long k1 = r / N2, k2 = split_k2_of_pos(r % N2, Qf);
+    const T xi = src[k1 + (long long)N1 * k2 + M * p].y * h;
+    double turns = (double)xi * 0.15915494309189533577;
+    turns -= floor(turns);
+    out[o] = (unsigned)(unsigned long long)llrint(turns * 4294967296.0);
+}
 // DM transfer function in the split order (k_make_dm_table's arithmetic on the grid of N = R M frequencies); `nat` != nullptr: H in natural order as well
 template <typename T>
-__global__ void k_make_split_dm_table(cx<T>* __restrict__ out, cx<T>* __restrict__ nat, int N1, int N2, int R, double val, double D, T inv_n) {
+__global__ void k_make_split_dm_table(cx<T>* __restrict__ out, cx<T>* __restrict__ nat, int N1, int N2, int R, double val, double D, T inv_n, int Qf) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long M = (long long)N1 * N2, N = M * R;
     if (o >= N) return;
     const long long p = o / M, r = o % M;
-    const long long k = (r / N2) + (long long)N1 * (r % N2) + M * p;
+    const long long k = (r / N2) + (long long)N1 * split_k2_of_pos(r % N2, Qf) + M * p;
     const long long ks = k < (N + 1) / 2 ? k : k - N;
     const double w = ((double)ks * val) * 2.0 * 3.141592653589793;
     const double ph = ((w * w) * D) / 2.0;

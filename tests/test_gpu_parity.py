@@ -3204,7 +3204,10 @@ def test_a_rated_pair_of_lane_streams_outlives_its_plan(monkeypatch):
             assert p.lanes == 2
             p.set_linear_operator(D); p.set_field(a)
             p.propagate_fixed(1.3, hs); p.synchronize()
-            t0 = time.perf_counter(); p.propagate_fixed(1.3, hs); p.synchronize(); t = time.perf_counter() - t0
+            t = None
+            for rep in range(3):              # (the best of three: a box that is still waking up is slow once)
+                t0 = time.perf_counter(); p.propagate_fixed(1.3, hs); p.synchronize(); el = time.perf_counter() - t0
+                t = el if t is None else min(t, el)
             p.set_field(a); p.propagate_fixed(1.3, hs)
             outs.append(p.get_field())
             info = p.last_run_info()

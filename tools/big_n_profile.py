@@ -48,7 +48,7 @@ for k in (21, 22, 23, 24):
         m = re.search(r"k_time<[a-z]+, \d+, \d+, \d+, (\d+)", name)
         if m:
             return m.group(1) == "1"
-        m = re.search(r"k_freq<[a-z]+, \d+, \d+, \d+, (\d+)", name)
+        m = re.search(r"k_freq(?:_half)?<[a-z]+, \d+, \d+, \d+, (\d+)", name)
         if m:
             return m.group(1) in (("2", "5") if k > 22 else ("3",))
         return False
