@@ -147,7 +147,7 @@ hipError_t launch_freq(int N2, int nrows, hipStream_t s, FreqArgs<T> a, int E) {
 
 template <typename T, int MODE, int R>
 hipError_t launch_split_mid_r(hipStream_t s, const SplitArgs<T>& a) {
-    constexpr int V = sizeof(T) == 4 ? 2 : 1;
+    constexpr int V = split_positions<T, R>();
     const long long units = (long long)a.N1 * a.N2 / V;
     hipLaunchKernelGGL((k_split_mid<T, R, MODE>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

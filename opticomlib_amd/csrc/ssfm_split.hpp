@@ -46,10 +46,13 @@ template <typename T> struct SplitArgs {
 // the row frequency k2 at position `pos` of a sub-row between the two halves of the row pass
 __host__ __device__ __forceinline__ long long split_k2_of_pos(long long pos, int Qf) { return Qf > 0 ? u16_col_of_pos(pos, Qf) : pos; }
 
-// One thread: V consecutive positions (16 bytes) of all R sub-rows of every outer row -- twiddles and operator formed once, applied to every row.
+// One thread: V consecutive positions (16 bytes) of all R sub-rows of every outer row -- twiddles and operator formed once, applied to every row.  R = 16 in complex64
+// needs 256 VGPRs + 42 AGPRs (one wave per SIMD); the same kernel with ONE position per thread (166 VGPRs, three waves per SIMD, 8-byte accesses) takes the same time
+// (2^24 x 2: 441-450 against 446-449 us per step, profiles/r06_split_ab.txt): sixteen 8 MiB-apart streams per wavefront are bound by the memory system, not by occupancy.
+template <typename T, int R> __host__ __device__ constexpr int split_positions() { return sizeof(T) == 4 ? 2 : 1; }
 template <typename T, int R, int MODE>
 __global__ __launch_bounds__(256) void k_split_mid(const SplitArgs<T> a) {
-    constexpr int V = sizeof(T) == 4 ? 2 : 1;
+    constexpr int V = split_positions<T, R>();
     typedef T v4_t __attribute__((ext_vector_type(V * 2)));
     const long long M = (long long)a.N1 * a.N2;
     const long long unit = (long long)blockIdx.x * 256 + threadIdx.x;
