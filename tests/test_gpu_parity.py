@@ -3223,3 +3223,67 @@ def test_a_rated_pair_of_lane_streams_outlives_its_plan(monkeypatch):
     for o in outs[1:]:
         np.testing.assert_array_equal(o, outs[0])
     print(f"plan creation: {created[0] * 1e3:.1f} ms with a rating, {min(created[1:]) * 1e3:.1f} ms with a pooled pair")
+
+
+def test_scalar_log_of_a_capture_against_the_oracle():
+    """The per-step scalars of ssfm_propagate_fixed_capture (mean and maximum of |A|^2 of every row after every step, accumulated inside the column kernels) against the
+    ORACLE's every-step fields -- round 5 checked the log against the library's own snapshots only."""
+    gv(**workloads.BENCH_GV)
+    n = 1 << 14
+    a = workloads.qpsk_field(n, seed=33, n_pol=2, power_w=4e-3)
+    kw = dict(length=23 * 0.25, h=0.25, **workloads.SMF)
+    zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+    want_power = np.mean(np.abs(Ar.astype(np.complex128)) ** 2, axis=-1)          # (steps + 1, 2)
+    want_peak = np.max(np.abs(Ar.astype(np.complex128)) ** 2, axis=-1)
+    p = _lib.Plan(n, 2, _lib.C64)
+    try:
+        p.set_linear_operator(oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13))
+        p.set_field(a.astype(np.complex64))
+        cap = p.propagate_fixed_capture(1.3, np.full(23, 0.25, np.float32), every=23, scalars=True)
+    finally:
+        p.close()
+    assert cap["power"].shape == want_power.shape == (24, 2)
+    np.testing.assert_allclose(cap["power"], want_power, rtol=2e-5)                # (the log sums |A|^2 in float32; the fields themselves agree to 2e-5 of the peak)
+    np.testing.assert_allclose(cap["peak"], want_peak, rtol=1e-4)
+    assert within(cap["fields"][-1], Ar[-1], kw=kw, what="oracle, the capture run's end field")
+
+
+def test_split_plans_with_odd_row_counts_and_through_the_sharded_entry_point(monkeypatch):
+    """Split plans whose rows do not pair into two lanes (three rows: one lane), a single row, and the batched plan behind dist.propagate_channels (four rows of two
+    independent fields) -- each row against the same row propagated alone on the direct engine (SSFM_SPLIT_ABOVE=20: 2^21 samples as two sub-sequences)."""
+    from opticomlib_amd import dist as od
+    gv(**workloads.BENCH_GV)
+    n = 1 << 21
+    f = np.stack([workloads.qpsk_field(n, seed=70 + k, n_pol=2, power_w=3e-3) for k in range(2)]).astype(np.complex64)      # (2 fields, 2 pols, n)
+    rows = f.reshape(4, n)
+    hs = np.full(3, 0.25, np.float32)
+    D = oa.devices.linear_operator(n, gv.dt, 0.2, -21.7, 0.13)
+    monkeypatch.delenv("SSFM_SPLIT_ABOVE", raising=False)
+    want = []
+    for r in rows[:3]:
+        p = _lib.Plan(n, 1, _lib.C64)
+        try:
+            p.set_linear_operator(D); p.set_field(r.reshape(1, n)); p.propagate_fixed(1.3, hs)
+            want.append(p.get_field()[0])
+            assert p.last_run_info()["engine"] == "two_kernel"
+        finally:
+            p.close()
+    monkeypatch.setenv("SSFM_SPLIT_ABOVE", "20")
+    oa.devices.release_plans()
+    for batch in (3, 1):
+        p = _lib.Plan(n, batch, _lib.C64)
+        try:
+            p.set_linear_operator(D); p.set_field(rows[:batch]); p.propagate_fixed(1.3, hs)
+            got = p.get_field()
+            info = p.last_run_info()
+            assert info["engine"] == "split" and info["lanes"] == 1, info
+        finally:
+            p.close()
+        for k in range(batch):
+            assert within(got[k], want[k], tol_at(3), steps=3, what=f"split plan of {batch} row(s), row {k}, against the direct engine")
+    outs = od.propagate_channels(f, gv.dt, length=0.75, h=0.25, **workloads.SMF)
+    assert within(outs[0], np.stack(want[:2]), tol_at(3), steps=3, what="split plans behind dist.propagate_channels against the direct engine")
+    back = od.propagate_channels(f[:1], gv.dt, dbp=True, length=0.75, h=0.25, **workloads.SMF)                               # FIBER + DBP on a resident split plan
+    ref = orc.dbp_c64(orc.fiber_c64(f[0], gv.dt, length=0.75, h=0.25, **workloads.SMF), gv.dt, length=0.75, h=0.25, **workloads.SMF)
+    assert within(back[0], ref, steps=6, what="oracle FIBER + DBP, 2^21 x 2 as split plans")
+    oa.devices.release_plans()
