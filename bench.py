@@ -359,6 +359,47 @@ def secondary_c1(a, dt, fibre, device):
             "note": "algorithmic bytes 64 B per sample*step (complex128); not part of `value`"}
 
 
+def secondary_big(dt, fibre, device, log2n=24, steps=20):
+    """The largest field the library takes (round 6: 2^24 samples x 2 polarisations, a "split plan" -- DESIGN.md 5b), reported beside the headline: 20 of C2's steps on a
+    synthetic complex64 field (band-limited noise: the content does not matter to the timing), with the one property that can be checked without an oracle run of minutes --
+    the energy follows the float32 attenuation factor (every other operator of a step is unitary)."""
+    import numpy as np
+    from opticomlib_amd import _lib, devices
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n)
+    a = np.empty((N_POL, n), dtype=np.complex64)
+    for r in range(N_POL):                                   # (smoothed white noise, 1 mW per polarisation; built row by row: 2^24 samples per call)
+        w = (rng.standard_normal(n, dtype=np.float32) + 1j * rng.standard_normal(n, dtype=np.float32)).astype(np.complex64)
+        w = w + np.roll(w, 1) + np.roll(w, 2) + np.roll(w, 3)
+        a[r] = w * np.float32(np.sqrt(1e-3 / np.mean(np.abs(w[: 1 << 16]) ** 2)))
+    hs = np.full(steps, H_KM, np.float32)
+    p = _lib.Plan(n, N_POL, _lib.C64, device=device)
+    try:
+        p.set_linear_operator(devices.linear_operator(n, dt, fibre["alpha"], fibre["beta_2"], fibre["beta_3"], _lib.C64))
+        p.set_field(a)
+        p.propagate_fixed(fibre["gamma"], hs)
+        p.synchronize()
+        y = p.get_field()
+        e_in = np.sum(np.abs(a.astype(np.complex128)) ** 2, axis=-1)
+        e_out = np.sum(np.abs(y.astype(np.complex128)) ** 2, axis=-1)
+        att = float(np.exp(np.complex64(-np.float32(fibre["alpha"] / 4.343) / 2) * np.float32(H_KM)).real)
+        energy_err = float(np.max(np.abs(e_out / e_in / att ** (2 * steps) - 1.0)))
+        reps = 3
+        t = time.perf_counter()
+        for _ in range(reps):
+            p.propagate_fixed(fibre["gamma"], hs)
+        p.synchronize()
+        el = (time.perf_counter() - t) / reps
+        info = p.last_run_info()
+    finally:
+        p.close()
+    rate = n * steps / el
+    return {"workload": f"2^{log2n}-sample dual-pol field (256 MiB), complex64, {steps} of C2's steps (h = {H_KM} km), synthetic band-limited noise", "dtype": "c64", "engine": info["engine"],
+            "value": rate, "unit": "sample*steps/s", "us_per_ssfm_step": el / steps * 1e6, "step_frac": 2 * N_POL * 8 * rate / (HBM_PEAK_GBS * 1e9),
+            "energy_against_attenuation": energy_err,
+            "note": "rows of more than 2^22 samples run as split plans: four passes per step (DESIGN.md 5b); algorithmic bytes 32 B per sample*step; not part of `value`"}
+
+
 def _manycore_worker(job):
     seed, dt, fibre, steps = job
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -627,6 +668,7 @@ def main():
     cpu = None
     cpu_many = None
     other = None
+    big = None
     if rank == 0:
         per_gpu_rate = value * fields_here / max(total_fields, 1)
         roofline = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
@@ -696,6 +738,10 @@ def main():
             })
         if world == 1 and workload == "c2" and not args.no_secondary:
             other = secondary_c1(a_c2, dt, fibre, local_rank)
+            try:
+                big = secondary_big(dt, fibre, local_rank)
+            except Exception as e:                               # (reported, never fatal: the headline line stands on its own)
+                big = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.cpu_steps > 0:
             if a_c2 is None:
                 a_c2 = workloads.qpsk_field(n, seed=2024, n_pol=N_POL)
@@ -751,6 +797,7 @@ def main():
         "cpu_baseline": cpu,
         **({"cpu_baseline_manycore": cpu_many} if cpu_many else {}),
         **({"secondary": other} if other else {}),
+        **({"secondary_big_field": big} if big else {}),
         "cpu_affinity": cpu_affinity,
     })
 
