@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +112,7 @@ struct Workspace {
     unsigned long long* link_U = nullptr;    // totals that carry their own validity: 16-byte units {value, tag} (sos_filter_impl.inc group_start)
     size_t link_U_cap = 0;
     unsigned long long link_tag = 0;         // the call counter the tags are; never repeated, never 0
+    int look = 1 << 30;                      // powers of the group map that matter for the filter of `table_key` (sos_filter_impl.inc group_start_near)
     unsigned epoch = 0;
     int* status = nullptr;
     int give_ups = 0;                    // calls IN A ROW that fell back to three launches after waiting in vain; from kMaxGiveUps on the form rests
@@ -146,6 +148,11 @@ constexpr int kMaxGiveUps = 3, kRestCalls = 1000;
 inline bool one_launch_enabled() {
     const char* e = std::getenv("SSFM_SOS_ONE_LAUNCH");
     return !(e && std::atoi(e) == 0);
+}
+// SSFM_SOS_NEAR=0: a group's start state from ALL the earlier totals of its row, whatever the group map's powers are (read per call)
+inline bool sos_near_enabled() {
+    const char* e = std::getenv("SSFM_SOS_NEAR");
+    return !(e && e[0] == '0');
 }
 // how long a workgroup waits for a total before it gives the call up, in 10 ns ticks (SSFM_SOS_PATIENCE_US, default 2 ms)
 inline long long one_launch_patience() {
