@@ -68,8 +68,21 @@ constexpr int kWave = 64;          // lanes per wavefront
 // (first version: 1 -> 131 us); 2^20 real 45 / 48-50 / 43; but the short calls of a 2^14 ... 2^16-sample link, which
 // are a latency chain of four small kernels, run 11-12 % faster with 2 (2^16 real 32.3 -> 28.5 us, 2^14 complex 38.1 ->
 // 34.0): `sos_waves()` picks 2 up to kSmallChunks chunks in all, SOS_WAVES above.
+// Round 6: the small shape is ONE wavefront (SOS_WAVES_SMALL) and is taken wherever its grid is resident at once -- with the look-back near
+// (sos_filter_impl.inc group_start_near) a smaller group costs nothing and has no carry between wavefronts: 4-15 % under two wavefronts from 2^14 to
+// 2^20 samples (profiles/r06_sos_w1.txt), 15-25 % under the shapes round 5 chose for 2^17 ... 2^20 (profiles/r06_sos_shape_sweep.txt).  Asking the
+// compiler for three wavefronts per SIMD so that 2^20 x 2 complex128 fits too (SOS_SMALL_EU=3): no gain there, 2-4 us lost at 2^18 x 2 -- stays 1.
 constexpr int kWavesLarge = SOS_WAVES;
-constexpr int kWavesSmall = 2;
+#ifndef SOS_WAVES_SMALL
+#define SOS_WAVES_SMALL 1
+#endif
+#ifndef SOS_SMALL_EU
+#define SOS_SMALL_EU 1
+#endif
+#ifndef SOS_SMALL_AHEAD
+#define SOS_SMALL_AHEAD 1
+#endif
+constexpr int kWavesSmall = SOS_WAVES_SMALL;
 constexpr long long kSmallChunks = 16384;
 constexpr int kMaxSections = 4;    // Bessel orders up to 8
 
@@ -112,6 +125,9 @@ struct Workspace {
     unsigned long long* link_U = nullptr;    // totals that carry their own validity: 16-byte units {value, tag} (sos_filter_impl.inc group_start)
     size_t link_U_cap = 0;
     unsigned long long link_tag = 0;         // the call counter the tags are; never repeated, never 0
+    double* meet_tab = nullptr;              // the single-meeting kernels' maps (sos_filter_impl.inc build_meet_tables), for the filter and row end of `meet_key`
+    size_t meet_cap = 0;
+    std::vector<double> meet_key;
     int look = 1 << 30;                      // powers of the group map that matter for the filter of `table_key` (sos_filter_impl.inc group_start_near)
     unsigned epoch = 0;
     int* status = nullptr;
@@ -154,6 +170,30 @@ inline bool sos_near_enabled() {
     const char* e = std::getenv("SSFM_SOS_NEAR");
     return !(e && e[0] == '0');
 }
+// SSFM_SOS_MEET=1: ONE meeting of the workgroups per call instead of two (sos_filter_impl.inc meet_states; read per call).  Built for the verdict of round 5,
+// correct (the parity tests run it), and NOT the default: the wait it saves (2.8 us at 2^20 x 2 once the look-back is near) is paid back by the second pass over
+// the forward outputs and by the contention of workgroups that no wait takes out of step any more -- 27.7-28.8 us against 26.8-27.2 (profiles/r06_sos_meet_ab.txt).
+inline bool sos_meet_enabled() {
+    const char* e = std::getenv("SSFM_SOS_MEET");
+    return e && e[0] == '1';
+}
+// A sufficient condition, from the cascade's poles alone, for the powers of the map over `len` samples to be negligible within kNearCertain groups (the
+// kernels' own test is on the matrices the host builds, Workspace::look; this one lets the dispatcher choose a shape before any table exists): the largest
+// pole modulus r has r^(len * kNearCertain) < 1e-60 -- twenty orders below the kernels' threshold for whatever the transient in front of the decay is.
+constexpr int kNearCertain = 4;
+template <int NS> bool near_is_certain(const SosCoefs& c, long long len) {
+    if (!sos_near_enabled()) return false;
+    double r2 = 0.0;
+    for (int s = 0; s < NS; ++s) {
+        const double a1 = c.a1[s], a2 = c.a2[s], disc = a1 * a1 - 4.0 * a2;
+        double m2;
+        if (disc < 0.0) m2 = a2;                                             // a complex pair: |z|^2 = a2
+        else { const double z = 0.5 * (std::fabs(a1) + std::sqrt(disc)); m2 = z * z; }
+        r2 = m2 > r2 ? m2 : r2;
+    }
+    if (!(r2 < 1.0)) return false;
+    return 0.5 * std::log(r2) * (double)len * kNearCertain < -138.2;          // ln 1e-60
+}
 // how long a workgroup waits for a total before it gives the call up, in 10 ns ticks (SSFM_SOS_PATIENCE_US, default 2 ms)
 inline long long one_launch_patience() {
     if (const char* e = std::getenv("SSFM_SOS_PATIENCE_US")) { const long long v = std::atoll(e); if (v > 0) return v * 100; }
@@ -180,8 +220,22 @@ int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const dou
                long long n, int rows, int edge, bool on_device) {
     if (kWavesSmall != kWavesLarge && sos_waves(n, rows, edge) == kWavesSmall)
         return chunk_short::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+    // Round 6: with the look-back near (group_start_near) the two-wavefront shape is the fastest wherever its grid is resident at once, not only for short
+    // calls -- 2^20 float64 15.6 us against 18.0, 2^19 x 2 complex128 20.6 against 22.9 (profiles/r06_sos_shape_sweep.txt; orders up to 4, which were measured)
+    const bool forced = std::getenv("SOS_WAVES_FORCE") != nullptr;
+    if (kWavesSmall != kWavesLarge && !forced && chunk_short::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
+        return chunk_short::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+    // ... then the short chunk in four wavefronts while that is at most ONE workgroup per CU (orders 4 to 8: 15.5 / 34 / 42 us against the long chunk's 17 / 37 / 45),
+    // the long chunk above (two workgroups per CU hold what three of the short one would)
+    if (!forced && !std::getenv("SSFM_SOS_LONG_CHUNK")) {
+        const long long groups = ((n + 2ll * edge + chunk_short::kChunk - 1) / chunk_short::kChunk + kWave * kWavesLarge - 1) / (kWave * kWavesLarge);
+        static int cus = 0;
+        if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v; }
+        if (cus > 0 && groups * rows <= cus && chunk_short::one_launch_would_run<NS, CH, kWavesLarge>(w, c, n, rows, edge))
+            return chunk_short::run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+    }
     const char* e = std::getenv("SSFM_SOS_LONG_CHUNK");
-    if (!(e && std::atoi(e) == 0) && chunk_long::one_launch_would_run<NS, CH, kWavesLarge>(w, n, rows, edge))
+    if (!(e && std::atoi(e) == 0) && chunk_long::one_launch_would_run<NS, CH, kWavesLarge>(w, c, n, rows, edge))
         return chunk_long::run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
     return chunk_short::run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
 }

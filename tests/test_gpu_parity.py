@@ -1461,14 +1461,14 @@ def test_operator_tables_of_one_schedule_do_not_evict_each_other():
         assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("waves", ["2", "4"])
+@pytest.mark.parametrize("waves", ["1", "4"])
 def test_sosfiltfilt_both_workgroup_shapes(waves, monkeypatch):
-    """The filter kernels exist with 2 and with 4 wavefronts per workgroup and pick by the size of the call
-    (sos_filter.hip `sos_waves`); here both shapes run every size, across their group boundaries (64 W chunks of 12)."""
+    """The filter kernels exist with 1 (round 6; 2 before) and with 4 wavefronts per workgroup and pick by the size of the call
+    (sos_filter.hip `run_filter`); here both shapes run every size, across their group boundaries (64 W chunks of 12)."""
     from scipy import signal as sg
     monkeypatch.setenv("SOS_WAVES_FORCE", waves)
     # (... and of 18: with four wavefronts a call that fits the one-launch form takes the long chunk; 18 * 64 = 1152 per wavefront, 4608 per group)
-    for order, n in ((4, 1530), (4, 1537), (4, 3060), (4, 3073), (3, 12 * 128 * 7 + 5), (8, 12 * 256 * 3 - 31), (4, (1 << 18) + 3),
+    for order, n in ((4, 768 - 30), (4, 768 - 29), (4, 3 * 768 - 30 + 1), (4, 1530), (4, 1537), (4, 3060), (4, 3073), (3, 12 * 128 * 7 + 5), (8, 12 * 256 * 3 - 31), (4, (1 << 18) + 3),
                      (4, 4608 - 30), (4, 4608 - 29), (4, 2 * 4608 - 30 - 18), (2, 1152 * 3 - 18), (5, 18 * 256 * 5 + 1), (4, 18 * 64 * 9 - 30 + 17)):
         sos = sg.bessel(order, 0.07 if n > 4096 else 0.2, "low", norm="mag", output="sos")
         zi = sg.sosfilt_zi(sos)
@@ -1478,7 +1478,7 @@ def test_sosfiltfilt_both_workgroup_shapes(waves, monkeypatch):
         xc = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n)))
         assert within(_lib.sosfiltfilt(sos, zi, xc), sg.sosfiltfilt(sos, xc, axis=-1), TOL_FILT)
         # the other shape right after: the tables of the group level are rebuilt for it
-        monkeypatch.setenv("SOS_WAVES_FORCE", "4" if waves == "2" else "2")
+        monkeypatch.setenv("SOS_WAVES_FORCE", "4" if waves == "1" else "1")
         assert within(_lib.sosfiltfilt(sos, zi, x), sg.sosfiltfilt(sos, x), TOL_FILT)
         monkeypatch.setenv("SOS_WAVES_FORCE", waves)
 
@@ -1539,6 +1539,37 @@ def test_sosfiltfilt_in_one_launch_and_in_three(order, n, rows, cplx, monkeypatc
     assert within(one, three, 1e-13)
     if order <= 4:
         assert launches_default == 1                                   # (orders 5 to 8 fit one workgroup per CU: the longest calls fall back)
+
+
+@pytest.mark.parametrize("wn", [0.3, 0.06, 0.004, 0.0012, 0.0003])
+@pytest.mark.parametrize("n,rows,cplx", [(1 << 18, 2, True), (60000, 1, False), (1 << 20, 1, False)])
+def test_sosfiltfilt_start_states_from_the_totals_that_matter(wn, n, rows, cplx, monkeypatch):
+    """Round 6: a workgroup of the one-launch form builds its start state from the nearest totals only, as many as the powers of the group map stay
+    above 1e-40 (one at these cut-offs down to fs / 500, two or three below, ALL of them -- the round-5 path -- for the narrowest here).  Same result as
+    with every total (SSFM_SOS_NEAR=0), and SciPy's within the filter's conditioning."""
+    from scipy import signal as sg
+    sos = sg.bessel(4, wn, "low", norm="mag", output="sos")
+    zi = sg.sosfilt_zi(sos)
+    rng = np.random.default_rng(int(n + 1e5 * wn))
+    x = rng.standard_normal((rows, n)).cumsum(axis=-1) * 0.02 + rng.standard_normal((rows, n))
+    if cplx:
+        x = x + 1j * rng.standard_normal((rows, n))
+    want = sg.sosfiltfilt(sos, x, axis=-1)
+    bound = max(TOL_FILT, 5 * 5e-20 * (2.0 / wn) ** 3)                  # (DESIGN.md section 7: conditioning of the chunked recurrence)
+    monkeypatch.delenv("SSFM_SOS_NEAR", raising=False)
+    near = _lib.sosfiltfilt(sos, zi, x)
+    assert _lib.sosfiltfilt_last_launches() == 1
+    monkeypatch.setenv("SSFM_SOS_NEAR", "0")
+    every = _lib.sosfiltfilt(sos, zi, x)
+    assert _lib.sosfiltfilt_last_launches() == 1
+    assert within(near, want, bound) and within(every, want, bound)
+    assert within(near, every, max(1e-13, bound / 10))
+    # ... and the ONE-meeting kernels (opt-in: they are not faster, DESIGN.md section 7; taken when the look-back is at most two groups, else the default runs)
+    monkeypatch.delenv("SSFM_SOS_NEAR", raising=False)
+    monkeypatch.setenv("SSFM_SOS_MEET", "1")
+    met = _lib.sosfiltfilt(sos, zi, x)
+    assert _lib.sosfiltfilt_last_launches() == 1
+    assert within(met, want, bound) and within(met, near, max(1e-13, bound / 10))
 
 
 def test_sosfiltfilt_one_launch_gives_up_cleanly(monkeypatch):

@@ -19,7 +19,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   rm -rf ${T}_sq
   rocprofv3 --pmc $set --output-format csv -d ${T}_sq -- python3 $R/tools/sos_prof.py > /dev/null 2> ${T}_sq.err
-  python3 $R/tools/sq_summary.py ${T}_sq "filtfilt_c=k_filtfilt<2, 2, 4>" "filtfilt_r=k_filtfilt<2, 1, 4>" >> ${T}_sq.txt
+  python3 $R/tools/sq_summary.py ${T}_sq "filtfilt_c=k_filtfilt<2, 2, 4" "filtfilt_r=k_filtfilt<2, 1, 1" >> ${T}_sq.txt
 done
 find ${T}_sq -name "*.csv" -size +1M -delete
 if [ -f $R/build/var/_ssfm_tl.so ]; then
