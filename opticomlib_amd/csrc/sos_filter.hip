@@ -223,8 +223,16 @@ int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const dou
     // Round 6: with the look-back near (group_start_near) the two-wavefront shape is the fastest wherever its grid is resident at once, not only for short
     // calls -- 2^20 float64 15.6 us against 18.0, 2^19 x 2 complex128 20.6 against 22.9 (profiles/r06_sos_shape_sweep.txt; orders up to 4, which were measured)
     const bool forced = std::getenv("SOS_WAVES_FORCE") != nullptr;
+    if (const char* l1 = std::getenv("SSFM_SOS_LONG1")) {          // (1, dev aid: the long chunk in one wavefront BEFORE the short one)
+        if (l1[0] == '1' && chunk_long::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
+            return chunk_long::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+    }
     if (kWavesSmall != kWavesLarge && !forced && chunk_short::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
         return chunk_short::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+    // ... then one wavefront with the LONG chunk (SSFM_SOS_LONG1=0: never)
+    if (kWavesSmall != kWavesLarge && !forced && !std::getenv("SSFM_SOS_LONG_CHUNK") && !(std::getenv("SSFM_SOS_LONG1") && std::getenv("SSFM_SOS_LONG1")[0] == '0') &&
+        chunk_long::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
+        return chunk_long::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
     // ... then the short chunk in four wavefronts while that is at most ONE workgroup per CU (orders 4 to 8: 15.5 / 34 / 42 us against the long chunk's 17 / 37 / 45),
     // the long chunk above (two workgroups per CU hold what three of the short one would)
     if (!forced && !std::getenv("SSFM_SOS_LONG_CHUNK")) {

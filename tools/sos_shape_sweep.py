@@ -1,4 +1,4 @@
-"""Zero-phase filter: kernel time over sizes for the three workgroup shapes (short chunk x 2 or 4 wavefronts, long chunk x 4), to place the dispatcher's thresholds.
+"""Zero-phase filter: kernel time over sizes for three workgroup shapes (short chunk x 1 or 4 wavefronts, long chunk x 4) and the dispatcher's own choice (which also has the long chunk x 1), to place the dispatcher's thresholds.
     python tools/sos_shape_sweep.py  (GPU box)"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,7 +6,7 @@ from opticomlib_amd import _lib
 from scipy import signal as sg
 ORDER = int(os.environ.get("ORDER", "4"))
 sos = sg.bessel(ORDER, 0.05, "low", norm="mag", output="sos"); zi = sg.sosfilt_zi(sos)
-variants = (("short x2", {"SOS_WAVES_FORCE": "2"}), ("short x4", {"SOS_WAVES_FORCE": "4", "SSFM_SOS_LONG_CHUNK": "0"}), ("long x4", {"SOS_WAVES_FORCE": "4"}), ("default", {}))
+variants = (("short x1", {"SOS_WAVES_FORCE": "1"}), ("short x4", {"SOS_WAVES_FORCE": "4", "SSFM_SOS_LONG_CHUNK": "0"}), ("long x4", {"SOS_WAVES_FORCE": "4"}), ("default", {}))
 print("shape".ljust(28) + "".join(v[0].rjust(12) for v in variants) + "   (kernels, us; * = three launches)")
 for cplx, rows in ((False, 1), (True, 1), (True, 2)):
     for lg in range(int(os.environ.get("LG0", "13")), 21):
