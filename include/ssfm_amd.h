@@ -318,7 +318,10 @@ SSFM_API int ssfm_chirp_setup(ssfm_plan* plan, int64_t plan_n, int64_t n);
  * (HOST, nullable, max_steps + 1 doubles) receives z after every step, *steps_out the steps taken.  Engines, chosen inside: the whole run in one
  * launch for plan_n <= 4096 (a workgroup per row); four launches per fixed step for schedules of up to four step sizes (the chirps of neighbouring
  * steps cancel: one pointwise launch before and after the run); five otherwise, seven per adaptive step.  A caller that wants the field after
- * every step (return_steps) calls it a step at a time (nsteps = 1, or max_steps = 1 over the rest of the length).  Synchronous. */
+ * every step (return_steps) calls it a step at a time (nsteps = 1, or max_steps = 1 over the rest of the length).  Synchronous.
+ * f32 != 0 also says that the CALLER's field is complex64 (widened into A for the call): such a four-launch run on a line of 2^18 points and more keeps the
+ * line as complex64 values BETWEEN its passes -- every pass computes in float64 -- which halves the field's bytes per pass and sits a few 1e-7 from the
+ * complex128 line after 100 steps (SSFM_CHIRP_HALF=0: never); the rows go out on the plan's two lanes. */
 SSFM_API int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, void* A, void* P, const void* chirp, const void* Dt, int64_t n, double gamma,
                          const double* hs, int64_t nsteps, double length, double phi_max, int f32, int64_t max_steps, double* z_out, int64_t* steps_out);
 /* The same run for complex64 callers in ONE launch on a complex64 line: the plan is COMPLEX64 and its length is the line's, M = 2^k >= 2n - 1 -- a

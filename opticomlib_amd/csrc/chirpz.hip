@@ -39,8 +39,9 @@ struct ChirpCtl {
     unsigned long long maxbits;
 };
 
+// (half: the line is stored as complex64 -- ssfm_chirp_line_run for a complex64 caller, ssfm_kernels.hpp time_body H)
 __global__ __launch_bounds__(256) void k_chirp_pre(const double2* __restrict__ A, double* __restrict__ P, const double2* __restrict__ chirp,
-                                                   double2* __restrict__ F, long long n, long long M, int batch, double gamma, double hh, const ChirpCtl* __restrict__ ctl) {
+                                                   double2* __restrict__ F, long long n, long long M, int batch, double gamma, double hh, const ChirpCtl* __restrict__ ctl, int half = 0) {
     if (ctl) { if (ctl->done) return; hh = 0.5 * ctl->h; }
     const long long total = M * batch;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256) void k_chirp_pre(const double2* __restrict__ A
             const double2 w = chirp[m];
             y = make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
         }
-        F[i] = y;
+        if (half) reinterpret_cast<float2*>(F)[i] = make_float2((float)y.x, (float)y.y);
+        else F[i] = y;
     }
 }
 
@@ -87,13 +89,15 @@ __global__ __launch_bounds__(256) void k_chirp_mid(const double2* __restrict__ t
 
 __global__ __launch_bounds__(256) void k_chirp_post(double2* __restrict__ A, const double* __restrict__ P, const double2* __restrict__ chirp,
                                                     const double2* __restrict__ F, long long n, long long M, int batch, double gamma, double hh,
-                                                    double scale, unsigned long long* __restrict__ maxbits, const ChirpCtl* __restrict__ ctl) {
+                                                    double scale, unsigned long long* __restrict__ maxbits, const ChirpCtl* __restrict__ ctl, int half = 0) {
     if (ctl) { if (ctl->done) return; hh = 0.5 * ctl->h; }
     const long long total = n * batch;
     double pmax = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / n, m = i - r * n;
-        const double2 z = F[r * M + m];
+        double2 z;
+        if (half) { const float2 q = reinterpret_cast<const float2*>(F)[r * M + m]; z = make_double2((double)q.x, (double)q.y); }
+        else z = F[r * M + m];
         const double2 w = chirp[m];
         double2 a = make_double2((z.x * w.x + z.y * w.y) * scale, (z.y * w.x - z.x * w.y) * scale);     // z * conj(c) / N
         if (gamma != 0.0) {
@@ -340,13 +344,17 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
                                        (const ChirpCtl*)nullptr, 1.0 / (double)n);
                     mulp[i] = tabs + i * (size_t)t.M;
                 }
+                // A complex64 caller's run (f32) on a line of 2^18 points and more: the line holds complex64 values BETWEEN the passes, every pass computes in
+                // float64 (ssfm_kernels.hpp time_body, H) -- half the bytes of the field per pass, one rounding to complex64 per pass.  SSFM_CHIRP_HALF=0: never.
+                const char* he = std::getenv("SSFM_CHIRP_HALF");
+                const int half = (f32 && t.M >= (1ll << 18) && !(he && he[0] == '0') && ssfm::plan_line_half_ok(plan)) ? 1 : 0;
                 hipLaunchKernelGGL(k_chirp_pre, dim3(blocks_for(t.M * batch)), dim3(256), 0, t.stream, (const double2*)A, (double*)nullptr, (const double2*)chirp, t.F,
-                                   (long long)n, t.M, batch, 0.0, 0.0, (const ChirpCtl*)nullptr);
+                                   (long long)n, t.M, batch, 0.0, 0.0, (const ChirpCtl*)nullptr, half);
                 HIP_TRY(hipGetLastError());
-                const int rc = ssfm::plan_chirp_line_run(plan, mulp, which.data(), hs, nsteps, gamma, n);
+                const int rc = ssfm::plan_chirp_line_run(plan, mulp, which.data(), hs, nsteps, gamma, n, half);
                 if (rc == SSFM_OK) {
                     hipLaunchKernelGGL(k_chirp_post, dim3(blocks_for((long long)n * batch)), dim3(256), 0, t.stream, (double2*)A, (const double*)nullptr, (const double2*)chirp,
-                                       (const double2*)t.F, (long long)n, t.M, batch, 0.0, 0.0, 1.0, (unsigned long long*)nullptr, (const ChirpCtl*)nullptr);
+                                       (const double2*)t.F, (long long)n, t.M, batch, 0.0, 0.0, 1.0, (unsigned long long*)nullptr, (const ChirpCtl*)nullptr, half);
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipStreamSynchronize(t.stream));
                     if (steps_out) *steps_out = nsteps_given;

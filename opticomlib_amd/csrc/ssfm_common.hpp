@@ -42,7 +42,8 @@ SSFM_INTERNAL void* plan_field(ssfm_plan* plan);
 SSFM_INTERNAL int plan_chirp_step(ssfm_plan* plan, const void* mul_dev, const ChirpStepIO* io);
 // a whole fixed-step run on the plan's line in four launches per step: the line holds A c (zero from `keep` up) on entry and on return; slots 0 / 1 hold the
 // convolutions' tables; mul[which[s]] = exp(D~ h_s) / keep below `keep`, zero above.  SSFM_ERR_UNSUPPORTED: a plan in the 16-byte-unit layout
-SSFM_INTERNAL int plan_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep);
+SSFM_INTERNAL int plan_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep, int half);
+SSFM_INTERNAL int plan_line_half_ok(ssfm_plan* plan);        // 1: the plan has the passes that keep the line in complex64 between them (ssfm_kernels.hpp time_body, H)
 // the one-launch engines: a workgroup per row on a line of <= 4096 points (the plan's precision), or the one-XCD engine of a complex64 line of 2^13 ... 2^17
 // points; SSFM_ERR_UNSUPPORTED with the field as it came when the plan has no such engine or its workgroups did not meet
 SSFM_INTERNAL int plan_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps);

@@ -145,6 +145,47 @@ hipError_t launch_freq(int N2, int nrows, hipStream_t s, FreqArgs<T> a, int E) {
     return E == 8 ? launch_freq_e<T, MODE, 8>(N2, nrows, s, a) : launch_freq_e<T, MODE, 16>(N2, nrows, s, a);
 }
 
+// The passes of a chirp-z line whose field is stored as complex64 on a complex128 plan (ssfm_kernels.hpp time_body / freq_body, H): the shapes such plans have
+// from 2^18 points up -- 256 column points x 8 per thread, 512 x 16; rows of 1024 ... 8192 points x 16 per thread.
+template <int MODE, int N1, int E>
+hipError_t launch_time_h_n1(dim3 grid, hipStream_t s, const TimeArgs<double>& a) {
+    constexpr int C = cols_per_tile<double>();
+    constexpr size_t lds = (fft_nstages(N1, E) > 1 ? (size_t)N1 * C * sizeof(cx<double>) : 0) + (size_t)E * C * sizeof(cx<double>)
+                         + (size_t)fft_tw_lds_entries(N1, E) * sizeof(cx<double>);
+    static hipError_t attr = allow_lds(k_time_h<double, N1, C, E, MODE>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_time_h<double, N1, C, E, MODE>), grid, dim3(N1 * C / E), lds, s, SSFM_TIME_KERNEL_ARGS(a));
+    return hipGetLastError();
+}
+constexpr bool line_half_shape(int N1, int N2, int E, int Ef) { return ((N1 == 256 && E == 8) || (N1 == 512 && E == 16)) && Ef == 16 && N2 >= 1024 && N2 <= 8192; }
+template <int MODE>
+hipError_t launch_time_h(int N1, int batch, hipStream_t s, TimeArgs<double> a, int E) {
+    a.rows = batch;
+    const dim3 grid((unsigned)(a.N2 / cols_per_tile<double>()) * batch);
+    if (N1 == 256 && E == 8) return launch_time_h_n1<MODE, 256, 8>(grid, s, a);
+    if (N1 == 512 && E == 16) return launch_time_h_n1<MODE, 512, 16>(grid, s, a);
+    return hipErrorInvalidValue;
+}
+template <int N2>
+hipError_t launch_freq_h_n2(int nrows, hipStream_t s, const FreqArgs<double>& a) {
+    constexpr int E = 16, ROWS = freq_rows(N2, E);
+    constexpr size_t lds = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<double>) : 0) + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<double>);
+    static hipError_t attr = allow_lds(k_freq_h<double, N2, ROWS, E, FM_TABLE>, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((k_freq_h<double, N2, ROWS, E, FM_TABLE>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, SSFM_FREQ_KERNEL_ARGS(a));
+    return hipGetLastError();
+}
+inline hipError_t launch_freq_h(int N2, int nrows, hipStream_t s, FreqArgs<double> a) {
+    a.rows = nrows / a.N1;
+    switch (N2) {
+        case 1024: return launch_freq_h_n2<1024>(nrows, s, a);
+        case 2048: return launch_freq_h_n2<2048>(nrows, s, a);
+        case 4096: return launch_freq_h_n2<4096>(nrows, s, a);
+        case 8192: return launch_freq_h_n2<8192>(nrows, s, a);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <typename T, int MODE, int R>
 hipError_t launch_split_mid_r(hipStream_t s, const SplitArgs<T>& a) {
     constexpr int V = split_positions<T, R>();
@@ -2506,30 +2547,76 @@ template <typename T> struct PlanT : PlanBase {
     // pass with the table product (TM_MID_L, mul[which[s]]: exp(D~ h) / n below keep, zero above), row pass (slot 1), column pass with the second half
     // rotation of this step and the first of the next in one (the padding set to zero first) -- instead of the five of ssfm_chirp_step; the caller
     // multiplies by conj(c) when the run is over.
-    int chirp_line_run(const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma_d, int64_t keep) {
+    // half: the line holds complex64 values between the passes (a complex64 caller's run; line_half_ok() says whether this plan has those kernels)
+    bool line_half_ok() const { return sizeof(T) == 8 && !u16 && !is_split() && line_half_shape(N1, N2, E, Ef); }
+    int chirp_line_run(const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma_d, int64_t keep, int c64_line = 0) {
         if (int rc = no_split("chirp-z")) return rc;
+        if (c64_line && !line_half_ok()) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_line_run: no complex64-storage passes for this plan");
         if (!xfer_tab[0] || !xfer_tab[1]) return fail(SSFM_ERR_STATE, "ssfm_chirp_line_run: slots 0 and 1 must hold tables");
         if (u16) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_line_run: not for plans in the 16-byte-unit layout");
         if (!mul || !which || !hs || nsteps < 1 || keep < 2 || keep > n) return fail(SSFM_ERR_INVALID, "ssfm_chirp_line_run: bad arguments");
+        for (int64_t s = 0; s < nsteps; ++s)
+            if (!mul[which[s]]) return fail(SSFM_ERR_INVALID, "ssfm_chirp_line_run: step %lld has no table", (long long)s);
         if (int rc = use_device()) return rc;
         const T gamma = (T)gamma_d, half = (T)0.5;
-        HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, targs(gamma, (T)0, (T)hs[0] * half, nullptr), E)));
+        // Round 6: the rows go out on the plan's LANES (one stream per half of the rows, as the fixed-step run of a power of two does) -- a column pass is bound by
+        // latencies (one wavefront per SIMD in complex128), a row pass by bytes, and side by side they fill each other's gaps: 2^22-point rows x 2, complex128,
+        // 176 us per step in one launch per pass against 149 on two lanes (tools/big_n_c128.py).  SSFM_LANES=1: one launch per pass as before.
+        const int L = (nlanes > 1 && batch % nlanes == 0) ? nlanes : 1;
+        const int rows = batch / L;
+        // (c64_line: the field buffers hold complex64 values -- a row starts `n` float pairs after the one before)
+        auto row_ptr = [&](cx<T>* base, int row0) -> cx<T>* {
+            return c64_line ? reinterpret_cast<cx<T>*>(reinterpret_cast<cx<float>*>(base) + (size_t)row0 * n) : base + (size_t)row0 * n;
+        };
+        auto TA = [&](T g_, T hp, T hn, int g) {
+            TimeArgs<T> a = targs(g_, hp, hn, nullptr, g * rows, g);
+            a.F = row_ptr(F, g * rows); a.Y = row_ptr(Y, g * rows);
+            return a;
+        };
+        auto FA = [&](const cx<T>* tab, int g) {
+            FreqArgs<T> a = fargs(tab, 0, nullptr, g * rows, g);
+            a.F = row_ptr(Y, g * rows);
+            return a;
+        };
+        auto time_launch = [&](auto mode_tag, const TimeArgs<T>& a, hipStream_t st) -> hipError_t {
+            constexpr int MODE = decltype(mode_tag)::value;
+            if constexpr (sizeof(T) == 8) { if (c64_line) return launch_time_h<MODE>(N1, rows, st, a, E); }
+            return launch_time<T, MODE>(N1, rows, st, a, E);
+        };
+        auto freq_launch = [&](const FreqArgs<T>& a, hipStream_t st) -> hipError_t {
+            if constexpr (sizeof(T) == 8) { if (c64_line) return launch_freq_h(N2, N1 * rows, st, a); }
+            return launch_freq<T, FM_TABLE>(N2, N1 * rows, st, a, Ef);
+        };
+        auto lane_st = [&](int g) { return L > 1 ? lane_stream[g] : stream; };
+        if (L > 1) {
+            HIP_TRY(hipEventRecord(fork_ev, stream));
+            for (int g = 1; g < L; ++g) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
+        }
+        for (int g = 0; g < L; ++g) HIP_TRY(time_launch(std::integral_constant<int, TM_BEGIN>{}, TA(gamma, (T)0, (T)hs[0] * half, g), lane_st(g)));
         for (int64_t s = 0; s < nsteps; ++s) {
-            HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[0], 0, nullptr), Ef)));
-            TimeArgs<T> tl = targs((T)0, (T)0, (T)0, nullptr);
-            tl.mul = static_cast<const cx<T>*>(mul[which[s]]);
-            if (!tl.mul) return fail(SSFM_ERR_INVALID, "ssfm_chirp_line_run: step %lld has no table", (long long)s);
-            HIP_TRY((launch_time<T, TM_MID_L>(N1, batch, stream, tl, E)));
-            HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[1], 0, nullptr), Ef)));
-            if (s + 1 < nsteps) {
-                TimeArgs<T> tm = targs(gamma, (T)hs[s] * half, (T)hs[s + 1] * half, nullptr);
-                tm.keep = (int)keep;
-                HIP_TRY((launch_time<T, TM_MID>(N1, batch, stream, tm, E)));
-            } else {
-                HIP_TRY((launch_time<T, TM_END>(N1, batch, stream, targs(gamma, (T)hs[s] * half, (T)0, nullptr), E)));
+            for (int g = 0; g < L; ++g) HIP_TRY(freq_launch(FA(xfer_tab[0], g), lane_st(g)));
+            for (int g = 0; g < L; ++g) {
+                TimeArgs<T> tl = TA((T)0, (T)0, (T)0, g);
+                tl.mul = static_cast<const cx<T>*>(mul[which[s]]);
+                tl.keep = (int)keep;
+                HIP_TRY(time_launch(std::integral_constant<int, TM_MID_L>{}, tl, lane_st(g)));
+            }
+            for (int g = 0; g < L; ++g) HIP_TRY(freq_launch(FA(xfer_tab[1], g), lane_st(g)));
+            for (int g = 0; g < L; ++g) {
+                if (s + 1 < nsteps) {
+                    TimeArgs<T> tm = TA(gamma, (T)hs[s] * half, (T)hs[s + 1] * half, g);
+                    tm.keep = (int)keep;
+                    HIP_TRY(time_launch(std::integral_constant<int, TM_MID>{}, tm, lane_st(g)));
+                } else {
+                    HIP_TRY(time_launch(std::integral_constant<int, TM_END>{}, TA(gamma, (T)hs[s] * half, (T)0, g), lane_st(g)));
+                }
             }
         }
-        last_launches += 1 + 4 * nsteps;
+        for (int g = 1; g < L; ++g) {
+            HIP_TRY(hipEventRecord(lane_ev[g], lane_stream[g]));
+            HIP_TRY(hipStreamWaitEvent(stream, lane_ev[g], 0));
+        }
+        last_launches += (1 + 4 * nsteps) * L;
         last_engine = SSFM_ENGINE_CHIRP_STEPS;
         last_fell_back = 0;
         return SSFM_OK;
@@ -3152,8 +3239,12 @@ int plan_chirp_step(ssfm_plan* plan, const void* mul_dev, const ChirpStepIO* io)
     if (!io) return fail(SSFM_ERR_INVALID, "chirp step: NULL field description");
     WITH_PLAN(plan, P_->apply_tables_mul(mul_dev, io));
 }
-int plan_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep) {
-    WITH_PLAN(plan, P_->chirp_line_run(mul, which, hs, nsteps, gamma, keep));
+int plan_chirp_line_run(ssfm_plan* plan, const void* const* mul, const unsigned char* which, const double* hs, int64_t nsteps, double gamma, int64_t keep, int half) {
+    WITH_PLAN(plan, P_->chirp_line_run(mul, which, hs, nsteps, gamma, keep, half));
+}
+int plan_line_half_ok(ssfm_plan* plan) {
+    if (!plan || !plan->impl || plan->impl->precision == SSFM_C64) return 0;
+    return static_cast<PlanT<double>*>(plan->impl)->line_half_ok() ? 1 : 0;
 }
 int plan_chirp_small(ssfm_plan* plan, void* A, const void* chirp, const void* Dt, int64_t n, double gamma, const double* hs, int64_t nsteps) {
     WITH_PLAN(plan, P_->chirp_small(A, chirp, Dt, n, gamma, hs, nsteps));

@@ -610,8 +610,12 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
 // LOG: the instantiation that keeps the scalar log of a capture run (TimeArgs::scal).  A template parameter rather than a test of the pointer: the kernels of
 // every other run are then the very code they were without it -- the same registers, the same contractions, the same bits (a run-time branch in the column
 // kernels changed which products the compiler fuses, and the adaptive step's z log with them, in the last bit).
-template <typename T, int N1, int C, int E, int MODE, bool U16, bool PK = false, bool LOG = false>
+// H (round 6): the FIELD between the passes is stored as complex64 while everything this kernel computes stays in T = double -- the line of a chirp-z run of a complex64
+// caller (ssfm_chirp_line_run): a pass then moves 8 instead of 16 bytes per point and direction, and the result is rounded to complex64 once per PASS (four times a step,
+// 6e-8 each, unbiased) instead of at every butterfly of a complex64 transform of 2^18 ... 2^22 points.  The buffers are the complex128 plan's own, half used.
+template <typename T, int N1, int C, int E, int MODE, bool U16, bool PK = false, bool LOG = false, bool H = false>
 __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned bid, const unsigned nblk) {
+    static_assert(!H || (sizeof(T) == 8 && !U16 && !PK && !LOG && (MODE == TM_BEGIN || MODE == TM_MID || MODE == TM_MID_L || MODE == TM_END)), "H: the plain layout of a complex128 plan, the line's four passes");
     constexpr int Q = N1 / E;                      // threads per column
     static_assert(!U16 || (sizeof(T) == 4 && C == 16 && Q % 4 == 0 && E % 2 == 0), "U16 layout: complex64, 16 columns, whole waves of 4 j");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -731,8 +735,14 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             }
         }
         if (!loaded) {
+        if constexpr (H) {
+            const cx<float>* __restrict__ s32 = reinterpret_cast<const cx<float>*>(MODE == TM_BEGIN ? a.F : a.Y) + (long long)brow * N;
+#pragma unroll
+            for (int t = 0; t < E; ++t) { const cx<float> q = s32[off + t * stride]; v[t] = mk<T>((T)q.x, (T)q.y); }
+        } else {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = src[off + t * stride];
+        }
         }
     }
     cx<T>* Bs = lds + (fft_nstages(N1, E) > 1 ? N1 * C : 0);
@@ -1134,8 +1144,18 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             }
         } else
         if (a.mul != nullptr) {
+            if (a.keep > 0) {
+                // (a launch of its own on a long line, ssfm_chirp_line_run: the table is zero from `keep` up -- three quarters of a line just above a power of
+                // two -- and reading the zeros doubled what this pass reads: 150 us per 2^22-point row against the 78 of the pass that carries the rotation)
 #pragma unroll
-            for (int t = 0; t < E; ++t) v[t] = cmul(v[t], a.mul[off + t * stride]);
+                for (int t = 0; t < E; ++t) {
+                    const int m = off + t * stride;
+                    v[t] = m < a.keep ? cmul(v[t], a.mul[m]) : mk<T>((T)0, (T)0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < E; ++t) v[t] = cmul(v[t], a.mul[off + t * stride]);
+            }
         }
     }
     if constexpr (MODE == TM_MID && !U16) {
@@ -1188,8 +1208,14 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
                 }
             }
             // (time-order output: plain stores -- it is read by whatever comes after the run, not by the next pass)
+            if constexpr (H) {
+                cx<float>* __restrict__ F32 = reinterpret_cast<cx<float>*>(a.F) + (long long)brow * N;
+#pragma unroll
+                for (int t = 0; t < E; ++t) F32[off + t * stride] = mk<float>((float)v[t].x, (float)v[t].y);
+            } else {
 #pragma unroll
             for (int t = 0; t < E; ++t) Fb[off + t * stride] = v[t];
+            }
         } else {
             // tile-private 16-byte units in the Y buffer: only this tile's BEGIN_Y (or UNPACK) reads them back
 #pragma unroll
@@ -1232,6 +1258,13 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
             u4_t q;
             q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
             pass_store<PK>(reinterpret_cast<u4_t*>(&Yb[offy + 2 * g * stride]), q);
+        }
+    } else if constexpr (H) {
+        cx<float>* __restrict__ Y32 = reinterpret_cast<cx<float>*>(a.Y) + (long long)brow * N;
+#pragma unroll
+        for (int t = 0; t < E; ++t) {
+            const cx<T> y = cmul(v[t], w[t]);
+            pass_store<PK>(&Y32[off + t * stride], mk<float>((float)y.x, (float)y.y));
         }
     } else {
 #pragma unroll
@@ -1304,6 +1337,19 @@ __global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time(cx<T>* Y, T*
     a.trace = c.trace; a.trace_slot = c.trace_slot;
 #endif
     time_body<T, N1, C, E, MODE, U16, false, LOG>(a, blockIdx.x, gridDim.x);
+}
+// ... and with the field between the passes in complex64 (time_body, H): complex128 plans, the passes of a chirp-z line
+template <typename T, int N1, int C, int E, int MODE>
+__global__ SSFM_KERNEL_BOUNDS(N1 * C / E, sizeof(T), E) void k_time_h(cx<T>* Y, T* P, const cx<T>* twA, const cx<T>* twB, const cx<T>* tw1, int N2, int rows, int Qf,
+                                                                       T gamma, T hh_prev, T hh_next, const TimeArgsCold<T> c) {
+    TimeArgs<T> a;
+    a.Y = Y; a.P = P; a.twA = twA; a.twB = twB; a.tw1 = tw1; a.gamma = gamma; a.hh_prev = hh_prev; a.hh_next = hh_next; a.N2 = N2; a.rows = rows; a.Qf = Qf;
+    a.F = c.F; a.twN = c.twN; a.st = c.st; a.zlog = c.zlog; a.step = c.step; a.derive = c.derive; a.s_in = c.s_in; a.s_out = c.s_out; a.mul = c.mul; a.pkeep = c.pkeep; a.cz = c.cz;
+    a.keep = c.keep; a.scal = c.scal;
+#if SSFM_TRACE
+    a.trace = c.trace; a.trace_slot = c.trace_slot;
+#endif
+    time_body<T, N1, C, E, MODE, false, false, false, true>(a, blockIdx.x, gridDim.x);
 }
 // host side: the launch of k_time from a TimeArgs
 #define SSFM_TIME_KERNEL_ARGS(a) (a).Y, (a).P, (a).twA, (a).twB, (a).tw1, (a).N2, (a).rows, (a).Qf, (a).gamma, (a).hh_prev, (a).hh_next, ssfm::time_args_cold(a)
@@ -1404,8 +1450,9 @@ template <int E> __device__ __forceinline__ void fly_factors(cf64 (&m)[E], const
 }
 
 // The body of k_freq for workgroup `bid` (PK: see time_body)
-template <typename T, int N2, int ROWS, int E, int MODE, bool U16, bool PK = false>
+template <typename T, int N2, int ROWS, int E, int MODE, bool U16, bool PK = false, bool H = false>
 __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned bid) {
+    static_assert(!H || (sizeof(T) == 8 && !U16 && !PK && MODE == FM_TABLE), "H (see time_body): the plain layout of a complex128 plan, a table of complex numbers");
     constexpr int Q = N2 / E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem_raw);
@@ -1512,6 +1559,10 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
             v[2 * g + 1] = mk<T>(q.z, q.w);
         }
         }
+    } else if constexpr (H) {
+        const cx<float>* __restrict__ F32 = reinterpret_cast<const cx<float>*>(a.F) + row * N2;
+#pragma unroll
+        for (int t = 0; t < E; ++t) { const cx<float> q = F32[j + t * Q]; v[t] = mk<T>((T)q.x, (T)q.y); }
     } else {
 #pragma unroll
         for (int t = 0; t < E; ++t) v[t] = Frow[j + t * Q];
@@ -1586,6 +1637,10 @@ __device__ __forceinline__ void freq_body(const FreqArgs<T>& a, const unsigned b
             q.x = v[2 * g].x; q.y = v[2 * g].y; q.z = v[2 * g + 1].x; q.w = v[2 * g + 1].y;
             pass_store<PK>(reinterpret_cast<u4_t*>(Frow) + g * Q + j, q);
         }
+    } else if constexpr (H) {
+        cx<float>* __restrict__ F32 = reinterpret_cast<cx<float>*>(a.F) + row * N2;
+#pragma unroll
+        for (int t = 0; t < E; ++t) pass_store<PK>(&F32[j + t * Q], mk<float>((float)v[t].x, (float)v[t].y));
     } else {
 #pragma unroll
         for (int t = 0; t < E; ++t) pass_store<PK>(&Frow[j + t * Q], v[t]);
@@ -1613,6 +1668,21 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(cx<T>* F,
     a.trace = trace; a.trace_slot = trace_slot;
 #endif
     freq_body<T, N2, ROWS, E, MODE, U16, false>(a, blockIdx.x);
+}
+// ... with the field in complex64 on either side (freq_body, H)
+template <typename T, int N2, int ROWS, int E, int MODE>
+__global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq_h(cx<T>* F, const cx<T>* tab, const cx<T>* tw2, const AdaptState<T>* st, T h, T amp, T inv_n, int step, int N1,
+                                                                       int rows, int u16
+#if SSFM_TRACE
+                                                                       , unsigned long long* trace, int trace_slot
+#endif
+                                                                       ) {
+    FreqArgs<T> a;
+    a.F = F; a.tab = tab; a.tw2 = tw2; a.st = st; a.h = h; a.amp = amp; a.inv_n = inv_n; a.step = step; a.N1 = N1; a.rows = rows; a.u16 = u16;
+#if SSFM_TRACE
+    a.trace = trace; a.trace_slot = trace_slot;
+#endif
+    freq_body<T, N2, ROWS, E, MODE, false, false, true>(a, blockIdx.x);
 }
 // The two halves of a split plan's row pass (FM_FWD_ONLY, FM_INV_ONLY: one transform, no operator, 113-122 registers) without the two-per-CU pin of k_freq: they
 // stream rows of a field that no cache holds (2^23 samples and more per row), and three or four workgroups per CU hide more of that latency than two.

@@ -537,7 +537,7 @@ def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, g
         if h is None:
             b2, b3 = rt(beta_2), rt(beta_3)
             if bool((b2 == 0 and b3 == 0) or rt(gamma) == 0):                  # one step of the whole length (reference devices.py:1163-1170)
-                eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(L)]))
+                eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(L)]), f32=(prec == _lib.C64))
                 zs = [rt(0), L]
             else:
                 if not float(L) > 0:
@@ -552,7 +552,7 @@ def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, g
                     z0 = zs[-1]
         else:
             hs, z_all = step_schedule(length, h, prec)
-            eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.asarray(hs, dtype=np.float64))
+            eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.asarray(hs, dtype=np.float64), f32=(prec == _lib.C64))
             zs = list(z_all)
         return A, zs, snaps
     # A caller that wants the field after every step (return_steps), a progress bar, or SSFM_CHIRP_LOOP=python: the same C entry point a step at a time
@@ -570,7 +570,7 @@ def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, g
         z = rt(0)
         while z < L:
             if single:
-                eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(L)]))
+                eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(L)]), f32=(prec == _lib.C64))
                 hk = L
             else:
                 _, zz = eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, None, length=float(rt(L - z)), phi_max=float(rt(phi_max)), f32=(prec == _lib.C64), max_steps=1)
@@ -582,7 +582,7 @@ def _fiber_chirpz_locked(eng, A_dev, shape, dt, length, alpha, beta_2, beta_3, g
     else:
         hs, z_all = step_schedule(length, h, prec)
         for k, hk in enumerate(hs):
-            eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(hk)]))
+            eng.plan.chirp_propagate(A, P, eng.chirp, Dt, g, np.array([float(hk)]), f32=(prec == _lib.C64))
             steps += 1
             after_step(hk)
         zs = list(z_all)

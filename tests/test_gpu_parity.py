@@ -179,6 +179,35 @@ def test_any_length_fixed_step_against_oracle(n, npol):
     assert within(back.signal, orc.dbp_c64(ref, gv.dt, **kw), steps=2 * steps_of(kw), what="oracle FIBER + DBP")
 
 
+@pytest.mark.parametrize("n,npol,steps", [(100003, 2, 40), (140001, 1, 120), (300007, 2, 12)])
+def test_long_lines_hold_complex64_between_float64_passes(n, npol, steps, monkeypatch):
+    """Round 6: a complex64 caller's fixed-step run of more than 65536 samples that are not a power of two keeps its chirp-z line (2^18 points and more) as
+    complex64 BETWEEN the passes while every pass computes in float64 (ssfm_kernels.hpp time_body / freq_body, H) and goes out on the plan's two lanes: against
+    the complex128 line of the same schedule (SSFM_CHIRP_HALF=0; 1e-13 from the float64 solution) the difference is the four roundings to complex64 per step --
+    a few 1e-7, twenty times inside the bound; against the oracle it is the oracle's own float32 transforms.  One lane: the same bits."""
+    gv(**workloads.BENCH_GV)
+    rng = np.random.default_rng(n)
+    a = ((rng.standard_normal((npol, n)) + 1j * rng.standard_normal((npol, n))) * 0.03).astype(np.complex64)
+    a = a[0] if npol == 1 else a
+    kw = dict(length=steps * 0.25 - 0.1, h=0.25, **workloads.SMF)                     # (the last step short: two step sizes)
+    for k in ("SSFM_CHIRP_HALF", "SSFM_LANES"):
+        monkeypatch.delenv(k, raising=False)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    assert y.dtype == np.complex64 and y.shape == a.shape
+    monkeypatch.setenv("SSFM_LANES", "1")
+    assert np.array_equal(oa.FIBER(optical_signal(a), **kw).signal, y)
+    monkeypatch.delenv("SSFM_LANES")
+    monkeypatch.setenv("SSFM_CHIRP_HALF", "0")
+    wide = oa.FIBER(optical_signal(a), **kw).signal
+    monkeypatch.delenv("SSFM_CHIRP_HALF")
+    assert not np.array_equal(wide, y)                                                # (the knob really chose the other line)
+    assert within(y, wide, 2e-6, kw=kw, what="complex128 line of the same schedule")
+    if n * steps <= 6e6:
+        assert within(y, orc.fiber_c64(a, gv.dt, **kw), kw=kw, what="oracle")
+        y128 = oa.FIBER(optical_signal(a), precision="complex128", **kw).signal      # a complex128 caller never takes it: the float64 restatement to 1e-10
+        assert y128.dtype == np.complex128 and within(y128, orc.fiber_c128(a, gv.dt, **kw), TOL_C128, kw=kw, what="float64 restatement")
+
+
 @pytest.mark.parametrize("n", [3000, 5001])
 def test_any_length_adaptive_complex128_and_dm(n):
     gv(**workloads.BENCH_GV)

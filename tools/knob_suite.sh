@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 OUT=gpurun_out/${TAG}_knob_suite.txt
 : > $OUT
 for k in "SSFM_LANES=1" "SSFM_E=8" "SSFM_EF=8" "SSFM_SMALL=0" "SSFM_ADAPT_FUSED=0" "SSFM_FUSED_PATIENCE_TICKS=-1" "SSFM_PHASE_TABLE=0" "SSFM_FORCE_FLY=1" \
-         "SSFM_LANE_THREADS=0" "SSFM_MEDIUM=0" "SSFM_MEDIUM_ADAPT=0" "SSFM_MEDIUM_SPLIT=0" "SSFM_SOS_ONE_LAUNCH=0" "SSFM_SOS_LONG_CHUNK=0" "SSFM_SOS_NEAR=0" "SSFM_SOS_MEET=1" \
+         "SSFM_LANE_THREADS=0" "SSFM_MEDIUM=0" "SSFM_MEDIUM_ADAPT=0" "SSFM_MEDIUM_SPLIT=0" "SSFM_SOS_ONE_LAUNCH=0" "SSFM_SOS_LONG_CHUNK=0" "SSFM_SOS_NEAR=0" "SSFM_SOS_MEET=1" "SSFM_CHIRP_HALF=0" \
          "SSFM_CHIRP_LOOP=python" "SSFM_CHIRP_SMALL=0" "SSFM_LANE_POOL_OFF=1" "SSFM_SPLIT_LOG2M=21"; do
   echo "== $k" >> $OUT; env $k timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "^FAILED|passed|failed" >> $OUT
 done
