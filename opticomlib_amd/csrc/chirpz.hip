@@ -287,14 +287,21 @@ extern "C" int ssfm_chirp_propagate(ssfm_plan* plan, int64_t plan_n, int batch, 
     // (An adaptive step without the table launch -- the middle column launch forming exp(D~ h) itself from the control block's step size, six launches
     // instead of seven -- was measured at the end of round 4 and is not faster: 32.4 / 36.7 / 41.5 against 30.5 / 36.8 / 41.3 us per step at 3000 x 2 /
     // 15060 x 2 / 32752 x 2: sixteen float64 sincos + exp per thread weigh what the launch saved.)
+    // Long lines (2^18 points and more): the rows on the plan's two lanes, a table of n entries instead of M (the middle pass sets the padding to zero itself), and for a
+    // complex64 caller complex64 values between the float64 passes -- as the four-launch run below (round 6; ssfm_host.hip chirp_line_run).  SSFM_CHIRP_HALF=0: as before.
+    const char* he_ = std::getenv("SSFM_CHIRP_HALF");
+    const bool lean = t.M >= (1ll << 18) && !(he_ && he_[0] == '0');
+    const bool c64_steps = lean && f32 && ssfm::plan_line_half_ok(plan);
     auto step = [&](double h, const ChirpCtl* ctl, unsigned long long* mb) -> int {
         if (ctl || !mtab_set || std::memcmp(&mtab_h, &h, sizeof(h)) != 0) {
-            hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(t.M)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, t.M, h, ctl);
+            const long long entries = lean ? (long long)n : t.M;
+            hipLaunchKernelGGL(k_chirp_mktab, dim3(blocks_for(entries)), dim3(256), 0, t.stream, (const double2*)Dt, mtab, (long long)n, entries, h, ctl);
             mtab_h = h; mtab_set = true;
         }
         ssfm::ChirpStepIO io;
         io.A = A; io.P = P; io.chirp = chirp; io.n = n; io.gamma = gamma; io.hh = 0.5 * h;
         io.h_dev = ctl ? &ctl->h : nullptr; io.done_dev = ctl ? &ctl->done : nullptr; io.maxbits_dev = mb;
+        io.lean = lean ? 1 : 0; io.c64_line = c64_steps ? 1 : 0;
         return ssfm::plan_chirp_step(plan, mtab, &io);
     };
     std::vector<double> hs_used;

@@ -35,6 +35,8 @@ struct ChirpStepIO {
     const void* h_dev;
     const void* done_dev;
     void* maxbits_dev;
+    int c64_line = 0;        // the plan's line holds complex64 values between the passes (plan_line_half_ok; a complex64 caller's run)
+    int lean = 0;            // the table holds `n` entries only (nothing is read from `n` up: the padding is set to zero instead) and the rows go out on the plan's lanes
 };
 SSFM_INTERNAL void* plan_stream(ssfm_plan* plan);            // the plan's stream / field buffer WITHOUT marking the plan as externally ordered (ssfm_stream does)
 SSFM_INTERNAL void* plan_field(ssfm_plan* plan);

@@ -167,21 +167,26 @@ hipError_t launch_time_h(int N1, int batch, hipStream_t s, TimeArgs<double> a, i
     return hipErrorInvalidValue;
 }
 template <int N2>
-hipError_t launch_freq_h_n2(int nrows, hipStream_t s, const FreqArgs<double>& a) {
+hipError_t launch_freq_h_n2(int nrows, hipStream_t s, const FreqArgs<double>& a, const int* done) {
     constexpr int E = 16, ROWS = freq_rows(N2, E);
     constexpr size_t lds = (fft_nstages(N2, E) > 1 ? (size_t)ROWS * row_lds_elems(N2, E) * sizeof(cx<double>) : 0) + (size_t)fft_tw_lds_entries(N2, E) * sizeof(cx<double>);
     static hipError_t attr = allow_lds(k_freq_h<double, N2, ROWS, E, FM_TABLE>, lds);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((k_freq_h<double, N2, ROWS, E, FM_TABLE>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, SSFM_FREQ_KERNEL_ARGS(a));
+#if SSFM_TRACE
+    hipLaunchKernelGGL((k_freq_h<double, N2, ROWS, E, FM_TABLE>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, a.F, a.tab, a.tw2, a.st, a.h, a.amp, a.inv_n, a.step, a.N1, a.rows, a.u16, done,
+                       a.trace, a.trace_slot);
+#else
+    hipLaunchKernelGGL((k_freq_h<double, N2, ROWS, E, FM_TABLE>), dim3(nrows / ROWS), dim3(ROWS * N2 / E), lds, s, a.F, a.tab, a.tw2, a.st, a.h, a.amp, a.inv_n, a.step, a.N1, a.rows, a.u16, done);
+#endif
     return hipGetLastError();
 }
-inline hipError_t launch_freq_h(int N2, int nrows, hipStream_t s, FreqArgs<double> a) {
+inline hipError_t launch_freq_h(int N2, int nrows, hipStream_t s, FreqArgs<double> a, const int* done = nullptr) {
     a.rows = nrows / a.N1;
     switch (N2) {
-        case 1024: return launch_freq_h_n2<1024>(nrows, s, a);
-        case 2048: return launch_freq_h_n2<2048>(nrows, s, a);
-        case 4096: return launch_freq_h_n2<4096>(nrows, s, a);
-        case 8192: return launch_freq_h_n2<8192>(nrows, s, a);
+        case 1024: return launch_freq_h_n2<1024>(nrows, s, a, done);
+        case 2048: return launch_freq_h_n2<2048>(nrows, s, a, done);
+        case 4096: return launch_freq_h_n2<4096>(nrows, s, a, done);
+        case 8192: return launch_freq_h_n2<8192>(nrows, s, a, done);
     }
     return hipErrorInvalidValue;
 }
@@ -2532,6 +2537,57 @@ template <typename T> struct PlanT : PlanBase {
         }
         if (int rc = use_device()) return rc;
         if (io) last_engine = SSFM_ENGINE_CHIRP_STEPS;
+        if (io && (io->lean || io->c64_line)) {
+            // Round 6 (the adaptive runs of long lines): the rows on the plan's lanes, the middle pass reads `n` table entries instead of the line's length, and -- a
+            // complex64 caller -- the line holds complex64 values between the passes (chirp_line_run has the reasons and the numbers)
+            const bool c64_line = io->c64_line != 0;
+            if (c64_line && !line_half_ok()) return fail(SSFM_ERR_UNSUPPORTED, "ssfm_chirp_step: no complex64-storage passes for this plan");
+            const int L = (nlanes > 1 && batch % nlanes == 0) ? nlanes : 1;
+            const int rows = batch / L;
+            auto row_ptr = [&](cx<T>* base, int row0) -> cx<T>* {
+                return c64_line ? reinterpret_cast<cx<T>*>(reinterpret_cast<cx<float>*>(base) + (size_t)row0 * n) : base + (size_t)row0 * n;
+            };
+            auto time_launch = [&](auto mode_tag, const TimeArgs<T>& a, hipStream_t st) -> hipError_t {
+                constexpr int MODE = decltype(mode_tag)::value;
+                if constexpr (sizeof(T) == 8) { if (c64_line) return launch_time_h<MODE>(N1, rows, st, a, E); }
+                return launch_time<T, MODE>(N1, rows, st, a, E);
+            };
+            auto freq_launch = [&](const cx<T>* tab, int g, hipStream_t st) -> hipError_t {
+                FreqArgs<T> a = fargs(tab, 0, nullptr, g * rows, g);
+                a.F = row_ptr(Y, g * rows);
+                if constexpr (sizeof(T) == 8) { if (c64_line) return launch_freq_h(N2, N1 * rows, st, a, tb.cz.done); }
+                return launch_freq<T, FM_TABLE>(N2, N1 * rows, st, a, Ef);
+            };
+            auto lane_st = [&](int g) { return L > 1 ? lane_stream[g] : stream; };
+            auto ends = [&](int g) {
+                TimeArgs<T> a = tb;
+                a.F = row_ptr(F, g * rows); a.Y = row_ptr(Y, g * rows); a.P = P + (size_t)(g * rows) * n;
+                a.cz.A = tb.cz.A + (size_t)(g * rows) * io->n; a.cz.P = tb.cz.P + (size_t)(g * rows) * io->n;
+                return a;
+            };
+            if (L > 1) {
+                HIP_TRY(hipEventRecord(fork_ev, stream));
+                for (int g = 1; g < L; ++g) HIP_TRY(hipStreamWaitEvent(lane_stream[g], fork_ev, 0));
+            }
+            for (int g = 0; g < L; ++g) HIP_TRY(time_launch(std::integral_constant<int, TM_BEGIN>{}, ends(g), lane_st(g)));
+            for (int g = 0; g < L; ++g) HIP_TRY(freq_launch(xfer_tab[0], g, lane_st(g)));
+            for (int g = 0; g < L; ++g) {
+                TimeArgs<T> tm = targs(0, 0, 0, nullptr, g * rows, g);
+                tm.F = row_ptr(F, g * rows); tm.Y = row_ptr(Y, g * rows);
+                tm.mul = static_cast<const cx<T>*>(mul_dev);
+                tm.cz.done = tb.cz.done;
+                if (io->lean) tm.keep = (int)io->n;
+                HIP_TRY(time_launch(std::integral_constant<int, TM_MID>{}, tm, lane_st(g)));
+            }
+            for (int g = 0; g < L; ++g) HIP_TRY(freq_launch(xfer_tab[1], g, lane_st(g)));
+            for (int g = 0; g < L; ++g) HIP_TRY(time_launch(std::integral_constant<int, TM_END>{}, ends(g), lane_st(g)));
+            for (int g = 1; g < L; ++g) {
+                HIP_TRY(hipEventRecord(lane_ev[g], lane_stream[g]));
+                HIP_TRY(hipStreamWaitEvent(stream, lane_ev[g], 0));
+            }
+            last_launches += 5 * L;
+            return SSFM_OK;
+        }
         HIP_TRY((launch_time<T, TM_BEGIN>(N1, batch, stream, tb, E)));
         HIP_TRY((launch_freq<T, FM_TABLE>(N2, N1 * batch, stream, fargs(xfer_tab[0], 0, nullptr), Ef)));
         TimeArgs<T> tm = targs(0, 0, 0, nullptr);

@@ -616,6 +616,11 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
 template <typename T, int N1, int C, int E, int MODE, bool U16, bool PK = false, bool LOG = false, bool H = false>
 __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned bid, const unsigned nblk) {
     static_assert(!H || (sizeof(T) == 8 && !U16 && !PK && !LOG && (MODE == TM_BEGIN || MODE == TM_MID || MODE == TM_MID_L || MODE == TM_END)), "H: the plain layout of a complex128 plan, the line's four passes");
+    if constexpr (H) {
+        // (a pass queued behind the end of an adaptive run does nothing at all: round 5's left the caller's field alone but still transformed the line -- 100-120 us each
+        // at 2^22 points -- and an adaptive run queues well past its end, its step only grows along the fibre)
+        if (a.cz.done != nullptr && *a.cz.done) return;
+    }
     constexpr int Q = N1 / E;                      // threads per column
     static_assert(!U16 || (sizeof(T) == 4 && C == 16 && Q % 4 == 0 && E % 2 == 0), "U16 layout: complex64, 16 columns, whole waves of 4 j");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1160,8 +1165,16 @@ __device__ __forceinline__ void time_body(const TimeArgs<T>& a, const unsigned b
     }
     if constexpr (MODE == TM_MID && !U16) {
         if (a.mul != nullptr) {
+            if (a.keep > 0) {            // (the table has `keep` entries; the samples from there on were set to zero above)
+#pragma unroll
+                for (int t = 0; t < E; ++t) {
+                    const int m = off + t * stride;
+                    if (m < a.keep) v[t] = cmul(v[t], a.mul[m]);
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < E; ++t) v[t] = cmul(v[t], a.mul[off + t * stride]);
+            }
         }
     }
     if constexpr (MODE == TM_MID_A) {
@@ -1672,11 +1685,12 @@ __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq(cx<T>* F,
 // ... with the field in complex64 on either side (freq_body, H)
 template <typename T, int N2, int ROWS, int E, int MODE>
 __global__ SSFM_KERNEL_BOUNDS(ROWS * N2 / E, sizeof(T), E) void k_freq_h(cx<T>* F, const cx<T>* tab, const cx<T>* tw2, const AdaptState<T>* st, T h, T amp, T inv_n, int step, int N1,
-                                                                       int rows, int u16
+                                                                       int rows, int u16, const int* done
 #if SSFM_TRACE
                                                                        , unsigned long long* trace, int trace_slot
 #endif
                                                                        ) {
+    if (done != nullptr && *done) return;            // (queued behind the end of an adaptive run: see time_body, H)
     FreqArgs<T> a;
     a.F = F; a.tab = tab; a.tw2 = tw2; a.st = st; a.h = h; a.amp = amp; a.inv_n = inv_n; a.step = step; a.N1 = N1; a.rows = rows; a.u16 = u16;
 #if SSFM_TRACE

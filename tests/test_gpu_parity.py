@@ -208,6 +208,46 @@ def test_long_lines_hold_complex64_between_float64_passes(n, npol, steps, monkey
         assert y128.dtype == np.complex128 and within(y128, orc.fiber_c128(a, gv.dt, **kw), TOL_C128, kw=kw, what="float64 restatement")
 
 
+def test_long_lines_adaptive_run(monkeypatch):
+    """... and the adaptive run of such a length (the reference's default, h=None): five passes per step with the caller's field at both ends of every step -- the
+    line between them complex64, a table of n entries, nothing done by the passes queued behind the run's end.  Same z log as the complex128 line and as the oracle
+    (float32 step arithmetic in both), the field within the bound of the oracle and 2e-6 of the complex128 line."""
+    gv(**workloads.BENCH_GV)
+    n = 100003
+    rng = np.random.default_rng(n + 5)
+    a = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))) * 0.14
+    # (noise in an eighth of the band, as a signal of two samples per symbol in a 16-sample grid would be: with the WHOLE band full -- 28 rad of dispersion per km at its edge --
+    # the reference's own float32 z accumulation decides the length of the last, clamped step to 3e-6 km, and two correct runs end 3e-5 apart: tests/diag/adaptive_long_diag.py)
+    spec = np.fft.fft(a, axis=-1)
+    spec[:, n // 16: n - n // 16] = 0
+    a = np.fft.ifft(spec, axis=-1).astype(np.complex64)
+    kw = dict(length=12, phi_max=0.02, **workloads.SMF)
+    monkeypatch.delenv("SSFM_CHIRP_HALF", raising=False)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+    monkeypatch.setenv("SSFM_CHIRP_HALF", "0")
+    wide = oa.FIBER(optical_signal(a), **kw).signal
+    zw, _ = oa.FIBER(optical_signal(a), return_steps=True, **kw)
+    monkeypatch.delenv("SSFM_CHIRP_HALF")
+    zr, Ar = orc.fiber_c64(a, gv.dt, return_steps=True, **kw)
+    steps = len(zr) - 1
+    assert steps >= 8 and len(z) == len(zw) == len(zr)
+    np.testing.assert_allclose(z, zw, rtol=1e-6)
+    np.testing.assert_allclose(z, zr, rtol=2e-4)
+    assert not np.array_equal(y, wide) and within(y, wide, 2e-6, steps=steps, what="complex128 line, adaptive")
+    # The oracle transforms this PRIME length in float32 (pocketfft's Bluestein): its own maxima, and with them its step sizes, move by up to 1.5e-4 of a step, and a
+    # band full of noise turns that into several 1e-5 of the field.  The judge of both runs is the float64 solution of the reference's adaptive problem
+    # (fuzz_cases.truth_adaptive_f64: float32 coefficients and step rule, float64 transforms): the HIP run is held to it by HALF the bound and takes ITS steps,
+    # the oracle is wherever it is, and the two are held together by the sum.
+    zt, truth = _fuzz_module().truth_adaptive_f64(a, gv.dt, kw)
+    assert len(zt) == len(z)
+    np.testing.assert_allclose(z, zt, rtol=3e-6)
+    oracle_off = relmax(Ar[-1], truth)
+    assert within(y, truth, 0.5 * tol_at(steps), steps=steps, what="float64 solution of the adaptive problem")
+    assert within(y, Ar[-1], oracle_off + 0.5 * tol_at(steps), steps=steps, what=f"oracle adaptive (itself {oracle_off:.2e} from the float64 solution)")
+    assert within(A_z[-1], y, 1e-6, steps=steps, what="return_steps, the same run a step at a time")
+
+
 @pytest.mark.parametrize("n", [3000, 5001])
 def test_any_length_adaptive_complex128_and_dm(n):
     gv(**workloads.BENCH_GV)
