@@ -3195,6 +3195,32 @@ def test_two_to_the_23_long_run_against_the_oracle_fixture(golden_dir):
     _BIG.clear()
 
 
+def test_full_size_length_that_is_not_a_power_of_two_against_the_oracle_fixture(golden_dir):
+    """The reference's PRBS-16 word at 16 samples per bit -- (2^16 - 1) * 16 = 1 048 560 samples per polarisation, dual-pol -- through the chirp-z line that keeps complex64
+    values between float64 passes (round 6), against the ORACLE's run of the same (tests/golden/make_anyn_strided.py): 100 of C2's steps, and the adaptive run with its z log."""
+    g = np.load(os.path.join(golden_dir, "anyn_strided.npz"))
+    st, n = int(g["stride"]), int(g["n"])
+    gv(**workloads.BENCH_GV)
+    a = workloads.qpsk_field(n, seed=1616, n_pol=2, power_w=2e-3)
+    kw = dict(length=12.5, h=0.125, **workloads.SMF)
+    y = oa.FIBER(optical_signal(a), **kw).signal
+    assert y.dtype == np.complex64 and y.shape == (2, n) and steps_of(kw) == 100
+    assert within(y[:, ::st], g["fixed_samples"], kw=kw, what="oracle fixture, 1048560 x 2, 100 steps")
+    np.testing.assert_allclose(np.mean(np.abs(y.astype(np.complex128)) ** 2, axis=-1), g["fixed_power"], rtol=1e-4)
+    kwa = dict(length=10.0, phi_max=0.002, **workloads.SMF)
+    z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kwa)
+    zr = g["adapt_z"]
+    assert len(z) == len(zr)
+    np.testing.assert_allclose(z, zr, rtol=2e-5)
+    steps = len(zr) - 1
+    assert within(A_z[-1][:, ::st], g["adapt_samples"], steps=steps, what=f"oracle fixture, 1048560 x 2, adaptive ({steps} steps)")
+    np.testing.assert_allclose(np.mean(np.abs(A_z[-1].astype(np.complex128)) ** 2, axis=-1), g["adapt_power"], rtol=1e-4)
+    del A_z
+    ya = oa.FIBER(optical_signal(a), **kwa).signal                       # (the whole run from C: the same bits as a step at a time)
+    assert within(ya[:, ::st], g["adapt_samples"], steps=steps, what="oracle fixture, adaptive, one call")
+    oa.devices.release_plans()
+
+
 # ----------------------------------------------------------------------- adaptive runs with a capture that keeps the run's engine (round 6)
 @pytest.mark.parametrize("log2n,npol,prec", [(14, 2, "c64"), (18, 2, "c64"), (20, 2, "c64"), (16, 2, "c128")])
 def test_adaptive_capture_keeps_the_engine_and_every_snapshot_is_a_plain_run_stopped_there(log2n, npol, prec):
