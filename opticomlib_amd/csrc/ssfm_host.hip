@@ -475,6 +475,7 @@ int streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned* words /* tw
 // lanes that share a hardware queue 2 x).  At run time a fixed-step run whose own launch period exceeds kLaneSlowRatio x the best period the plan has seen
 // has its lanes rated again (PlanT::lane_health).
 constexpr float kLaneGoodRatio = 1.6f;
+constexpr float kLaneGoodRatioBig = 2.1f;
 constexpr float kLaneSlowRatio = 1.8f;
 constexpr float kLaneSuspectRatio = 1.3f;        // two checked runs in a row beyond this (round 6: profiles/r05_final_lane_stability.txt had one plan at 1.37 x that 1.8 never sees)
 constexpr int kLaneDroppedCooldown = 32;         // runs after which a plan that dropped to one lane tries its second lane again
@@ -1087,10 +1088,12 @@ template <typename T> struct PlanT : PlanBase {
         (void)hipFree(words);
         if (shared) return 2;
         float alone = 1e30f, pair = 0.f;
+        // (rows of 32 MiB and more -- complex128 plans of 2^21 points up, the lines of long chirp-z runs: a launch is 30-100 us long, a third of the probe steps measure it as well)
+        const int probe_steps = big_rows() ? kLaneProbeSteps / 3 : kLaneProbeSteps;
         for (int r = 0; r < 2; ++r) {           // (the slow state is erratic -- one of its readings may look good: the WORSE of two, against the better alone)
             float a1 = 0.f, p1 = 0.f;
-            if (measure_lanes(1u, kLaneProbeSteps, Fx, Yx, Px, &a1) != SSFM_OK) return -1;
-            if (measure_lanes(1u | (1u << g), kLaneProbeSteps, Fx, Yx, Px, &p1) != SSFM_OK) return -1;
+            if (measure_lanes(1u, probe_steps, Fx, Yx, Px, &a1) != SSFM_OK) return -1;
+            if (measure_lanes(1u | (1u << g), probe_steps, Fx, Yx, Px, &p1) != SSFM_OK) return -1;
             alone = a1 < alone ? a1 : alone;
             pair = p1 > pair ? p1 : pair;
         }
@@ -1100,8 +1103,12 @@ template <typename T> struct PlanT : PlanBase {
         std::fprintf(stderr, "lane rating: lane %d: %.2f us per launch alone, %.2f with lane 0 beside it\n", g, alone, pair);
 #endif
         if (lane_fault == 2) { *score = 9.f; return 1; }
-        return *score > kLaneGoodRatio ? 1 : 0;
+        // Round 6: a kernel that moves 32 MiB and more per row keeps the memory system busy by itself, and its twin beside it legitimately takes up to twice as long per launch
+        // (2^22-point complex128 rows: 1.80-1.82, and two lanes are still 18 % faster per step than one launch for both rows) -- rated against 1.6 such a pair was "in the way",
+        // had four replacement streams tried in vain, was never pooled, and every such plan took 117 ms to make (tools/plan_create_time.py).  The slow states measure 2.3-6 x.
+        return *score > (big_rows() ? kLaneGoodRatioBig : kLaneGoodRatio) ? 1 : 0;
     }
+    bool big_rows() const { return (size_t)n * sizeof(cx<T>) >= ((size_t)32 << 20); }
     // Rate every lane beyond the first; a lane that is not good tries replacement streams four at a time -- made together, so that the runtime's
     // least-used rule spreads them over the class's hardware queues -- the first good one (else the best one) replaces the lane's stream, the rest go.
     int rate_and_replace_lanes(cx<T>* Fx, cx<T>* Yx, T* Px, bool* replaced) {
