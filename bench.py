@@ -65,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=48, help="SSFM steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-kernel HIP-event passes")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C1 (complex128) figure reported beside the headline")
+    ap.add_argument("--no-big-field", action="store_true", help="skip the 2^24 x 2 figure (its split plan runs the headline's column kernel over 32 rows per launch: under "
+                                                                "rocprofv3 --stats those launches would share a row of the summary with the headline's)")
     ap.add_argument("--cpu-manycore", type=int, default=0, help="also time the tidied CPU variant on this many processes (0 = skip)")
     ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4"], default="auto")
     ap.add_argument("--launch-timeout", type=float, default=600.0,
@@ -739,7 +741,7 @@ def main():
         if world == 1 and workload == "c2" and not args.no_secondary:
             other = secondary_c1(a_c2, dt, fibre, local_rank)
             try:
-                big = secondary_big(dt, fibre, local_rank)
+                big = None if args.no_big_field else secondary_big(dt, fibre, local_rank)
             except Exception as e:                               # (reported, never fatal: the headline line stands on its own)
                 big = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.cpu_steps > 0:

@@ -190,8 +190,9 @@ def test_long_lines_hold_complex64_between_float64_passes(n, npol, steps, monkey
     a = ((rng.standard_normal((npol, n)) + 1j * rng.standard_normal((npol, n))) * 0.03).astype(np.complex64)
     a = a[0] if npol == 1 else a
     kw = dict(length=steps * 0.25 - 0.1, h=0.25, **workloads.SMF)                     # (the last step short: two step sizes)
-    for k in ("SSFM_CHIRP_HALF", "SSFM_LANES"):
-        monkeypatch.delenv(k, raising=False)
+    for k in ("SSFM_CHIRP_HALF", "SSFM_LANES", "SSFM_E", "SSFM_EF"):            # (the knobs this comparison of two lines depends on are pinned: the complex64-storage passes
+        monkeypatch.delenv(k, raising=False)                                    # exist for the plans' default points per thread)
+    oa.devices.release_plans()
     y = oa.FIBER(optical_signal(a), **kw).signal
     assert y.dtype == np.complex64 and y.shape == a.shape
     monkeypatch.setenv("SSFM_LANES", "1")
@@ -222,7 +223,9 @@ def test_long_lines_adaptive_run(monkeypatch):
     spec[:, n // 16: n - n // 16] = 0
     a = np.fft.ifft(spec, axis=-1).astype(np.complex64)
     kw = dict(length=12, phi_max=0.02, **workloads.SMF)
-    monkeypatch.delenv("SSFM_CHIRP_HALF", raising=False)
+    for k in ("SSFM_CHIRP_HALF", "SSFM_E", "SSFM_EF"):
+        monkeypatch.delenv(k, raising=False)
+    oa.devices.release_plans()
     y = oa.FIBER(optical_signal(a), **kw).signal
     z, A_z = oa.FIBER(optical_signal(a), return_steps=True, **kw)
     monkeypatch.setenv("SSFM_CHIRP_HALF", "0")
@@ -1625,6 +1628,8 @@ def test_sosfiltfilt_start_states_from_the_totals_that_matter(wn, n, rows, cplx,
         x = x + 1j * rng.standard_normal((rows, n))
     want = sg.sosfiltfilt(sos, x, axis=-1)
     bound = max(TOL_FILT, 5 * 5e-20 * (2.0 / wn) ** 3)                  # (conditioning of the chunked recurrence)
+    monkeypatch.delenv("SSFM_SOS_ONE_LAUNCH", raising=False)              # (the look-back is the one-launch form's: the knobs this test depends on are pinned)
+    monkeypatch.delenv("SSFM_SOS_MEET", raising=False)
     monkeypatch.delenv("SSFM_SOS_NEAR", raising=False)
     near = _lib.sosfiltfilt(sos, zi, x)
     assert _lib.sosfiltfilt_last_launches() == 1

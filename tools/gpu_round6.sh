@@ -22,7 +22,7 @@ done
 timeout 200 python bench.py --gpus 2 --steps 1 --warmup 0 --cpu-steps 0 --no-profile-pass --no-secondary --launch-timeout 60 > ${T}_bench_2ranks_nccl_one_gpu.json 2> ${T}_bench_2ranks_nccl_one_gpu.err; echo "bench --gpus 2 over RCCL on a one-GPU box rc=$? (expected: non-zero, within the budget)"; tail -3 ${T}_bench_2ranks_nccl_one_gpu.err | cut -c1-300
 { echo "== launch timeline of the two lanes (tools/trace_timeline.py, -DSSFM_TRACE=1 build)"; SSFM_LIB=build/var/_ssfm_trace.so python tools/trace_timeline.py 2>&1 | tail -14; } > ${T}_c2_trace.txt 2>&1; tail -3 ${T}_c2_trace.txt
 rm -rf ${T}_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_prof -- python3 bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass > ${T}_prof_bench.json 2> ${T}_prof.err; echo "rocprof rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d ${T}_prof -- python3 bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-profile-pass --no-big-field > ${T}_prof_bench.json 2> ${T}_prof.err; echo "rocprof rc=$?"
 find ${T}_prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} ${T}_kernel_stats.csv; head -8 ${T}_kernel_stats.csv
 find ${T}_prof -name "*kernel_trace.csv" -size +2M -delete
 bash tools/gpu_pmc.sh ${TAG}_pmc > ${T}_pmc.log 2>&1; tail -3 ${T}_pmc.log
