@@ -249,6 +249,13 @@ def test_long_lines_adaptive_run(monkeypatch):
     assert within(y, truth, 0.5 * tol_at(steps), steps=steps, what="float64 solution of the adaptive problem")
     assert within(y, Ar[-1], oracle_off + 0.5 * tol_at(steps), steps=steps, what=f"oracle adaptive (itself {oracle_off:.2e} from the float64 solution)")
     assert within(A_z[-1], y, 1e-6, steps=steps, what="return_steps, the same run a step at a time")
+    # a complex128 caller's adaptive run of this length takes the lanes and the short table too, and keeps its complex128 line: the same field as round 5's form to 1e-12
+    kw128 = dict(kw, length=4)
+    y128 = oa.FIBER(optical_signal(a), precision="complex128", **kw128).signal
+    monkeypatch.setenv("SSFM_CHIRP_HALF", "0")
+    w128 = oa.FIBER(optical_signal(a), precision="complex128", **kw128).signal
+    monkeypatch.delenv("SSFM_CHIRP_HALF")
+    assert y128.dtype == np.complex128 and within(y128, w128, 1e-12, what="complex128 caller, adaptive: lanes and a table of n entries against round 5's form")
 
 
 @pytest.mark.parametrize("n", [3000, 5001])
