@@ -402,6 +402,74 @@ def secondary_big(dt, fibre, device, log2n=24, steps=20):
             "note": "rows of more than 2^22 samples run as split plans: four passes per step (DESIGN.md 5b); algorithmic bytes 32 B per sample*step; not part of `value`"}
 
 
+def secondary_filter(a_c2, device):
+    """The zero-phase Bessel filter of LPF / BPF on the headline's field, device-resident: a 4th-order BPF of the 2^20 x 2 complex128 field, kernels
+    per call by the library's own HIP events, with the check against SciPy on one row.  x read once + y written once = 32 B per complex sample: its roofline."""
+    import numpy as np
+    from scipy import signal as sg
+    from opticomlib_amd import _lib
+    n = a_c2.shape[-1]
+    from opticomlib_amd import workloads
+    sos = sg.bessel(4, 30e9, "low", fs=workloads.BENCH_GV["sps"] * workloads.BENCH_GV["R"], norm="mag", output="sos")
+    zi = sg.sosfilt_zi(sos)
+    x = a_c2.astype(np.complex128)
+    p, q = _lib.Plan(n, N_POL, _lib.C128, device=device), _lib.Plan(n, N_POL, _lib.C128, device=device)
+    try:
+        p.set_field(x)
+        p.synchronize()
+        for _ in range(20):
+            _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, q.field_device_ptr, n, N_POL, True, device)
+        err = float(np.abs(q.get_field()[0] - sg.sosfiltfilt(sos, x[0])).max() / np.abs(x[0]).max())
+        t = 0.0
+        reps = 200
+        for _ in range(reps):
+            _lib.sosfiltfilt_device(sos, zi, p.field_device_ptr, q.field_device_ptr, n, N_POL, True, device)
+            t += _lib.sosfiltfilt_last_ms()
+        us = t / reps * 1e3
+        launches = _lib.sosfiltfilt_last_launches()
+    finally:
+        p.close()
+        q.close()
+    nbytes = 2 * 16 * n * N_POL
+    return {"workload": "BPF (4th-order Bessel, zero phase) of the 2^20-sample dual-pol field, complex128, device-resident, 200 calls", "dtype": "f64", "kernel_us_per_call": us,
+            "launches_per_call": launches, "algorithmic_bytes_per_call": nbytes, "achieved_GBs": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBS,
+            "against_scipy": err, "note": "kernels by the library's HIP events around each call; not part of `value`"}
+
+
+def secondary_any_length(dt, fibre):
+    """A length that is NOT a power of two, at the reference's own size: the PRBS-16 word at 16 samples per bit, (2^16 - 1) * 16 = 1 048 560 samples x 2.
+    Per step: the slope between a 100-step and a 400-step FIBER() call (host arrays in and out: the call's fixed costs cancel); beside it the ratio to the headline's step."""
+    import numpy as np
+    import opticomlib_amd as oa
+    from opticomlib_amd import workloads
+    from opticomlib_amd.typing import gv, optical_signal
+    gv(**workloads.BENCH_GV)
+    n = ((1 << 16) - 1) * 16
+    a = workloads.qpsk_field(n, seed=1616, n_pol=N_POL, power_w=2e-3)
+    x = optical_signal(a)
+    t = {}
+    for steps in (100, 400):
+        kw = dict(length=steps * H_KM, h=H_KM, **fibre)
+        if steps == 100:
+            y = oa.FIBER(x, **kw).signal
+            e_in = np.sum(np.abs(a.astype(np.complex128)) ** 2, axis=-1)
+            e_out = np.sum(np.abs(y.astype(np.complex128)) ** 2, axis=-1)
+            att = float(np.exp(np.complex64(-np.float32(fibre["alpha"] / 4.343) / 2) * np.float32(H_KM)).real)
+            energy_err = float(np.max(np.abs(e_out / e_in / att ** (2 * steps) - 1.0)))
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            oa.FIBER(x, **kw)
+            best = min(best, time.perf_counter() - t0)
+        t[steps] = best
+    oa.devices.release_plans()
+    us = (t[400] - t[100]) / 300 * 1e6
+    return {"workload": f"{n}-sample dual-pol field ((2^16 - 1) * 16: not a power of two), complex64 caller, C2's steps (h = {H_KM} km)", "dtype": "c64 between f64 passes",
+            "us_per_ssfm_step": us, "value": n / (us * 1e-6), "unit": "sample*steps/s", "fixed_ms_per_call": (4 * t[100] - t[400]) / 3 * 1e3,
+            "energy_against_attenuation": energy_err,
+            "note": "chirp-z line of 2^21 points, four passes per step on two lanes; slope between a 100-step and a 400-step FIBER() call; not part of `value`"}
+
+
 def _manycore_worker(job):
     seed, dt, fibre, steps = job
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -671,6 +739,7 @@ def main():
     cpu_many = None
     other = None
     big = None
+    extra = {}
     if rank == 0:
         per_gpu_rate = value * fields_here / max(total_fields, 1)
         roofline = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
@@ -744,6 +813,14 @@ def main():
                 big = None if args.no_big_field else secondary_big(dt, fibre, local_rank)
             except Exception as e:                               # (reported, never fatal: the headline line stands on its own)
                 big = {"error": f"{type(e).__name__}: {e}"}
+            extra = {}
+            for name, fn in (("secondary_filter", lambda: secondary_filter(a_c2, local_rank)), ("secondary_any_length", lambda: secondary_any_length(dt, fibre))):
+                if args.no_big_field:
+                    continue
+                try:
+                    extra[name] = fn()
+                except Exception as e:
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.cpu_steps > 0:
             if a_c2 is None:
                 a_c2 = workloads.qpsk_field(n, seed=2024, n_pol=N_POL)
@@ -800,6 +877,7 @@ def main():
         **({"cpu_baseline_manycore": cpu_many} if cpu_many else {}),
         **({"secondary": other} if other else {}),
         **({"secondary_big_field": big} if big else {}),
+        **extra,
         "cpu_affinity": cpu_affinity,
     })
 
