@@ -218,32 +218,32 @@ inline int sos_waves(long long n, int rows, int edge) {
 template <int NS, int CH>
 int run_filter(Workspace& w, const SosCoefs& c, const double* sos_key, const double* zi_h, const double* x, double* y,
                long long n, int rows, int edge, bool on_device) {
-    if (kWavesSmall != kWavesLarge && sos_waves(n, rows, edge) == kWavesSmall)
-        return chunk_short::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
-    // Round 6: with the look-back near (group_start_near) the two-wavefront shape is the fastest wherever its grid is resident at once, not only for short
-    // calls -- 2^20 float64 15.6 us against 18.0, 2^19 x 2 complex128 20.6 against 22.9 (profiles/r06_sos_shape_sweep.txt; orders up to 4, which were measured)
+    // Which workgroup shape a call takes (round 6; profiles/r06_sos_shape_sweep.txt, r06_sos_w1.txt -- orders 2 to 8, 8192 ... 2^20 samples, three layouts):
+    //  1. ONE wavefront per workgroup, short chunk, wherever that grid is resident at once: with the look-back near (group_start_near) a small group costs nothing and has no
+    //     carry between wavefronts -- the best shape or within 4 % of it everywhere it fits (2^20 float64 15.3 us against 17.7 in four wavefronts of the long chunk);
+    //  2. one wavefront with the LONG chunk where only that fits (1.5 ... 2.1 M complex samples: 22.5 against 25.4 us at 786 432 x 2);
+    //  3. four wavefronts of the short chunk while that is at most one workgroup per CU (orders 4 to 8: 15.5 / 34 / 42 us against the long chunk's 17 / 37 / 45);
+    //  4. four wavefronts of the long chunk (two workgroups per CU hold what three of the short one would); 5. the short chunk in three launches.
+    // SOS_WAVES_FORCE (test aid) pins the wavefronts, SSFM_SOS_LONG_CHUNK=0 the short chunk.
     const bool forced = std::getenv("SOS_WAVES_FORCE") != nullptr;
-    if (const char* l1 = std::getenv("SSFM_SOS_LONG1")) {          // (1, dev aid: the long chunk in one wavefront BEFORE the short one)
-        if (l1[0] == '1' && chunk_long::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
-            return chunk_long::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
-    }
-    if (kWavesSmall != kWavesLarge && !forced && chunk_short::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
+    const char* lc = std::getenv("SSFM_SOS_LONG_CHUNK");
+    const bool long_ok = !(lc && std::atoi(lc) == 0);
+    if (kWavesSmall != kWavesLarge && sos_waves(n, rows, edge) == kWavesSmall)          // (short calls -- in whatever form -- and the test aid)
         return chunk_short::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
-    // ... then one wavefront with the LONG chunk (SSFM_SOS_LONG1=0: never)
-    if (kWavesSmall != kWavesLarge && !forced && !std::getenv("SSFM_SOS_LONG_CHUNK") && !(std::getenv("SSFM_SOS_LONG1") && std::getenv("SSFM_SOS_LONG1")[0] == '0') &&
-        chunk_long::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
-        return chunk_long::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
-    // ... then the short chunk in four wavefronts while that is at most ONE workgroup per CU (orders 4 to 8: 15.5 / 34 / 42 us against the long chunk's 17 / 37 / 45),
-    // the long chunk above (two workgroups per CU hold what three of the short one would)
-    if (!forced && !std::getenv("SSFM_SOS_LONG_CHUNK")) {
-        const long long groups = ((n + 2ll * edge + chunk_short::kChunk - 1) / chunk_short::kChunk + kWave * kWavesLarge - 1) / (kWave * kWavesLarge);
-        static int cus = 0;
-        if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v; }
-        if (cus > 0 && groups * rows <= cus && chunk_short::one_launch_would_run<NS, CH, kWavesLarge>(w, c, n, rows, edge))
-            return chunk_short::run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+    if (kWavesSmall != kWavesLarge && !forced) {
+        if (chunk_short::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
+            return chunk_short::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+        if (long_ok && chunk_long::one_launch_would_run<NS, CH, kWavesSmall>(w, c, n, rows, edge))
+            return chunk_long::run_filter_w<NS, CH, kWavesSmall>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+        if (long_ok) {
+            const long long groups = ((n + 2ll * edge + chunk_short::kChunk - 1) / chunk_short::kChunk + kWave * kWavesLarge - 1) / (kWave * kWavesLarge);
+            static int cus = 0;
+            if (!cus) { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v; }
+            if (cus > 0 && groups * rows <= cus && chunk_short::one_launch_would_run<NS, CH, kWavesLarge>(w, c, n, rows, edge))
+                return chunk_short::run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
+        }
     }
-    const char* e = std::getenv("SSFM_SOS_LONG_CHUNK");
-    if (!(e && std::atoi(e) == 0) && chunk_long::one_launch_would_run<NS, CH, kWavesLarge>(w, c, n, rows, edge))
+    if (long_ok && chunk_long::one_launch_would_run<NS, CH, kWavesLarge>(w, c, n, rows, edge))
         return chunk_long::run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
     return chunk_short::run_filter_w<NS, CH, kWavesLarge>(w, c, sos_key, zi_h, x, y, n, rows, edge, on_device);
 }
