@@ -2186,6 +2186,32 @@ def test_mzm_with_filter_and_the_transmitter_chain(golden_dir):
     assert within(rx.signal, want_rx, 1e-4)  # |E|^2 of fields that agree to 2e-5
 
 
+def test_the_example_link_at_a_whole_prbs_word():
+    """The same chain on a WHOLE PRBS word, as the reference's scripts use it (PRBS(order) has 2^order - 1 bits): order 11 at 64 samples per bit = 131 008 samples, not a
+    power of two -- the transmitter on the device, the fibre adaptive (h=None) on the chirp-z line that holds complex64 values between float64 passes (round 6), the detector's
+    filter at that length."""
+    from oracle import transmitter_numpy as tx, frontend_numpy as fe
+    gv(sps=64, R=10e9, N=(1 << 11) - 1)
+    seq = oa.PRBS(order=11)
+    assert seq.data.size == (1 << 11) - 1
+    drive = oa.DAC(seq, Vpp=5.0, offset=-2.5, pulse_shape="gaussian")
+    mod = oa.MZM(oa.LASER(P0=8), drive, bias=-2.5, Vpi=5.0, loss_dB=3, ER_dB=26)
+    n = ((1 << 11) - 1) * 64
+    want_v = tx.dac(seq.data, 64, gv.fs, pulse_shape="gaussian", Vpp=5.0, offset=-2.5)
+    want_m, _ = tx.mzm(tx.laser(gv.t, gv.dt, gv.fs, 8), None, want_v, None, gv.fs, bias=-2.5, Vpi=5.0, loss_dB=3, ER_dB=26)
+    assert mod.signal.shape == (n,) and within(mod.signal, want_m, 1e-12)
+    kw = dict(length=80, alpha=0.2, beta_2=-20, gamma=2)
+    out = oa.FIBER(mod, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        zo, Ao = orc.fiber_c64(want_m, gv.dt, return_steps=True, **kw)
+    steps = len(zo) - 1
+    assert steps >= 10 and within(out.signal, Ao[-1], steps=steps, what=f"oracle, the example link at a whole PRBS-11 word (adaptive, {steps} steps)")
+    rx = oa.PD(out, BW=gv.R * 0.75, include_noise="none")
+    want_rx, _ = fe.pd(Ao[-1], None, gv.fs, gv.R * 0.75, include_noise="none")
+    assert within(rx.signal, want_rx, 1e-4)  # |E|^2 of fields that agree to 2e-5
+
+
 # ----------------------------------------------------------------------- device-resident signals
 def _chain(x, keep):
     """FIBER -> EDFA-like noise loading -> FIBER -> DBP -> DM -> BPF -> PD, as a link script would write it."""
